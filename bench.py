@@ -1,0 +1,242 @@
+"""Benchmark of the MI355X metric-evaluation hot path (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" = one fused pass of the deterministic suite (MSE + RMSE + MAE + Bias +
+ACC for the 13 predefined slice regions of scripts/evaluate.py:345-374) over a
+batch of `--units` (init, lead) units of 13 x 721 x 1440 float32 points each,
+i.e. BASELINE config 2, followed by the running init-time mean.  Forecast,
+truth and climatology are synthetic N(0,1) and already resident in HBM when the
+timed region starts; truth and climatology slabs are gathered by index tables
+exactly like the product path does for valid_time / (dayofyear, hour).  Units
+are drawn round-robin from a pool much larger than the 256 MiB Infinity Cache.
+
+For N > 1 (torchrun, one rank per GPU) every rank evaluates its own shard of
+init-times (weak scaling) and the only exchange is one RCCL all-reduce of the
+[sum, count] accumulators at the end (evaluation.py:740-744's xbeam.Mean).
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+N_LEV, N_LAT, N_LON = 13, 721, 1440
+PTS_PER_UNIT = N_LEV * N_LAT * N_LON
+BYTES_PER_PT = 12.0  # forecast 4 + truth 4 + climatology 4
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def predefined_regions():
+  from weatherbench2_amd.regions import SliceRegion as R
+  return {
+      'global': R(),
+      'tropics': R(lat_slice=slice(-20, 20)),
+      'extra-tropics': R(lat_slice=[slice(None, -20), slice(20, None)]),
+      'northern-hemisphere': R(lat_slice=slice(20, None)),
+      'southern-hemisphere': R(lat_slice=slice(None, -20)),
+      'europe': R(lat_slice=slice(35, 75),
+                  lon_slice=[slice(360 - 12.5, None), slice(0, 42.5)]),
+      'north-america': R(lat_slice=slice(25, 60),
+                         lon_slice=slice(360 - 120, 360 - 75)),
+      'north-atlantic': R(lat_slice=slice(25, 65),
+                          lon_slice=slice(360 - 70, 360 - 10)),
+      'north-pacific': R(lat_slice=slice(25, 60),
+                         lon_slice=slice(145, 360 - 130)),
+      'east-asia': R(lat_slice=slice(25, 60), lon_slice=slice(102.5, 150)),
+      'ausnz': R(lat_slice=slice(-45, -12.5), lon_slice=slice(120, 175)),
+      'arctic': R(lat_slice=slice(60, 90)),
+      'antarctic': R(lat_slice=slice(-90, -60)),
+  }
+
+
+def cpu_baseline(seconds_budget: float = 20.0) -> dict:
+  """Times the NumPy oracle (the restated reference path: one metric x one
+  region at a time, like evaluation.py:408-435) on this box's host cores."""
+  from oracle import metrics_np as om
+  from oracle.named import DS, NA
+  from tests import helpers
+  n_lev = 1
+  rs = np.random.RandomState(0)
+  lat = np.linspace(-90, 90, N_LAT)
+  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  dims = ('time', 'level', 'latitude', 'longitude')
+  coords = {'time': np.array(['2020-01-01T00'], dtype='datetime64[ns]'),
+            'level': np.arange(n_lev), 'latitude': lat, 'longitude': lon}
+  mk = lambda: rs.standard_normal((1, n_lev, N_LAT, N_LON)).astype(np.float32)
+  f, t = DS({'z': NA(mk(), dims)}, coords), DS({'z': NA(mk(), dims)}, coords)
+  clim = DS({'z': NA(mk(), ('dayofyear',) + dims[1:])},
+            {'dayofyear': np.array([1]), 'level': coords['level'],
+             'latitude': lat, 'longitude': lon})
+  metrics = {'mse': om.MSE(), 'rmse': om.RMSESqrtBeforeTimeAvg(),
+             'mae': om.MAE(), 'bias': om.Bias(), 'acc': om.ACC(clim)}
+  regions = helpers.predefined_regions(oracle=True)
+  t0 = time.perf_counter()
+  done = 0
+  for rname, region in regions.items():
+    for m in metrics.values():
+      m.compute_chunk(f, t, region=region)
+    done += 1
+    if time.perf_counter() - t0 > seconds_budget:
+      break
+  dt = time.perf_counter() - t0
+  # evals/s for the FULL metric x region set, extrapolated from `done` regions
+  full = dt * len(regions) / done
+  return {
+      'value': n_lev * N_LAT * N_LON / full, 'unit': 'grid-point-evals/s',
+      'cores': 1, 'kind': 'port',
+      'sample': (f'NumPy oracle (xarray-semantics restatement; the reference '
+                 f'itself needs xarray, absent here), 1 process, 1 level x '
+                 f'721 x 1440 f32, 5 metrics x {done}/{len(regions)} regions '
+                 f'timed in {dt:.1f} s, scaled to all regions; host has '
+                 f'{os.cpu_count()} logical cores'),
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--units', type=int, default=16,
+                  help='(init, lead) units per step and per GPU')
+  ap.add_argument('--pool', type=int, default=48,
+                  help='distinct units resident in HBM per input')
+  ap.add_argument('--rows-per-chunk', type=int, default=16)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.gpus != world:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run')
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=dev)
+
+  lat = np.linspace(-90, 90, N_LAT)
+  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(), dev,
+                           rows_per_chunk=args.rows_per_chunk)
+  units, pool = args.units, max(args.pool, args.units)
+  gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+  mk = lambda: torch.randn((pool * N_LEV, N_LAT, N_LON), generator=gen,
+                           device=dev, dtype=torch.float32)
+  fpool, tpool, cpool = mk(), mk(), mk()
+  n_outer = units * N_LEV
+  nr = pl.n_region
+  total = torch.zeros((_lib.NMETRIC * nr, N_LEV), dtype=torch.float64, device=dev)
+  count = torch.zeros_like(total)
+  lev = torch.arange(N_LEV, device=dev, dtype=torch.int64)
+
+  def tables(step):
+    """Slab tables of this step: forecast units are consecutive pool entries,
+    truth / climatology are gathered through (different) offsets."""
+    u = (step * units + torch.arange(units, device=dev)) % pool
+    fu = (u[:, None] * N_LEV + lev[None]).reshape(-1)
+    tu = (((u + 7) % pool)[:, None] * N_LEV + lev[None]).reshape(-1)
+    cu = (((u * 5 + 3) % pool)[:, None] * N_LEV + lev[None]).reshape(-1)
+    return fu.contiguous(), tu.contiguous(), cu.contiguous()
+
+  all_tables = [tables(s) for s in range(args.warmup + args.steps)]
+  k1_events = []
+
+  def step(i, timed):
+    fu, tu, cu = all_tables[i]
+    if timed:
+      e0 = torch.cuda.Event(enable_timing=True)
+      e1 = torch.cuda.Event(enable_timing=True)
+      engine.K1_EVENTS = (e0, e1)
+      k1_events.append((e0, e1))
+    else:
+      engine.K1_EVENTS = None
+    metrics, _ = engine.stream_reduce(
+        pl, _lib.MODE_DET_ACC, [fpool, tpool, cpool], [fu, tu, cu], n_outer,
+        skipna=False)
+    # running init-time mean: (metric*region, unit, level)
+    engine.time_accumulate(metrics.view(_lib.NMETRIC * nr, units, N_LEV), 1,
+                           False, total, count)
+
+  for i in range(args.warmup):
+    step(i, False)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    step(args.warmup + i, True)
+  if world > 1:
+    packed = torch.stack([total, count])
+    dist.all_reduce(packed)  # RCCL over xGMI: the only exchange of the path
+    total, count = packed[0], packed[1]
+  mean = total / count
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  assert torch.isfinite(mean).all()
+
+  k1_ms = [a.elapsed_time(b) for a, b in k1_events]
+  k1_avg_s = float(np.mean(k1_ms)) / 1e3
+  pts_step = units * PTS_PER_UNIT
+  achieved = pts_step * BYTES_PER_PT / k1_avg_s / 1e9
+  out = {
+      'metric': 'grid-point-evals/sec (721x1440x13)',
+      'value': world * pts_step * args.steps / dt,
+      'unit': 'grid-point-evals/s',
+      'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': dt / args.steps * 1e3,
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f32 elementwise, f64 accumulate', 'data': 'synthetic',
+      'config': {
+          'workload': ('BASELINE configs[1]: 721x1440x13 f32, deterministic '
+                       'MSE+RMSE+MAE+Bias+ACC, 13 predefined slice regions, '
+                       'running init-time mean'),
+          'units_per_step_per_gpu': units, 'pool_units': pool,
+          'regions': nr, 'rows_per_chunk': args.rows_per_chunk,
+          'parallelism': f'init-time shards x{world}, 1 all-reduce of [sum,count]',
+      },
+      'roofline': {
+          'bound': 'hbm', 'kernel': 'stream_partials_kernel<float,4,DET_ACC>',
+          'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+          'frac': achieved / HBM_PEAK_GBPS,
+          'frac_of_measured_copy_6290': achieved / 6290.0,
+          'kernel_ms': k1_avg_s * 1e3,
+          'algorithmic_bytes_per_launch': pts_step * BYTES_PER_PT,
+          'traffic': None,
+      },
+  }
+  if rank == 0:
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

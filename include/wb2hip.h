@@ -1,0 +1,149 @@
+/*
+ * wb2hip.h -- C ABI of libwb2hip.so: MI355X (gfx950) kernels for the
+ * WeatherBench2 per-chunk metric-evaluation hot path.
+ *
+ * The reference (google-research/weatherbench2) is pure Python; it has no FFI.
+ * Its boundary for this path is the duck-typed operator protocol
+ *   Metric.compute_chunk(forecast, truth, region, skipna)   weatherbench2/metrics.py:88-115
+ *   Region.apply(dataset, weights)                          weatherbench2/regions.py:40-54
+ *   DerivedVariable.compute(dataset)                        weatherbench2/derived_variables.py:54-56
+ * called from evaluation._metric_and_region_loop            weatherbench2/evaluation.py:388-438.
+ * The entry points below are what a ctypes binding of that protocol calls (see
+ * INTEGRATION.md); each one names the reference arithmetic it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; wb2_last_error() gives
+ *    the (thread-local) message.  Nothing throws, nothing takes ownership of a
+ *    caller buffer, nothing allocates device memory.
+ *  - every pointer marked DEV is a device (HBM) pointer; `stream` is a
+ *    hipStream_t passed as void* (NULL = the default stream).  All work is
+ *    enqueued asynchronously on `stream`.
+ *  - a "slab" is one 2-D (n_row, n_col) field, n_col contiguous.  For the
+ *    (…, latitude, longitude) layout of 0.25-degree ERA5 rows are latitudes; for
+ *    the (…, longitude, latitude) layout of the low-resolution/mocked datasets
+ *    rows are longitudes.  `n_outer` counts the slabs = product of all
+ *    non-spatial dims (time, lead, level, …).
+ *  - regions are decomposed on the host into `bands` of rows and `segs` of
+ *    columns with identical membership; the streaming kernel emits partial sums
+ *    per (outer, row-chunk, col-tile, weight-field, seg) and the combine kernel
+ *    folds them into every region at once.  See DESIGN.md.
+ */
+#ifndef WB2HIP_H_
+#define WB2HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WB2_VERSION 1
+
+/* element types of the data slabs */
+#define WB2_F32 0
+#define WB2_F64 1
+
+/* streaming-reduction modes (which reference metrics one pass feeds) */
+#define WB2_MODE_DET 0      /* forecast,truth        -> MSE/RMSE/MAE/Bias      metrics.py:236-359 */
+#define WB2_MODE_DET_ACC 1  /* forecast,truth,clim   -> the above + ACC        metrics.py:377-414 */
+#define WB2_MODE_WIND 2     /* fu,tu,fv,tv           -> WindVectorMSE/RMSE     metrics.py:175-233 */
+
+/* number of metrics written by wb2_det_combine, in this order */
+#define WB2_NMETRIC 5
+#define WB2_METRIC_MSE 0
+#define WB2_METRIC_RMSE 1
+#define WB2_METRIC_MAE 2
+#define WB2_METRIC_BIAS 3
+#define WB2_METRIC_ACC 4
+
+int wb2_version(void);
+const char* wb2_last_error(void);
+
+/* Number of accumulated sums ("slots") per cell for a mode.
+ *   DET      : S(w d) S(w|d|) S(w d^2)                                  [+ S(w notnull d)]
+ *   DET_ACC  : the above + S(w fa ta) S(w fa^2) S(w ta^2)               [+ 3 more notnull sums]
+ *   WIND     : S(w (du^2+dv^2))                                         [+ 1]
+ * The bracketed sums-of-weights exist only when skipna != 0 (xarray computes
+ * them always, but without NaNs they are data independent: metrics.py:161-163). */
+int wb2_num_slots(int mode, int skipna);
+
+/* Columns one workgroup covers; n_ctile = ceil(n_col / wb2_tile_cols(...)). */
+int wb2_tile_cols(int dtype, int n_col, int aligned16);
+
+/*
+ * K1: fused weighted streaming reduction.  Replaces the elementwise temporaries
+ * and the two einsums of _spatial_average (metrics.py:141-163) for every metric
+ * of `mode` and every region, reading each input exactly once.
+ *
+ *  in[i]       DEV  input i (mode order above); slab o of input i starts at
+ *                   element  (slab[i] ? slab[i][o] : o) * n_row * n_col
+ *  slab[i]     DEV  int64[n_outer] or NULL (identity); lets truth / climatology
+ *                   be gathered by valid time without a copy (metrics.py:398-404,
+ *                   evaluation.py:474-475)
+ *  w_row       DEV  double[n_row]  > 0   (latitude weights when rows = lat, else 1)
+ *  w_col       DEV  double[n_col]  > 0   (latitude weights when cols = lat, else 1)
+ *  wfield      DEV  double[n_row*n_col] or NULL: a 2-D weight factor such as the
+ *                   land-sea mask (regions.py:112-138); points with wfield <= 0
+ *                   are excluded (metrics.py:159-160).
+ *  chunk_row0/chunk_nrow  DEV int32[n_chunk]: row range of each chunk (a chunk
+ *                   never straddles a band boundary; nrow == 0 chunks are padding)
+ *  seg_col0    DEV  int32[n_seg+1]: column range of each seg
+ *  partials    DEV  double[n_outer][n_chunk][n_ctile][nwf][n_seg][K] (out),
+ *                   nwf = wfield ? 2 : 1, K = wb2_num_slots(mode, skipna).
+ *                   Entries of padding chunks are not written.
+ *  n_ctile          must equal ceil(n_col / wb2_tile_cols(dtype, n_col, a16))
+ *                   with a16 = all of in[] (and wfield) are 16-byte aligned; it
+ *                   is passed explicitly so that the caller's allocation of
+ *                   `partials` and the launch can never disagree.
+ */
+int wb2_stream_partials(int mode, int dtype, int skipna,
+                        const void* const* in, const int64_t* const* slab,
+                        int64_t n_outer, int32_t n_row, int32_t n_col,
+                        const double* w_row, const double* w_col,
+                        const double* wfield,
+                        const int32_t* chunk_row0, const int32_t* chunk_nrow,
+                        int32_t n_chunk, int32_t n_ctile,
+                        const int32_t* seg_col0, int32_t n_seg,
+                        double* partials, void* stream);
+
+/*
+ * K2: fold the partials into per-region sums and finalise the metrics.
+ * Replaces the region loop + concat of evaluation.py:416-430 and the ratio /
+ * sqrt epilogues of metrics.py:172, 233, 407-414.
+ *
+ *  band_chunk0 DEV int32[n_band+1]: chunks (before col-tiling) of band b are
+ *                  [band_chunk0[b], band_chunk0[b+1])
+ *  coef_band   DEV double[n_region][n_band]: multiplicity of the band's rows in
+ *                  the region (0 = excluded; SliceRegion lists may repeat rows)
+ *  coef_seg    DEV double[n_region][n_seg]:  same for columns
+ *  region_wf   DEV int32[n_region]: 0 = uniform weights, 1 = `wfield`
+ *  region_wsum DEV double[n_region]: sum of the region's weights (used as the
+ *                  denominator when skipna == 0)
+ *  sums        DEV double[n_outer][n_region][K]           (out, may be NULL)
+ *  metrics     DEV double[WB2_NMETRIC][n_region][n_outer] (out, may be NULL).
+ *                  For WB2_MODE_WIND only MSE and RMSE are meaningful.
+ */
+int wb2_det_combine(int mode, int skipna, const double* partials,
+                    int64_t n_outer, int32_t n_chunk, int32_t n_ctile,
+                    int32_t nwf, int32_t n_seg,
+                    const int32_t* band_chunk0, int32_t n_band,
+                    const double* coef_band, const double* coef_seg,
+                    const int32_t* region_wf, const double* region_wsum,
+                    int32_t n_region, double* sums, double* metrics,
+                    void* stream);
+
+/*
+ * Running temporal mean (Metric.compute's .mean(init_time) metrics.py:125-138
+ * and the (sum, count) combiner of xbeam.Mean, evaluation.py:740-744).
+ *   values DEV double[n_lead][n_time][n_tail] viewed as (lead.., time, tail..)
+ *   sum, count DEV double[n_lead][n_tail]  (in/out, caller zero-initialises)
+ * skipna != 0: NaN values add nothing to sum nor count.
+ */
+int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
+                        int64_t n_tail, int skipna, double* sum, double* count,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* WB2HIP_H_ */

@@ -1,0 +1,292 @@
+"""GPU parity: fused deterministic kernels vs the NumPy oracle (run with -m gpu).
+
+Small/medium sizes are compared with the oracle directly (fp64 results, rtol
+1e-9 -- the contract is 1e-5); BASELINE sizes (721x1440x13) are checked through
+size-independent properties and against a float64 torch evaluation.
+"""
+import numpy as np
+import pytest
+
+from oracle import fixtures
+from oracle import metrics_np as om
+from oracle import regions_np as oreg
+from oracle.named import DS, NA
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope='module')
+def gm():
+  import torch
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device')
+  from weatherbench2_amd import metrics as gm
+  return gm
+
+
+def _oracle_suite(clim):
+  return {'mse': om.MSE(), 'rmse': om.RMSESqrtBeforeTimeAvg(), 'mae': om.MAE(),
+          'bias': om.Bias(), 'acc': om.ACC(clim)}
+
+
+def _gpu_suite(gm, clim):
+  return {'mse': gm.MSE(), 'rmse': gm.RMSESqrtBeforeTimeAvg(), 'mae': gm.MAE(),
+          'bias': gm.Bias(), 'acc': gm.ACC(clim)}
+
+
+def _clim_like(truth: DS, seed=7, hourly=True):
+  kw = dict(variables_3d=list(truth.keys()), variables_2d=[],
+            spatial_resolution_in_degrees=180 / (len(truth.coord('latitude')) - 1),
+            levels=tuple(truth.coord('level')))
+  clim = fixtures.mock_hourly_climatology_data(hour_interval=3, **kw) if hourly \
+      else None
+  return fixtures.random_like(clim, seed=seed)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('skipna', [False, True])
+def test_suite_matches_oracle_mock_layout(gm, dtype, skipna):
+  """(…, longitude, latitude) mocks, truth broadcast over lead, with NaNs."""
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      variables=('geopotential', 'temperature'))
+  clim = _clim_like(truth)
+  cast = lambda ds: ds.copy(data={k: v.data.astype(dtype) for k, v in ds.items()})
+  truth, forecast, clim = cast(truth), cast(forecast), cast(clim)
+  if skipna:
+    forecast = fixtures.insert_nan(forecast, 0.05, seed=1)
+    truth = fixtures.insert_nan(truth, 0.05, seed=2)
+  g_truth, g_forecast, g_clim = map(helpers.to_gpu_dataset,
+                                    (truth, forecast, clim))
+  regions = {'global': None, 'extra': oreg.ExtraTropicalRegion(),
+             'tropics': oreg.SliceRegion(lat_slice=slice(-20, 20)),
+             'box': oreg.SliceRegion(lat_slice=slice(-30, 60),
+                                     lon_slice=[slice(300, None),
+                                                slice(0, 90)])}
+  g_regions = {k: helpers.to_gpu_region(v) for k, v in regions.items()}
+  osuite, gsuite = _oracle_suite(clim), _gpu_suite(gm, g_clim)
+  with gm.fused_regions(g_regions):
+    for rname, region in regions.items():
+      for mname in osuite:
+        want = osuite[mname].compute_chunk(forecast, truth, region=region,
+                                           skipna=skipna)
+        got = gsuite[mname].compute_chunk(g_forecast, g_truth,
+                                          region=g_regions[rname],
+                                          skipna=skipna)
+        for var in want.keys():
+          assert got[var].dims == want[var].dims
+          helpers.assert_close(got[var].values, want[var].data, rtol=RTOL,
+                               atol=1e-12, err_msg=f'{mname}/{rname}/{var}')
+
+
+def test_wind_vector_rmse_known_answer(gm):
+  # metrics_test.py:84-131 -> [0, 10, nan]
+  kw = dict(variables_3d=['u_component_of_wind', 'v_component_of_wind'],
+            variables_2d=[], time_start='2022-01-01', time_stop='2022-01-02')
+  forecast = fixtures.mock_forecast_data(lead_stop='0 day', **kw)
+  truth = fixtures.mock_truth_data(**kw)
+  fmod = DS({'u_component_of_wind': NA(np.float32([0, 3, np.nan]), ('level',)),
+             'v_component_of_wind': NA(np.float32([0, -4, 1]), ('level',))})
+  tmod = DS({'u_component_of_wind': NA(np.float32([0, -3, np.nan]), ('level',)),
+             'v_component_of_wind': NA(np.float32([0, 4, 1]), ('level',))})
+  forecast, truth = forecast + fmod, truth + tmod
+  wv = gm.WindVectorRMSESqrtBeforeTimeAvg(
+      u_name='u_component_of_wind', v_name='v_component_of_wind',
+      vector_name='wind_vector')
+  result = wv.compute(helpers.to_gpu_dataset(forecast),
+                      helpers.to_gpu_dataset(truth))
+  np.testing.assert_allclose(result['wind_vector'].values.squeeze(),
+                             np.array([0, 10, np.nan]))
+  # and as part of RMSE(wind_vector_rmse=[...]) (metrics.py:262-269)
+  rmse = gm.RMSESqrtBeforeTimeAvg(wind_vector_rmse=[wv]).compute_chunk(
+      helpers.to_gpu_dataset(forecast), helpers.to_gpu_dataset(truth))
+  assert set(rmse.keys()) == {'u_component_of_wind', 'v_component_of_wind',
+                              'wind_vector'}
+
+
+@pytest.mark.parametrize('invalid_value', [np.inf, np.nan])
+def test_rmse_over_invalid_region(gm, invalid_value):
+  # metrics_test.py:133-152
+  from weatherbench2_amd import regions as gr
+  from weatherbench2_amd import xarray_lite as xl
+  data = np.array([0.0, invalid_value, 0.0]).reshape(1, 1, 3)
+  coords = {'latitude': np.array([-45, 0, 45]), 'longitude': np.array([0]),
+            'time': np.array([0])}
+  truth = xl.Dataset({'wind_speed': xl.DataArray(
+      data, ('time', 'longitude', 'latitude'))}, coords)
+  forecast = xl.Dataset({'wind_speed': xl.DataArray(
+      data + 1, ('time', 'longitude', 'latitude'))}, coords)
+  rmse = gm.RMSESqrtBeforeTimeAvg()
+  actual = rmse.compute(forecast, truth)
+  assert np.isnan(actual['wind_speed'].values)
+  actual = rmse.compute(forecast, truth, region=gr.ExtraTropicalRegion())
+  np.testing.assert_allclose(actual['wind_speed'].values, 1.0)
+
+
+def test_acc_accepts_mean_suffix_and_missing_raises(gm):
+  # metrics_test.py:154-170 + metrics.py:73-77
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      time_resolution='6 hours')
+  clim = fixtures.random_like(fixtures.mock_hourly_climatology_data(
+      hour_interval=6, variables_3d=['geopotential'], variables_2d=[],
+      spatial_resolution_in_degrees=30), seed=3)
+  clim_mean = clim.rename_vars({'geopotential': 'geopotential_mean'})
+  g = helpers.to_gpu_dataset
+  acc1 = gm.ACC(g(clim)).compute_chunk(g(forecast), g(truth))
+  acc2 = gm.ACC(g(clim_mean)).compute_chunk(g(forecast), g(truth))
+  want = om.ACC(clim).compute_chunk(forecast, truth)
+  helpers.assert_close(acc1['geopotential'].values, want['geopotential'].data,
+                       rtol=RTOL)
+  np.testing.assert_array_equal(acc1['geopotential'].values,
+                                acc2['geopotential'].values)
+  bad = clim.rename_vars({'geopotential': 'other'})
+  with pytest.raises(KeyError):
+    gm.ACC(g(bad)).compute_chunk(g(forecast), g(truth))
+
+
+def test_land_and_combined_regions(gm):
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      spatial_resolution_in_degrees=10)
+  lat, lon = truth.coord('latitude'), truth.coord('longitude')
+  rs = np.random.RandomState(0)
+  frac = np.clip(rs.rand(len(lat), len(lon)) * 1.5 - 0.25, 0, 1)
+  lsm = NA(frac, ('latitude', 'longitude'))
+  regions = {
+      'land': oreg.LandRegion(lsm, lat, lon),
+      'land_thr': oreg.LandRegion(lsm, lat, lon, threshold=0.5),
+      'tropics_land': oreg.CombinedRegion([
+          oreg.SliceRegion(lat_slice=slice(-20, 20)),
+          oreg.LandRegion(lsm, lat, lon)]),
+      'xt_land': oreg.CombinedRegion([
+          oreg.SliceRegion(lat_slice=[slice(None, -20), slice(20, None)]),
+          oreg.LandRegion(lsm, lat, lon)]),
+  }
+  forecast_nan = fixtures.insert_nan(forecast, 0.02, seed=5)
+  g = helpers.to_gpu_dataset
+  for skipna, fc in ((False, forecast), (True, forecast_nan)):
+    for rname, region in regions.items():
+      g_region = helpers.to_gpu_region(region)
+      for oc, gc in ((om.MSE(), gm.MSE()), (om.MAE(), gm.MAE()),
+                     (om.Bias(), gm.Bias())):
+        want = oc.compute_chunk(fc, truth, region=region, skipna=skipna)
+        got = gc.compute_chunk(g(fc), g(truth), region=g_region, skipna=skipna)
+        helpers.assert_close(got['geopotential'].values,
+                             want['geopotential'].data, rtol=RTOL, atol=1e-12,
+                             err_msg=f'{rname} skipna={skipna}')
+
+
+def test_nan_outside_region_does_not_poison(gm):
+  truth, forecast = fixtures.get_random_truth_and_forecast()
+  data = forecast['geopotential'].data.copy()
+  lat = truth.coord('latitude')
+  data[..., np.abs(lat) < 20] = np.nan  # tropics are NaN
+  forecast = forecast.copy(data={'geopotential': data})
+  g = helpers.to_gpu_dataset
+  regions = {'global': None, 'xt': oreg.ExtraTropicalRegion()}
+  g_regions = {k: helpers.to_gpu_region(v) for k, v in regions.items()}
+  with gm.fused_regions(g_regions):
+    glob = gm.MSE().compute_chunk(g(forecast), g(truth), region=g_regions['global'])
+    xt = gm.MSE().compute_chunk(g(forecast), g(truth), region=g_regions['xt'])
+  assert np.isnan(glob['geopotential'].values).all()
+  want = om.MSE().compute_chunk(forecast, truth, region=regions['xt'])
+  helpers.assert_close(xt['geopotential'].values, want['geopotential'].data,
+                       rtol=RTOL)
+
+
+def test_quarter_degree_all_predefined_regions(gm):
+  """One 0.25-degree level slab pair vs the oracle for the 13 slice regions."""
+  import torch
+  from weatherbench2_amd import xarray_lite as xl
+  n_lat, n_lon, n_lev = 721, 1440, 2
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  rs = np.random.RandomState(11)
+  dims = ('time', 'level', 'latitude', 'longitude')
+  f = rs.normal(size=(1, n_lev, n_lat, n_lon)).astype(np.float32)
+  t = rs.normal(size=(1, n_lev, n_lat, n_lon)).astype(np.float32)
+  c = rs.normal(size=(1, 2, n_lev, n_lat, n_lon)).astype(np.float32)
+  coords = {'time': np.array(['2020-01-02T00'], dtype='datetime64[ns]'),
+            'level': np.array([500, 850]), 'latitude': lat, 'longitude': lon}
+  ods_f = DS({'z': NA(f, dims)}, coords)
+  ods_t = DS({'z': NA(t, dims)}, coords)
+  ccoords = {'hour': np.array([0]), 'dayofyear': np.array([1, 2]),
+             'level': coords['level'], 'latitude': lat, 'longitude': lon}
+  ods_c = DS({'z': NA(c, ('hour', 'dayofyear') + dims[1:])}, ccoords)
+  oregions = helpers.predefined_regions(oracle=True)
+  gregions = helpers.predefined_regions(oracle=False)
+  g = helpers.to_gpu_dataset
+  gf, gt, gc = g(ods_f), g(ods_t), g(ods_c)
+  osuite, gsuite = _oracle_suite(ods_c), _gpu_suite(gm, gc)
+  with gm.fused_regions(gregions):
+    for rname in oregions:
+      for mname in osuite:
+        want = osuite[mname].compute_chunk(ods_f, ods_t,
+                                           region=oregions[rname])
+        got = gsuite[mname].compute_chunk(gf, gt, region=gregions[rname])
+        helpers.assert_close(got['z'].values, want['z'].data, rtol=1e-9,
+                             atol=1e-12, err_msg=f'{mname}/{rname}')
+
+
+def test_full_size_properties():
+  """721x1440x13 unit: determinism, torch-fp64 agreement, scale/shift laws."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  dev = torch.device('cuda')
+  n_lev, n_lat, n_lon = 13, 721, 1440
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  regions = helpers.predefined_regions(oracle=False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev)
+  gen = torch.Generator(device=dev).manual_seed(1234)
+  f, t, c = (torch.randn((n_lev, n_lat, n_lon), generator=gen, device=dev,
+                         dtype=torch.float32) for _ in range(3))
+  m1, s1 = engine.stream_reduce(pl, _lib.MODE_DET_ACC, [f, t, c],
+                                [None, None, None], n_lev, False, True)
+  m2, s2 = engine.stream_reduce(pl, _lib.MODE_DET_ACC, [f, t, c],
+                                [None, None, None], n_lev, False, True)
+  torch.cuda.synchronize()
+  assert torch.equal(m1, m2) and torch.equal(s1, s2)  # bit-reproducible
+  # fp64 torch evaluation of the global region (same fp32 elementwise values)
+  w = torch.as_tensor(pl.w_lat, device=dev)[None, :, None]
+  d = (f - t)
+  fa, ta = f - c, t - c
+  den = w.sum() * n_lon
+  want = {
+      'mse': ((d * d).double() * w).sum((1, 2)) / den,
+      'mae': (d.abs().double() * w).sum((1, 2)) / den,
+      'bias': (d.double() * w).sum((1, 2)) / den,
+      'acc': ((fa * ta).double() * w).sum((1, 2)) / torch.sqrt(
+          ((fa * fa).double() * w).sum((1, 2))
+          * ((ta * ta).double() * w).sum((1, 2))),
+  }
+  gi = pl.region_names.index('global')
+  for name, val in want.items():
+    got = m1[_lib.METRIC_INDEX[name], gi]
+    torch.testing.assert_close(got, val, rtol=1e-10, atol=1e-13)
+  # region additivity: tropics + extra-tropics count rows +-20 twice
+  si = {k: pl.region_names.index(k) for k in pl.region_names}
+  k_d2 = 2
+  tro = s1[:, si['tropics'], k_d2]
+  xt = s1[:, si['extra-tropics'], k_d2]
+  nh = s1[:, si['northern-hemisphere'], k_d2]
+  sh = s1[:, si['southern-hemisphere'], k_d2]
+  torch.testing.assert_close(xt, nh + sh, rtol=1e-12, atol=0)
+  row = lambda r: ((d[:, r] * d[:, r]).double().sum(-1) * pl.w_lat[r])
+  overlap = row(280) + row(440)
+  torch.testing.assert_close(tro + xt - overlap, s1[:, si['global'], k_d2],
+                             rtol=1e-12, atol=0)
+  # scaling law: MSE(a f, a t) = a^2 MSE(f, t) exactly for a power of two
+  m4, _ = engine.stream_reduce(pl, _lib.MODE_DET, [f * 4, t * 4], [None, None],
+                               n_lev, False)
+  torch.testing.assert_close(m4[0], m1[0] * 16, rtol=1e-14, atol=0)
+  # swap law: bias(t, f) = -bias(f, t), mse symmetric
+  ms, _ = engine.stream_reduce(pl, _lib.MODE_DET, [t, f], [None, None], n_lev,
+                               False)
+  assert torch.equal(ms[3], -m1[3]) and torch.equal(ms[0], m1[0])
+  # slab tables: gathering truth through a permutation == permuting results
+  perm = torch.randperm(n_lev, device=dev)
+  mp, _ = engine.stream_reduce(pl, _lib.MODE_DET, [f[perm].contiguous(), t],
+                               [None, perm.to(torch.int64)], n_lev, False)
+  assert torch.equal(mp[0], m1[0][:, perm])

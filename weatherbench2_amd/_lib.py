@@ -1,0 +1,117 @@
+"""ctypes binding of libwb2hip.so (the C ABI declared in include/wb2hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails the
+product path raises.  torch is imported first on purpose: it ships its own
+libamdhip64.so.7 and the dynamic linker then resolves our DT_NEEDED entry to
+that already-loaded runtime, so torch tensors' device pointers and our kernels
+live in ONE HIP runtime / context.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+from weatherbench2_amd import build as _build
+
+WB2_F32, WB2_F64 = 0, 1
+MODE_DET, MODE_DET_ACC, MODE_WIND = 0, 1, 2
+NMETRIC = 5
+METRIC_INDEX = {'mse': 0, 'rmse': 1, 'mae': 2, 'bias': 3, 'acc': 4}
+
+_c = ctypes
+_vp, _i32, _i64, _int = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_int
+
+_SIGNATURES = {
+    'wb2_version': (_int, []),
+    'wb2_last_error': (_c.c_char_p, []),
+    'wb2_num_slots': (_int, [_int, _int]),
+    'wb2_tile_cols': (_int, [_int, _int, _int]),
+    'wb2_stream_partials': (_int, [
+        _int, _int, _int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i32, _i32,
+        _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    'wb2_det_combine': (_int, [
+        _int, _int, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
+        _vp, _vp, _i32, _vp, _vp, _vp]),
+    'wb2_time_accumulate': (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp,
+                                   _vp]),
+    'wb2_ens_partials': (_int, [
+        _int, _int, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp,
+        _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    'wb2_ens_combine': (_int, [
+        _int, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
+        _vp, _vp, _i32, _vp, _vp, _vp]),
+    'wb2_ens_num_slots': (_int, [_int]),
+    'wb2_ens_tile_cols': (_int, [_i32]),
+    'wb2_spectrum_plan_create': (_int, [_i32, _i64, _c.POINTER(_vp)]),
+    'wb2_spectrum_plan_destroy': (_int, [_vp]),
+    'wb2_spectrum_plan_workspace': (_i64, [_vp]),
+    'wb2_zonal_spectrum': (_int, [_vp, _int, _vp, _i64, _i32, _vp, _i32, _int,
+                                  _vp, _vp, _vp]),
+}
+
+# Entry points still under construction (removed as they land).
+_PENDING = {'wb2_ens_partials', 'wb2_ens_combine', 'wb2_ens_num_slots',
+            'wb2_ens_tile_cols', 'wb2_spectrum_plan_create',
+            'wb2_spectrum_plan_destroy', 'wb2_spectrum_plan_workspace',
+            'wb2_zonal_spectrum'}
+
+_lib = None
+
+
+class Wb2HipError(RuntimeError):
+  pass
+
+
+def lib_path() -> str:
+  return _build.LIB_PATH
+
+
+def load():
+  """Loads (once) and returns the ctypes handle; raises if unavailable."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  path = lib_path()
+  if not os.path.exists(path):
+    raise Wb2HipError(
+        f'{path} is missing: run `python -c "import __graft_entry__ as g; '
+        'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.')
+  lib = ctypes.CDLL(path)
+  for name, (restype, argtypes) in _SIGNATURES.items():
+    try:
+      fn = getattr(lib, name)
+    except AttributeError as e:
+      if name in _PENDING:
+        continue
+      raise Wb2HipError(f'{path} does not export {name}: stale build? '
+                        'rebuild with __graft_entry__.build()') from e
+    fn.restype = restype
+    fn.argtypes = argtypes
+  if lib.wb2_version() != 1:
+    raise Wb2HipError(f'{path}: unexpected ABI version {lib.wb2_version()}')
+  _lib = lib
+  return lib
+
+
+def exported_symbols() -> list[str]:
+  return sorted(_SIGNATURES)
+
+
+def check(status: int, what: str):
+  if status != 0:
+    msg = load().wb2_last_error().decode(errors='replace')
+    raise Wb2HipError(f'{what} failed ({status}): {msg}')
+
+
+def ptr(t) -> int:
+  """Device (or host) address of a torch tensor / None."""
+  return 0 if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+  arr = (_vp * len(tensors))()
+  for i, t in enumerate(tensors):
+    arr[i] = ptr(t) or None
+  return arr

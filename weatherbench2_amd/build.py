@@ -1,0 +1,54 @@
+"""Builds libwb2hip.so in-tree with hipcc for gfx950 (no JIT cache, no pip)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, 'csrc')
+LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
+SOURCES = ('common.cpp', 'stream_reduce.hip', 'ensemble.hip', 'spectrum.hip')
+
+
+def _hipcc() -> str:
+  for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+    if cand and (os.path.isabs(cand) and os.path.exists(cand)
+                 or not os.path.isabs(cand)):
+      return cand
+  raise RuntimeError('hipcc not found')
+
+
+def sources() -> list[str]:
+  return [os.path.join(CSRC, s) for s in SOURCES
+          if os.path.exists(os.path.join(CSRC, s))]
+
+
+def needs_rebuild() -> bool:
+  if not os.path.exists(LIB_PATH):
+    return True
+  t = os.path.getmtime(LIB_PATH)
+  deps = sources() + [os.path.join(CSRC, 'common.hpp'),
+                      os.path.join(ROOT, 'include', 'wb2hip.h')]
+  return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+  """Compiles every HIP source for gfx950 into weatherbench2_amd/libwb2hip.so."""
+  if not force and not needs_rebuild():
+    return LIB_PATH
+  cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17',
+         '-ffp-contract=off', '-fPIC', '-shared',
+         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
+         '-o', LIB_PATH] + sources()
+  if any(s.endswith('spectrum.hip') for s in sources()):
+    cmd += ['-L/opt/rocm/lib', '-lhipfft']
+  if verbose:
+    print('[wb2hip build]', ' '.join(cmd), file=sys.stderr)
+  subprocess.run(cmd, check=True)
+  return LIB_PATH
+
+
+if __name__ == '__main__':
+  build(force='--force' in sys.argv)

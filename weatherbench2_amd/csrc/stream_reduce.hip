@@ -1,0 +1,605 @@
+// K1/K2 of libwb2hip.so: the fused, region-aware, latitude-weighted streaming
+// reduction behind MSE / RMSE / MAE / Bias / ACC / WindVector{MSE,RMSE}.
+//
+// Replaces (reference = /root/reference/weatherbench2):
+//   metrics.py:141-163  _spatial_average     (einsum(x,w) / einsum(notnull(x),w))
+//   metrics.py:166-172  _spatial_average_l2_norm
+//   metrics.py:175-414  WindVectorMSE, RMSE, MSE, MAE, Bias, ACC elementwise temps
+//   regions.py:57-158   Region.apply (slice / extra-tropics / land / combined)
+//   evaluation.py:408-437  the metric x region loop
+//
+// HBM-bandwidth bound (12 B per grid point for f32 f,t,c; no reuse), so the
+// design is a pure stream: every thread OWNS `VEC` adjacent columns of the slab
+// (16-byte loads, a wavefront covers 1 KiB of a row) and walks down the rows of
+// one row-chunk keeping one fp64 accumulator per (weight-field, owned column,
+// slot) in VGPRs.  Region membership never enters the hot loop: columns with the
+// same membership form a `seg`, rows a `band`; the per-column sums are folded
+// into per-seg sums once per workgroup through LDS + a wave64 shuffle tree, and a
+// tiny second kernel folds (band, seg) cells into every region.  No atomics, so
+// results are bit-reproducible run to run.
+//
+// Elementwise arithmetic is done in the INPUT dtype, like numpy does under
+// xarray (float32 stays float32; -ffp-contract=off keeps products unfused),
+// and every sum is accumulated in fp64 like the promoted einsum.
+
+#include "common.hpp"
+#include "wb2hip.h"
+
+#include <type_traits>
+
+namespace wb2 {
+namespace {
+
+constexpr int kMaxIn = 4;
+
+struct StreamParams {
+  const void* in[kMaxIn];
+  const long long* slab[kMaxIn];
+  const double* w_row;
+  const double* w_col;
+  const double* wfield;
+  const int* chunk_row0;
+  const int* chunk_nrow;
+  const int* seg_col0;
+  double* partials;
+  long long n_outer;
+  int n_row, n_col, n_chunk, n_ctile, n_seg;
+};
+
+template <int MODE, bool SKIPNA>
+struct ModeTraits;
+template <bool S>
+struct ModeTraits<WB2_MODE_DET, S> {
+  static constexpr int NIN = 2, KQ = 3, K = KQ + (S ? 1 : 0);
+};
+template <bool S>
+struct ModeTraits<WB2_MODE_DET_ACC, S> {
+  static constexpr int NIN = 3, KQ = 6, K = KQ + (S ? 4 : 0);
+};
+template <bool S>
+struct ModeTraits<WB2_MODE_WIND, S> {
+  static constexpr int NIN = 4, KQ = 1, K = KQ + (S ? 1 : 0);
+};
+
+// One grid point: inputs -> the K values whose weighted sums we need.  With
+// SKIPNA, NaN numerators become 0 and the trailing slots carry notnull() as
+// 1.0/0.0 so that the same weighted accumulation yields xarray's sum_of_weights.
+template <int MODE, bool SKIPNA, typename T>
+__device__ __forceinline__ void eval_slots(
+    const T (&in)[ModeTraits<MODE, SKIPNA>::NIN],
+    double (&x)[ModeTraits<MODE, SKIPNA>::K]) {
+  if constexpr (MODE == WB2_MODE_WIND) {
+    const T du = in[0] - in[1];
+    const T dv = in[2] - in[3];
+    const T q = du * du + dv * dv;  // metrics.py:195-197
+    if constexpr (SKIPNA) {
+      const bool ok = !is_nan(q);
+      x[0] = ok ? (double)q : 0.0;
+      x[1] = ok ? 1.0 : 0.0;
+    } else {
+      x[0] = (double)q;
+    }
+  } else {
+    const T f = in[0], t = in[1];
+    const T d = f - t;       // metrics.py:264, 284, 329, 358
+    const T ad = abs_of(d);  // MAE
+    const T d2 = d * d;      // MSE / RMSE
+    if constexpr (SKIPNA) {
+      const bool ok = !is_nan(d);
+      x[0] = ok ? (double)d : 0.0;
+      x[1] = ok ? (double)ad : 0.0;
+      x[2] = ok ? (double)d2 : 0.0;
+    } else {
+      x[0] = (double)d;
+      x[1] = (double)ad;
+      x[2] = (double)d2;
+    }
+    if constexpr (MODE == WB2_MODE_DET_ACC) {
+      const T c = in[2];
+      const T fa = f - c;  // metrics.py:405
+      const T ta = t - c;  // metrics.py:406
+      const T p = fa * ta, fa2 = fa * fa, ta2 = ta * ta;
+      if constexpr (SKIPNA) {
+        const bool okd = !is_nan(d), okp = !is_nan(p), okf = !is_nan(fa2),
+                   okt = !is_nan(ta2);
+        x[3] = okp ? (double)p : 0.0;
+        x[4] = okf ? (double)fa2 : 0.0;
+        x[5] = okt ? (double)ta2 : 0.0;
+        x[6] = okd ? 1.0 : 0.0;
+        x[7] = okp ? 1.0 : 0.0;
+        x[8] = okf ? 1.0 : 0.0;
+        x[9] = okt ? 1.0 : 0.0;
+      } else {
+        x[3] = (double)p;
+        x[4] = (double)fa2;
+        x[5] = (double)ta2;
+      }
+    } else if constexpr (SKIPNA) {
+      x[3] = !is_nan(d) ? 1.0 : 0.0;
+    }
+  }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p,
+                                         T (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    v[0] = __builtin_nontemporal_load(p);
+  } else {
+    typedef T V __attribute__((ext_vector_type(VEC)));
+    const V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = x[e];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_wf(const double* __restrict__ p,
+                                        double (&v)[VEC]) {
+  // The weight field is re-read by every outer slab: keep it cacheable.
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[e] = p[e];
+}
+
+// Rows of one chunk are processed U at a time so that U*NIN 16-byte loads per
+// lane are in flight before the first one is consumed.
+template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
+__global__ void __launch_bounds__(512)
+    stream_partials_kernel(const StreamParams p) {
+  using M = ModeTraits<MODE, SKIPNA>;
+  constexpr int NIN = M::NIN, K = M::K, NWF = WF ? 2 : 1;
+  constexpr int U = (sizeof(T) * VEC >= 16) ? (NIN >= 4 ? 2 : 4) : 8;
+  constexpr int KB = K >= 2 ? 2 : 1;  // slots staged through LDS per pass
+
+  const int tid = threadIdx.x;
+  const long long oc = blockIdx.x;
+  const int chunk = (int)(oc % p.n_chunk);
+  const long long o = oc / p.n_chunk;
+  const int ct = blockIdx.y;
+  const int tile_cols = blockDim.x * VEC;
+  const int tile_col0 = ct * tile_cols;
+  const int col0 = tile_col0 + tid * VEC;
+  const bool active = col0 < p.n_col;
+  const int row0 = p.chunk_row0[chunk];
+  const int nrow = p.chunk_nrow[chunk];
+  if (nrow <= 0) return;  // padding chunk (uniform for the whole workgroup)
+
+  double acc[NWF][VEC][K];
+#pragma unroll
+  for (int w = 0; w < NWF; ++w)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[w][e][k] = 0.0;
+
+  if (active) {
+    const long long slab_elems = (long long)p.n_row * p.n_col;
+    const T* base[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const long long s = p.slab[i] ? p.slab[i][o] : o;
+      base[i] = static_cast<const T*>(p.in[i]) + s * slab_elems +
+                (long long)row0 * p.n_col + col0;
+    }
+    const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + col0
+                           : nullptr;
+    const double* wrp = p.w_row + row0;
+
+    auto consume = [&](const T (&v)[NIN][VEC], const double (&wf)[VEC],
+                       double wr) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T in[NIN];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) in[i] = v[i][e];
+        double x[K];
+        eval_slots<MODE, SKIPNA, T>(in, x);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          acc[0][e][k] = __builtin_fma(wr, x[k], acc[0][e][k]);
+        if constexpr (WF) {
+          // metrics.py:159-160: values where the weight is not > 0 become 0.
+          const bool inside = wf[e] > 0.0;
+          const double w2 = inside ? wr * wf[e] : 0.0;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            acc[1][e][k] =
+                __builtin_fma(w2, inside ? x[k] : 0.0, acc[1][e][k]);
+        }
+      }
+    };
+
+    int r = 0;
+    for (; r + U <= nrow; r += U) {
+      T v[U][NIN][VEC];
+      double wf[U][VEC];
+      double wr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i)
+          load_vec<T, VEC>(base[i] + (long long)(r + u) * p.n_col, v[u][i]);
+        if constexpr (WF) {
+          load_wf<VEC>(wfp + (long long)(r + u) * p.n_col, wf[u]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) wf[u][e] = 1.0;
+        }
+        wr[u] = wrp[r + u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) consume(v[u], wf[u], wr[u]);
+    }
+    for (; r < nrow; ++r) {
+      T v[NIN][VEC];
+      double wf[VEC];
+#pragma unroll
+      for (int i = 0; i < NIN; ++i)
+        load_vec<T, VEC>(base[i] + (long long)r * p.n_col, v[i]);
+      if constexpr (WF) {
+        load_wf<VEC>(wfp + (long long)r * p.n_col, wf);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) wf[e] = 1.0;
+      }
+      consume(v, wf, wrp[r]);
+    }
+  }
+
+  // ---- fold owned columns into segs: LDS staging + wave64 shuffle tree ----
+  extern __shared__ double sdata[];  // [KB][tile_cols]
+  const int lane = tid & (kWave - 1), wave = tid / kWave,
+            nwave = blockDim.x / kWave;
+  double wcol[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) wcol[e] = active ? p.w_col[col0 + e] : 0.0;
+  double* out = p.partials +
+                ((oc * p.n_ctile + ct) * NWF) * (long long)p.n_seg * K;
+#pragma unroll
+  for (int w = 0; w < NWF; ++w) {
+#pragma unroll
+    for (int k0 = 0; k0 < K; k0 += KB) {
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        if (k0 + kk < K) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            sdata[kk * tile_cols + tid * VEC + e] =
+                active ? acc[w][e][k0 + kk] * wcol[e] : 0.0;
+        }
+      }
+      __syncthreads();
+      for (int s = wave; s < p.n_seg; s += nwave) {
+        int a = p.seg_col0[s] - tile_col0, b = p.seg_col0[s + 1] - tile_col0;
+        a = a < 0 ? 0 : a;
+        b = b > tile_cols ? tile_cols : b;
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          if (k0 + kk < K) {
+            double v = 0.0;
+            for (int i = a + lane; i < b; i += kWave)
+              v += sdata[kk * tile_cols + i];
+            v = wave_sum(v);
+            if (lane == 0) out[((long long)w * p.n_seg + s) * K + k0 + kk] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2: (chunk, col-tile) partials -> band sums (LDS) -> region sums -> metrics
+// ---------------------------------------------------------------------------
+struct CombineParams {
+  const double* partials;
+  const int* band_chunk0;
+  const double* coef_band;
+  const double* coef_seg;
+  const int* region_wf;
+  const double* region_wsum;
+  double* sums;
+  double* metrics;
+  long long n_outer;
+  int n_chunk, n_ctile, nwf, n_seg, n_band, n_region, K, mode, skipna;
+};
+
+__device__ __forceinline__ double nan_if_zero(double d) {
+  return d != 0.0 ? d : __builtin_nan("");
+}
+
+__global__ void __launch_bounds__(256) det_combine_kernel(const CombineParams p) {
+  extern __shared__ double lds[];
+  const int K = p.K;
+  const int cell = p.nwf * p.n_seg * K;
+  double* bandsum = lds;                     // [n_band][nwf][n_seg][K]
+  double* rsum = lds + p.n_band * cell;      // [n_region][K]
+  const long long o = blockIdx.x;
+  const int tid = threadIdx.x;
+  const long long n_chunkx = (long long)p.n_chunk * p.n_ctile;
+  const double* part = p.partials + o * n_chunkx * cell;
+
+  for (int idx = tid; idx < p.n_band * cell; idx += blockDim.x) {
+    const int b = idx / cell, j = idx - b * cell;
+    double v = 0.0;
+    const long long c0 = (long long)p.band_chunk0[b] * p.n_ctile,
+                    c1 = (long long)p.band_chunk0[b + 1] * p.n_ctile;
+    for (long long cx = c0; cx < c1; ++cx) v += part[cx * cell + j];
+    bandsum[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < p.n_region * K; idx += blockDim.x) {
+    const int r = idx / K, k = idx - r * K;
+    const int wf = p.region_wf[r];
+    double v = 0.0;
+    for (int b = 0; b < p.n_band; ++b) {
+      const double cb = p.coef_band[r * p.n_band + b];
+      if (cb == 0.0) continue;  // excluded cells may hold NaN: never touch them
+      for (int s = 0; s < p.n_seg; ++s) {
+        const double cs = p.coef_seg[r * p.n_seg + s];
+        if (cs == 0.0) continue;
+        v += (cb * cs) * bandsum[((b * p.nwf + wf) * p.n_seg + s) * K + k];
+      }
+    }
+    rsum[idx] = v;
+    if (p.sums) p.sums[(o * p.n_region + r) * K + k] = v;
+  }
+  __syncthreads();
+  if (!p.metrics) return;
+  for (int r = tid; r < p.n_region; r += blockDim.x) {
+    const double* s = rsum + r * K;
+    const double nan = __builtin_nan("");
+    const double wsum = nan_if_zero(p.region_wsum[r]);
+    double mse = nan, rmse = nan, mae = nan, bias = nan, acc = nan;
+    if (p.mode == WB2_MODE_WIND) {
+      const double den = p.skipna ? nan_if_zero(s[1]) : wsum;
+      mse = s[0] / den;
+      rmse = sqrt(mse);
+    } else {
+      const int kq = p.mode == WB2_MODE_DET_ACC ? 6 : 3;
+      const double den_d = p.skipna ? nan_if_zero(s[kq]) : wsum;
+      bias = s[0] / den_d;
+      mae = s[1] / den_d;
+      mse = s[2] / den_d;
+      rmse = sqrt(mse);
+      if (p.mode == WB2_MODE_DET_ACC) {
+        const double den_p = p.skipna ? nan_if_zero(s[7]) : wsum;
+        const double den_f = p.skipna ? nan_if_zero(s[8]) : wsum;
+        const double den_t = p.skipna ? nan_if_zero(s[9]) : wsum;
+        // metrics.py:407-414
+        acc = (s[3] / den_p) / sqrt((s[4] / den_f) * (s[5] / den_t));
+      }
+    }
+    const long long stride = (long long)p.n_region * p.n_outer;
+    double* m = p.metrics + (long long)r * p.n_outer + o;
+    m[WB2_METRIC_MSE * stride] = mse;
+    m[WB2_METRIC_RMSE * stride] = rmse;
+    m[WB2_METRIC_MAE * stride] = mae;
+    m[WB2_METRIC_BIAS * stride] = bias;
+    m[WB2_METRIC_ACC * stride] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    time_accumulate_kernel(const double* __restrict__ values, long long n_lead,
+                           long long n_time, long long n_tail, int skipna,
+                           double* __restrict__ sum,
+                           double* __restrict__ count) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_lead * n_tail) return;
+  const long long l = idx / n_tail, j = idx - l * n_tail;
+  double s = 0.0, c = 0.0;
+  for (long long t = 0; t < n_time; ++t) {
+    const double v = values[(l * n_time + t) * n_tail + j];
+    if (skipna && is_nan(v)) continue;
+    s += v;
+    c += 1.0;
+  }
+  sum[idx] += s;
+  count[idx] += c;
+}
+
+// ---------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------
+template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
+int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
+  constexpr int K = ModeTraits<MODE, SKIPNA>::K;
+  constexpr int KB = K >= 2 ? 2 : 1;
+  const size_t lds = (size_t)KB * threads * VEC * sizeof(double);
+  const dim3 grid((unsigned)(p.n_outer * p.n_chunk), (unsigned)p.n_ctile);
+  hipLaunchKernelGGL((stream_partials_kernel<T, VEC, MODE, SKIPNA, WF>), grid,
+                     dim3(threads), lds, stream, p);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int VEC, int MODE>
+int launch_stream_flags(const StreamParams& p, bool skipna, bool wf,
+                        int threads, hipStream_t stream) {
+  if (skipna) {
+    return wf ? launch_stream<T, VEC, MODE, true, true>(p, threads, stream)
+              : launch_stream<T, VEC, MODE, true, false>(p, threads, stream);
+  }
+  return wf ? launch_stream<T, VEC, MODE, false, true>(p, threads, stream)
+            : launch_stream<T, VEC, MODE, false, false>(p, threads, stream);
+}
+
+template <typename T, int VECW>
+int launch_stream_mode(const StreamParams& p, int mode, bool vec, bool skipna,
+                       bool wf, int threads, hipStream_t stream) {
+#define WB2_MODE_CASE(M)                                                     \
+  case M:                                                                    \
+    return vec ? launch_stream_flags<T, VECW, M>(p, skipna, wf, threads,     \
+                                                 stream)                     \
+               : launch_stream_flags<T, 1, M>(p, skipna, wf, threads, stream);
+  switch (mode) {
+    WB2_MODE_CASE(WB2_MODE_DET)
+    WB2_MODE_CASE(WB2_MODE_DET_ACC)
+    WB2_MODE_CASE(WB2_MODE_WIND)
+  }
+#undef WB2_MODE_CASE
+  return fail("unknown mode %d", mode);
+}
+
+int vec_width(int dtype, int n_col, bool aligned16) {
+  const int w = dtype == WB2_F32 ? 4 : 2;
+  return (aligned16 && n_col % w == 0) ? w : 1;
+}
+
+int threads_for(int n_col, int vec) {
+  const int lanes = (n_col + vec - 1) / vec;
+  int threads = ((lanes + kWave - 1) / kWave) * kWave;
+  return threads > 512 ? 512 : threads;
+}
+
+int mode_nin(int mode) {
+  return mode == WB2_MODE_DET ? 2 : mode == WB2_MODE_DET_ACC ? 3 : 4;
+}
+
+}  // namespace
+}  // namespace wb2
+
+extern "C" {
+
+int wb2_num_slots(int mode, int skipna) {
+  switch (mode) {
+    case WB2_MODE_DET: return skipna ? 4 : 3;
+    case WB2_MODE_DET_ACC: return skipna ? 10 : 6;
+    case WB2_MODE_WIND: return skipna ? 2 : 1;
+  }
+  return wb2::fail("unknown mode %d", mode);
+}
+
+int wb2_tile_cols(int dtype, int n_col, int aligned16) {
+  if (dtype != WB2_F32 && dtype != WB2_F64) return wb2::fail("bad dtype");
+  const int vec = wb2::vec_width(dtype, n_col, aligned16 != 0);
+  return wb2::threads_for(n_col, vec) * vec;
+}
+
+int wb2_stream_partials(int mode, int dtype, int skipna,
+                        const void* const* in, const int64_t* const* slab,
+                        int64_t n_outer, int32_t n_row, int32_t n_col,
+                        const double* w_row, const double* w_col,
+                        const double* wfield, const int32_t* chunk_row0,
+                        const int32_t* chunk_nrow, int32_t n_chunk,
+                        int32_t n_ctile, const int32_t* seg_col0,
+                        int32_t n_seg, double* partials, void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(mode >= 0 && mode <= 2, "unknown mode %d", mode);
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE(in && w_row && w_col && chunk_row0 && chunk_nrow && seg_col0 &&
+                  partials,
+              "null pointer argument");
+  WB2_REQUIRE(n_outer >= 0 && n_row > 0 && n_col > 0 && n_chunk > 0 &&
+                  n_seg > 0,
+              "bad sizes: n_outer=%lld n_row=%d n_col=%d n_chunk=%d n_seg=%d",
+              (long long)n_outer, n_row, n_col, n_chunk, n_seg);
+  if (n_outer == 0) return 0;
+  WB2_REQUIRE(n_outer * (int64_t)n_chunk < (1ll << 31),
+              "grid too large: n_outer*n_chunk=%lld",
+              (long long)(n_outer * n_chunk));
+  StreamParams p{};
+  const int nin = mode_nin(mode);
+  bool aligned = true;
+  for (int i = 0; i < nin; ++i) {
+    WB2_REQUIRE(in[i] != nullptr, "input %d is null", i);
+    p.in[i] = in[i];
+    p.slab[i] = slab ? reinterpret_cast<const long long*>(slab[i]) : nullptr;
+    aligned = aligned && (reinterpret_cast<uintptr_t>(in[i]) % 16 == 0);
+  }
+  if (wfield) aligned = aligned && reinterpret_cast<uintptr_t>(wfield) % 16 == 0;
+  const int vec = vec_width(dtype, n_col, aligned);
+  const int threads = threads_for(n_col, vec);
+  p.w_row = w_row;
+  p.w_col = w_col;
+  p.wfield = wfield;
+  p.chunk_row0 = chunk_row0;
+  p.chunk_nrow = chunk_nrow;
+  p.seg_col0 = seg_col0;
+  p.partials = partials;
+  p.n_outer = n_outer;
+  p.n_row = n_row;
+  p.n_col = n_col;
+  p.n_chunk = n_chunk;
+  p.n_ctile = (n_col + threads * vec - 1) / (threads * vec);
+  WB2_REQUIRE(p.n_ctile == n_ctile,
+              "n_ctile=%d does not match the launch geometry (%d): inputs "
+              "must be 16-byte aligned iff wb2_tile_cols() was asked so",
+              n_ctile, p.n_ctile);
+  p.n_seg = n_seg;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    return launch_stream_mode<float, 4>(p, mode, vec > 1, skipna != 0,
+                                        wfield != nullptr, threads, s);
+  return launch_stream_mode<double, 2>(p, mode, vec > 1, skipna != 0,
+                                       wfield != nullptr, threads, s);
+}
+
+int wb2_det_combine(int mode, int skipna, const double* partials,
+                    int64_t n_outer, int32_t n_chunk, int32_t n_ctile,
+                    int32_t nwf, int32_t n_seg, const int32_t* band_chunk0,
+                    int32_t n_band, const double* coef_band,
+                    const double* coef_seg, const int32_t* region_wf,
+                    const double* region_wsum, int32_t n_region, double* sums,
+                    double* metrics, void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(mode >= 0 && mode <= 2, "unknown mode %d", mode);
+  WB2_REQUIRE(partials && band_chunk0 && coef_band && coef_seg && region_wf &&
+                  region_wsum,
+              "null pointer argument");
+  WB2_REQUIRE(n_outer >= 0 && n_chunk > 0 && n_ctile > 0 &&
+                  (nwf == 1 || nwf == 2) && n_seg > 0 && n_band > 0 &&
+                  n_region > 0,
+              "bad sizes");
+  if (n_outer == 0) return 0;
+  CombineParams p{};
+  p.partials = partials;
+  p.band_chunk0 = band_chunk0;
+  p.coef_band = coef_band;
+  p.coef_seg = coef_seg;
+  p.region_wf = region_wf;
+  p.region_wsum = region_wsum;
+  p.sums = sums;
+  p.metrics = metrics;
+  p.n_outer = n_outer;
+  p.n_chunk = n_chunk;
+  p.n_ctile = n_ctile;
+  p.nwf = nwf;
+  p.n_seg = n_seg;
+  p.n_band = n_band;
+  p.n_region = n_region;
+  p.K = wb2_num_slots(mode, skipna);
+  p.mode = mode;
+  p.skipna = skipna != 0;
+  const size_t lds =
+      ((size_t)n_band * nwf * n_seg * p.K + (size_t)n_region * p.K) *
+      sizeof(double);
+  WB2_REQUIRE(lds <= 64 * 1024,
+              "region decomposition too fine for the combine kernel's LDS "
+              "(%zu bytes > 64 KiB): n_band=%d n_seg=%d",
+              lds, n_band, n_seg);
+  hipLaunchKernelGGL(det_combine_kernel, dim3((unsigned)n_outer), dim3(256),
+                     lds, static_cast<hipStream_t>(stream), p);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
+                        int64_t n_tail, int skipna, double* sum, double* count,
+                        void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(values && sum && count, "null pointer argument");
+  WB2_REQUIRE(n_lead >= 0 && n_time >= 0 && n_tail >= 0, "bad sizes");
+  const long long n = n_lead * n_tail;
+  if (n == 0 || n_time == 0) return 0;
+  hipLaunchKernelGGL(time_accumulate_kernel, dim3((unsigned)((n + 255) / 256)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), values,
+                     (long long)n_lead, (long long)n_time, (long long)n_tail,
+                     skipna, sum, count);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""Launch layer: torch tensors (device memory, streams) -> C-ABI kernels.
+
+PyTorch is plumbing here: it owns HBM allocations and the current HIP stream;
+every FLOP of the hot path runs in libwb2hip.so.
+"""
+from __future__ import annotations
+
+import typing as t
+
+import numpy as np
+import torch
+
+from weatherbench2_amd import _lib
+from weatherbench2_amd.plan import ReductionPlan
+
+_DTYPES = {torch.float32: _lib.WB2_F32, torch.float64: _lib.WB2_F64}
+
+# bench.py hook: (start, stop) torch.cuda.Event pair recorded around the K1
+# launch on the stream it is launched on (the current torch stream).
+K1_EVENTS = None
+
+
+def current_stream_ptr(device) -> int:
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu() -> torch.device:
+  if not torch.cuda.is_available():
+    raise _lib.Wb2HipError(
+        'no HIP device visible: the MI355X path has no CPU fallback')
+  return torch.device('cuda', torch.cuda.current_device())
+
+
+def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
+  """numpy / torch / DLPack-capable array -> contiguous tensor on `device`."""
+  if isinstance(x, torch.Tensor):
+    ten = x
+  elif isinstance(x, np.ndarray):
+    if not x.dtype.isnative:
+      x = x.astype(x.dtype.newbyteorder('='))
+    ten = torch.from_numpy(np.ascontiguousarray(x))
+  elif hasattr(x, '__dlpack__'):
+    ten = torch.from_dlpack(x)
+  else:
+    ten = torch.as_tensor(np.asarray(x))
+  if dtype is not None and ten.dtype != dtype:
+    ten = ten.to(dtype)
+  if ten.device != device:
+    ten = ten.to(device, non_blocking=True)
+  return ten.contiguous()
+
+
+def stream_reduce(plan: ReductionPlan, mode: int,
+                  inputs: t.Sequence[torch.Tensor],
+                  slabs: t.Sequence[t.Optional[torch.Tensor]], n_outer: int,
+                  skipna: bool, want_sums: bool = False):
+  """Runs K1 + K2.  `inputs[i]` is [n_slab_i, n_row, n_col] on the plan's device.
+
+  Returns (metrics[NMETRIC, n_region, n_outer], sums[n_outer, n_region, K] or
+  None) as float64 device tensors; the call is asynchronous on the current
+  stream.
+  """
+  lib = _lib.load()
+  dev = plan.device
+  dtype = inputs[0].dtype
+  if dtype not in _DTYPES:
+    raise TypeError(f'unsupported dtype {dtype}')
+  for x in inputs:
+    if x.dtype != dtype or x.device != dev or not x.is_contiguous():
+      raise ValueError('inputs must share dtype/device and be contiguous')
+    if tuple(x.shape[-2:]) != (plan.n_row, plan.n_col):
+      raise ValueError(f'slab shape {tuple(x.shape[-2:])} != plan '
+                       f'({plan.n_row}, {plan.n_col})')
+  for s, x in zip(slabs, inputs):
+    if s is None and x.shape[0] != n_outer:
+      raise ValueError('input without a slab table must have n_outer slabs')
+    if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
+      raise ValueError('slab tables are int64[n_outer]')
+  code = _DTYPES[dtype]
+  k = lib.wb2_num_slots(mode, int(skipna))
+  aligned = all(x.data_ptr() % 16 == 0 for x in inputs) and (
+      plan.wfield is None or plan.wfield.data_ptr() % 16 == 0)
+  tile = lib.wb2_tile_cols(code, plan.n_col, int(aligned))
+  n_ctile = -(-plan.n_col // tile)
+  stream = current_stream_ptr(dev)
+  partials = torch.empty(
+      (n_outer, plan.n_chunk, n_ctile, plan.nwf, plan.n_seg, k),
+      dtype=torch.float64, device=dev)
+  if K1_EVENTS is not None:
+    K1_EVENTS[0].record()
+  _lib.check(lib.wb2_stream_partials(
+      mode, code, int(skipna), _lib.ptr_array(inputs), _lib.ptr_array(slabs),
+      n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
+      _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
+      _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
+      _lib.ptr(plan.seg_col0), plan.n_seg, _lib.ptr(partials), stream),
+              'wb2_stream_partials')
+  if K1_EVENTS is not None:
+    K1_EVENTS[1].record()
+  metrics = torch.empty((_lib.NMETRIC, plan.n_region, n_outer),
+                        dtype=torch.float64, device=dev)
+  sums = (torch.empty((n_outer, plan.n_region, k), dtype=torch.float64,
+                      device=dev) if want_sums else None)
+  _lib.check(lib.wb2_det_combine(
+      mode, int(skipna), _lib.ptr(partials), n_outer, plan.n_chunk, n_ctile,
+      plan.nwf, plan.n_seg, _lib.ptr(plan.band_chunk0), plan.n_band,
+      _lib.ptr(plan.coef_band), _lib.ptr(plan.coef_seg),
+      _lib.ptr(plan.region_wf), _lib.ptr(plan.region_wsum), plan.n_region,
+      _lib.ptr(sums), _lib.ptr(metrics), stream), 'wb2_det_combine')
+  return metrics, sums
+
+
+def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
+                    total: torch.Tensor, count: torch.Tensor):
+  """total/count += sum/notnull-count of `values` over `time_axis` (device)."""
+  lib = _lib.load()
+  values = values.contiguous()
+  shape = tuple(values.shape)
+  n_lead = int(np.prod(shape[:time_axis], dtype=np.int64))
+  n_time = shape[time_axis]
+  n_tail = int(np.prod(shape[time_axis + 1:], dtype=np.int64))
+  if total.numel() != n_lead * n_tail or count.numel() != n_lead * n_tail:
+    raise ValueError('accumulator shape mismatch')
+  _lib.check(lib.wb2_time_accumulate(
+      _lib.ptr(values), n_lead, n_time, n_tail, int(skipna), _lib.ptr(total),
+      _lib.ptr(count), current_stream_ptr(values.device)),
+             'wb2_time_accumulate')

@@ -1,0 +1,530 @@
+"""GPU metric operators with the reference's `Metric` protocol.
+
+Same class names, constructor fields, `compute_chunk(forecast, truth, region,
+skipna)` / `compute(...)` signatures, result layout (every input variable, all
+non-spatial dims kept, no latitude/longitude) and error behaviour as
+weatherbench2/metrics.py -- so they are drop-in values for
+`config.Eval.metrics` -- but the arithmetic is ONE fused HIP pass per
+(forecast, truth) chunk:
+
+  reference                                   here
+  ------------------------------------------  ---------------------------------
+  MSE/RMSE/MAE/Bias each recompute f - t and  one read of f, t (and the
+  run 2 einsums (metrics.py:236-359), ACC     climatology for ACC) feeds all
+  three more (:377-414), all of it again per  five metrics and EVERY region
+  region (evaluation.py:416-430)              (csrc/stream_reduce.hip)
+  truth.sel(time=valid_time) and              no copies: per-slab index tables
+  climatology.sel(dayofyear, hour) copies     gather truth/climatology slabs
+  (evaluation.py:474-475, metrics.py:398-404) inside the kernel
+
+Because the reference's loop asks for one (metric, region) at a time, results
+of a pass are cached per chunk (the reference does the same for CRPS with
+`dataset_safe_lru_cache`, metrics.py:775-780): the first call computes all
+metrics of the pass for all regions announced through `fused_regions(...)`
+(or for just the requested one), later calls are lookups.
+"""
+from __future__ import annotations
+
+import contextlib
+import dataclasses
+import typing as t
+
+import numpy as np
+import torch
+
+from weatherbench2_amd import _lib
+from weatherbench2_amd import engine
+from weatherbench2_amd import plan as plan_lib
+from weatherbench2_amd import xarray_lite as xl
+from weatherbench2_amd.regions import Region
+
+REALIZATION = 'realization'
+_SPATIAL = ('latitude', 'longitude')
+
+
+# ---------------------------------------------------------------------------
+# region announcement + per-chunk result cache
+# ---------------------------------------------------------------------------
+_ACTIVE_REGIONS: list = []  # stack of ordered {name: Region|None} dicts
+
+
+@contextlib.contextmanager
+def fused_regions(regions: t.Optional[dict]):
+  """Announce the regions a loop is about to iterate so one pass serves all."""
+  _ACTIVE_REGIONS.append(dict(regions) if regions else {'__none__': None})
+  try:
+    yield
+  finally:
+    _ACTIVE_REGIONS.pop()
+
+
+def _region_set_for(region) -> tuple[dict, str]:
+  """Returns (ordered region dict to evaluate, key of the requested one)."""
+  if _ACTIVE_REGIONS:
+    active = _ACTIVE_REGIONS[-1]
+    for k, v in active.items():
+      if v is region:
+        return active, k
+  return {'__requested__': region}, '__requested__'
+
+
+class _LRU:
+
+  def __init__(self, maxsize):
+    self.maxsize = maxsize
+    self.items: list = []  # (key, pins, value), most recent last
+
+  def get(self, key):
+    for i, (k, _, v) in enumerate(self.items):
+      if k == key:
+        self.items.append(self.items.pop(i))
+        return v
+    return None
+
+  def put(self, key, pins, value):
+    self.items = [it for it in self.items if it[0] != key]
+    self.items.append((key, pins, value))
+    while len(self.items) > self.maxsize:
+      self.items.pop(0)
+
+  def clear(self):
+    self.items.clear()
+
+
+_RESULTS = _LRU(8)    # fused pass results
+_DEVICE = _LRU(12)    # host array -> device tensor uploads
+
+
+def clear_caches():
+  _RESULTS.clear()
+  _DEVICE.clear()
+
+
+def _to_device(data, device) -> torch.Tensor:
+  if isinstance(data, torch.Tensor) and data.device == device:
+    return data
+  key = id(data)
+  hit = _DEVICE.get(key)
+  if hit is not None:
+    return hit
+  ten = engine.as_device_tensor(data, device)
+  _DEVICE.put(key, (data,), ten)
+  return ten
+
+
+# ---------------------------------------------------------------------------
+# chunk geometry
+# ---------------------------------------------------------------------------
+@dataclasses.dataclass
+class _Geometry:
+  layout: str
+  out_dims: tuple
+  out_shape: tuple
+  latitude: np.ndarray
+  longitude: np.ndarray
+
+  @property
+  def n_outer(self):
+    return int(np.prod(self.out_shape, dtype=np.int64))
+
+
+def _spatial_last(da: xl.DataArray, layout: t.Optional[str]):
+  """Returns (data with the two spatial dims last, non-spatial dims, layout)."""
+  for d in _SPATIAL:
+    if d not in da.dims:
+      raise ValueError(f'{d!r} missing from dims {da.dims}')
+  rest = tuple(d for d in da.dims if d not in _SPATIAL)
+  tail = tuple(d for d in da.dims if d in _SPATIAL)
+  if layout is None:
+    layout = plan_lib.LATLON if tail == _SPATIAL else plan_lib.LONLAT
+  want = _SPATIAL if layout == plan_lib.LATLON else _SPATIAL[::-1]
+  if da.dims[-2:] == want:
+    return da.data, rest, layout
+  moved = da.transpose(*rest, *want)
+  data = moved.data
+  data = data.contiguous() if isinstance(data, torch.Tensor) else (
+      np.ascontiguousarray(data))
+  return data, rest, layout
+
+
+def _slab_table(out_dims, out_shape, in_dims, in_shape, extra=None):
+  """int64[n_outer] slab index of an input broadcast (by name) to out_dims."""
+  if tuple(in_dims) == tuple(out_dims) and extra is None:
+    if tuple(in_shape) != tuple(out_shape):
+      raise ValueError(f'shape mismatch {in_shape} vs {out_shape}')
+    return None
+  table = np.zeros(out_shape, dtype=np.int64)
+  stride = 1
+  for d, n in reversed(list(zip(in_dims, in_shape))):
+    if d not in out_dims:
+      raise ValueError(f'dimension {d!r} not in {out_dims}')
+    ax = out_dims.index(d)
+    if out_shape[ax] != n:
+      raise ValueError(f'size mismatch on {d!r}: {n} vs {out_shape[ax]}')
+    shape = [1] * len(out_shape)
+    shape[ax] = n
+    table = table + (np.arange(n, dtype=np.int64) * stride).reshape(shape)
+    stride *= n
+  if extra is not None:
+    table = table + extra
+  return np.ascontiguousarray(table).ravel()
+
+
+def _coord_values(ds: xl.Dataset, name: str) -> np.ndarray:
+  c = ds.coords[name]
+  return np.asarray(c.values if isinstance(c, xl.DataArray) else c)
+
+
+def _geometry(forecast: xl.Dataset, fvar: xl.DataArray, others) -> tuple:
+  """Common output dims (xarray broadcast order) for one variable."""
+  fdata, frest, layout = _spatial_last(fvar, None)
+  out_dims = list(frest)
+  sizes = dict(fvar.sizes)
+  prepared = [(fdata, frest)]
+  for da in others:
+    data, rest, _ = _spatial_last(da, layout)
+    for d in rest:
+      if d not in out_dims:
+        out_dims.append(d)
+        sizes[d] = da.sizes[d]
+    prepared.append((data, rest))
+  out_dims = tuple(out_dims)
+  out_shape = tuple(sizes[d] for d in out_dims)
+  geo = _Geometry(layout, out_dims, out_shape,
+                  _coord_values(forecast, 'latitude'),
+                  _coord_values(forecast, 'longitude'))
+  return geo, prepared
+
+
+def _check_grid(geo: _Geometry, data) -> None:
+  n_lat, n_lon = len(geo.latitude), len(geo.longitude)
+  want = (n_lat, n_lon) if geo.layout == plan_lib.LATLON else (n_lon, n_lat)
+  if tuple(data.shape[-2:]) != want:
+    raise ValueError(f'spatial shape {tuple(data.shape[-2:])} does not match '
+                     f'the coordinates {want}')
+
+
+# ---------------------------------------------------------------------------
+# climatology gather tables (metrics.py:63-81, 394-404)
+# ---------------------------------------------------------------------------
+def _get_climatology_chunk(climatology: xl.Dataset, truth: xl.Dataset) -> dict:
+  """Maps each truth variable to its climatology DataArray (KeyError like ref)."""
+  names = list(truth.keys())
+  if all(k in climatology for k in names):
+    return {k: climatology[k] for k in names}
+  clim_var_dict = {str(k) + '_mean': k for k in names}
+  not_found = set(names).difference(climatology.keys())
+  not_found_means = set(clim_var_dict).difference(climatology.keys())
+  if not_found and not_found_means:
+    raise KeyError(f'Did not find {not_found} keys in climatology. Appending '
+                   "'mean' did not help.")
+  return {v: climatology[k] for k, v in clim_var_dict.items()}
+
+
+def _label_positions(have: np.ndarray, want: np.ndarray, what: str):
+  pos = {v: i for i, v in enumerate(np.asarray(have).tolist())}
+  try:
+    return np.array([pos[v] for v in np.asarray(want).ravel().tolist()],
+                    dtype=np.int64).reshape(np.shape(want))
+  except KeyError as e:
+    raise KeyError(f'{what} label {e} not found in climatology') from e
+
+
+def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
+                       forecast: xl.Dataset, geo: _Geometry, crest: tuple):
+  """int64[n_outer]: which climatology slab each output slab subtracts."""
+  import pandas as pd
+  if 'init_time' in forecast.dims:
+    time_dims = ('init_time', 'lead_time')
+    vt = forecast.coords['valid_time']
+    vt = vt.transpose(*time_dims).values if isinstance(
+        vt, xl.DataArray) else np.asarray(vt)
+  else:
+    time_dims = ('time',)
+    vt = _coord_values(forecast, 'time')
+  idx = pd.DatetimeIndex(np.asarray(vt).ravel())
+  shape = np.shape(vt)
+  doy = np.asarray(idx.dayofyear).reshape(shape)
+  hour = np.asarray(idx.hour).reshape(shape)
+
+  stride, strides = 1, {}
+  for d, n in reversed(list(zip(crest, [cvar.sizes[d] for d in crest]))):
+    strides[d] = stride
+    stride *= n
+  unknown = set(crest) - {'dayofyear', 'hour', 'level'}
+  if unknown:
+    raise ValueError(f'unsupported climatology dims {unknown}')
+  # time part, shaped like the time dims
+  tpart = _label_positions(_coord_values(climatology, 'dayofyear'), doy,
+                           'dayofyear') * strides['dayofyear']
+  if 'hour' in climatology.coords and 'hour' in crest:
+    tpart = tpart + _label_positions(_coord_values(climatology, 'hour'), hour,
+                                     'hour') * strides['hour']
+  table = np.zeros(geo.out_shape, dtype=np.int64)
+  shape = [1] * len(geo.out_shape)
+  for d, n in zip(time_dims, np.shape(vt)):
+    if d not in geo.out_dims:
+      raise ValueError(f'time dim {d!r} missing from the forecast variable')
+    shape[geo.out_dims.index(d)] = n
+  order = [d for d in geo.out_dims if d in time_dims]
+  tpart = np.transpose(tpart, [time_dims.index(d) for d in order])
+  table = table + tpart.reshape(shape)
+  if 'level' in crest:
+    if 'level' not in geo.out_dims:
+      raise ValueError('climatology has a level dim but the forecast has none')
+    lv = _label_positions(_coord_values(climatology, 'level'),
+                          _coord_values(forecast, 'level'), 'level')
+    shape = [1] * len(geo.out_shape)
+    shape[geo.out_dims.index('level')] = len(lv)
+    table = table + (lv * strides['level']).reshape(shape)
+  return np.ascontiguousarray(table).ravel()
+
+
+# ---------------------------------------------------------------------------
+# the fused passes
+# ---------------------------------------------------------------------------
+def _run_pass(mode, geo, arrays, tables, region, skipna):
+  """Uploads (if needed), launches, returns {region_key: metrics[NMETRIC, ...]}."""
+  device = engine.require_gpu()
+  regions, rkey = _region_set_for(region)
+  pl = plan_lib.cached_plan(geo.latitude, geo.longitude, geo.layout, regions,
+                            device)
+  tensors = [_to_device(a, device) for a in arrays]
+  dtype = torch.result_type(tensors[0], tensors[1])
+  for x in tensors[2:]:
+    dtype = torch.promote_types(dtype, x.dtype)
+  if dtype not in (torch.float32, torch.float64):
+    dtype = torch.float64
+  tensors = [x if x.dtype == dtype else x.to(dtype) for x in tensors]
+  for x in tensors:
+    _check_grid(geo, x)
+  flat = [x.reshape(-1, pl.n_row, pl.n_col) for x in tensors]
+  slabs = [None if tb is None else torch.from_numpy(tb).to(device)
+           for tb in tables]
+  metrics, _ = engine.stream_reduce(pl, mode, flat, slabs, geo.n_outer, skipna)
+  host = metrics.cpu().numpy().reshape(
+      (_lib.NMETRIC, pl.n_region) + geo.out_shape)
+  return {name: host[:, i] for i, name in enumerate(pl.region_names)}, rkey
+
+
+def _result_key(kind, arrays, region_key_obj, skipna):
+  regions, _ = _region_set_for(region_key_obj)
+  return (kind, tuple(id(a) for a in arrays),
+          tuple((k, id(v)) for k, v in regions.items()), bool(skipna))
+
+
+def _det_pass(forecast, truth, name, region, skipna, climatology=None):
+  """All five deterministic metrics of one variable, for the active regions."""
+  fvar, tvar = forecast[name], truth[name]
+  cvar = None
+  if climatology is not None:
+    cvar = _get_climatology_chunk(climatology, truth)[name]
+  pins = [fvar.data, tvar.data] + ([cvar.data] if cvar is not None else [])
+  key = _result_key('det', pins[:2], region, skipna)
+  hit = _RESULTS.get(key)
+  # A cached ACC pass also answers MSE/RMSE/MAE/Bias queries.
+  if hit is not None and (cvar is None or hit['clim'] == id(cvar.data)):
+    return hit['geo'], hit['by_region']
+  geo, prepared = _geometry(forecast, fvar, [tvar])
+  tables = [_slab_table(geo.out_dims, geo.out_shape, p[1], p[0].shape[:-2])
+            for p in prepared]
+  mode = _lib.MODE_DET
+  if cvar is not None:
+    crest = tuple(d for d in cvar.dims if d not in _SPATIAL)
+    cdata, _, _ = _spatial_last(cvar, geo.layout)
+    prepared.append((cdata, crest))
+    tables.append(_climatology_slabs(climatology, cvar, forecast, geo, crest))
+    mode = _lib.MODE_DET_ACC
+  by_region, _ = _run_pass(mode, geo, [p[0] for p in prepared], tables, region,
+                           skipna)
+  _RESULTS.put(key, tuple(pins), {
+      'geo': geo, 'by_region': by_region,
+      'clim': None if cvar is None else id(cvar.data)})
+  return geo, by_region
+
+
+def _result_coords(forecast: xl.Dataset, out_dims) -> dict:
+  coords = {}
+  for k, c in forecast.coords.items():
+    if k in _SPATIAL:
+      continue
+    if isinstance(c, xl.DataArray):
+      if all(d in out_dims for d in c.dims):
+        coords[k] = c
+    elif k in out_dims:
+      coords[k] = c
+  return coords
+
+
+def _assemble(forecast, per_var: dict) -> xl.Dataset:
+  """{var: (out_dims, array)} -> Dataset without spatial dims."""
+  out = xl.Dataset()
+  for name, (dims, arr) in per_var.items():
+    out.coords.update(_result_coords(forecast, dims))
+  for name, (dims, arr) in per_var.items():
+    out.data_vars[name] = xl.DataArray(np.array(arr, dtype=np.float64), dims,
+                                       out.coords, name)
+  return out
+
+
+def _common_vars(forecast, truth):
+  return [k for k in forecast.keys() if k in truth]
+
+
+# ---------------------------------------------------------------------------
+# Metric classes (metrics.py:84-414)
+# ---------------------------------------------------------------------------
+@dataclasses.dataclass
+class Metric:
+  """Base class for metrics (metrics.py:84-138)."""
+
+  def compute_chunk(self, forecast, truth, region: t.Optional[Region] = None,
+                    skipna: bool = False) -> xl.Dataset:
+    raise NotImplementedError
+
+  def compute(self, forecast, truth, region: t.Optional[Region] = None,
+              skipna: bool = False) -> xl.Dataset:
+    """Evaluate this metric on datasets with full temporal coverages."""
+    forecast = xl.as_dataset(forecast)
+    if 'time' in forecast.dims:
+      avg_dim = 'time'
+    elif 'init_time' in forecast.dims:
+      avg_dim = 'init_time'
+    else:
+      raise ValueError(
+          f'Forecast has neither valid_time or init_time dimension {forecast}')
+    return self.compute_chunk(forecast, truth, region=region,
+                              skipna=skipna).mean(avg_dim, skipna=skipna)
+
+
+class _DetMetric(Metric):
+  _index: int = -1
+
+  def _scalar(self, forecast, truth, region, skipna) -> xl.Dataset:
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    per_var = {}
+    for name in _common_vars(forecast, truth):
+      geo, by_region = _det_pass(forecast, truth, name, region, skipna)
+      _, rkey = _region_set_for(region)
+      per_var[name] = (geo.out_dims, by_region[rkey][self._index])
+    return _assemble(forecast, per_var)
+
+
+def _wind_pass(forecast, truth, u_name, v_name, region, skipna):
+  fu, fv, tu, tv = (forecast[u_name], forecast[v_name], truth[u_name],
+                    truth[v_name])
+  pins = [fu.data, tu.data, fv.data, tv.data]
+  key = _result_key('wind', pins, region, skipna)
+  hit = _RESULTS.get(key)
+  if hit is not None:
+    return hit
+  geo, prepared = _geometry(forecast, fu, [tu, fv, tv])
+  tables = [_slab_table(geo.out_dims, geo.out_shape, p[1], p[0].shape[:-2])
+            for p in prepared]
+  by_region, _ = _run_pass(_lib.MODE_WIND, geo, [p[0] for p in prepared],
+                           tables, region, skipna)
+  value = (geo, by_region)
+  _RESULTS.put(key, tuple(pins), value)
+  return value
+
+
+@dataclasses.dataclass
+class WindVectorMSE(Metric):
+  """Wind vector mean square error (metrics.py:175-202)."""
+
+  u_name: str
+  v_name: str
+  vector_name: str
+  _index = _lib.METRIC_INDEX['mse']
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    geo, by_region = _wind_pass(forecast, truth, self.u_name, self.v_name,
+                                region, skipna)
+    _, rkey = _region_set_for(region)
+    return _assemble(forecast, {
+        self.vector_name: (geo.out_dims, by_region[rkey][self._index])})
+
+
+@dataclasses.dataclass
+class WindVectorRMSESqrtBeforeTimeAvg(WindVectorMSE):
+  """Wind vector RMSE, sqrt before time averaging (metrics.py:205-233)."""
+
+  _index = _lib.METRIC_INDEX['rmse']
+
+
+@dataclasses.dataclass
+class RMSESqrtBeforeTimeAvg(_DetMetric):
+  """Root mean squared error, sqrt before time averaging (metrics.py:236-269)."""
+
+  wind_vector_rmse: t.Optional[list] = None
+  _index = _lib.METRIC_INDEX['rmse']
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    results = self._scalar(forecast, truth, region, skipna)
+    if self.wind_vector_rmse is not None:
+      for wv in self.wind_vector_rmse:
+        results[wv.vector_name] = wv.compute_chunk(
+            forecast, truth, region=region, skipna=skipna)[wv.vector_name]
+    return results
+
+
+@dataclasses.dataclass
+class MSE(_DetMetric):
+  """Mean squared error (metrics.py:272-301)."""
+
+  wind_vector_mse: t.Optional[list] = None
+  _index = _lib.METRIC_INDEX['mse']
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    results = self._scalar(forecast, truth, region, skipna)
+    if self.wind_vector_mse is not None:
+      for wv in self.wind_vector_mse:
+        results[wv.vector_name] = wv.compute_chunk(
+            forecast, truth, region=region, skipna=skipna)[wv.vector_name]
+    return results
+
+
+@dataclasses.dataclass
+class MAE(_DetMetric):
+  """Mean absolute error (metrics.py:319-330)."""
+
+  _index = _lib.METRIC_INDEX['mae']
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    return self._scalar(forecast, truth, region, skipna)
+
+
+@dataclasses.dataclass
+class Bias(_DetMetric):
+  """Bias (metrics.py:348-359)."""
+
+  _index = _lib.METRIC_INDEX['bias']
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    return self._scalar(forecast, truth, region, skipna)
+
+
+@dataclasses.dataclass
+class ACC(Metric):
+  """Anomaly correlation coefficient (metrics.py:377-414).
+
+  Attribute:
+    climatology: Climatology for computing anomalies (Dataset with dims
+      [hour,] dayofyear[, level], latitude, longitude).
+  """
+
+  climatology: t.Any = None
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    climatology = xl.as_dataset(self.climatology)
+    per_var = {}
+    _get_climatology_chunk(climatology, truth)  # KeyError like the reference
+    for name in _common_vars(forecast, truth):
+      geo, by_region = _det_pass(forecast, truth, name, region, skipna,
+                                 climatology)
+      _, rkey = _region_set_for(region)
+      per_var[name] = (geo.out_dims,
+                       by_region[rkey][_lib.METRIC_INDEX['acc']])
+    return _assemble(forecast, per_var)

@@ -1,0 +1,350 @@
+"""Minimal labelled arrays: the slice of the xarray API this path touches.
+
+xarray is not installable in the build image, and the reference's operator
+protocol (`Metric.compute_chunk(forecast: xr.Dataset, ...) -> xr.Dataset`,
+weatherbench2/metrics.py:88-115) is expressed in it.  `Dataset`/`DataArray`
+here mirror the few members that protocol and `_metric_and_region_loop`
+(evaluation.py:388-438) use -- `dims`, `sizes`, `coords`, `data_vars`, item
+access, `mean`, `expand_dims`, `concat`, `merge` -- so that the GPU metrics can
+be driven, and tested, without xarray.  When real xarray IS importable,
+`from_xarray` / `to_xarray` convert at the boundary.
+
+`DataArray.data` may be a numpy array (host) or a torch tensor (device, e.g.
+obtained through DLPack); results of scalar metrics are small host arrays.
+"""
+from __future__ import annotations
+
+import typing as t
+
+import numpy as np
+
+try:  # optional
+  import xarray as _xr  # type: ignore
+except Exception:  # pragma: no cover - xarray is absent in the build image
+  _xr = None
+
+
+def _is_torch(x) -> bool:
+  return type(x).__module__.startswith('torch')
+
+
+class DataArray:
+  """N-d array with named dims and (1-D, per-dim) coordinates."""
+
+  def __init__(self, data, dims: t.Sequence[str] = (), coords=None, name=None):
+    if not _is_torch(data):
+      data = np.asarray(data)
+    self.data = data
+    self.dims = tuple(dims)
+    if len(self.dims) != data.ndim:
+      raise ValueError(f'dims {self.dims} do not match shape {tuple(data.shape)}')
+    self.coords = dict(coords or {})
+    self.name = name
+
+  @property
+  def shape(self):
+    return tuple(self.data.shape)
+
+  @property
+  def ndim(self):
+    return self.data.ndim
+
+  @property
+  def sizes(self):
+    return dict(zip(self.dims, self.shape))
+
+  @property
+  def dtype(self):
+    return self.data.dtype
+
+  @property
+  def values(self) -> np.ndarray:
+    if _is_torch(self.data):
+      return self.data.detach().cpu().numpy()
+    return self.data
+
+  def copy(self, data=None):
+    return DataArray(self.data if data is None else data, self.dims,
+                     self.coords, self.name)
+
+  def __repr__(self):
+    return (f'<wb2hip.DataArray {self.name or ""} dims={self.dims} '
+            f'shape={self.shape} dtype={self.dtype}>')
+
+  def _host(self) -> 'DataArray':
+    return DataArray(self.values, self.dims, self.coords, self.name)
+
+  def transpose(self, *dims):
+    perm = [self.dims.index(d) for d in dims]
+    if _is_torch(self.data):
+      data = self.data.permute(*perm)
+    else:
+      data = np.transpose(self.data, perm)
+    return DataArray(data, dims, self.coords, self.name)
+
+  def isel(self, **indexers):
+    data, dims, coords = self.data, list(self.dims), dict(self.coords)
+    for dim, idx in indexers.items():
+      if dim not in dims:
+        continue
+      ax = dims.index(dim)
+      sl = [slice(None)] * data.ndim
+      sl[ax] = idx
+      data = data[tuple(sl)]
+      if np.ndim(idx) == 0 and not isinstance(idx, slice):
+        dims.pop(ax)
+        coords.pop(dim, None)
+      elif dim in coords:
+        coords[dim] = np.asarray(coords[dim])[idx]
+    return DataArray(data, dims, coords, self.name)
+
+  def expand_dims(self, dim: t.Union[str, dict], axis: int = 0):
+    """`dim` is a name or {name: labels}; new dims go first (xarray)."""
+    if isinstance(dim, str):
+      dim = {dim: None}
+    out = self
+    for name, labels in reversed(list(dim.items())):
+      n = 1 if labels is None else len(np.atleast_1d(labels))
+      data = out.values[None] if n == 1 else np.broadcast_to(
+          out.values[None], (n,) + out.shape).copy()
+      coords = dict(out.coords)
+      if labels is not None:
+        coords[name] = np.atleast_1d(labels)
+      out = DataArray(data, (name,) + out.dims, coords, out.name)
+    return out
+
+  def mean(self, dim=None, skipna: bool = False):
+    a = self.values
+    if dim is None:
+      axes, keep = tuple(range(a.ndim)), ()
+    else:
+      dim = (dim,) if isinstance(dim, str) else tuple(dim)
+      axes = tuple(self.dims.index(d) for d in dim if d in self.dims)
+      keep = tuple(d for d in self.dims if d not in dim)
+    if not axes:
+      return self
+    import warnings
+    with warnings.catch_warnings(), np.errstate(all='ignore'):
+      warnings.simplefilter('ignore')
+      out = (np.nanmean if skipna else np.mean)(a, axis=axes)
+    coords = {k: v for k, v in self.coords.items() if k in keep or
+              (k not in self.dims)}
+    return DataArray(out, keep, coords, self.name)
+
+  # small host-side arithmetic (results are tiny)
+  def _bin(self, other, fn):
+    o = other.values if isinstance(other, DataArray) else other
+    if isinstance(other, DataArray) and other.dims != self.dims:
+      raise ValueError(f'dims differ: {self.dims} vs {other.dims}')
+    with np.errstate(all='ignore'):
+      return DataArray(fn(self.values, o), self.dims, self.coords, self.name)
+
+  def __add__(self, o): return self._bin(o, np.add)
+  def __sub__(self, o): return self._bin(o, np.subtract)
+  def __mul__(self, o): return self._bin(o, np.multiply)
+  def __rmul__(self, o): return self._bin(o, np.multiply)
+  def __truediv__(self, o): return self._bin(o, np.true_divide)
+
+  def sqrt(self):
+    with np.errstate(all='ignore'):
+      return DataArray(np.sqrt(self.values), self.dims, self.coords, self.name)
+
+
+class Dataset:
+  """Dict of DataArrays sharing coordinates."""
+
+  def __init__(self, data_vars=None, coords=None, attrs=None):
+    self.coords = dict(coords or {})
+    self.data_vars: dict[str, DataArray] = {}
+    self.attrs = dict(attrs or {})
+    for k, v in (data_vars or {}).items():
+      self[k] = v
+
+  def __setitem__(self, name, value):
+    if isinstance(value, tuple):
+      value = DataArray(value[1], value[0])
+    if not isinstance(value, DataArray):
+      value = DataArray(value, ())
+    for k, c in value.coords.items():
+      self.coords.setdefault(k, c)
+    value = DataArray(value.data, value.dims,
+                      {k: v for k, v in self.coords.items()}, name)
+    self.data_vars[name] = value
+
+  def __getitem__(self, name):
+    if name in self.data_vars:
+      return self.data_vars[name]
+    if name in self.coords:
+      c = self.coords[name]
+      return c if isinstance(c, DataArray) else DataArray(c, (name,),
+                                                          {name: c}, name)
+    raise KeyError(name)
+
+  def __contains__(self, name): return name in self.data_vars
+  def __iter__(self): return iter(self.data_vars)
+  def __len__(self): return len(self.data_vars)
+  def keys(self): return self.data_vars.keys()
+  def items(self): return self.data_vars.items()
+
+  @property
+  def dims(self):
+    out = {}
+    for v in self.data_vars.values():
+      out.update(v.sizes)
+    return out
+
+  sizes = dims
+
+  def __repr__(self):
+    return (f'<wb2hip.Dataset vars={list(self.data_vars)} dims={self.dims}>')
+
+  def map(self, fn):
+    return Dataset({k: fn(v) for k, v in self.data_vars.items()}, self.coords,
+                   self.attrs)
+
+  def copy(self, data=None):
+    if data is None:
+      return Dataset(dict(self.data_vars), self.coords, self.attrs)
+    return Dataset({k: v.copy(data[k]) for k, v in self.data_vars.items()},
+                   self.coords, self.attrs)
+
+  def isel(self, **indexers):
+    coords = dict(self.coords)
+    for dim, idx in indexers.items():
+      if dim in coords and not isinstance(coords[dim], DataArray):
+        if np.ndim(idx) == 0 and not isinstance(idx, slice):
+          coords.pop(dim)
+        else:
+          coords[dim] = np.asarray(coords[dim])[idx]
+    out = Dataset(coords=coords, attrs=self.attrs)
+    for k, v in self.data_vars.items():
+      w = v.isel(**indexers)
+      out.data_vars[k] = DataArray(w.data, w.dims, coords, k)
+    return out
+
+  def mean(self, dim=None, skipna: bool = False):
+    dims = (dim,) if isinstance(dim, str) else tuple(dim or ())
+    coords = {k: v for k, v in self.coords.items() if k not in dims}
+    out = Dataset(coords=coords, attrs=self.attrs)
+    for k, v in self.data_vars.items():
+      m = v.mean(dim, skipna=skipna)
+      out.data_vars[k] = DataArray(m.data, m.dims, coords, k)
+    return out
+
+  def expand_dims(self, dim):
+    if isinstance(dim, str):
+      dim = {dim: None}
+    coords = dict(self.coords)
+    for name, labels in dim.items():
+      if isinstance(labels, DataArray):
+        labels = labels.values
+        dim = {**dim, name: labels}
+      if labels is not None:
+        coords[name] = np.atleast_1d(labels)
+    out = Dataset(coords=coords, attrs=self.attrs)
+    for k, v in self.data_vars.items():
+      w = v.expand_dims(dim)
+      out.data_vars[k] = DataArray(w.data, w.dims, coords, k)
+    return out
+
+  def assign_attrs(self, **attrs):
+    return Dataset(dict(self.data_vars), self.coords, {**self.attrs, **attrs})
+
+  def _bin(self, other, fn):
+    if isinstance(other, Dataset):
+      names = [k for k in self.data_vars if k in other.data_vars]
+      return Dataset({k: fn(self.data_vars[k], other.data_vars[k])
+                      for k in names}, self.coords, self.attrs)
+    return self.map(lambda v: fn(v, other))
+
+  def __add__(self, o): return self._bin(o, lambda a, b: a + b)
+  def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
+  def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+  def __rmul__(self, o): return self._bin(o, lambda a, b: a * b)
+  def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
+
+  def sqrt(self): return self.map(lambda v: v.sqrt())
+
+
+def concat(datasets: t.Sequence[Dataset], dim: str) -> Dataset:
+  """xr.concat along an existing length-1 dim (evaluation.py:430)."""
+  first = datasets[0]
+  coords = dict(first.coords)
+  coords[dim] = np.concatenate([np.atleast_1d(d.coords[dim]) for d in datasets])
+  out = Dataset(coords=coords, attrs=first.attrs)
+  for k, v in first.data_vars.items():
+    ax = v.dims.index(dim)
+    data = np.concatenate([d.data_vars[k].values for d in datasets], axis=ax)
+    out.data_vars[k] = DataArray(data, v.dims, coords, k)
+  return out
+
+
+def merge(datasets: t.Sequence[Dataset]) -> Dataset:
+  """xr.merge of results that differ along `metric` (evaluation.py:437).
+
+  Variables missing from one operand are NaN-filled, like xarray's outer join.
+  """
+  labels: list = []
+  for d in datasets:
+    for m in np.atleast_1d(d.coords['metric']):
+      if m not in labels:
+        labels.append(m)
+  names: list = []
+  for d in datasets:
+    names += [k for k in d.data_vars if k not in names]
+  coords = {}
+  for d in datasets:
+    for k, v in d.coords.items():
+      coords.setdefault(k, v)
+  coords['metric'] = np.array(labels, dtype=object)
+  out = Dataset(coords=coords)
+  for name in names:
+    ref = next(d.data_vars[name] for d in datasets if name in d.data_vars)
+    ax = ref.dims.index('metric')
+    shape = list(ref.shape)
+    shape[ax] = len(labels)
+    data = np.full(shape, np.nan, dtype=np.float64)
+    for d in datasets:
+      if name not in d.data_vars:
+        continue
+      v = d.data_vars[name]
+      for i, m in enumerate(np.atleast_1d(d.coords['metric'])):
+        sl = [slice(None)] * len(shape)
+        sl[ax] = labels.index(m)
+        src = [slice(None)] * len(shape)
+        src[ax] = i
+        data[tuple(sl)] = v.values[tuple(src)]
+    out.data_vars[name] = DataArray(data, ref.dims, coords, name)
+  return out
+
+
+# -- optional bridges to real xarray -----------------------------------------
+def from_xarray(ds) -> Dataset:
+  coords = {}
+  for k, c in ds.coords.items():
+    coords[k] = (np.asarray(c.values) if c.ndim <= 1 and c.dims == (k,)
+                 else DataArray(np.asarray(c.values), c.dims))
+  return Dataset({k: DataArray(v.data, v.dims) for k, v in ds.data_vars.items()},
+                 coords, dict(ds.attrs))
+
+
+def to_xarray(ds: Dataset):
+  if _xr is None:
+    raise ImportError('xarray is not installed')
+  coords = {}
+  for k, c in ds.coords.items():
+    if isinstance(c, DataArray):
+      coords[k] = (c.dims, c.values)
+    elif any(k in v.dims for v in ds.data_vars.values()):
+      coords[k] = (k, np.asarray(c))
+  return _xr.Dataset({k: (v.dims, v.values) for k, v in ds.data_vars.items()},
+                     coords=coords, attrs=ds.attrs)
+
+
+def as_dataset(obj) -> Dataset:
+  """Accepts a lite Dataset or (when importable) a real xarray.Dataset."""
+  if isinstance(obj, Dataset):
+    return obj
+  if _xr is not None and isinstance(obj, _xr.Dataset):
+    return from_xarray(obj)
+  raise TypeError(f'expected a Dataset, got {type(obj)}')
