@@ -67,7 +67,8 @@ const char* wb2_last_error(void);
  * them always, but without NaNs they are data independent: metrics.py:161-163). */
 int wb2_num_slots(int mode, int skipna);
 
-/* Columns one workgroup covers; n_ctile = ceil(n_col / wb2_tile_cols(...)). */
+/* Columns one wavefront covers (64 lanes x 16-byte vectors when n_col and the
+ * base pointers allow it); n_ctile = ceil(n_col / wb2_tile_cols(...)). */
 int wb2_tile_cols(int dtype, int n_col, int aligned16);
 
 /*
@@ -81,7 +82,8 @@ int wb2_tile_cols(int dtype, int n_col, int aligned16);
  *                   be gathered by valid time without a copy (metrics.py:398-404,
  *                   evaluation.py:474-475)
  *  w_row       DEV  double[n_row]  > 0   (latitude weights when rows = lat, else 1)
- *  w_col       DEV  double[n_col]  > 0   (latitude weights when cols = lat, else 1)
+ *  w_col       DEV  double[n_col]  > 0   (latitude weights when cols = lat) or NULL
+ *                   when every column weight is 1 (rows = lat)
  *  wfield      DEV  double[n_row*n_col] or NULL: a 2-D weight factor such as the
  *                   land-sea mask (regions.py:112-138); points with wfield <= 0
  *                   are excluded (metrics.py:159-160).

@@ -65,7 +65,8 @@ class Wb2HipError(RuntimeError):
 
 
 def lib_path() -> str:
-  return _build.LIB_PATH
+  # WB2HIP_LIB selects an alternative build (kernel-tuning sweeps only).
+  return os.environ.get('WB2HIP_LIB') or _build.LIB_PATH
 
 
 def load():

@@ -36,6 +36,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Deterministic 64-lane butterfly sum; every lane gets the result.
+__device__ __forceinline__ double wave_allsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
 __device__ __forceinline__ bool is_nan(float x) { return x != x; }
 __device__ __forceinline__ bool is_nan(double x) { return x != x; }
 __device__ __forceinline__ float abs_of(float x) { return __builtin_fabsf(x); }

@@ -120,14 +120,34 @@ __device__ __forceinline__ void eval_slots(
   }
 }
 
+// Tuning knobs (defaults are the measured best; see DESIGN.md / profiles/).
+#ifndef WB2_U_ROWS
+#define WB2_U_ROWS 2
+#endif
+#ifndef WB2_NT_LOADS
+#define WB2_NT_LOADS 1
+#endif
+#ifndef WB2_DIAG
+#define WB2_DIAG 0  // 1: skip the fold/store epilogue, 2: trivial arithmetic
+#endif
+#ifndef WB2_MIN_WAVES
+#define WB2_MIN_WAVES 1
+#endif
+
+#if WB2_NT_LOADS
+#define WB2_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define WB2_LOAD(ptr) (*(ptr))
+#endif
+
 template <typename T, int VEC>
 __device__ __forceinline__ void load_vec(const T* __restrict__ p,
                                          T (&v)[VEC]) {
   if constexpr (VEC == 1) {
-    v[0] = __builtin_nontemporal_load(p);
+    v[0] = WB2_LOAD(p);
   } else {
     typedef T V __attribute__((ext_vector_type(VEC)));
-    const V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    const V x = WB2_LOAD(reinterpret_cast<const V*>(p));
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = x[e];
   }
@@ -141,28 +161,51 @@ __device__ __forceinline__ void load_wf(const double* __restrict__ p,
   for (int e = 0; e < VEC; ++e) v[e] = p[e];
 }
 
+// Geometry: blockIdx.x = tile_block * n_chunk + chunk (n_chunk % 8 == 0, so a
+// chunk always lands on XCD chunk % 8), blockIdx.y/z = outer slab.  Every WAVE
+// of the workgroup owns one column tile of 64*VEC columns and is completely
+// independent of the others (no LDS, no barrier): waves stream, then fold their
+// own columns into the segs that intersect their tile with a wave64 butterfly.
+//
 // Rows of one chunk are processed U at a time so that U*NIN 16-byte loads per
-// lane are in flight before the first one is consumed.
+// lane are in flight before the first one is consumed.  The prologue is written
+// branch-free on purpose: every scalar (table / slab-index) load is issued
+// before the first wait, instead of one dependent round trip per table.
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, WB2_MIN_WAVES)
     stream_partials_kernel(const StreamParams p) {
   using M = ModeTraits<MODE, SKIPNA>;
   constexpr int NIN = M::NIN, K = M::K, NWF = WF ? 2 : 1;
-  constexpr int U = (sizeof(T) * VEC >= 16) ? (NIN >= 4 ? 2 : 4) : 8;
-  constexpr int KB = K >= 2 ? 2 : 1;  // slots staged through LDS per pass
+  constexpr int U =
+      (sizeof(T) * VEC >= 16) ? (NIN >= 4 ? WB2_U_ROWS / 2 : WB2_U_ROWS) : 8;
+  constexpr int TILE = kWave * VEC;
 
-  const int tid = threadIdx.x;
-  const long long oc = blockIdx.x;
-  const int chunk = (int)(oc % p.n_chunk);
-  const long long o = oc / p.n_chunk;
-  const int ct = blockIdx.y;
-  const int tile_cols = blockDim.x * VEC;
-  const int tile_col0 = ct * tile_cols;
-  const int col0 = tile_col0 + tid * VEC;
-  const bool active = col0 < p.n_col;
+  const int lane = threadIdx.x & (kWave - 1);
+  // readfirstlane: tell the compiler the wave index is wave-uniform (SGPR).
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int nwave = blockDim.x / kWave;
+  const unsigned bx = blockIdx.x;
+  const unsigned tblk = bx / (unsigned)p.n_chunk;
+  const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
+  const long long o = (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  const int tile = (int)tblk * nwave + wave;
+
+  // ---- branch-free prologue: issue every scalar load before any wait ----
   const int row0 = p.chunk_row0[chunk];
   const int nrow = p.chunk_nrow[chunk];
-  if (nrow <= 0) return;  // padding chunk (uniform for the whole workgroup)
+  long long slab_idx[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    // Identity when no table is given; the dummy read keeps the load
+    // unconditional (chunk tables are >= 8 ints, i.e. >= 4 readable int64).
+    const long long* tab =
+        p.slab[i] ? p.slab[i] : reinterpret_cast<const long long*>(p.chunk_row0);
+    const long long v = tab[p.slab[i] ? o : 0];
+    slab_idx[i] = p.slab[i] ? v : o;
+  }
+  const int col0 = tile * TILE + lane * VEC;
+  const bool active = tile < p.n_ctile && col0 < p.n_col;
+  if (nrow <= 0 || tile >= p.n_ctile) return;  // wave-uniform
 
   double acc[NWF][VEC][K];
 #pragma unroll
@@ -176,11 +219,9 @@ __global__ void __launch_bounds__(512)
     const long long slab_elems = (long long)p.n_row * p.n_col;
     const T* base[NIN];
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) {
-      const long long s = p.slab[i] ? p.slab[i][o] : o;
-      base[i] = static_cast<const T*>(p.in[i]) + s * slab_elems +
+    for (int i = 0; i < NIN; ++i)
+      base[i] = static_cast<const T*>(p.in[i]) + slab_idx[i] * slab_elems +
                 (long long)row0 * p.n_col + col0;
-    }
     const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + col0
                            : nullptr;
     const double* wrp = p.w_row + row0;
@@ -193,10 +234,17 @@ __global__ void __launch_bounds__(512)
 #pragma unroll
         for (int i = 0; i < NIN; ++i) in[i] = v[i][e];
         double x[K];
+#if WB2_DIAG == 2
+        for (int k = 0; k < K; ++k) x[k] = 0.0;
+        T sdiag = 0;
+        for (int i = 0; i < NIN; ++i) sdiag += in[i];
+        acc[0][e][0] += (double)sdiag;
+#else
         eval_slots<MODE, SKIPNA, T>(in, x);
 #pragma unroll
         for (int k = 0; k < K; ++k)
           acc[0][e][k] = __builtin_fma(wr, x[k], acc[0][e][k]);
+#endif
         if constexpr (WF) {
           // metrics.py:159-160: values where the weight is not > 0 become 0.
           const bool inside = wf[e] > 0.0;
@@ -210,6 +258,7 @@ __global__ void __launch_bounds__(512)
     };
 
     int r = 0;
+#pragma clang loop unroll(disable)
     for (; r + U <= nrow; r += U) {
       T v[U][NIN][VEC];
       double wf[U][VEC];
@@ -227,9 +276,13 @@ __global__ void __launch_bounds__(512)
         }
         wr[u] = wrp[r + u];
       }
+      // Keep every load of the batch in flight before the first use: without
+      // this hipcc sinks half of them below the arithmetic (register heuristics).
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) consume(v[u], wf[u], wr[u]);
     }
+#pragma clang loop unroll(disable)
     for (; r < nrow; ++r) {
       T v[NIN][VEC];
       double wf[VEC];
@@ -244,47 +297,55 @@ __global__ void __launch_bounds__(512)
       }
       consume(v, wf, wrp[r]);
     }
+    if (p.w_col) {  // only when columns are latitudes (lon-lat layout)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const double wc = p.w_col[col0 + e];
+#pragma unroll
+        for (int w = 0; w < NWF; ++w)
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[w][e][k] *= wc;
+      }
+    }
   }
 
-  // ---- fold owned columns into segs: LDS staging + wave64 shuffle tree ----
-  extern __shared__ double sdata[];  // [KB][tile_cols]
-  const int lane = tid & (kWave - 1), wave = tid / kWave,
-            nwave = blockDim.x / kWave;
-  double wcol[VEC];
+  // ---- fold owned columns into the segs intersecting this wave's tile ----
+#if WB2_DIAG == 1
+  if (acc[0][0][0] == 1.2345) p.partials[0] = acc[0][0][0] + acc[0][VEC - 1][K - 1];
+  return;
+#endif
+  const int tile_c0 = tile * TILE;
+  const int tile_c1 = min(tile_c0 + TILE, p.n_col);
+  int s_lo = 0;
+  while (p.seg_col0[s_lo + 1] <= tile_c0) ++s_lo;
+  int s_hi = s_lo;
+  while (s_hi + 1 < p.n_seg && p.seg_col0[s_hi + 1] < tile_c1) ++s_hi;
+  const long long item = (o * p.n_chunk + chunk) * p.n_ctile + tile;
+  double* out = p.partials + item * (long long)(NWF * p.n_seg * K);
+  for (int idx = lane; idx < NWF * p.n_seg * K; idx += kWave) {
+    const int s = (idx / K) % p.n_seg;
+    if (s < s_lo || s > s_hi) out[idx] = 0.0;
+  }
+  for (int s = s_lo; s <= s_hi; ++s) {
+    const int c0 = p.seg_col0[s], c1 = p.seg_col0[s + 1];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) wcol[e] = active ? p.w_col[col0 + e] : 0.0;
-  double* out = p.partials +
-                ((oc * p.n_ctile + ct) * NWF) * (long long)p.n_seg * K;
+    for (int w = 0; w < NWF; ++w) {
+      double v[K];
 #pragma unroll
-  for (int w = 0; w < NWF; ++w) {
+      for (int k = 0; k < K; ++k) v[k] = 0.0;
 #pragma unroll
-    for (int k0 = 0; k0 < K; k0 += KB) {
-      __syncthreads();
+      for (int e = 0; e < VEC; ++e) {
+        const bool in_seg = (col0 + e >= c0) && (col0 + e < c1);
 #pragma unroll
-      for (int kk = 0; kk < KB; ++kk) {
-        if (k0 + kk < K) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            sdata[kk * tile_cols + tid * VEC + e] =
-                active ? acc[w][e][k0 + kk] * wcol[e] : 0.0;
-        }
+        for (int k = 0; k < K; ++k) v[k] += in_seg ? acc[w][e][k] : 0.0;
       }
-      __syncthreads();
-      for (int s = wave; s < p.n_seg; s += nwave) {
-        int a = p.seg_col0[s] - tile_col0, b = p.seg_col0[s + 1] - tile_col0;
-        a = a < 0 ? 0 : a;
-        b = b > tile_cols ? tile_cols : b;
+      double mine = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-          if (k0 + kk < K) {
-            double v = 0.0;
-            for (int i = a + lane; i < b; i += kWave)
-              v += sdata[kk * tile_cols + i];
-            v = wave_sum(v);
-            if (lane == 0) out[((long long)w * p.n_seg + s) * K + k0 + kk] = v;
-          }
-        }
+      for (int k = 0; k < K; ++k) {
+        const double tot = wave_allsum(v[k]);
+        mine = (lane == k) ? tot : mine;
       }
+      if (lane < K) out[((long long)w * p.n_seg + s) * K + lane] = mine;
     }
   }
 }
@@ -405,12 +466,15 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
 int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
-  constexpr int K = ModeTraits<MODE, SKIPNA>::K;
-  constexpr int KB = K >= 2 ? 2 : 1;
-  const size_t lds = (size_t)KB * threads * VEC * sizeof(double);
-  const dim3 grid((unsigned)(p.n_outer * p.n_chunk), (unsigned)p.n_ctile);
+  const int nwave = threads / kWave;
+  const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
+  const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
+  const long long gz = (p.n_outer + gy - 1) / gy;
+  if (gy * gz != p.n_outer)
+    return fail("n_outer=%lld is not a multiple of 32768", p.n_outer);
+  const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
   hipLaunchKernelGGL((stream_partials_kernel<T, VEC, MODE, SKIPNA, WF>), grid,
-                     dim3(threads), lds, stream, p);
+                     dim3(threads), 0, stream, p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -448,6 +512,7 @@ int vec_width(int dtype, int n_col, bool aligned16) {
   return (aligned16 && n_col % w == 0) ? w : 1;
 }
 
+// One wave per column tile; up to 8 tiles share a workgroup.
 int threads_for(int n_col, int vec) {
   const int lanes = (n_col + vec - 1) / vec;
   int threads = ((lanes + kWave - 1) / kWave) * kWave;
@@ -474,8 +539,7 @@ int wb2_num_slots(int mode, int skipna) {
 
 int wb2_tile_cols(int dtype, int n_col, int aligned16) {
   if (dtype != WB2_F32 && dtype != WB2_F64) return wb2::fail("bad dtype");
-  const int vec = wb2::vec_width(dtype, n_col, aligned16 != 0);
-  return wb2::threads_for(n_col, vec) * vec;
+  return wb2::kWave * wb2::vec_width(dtype, n_col, aligned16 != 0);
 }
 
 int wb2_stream_partials(int mode, int dtype, int skipna,
@@ -489,17 +553,17 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
   using namespace wb2;
   WB2_REQUIRE(mode >= 0 && mode <= 2, "unknown mode %d", mode);
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
-  WB2_REQUIRE(in && w_row && w_col && chunk_row0 && chunk_nrow && seg_col0 &&
-                  partials,
+  WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && partials,
               "null pointer argument");
   WB2_REQUIRE(n_outer >= 0 && n_row > 0 && n_col > 0 && n_chunk > 0 &&
                   n_seg > 0,
               "bad sizes: n_outer=%lld n_row=%d n_col=%d n_chunk=%d n_seg=%d",
               (long long)n_outer, n_row, n_col, n_chunk, n_seg);
   if (n_outer == 0) return 0;
-  WB2_REQUIRE(n_outer * (int64_t)n_chunk < (1ll << 31),
-              "grid too large: n_outer*n_chunk=%lld",
-              (long long)(n_outer * n_chunk));
+  WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
+  WB2_REQUIRE(n_outer < 32768 || n_outer % 32768 == 0,
+              "n_outer=%lld: above 32767 slabs n_outer must be a multiple of "
+              "32768 (split the call)", (long long)n_outer);
   StreamParams p{};
   const int nin = mode_nin(mode);
   bool aligned = true;
@@ -523,7 +587,7 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
   p.n_row = n_row;
   p.n_col = n_col;
   p.n_chunk = n_chunk;
-  p.n_ctile = (n_col + threads * vec - 1) / (threads * vec);
+  p.n_ctile = (n_col + kWave * vec - 1) / (kWave * vec);
   WB2_REQUIRE(p.n_ctile == n_ctile,
               "n_ctile=%d does not match the launch geometry (%d): inputs "
               "must be 16-byte aligned iff wb2_tile_cols() was asked so",

@@ -83,7 +83,7 @@ class ReductionPlan:
   # device tables (torch, on `device`)
   device: torch.device = None
   w_row: torch.Tensor = None
-  w_col: torch.Tensor = None
+  w_col: t.Optional[torch.Tensor] = None  # None = all ones
   wfield: t.Optional[torch.Tensor] = None
   chunk_row0: torch.Tensor = None
   chunk_nrow: torch.Tensor = None
@@ -180,6 +180,8 @@ def build_plan(latitude: np.ndarray, longitude: np.ndarray, layout: str,
       wsum[i] = np.einsum('i,ij,j->', wl, s.field, s.lon_mult.astype(float))
 
   dev = torch.device(device)
+  if dev.type == 'cuda' and dev.index is None:
+    dev = torch.device('cuda', torch.cuda.current_device())
 
   def up(a, dtype):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
@@ -190,7 +192,8 @@ def build_plan(latitude: np.ndarray, longitude: np.ndarray, layout: str,
       chunk_row0_host=np.array(chunk_row0, dtype=np.int32),
       chunk_nrow_host=np.array(chunk_nrow, dtype=np.int32),
       region_wsum_host=wsum, device=dev,
-      w_row=up(w_row, torch.float64), w_col=up(w_col, torch.float64),
+      w_row=up(w_row, torch.float64),
+      w_col=None if layout == LATLON else up(w_col, torch.float64),
       wfield=None if field_rc is None else up(field_rc, torch.float64),
       chunk_row0=up(chunk_row0, torch.int32),
       chunk_nrow=up(chunk_nrow, torch.int32),
