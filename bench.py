@@ -66,7 +66,7 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict:
   from oracle import metrics_np as om
   from oracle.named import DS, NA
   from tests import helpers
-  n_lev = 1
+  n_lev = N_LEV
   rs = np.random.RandomState(0)
   lat = np.linspace(-90, 90, N_LAT)
   lon = np.linspace(0, 360, N_LON, endpoint=False)
@@ -96,7 +96,7 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict:
       'value': n_lev * N_LAT * N_LON / full, 'unit': 'grid-point-evals/s',
       'cores': 1, 'kind': 'port',
       'sample': (f'NumPy oracle (xarray-semantics restatement; the reference '
-                 f'itself needs xarray, absent here), 1 process, 1 level x '
+                 f'itself needs xarray, absent here), 1 process, {n_lev} levels x '
                  f'721 x 1440 f32, 5 metrics x {done}/{len(regions)} regions '
                  f'timed in {dt:.1f} s, scaled to all regions; host has '
                  f'{os.cpu_count()} logical cores'),

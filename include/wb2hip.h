@@ -48,6 +48,9 @@ extern "C" {
 #define WB2_MODE_DET_ACC 1  /* forecast,truth,clim   -> the above + ACC        metrics.py:377-414 */
 #define WB2_MODE_WIND 2     /* fu,tu,fv,tv           -> WindVectorMSE/RMSE     metrics.py:175-233 */
 
+#define WB2_MODE_ENS 3      /* members,truth         -> CRPS & ensemble moments  metrics.py:532-846,1161-1363
+                             * (partials come from wb2_ens_partials)              */
+
 /* number of metrics written by wb2_det_combine, in this order */
 #define WB2_NMETRIC 5
 #define WB2_METRIC_MSE 0
@@ -55,6 +58,17 @@ extern "C" {
 #define WB2_METRIC_MAE 2
 #define WB2_METRIC_BIAS 3
 #define WB2_METRIC_ACC 4
+
+/* metrics written by wb2_ens_combine, in this order */
+#define WB2_NMETRIC_ENS 8
+#define WB2_ENS_CRPS 0          /* CRPS                                metrics.py:610-675  */
+#define WB2_ENS_CRPS_SPREAD 1   /* CRPSSpread                          metrics.py:678-694  */
+#define WB2_ENS_CRPS_SKILL 2    /* CRPSSkill                           metrics.py:697-715  */
+#define WB2_ENS_MEAN_MSE 3      /* EnsembleMeanMSE                     metrics.py:1310-1333 */
+#define WB2_ENS_MEAN_RMSE 4     /* EnsembleMeanRMSESqrtBeforeTimeAvg   metrics.py:1269-1307 */
+#define WB2_ENS_VARIANCE 5      /* EnsembleVariance                    metrics.py:1213-1241 */
+#define WB2_ENS_STDDEV 6        /* EnsembleStddevSqrtBeforeTimeAvg     metrics.py:1161-1210 */
+#define WB2_ENS_DEBIASED_MSE 7  /* DebiasedEnsembleMeanMSE             metrics.py:1336-1363 */
 
 int wb2_version(void);
 const char* wb2_last_error(void);
@@ -90,7 +104,12 @@ int wb2_tile_cols(int dtype, int n_col, int aligned16);
  *  chunk_row0/chunk_nrow  DEV int32[n_chunk]: row range of each chunk (a chunk
  *                   never straddles a band boundary; nrow == 0 chunks are padding)
  *  seg_col0    DEV  int32[n_seg+1]: column range of each seg
- *  partials    DEV  double[n_outer][n_chunk][n_ctile][nwf][n_seg][K] (out),
+ *  seg_eoff    DEV  int32[n_seg+1]: prefix sum of the number of column tiles each
+ *                   seg intersects, tiles(s) = (seg_col0[s+1]-1)/T - seg_col0[s]/T + 1
+ *                   with T = wb2_tile_cols(...).  A (seg, tile) pair is one
+ *                   "entry" e = seg_eoff[s] + tile - seg_col0[s]/T; n_ts =
+ *                   seg_eoff[n_seg] entries exist per (outer, chunk, weight field).
+ *  partials    DEV  double[n_outer][n_chunk][nwf][n_ts][K] (out),
  *                   nwf = wfield ? 2 : 1, K = wb2_num_slots(mode, skipna).
  *                   Entries of padding chunks are not written.
  *  n_ctile          must equal ceil(n_col / wb2_tile_cols(dtype, n_col, a16))
@@ -105,7 +124,8 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         const double* wfield,
                         const int32_t* chunk_row0, const int32_t* chunk_nrow,
                         int32_t n_chunk, int32_t n_ctile,
-                        const int32_t* seg_col0, int32_t n_seg,
+                        const int32_t* seg_col0, const int32_t* seg_eoff,
+                        int32_t n_seg, int32_t n_ts,
                         double* partials, void* stream);
 
 /*
@@ -113,8 +133,10 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
  * Replaces the region loop + concat of evaluation.py:416-430 and the ratio /
  * sqrt epilogues of metrics.py:172, 233, 407-414.
  *
- *  band_chunk0 DEV int32[n_band+1]: chunks (before col-tiling) of band b are
+ *  band_chunk0 DEV int32[n_band+1]: chunks of band b are
  *                  [band_chunk0[b], band_chunk0[b+1])
+ *  seg_eoff    DEV int32[n_seg+1]: as above (entries of seg s are
+ *                  [seg_eoff[s], seg_eoff[s+1]))
  *  coef_band   DEV double[n_region][n_band]: multiplicity of the band's rows in
  *                  the region (0 = excluded; SliceRegion lists may repeat rows)
  *  coef_seg    DEV double[n_region][n_seg]:  same for columns
@@ -126,8 +148,49 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
  *                  For WB2_MODE_WIND only MSE and RMSE are meaningful.
  */
 int wb2_det_combine(int mode, int skipna, const double* partials,
-                    int64_t n_outer, int32_t n_chunk, int32_t n_ctile,
-                    int32_t nwf, int32_t n_seg,
+                    int64_t n_outer, int32_t n_chunk, int32_t nwf,
+                    int32_t n_seg, const int32_t* seg_eoff, int32_t n_ts,
+                    const int32_t* band_chunk0, int32_t n_band,
+                    const double* coef_band, const double* coef_seg,
+                    const int32_t* region_wf, const double* region_wsum,
+                    int32_t n_region, double* sums, double* metrics,
+                    void* stream);
+
+/*
+ * K3: fused ensemble pass.  Replaces the member mean / var(ddof=1) / abs-mean
+ * sweeps (metrics.py:562-565, 824), the argsort ranks (:827-846) and the
+ * rank-weighted sum (:804-813) with ONE read of the members: a lane keeps the M
+ * values of its grid point in registers and sorts them with a sorting network.
+ *
+ *  ens         DEV  member m, slab s starts at element
+ *                   m * member_stride + s * n_row * n_col  (member-major, e.g.
+ *                   dims (realization, ..., lat, lon) as in schema.py:113-114)
+ *  ens_slab / truth_slab  DEV int64[n_outer] or NULL (identity)
+ *  n_member         1 <= M <= 128 (float32) / 64 (float64).  M == 1 yields
+ *                   var = NaN; callers apply the reference's M == 1 special
+ *                   cases (metrics.py:1196-1204) themselves.
+ *  partials    DEV  double[n_outer][n_chunk][nwf][n_ts][K], K = wb2_ens_num_slots,
+ *                   with the column tile width wb2_ens_tile_cols() (= 64)
+ * Everything else as for wb2_stream_partials.
+ */
+int wb2_ens_num_slots(int skipna);
+int wb2_ens_tile_cols(int32_t n_col);
+int wb2_ens_partials(int dtype, int skipna, const void* ens,
+                     const int64_t* ens_slab, const void* truth,
+                     const int64_t* truth_slab, int32_t n_member,
+                     int64_t member_stride, int64_t n_outer, int32_t n_row,
+                     int32_t n_col, const double* w_row, const double* w_col,
+                     const double* wfield, const int32_t* chunk_row0,
+                     const int32_t* chunk_nrow, int32_t n_chunk,
+                     int32_t n_ctile, const int32_t* seg_col0,
+                     const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
+                     double* partials, void* stream);
+
+/* Region fold + finalisation for the ensemble pass (same tables as
+ * wb2_det_combine); metrics is double[WB2_NMETRIC_ENS][n_region][n_outer]. */
+int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,
+                    int32_t n_chunk, int32_t nwf, int32_t n_seg,
+                    const int32_t* seg_eoff, int32_t n_ts,
                     const int32_t* band_chunk0, int32_t n_band,
                     const double* coef_band, const double* coef_seg,
                     const int32_t* region_wf, const double* region_wsum,

@@ -1,0 +1,185 @@
+"""GPU parity: fused ensemble kernel vs the NumPy oracle (run with -m gpu)."""
+import numpy as np
+import pytest
+
+from oracle import fixtures
+from oracle import metrics_np as om
+from oracle import regions_np as oreg
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = [('CRPS', 'CRPS'), ('CRPSSpread', 'CRPSSpread'),
+         ('CRPSSkill', 'CRPSSkill'),
+         ('EnsembleMeanMSE', 'EnsembleMeanMSE'),
+         ('EnsembleMeanRMSESqrtBeforeTimeAvg',
+          'EnsembleMeanRMSESqrtBeforeTimeAvg'),
+         ('EnsembleVariance', 'EnsembleVariance'),
+         ('EnsembleStddevSqrtBeforeTimeAvg',
+          'EnsembleStddevSqrtBeforeTimeAvg'),
+         ('DebiasedEnsembleMeanMSE', 'DebiasedEnsembleMeanMSE')]
+
+
+@pytest.fixture(scope='module')
+def gm():
+  import torch
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device')
+  from weatherbench2_amd import metrics as gm
+  return gm
+
+
+def _cast(ds, dtype):
+  return ds.copy(data={k: v.data.astype(dtype) for k, v in ds.items()})
+
+
+@pytest.mark.parametrize('ensemble_size', [1, 2, 3, 5, 7, 10, 50, 100])
+def test_all_ensemble_metrics_match_oracle(gm, ensemble_size):
+  """get_random_truth_and_forecast (metrics_test.py:28-58) at float32."""
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, lead_stop='2 day')
+  truth, forecast = _cast(truth, np.float32), _cast(forecast, np.float32)
+  g = helpers.to_gpu_dataset
+  regions = {'global': None, 'xt': oreg.ExtraTropicalRegion(),
+             'box': oreg.SliceRegion(lat_slice=slice(-30, 60),
+                                     lon_slice=slice(30, 200))}
+  g_regions = {k: helpers.to_gpu_region(v) for k, v in regions.items()}
+  with gm.fused_regions(g_regions):
+    for oname, gname in PAIRS:
+      for rname, region in regions.items():
+        want = getattr(om, oname)().compute_chunk(forecast, truth,
+                                                  region=region)
+        got = getattr(gm, gname)().compute_chunk(g(forecast), g(truth),
+                                                 region=g_regions[rname])
+        assert got['geopotential'].dims == want['geopotential'].dims
+        # float32 member statistics: identical op order => ~1e-7; the contract
+        # is 1e-5 relative.
+        helpers.assert_close(got['geopotential'].values,
+                             want['geopotential'].data, rtol=2e-6, atol=1e-7,
+                             err_msg=f'{oname}/{rname}/M={ensemble_size}')
+
+
+@pytest.mark.parametrize('ensemble_size', [2, 5])
+def test_crps_vs_brute_force_float64(gm, ensemble_size):
+  # metrics_test.py:192-206, float64 inputs as in the reference test
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size)
+  expected = om.crps_brute_force(forecast, truth, skipna=False)['score']
+  g = helpers.to_gpu_dataset
+  got = gm.CRPS().compute_chunk(g(forecast), g(truth))
+  helpers.assert_close(got['geopotential'].values,
+                       expected['geopotential'].data, rtol=1e-9, atol=1e-12)
+  assert gm.CRPS().compute(g(forecast), g(truth)).attrs['ensemble_size'] == (
+      ensemble_size)
+
+
+@pytest.mark.parametrize('skipna', [True, False])
+def test_nan_forecasts(gm, skipna):
+  # metrics_test.py:230-267 (+ every ensemble metric vs the oracle)
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      variables=['geopotential', 'temperature'], ensemble_size=7)
+  new_values = forecast['geopotential'].data.copy()
+  new_values[(0,) * new_values.ndim] = np.nan
+  forecast = forecast.copy(data={'geopotential': new_values,
+                                 'temperature': forecast['temperature'].data})
+  g = helpers.to_gpu_dataset
+  crps = gm.CRPS().compute_chunk(g(forecast), g(truth), skipna=skipna)
+  score = crps['geopotential'].values.copy()
+  assert np.isnan(score[0, 0, 0]) != skipna
+  score[0, 0, 0] = 0
+  assert np.all(np.isfinite(score))
+  assert np.all(np.isfinite(crps['temperature'].values))
+  for oname, gname in PAIRS:
+    want = getattr(om, oname)().compute_chunk(forecast, truth, skipna=skipna)
+    got = getattr(gm, gname)().compute_chunk(g(forecast), g(truth),
+                                             skipna=skipna)
+    for var in ('geopotential', 'temperature'):
+      helpers.assert_close(got[var].values, want[var].data, rtol=1e-9,
+                           atol=1e-12, err_msg=f'{oname}/{var}')
+
+
+def test_scattered_nans_skipna(gm):
+  truth, forecast = fixtures.get_random_truth_and_forecast(ensemble_size=5)
+  forecast = fixtures.insert_nan(forecast, 0.3, seed=3)
+  truth = fixtures.insert_nan(truth, 0.05, seed=4)
+  g = helpers.to_gpu_dataset
+  for oname, gname in PAIRS:
+    want = getattr(om, oname)().compute_chunk(forecast, truth, skipna=True)
+    got = getattr(gm, gname)().compute_chunk(g(forecast), g(truth),
+                                             skipna=True)
+    helpers.assert_close(got['geopotential'].values,
+                         want['geopotential'].data, rtol=1e-9, atol=1e-12,
+                         err_msg=oname)
+
+
+def test_repeated_members_and_missing_dim(gm):
+  # metrics_test.py:269-281 and metrics.py:574-581
+  truth, forecast = fixtures.get_random_truth_and_forecast(ensemble_size=7)
+  vals = forecast['geopotential'].data.copy()
+  vals[0] = vals[1]
+  forecast = forecast.copy(data={'geopotential': vals})
+  g = helpers.to_gpu_dataset
+  got = gm.CRPS().compute_chunk(g(forecast), g(truth))
+  want = om.crps_brute_force(forecast, truth, skipna=False)['score']
+  helpers.assert_close(got['geopotential'].values, want['geopotential'].data,
+                       rtol=1e-9)
+  with pytest.raises(ValueError):
+    gm.CRPS(ensemble_dim='number').compute_chunk(g(forecast), g(truth))
+
+
+def test_ensemble_dim_not_leading(gm):
+  """Members in the middle of the dims: handled by slab tables, no copy."""
+  from oracle.named import DS
+  truth, forecast = fixtures.get_random_truth_and_forecast(ensemble_size=4)
+  v = forecast['geopotential']
+  dims = ('prediction_timedelta', 'realization', 'time', 'level', 'longitude',
+          'latitude')
+  moved = DS({'geopotential': v.transpose(*dims).copy(
+      data=np.ascontiguousarray(v.transpose(*dims).data))}, forecast.coords)
+  g = helpers.to_gpu_dataset
+  got = gm.CRPS().compute_chunk(g(moved), g(truth))
+  want = om.CRPS().compute_chunk(forecast, truth)
+  helpers.assert_close(got['geopotential'].values, want['geopotential'].data,
+                       rtol=1e-9)
+
+
+def test_quarter_degree_50_members_properties():
+  """BASELINE config 3 shape (721x1440, 50 members, one level): torch check."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  dev = torch.device('cuda')
+  n_lat, n_lon, m = 721, 1440, 50
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON,
+                           helpers.predefined_regions(oracle=False), dev)
+  gen = torch.Generator(device=dev).manual_seed(7)
+  x = torch.randn((m, 2, n_lat, n_lon), generator=gen, device=dev)
+  t = torch.randn((2, n_lat, n_lon), generator=gen, device=dev)
+  m1, s1 = engine.ensemble_reduce(pl, x, 2 * n_lat * n_lon, m, None, t, None,
+                                  2, False, True)
+  m2, s2 = engine.ensemble_reduce(pl, x, 2 * n_lat * n_lon, m, None, t, None,
+                                  2, False, True)
+  assert torch.equal(m1, m2) and torch.equal(s1, s2)
+  w = torch.as_tensor(pl.w_lat, device=dev)[None, :, None]
+  den = w.sum() * n_lon
+  sa = lambda f: (f.double() * w).sum((1, 2)) / den
+  xs = torch.sort(x, dim=0).values
+  coef = (2 * torch.arange(1, m + 1, device=dev) - m - 1).double()
+  spread = 2 * (xs.double() * coef[:, None, None, None]).mean(0) / (m - 1)
+  skill = (t[None] - x).abs().mean(0)
+  gi = pl.region_names.index('global')
+  idx = _lib.ENS_METRIC_INDEX
+  torch.testing.assert_close(m1[idx['crps_spread'], gi], sa(spread),
+                             rtol=1e-10, atol=0)
+  torch.testing.assert_close(m1[idx['crps_skill'], gi], sa(skill), rtol=1e-6,
+                             atol=0)
+  torch.testing.assert_close(m1[idx['ensemble_variance'], gi],
+                             sa(x.var(0, unbiased=True)), rtol=1e-6, atol=0)
+  torch.testing.assert_close(m1[idx['ensemble_mean_mse'], gi],
+                             sa((t - x.mean(0)) ** 2), rtol=1e-6, atol=0)
+  # permutation invariance of the members (sort-based spread is exact)
+  perm = torch.randperm(m, device=dev)
+  m3, _ = engine.ensemble_reduce(pl, x[perm].contiguous(), 2 * n_lat * n_lon,
+                                 m, None, t, None, 2, False)
+  assert torch.equal(m3[idx['crps_spread']], m1[idx['crps_spread']])

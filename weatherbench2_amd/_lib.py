@@ -18,7 +18,12 @@ from weatherbench2_amd import build as _build
 WB2_F32, WB2_F64 = 0, 1
 MODE_DET, MODE_DET_ACC, MODE_WIND = 0, 1, 2
 NMETRIC = 5
+NMETRIC_ENS = 8
 METRIC_INDEX = {'mse': 0, 'rmse': 1, 'mae': 2, 'bias': 3, 'acc': 4}
+ENS_METRIC_INDEX = {'crps': 0, 'crps_spread': 1, 'crps_skill': 2,
+                    'ensemble_mean_mse': 3, 'ensemble_mean_rmse': 4,
+                    'ensemble_variance': 5, 'ensemble_stddev': 6,
+                    'debiased_ensemble_mean_mse': 7}
 
 _c = ctypes
 _vp, _i32, _i64, _int = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_int
@@ -30,17 +35,17 @@ _SIGNATURES = {
     'wb2_tile_cols': (_int, [_int, _int, _int]),
     'wb2_stream_partials': (_int, [
         _int, _int, _int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i32, _i32,
-        _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+        _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'wb2_det_combine': (_int, [
-        _int, _int, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
-        _vp, _vp, _i32, _vp, _vp, _vp]),
+        _int, _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp,
+        _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     'wb2_time_accumulate': (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp,
                                    _vp]),
     'wb2_ens_partials': (_int, [
-        _int, _int, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp,
-        _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+        _int, _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp,
+        _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'wb2_ens_combine': (_int, [
-        _int, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
+        _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
         _vp, _vp, _i32, _vp, _vp, _vp]),
     'wb2_ens_num_slots': (_int, [_int]),
     'wb2_ens_tile_cols': (_int, [_i32]),
@@ -52,8 +57,7 @@ _SIGNATURES = {
 }
 
 # Entry points still under construction (removed as they land).
-_PENDING = {'wb2_ens_partials', 'wb2_ens_combine', 'wb2_ens_num_slots',
-            'wb2_ens_tile_cols', 'wb2_spectrum_plan_create',
+_PENDING = {'wb2_spectrum_plan_create',
             'wb2_spectrum_plan_destroy', 'wb2_spectrum_plan_workspace',
             'wb2_zonal_spectrum'}
 

@@ -35,18 +35,36 @@ def needs_rebuild() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-  """Compiles every HIP source for gfx950 into weatherbench2_amd/libwb2hip.so."""
+  """Compiles every HIP source for gfx950 into weatherbench2_amd/libwb2hip.so.
+
+  One hipcc process per translation unit (in parallel), then one link step.
+  """
   if not force and not needs_rebuild():
     return LIB_PATH
-  cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17',
-         '-ffp-contract=off', '-fPIC', '-shared',
-         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
-         '-o', LIB_PATH] + sources()
+  import concurrent.futures
+  obj_dir = os.path.join(ROOT, 'build', 'obj')
+  os.makedirs(obj_dir, exist_ok=True)
+  flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
+           '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+  extra = os.environ.get('WB2HIP_CXXFLAGS', '').split()
+
+  def compile_one(src):
+    obj = os.path.join(obj_dir, os.path.basename(src) + '.o')
+    cmd = [_hipcc()] + flags + extra + ['-c', src, '-o', obj]
+    if verbose:
+      print('[wb2hip build]', ' '.join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return obj
+
+  with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
+    objs = list(pool.map(compile_one, sources()))
+  link = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH
+          ] + objs
   if any(s.endswith('spectrum.hip') for s in sources()):
-    cmd += ['-L/opt/rocm/lib', '-lhipfft']
+    link += ['-L/opt/rocm/lib', '-lhipfft']
   if verbose:
-    print('[wb2hip build]', ' '.join(cmd), file=sys.stderr)
-  subprocess.run(cmd, check=True)
+    print('[wb2hip build]', ' '.join(link), file=sys.stderr)
+  subprocess.run(link, check=True)
   return LIB_PATH
 
 

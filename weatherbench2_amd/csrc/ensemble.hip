@@ -1,0 +1,366 @@
+// K3 of libwb2hip.so: fused ensemble metrics.  One read of the M members (+ the
+// truth) feeds CRPS skill / spread, ensemble-mean MSE, ensemble variance,
+// stddev^2 and the debiased MSE, for every region at once.
+//
+// Replaces (reference = /root/reference/weatherbench2/metrics.py):
+//   :532-565   _debiased_ensemble_mean_mse      (mean, var(ddof=1) over members)
+//   :781-813   _pointwise_crps_spread           (argsort ranks, sum (2r-M-1) x)
+//   :816-824   _pointwise_crps_skill            (mean |t - x|)
+//   :827-846   _rank_ds / _rankdata             (the argsort + put_along_axis)
+//   :1161-1363 EnsembleStddev / Variance / MeanRMSE / MeanMSE / DebiasedMeanMSE
+// followed by the same _spatial_average (:141-163) as the deterministic path.
+//
+// One lane owns one grid point (column) of the current row and keeps its M
+// member values in VGPRs; ranks never materialise: the members are sorted with
+// a straight-line Batcher network (sort_networks.inc) and the rank-weighted sum
+// is taken in sorted order.  Member statistics are computed in the input dtype
+// in member order (numpy reduces the leading axis sequentially); the
+// rank-weighted sum is fp64 (numpy: int64 * float32 -> float64); all spatial
+// sums are fp64.
+//
+// Slots: 0 skill, 1 spread, 2 (t-mean)^2, 3 var, 4 std^2, 5 debiased
+//        [skipna: 6 n(skill,mse), 7 n(spread), 8 n(var,std^2), 9 n(debiased)]
+
+#include "common.hpp"
+#include "reduce_common.hpp"
+#include "sort_networks.inc"
+#include "wb2hip.h"
+
+#include <limits>
+
+namespace wb2 {
+namespace {
+
+struct EnsParams {
+  const void* ens;
+  const void* truth;
+  const long long* ens_slab;
+  const long long* truth_slab;
+  const double* w_row;
+  const double* w_col;
+  const double* wfield;
+  const int* chunk_row0;
+  const int* chunk_nrow;
+  const int* seg_col0;
+  const int* seg_eoff;
+  double* partials;
+  long long member_stride;
+  long long n_outer;
+  int n_member, n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
+};
+
+// v_min_f32 / v_max_f32 (NaNs never reach the network: they are replaced first
+// or the result is overridden).
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
+
+template <int NPAD, typename T>
+__device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
+#define WB2_CE(i, j)                  \
+  {                                   \
+    const T lo_ = vmin(x[i], x[j]);   \
+    const T hi_ = vmax(x[i], x[j]);   \
+    x[i] = lo_;                       \
+    x[j] = hi_;                       \
+  }
+  if constexpr (NPAD == 2) { WB2_SORT_NETWORK_2 }
+  if constexpr (NPAD == 4) { WB2_SORT_NETWORK_4 }
+  if constexpr (NPAD == 8) { WB2_SORT_NETWORK_8 }
+  if constexpr (NPAD == 16) { WB2_SORT_NETWORK_16 }
+  if constexpr (NPAD == 32) { WB2_SORT_NETWORK_32 }
+  if constexpr (NPAD == 64) { WB2_SORT_NETWORK_64 }
+  if constexpr (NPAD == 128) { WB2_SORT_NETWORK_128 }
+#undef WB2_CE
+}
+
+template <typename T>
+__device__ __forceinline__ T sqrt_of(T x);
+template <>
+__device__ __forceinline__ float sqrt_of(float x) { return __builtin_sqrtf(x); }
+template <>
+__device__ __forceinline__ double sqrt_of(double x) { return __builtin_sqrt(x); }
+
+// One grid point -> the K slot values (see header comment).  MS > 0: the member
+// count is the compile-time constant MS (exact network, no selects); MS == 0:
+// runtime M <= NPAD, slots >= M are neutralised with selects (straight-line code
+// on purpose: per-member branches wreck hipcc's register allocation).
+template <typename T, int NPAD, int MS, bool SKIPNA>
+__device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt,
+                                          double (&out)[SKIPNA ? 10 : 6]) {
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  const T inf = std::numeric_limits<T>::infinity();
+  constexpr int NM = MS > 0 ? MS : NPAD;  // slots visited
+  const int M = MS > 0 ? MS : Mrt;
+  auto live = [&](int m) { return MS > 0 ? true : m < M; };
+  T sum = 0, sk = 0;
+  int n = 0;          // valid members (SKIPNA)
+  bool bad = false;   // any NaN member (!SKIPNA)
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const bool isn = is_nan(x[m]);
+    const bool use = live(m) && (SKIPNA ? !isn : true);
+    sum += use ? x[m] : (T)0;
+    sk += use ? abs_of(t - x[m]) : (T)0;
+    n += use ? 1 : 0;
+    bad = bad || (live(m) && isn);
+  }
+  const int cnt = SKIPNA ? n : M;
+  // metrics.py:562-565 / :824 -- numpy mean / var(ddof=1) / mean(abs) over the
+  // leading (member) axis: sequential, in the input dtype (nan* variants reduce
+  // over the valid members only).
+  const T mean = sum / (T)cnt;
+  T sq = 0;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
+    const T d = x[m] - mean;
+    sq += use ? d * d : (T)0;
+  }
+  T var = sq / (T)(cnt - 1);
+  if (SKIPNA && cnt <= 1) var = nan;
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  const T deb = mse - var / (T)M;
+  T skill = sk / (T)cnt;
+  if (SKIPNA && is_nan(t)) skill = nan;
+  // metrics.py:804-813: 2 * mean_m((2 r_m - M - 1) x_m) / (M - 1) in fp64; ranks
+  // come from the FULL ensemble with NaN last (np.argsort), so sort with
+  // NaN -> +inf and weight the i-th smallest by 2(i+1) - M - 1.
+  double spread = 0.0;
+  if (M >= 2) {
+#pragma unroll
+    for (int m = 0; m < NPAD; ++m) {
+      if (m >= NM) {
+        x[m] = inf;
+      } else {
+        x[m] = (!live(m) || (SKIPNA && is_nan(x[m]))) ? inf : x[m];
+      }
+    }
+    sort_network<NPAD>(x);
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const bool use = SKIPNA ? m < n : live(m);
+      s = __builtin_fma((double)(2 * (m + 1) - M - 1), use ? (double)x[m] : 0.0,
+                        s);
+    }
+    spread = 2.0 * (s / (double)cnt) / (double)(M - 1);
+    if (!SKIPNA && bad) spread = (double)nan;  // a NaN member poisons the mean
+  }
+  if constexpr (!SKIPNA) {
+    out[0] = (double)skill;
+    out[1] = spread;
+    out[2] = (double)mse;
+    out[3] = (double)var;
+    out[4] = (double)(sd * sd);
+    out[5] = (double)deb;
+  } else {
+    const bool ok_skill = !is_nan(skill), ok_spread = !is_nan(spread),
+               ok_mse = !is_nan(mse), ok_var = !is_nan(var),
+               ok_deb = !is_nan(deb);
+    out[0] = ok_skill ? (double)skill : 0.0;
+    out[1] = ok_spread ? spread : 0.0;
+    out[2] = ok_mse ? (double)mse : 0.0;
+    out[3] = ok_var ? (double)var : 0.0;
+    out[4] = ok_var ? (double)(sd * sd) : 0.0;
+    out[5] = ok_deb ? (double)deb : 0.0;
+    out[6] = ok_skill ? 1.0 : 0.0;  // == ok_mse (same NaN pattern)
+    out[7] = ok_spread ? 1.0 : 0.0;
+    out[8] = ok_var ? 1.0 : 0.0;
+    out[9] = ok_deb ? 1.0 : 0.0;
+  }
+}
+
+template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
+__global__ void __launch_bounds__(256)
+    ens_partials_kernel(const EnsParams p) {
+  constexpr int K = SKIPNA ? 10 : 6, NWF = WF ? 2 : 1;
+  constexpr int NM = MS > 0 ? MS : NPAD;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int nwave = blockDim.x / kWave;
+  const unsigned bx = blockIdx.x;
+  const unsigned tblk = bx / (unsigned)p.n_chunk;
+  const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
+  const long long o = (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  const int tile = (int)tblk * nwave + wave;
+
+  const int row0 = p.chunk_row0[chunk];
+  const int nrow = p.chunk_nrow[chunk];
+  const long long* dummy = reinterpret_cast<const long long*>(p.chunk_row0);
+  const long long es_v = (p.ens_slab ? p.ens_slab : dummy)[p.ens_slab ? o : 0];
+  const long long ts_v =
+      (p.truth_slab ? p.truth_slab : dummy)[p.truth_slab ? o : 0];
+  const long long es = p.ens_slab ? es_v : o, ts = p.truth_slab ? ts_v : o;
+  const int col0 = tile * kWave + lane;
+  const bool active = tile < p.n_ctile && col0 < p.n_col;
+  if (nrow <= 0 || tile >= p.n_ctile) return;
+  const int M = MS > 0 ? MS : p.n_member;
+
+  double acc[NWF][1][K];
+#pragma unroll
+  for (int w = 0; w < NWF; ++w)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[w][0][k] = 0.0;
+
+  if (active) {
+    const long long slab_elems = (long long)p.n_row * p.n_col;
+    const T* xb = static_cast<const T*>(p.ens) + es * slab_elems +
+                  (long long)row0 * p.n_col + col0;
+    const T* tb = static_cast<const T*>(p.truth) + ts * slab_elems +
+                  (long long)row0 * p.n_col + col0;
+    const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + col0
+                           : nullptr;
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < nrow; ++r) {
+      T x[NPAD];
+      const long long off = (long long)r * p.n_col;
+#pragma unroll
+      for (int m = 0; m < NPAD; ++m) {
+        if (m < NM) {
+          // runtime M: slots >= M re-read the last member (cache hit, ignored)
+          const int mm = MS > 0 ? m : (m < M ? m : M - 1);
+          x[m] = __builtin_nontemporal_load(xb + mm * p.member_stride + off);
+        } else {
+          x[m] = (T)0;
+        }
+      }
+      const T t = __builtin_nontemporal_load(tb + off);
+      const double wr = p.w_row[row0 + r];
+      double wf = 1.0;
+      if constexpr (WF) wf = wfp[off];
+      __builtin_amdgcn_sched_barrier(0);
+      double v[K];
+      ens_point<T, NPAD, MS, SKIPNA>(x, t, M, v);
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        acc[0][0][k] = __builtin_fma(wr, v[k], acc[0][0][k]);
+      if constexpr (WF) {
+        const bool inside = wf > 0.0;
+        const double w2 = inside ? wr * wf : 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          acc[1][0][k] = __builtin_fma(w2, inside ? v[k] : 0.0, acc[1][0][k]);
+      }
+    }
+    if (p.w_col) {
+      const double wc = p.w_col[col0];
+#pragma unroll
+      for (int w = 0; w < NWF; ++w)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[w][0][k] *= wc;
+    }
+  }
+  fold_tile_to_segs<NWF, 1, K>(
+      acc, lane, tile, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg, p.n_ts,
+      p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
+}
+
+template <typename T, int NPAD, int MS>
+int launch_ens(const EnsParams& p, bool skipna, bool wf, hipStream_t stream) {
+  int nwave = p.n_ctile < 4 ? p.n_ctile : 4;
+  const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
+  const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
+  const long long gz = (p.n_outer + gy - 1) / gy;
+  const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
+  const dim3 block(nwave * kWave);
+#define WB2_L(S, W)                                                            \
+  hipLaunchKernelGGL((ens_partials_kernel<T, NPAD, MS, S, W>), grid, block, 0, \
+                     stream, p)
+  if (skipna) {
+    if (wf) WB2_L(true, true); else WB2_L(true, false);
+  } else {
+    if (wf) WB2_L(false, true); else WB2_L(false, false);
+  }
+#undef WB2_L
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_ens_npad(const EnsParams& p, bool skipna, bool wf,
+                    hipStream_t stream) {
+  const int m = p.n_member;
+  // exact-size kernel for the operational ensemble size (IFS ENS: 50 members)
+  if (m == 50) return launch_ens<T, 64, 50>(p, skipna, wf, stream);
+  if (m <= 4) return launch_ens<T, 4, 0>(p, skipna, wf, stream);
+  if (m <= 16) return launch_ens<T, 16, 0>(p, skipna, wf, stream);
+  if (m <= 32) return launch_ens<T, 32, 0>(p, skipna, wf, stream);
+  if (m <= 64) return launch_ens<T, 64, 0>(p, skipna, wf, stream);
+  if constexpr (sizeof(T) == 4) {
+    if (m <= 128) return launch_ens<T, 128, 0>(p, skipna, wf, stream);
+  }
+  return fail("n_member=%d is not supported by the register sort (max 128 for "
+              "float32, 64 for float64)", m);
+}
+
+}  // namespace
+}  // namespace wb2
+
+extern "C" {
+
+int wb2_ens_num_slots(int skipna) { return skipna ? 10 : 6; }
+
+int wb2_ens_tile_cols(int32_t n_col) {
+  (void)n_col;
+  return wb2::kWave;
+}
+
+int wb2_ens_partials(int dtype, int skipna, const void* ens,
+                     const int64_t* ens_slab, const void* truth,
+                     const int64_t* truth_slab, int32_t n_member,
+                     int64_t member_stride, int64_t n_outer, int32_t n_row,
+                     int32_t n_col, const double* w_row, const double* w_col,
+                     const double* wfield, const int32_t* chunk_row0,
+                     const int32_t* chunk_nrow, int32_t n_chunk,
+                     int32_t n_ctile, const int32_t* seg_col0,
+                     const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
+                     double* partials, void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE(ens && truth && w_row && chunk_row0 && chunk_nrow && seg_col0 &&
+                  seg_eoff && partials,
+              "null pointer argument");
+  WB2_REQUIRE(n_member >= 1, "n_member=%d", n_member);
+  WB2_REQUIRE(n_outer >= 0 && n_row > 0 && n_col > 0 && n_chunk > 0 &&
+                  n_seg > 0 && n_ts >= n_seg,
+              "bad sizes");
+  WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
+  WB2_REQUIRE(n_outer < 32768 || n_outer % 32768 == 0,
+              "n_outer=%lld: above 32767 slabs n_outer must be a multiple of "
+              "32768 (split the call)", (long long)n_outer);
+  WB2_REQUIRE(n_ctile == (n_col + kWave - 1) / kWave,
+              "n_ctile=%d does not match ceil(n_col / 64)", n_ctile);
+  if (n_outer == 0) return 0;
+  EnsParams p{};
+  p.ens = ens;
+  p.truth = truth;
+  p.ens_slab = reinterpret_cast<const long long*>(ens_slab);
+  p.truth_slab = reinterpret_cast<const long long*>(truth_slab);
+  p.w_row = w_row;
+  p.w_col = w_col;
+  p.wfield = wfield;
+  p.chunk_row0 = chunk_row0;
+  p.chunk_nrow = chunk_nrow;
+  p.seg_col0 = seg_col0;
+  p.seg_eoff = seg_eoff;
+  p.partials = partials;
+  p.member_stride = member_stride;
+  p.n_outer = n_outer;
+  p.n_member = n_member;
+  p.n_row = n_row;
+  p.n_col = n_col;
+  p.n_chunk = n_chunk;
+  p.n_ctile = n_ctile;
+  p.n_seg = n_seg;
+  p.n_ts = n_ts;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    return launch_ens_npad<float>(p, skipna != 0, wfield != nullptr, s);
+  return launch_ens_npad<double>(p, skipna != 0, wfield != nullptr, s);
+}
+
+}  // extern "C"

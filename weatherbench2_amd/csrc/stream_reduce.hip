@@ -23,6 +23,7 @@
 // and every sum is accumulated in fp64 like the promoted einsum.
 
 #include "common.hpp"
+#include "reduce_common.hpp"
 #include "wb2hip.h"
 
 #include <type_traits>
@@ -41,9 +42,10 @@ struct StreamParams {
   const int* chunk_row0;
   const int* chunk_nrow;
   const int* seg_col0;
+  const int* seg_eoff;
   double* partials;
   long long n_outer;
-  int n_row, n_col, n_chunk, n_ctile, n_seg;
+  int n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
 };
 
 template <int MODE, bool SKIPNA>
@@ -314,40 +316,9 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
   if (acc[0][0][0] == 1.2345) p.partials[0] = acc[0][0][0] + acc[0][VEC - 1][K - 1];
   return;
 #endif
-  const int tile_c0 = tile * TILE;
-  const int tile_c1 = min(tile_c0 + TILE, p.n_col);
-  int s_lo = 0;
-  while (p.seg_col0[s_lo + 1] <= tile_c0) ++s_lo;
-  int s_hi = s_lo;
-  while (s_hi + 1 < p.n_seg && p.seg_col0[s_hi + 1] < tile_c1) ++s_hi;
-  const long long item = (o * p.n_chunk + chunk) * p.n_ctile + tile;
-  double* out = p.partials + item * (long long)(NWF * p.n_seg * K);
-  for (int idx = lane; idx < NWF * p.n_seg * K; idx += kWave) {
-    const int s = (idx / K) % p.n_seg;
-    if (s < s_lo || s > s_hi) out[idx] = 0.0;
-  }
-  for (int s = s_lo; s <= s_hi; ++s) {
-    const int c0 = p.seg_col0[s], c1 = p.seg_col0[s + 1];
-#pragma unroll
-    for (int w = 0; w < NWF; ++w) {
-      double v[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) v[k] = 0.0;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const bool in_seg = (col0 + e >= c0) && (col0 + e < c1);
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] += in_seg ? acc[w][e][k] : 0.0;
-      }
-      double mine = 0.0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const double tot = wave_allsum(v[k]);
-        mine = (lane == k) ? tot : mine;
-      }
-      if (lane < K) out[((long long)w * p.n_seg + s) * K + lane] = mine;
-    }
-  }
+  fold_tile_to_segs<NWF, VEC, K>(
+      acc, lane, tile, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg, p.n_ts,
+      p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
 }
 
 // ---------------------------------------------------------------------------
@@ -355,6 +326,7 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
 // ---------------------------------------------------------------------------
 struct CombineParams {
   const double* partials;
+  const int* seg_eoff;
   const int* band_chunk0;
   const double* coef_band;
   const double* coef_seg;
@@ -363,14 +335,14 @@ struct CombineParams {
   double* sums;
   double* metrics;
   long long n_outer;
-  int n_chunk, n_ctile, nwf, n_seg, n_band, n_region, K, mode, skipna;
+  int n_chunk, nwf, n_seg, n_ts, n_band, n_region, K, mode, skipna;
 };
 
 __device__ __forceinline__ double nan_if_zero(double d) {
   return d != 0.0 ? d : __builtin_nan("");
 }
 
-__global__ void __launch_bounds__(256) det_combine_kernel(const CombineParams p) {
+__global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p) {
   extern __shared__ double lds[];
   const int K = p.K;
   const int cell = p.nwf * p.n_seg * K;
@@ -378,15 +350,34 @@ __global__ void __launch_bounds__(256) det_combine_kernel(const CombineParams p)
   double* rsum = lds + p.n_band * cell;      // [n_region][K]
   const long long o = blockIdx.x;
   const int tid = threadIdx.x;
-  const long long n_chunkx = (long long)p.n_chunk * p.n_ctile;
-  const double* part = p.partials + o * n_chunkx * cell;
+  const long long chunk_stride = (long long)p.nwf * p.n_ts * K;
+  const double* part = p.partials + o * p.n_chunk * chunk_stride;
 
+  // One thread per (band, weight field, seg, slot).  Its (chunk, entry) terms
+  // are independent loads: walk the flattened term index four at a time so four
+  // loads are in flight per wait (the sum order stays fixed: deterministic).
   for (int idx = tid; idx < p.n_band * cell; idx += blockDim.x) {
     const int b = idx / cell, j = idx - b * cell;
+    const int w = j / (p.n_seg * K), sk = j - w * (p.n_seg * K);
+    const int s = sk / K, k = sk - s * K;
+    const int e0 = p.seg_eoff[s], ne = p.seg_eoff[s + 1] - e0;
+    const int c0 = p.band_chunk0[b], n = (p.band_chunk0[b + 1] - c0) * ne;
+    const double* base = part + ((long long)w * p.n_ts) * K + k;
+    auto term = [&](int i) {
+      const int c = c0 + i / ne, e = e0 + i % ne;
+      return base[c * chunk_stride + (long long)e * K];
+    };
     double v = 0.0;
-    const long long c0 = (long long)p.band_chunk0[b] * p.n_ctile,
-                    c1 = (long long)p.band_chunk0[b + 1] * p.n_ctile;
-    for (long long cx = c0; cx < c1; ++cx) v += part[cx * cell + j];
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+      const double t0 = term(i), t1 = term(i + 1), t2 = term(i + 2),
+                   t3 = term(i + 3);
+      v += t0;
+      v += t1;
+      v += t2;
+      v += t3;
+    }
+    for (; i < n; ++i) v += term(i);
     bandsum[idx] = v;
   }
   __syncthreads();
@@ -413,6 +404,25 @@ __global__ void __launch_bounds__(256) det_combine_kernel(const CombineParams p)
     const double nan = __builtin_nan("");
     const double wsum = nan_if_zero(p.region_wsum[r]);
     double mse = nan, rmse = nan, mae = nan, bias = nan, acc = nan;
+    if (p.mode == WB2_MODE_ENS) {
+      const double n_skill = p.skipna ? nan_if_zero(s[6]) : wsum;
+      const double n_spread = p.skipna ? nan_if_zero(s[7]) : wsum;
+      const double n_var = p.skipna ? nan_if_zero(s[8]) : wsum;
+      const double n_deb = p.skipna ? nan_if_zero(s[9]) : wsum;
+      const double skill = s[0] / n_skill, spread = s[1] / n_spread;
+      const double emse = s[2] / n_skill, var = s[3] / n_var;
+      const long long stride = (long long)p.n_region * p.n_outer;
+      double* m = p.metrics + (long long)r * p.n_outer + o;
+      m[WB2_ENS_CRPS * stride] = skill - 0.5 * spread;  // metrics.py:665-675
+      m[WB2_ENS_CRPS_SPREAD * stride] = spread;
+      m[WB2_ENS_CRPS_SKILL * stride] = skill;
+      m[WB2_ENS_MEAN_MSE * stride] = emse;
+      m[WB2_ENS_MEAN_RMSE * stride] = sqrt(emse);        // :1302-1307
+      m[WB2_ENS_VARIANCE * stride] = var;
+      m[WB2_ENS_STDDEV * stride] = sqrt(s[4] / n_var);   // :1205-1210
+      m[WB2_ENS_DEBIASED_MSE * stride] = s[5] / n_deb;
+      continue;
+    }
     if (p.mode == WB2_MODE_WIND) {
       const double den = p.skipna ? nan_if_zero(s[1]) : wsum;
       mse = s[0] / den;
@@ -549,11 +559,13 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         const double* wfield, const int32_t* chunk_row0,
                         const int32_t* chunk_nrow, int32_t n_chunk,
                         int32_t n_ctile, const int32_t* seg_col0,
-                        int32_t n_seg, double* partials, void* stream) {
+                        const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
+                        double* partials, void* stream) {
   using namespace wb2;
   WB2_REQUIRE(mode >= 0 && mode <= 2, "unknown mode %d", mode);
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
-  WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && partials,
+  WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && seg_eoff &&
+                  partials,
               "null pointer argument");
   WB2_REQUIRE(n_outer >= 0 && n_row > 0 && n_col > 0 && n_chunk > 0 &&
                   n_seg > 0,
@@ -582,6 +594,8 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
   p.chunk_row0 = chunk_row0;
   p.chunk_nrow = chunk_nrow;
   p.seg_col0 = seg_col0;
+  p.seg_eoff = seg_eoff;
+  p.n_ts = n_ts;
   p.partials = partials;
   p.n_outer = n_outer;
   p.n_row = n_row;
@@ -602,24 +616,26 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
 }
 
 int wb2_det_combine(int mode, int skipna, const double* partials,
-                    int64_t n_outer, int32_t n_chunk, int32_t n_ctile,
-                    int32_t nwf, int32_t n_seg, const int32_t* band_chunk0,
-                    int32_t n_band, const double* coef_band,
+                    int64_t n_outer, int32_t n_chunk, int32_t nwf,
+                    int32_t n_seg, const int32_t* seg_eoff, int32_t n_ts,
+                    const int32_t* band_chunk0, int32_t n_band,
+                    const double* coef_band,
                     const double* coef_seg, const int32_t* region_wf,
                     const double* region_wsum, int32_t n_region, double* sums,
                     double* metrics, void* stream) {
   using namespace wb2;
-  WB2_REQUIRE(mode >= 0 && mode <= 2, "unknown mode %d", mode);
-  WB2_REQUIRE(partials && band_chunk0 && coef_band && coef_seg && region_wf &&
-                  region_wsum,
+  WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_ENS, "unknown mode %d", mode);
+  WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
+                  region_wf && region_wsum,
               "null pointer argument");
-  WB2_REQUIRE(n_outer >= 0 && n_chunk > 0 && n_ctile > 0 &&
+  WB2_REQUIRE(n_outer >= 0 && n_chunk > 0 && n_ts >= n_seg &&
                   (nwf == 1 || nwf == 2) && n_seg > 0 && n_band > 0 &&
                   n_region > 0,
               "bad sizes");
   if (n_outer == 0) return 0;
   CombineParams p{};
   p.partials = partials;
+  p.seg_eoff = seg_eoff;
   p.band_chunk0 = band_chunk0;
   p.coef_band = coef_band;
   p.coef_seg = coef_seg;
@@ -629,12 +645,13 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
   p.metrics = metrics;
   p.n_outer = n_outer;
   p.n_chunk = n_chunk;
-  p.n_ctile = n_ctile;
   p.nwf = nwf;
   p.n_seg = n_seg;
+  p.n_ts = n_ts;
   p.n_band = n_band;
   p.n_region = n_region;
-  p.K = wb2_num_slots(mode, skipna);
+  p.K = mode == WB2_MODE_ENS ? wb2_ens_num_slots(skipna)
+                             : wb2_num_slots(mode, skipna);
   p.mode = mode;
   p.skipna = skipna != 0;
   const size_t lds =
@@ -644,10 +661,24 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
               "region decomposition too fine for the combine kernel's LDS "
               "(%zu bytes > 64 KiB): n_band=%d n_seg=%d",
               lds, n_band, n_seg);
-  hipLaunchKernelGGL(det_combine_kernel, dim3((unsigned)n_outer), dim3(256),
+  hipLaunchKernelGGL(det_combine_kernel, dim3((unsigned)n_outer), dim3(1024),
                      lds, static_cast<hipStream_t>(stream), p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
+}
+
+int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,
+                    int32_t n_chunk, int32_t nwf, int32_t n_seg,
+                    const int32_t* seg_eoff, int32_t n_ts,
+                    const int32_t* band_chunk0, int32_t n_band,
+                    const double* coef_band, const double* coef_seg,
+                    const int32_t* region_wf, const double* region_wsum,
+                    int32_t n_region, double* sums, double* metrics,
+                    void* stream) {
+  return wb2_det_combine(WB2_MODE_ENS, skipna, partials, n_outer, n_chunk, nwf,
+                         n_seg, seg_eoff, n_ts, band_chunk0, n_band, coef_band,
+                         coef_seg, region_wf, region_wsum, n_region, sums,
+                         metrics, stream);
 }
 
 int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,

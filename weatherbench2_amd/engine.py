@@ -83,9 +83,9 @@ def stream_reduce(plan: ReductionPlan, mode: int,
   tile = lib.wb2_tile_cols(code, plan.n_col, int(aligned))
   n_ctile = -(-plan.n_col // tile)
   stream = current_stream_ptr(dev)
-  partials = torch.empty(
-      (n_outer, plan.n_chunk, n_ctile, plan.nwf, plan.n_seg, k),
-      dtype=torch.float64, device=dev)
+  seg_eoff, n_ts = plan.seg_entries(tile)
+  partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
+                         dtype=torch.float64, device=dev)
   if K1_EVENTS is not None:
     K1_EVENTS[0].record()
   _lib.check(lib.wb2_stream_partials(
@@ -93,7 +93,8 @@ def stream_reduce(plan: ReductionPlan, mode: int,
       n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
       _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
       _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
-      _lib.ptr(plan.seg_col0), plan.n_seg, _lib.ptr(partials), stream),
+      _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
+      _lib.ptr(partials), stream),
               'wb2_stream_partials')
   if K1_EVENTS is not None:
     K1_EVENTS[1].record()
@@ -102,11 +103,65 @@ def stream_reduce(plan: ReductionPlan, mode: int,
   sums = (torch.empty((n_outer, plan.n_region, k), dtype=torch.float64,
                       device=dev) if want_sums else None)
   _lib.check(lib.wb2_det_combine(
-      mode, int(skipna), _lib.ptr(partials), n_outer, plan.n_chunk, n_ctile,
-      plan.nwf, plan.n_seg, _lib.ptr(plan.band_chunk0), plan.n_band,
+      mode, int(skipna), _lib.ptr(partials), n_outer, plan.n_chunk, plan.nwf,
+      plan.n_seg, _lib.ptr(seg_eoff), n_ts, _lib.ptr(plan.band_chunk0),
+      plan.n_band,
       _lib.ptr(plan.coef_band), _lib.ptr(plan.coef_seg),
       _lib.ptr(plan.region_wf), _lib.ptr(plan.region_wsum), plan.n_region,
       _lib.ptr(sums), _lib.ptr(metrics), stream), 'wb2_det_combine')
+  return metrics, sums
+
+
+def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
+                    member_stride: int, n_member: int,
+                    ens_slab: t.Optional[torch.Tensor], truth: torch.Tensor,
+                    truth_slab: t.Optional[torch.Tensor], n_outer: int,
+                    skipna: bool, want_sums: bool = False):
+  """Runs K3 + the region fold.  `ens` holds the members member-major with
+  `member_stride` elements between members; `truth` is [n_slab, n_row, n_col].
+
+  Returns (metrics[NMETRIC_ENS, n_region, n_outer], sums or None).
+  """
+  lib = _lib.load()
+  dev = plan.device
+  dtype = ens.dtype
+  if dtype not in _DTYPES or truth.dtype != dtype:
+    raise TypeError(f'unsupported / mismatched dtypes {ens.dtype} {truth.dtype}')
+  for x in (ens, truth):
+    if x.device != dev or not x.is_contiguous():
+      raise ValueError('inputs must be contiguous on the plan device')
+  for s in (ens_slab, truth_slab):
+    if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
+      raise ValueError('slab tables are int64[n_outer]')
+  k = lib.wb2_ens_num_slots(int(skipna))
+  tile = lib.wb2_ens_tile_cols(plan.n_col)
+  n_ctile = -(-plan.n_col // tile)
+  seg_eoff, n_ts = plan.seg_entries(tile)
+  stream = current_stream_ptr(dev)
+  partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
+                         dtype=torch.float64, device=dev)
+  if K1_EVENTS is not None:
+    K1_EVENTS[0].record()
+  _lib.check(lib.wb2_ens_partials(
+      _DTYPES[dtype], int(skipna), _lib.ptr(ens), _lib.ptr(ens_slab),
+      _lib.ptr(truth), _lib.ptr(truth_slab), n_member, member_stride, n_outer,
+      plan.n_row, plan.n_col, _lib.ptr(plan.w_row), _lib.ptr(plan.w_col),
+      _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
+      _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
+      _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
+      _lib.ptr(partials), stream), 'wb2_ens_partials')
+  if K1_EVENTS is not None:
+    K1_EVENTS[1].record()
+  metrics = torch.empty((_lib.NMETRIC_ENS, plan.n_region, n_outer),
+                        dtype=torch.float64, device=dev)
+  sums = (torch.empty((n_outer, plan.n_region, k), dtype=torch.float64,
+                      device=dev) if want_sums else None)
+  _lib.check(lib.wb2_ens_combine(
+      int(skipna), _lib.ptr(partials), n_outer, plan.n_chunk, plan.nwf,
+      plan.n_seg, _lib.ptr(seg_eoff), n_ts, _lib.ptr(plan.band_chunk0),
+      plan.n_band, _lib.ptr(plan.coef_band), _lib.ptr(plan.coef_seg),
+      _lib.ptr(plan.region_wf), _lib.ptr(plan.region_wsum), plan.n_region,
+      _lib.ptr(sums), _lib.ptr(metrics), stream), 'wb2_ens_combine')
   return metrics, sums
 
 

@@ -528,3 +528,187 @@ class ACC(Metric):
       per_var[name] = (geo.out_dims,
                        by_region[rkey][_lib.METRIC_INDEX['acc']])
     return _assemble(forecast, per_var)
+
+
+# ---------------------------------------------------------------------------
+# Ensemble metrics (metrics.py:532-846, 1161-1363): one fused pass per chunk
+# ---------------------------------------------------------------------------
+def _get_n_ensemble(ds: xl.Dataset, ensemble_dim: str,
+                    expect_n_ensemble_at_least: int = 1) -> int:
+  """metrics.py:568-582 (same messages)."""
+  if ensemble_dim not in ds.dims:
+    raise ValueError(f'{ensemble_dim=} not found in {ds.dims=}')
+  n_ensemble = ds.sizes[ensemble_dim]
+  if n_ensemble < expect_n_ensemble_at_least:
+    raise ValueError(f'{n_ensemble=} is less than expected size of '
+                     f'{expect_n_ensemble_at_least}')
+  return n_ensemble
+
+
+def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna):
+  """All ensemble metrics of one variable for the active regions."""
+  fvar, tvar = forecast[name], truth[name]
+  pins = [fvar.data, tvar.data]
+  key = _result_key('ens:' + ensemble_dim, pins, region, skipna)
+  hit = _RESULTS.get(key)
+  if hit is not None:
+    return hit
+  if ensemble_dim not in fvar.dims:
+    raise ValueError(f'{ensemble_dim=} not found in {fvar.dims=}')
+  fdata, frest, layout = _spatial_last(fvar, None)
+  tdata, trest, _ = _spatial_last(tvar, layout)
+  if ensemble_dim in trest:
+    raise ValueError(f'truth must not have the ensemble dim {ensemble_dim!r}')
+  fsizes = dict(zip(frest, fdata.shape[:-2]))
+  n_member = fsizes[ensemble_dim]
+  out_dims = [d for d in frest if d != ensemble_dim]
+  sizes = {d: fsizes[d] for d in out_dims}
+  for d, n in zip(trest, tdata.shape[:-2]):
+    if d not in out_dims:
+      out_dims.append(d)
+      sizes[d] = n
+  out_dims = tuple(out_dims)
+  out_shape = tuple(sizes[d] for d in out_dims)
+  geo = _Geometry(layout, out_dims, out_shape,
+                  _coord_values(forecast, 'latitude'),
+                  _coord_values(forecast, 'longitude'))
+  # member m, outer index o  ->  slab  m * stride_member + ens_table[o]
+  stride, strides = 1, {}
+  for d in reversed(frest):
+    strides[d] = stride
+    stride *= fsizes[d]
+  ens_table = np.zeros(out_shape, dtype=np.int64)
+  for d in frest:
+    if d == ensemble_dim:
+      continue
+    shape = [1] * len(out_shape)
+    shape[out_dims.index(d)] = fsizes[d]
+    ens_table = ens_table + (np.arange(fsizes[d], dtype=np.int64)
+                             * strides[d]).reshape(shape)
+  ens_table = np.ascontiguousarray(ens_table).ravel()
+  identity = np.array_equal(ens_table, np.arange(ens_table.size))
+  truth_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
+
+  device = engine.require_gpu()
+  regions, _ = _region_set_for(region)
+  pl = plan_lib.cached_plan(geo.latitude, geo.longitude, geo.layout, regions,
+                            device)
+  ften, tten = _to_device(fdata, device), _to_device(tdata, device)
+  dtype = torch.promote_types(ften.dtype, tten.dtype)
+  if dtype not in (torch.float32, torch.float64):
+    dtype = torch.float64
+  ften = ften if ften.dtype == dtype else ften.to(dtype)
+  tten = tten if tten.dtype == dtype else tten.to(dtype)
+  _check_grid(geo, ften)
+  _check_grid(geo, tten)
+  slab_elems = pl.n_row * pl.n_col
+  to_dev = lambda tb: None if tb is None else torch.from_numpy(tb).to(device)
+  try:
+    metrics, _ = engine.ensemble_reduce(
+        pl, ften, strides[ensemble_dim] * slab_elems, n_member,
+        None if identity else to_dev(ens_table),
+        tten.reshape(-1, pl.n_row, pl.n_col), to_dev(truth_table),
+        geo.n_outer, skipna)
+  except _lib.Wb2HipError as e:
+    if 'not supported by the register sort' in str(e):
+      raise NotImplementedError(str(e)) from e
+    raise
+  host = metrics.cpu().numpy().reshape(
+      (_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
+  value = (geo, {nm: host[:, i] for i, nm in enumerate(pl.region_names)},
+           n_member)
+  _RESULTS.put(key, tuple(pins), value)
+  return value
+
+
+@dataclasses.dataclass
+class EnsembleMetric(Metric):
+  """Ensemble metric base class (metrics.py:585-607)."""
+
+  ensemble_dim: str = REALIZATION
+  _metric = ''
+  _zero_if_single = False  # metrics.py:1196-1204, 1228-1235, 783-784
+  # xarray puts the dims of the LEFT operand first: metrics built from
+  # `truth - forecast...` (skill, CRPS, mean MSE/RMSE, debiased) come out in
+  # truth-first order, the ones built from the forecast alone in forecast order.
+  _truth_first = True
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    _get_n_ensemble(forecast, self.ensemble_dim)  # raises like the reference
+    per_var = {}
+    for name in _common_vars(forecast, truth):
+      geo, by_region, n_member = _ens_pass(forecast, truth, name,
+                                           self.ensemble_dim, region, skipna)
+      _, rkey = _region_set_for(region)
+      values = by_region[rkey][_lib.ENS_METRIC_INDEX[self._metric]]
+      if self._zero_if_single and n_member == 1:
+        values = np.zeros_like(values)
+      dims = geo.out_dims
+      if self._truth_first:
+        tdims = [d for d in truth[name].dims if d in dims]
+        order = tuple(tdims + [d for d in dims if d not in tdims])
+        values = np.transpose(values, [dims.index(d) for d in order])
+        dims = order
+      per_var[name] = (dims, values)
+    return _assemble(forecast, per_var)
+
+  def compute(self, forecast, truth, region=None, skipna=False):
+    """Evaluate this metric on datasets with full temporal coverages."""
+    forecast = xl.as_dataset(forecast)
+    result = super().compute(forecast, truth, region=region, skipna=skipna)
+    return result.assign_attrs(ensemble_size=forecast.sizes[self.ensemble_dim])
+
+
+@dataclasses.dataclass
+class CRPS(EnsembleMetric):
+  """Continuous Ranked Probability Score = skill - 0.5 spread (metrics.py:610-675)."""
+  _metric = 'crps'
+
+
+@dataclasses.dataclass
+class CRPSSpread(EnsembleMetric):
+  """E|X - X'| (metrics.py:678-694); zero for one member (:783-784)."""
+  _metric = 'crps_spread'
+  _zero_if_single = True
+  _truth_first = False
+
+
+@dataclasses.dataclass
+class CRPSSkill(EnsembleMetric):
+  """E|X - Y| (metrics.py:697-715)."""
+  _metric = 'crps_skill'
+
+
+@dataclasses.dataclass
+class EnsembleStddevSqrtBeforeTimeAvg(EnsembleMetric):
+  """sqrt(spatial mean of std(ddof=1)^2) (metrics.py:1161-1210)."""
+  _metric = 'ensemble_stddev'
+  _zero_if_single = True
+  _truth_first = False
+
+
+@dataclasses.dataclass
+class EnsembleVariance(EnsembleMetric):
+  """Spatial mean of var(ddof=1) (metrics.py:1213-1241)."""
+  _metric = 'ensemble_variance'
+  _zero_if_single = True
+  _truth_first = False
+
+
+@dataclasses.dataclass
+class EnsembleMeanRMSESqrtBeforeTimeAvg(EnsembleMetric):
+  """RMSE of the ensemble mean (metrics.py:1269-1307)."""
+  _metric = 'ensemble_mean_rmse'
+
+
+@dataclasses.dataclass
+class EnsembleMeanMSE(EnsembleMetric):
+  """MSE of the ensemble mean (metrics.py:1310-1333)."""
+  _metric = 'ensemble_mean_mse'
+
+
+@dataclasses.dataclass
+class DebiasedEnsembleMeanMSE(EnsembleMetric):
+  """(t - mean)^2 - var / n (metrics.py:1336-1363); NaN for one member."""
+  _metric = 'debiased_ensemble_mean_mse'

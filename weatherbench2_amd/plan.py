@@ -94,6 +94,18 @@ class ReductionPlan:
   region_wf: torch.Tensor = None
   region_wsum: torch.Tensor = None
   _pins: tuple = ()
+  _eoff: dict = dataclasses.field(default_factory=dict)
+
+  def seg_entries(self, tile_cols: int):
+    """(seg_eoff device tensor, n_ts) for a column-tile width (wb2hip.h)."""
+    hit = self._eoff.get(tile_cols)
+    if hit is None:
+      c = self.seg_col0_host.astype(np.int64)
+      ntile = (c[1:] - 1) // tile_cols - c[:-1] // tile_cols + 1
+      eoff = np.concatenate([[0], np.cumsum(ntile)]).astype(np.int32)
+      hit = (torch.as_tensor(eoff).to(self.device), int(eoff[-1]))
+      self._eoff[tile_cols] = hit
+    return hit
 
   @property
   def n_chunk(self): return int(self.chunk_row0_host.shape[0])
