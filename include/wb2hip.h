@@ -208,6 +208,33 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         int64_t n_tail, int skipna, double* sum, double* count,
                         void* stream);
 
+/*
+ * K4: zonal energy spectrum, ZonalEnergySpectrum.compute
+ * (weatherbench2/derived_variables.py:592-626): batched real-to-complex FFT
+ * along longitude (rocFFT through hipFFT), then
+ *   S[row, k] = |F[k] / n_lon|^2 * (k == 0 ? 1 : 2) * circumference[row % n_lat]
+ * in fp64 (numpy widens float32 power * int64 to float64 at the same point).
+ *
+ *  plan        host handle for (dtype, n_lon, n_rows); creation may take seconds
+ *              (rocFFT compiles its kernels at run time) -- create once, reuse.
+ *  x           DEV [n_rows][n_lon], longitude contiguous; rows ordered
+ *              (time, ..., latitude) with latitude the fastest row index
+ *  circumference DEV double[n_lat] = cos(lat * pi / 180) * 2 pi R   (:578-581)
+ *  n_time      0: out is double[n_rows][n_lon/2+1] (what compute() returns);
+ *              > 0: rows are [n_time][n_rows / n_time] and out is the mean over
+ *              time, double[n_rows / n_time][n_lon/2+1]
+ *              (scripts/compute_zonal_energy_spectrum.py:234); skipna as in
+ *              xbeam.Mean.
+ *  workspace   DEV, wb2_spectrum_plan_workspace(plan) bytes, 256-byte aligned
+ */
+int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
+                             void** plan);
+int wb2_spectrum_plan_destroy(void* plan);
+int64_t wb2_spectrum_plan_workspace(void* plan);
+int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
+                       int32_t n_lat, int64_t n_time, int skipna, double* out,
+                       void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,191 @@
+"""CPU-side checks of the C-ABI boundary and the host planning logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+  header = open(os.path.join(ROOT, 'include', 'wb2hip.h')).read()
+  header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+  return sorted(set(re.findall(r'\b(wb2_[a-z0-9_]+)\s*\(', header)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+  from weatherbench2_amd import build
+  build.build(verbose=False)
+  from weatherbench2_amd import _lib
+  return _lib
+
+
+def test_library_loads_and_exports_every_declared_symbol(lib):
+  handle = lib.load()
+  declared = _declared_symbols()
+  assert len(declared) >= 14
+  for name in declared:
+    assert hasattr(handle, name), f'{name} declared in wb2hip.h but not exported'
+  assert sorted(lib.exported_symbols()) == declared
+  assert handle.wb2_version() == 1
+
+
+def test_pure_host_entry_points(lib):
+  h = lib.load()
+  assert h.wb2_num_slots(lib.MODE_DET, 0) == 3
+  assert h.wb2_num_slots(lib.MODE_DET, 1) == 4
+  assert h.wb2_num_slots(lib.MODE_DET_ACC, 0) == 6
+  assert h.wb2_num_slots(lib.MODE_DET_ACC, 1) == 10
+  assert h.wb2_num_slots(lib.MODE_WIND, 1) == 2
+  assert h.wb2_ens_num_slots(0) == 6 and h.wb2_ens_num_slots(1) == 10
+  assert h.wb2_tile_cols(lib.WB2_F32, 1440, 1) == 256
+  assert h.wb2_tile_cols(lib.WB2_F32, 1440, 0) == 64
+  assert h.wb2_tile_cols(lib.WB2_F32, 7, 1) == 64
+  assert h.wb2_tile_cols(lib.WB2_F64, 1440, 1) == 128
+  assert h.wb2_ens_tile_cols(1440) == 64
+  assert h.wb2_num_slots(99, 0) < 0
+  assert b'unknown mode' in h.wb2_last_error()
+
+
+def test_argument_validation_without_a_gpu(lib):
+  h = lib.load()
+  # null pointers are rejected before anything touches the device
+  rc = h.wb2_time_accumulate(None, 1, 1, 1, 0, None, None, None)
+  assert rc < 0 and b'null pointer' in h.wb2_last_error()
+
+
+def test_product_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, 'weatherbench2_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith('.py'):
+        src = open(os.path.join(dirpath, f)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_no_gpu_means_loud_failure(lib):
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('a GPU is visible')
+  from weatherbench2_amd import engine
+  with pytest.raises(lib.Wb2HipError):
+    engine.require_gpu()
+
+
+# ---------------------------------------------------------------------------
+# host planning: region decomposition is index/mask work -> bit-exact vs oracle
+# ---------------------------------------------------------------------------
+def _oracle_region_weights(region, lat, lon):
+  """Weights the reference would use, as a dense (lat, lon) array with
+  multiplicities (rows/cols selected twice count twice)."""
+  from oracle import metrics_np as om
+  from oracle.named import DS, NA
+  ds = DS({'x': NA(np.zeros((len(lat), len(lon))), ('latitude', 'longitude'))},
+          {'latitude': lat, 'longitude': lon})
+  w = om.get_lat_weights(lat)
+  if region is None:
+    full = np.broadcast_to(w.data[:, None], (len(lat), len(lon))).copy()
+    return full
+  ds2, w2 = region.apply(ds, w)
+  lat2, lon2 = ds2.coord('latitude'), ds2.coord('longitude')
+  ones = NA(np.ones((len(lat2), len(lon2))), ('latitude', 'longitude'))
+  dense = (ones * w2).transpose('latitude', 'longitude').data
+  full = np.zeros((len(lat), len(lon)))
+  li = {v: i for i, v in enumerate(lat.tolist())}
+  lj = {v: i for i, v in enumerate(lon.tolist())}
+  for a, la in enumerate(lat2.tolist()):
+    for b, lo in enumerate(lon2.tolist()):
+      full[li[la], lj[lo]] += dense[a, b]
+  return full
+
+
+@pytest.mark.parametrize('res', [30.0, 5.625, 1.0])
+def test_region_decomposition_matches_reference_semantics(res):
+  from oracle import regions_np as oreg
+  from oracle.named import NA
+  from tests import helpers
+  from weatherbench2_amd import plan as plan_lib
+  from weatherbench2_amd import regions as greg
+  n_lat = round(180 / res) + 1
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, round(360 / res), endpoint=False)
+  rs = np.random.RandomState(1)
+  lsm = np.clip(rs.rand(len(lat), len(lon)) * 1.4 - 0.2, 0, 1)
+  oregions = dict(helpers.predefined_regions(oracle=True))
+  oregions['none'] = None
+  oregions['xt'] = oreg.ExtraTropicalRegion()
+  oregions['overlap'] = oreg.SliceRegion(lat_slice=[slice(None, 10),
+                                                    slice(-10, None)])
+  oregions['land'] = oreg.LandRegion(NA(lsm, ('latitude', 'longitude')), lat,
+                                     lon)
+  oregions['tropics_land_thr'] = oreg.CombinedRegion([
+      oreg.SliceRegion(lat_slice=slice(-20, 20)),
+      oreg.LandRegion(NA(lsm, ('latitude', 'longitude')), lat, lon, 0.5)])
+  land_only = {k: v for k, v in oregions.items()
+               if k in ('land', 'tropics_land_thr')}
+  plain = {k: v for k, v in oregions.items() if k not in land_only}
+  for group in (plain, {**plain, 'land': oregions['land']},
+                {'tropics_land_thr': oregions['tropics_land_thr']}):
+    gregions = {k: helpers.to_gpu_region(v) for k, v in group.items()}
+    for layout in (plan_lib.LATLON, plan_lib.LONLAT):
+      pl = plan_lib.build_plan(lat, lon, layout, gregions, 'cpu',
+                               rows_per_chunk=5)
+      w_row = pl.w_row.numpy()
+      w_col = np.ones(pl.n_col) if pl.w_col is None else pl.w_col.numpy()
+      field = None if pl.wfield is None else pl.wfield.numpy()
+      band_of_row = np.repeat(np.arange(pl.n_band), np.diff(pl.band_row0))
+      seg_of_col = np.repeat(np.arange(pl.n_seg), np.diff(pl.seg_col0_host))
+      cb, cs = pl.coef_band.numpy(), pl.coef_seg.numpy()
+      for i, name in enumerate(pl.region_names):
+        dense = (cb[i][band_of_row][:, None] * cs[i][seg_of_col][None, :]
+                 * w_row[:, None] * w_col[None, :])
+        if pl.region_wf.numpy()[i]:
+          dense = dense * field
+        if layout == plan_lib.LONLAT:
+          dense = dense.T
+        want = _oracle_region_weights(group[name], lat, lon)
+        np.testing.assert_array_equal(dense != 0, want != 0, err_msg=name)
+        np.testing.assert_allclose(dense, want, rtol=1e-15, atol=0,
+                                   err_msg=name)
+        np.testing.assert_allclose(pl.region_wsum_host[i], want.sum(),
+                                   rtol=1e-12)
+      # chunks tile every band exactly once, padded to a multiple of 8
+      assert pl.n_chunk % 8 == 0
+      rows = np.concatenate([np.arange(r, r + n) for r, n in
+                             zip(pl.chunk_row0_host, pl.chunk_nrow_host)])
+      np.testing.assert_array_equal(rows, np.arange(pl.n_row))
+
+
+def test_lat_weights_follow_coordinate_dtype():
+  from oracle import metrics_np as om
+  from weatherbench2_amd import plan as plan_lib
+  for dtype in (np.float64, np.float32):
+    lat = np.linspace(-90, 90, 721).astype(dtype)
+    got = plan_lib.get_lat_weights(lat)
+    want = om.get_lat_weights(lat).data
+    assert got.dtype == dtype
+    np.testing.assert_array_equal(got, want)
+  with pytest.raises(ValueError):
+    plan_lib.get_lat_weights(np.array([10.0, 0.0, -10.0]))
+
+
+def test_seg_entry_tables():
+  from weatherbench2_amd import plan as plan_lib
+  from tests import helpers
+  lat = np.linspace(-90, 90, 721)
+  lon = np.linspace(0, 360, 1440, endpoint=False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON,
+                           helpers.predefined_regions(oracle=False), 'cpu')
+  for tile in (64, 128, 256):
+    eoff, n_ts = pl.seg_entries(tile)
+    eoff = eoff.numpy()
+    c = pl.seg_col0_host
+    count = 0
+    for s in range(pl.n_seg):
+      tiles = set(range(c[s] // tile, (c[s + 1] - 1) // tile + 1))
+      assert eoff[s + 1] - eoff[s] == len(tiles)
+      count += len(tiles)
+    assert n_ts == count

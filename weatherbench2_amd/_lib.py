@@ -49,17 +49,12 @@ _SIGNATURES = {
         _vp, _vp, _i32, _vp, _vp, _vp]),
     'wb2_ens_num_slots': (_int, [_int]),
     'wb2_ens_tile_cols': (_int, [_i32]),
-    'wb2_spectrum_plan_create': (_int, [_i32, _i64, _c.POINTER(_vp)]),
+    'wb2_spectrum_plan_create': (_int, [_int, _i32, _i64, _c.POINTER(_vp)]),
     'wb2_spectrum_plan_destroy': (_int, [_vp]),
     'wb2_spectrum_plan_workspace': (_i64, [_vp]),
-    'wb2_zonal_spectrum': (_int, [_vp, _int, _vp, _i64, _i32, _vp, _i32, _int,
-                                  _vp, _vp, _vp]),
+    'wb2_zonal_spectrum': (_int, [_vp, _vp, _vp, _i32, _i64, _int, _vp, _vp,
+                                  _vp]),
 }
-
-# Entry points still under construction (removed as they land).
-_PENDING = {'wb2_spectrum_plan_create',
-            'wb2_spectrum_plan_destroy', 'wb2_spectrum_plan_workspace',
-            'wb2_zonal_spectrum'}
 
 _lib = None
 
@@ -88,8 +83,6 @@ def load():
     try:
       fn = getattr(lib, name)
     except AttributeError as e:
-      if name in _PENDING:
-        continue
       raise Wb2HipError(f'{path} does not export {name}: stale build? '
                         'rebuild with __graft_entry__.build()') from e
     fn.restype = restype

@@ -1,0 +1,127 @@
+"""GPU derived variables with the reference's `DerivedVariable` protocol.
+
+Only `ZonalEnergySpectrum` is on the hot path (weatherbench2/
+derived_variables.py:531-626, driven by scripts/compute_zonal_energy_spectrum.py);
+the other derived variables are stencil/scan ops computed before the metric
+loop and stay on the host.
+"""
+from __future__ import annotations
+
+import dataclasses
+import typing as t
+
+import numpy as np
+import torch
+
+from weatherbench2_amd import engine
+from weatherbench2_amd import xarray_lite as xl
+
+EARTH_RADIUS_M = 1000 * (6357 + 6378) / 2  # schema.py:59
+
+
+@dataclasses.dataclass
+class DerivedVariable:
+  """Derived variable base class (derived_variables.py:29-56)."""
+
+  @property
+  def base_variables(self) -> list:
+    raise NotImplementedError
+
+  @property
+  def core_dims(self):
+    raise NotImplementedError
+
+  def compute(self, dataset):
+    raise NotImplementedError
+
+
+@dataclasses.dataclass
+class ZonalEnergySpectrum(DerivedVariable):
+  """Energy spectrum along the zonal direction (derived_variables.py:531-626).
+
+  S[0] = C |F[0]|^2, S[k] = 2 C |F[k]|^2 with F = rfft(f, norm='forward') and C
+  the circumference of the latitude circle.  The result keeps the input dims
+  with `longitude` replaced by a trailing `zonal_wavenumber`, and carries the
+  `frequency` / `wavelength` coordinates of the reference.
+  """
+
+  variable_name: str
+
+  @property
+  def base_variables(self) -> list:
+    return [self.variable_name]
+
+  @property
+  def core_dims(self):
+    return (['longitude'],), ['zonal_wavenumber']
+
+  @staticmethod
+  def _circumference(latitude: np.ndarray) -> np.ndarray:
+    """derived_variables.py:578-581."""
+    circum_at_equator = 2 * np.pi * EARTH_RADIUS_M
+    return np.cos(np.asarray(latitude) * np.pi / 180) * circum_at_equator
+
+  def lon_spacing_m(self, dataset) -> np.ndarray:
+    """derived_variables.py:583-590 (ValueError on non-uniform spacing)."""
+    dataset = xl.as_dataset(dataset)
+    longitude = np.asarray(dataset.coords['longitude'])
+    diffs = np.diff(longitude)
+    if np.max(np.abs(diffs - diffs[0])) > 1e-3:
+      raise ValueError(
+          f'Expected uniform longitude spacing. {longitude=}')
+    latitude = np.asarray(dataset.coords['latitude'])
+    return self._circumference(latitude) * diffs[0] / 360
+
+  def compute(self, dataset, time_mean_dim: t.Optional[str] = None,
+              skipna: bool = True) -> xl.DataArray:
+    """Zonal power at each wavenumber.  `time_mean_dim` (an extension) fuses
+    the mean over that dim, as scripts/compute_zonal_energy_spectrum.py:234
+    does afterwards with xbeam.Mean."""
+    dataset = xl.as_dataset(dataset)
+    spacing = self.lon_spacing_m(dataset)
+    da = dataset[self.variable_name]
+    for d in ('latitude', 'longitude'):
+      if d not in da.dims:
+        raise ValueError(f'{d!r} missing from {da.dims}')
+    rest = [d for d in da.dims if d not in ('latitude', 'longitude')]
+    if time_mean_dim is not None:
+      if time_mean_dim not in rest:
+        raise ValueError(f'{time_mean_dim!r} missing from {da.dims}')
+      rest = [time_mean_dim] + [d for d in rest if d != time_mean_dim]
+    order = tuple(rest) + ('latitude', 'longitude')
+    moved = da if da.dims == order else da.transpose(*order)
+    device = engine.require_gpu()
+    x = engine.as_device_tensor(moved.data, device)
+    if x.dtype not in (torch.float32, torch.float64):
+      x = x.to(torch.float64)
+    latitude = np.asarray(dataset.coords['latitude'])
+    longitude = np.asarray(dataset.coords['longitude'])
+    circ = torch.as_tensor(self._circumference(latitude).astype(np.float64)
+                           ).to(device)
+    n_time = x.shape[0] if time_mean_dim is not None else 0
+    out = engine.zonal_spectrum(x, circ, len(latitude), n_time, skipna)
+    out_dims = tuple(d for d in order[:-1] if d != time_mean_dim) + (
+        'zonal_wavenumber',)
+    # apply_ufunc keeps the input order with longitude moved last
+    # (derived_variables.py:604-609).
+    ref_dims = tuple(d for d in da.dims if d not in ('longitude',
+                                                      time_mean_dim)
+                     ) + ('zonal_wavenumber',)
+    n_bins = len(longitude) // 2 + 1
+    coords = {k: v for k, v in dataset.coords.items()
+              if k not in ('longitude', time_mean_dim)}
+    coords['zonal_wavenumber'] = np.arange(n_bins)
+    with np.errstate(divide='ignore'):
+      frequency = np.fft.rfftfreq(len(longitude))[:, None] / spacing[None, :]
+      wavelength = 1 / frequency
+    coords['frequency'] = xl.DataArray(frequency,
+                                       ('zonal_wavenumber', 'latitude'))
+    coords['wavelength'] = xl.DataArray(wavelength,
+                                        ('zonal_wavenumber', 'latitude'))
+    result = xl.DataArray(out.cpu().numpy(), out_dims, coords,
+                          self.variable_name)
+    if out_dims != ref_dims:
+      result = result.transpose(*ref_dims)
+      result = xl.DataArray(np.ascontiguousarray(result.data), ref_dims,
+                            coords, self.variable_name)
+    return result

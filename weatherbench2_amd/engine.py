@@ -180,3 +180,62 @@ def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
       _lib.ptr(values), n_lead, n_time, n_tail, int(skipna), _lib.ptr(total),
       _lib.ptr(count), current_stream_ptr(values.device)),
              'wb2_time_accumulate')
+
+
+class _SpectrumPlans:
+  """hipFFT plans are expensive (rocFFT compiles kernels): cache by shape."""
+
+  def __init__(self):
+    self.plans = {}
+
+  def get(self, dtype_code: int, n_lon: int, n_rows: int):
+    import ctypes
+    key = (dtype_code, n_lon, n_rows, torch.cuda.current_device())
+    hit = self.plans.get(key)
+    if hit is None:
+      lib = _lib.load()
+      handle = ctypes.c_void_p()
+      _lib.check(lib.wb2_spectrum_plan_create(dtype_code, n_lon, n_rows,
+                                              ctypes.byref(handle)),
+                 'wb2_spectrum_plan_create')
+      nbytes = lib.wb2_spectrum_plan_workspace(handle)
+      if nbytes < 0:
+        _lib.check(-1, 'wb2_spectrum_plan_workspace')
+      if len(self.plans) >= 8:  # bounded: drop the oldest plan
+        old_key = next(iter(self.plans))
+        lib.wb2_spectrum_plan_destroy(self.plans.pop(old_key)[0])
+      hit = (handle, int(nbytes))
+      self.plans[key] = hit
+    return hit
+
+
+_SPECTRUM_PLANS = _SpectrumPlans()
+
+
+def zonal_spectrum(x: torch.Tensor, circumference: torch.Tensor, n_lat: int,
+                   n_time: int = 0, skipna: bool = True) -> torch.Tensor:
+  """x: [..., n_lat, n_lon] contiguous device tensor (rows = everything but lon).
+
+  Returns float64 [..., n_lat, n_lon//2+1], or with n_time > 0 (x's LEADING
+  dim is time) the time mean [rest..., n_lat, n_lon//2+1].
+  """
+  lib = _lib.load()
+  if x.dtype not in _DTYPES or not x.is_contiguous():
+    raise ValueError('x must be a contiguous float32/float64 tensor')
+  n_lon = x.shape[-1]
+  n_rows = x.numel() // n_lon
+  handle, nbytes = _SPECTRUM_PLANS.get(_DTYPES[x.dtype], n_lon, n_rows)
+  work = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
+  n_bins = n_lon // 2 + 1
+  if n_time > 0:
+    if x.shape[0] != n_time:
+      raise ValueError('time must be the leading dim for the fused time mean')
+    out_shape = tuple(x.shape[1:-1]) + (n_bins,)
+  else:
+    out_shape = tuple(x.shape[:-1]) + (n_bins,)
+  out = torch.empty(out_shape, dtype=torch.float64, device=x.device)
+  _lib.check(lib.wb2_zonal_spectrum(
+      handle, _lib.ptr(x), _lib.ptr(circumference), n_lat, n_time, int(skipna),
+      _lib.ptr(out), _lib.ptr(work), current_stream_ptr(x.device)),
+             'wb2_zonal_spectrum')
+  return out
