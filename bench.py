@@ -114,7 +114,15 @@ def main():
                   help='distinct units resident in HBM per input')
   ap.add_argument('--rows-per-chunk', type=int, default=16)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--workload', default='deterministic',
+                  choices=['deterministic', 'ensemble', 'spectrum'],
+                  help='deterministic = BASELINE configs[1] (the headline '
+                       'metric); ensemble / spectrum = configs[2] / [3], used '
+                       'for profiles/ and DESIGN.md')
+  ap.add_argument('--members', type=int, default=50)
   args = ap.parse_args()
+  if args.workload != 'deterministic':
+    return secondary(args)
 
   import torch
   import torch.distributed as dist
@@ -177,13 +185,25 @@ def main():
 
   for i in range(args.warmup):
     step(i, False)
+  # Touch every op of the timed region once: on a cold box the first use of a
+  # torch kernel (the final division, the all-reduce) loads its code object,
+  # which costs tens of ms and is not part of the hot path.
+  _ = (total / count).sum().item()
+  if world > 1:
+    dist.all_reduce(torch.stack([total, count]))
+  total.zero_()
+  count.zero_()
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
+  g0 = torch.cuda.Event(enable_timing=True)
+  g1 = torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
+  g0.record()
   for i in range(args.steps):
     step(args.warmup + i, True)
+  g1.record()
   if world > 1:
     packed = torch.stack([total, count])
     dist.all_reduce(packed)  # RCCL over xGMI: the only exchange of the path
@@ -210,6 +230,7 @@ def main():
       'unit': 'grid-point-evals/s',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': dt / args.steps * 1e3,
+      'gpu_ms_per_step': g0.elapsed_time(g1) / args.steps,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32 elementwise, f64 accumulate', 'data': 'synthetic',
       'config': {
@@ -236,6 +257,94 @@ def main():
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
+
+
+def secondary(args):
+  """BASELINE configs[2] (50-member ensemble) and configs[3] (zonal spectrum)
+  on one GPU: same timing discipline, their own roofline."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  dev = torch.device('cuda', 0)
+  torch.cuda.set_device(dev)
+  lat = np.linspace(-90, 90, N_LAT)
+  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  gen = torch.Generator(device=dev).manual_seed(99)
+  events = []
+  if args.workload == 'ensemble':
+    m = args.members
+    n_slab = 13            # one unit of 13 levels per step
+    pool = 4               # 4 x 13 x 50 x 4.15 MB = 10.8 GB >> Infinity Cache
+    pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(),
+                             dev, rows_per_chunk=args.rows_per_chunk)
+    ens = torch.randn((m, pool * n_slab, N_LAT, N_LON), generator=gen,
+                      device=dev)
+    truth = torch.randn((pool * n_slab, N_LAT, N_LON), generator=gen,
+                        device=dev)
+    stride = pool * n_slab * N_LAT * N_LON
+    tabs = [(torch.arange(n_slab, device=dev) + (i % pool) * n_slab)
+            for i in range(pool)]
+    pts = n_slab * N_LAT * N_LON
+    bytes_per_pt = (m + 1) * 4.0
+
+    def step(i, timed):
+      if timed:
+        ev = (torch.cuda.Event(enable_timing=True),
+              torch.cuda.Event(enable_timing=True))
+        engine.K1_EVENTS = ev
+        events.append(ev)
+      else:
+        engine.K1_EVENTS = None
+      tab = tabs[i % pool]
+      engine.ensemble_reduce(pl, ens, stride, m, tab, truth, tab, n_slab, False)
+    kernel = f'ens_partials_kernel<float,64,{m if m == 50 else 0}>'
+    workload = (f'BASELINE configs[2]: 721x1440x13 f32, {m}-member CRPS + '
+                'spread/skill + ensemble-mean MSE + variance + debiased MSE, '
+                '13 regions')
+  else:
+    units = 8
+    pool = 6
+    x = torch.randn((pool * units, N_LEV, N_LAT, N_LON), generator=gen,
+                    device=dev)
+    from weatherbench2_amd.derived_variables import ZonalEnergySpectrum
+    circ = torch.as_tensor(ZonalEnergySpectrum._circumference(lat)).to(dev)
+    pts = units * PTS_PER_UNIT
+    bytes_per_pt = 4.0 + (N_LON // 2 + 1) * 8.0 / N_LON
+
+    def step(i, timed):
+      xs = x[(i % pool) * units:(i % pool + 1) * units]
+      if timed:
+        ev = (torch.cuda.Event(enable_timing=True),
+              torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+      engine.zonal_spectrum(xs, circ, N_LAT)
+      if timed:
+        ev[1].record()
+        events.append(ev)
+    kernel = 'rocFFT R2C (N=1440, batch 74984) + power_kernel<float>'
+    workload = ('BASELINE configs[3]: zonal energy spectrum of 8 units of '
+                '13x721x1440 f32 per step, per-unit spectrum materialised')
+  for i in range(args.warmup):
+    step(i, False)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    step(args.warmup + i, True)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  k_s = float(np.mean([a.elapsed_time(b) for a, b in events])) / 1e3
+  achieved = pts * bytes_per_pt / k_s / 1e9
+  print(json.dumps({
+      'metric': 'grid-point-evals/sec (721x1440x13)',
+      'value': pts * args.steps / dt, 'unit': 'grid-point-evals/s',
+      'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': workload},
+      'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved,
+                   'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                   'frac': achieved / HBM_PEAK_GBPS, 'kernel_ms': k_s * 1e3,
+                   'algorithmic_bytes_per_launch': pts * bytes_per_pt,
+                   'traffic': None}}))
 
 
 if __name__ == '__main__':
