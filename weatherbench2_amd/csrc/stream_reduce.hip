@@ -381,19 +381,34 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
     bandsum[idx] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < p.n_region * K; idx += blockDim.x) {
-    const int r = idx / K, k = idx - r * K;
+  // Region sums in two short steps (fixed order => deterministic):
+  //   (1) one thread per (region, band, slot): sum over the segs of the band,
+  //   (2) one thread per (region, slot): sum over bands.
+  // Cells whose coefficient is 0 are never read: they may legitimately hold
+  // NaN/Inf (metrics.py:159-160).
+  double* rb = rsum + p.n_region * K;  // [n_region][n_band][K]
+  for (int idx = tid; idx < p.n_region * p.n_band * K; idx += blockDim.x) {
+    const int r = idx / (p.n_band * K), bk = idx - r * (p.n_band * K);
+    const int b = bk / K, k = bk - b * K;
     const int wf = p.region_wf[r];
+    const double cb = p.coef_band[r * p.n_band + b];
     double v = 0.0;
-    for (int b = 0; b < p.n_band; ++b) {
-      const double cb = p.coef_band[r * p.n_band + b];
-      if (cb == 0.0) continue;  // excluded cells may hold NaN: never touch them
+    if (cb != 0.0) {
+      const double* row = bandsum + ((b * p.nwf + wf) * p.n_seg) * K + k;
       for (int s = 0; s < p.n_seg; ++s) {
         const double cs = p.coef_seg[r * p.n_seg + s];
-        if (cs == 0.0) continue;
-        v += (cb * cs) * bandsum[((b * p.nwf + wf) * p.n_seg + s) * K + k];
+        if (cs != 0.0) v += (cb * cs) * row[s * K];
       }
     }
+    rb[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < p.n_region * K; idx += blockDim.x) {
+    const int r = idx / K, k = idx - r * K;
+    double v = 0.0;
+    for (int b = 0; b < p.n_band; ++b)
+      if (p.coef_band[r * p.n_band + b] != 0.0)
+        v += rb[(r * p.n_band + b) * K + k];
     rsum[idx] = v;
     if (p.sums) p.sums[(o * p.n_region + r) * K + k] = v;
   }
@@ -461,12 +476,22 @@ __global__ void __launch_bounds__(256)
   if (idx >= n_lead * n_tail) return;
   const long long l = idx / n_tail, j = idx - l * n_tail;
   double s = 0.0, c = 0.0;
-  for (long long t = 0; t < n_time; ++t) {
-    const double v = values[(l * n_time + t) * n_tail + j];
-    if (skipna && is_nan(v)) continue;
-    s += v;
-    c += 1.0;
+  const double* base = values + l * n_time * n_tail + j;
+  auto add = [&](double v) {
+    const bool keep = !(skipna && is_nan(v));
+    s += keep ? v : 0.0;
+    c += keep ? 1.0 : 0.0;
+  };
+  long long t = 0;
+  for (; t + 4 <= n_time; t += 4) {  // four independent loads per wait
+    const double v0 = base[t * n_tail], v1 = base[(t + 1) * n_tail],
+                 v2 = base[(t + 2) * n_tail], v3 = base[(t + 3) * n_tail];
+    add(v0);
+    add(v1);
+    add(v2);
+    add(v3);
   }
+  for (; t < n_time; ++t) add(base[t * n_tail]);
   sum[idx] += s;
   count[idx] += c;
 }
@@ -654,9 +679,9 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
                              : wb2_num_slots(mode, skipna);
   p.mode = mode;
   p.skipna = skipna != 0;
-  const size_t lds =
-      ((size_t)n_band * nwf * n_seg * p.K + (size_t)n_region * p.K) *
-      sizeof(double);
+  const size_t lds = ((size_t)n_band * nwf * n_seg * p.K +
+                      (size_t)n_region * p.K * (1 + (size_t)n_band)) *
+                     sizeof(double);
   WB2_REQUIRE(lds <= 64 * 1024,
               "region decomposition too fine for the combine kernel's LDS "
               "(%zu bytes > 64 KiB): n_band=%d n_seg=%d",
