@@ -8,11 +8,17 @@
 //   spectrum = power * circumference(latitude)                 :578-581, 626
 // and, optionally, the time mean of scripts/compute_zonal_energy_spectrum.py:234.
 //
-// The batched real-to-complex FFT along longitude is rocFFT's (through hipFFT,
-// as BASELINE.json's north_star prescribes); the hand-written epilogue fuses
-// the 1/N normalisation, |.|^2, the x2 of the non-zero wavenumbers, the
-// circumference scale and (optionally) the deterministic time mean, and widens
-// to fp64 exactly where numpy does (float32 power * int64 -> float64).
+// The batched FFT along longitude is rocFFT's (through hipFFT, as
+// BASELINE.json's north_star prescribes).  For even n_lon the row is handed to
+// rocFFT as n_lon/2 COMPLEX points (z[m] = x[2m] + i x[2m+1]) and the
+// hand-written epilogue does the real-FFT recombination itself,
+//   X[k] = E[k] + W^k O[k],  E = (Z[k] + conj Z[N/2-k]) / 2,
+//                            O = (Z[k] - conj Z[N/2-k]) / 2i,  W = exp(-2 pi i / N),
+// fused with the 1/N normalisation, |.|^2, the x2 of the non-zero wavenumbers,
+// the circumference scale and (optionally) the deterministic time mean.  That
+// removes rocFFT's separate r2c post-processing pass over the data (odd n_lon
+// falls back to rocFFT's R2C).  fp64 appears exactly where numpy widens
+// (float32 power * int64 -> float64).
 
 #include "common.hpp"
 #include "wb2hip.h"
@@ -27,9 +33,14 @@ struct SpectrumPlan {
   int dtype = 0;
   int n_lon = 0;
   long long n_rows = 0;
-  size_t complex_bytes = 0;  // [n_rows][n_lon/2+1] complex
+  size_t complex_bytes = 0;  // [n_rows][n_lon/2 (+1)] complex
   size_t fft_work_bytes = 0;
+  bool packed = false;       // even n_lon: C2C on n_lon/2 points + own recombination
 };
+
+// native 2-vectors (re, im): accepted by the nontemporal builtins
+typedef float cf32 __attribute__((ext_vector_type(2)));
+typedef double cf64 __attribute__((ext_vector_type(2)));
 
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
@@ -37,30 +48,114 @@ inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 // One thread per (output row, bin).  With n_time > 0 the thread walks the
 // n_time input rows that map onto its output row in time order (deterministic
 // mean); skipna drops NaN spectra like xbeam.Mean(skipna=True).
-template <typename T, typename C>
-__global__ void __launch_bounds__(256)
-    power_kernel(const C* __restrict__ spec, const double* __restrict__ circ,
-                 int n_lat, int n_bins, long long rows_out, long long n_time,
-                 T inv_n, int skipna, double* __restrict__ out) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows_out * n_bins) return;
-  const long long r = idx / n_bins;
-  const int k = (int)(idx - r * n_bins);
-  const double c = circ[r % n_lat];
-  const double mult = k == 0 ? 1.0 : 2.0;  // derived_variables.py:600
-  const long long nt = n_time > 0 ? n_time : 1;
-  double sum = 0.0, cnt = 0.0;
-  for (long long t = 0; t < nt; ++t) {
-    const C f = spec[(t * rows_out + r) * n_bins + k];
-    // norm='forward': pocketfft scales the transform by 1/N in the input dtype
-    const T re = f.x * inv_n, im = f.y * inv_n;
-    const T p = re * re + im * im;  // real(f * conj(f)) in the input dtype
-    const double v = ((double)p * mult) * c;
-    if (skipna && is_nan(v)) continue;
-    sum += v;
-    cnt += 1.0;
+// PACKED: `spec` holds Z = FFT_{N/2}(x[2m] + i x[2m+1]) (n_half complex per row)
+// and the real-FFT recombination happens here; otherwise `spec` already is the
+// one-sided spectrum (n_bins complex per row).
+// W^k = exp(-i pi k / n_half), k = 0..n_half, evaluated in fp64, rounded once.
+template <typename C>
+__global__ void twiddle_kernel(C* __restrict__ tw, int n_half) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_half) return;
+  double sn, cs;
+  sincospi((double)k / (double)n_half, &sn, &cs);
+  tw[k].x = cs;
+  tw[k].y = -sn;
+}
+
+// Power of one bin from the transform values (see file header).
+template <typename T, typename C, bool PACKED>
+__device__ __forceinline__ double bin_power(C a, C b, C w, T inv_n, double mult,
+                                            double c) {
+  T re, im;
+  if constexpr (PACKED) {
+    // E = (a + conj b) / 2,  O = (a - conj b) / (2i),  X = E + W^k O
+    const T er = (a.x + b.x) * (T)0.5, ei = (a.y - b.y) * (T)0.5;
+    const T orr = (a.y + b.y) * (T)0.5, oi = (b.x - a.x) * (T)0.5;
+    re = (er + (w.x * orr - w.y * oi)) * inv_n;
+    im = (ei + (w.x * oi + w.y * orr)) * inv_n;
+  } else {
+    // norm='forward': the transform is scaled by 1/N in the input dtype
+    re = a.x * inv_n;
+    im = a.y * inv_n;
   }
-  out[idx] = n_time > 0 ? sum / cnt : sum;
+  const T p = re * re + im * im;  // real(f * conj(f)) in the input dtype
+  return ((double)p * mult) * c;
+}
+
+template <typename T, typename C, bool PACKED>
+__global__ void __launch_bounds__(256)
+    power_kernel(const C* __restrict__ spec, const C* __restrict__ tw,
+                 const double* __restrict__ circ, int n_lat, int n_bins,
+                 long long rows_out, long long n_time, T inv_n, int skipna,
+                 double* __restrict__ out) {
+  // One workgroup per output row; a thread owns the bin PAIRS 2j, 2j+1 for
+  // j = tid, tid + 256, ... (16-byte loads of the transform, 16-byte stores of
+  // the powers); the row index, its circumference and all row pointers are
+  // wave-uniform.
+  typedef T C2 __attribute__((ext_vector_type(4)));        // two complex values
+  typedef double D2 __attribute__((ext_vector_type(2)));
+  const long long nt = n_time > 0 ? n_time : 1;
+  const int n_half = n_bins - 1;            // PACKED: N/2 complex points per row
+  const int row_len = PACKED ? n_half : n_bins;
+  const long long r = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (r >= rows_out) return;
+  const double c = circ[(unsigned)(r % n_lat)];
+  double* orow = out + r * n_bins;
+  const bool vec_ok = (row_len % 2 == 0) &&
+                      (reinterpret_cast<uintptr_t>(spec) % sizeof(C2) == 0);
+  const int n_pair = vec_ok ? n_bins / 2 : 0;
+  for (int j = threadIdx.x; j < n_pair; j += blockDim.x) {
+    const int k = 2 * j;
+    C w0 = {1, 0}, w1 = {1, 0};
+    if constexpr (PACKED) {
+      w0 = tw[k];
+      w1 = tw[k + 1];
+    }
+    double s0 = 0.0, s1 = 0.0, n0 = 0.0, n1 = 0.0;
+    for (long long t = 0; t < nt; ++t) {
+      const C* row = spec + (t * rows_out + r) * row_len;
+      const C2 a2 = __builtin_nontemporal_load(
+          reinterpret_cast<const C2*>(row + k));
+      const C a0 = {a2.x, a2.y}, a1 = {a2.z, a2.w};
+      C b0 = a0, b1 = a1;
+      if constexpr (PACKED) {
+        b0 = row[k == 0 ? 0 : n_half - k];
+        b1 = row[n_half - k - 1];
+      }
+      const double v0 = bin_power<T, C, PACKED>(a0, b0, w0, inv_n,
+                                                k == 0 ? 1.0 : 2.0, c);
+      const double v1 = bin_power<T, C, PACKED>(a1, b1, w1, inv_n, 2.0, c);
+      const bool k0 = !(skipna && is_nan(v0)), k1 = !(skipna && is_nan(v1));
+      s0 += k0 ? v0 : 0.0;
+      n0 += k0 ? 1.0 : 0.0;
+      s1 += k1 ? v1 : 0.0;
+      n1 += k1 ? 1.0 : 0.0;
+    }
+    D2 o;
+    o.x = n_time > 0 ? s0 / n0 : s0;
+    o.y = n_time > 0 ? s1 / n1 : s1;
+    // rows are 8-byte aligned only (n_bins is odd for even n_lon)
+    __builtin_nontemporal_store(o.x, orow + k);
+    __builtin_nontemporal_store(o.y, orow + k + 1);
+  }
+  // leftover bins (the last one when n_bins is odd; all of them if !vec_ok)
+  for (int k = 2 * n_pair + threadIdx.x; k < n_bins; k += blockDim.x) {
+    C w = {1, 0};
+    if constexpr (PACKED) w = tw[k];
+    double sum = 0.0, cnt = 0.0;
+    for (long long t = 0; t < nt; ++t) {
+      const C* row = spec + (t * rows_out + r) * row_len;
+      const C a = row[PACKED && k == n_half ? 0 : k];
+      C b = a;
+      if constexpr (PACKED) b = row[k == 0 ? 0 : n_half - k];
+      const double v = bin_power<T, C, PACKED>(a, b, w, inv_n,
+                                               k == 0 ? 1.0 : 2.0, c);
+      const bool keep = !(skipna && is_nan(v));
+      sum += keep ? v : 0.0;
+      cnt += keep ? 1.0 : 0.0;
+    }
+    orow[k] = n_time > 0 ? sum / cnt : sum;
+  }
 }
 
 }  // namespace
@@ -79,16 +174,26 @@ int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
   p->n_lon = n_lon;
   p->n_rows = n_rows;
   const int n_bins = n_lon / 2 + 1;
+  p->packed = (n_lon % 2 == 0) && n_lon >= 4;
+  const int row_len = p->packed ? n_lon / 2 : n_bins;
   p->complex_bytes =
-      (size_t)n_rows * n_bins * (dtype == WB2_F32 ? 8 : 16);
-  int n[1] = {n_lon};
+      (size_t)n_rows * row_len * (dtype == WB2_F32 ? 8 : 16);
+  int n[1] = {p->packed ? n_lon / 2 : n_lon};
   hipfftResult rc = hipfftCreate(&p->fft);
   if (rc == HIPFFT_SUCCESS) rc = hipfftSetAutoAllocation(p->fft, 0);
   size_t work = 0;
-  if (rc == HIPFFT_SUCCESS)
-    rc = hipfftMakePlanMany(p->fft, 1, n, nullptr, 1, n_lon, nullptr, 1, n_bins,
-                            dtype == WB2_F32 ? HIPFFT_R2C : HIPFFT_D2Z,
-                            (int)n_rows, &work);
+  if (rc == HIPFFT_SUCCESS) {
+    if (p->packed) {
+      rc = hipfftMakePlanMany(p->fft, 1, n, nullptr, 1, n[0], nullptr, 1, n[0],
+                              dtype == WB2_F32 ? HIPFFT_C2C : HIPFFT_Z2Z,
+                              (int)n_rows, &work);
+    } else {
+      rc = hipfftMakePlanMany(p->fft, 1, n, nullptr, 1, n_lon, nullptr, 1,
+                              n_bins,
+                              dtype == WB2_F32 ? HIPFFT_R2C : HIPFFT_D2Z,
+                              (int)n_rows, &work);
+    }
+  }
   if (rc != HIPFFT_SUCCESS) {
     if (p->fft) hipfftDestroy(p->fft);
     delete p;
@@ -110,8 +215,9 @@ int wb2_spectrum_plan_destroy(void* plan) {
 int64_t wb2_spectrum_plan_workspace(void* plan) {
   auto* p = static_cast<wb2::SpectrumPlan*>(plan);
   if (!p) return wb2::fail("null plan");
+  const size_t tw = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
   return (int64_t)(wb2::align_up(p->complex_bytes) +
-                   wb2::align_up(p->fft_work_bytes));
+                   wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw));
 }
 
 int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
@@ -132,30 +238,50 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   char* ws = static_cast<char*>(workspace);
   void* spec = ws;
   void* fft_work = ws + align_up(p->complex_bytes);
+  void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
   hipfftResult rc = hipfftSetStream(p->fft, s);
   if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
     rc = hipfftSetWorkArea(p->fft, fft_work);
   if (rc == HIPFFT_SUCCESS) {
-    rc = p->dtype == WB2_F32
-             ? hipfftExecR2C(p->fft, (hipfftReal*)x, (hipfftComplex*)spec)
-             : hipfftExecD2Z(p->fft, (hipfftDoubleReal*)x,
-                             (hipfftDoubleComplex*)spec);
+    if (p->packed) {
+      rc = p->dtype == WB2_F32
+               ? hipfftExecC2C(p->fft, (hipfftComplex*)x, (hipfftComplex*)spec,
+                               HIPFFT_FORWARD)
+               : hipfftExecZ2Z(p->fft, (hipfftDoubleComplex*)x,
+                               (hipfftDoubleComplex*)spec, HIPFFT_FORWARD);
+    } else {
+      rc = p->dtype == WB2_F32
+               ? hipfftExecR2C(p->fft, (hipfftReal*)x, (hipfftComplex*)spec)
+               : hipfftExecD2Z(p->fft, (hipfftDoubleReal*)x,
+                               (hipfftDoubleComplex*)spec);
+    }
   }
   if (rc != HIPFFT_SUCCESS) return fail("hipFFT exec failed (%d)", (int)rc);
   const int n_bins = p->n_lon / 2 + 1;
-  const long long total = rows_out * n_bins;
-  const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (p->dtype == WB2_F32) {
-    hipLaunchKernelGGL((power_kernel<float, float2>), dim3(blocks), dim3(256),
-                       0, s, (const float2*)spec, circumference, n_lat, n_bins,
-                       rows_out, (long long)n_time, 1.0f / (float)p->n_lon,
-                       skipna, out);
-  } else {
-    hipLaunchKernelGGL((power_kernel<double, double2>), dim3(blocks),
-                       dim3(256), 0, s, (const double2*)spec, circumference,
-                       n_lat, n_bins, rows_out, (long long)n_time,
-                       1.0 / (double)p->n_lon, skipna, out);
+  const unsigned gx = (unsigned)(rows_out < 65536 ? rows_out : 65536);
+  const dim3 blocks(gx, (unsigned)((rows_out + gx - 1) / gx));
+  if (p->packed) {  // 721 twiddles: regenerated per call, nothing is cached
+    const unsigned tb = (unsigned)((n_bins + 255) / 256);
+    if (p->dtype == WB2_F32)
+      hipLaunchKernelGGL((twiddle_kernel<cf32>), dim3(tb), dim3(256), 0, s,
+                         (cf32*)tw, n_bins - 1);
+    else
+      hipLaunchKernelGGL((twiddle_kernel<cf64>), dim3(tb), dim3(256), 0, s,
+                         (cf64*)tw, n_bins - 1);
   }
+#define WB2_POWER(T, C, PK)                                                   \
+  hipLaunchKernelGGL((power_kernel<T, C, PK>), blocks, dim3(256), 0, s,       \
+                     (const C*)spec, (const C*)tw, circumference, n_lat,      \
+                     n_bins, rows_out, (long long)n_time, (T)1 / (T)p->n_lon, \
+                     skipna, out)
+  if (p->dtype == WB2_F32) {
+    if (p->packed) WB2_POWER(float, cf32, true);
+    else WB2_POWER(float, cf32, false);
+  } else {
+    if (p->packed) WB2_POWER(double, cf64, true);
+    else WB2_POWER(double, cf64, false);
+  }
+#undef WB2_POWER
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }
