@@ -320,7 +320,8 @@ def secondary(args):
       if timed:
         ev[1].record()
         events.append(ev)
-    kernel = 'rocFFT R2C (N=1440, batch 74984) + power_kernel<float>'
+    kernel = ('fused_spectrum_kernel<720> (LDS real FFT + power epilogue); '
+              'WB2HIP_SPECTRUM_BACKEND=rocfft selects rocFFT C2C + power_kernel')
     workload = ('BASELINE configs[3]: zonal energy spectrum of 8 units of '
                 '13x721x1440 f32 per step, per-unit spectrum materialised')
   for i in range(args.warmup):

@@ -152,3 +152,44 @@ def test_full_size_unit_parseval_and_determinism():
   want = spectrum_np.simple_power(row[None])[0] * float(circ[300])
   got = s1[5, 300].cpu().numpy()
   assert np.max(np.abs(got - want)) / want.sum() < 2e-6
+
+
+@pytest.mark.parametrize('n_lon', [64, 128, 240, 256, 360, 512, 720, 1024, 1440])
+def test_fused_fft_matches_rocfft_path(n_lon):
+  """The single-kernel LDS FFT and the rocFFT pipeline agree to fp32 noise."""
+  import os
+  import subprocess
+  import sys
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda')
+  gen = torch.Generator(device=dev).manual_seed(n_lon)
+  n_lat = 9
+  x = torch.randn((3, n_lat, n_lon), generator=gen, device=dev)
+  lat = np.linspace(-80, 80, n_lat)
+  circ = torch.as_tensor(spectrum_np.circumference(lat)).to(dev)
+  fused = engine.zonal_spectrum(x, circ, n_lat).cpu().numpy()
+  # fp64 numpy spectrum of the same float32 data as the common yardstick
+  want = spectrum_np.simple_power(x.cpu().numpy().astype(np.float64)) * (
+      spectrum_np.circumference(lat)[None, :, None])
+  assert _row_rel_err(fused, want) < 1e-6
+  # the rocFFT path in a child process (the backend is chosen at plan creation)
+  code = (
+      'import numpy as np, torch, sys\n'
+      'sys.path.insert(0, %r)\n'
+      'from weatherbench2_amd import engine\n'
+      'from oracle import spectrum_np\n'
+      'dev = torch.device("cuda")\n'
+      'gen = torch.Generator(device=dev).manual_seed(%d)\n'
+      'x = torch.randn((3, %d, %d), generator=gen, device=dev)\n'
+      'lat = np.linspace(-80, 80, %d)\n'
+      'circ = torch.as_tensor(spectrum_np.circumference(lat)).to(dev)\n'
+      'np.save(sys.argv[1], engine.zonal_spectrum(x, circ, %d).cpu().numpy())\n'
+  ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n_lon,
+       n_lat, n_lon, n_lat, n_lat)
+  out = f'/tmp/rocfft_{n_lon}.npy'
+  env = dict(os.environ, WB2HIP_SPECTRUM_BACKEND='rocfft')
+  subprocess.run([sys.executable, '-c', code, out], check=True, env=env,
+                 timeout=300)
+  rocfft = np.load(out)
+  assert _row_rel_err(fused, rocfft) < 2e-6

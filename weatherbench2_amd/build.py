@@ -9,7 +9,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
-SOURCES = ('common.cpp', 'stream_reduce.hip', 'ensemble.hip', 'spectrum.hip')
+SOURCES = ('common.cpp', 'stream_reduce.hip', 'ensemble.hip', 'spectrum.hip',
+           'spectrum_fused.hip')
 
 
 def _hipcc() -> str:

@@ -25,7 +25,18 @@
 
 #include <hipfft/hipfft.h>
 
+#include <cstdlib>
+#include <cstring>
+
 namespace wb2 {
+
+// spectrum_fused.hip: single-kernel path (LDS FFT + fused epilogue)
+bool fused_spectrum_supported(int dtype, int n_lon);
+size_t fused_spectrum_table_bytes(int n_lon);
+int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
+                       const double* circ, int n_lat, double* out, void* tables,
+                       hipStream_t s);
+
 namespace {
 
 struct SpectrumPlan {
@@ -36,6 +47,7 @@ struct SpectrumPlan {
   size_t complex_bytes = 0;  // [n_rows][n_lon/2 (+1)] complex
   size_t fft_work_bytes = 0;
   bool packed = false;       // even n_lon: C2C on n_lon/2 points + own recombination
+  bool fused = false;        // spectrum_fused.hip handles (dtype, n_lon)
 };
 
 // native 2-vectors (re, im): accepted by the nontemporal builtins
@@ -200,6 +212,10 @@ int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
     return fail("hipFFT plan creation failed (hipfftResult %d)", (int)rc);
   }
   p->fft_work_bytes = work;
+  // WB2HIP_SPECTRUM_BACKEND=rocfft forces the two-kernel path (tests, A/B runs)
+  const char* backend = std::getenv("WB2HIP_SPECTRUM_BACKEND");
+  p->fused = fused_spectrum_supported(dtype, n_lon) &&
+             !(backend && std::strcmp(backend, "rocfft") == 0);
   *plan_out = p;
   return 0;
 }
@@ -215,7 +231,9 @@ int wb2_spectrum_plan_destroy(void* plan) {
 int64_t wb2_spectrum_plan_workspace(void* plan) {
   auto* p = static_cast<wb2::SpectrumPlan*>(plan);
   if (!p) return wb2::fail("null plan");
-  const size_t tw = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
+  size_t tw = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
+  if (p->fused && wb2::fused_spectrum_table_bytes(p->n_lon) > tw)
+    tw = wb2::fused_spectrum_table_bytes(p->n_lon);
   return (int64_t)(wb2::align_up(p->complex_bytes) +
                    wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw));
 }
@@ -239,6 +257,9 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   void* spec = ws;
   void* fft_work = ws + align_up(p->complex_bytes);
   void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
+  if (p->fused && n_time == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+    return fused_spectrum_run(static_cast<const float*>(x), p->n_rows, p->n_lon,
+                              circumference, n_lat, out, tw, s);
   hipfftResult rc = hipfftSetStream(p->fft, s);
   if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
     rc = hipfftSetWorkArea(p->fft, fft_work);
