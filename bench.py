@@ -112,7 +112,8 @@ def main():
                   help='(init, lead) units per step and per GPU')
   ap.add_argument('--pool', type=int, default=48,
                   help='distinct units resident in HBM per input')
-  ap.add_argument('--rows-per-chunk', type=int, default=16)
+  ap.add_argument('--rows-per-chunk', type=int, default=0,
+                  help='0 = plan.auto_rows_per_chunk (32 at the default batch)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--workload', default='deterministic',
                   choices=['deterministic', 'ensemble', 'spectrum'],
@@ -142,9 +143,11 @@ def main():
 
   lat = np.linspace(-90, 90, N_LAT)
   lon = np.linspace(0, 360, N_LON, endpoint=False)
+  units, pool = args.units, max(args.pool, args.units)
+  if not args.rows_per_chunk:
+    args.rows_per_chunk = plan_lib.auto_rows_per_chunk(N_LAT, units * N_LEV)
   pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(), dev,
                            rows_per_chunk=args.rows_per_chunk)
-  units, pool = args.units, max(args.pool, args.units)
   gen = torch.Generator(device=dev).manual_seed(1234 + rank)
   mk = lambda: torch.randn((pool * N_LEV, N_LAT, N_LON), generator=gen,
                            device=dev, dtype=torch.float32)
@@ -275,7 +278,7 @@ def secondary(args):
     n_slab = 13            # one unit of 13 levels per step
     pool = 4               # 4 x 13 x 50 x 4.15 MB = 10.8 GB >> Infinity Cache
     pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(),
-                             dev, rows_per_chunk=args.rows_per_chunk)
+                             dev, rows_per_chunk=args.rows_per_chunk or 16)
     ens = torch.randn((m, pool * n_slab, N_LAT, N_LON), generator=gen,
                       device=dev)
     truth = torch.randn((pool * n_slab, N_LAT, N_LON), generator=gen,

@@ -287,8 +287,10 @@ def _run_pass(mode, geo, arrays, tables, region, skipna):
   """Uploads (if needed), launches, returns {region_key: metrics[NMETRIC, ...]}."""
   device = engine.require_gpu()
   regions, rkey = _region_set_for(region)
-  pl = plan_lib.cached_plan(geo.latitude, geo.longitude, geo.layout, regions,
-                            device)
+  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
+  pl = plan_lib.cached_plan(
+      geo.latitude, geo.longitude, geo.layout, regions, device,
+      plan_lib.auto_rows_per_chunk(n_row, geo.n_outer))
   tensors = [_to_device(a, device) for a in arrays]
   dtype = torch.result_type(tensors[0], tensors[1])
   for x in tensors[2:]:
@@ -591,8 +593,10 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna):
 
   device = engine.require_gpu()
   regions, _ = _region_set_for(region)
-  pl = plan_lib.cached_plan(geo.latitude, geo.longitude, geo.layout, regions,
-                            device)
+  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
+  pl = plan_lib.cached_plan(
+      geo.latitude, geo.longitude, geo.layout, regions, device,
+      plan_lib.auto_rows_per_chunk(n_row, geo.n_outer))
   ften, tten = _to_device(fdata, device), _to_device(tdata, device)
   dtype = torch.promote_types(ften.dtype, tten.dtype)
   if dtype not in (torch.float32, torch.float64):

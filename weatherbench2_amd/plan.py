@@ -33,6 +33,19 @@ LONLAT = 'lonlat'  # slabs are (longitude, latitude): rows = longitude
 DEFAULT_ROWS_PER_CHUNK = 16
 
 
+def auto_rows_per_chunk(n_row: int, n_outer: int) -> int:
+  """Rows per workgroup-chunk for a launch of `n_outer` slabs.
+
+  Measured on MI355X (profiles/r01_rows_per_chunk.md): 24-32 rows per chunk
+  is best once the launch has thousands of workgroups (bigger chunks amortise
+  the per-workgroup prologue/fold, but 48+ starves the tail); small launches
+  (one 13-level unit) want finer chunks so that all 256 CUs get work.
+  """
+  target_workgroups = 4096
+  rows = (n_row * max(int(n_outer), 1)) // target_workgroups
+  return int(min(32, max(8, rows)))
+
+
 def _assert_increasing(x: np.ndarray):
   if not (np.diff(x) > 0).all():
     raise ValueError(f'array is not increasing: {x}')
