@@ -209,6 +209,32 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         void* stream);
 
 /*
+ * K5: the Spatial* metrics (no spatial reduction): SpatialBias / SpatialMSE /
+ * SpatialMAE (weatherbench2/metrics.py:304-374).
+ *
+ * wb2_spatial_maps: per-time maps, written in the INPUT dtype like the
+ *   reference's elementwise arrays; slab o of `forecast`/`truth` is resolved
+ *   through the optional int64[n_outer] tables; any of bias/mse/mae may be NULL.
+ *   Outputs are [n_outer][n_point].
+ * wb2_spatial_accumulate: the temporal mean of those maps (Metric.compute
+ *   :117-138; xbeam.Mean evaluation.py:740-744) without materialising them:
+ *   adds, for every (rest, point), the sum over the chunk's n_time steps of
+ *   d, d^2, |d| (d = forecast - truth in the input dtype) to
+ *   sum[3][n_rest][n_point] (order bias, mse, mae) and, when skipna, the number
+ *   of non-NaN terms to count[3][n_rest][n_point].  Slab of (time i, rest j) =
+ *   table[i * n_rest + j] (identity when NULL).
+ */
+int wb2_spatial_maps(int dtype, const void* forecast, const int64_t* f_slab,
+                     const void* truth, const int64_t* t_slab, int64_t n_outer,
+                     int64_t n_point, void* bias, void* mse, void* mae,
+                     void* stream);
+int wb2_spatial_accumulate(int dtype, int skipna, const void* forecast,
+                           const int64_t* f_slab, const void* truth,
+                           const int64_t* t_slab, int64_t n_time,
+                           int64_t n_rest, int64_t n_point, double* sum,
+                           double* count, void* stream);
+
+/*
  * K4: zonal energy spectrum, ZonalEnergySpectrum.compute
  * (weatherbench2/derived_variables.py:592-626): batched real-to-complex FFT
  * along longitude (rocFFT through hipFFT), then

@@ -49,6 +49,10 @@ _SIGNATURES = {
         _vp, _vp, _i32, _vp, _vp, _vp]),
     'wb2_ens_num_slots': (_int, [_int]),
     'wb2_ens_tile_cols': (_int, [_i32]),
+    'wb2_spatial_maps': (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
+                                _vp, _vp]),
+    'wb2_spatial_accumulate': (_int, [_int, _int, _vp, _vp, _vp, _vp, _i64,
+                                      _i64, _i64, _vp, _vp, _vp]),
     'wb2_spectrum_plan_create': (_int, [_int, _i32, _i64, _c.POINTER(_vp)]),
     'wb2_spectrum_plan_destroy': (_int, [_vp]),
     'wb2_spectrum_plan_workspace': (_i64, [_vp]),

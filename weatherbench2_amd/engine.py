@@ -239,3 +239,35 @@ def zonal_spectrum(x: torch.Tensor, circumference: torch.Tensor, n_lat: int,
       _lib.ptr(out), _lib.ptr(work), current_stream_ptr(x.device)),
              'wb2_zonal_spectrum')
   return out
+
+
+def spatial_maps(forecast: torch.Tensor, f_slab, truth: torch.Tensor, t_slab,
+                 n_outer: int, n_point: int, want=('bias', 'mse', 'mae')):
+  """K5 per-time maps: returns {name: tensor[n_outer, n_point]} (input dtype)."""
+  lib = _lib.load()
+  dev = forecast.device
+  if forecast.dtype not in _DTYPES or truth.dtype != forecast.dtype:
+    raise TypeError('forecast/truth must share a float32/float64 dtype')
+  outs = {k: torch.empty((n_outer, n_point), dtype=forecast.dtype, device=dev)
+          for k in want}
+  _lib.check(lib.wb2_spatial_maps(
+      _DTYPES[forecast.dtype], _lib.ptr(forecast), _lib.ptr(f_slab),
+      _lib.ptr(truth), _lib.ptr(t_slab), n_outer, n_point,
+      _lib.ptr(outs.get('bias')), _lib.ptr(outs.get('mse')),
+      _lib.ptr(outs.get('mae')), current_stream_ptr(dev)), 'wb2_spatial_maps')
+  return outs
+
+
+def spatial_accumulate(forecast: torch.Tensor, f_slab, truth: torch.Tensor,
+                       t_slab, n_time: int, n_rest: int, n_point: int,
+                       skipna: bool, total: torch.Tensor,
+                       count: t.Optional[torch.Tensor]):
+  """K5 temporal accumulation into total/count [3, n_rest, n_point] (fp64)."""
+  lib = _lib.load()
+  if forecast.dtype not in _DTYPES or truth.dtype != forecast.dtype:
+    raise TypeError('forecast/truth must share a float32/float64 dtype')
+  _lib.check(lib.wb2_spatial_accumulate(
+      _DTYPES[forecast.dtype], int(skipna), _lib.ptr(forecast),
+      _lib.ptr(f_slab), _lib.ptr(truth), _lib.ptr(t_slab), n_time, n_rest,
+      n_point, _lib.ptr(total), _lib.ptr(count),
+      current_stream_ptr(forecast.device)), 'wb2_spatial_accumulate')

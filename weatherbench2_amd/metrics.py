@@ -716,3 +716,152 @@ class EnsembleMeanMSE(EnsembleMetric):
 class DebiasedEnsembleMeanMSE(EnsembleMetric):
   """(t - mean)^2 - var / n (metrics.py:1336-1363); NaN for one member."""
   _metric = 'debiased_ensemble_mean_mse'
+
+
+# ---------------------------------------------------------------------------
+# Spatial* metrics (metrics.py:304-374): maps, no spatial reduction
+# ---------------------------------------------------------------------------
+def _spatial_inputs(forecast, truth, name, time_first: t.Optional[str] = None):
+  """Device tensors + slab tables of one variable for the K5 kernels."""
+  fvar, tvar = forecast[name], truth[name]
+  geo, prepared = _geometry(forecast, fvar, [tvar])
+  out_dims, out_shape = geo.out_dims, geo.out_shape
+  if time_first is not None:
+    if time_first not in out_dims:
+      raise ValueError(f'{time_first!r} missing from {out_dims}')
+    order = (time_first,) + tuple(d for d in out_dims if d != time_first)
+    out_shape = tuple(out_shape[out_dims.index(d)] for d in order)
+    out_dims = order
+  tables = [_slab_table(out_dims, out_shape, p[1], p[0].shape[:-2])
+            for p in prepared]
+  device = engine.require_gpu()
+  tensors = [_to_device(p[0], device) for p in prepared]
+  dtype = torch.promote_types(tensors[0].dtype, tensors[1].dtype)
+  if dtype not in (torch.float32, torch.float64):
+    dtype = torch.float64
+  tensors = [x if x.dtype == dtype else x.to(dtype) for x in tensors]
+  for x in tensors:
+    _check_grid(geo, x)
+  slabs = [None if tb is None else torch.from_numpy(tb).to(device)
+           for tb in tables]
+  spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
+  n_point = len(geo.latitude) * len(geo.longitude)
+  spatial_shape = tuple(tensors[0].shape[-2:])
+  return tensors, slabs, out_dims, out_shape, spatial, spatial_shape, n_point
+
+
+def _spatial_coords(forecast, dims):
+  coords = _result_coords(forecast, dims)
+  for d in _SPATIAL:
+    coords[d] = forecast.coords[d]
+  return coords
+
+
+@dataclasses.dataclass
+class _SpatialMetric(Metric):
+  """Elementwise map of forecast - truth; `skipna` is ignored by
+  compute_chunk exactly like the reference (`del skipna`)."""
+
+  _map = ''
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    del skipna  # Ignored
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    out = xl.Dataset()
+    for name in _common_vars(forecast, truth):
+      pins = (forecast[name].data, truth[name].data)
+      key = ('spatial', id(pins[0]), id(pins[1]))
+      hit = _RESULTS.get(key)
+      if hit is None:
+        (tensors, slabs, out_dims, out_shape, spatial, spatial_shape,
+         n_point) = _spatial_inputs(forecast, truth, name)
+        n_outer = int(np.prod(out_shape, dtype=np.int64))
+        maps = engine.spatial_maps(
+            tensors[0].reshape(-1, n_point), slabs[0],
+            tensors[1].reshape(-1, n_point), slabs[1], n_outer, n_point)
+        dims = tuple(out_dims) + tuple(spatial)
+        hit = (dims, {k: v.reshape(out_shape + spatial_shape)
+                      for k, v in maps.items()})
+        _RESULTS.put(key, pins, hit)
+      dims, maps = hit
+      out.coords.update(_spatial_coords(forecast, dims))
+      out.data_vars[name] = xl.DataArray(maps[self._map], dims, out.coords,
+                                         name)
+    return out
+
+  def compute(self, forecast, truth, region=None, skipna=False):
+    """Temporal mean of the map, fused: no per-time map is materialised."""
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    if 'time' in forecast.dims:
+      avg_dim = 'time'
+    elif 'init_time' in forecast.dims:
+      avg_dim = 'init_time'
+    else:
+      raise ValueError(
+          f'Forecast has neither valid_time or init_time dimension {forecast}')
+    out = xl.Dataset()
+    for name in _common_vars(forecast, truth):
+      pins = (forecast[name].data, truth[name].data)
+      key = ('spatial_mean', id(pins[0]), id(pins[1]), bool(skipna))
+      hit = _RESULTS.get(key)
+      if hit is None:
+        (tensors, slabs, out_dims, out_shape, spatial, spatial_shape,
+         n_point) = _spatial_inputs(forecast, truth, name, time_first=avg_dim)
+        n_time = out_shape[0]
+        n_rest = int(np.prod(out_shape[1:], dtype=np.int64))
+        dev = tensors[0].device
+        total = torch.zeros((3, n_rest, n_point), dtype=torch.float64,
+                            device=dev)
+        count = torch.zeros_like(total) if skipna else None
+        engine.spatial_accumulate(
+            tensors[0].reshape(-1, n_point), slabs[0],
+            tensors[1].reshape(-1, n_point), slabs[1], n_time, n_rest,
+            n_point, skipna, total, count)
+        mean = total / (count if skipna else float(n_time))
+        mean = mean.to(tensors[0].dtype).reshape(
+            (3,) + tuple(out_shape[1:]) + spatial_shape)
+        dims = tuple(out_dims[1:]) + tuple(spatial)
+        hit = (dims, {'bias': mean[0], 'mse': mean[1], 'mae': mean[2]})
+        _RESULTS.put(key, pins, hit)
+      dims, maps = hit
+      out.coords.update(_spatial_coords(forecast, dims))
+      out.data_vars[name] = xl.DataArray(maps[self._map], dims, out.coords,
+                                         name)
+    return out
+
+
+@dataclasses.dataclass
+class SpatialMSE(_SpatialMetric):
+  """MSE without spatial averaging (metrics.py:304-316)."""
+  _map = 'mse'
+
+
+@dataclasses.dataclass
+class SpatialMAE(_SpatialMetric):
+  """Mean absolute error without spatial averaging (metrics.py:333-345)."""
+  _map = 'mae'
+
+
+@dataclasses.dataclass
+class SpatialBias(_SpatialMetric):
+  """Bias without spatial averaging (metrics.py:362-374)."""
+  _map = 'bias'
+
+
+def compute_spread_skill_ratio(results: xl.Dataset) -> xl.Dataset:
+  """ensemble_stddev / ensemble_mean_rmse along the `metric` dim
+  (weatherbench2/visualization.py:136-141); expects the two metrics under those
+  names, e.g. from EnsembleStddevSqrtBeforeTimeAvg / EnsembleMeanRMSESqrtBeforeTimeAvg."""
+  labels = list(np.atleast_1d(results.coords['metric']))
+  i_std, i_rmse = labels.index('ensemble_stddev'), labels.index(
+      'ensemble_mean_rmse')
+  out = xl.Dataset(coords={k: v for k, v in results.coords.items()
+                           if k != 'metric'})
+  for name, da in results.data_vars.items():
+    ax = da.dims.index('metric')
+    a = np.take(da.values, i_std, axis=ax)
+    b = np.take(da.values, i_rmse, axis=ax)
+    with np.errstate(all='ignore'):
+      out.data_vars[name] = xl.DataArray(
+          a / b, tuple(d for d in da.dims if d != 'metric'), out.coords, name)
+  return out

@@ -308,6 +308,10 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
       if name not in d.data_vars:
         continue
       v = d.data_vars[name]
+      if v.dims != ref.dims:  # xarray aligns by name: same dims, other order
+        if sorted(v.dims) != sorted(ref.dims):
+          raise ValueError(f'{name}: cannot merge dims {v.dims} with {ref.dims}')
+        v = v.transpose(*ref.dims)
       for i, m in enumerate(np.atleast_1d(d.coords['metric'])):
         sl = [slice(None)] * len(shape)
         sl[ax] = labels.index(m)
