@@ -51,6 +51,8 @@ extern "C" {
 #define WB2_MODE_ENS 3      /* members,truth         -> CRPS & ensemble moments  metrics.py:532-846,1161-1363
                              * (partials come from wb2_ens_partials)              */
 
+#define WB2_MODE_GAUSS 4    /* mean,std,truth        -> GaussianCRPS, GaussianVariance  metrics.py:849-937 */
+
 /* number of metrics written by wb2_det_combine, in this order */
 #define WB2_NMETRIC 5
 #define WB2_METRIC_MSE 0
@@ -58,6 +60,9 @@ extern "C" {
 #define WB2_METRIC_MAE 2
 #define WB2_METRIC_BIAS 3
 #define WB2_METRIC_ACC 4
+/* WB2_MODE_GAUSS reuses the first two metric rows */
+#define WB2_GAUSS_CRPS 0
+#define WB2_GAUSS_VARIANCE 1
 
 /* metrics written by wb2_ens_combine, in this order */
 #define WB2_NMETRIC_ENS 8
@@ -77,6 +82,7 @@ const char* wb2_last_error(void);
  *   DET      : S(w d) S(w|d|) S(w d^2)                                  [+ S(w notnull d)]
  *   DET_ACC  : the above + S(w fa ta) S(w fa^2) S(w ta^2)               [+ 3 more notnull sums]
  *   WIND     : S(w (du^2+dv^2))                                         [+ 1]
+ *   GAUSS    : S(w crps) S(w std^2)                                     [+ 2]
  * The bracketed sums-of-weights exist only when skipna != 0 (xarray computes
  * them always, but without NaNs they are data independent: metrics.py:161-163). */
 int wb2_num_slots(int mode, int skipna);

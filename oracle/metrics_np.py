@@ -424,6 +424,87 @@ class DebiasedEnsembleMeanMSE(EnsembleMetric):
         region, skipna)
 
 
+# ---------------------------------------------------------------------------
+# Tier 2: Gaussian CRPS / variance (metrics.py:849-937), EnergyScore (:1402-1517)
+# ---------------------------------------------------------------------------
+def pointwise_gaussian_crps(forecast: DS, truth: DS) -> DS:
+  """metrics.py:869-905.  scipy's norm.cdf/pdf promote to float64."""
+  from scipy import stats
+  dataset = {}
+  for var_name in [v for v in forecast.keys() if f'{v}_std' in forecast.keys()]:
+    fm = DS({var_name: forecast[var_name]}, forecast.coords)
+    diff = (fm - truth)[var_name]
+    std = forecast[f'{var_name}_std']
+    if diff.dims != std.dims or diff.shape != std.shape:
+      # std follows the forecast; restrict it like the aligned difference
+      a, _ = __import__('oracle.named', fromlist=['align_inner']).align_inner(
+          DS({var_name: std}, forecast.coords), truth)
+      std = a[var_name]
+    norm_diff = diff / std
+    with np.errstate(all='ignore'):
+      inner = (norm_diff * NA(2 * stats.norm.cdf(norm_diff.data) - 1,
+                              norm_diff.dims)
+               + NA(2 * stats.norm.pdf(norm_diff.data), norm_diff.dims)
+               - 1 / np.sqrt(np.pi))
+    dataset[var_name] = std * inner
+  return DS(dataset, (fm - truth).coords)
+
+
+@dataclasses.dataclass
+class GaussianCRPS(Metric):
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    return spatial_average(pointwise_gaussian_crps(forecast, truth), region,
+                           skipna)
+
+
+@dataclasses.dataclass
+class GaussianVariance(Metric):
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    dataset = {}
+    for var_name in [v for v in forecast.keys()
+                     if f'{v}_std' in forecast.keys()]:
+      dataset[var_name] = forecast[f'{var_name}_std'] * forecast[
+          f'{var_name}_std']
+    return spatial_average(DS(dataset, forecast.coords), region, skipna)
+
+
+def _ensemble_slice(ds: DS, dim: str, sl: slice) -> DS:
+  """metrics.py:591-596: isel + relabel 0..n-1."""
+  out = ds.isel(**{dim: sl})
+  out.coords[dim] = np.arange(out.sizes[dim])
+  return out
+
+
+@dataclasses.dataclass
+class EnergyScoreSpread(EnsembleMetric):
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    n_ensemble = _get_n_ensemble(forecast, self.ensemble_dim)
+    if n_ensemble == 1:
+      return _zeros_like_spatial_mean(forecast, self.ensemble_dim, region,
+                                      skipna)
+    return spatial_average_l2_norm(
+        _ensemble_slice(forecast, self.ensemble_dim, slice(None, -1))
+        - _ensemble_slice(forecast, self.ensemble_dim, slice(1, None)),
+        region, skipna).mean(self.ensemble_dim, skipna=skipna)
+
+
+@dataclasses.dataclass
+class EnergyScoreSkill(EnsembleMetric):
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    return spatial_average_l2_norm(forecast - truth, region, skipna).mean(
+        self.ensemble_dim, skipna=skipna)
+
+
+@dataclasses.dataclass
+class EnergyScore(EnsembleMetric):
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    return EnergyScoreSkill(self.ensemble_dim).compute_chunk(
+        forecast, truth, region, skipna
+    ) - 0.5 * EnergyScoreSpread(self.ensemble_dim).compute_chunk(
+        forecast, truth, region, skipna)
+
+
 def crps_brute_force(forecast: DS, truth: DS, skipna: bool) -> dict:
   """The reference TEST's O(M^2) eFAIR CRPS (metrics_test.py:896-920)."""
 

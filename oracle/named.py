@@ -250,9 +250,10 @@ class DS:
 
   def _binary(self, other, op):
     if isinstance(other, DS):
-      names = [k for k in self.vars if k in other.vars]
-      coords = {**other.coords, **self.coords}
-      return DS({k: op(self.vars[k], other.vars[k]) for k in names}, coords)
+      a, b = align_inner(self, other)
+      names = [k for k in a.vars if k in b.vars]
+      coords = {**b.coords, **a.coords}
+      return DS({k: op(a.vars[k], b.vars[k]) for k in names}, coords)
     return DS({k: op(v, other) for k, v in self.vars.items()}, self.coords)
 
   def __add__(self, o): return self._binary(o, lambda a, b: a + b)
@@ -291,3 +292,25 @@ class DS:
 
   def __repr__(self):
     return f'DS(vars={self.vars}, coords={list(self.coords)})'
+
+
+def align_inner(a: DS, b: DS):
+  """xarray's default arithmetic join: for every dimension coordinate the two
+  operands share, keep the labels present in both (left order)."""
+  sel_a, sel_b = {}, {}
+  for d, ca in a.coords.items():
+    cb = b.coords.get(d)
+    if cb is None or isinstance(ca, NA) or isinstance(cb, NA):
+      continue
+    ca, cb = np.asarray(ca), np.asarray(cb)
+    if ca.ndim != 1 or cb.ndim != 1 or d not in a.dims or d not in b.dims:
+      continue
+    if ca.shape == cb.shape and np.array_equal(ca, cb):
+      continue
+    pos_b = {v: i for i, v in enumerate(cb.tolist())}
+    keep = [(i, pos_b[v]) for i, v in enumerate(ca.tolist()) if v in pos_b]
+    sel_a[d] = np.array([i for i, _ in keep], dtype=int)
+    sel_b[d] = np.array([j for _, j in keep], dtype=int)
+  if sel_a:
+    a, b = a.isel(**sel_a), b.isel(**sel_b)
+  return a, b

@@ -197,6 +197,72 @@ def test_debiased_mse_versus_large_ensemble():
                              atol=4 * stderr)
 
 
+def _gaussian_fixture():
+  kw = dict(variables_3d=[], time_start='2022-01-01')
+  forecast = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature', '2m_temperature_std'],
+      time_stop='2022-01-02', lead_stop='1 day', **kw)
+  truth = fixtures.mock_truth_data(variables_2d=['2m_temperature'],
+                                   time_stop='2022-01-20', **kw)
+  return forecast, truth
+
+
+def test_gaussian_crps_known_answer():
+  # metrics_test.py:286-304 (forecast and truth only share ONE time label:
+  # xarray's inner join is part of the contract)
+  forecast, truth = _gaussian_fixture()
+  forecast = forecast + 1.0
+  truth = truth + 1.02
+  result = metrics.GaussianCRPS().compute(forecast, truth)
+  np.testing.assert_allclose(result['2m_temperature'].data,
+                             np.array([0.23385455, 0.23385455]), rtol=1e-6)
+
+
+def test_gaussian_variance_known_answer():
+  # metrics_test.py:340-362
+  forecast, truth = _gaussian_fixture()
+  forecast['2m_temperature_std'] = forecast['2m_temperature_std'] + 1.0
+  result = metrics.GaussianVariance().compute(forecast, truth)
+  np.testing.assert_allclose(result['2m_temperature'].data, [1.0, 1.0])
+
+
+@pytest.mark.parametrize('ensemble_size', [1, 2, 3])
+def test_energy_score_on_random_dataset(ensemble_size):
+  # metrics_test.py:924-965
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size)
+  score = metrics.EnergyScore().compute_chunk(forecast, truth)
+  spread = metrics.EnergyScoreSpread().compute_chunk(forecast, truth)
+  skill = metrics.EnergyScoreSkill().compute_chunk(forecast, truth)
+  want_sizes = {k: v for k, v in forecast.sizes.items()
+                if k not in ('realization', 'latitude', 'longitude')}
+  for ds in (score, spread, skill):
+    assert dict(ds['geopotential'].sizes) == want_sizes
+  if ensemble_size == 1:
+    np.testing.assert_array_equal(spread['geopotential'].data, 0)
+    np.testing.assert_allclose(score['geopotential'].data,
+                               skill['geopotential'].data)
+    return
+  n = np.prod(score['geopotential'].shape)
+  np.testing.assert_allclose(
+      spread['geopotential'].data.mean(), skill['geopotential'].data.mean(),
+      atol=4 * score['geopotential'].data.std() / np.sqrt(n))
+  np.testing.assert_allclose(
+      score['geopotential'].data,
+      skill['geopotential'].data - 0.5 * spread['geopotential'].data)
+
+
+def test_energy_score_effect_of_bias():
+  # metrics_test.py:967-981
+  truth, forecast = fixtures.get_random_truth_and_forecast(ensemble_size=10)
+  truth = truth + 1000
+  score = metrics.EnergyScore().compute_chunk(forecast, truth)
+  spread = metrics.EnergyScoreSpread().compute_chunk(forecast, truth)
+  np.testing.assert_allclose(1000, score['geopotential'].data.mean(), rtol=1e-3)
+  np.testing.assert_allclose(spread['geopotential'].data.mean(), np.sqrt(2),
+                             rtol=0.05)
+
+
 def test_land_region():
   # regions_test.py:25-49
   truth, forecast = fixtures.get_random_truth_and_forecast(

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 from weatherbench2_amd import build as _build
 
 WB2_F32, WB2_F64 = 0, 1
-MODE_DET, MODE_DET_ACC, MODE_WIND = 0, 1, 2
+MODE_DET, MODE_DET_ACC, MODE_WIND, MODE_ENS, MODE_GAUSS = 0, 1, 2, 3, 4
 NMETRIC = 5
 NMETRIC_ENS = 8
 METRIC_INDEX = {'mse': 0, 'rmse': 1, 'mae': 2, 'bias': 3, 'acc': 4}

@@ -62,6 +62,10 @@ template <bool S>
 struct ModeTraits<WB2_MODE_WIND, S> {
   static constexpr int NIN = 4, KQ = 1, K = KQ + (S ? 1 : 0);
 };
+template <bool S>
+struct ModeTraits<WB2_MODE_GAUSS, S> {
+  static constexpr int NIN = 3, KQ = 2, K = KQ + (S ? 2 : 0);
+};
 
 // One grid point: inputs -> the K values whose weighted sums we need.  With
 // SKIPNA, NaN numerators become 0 and the trailing slots carry notnull() as
@@ -70,7 +74,29 @@ template <int MODE, bool SKIPNA, typename T>
 __device__ __forceinline__ void eval_slots(
     const T (&in)[ModeTraits<MODE, SKIPNA>::NIN],
     double (&x)[ModeTraits<MODE, SKIPNA>::K]) {
-  if constexpr (MODE == WB2_MODE_WIND) {
+  if constexpr (MODE == WB2_MODE_GAUSS) {
+    // metrics.py:895-905, 925-927: in = (mean, std, truth).  The normalised
+    // difference is formed in the input dtype; scipy's norm.cdf / norm.pdf
+    // promote it to float64, and so does everything downstream.
+    const T mean = in[0], sd = in[1], y = in[2];
+    const T nd = (mean - y) / sd;
+    const double z = (double)nd;
+    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
+    const double pdf = exp(-0.5 * z * z) * 0.39894228040143267794;
+    const double crps =
+        (double)sd * (z * (2.0 * cdf - 1.0) + 2.0 * pdf - 0.56418958354775628695);
+    const T var = sd * sd;
+    if constexpr (SKIPNA) {
+      const bool okc = !is_nan(crps), okv = !is_nan(var);
+      x[0] = okc ? crps : 0.0;
+      x[1] = okv ? (double)var : 0.0;
+      x[2] = okc ? 1.0 : 0.0;
+      x[3] = okv ? 1.0 : 0.0;
+    } else {
+      x[0] = crps;
+      x[1] = (double)var;
+    }
+  } else if constexpr (MODE == WB2_MODE_WIND) {
     const T du = in[0] - in[1];
     const T dv = in[2] - in[3];
     const T q = du * du + dv * dv;  // metrics.py:195-197
@@ -438,6 +464,15 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
       m[WB2_ENS_DEBIASED_MSE * stride] = s[5] / n_deb;
       continue;
     }
+    if (p.mode == WB2_MODE_GAUSS) {
+      const long long stride = (long long)p.n_region * p.n_outer;
+      double* m = p.metrics + (long long)r * p.n_outer + o;
+      m[WB2_GAUSS_CRPS * stride] = s[0] / (p.skipna ? nan_if_zero(s[2]) : wsum);
+      m[WB2_GAUSS_VARIANCE * stride] =
+          s[1] / (p.skipna ? nan_if_zero(s[3]) : wsum);
+      for (int i = 2; i < WB2_NMETRIC; ++i) m[i * stride] = nan;
+      continue;
+    }
     if (p.mode == WB2_MODE_WIND) {
       const double den = p.skipna ? nan_if_zero(s[1]) : wsum;
       mse = s[0] / den;
@@ -537,6 +572,7 @@ int launch_stream_mode(const StreamParams& p, int mode, bool vec, bool skipna,
     WB2_MODE_CASE(WB2_MODE_DET)
     WB2_MODE_CASE(WB2_MODE_DET_ACC)
     WB2_MODE_CASE(WB2_MODE_WIND)
+    WB2_MODE_CASE(WB2_MODE_GAUSS)
   }
 #undef WB2_MODE_CASE
   return fail("unknown mode %d", mode);
@@ -555,7 +591,7 @@ int threads_for(int n_col, int vec) {
 }
 
 int mode_nin(int mode) {
-  return mode == WB2_MODE_DET ? 2 : mode == WB2_MODE_DET_ACC ? 3 : 4;
+  return mode == WB2_MODE_DET ? 2 : mode == WB2_MODE_WIND ? 4 : 3;
 }
 
 }  // namespace
@@ -568,6 +604,7 @@ int wb2_num_slots(int mode, int skipna) {
     case WB2_MODE_DET: return skipna ? 4 : 3;
     case WB2_MODE_DET_ACC: return skipna ? 10 : 6;
     case WB2_MODE_WIND: return skipna ? 2 : 1;
+    case WB2_MODE_GAUSS: return skipna ? 4 : 2;
   }
   return wb2::fail("unknown mode %d", mode);
 }
@@ -587,7 +624,9 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
                         double* partials, void* stream) {
   using namespace wb2;
-  WB2_REQUIRE(mode >= 0 && mode <= 2, "unknown mode %d", mode);
+  WB2_REQUIRE(mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC ||
+                  mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS,
+              "unknown mode %d", mode);
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && seg_eoff &&
                   partials,
@@ -649,7 +688,7 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
                     const double* region_wsum, int32_t n_region, double* sums,
                     double* metrics, void* stream) {
   using namespace wb2;
-  WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_ENS, "unknown mode %d", mode);
+  WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_GAUSS, "unknown mode %d", mode);
   WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
                   region_wf && region_wsum,
               "null pointer argument");

@@ -93,11 +93,27 @@ class _LRU:
 
 _RESULTS = _LRU(8)    # fused pass results
 _DEVICE = _LRU(12)    # host array -> device tensor uploads
+_ALIGNED = _LRU(4)    # (forecast, truth) -> label-aligned views
+
+
+def _inputs(forecast, truth) -> tuple:
+  """Datasets as the reference's `forecast - truth` would see them: converted
+  at the boundary and inner-joined on their shared dimension coordinates.  The
+  aligned pair is cached by identity so that every metric of a chunk sees the
+  SAME array objects (the per-chunk result caches key on them)."""
+  forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+  key = (id(forecast), id(truth))
+  hit = _ALIGNED.get(key)
+  if hit is None:
+    hit = xl.align_inner(forecast, truth, exclude=_SPATIAL)
+    _ALIGNED.put(key, (forecast, truth), hit)
+  return hit
 
 
 def clear_caches():
   _RESULTS.clear()
   _DEVICE.clear()
+  _ALIGNED.clear()
 
 
 def _to_device(data, device) -> torch.Tensor:
@@ -403,7 +419,7 @@ class _DetMetric(Metric):
   _index: int = -1
 
   def _scalar(self, forecast, truth, region, skipna) -> xl.Dataset:
-    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    forecast, truth = _inputs(forecast, truth)
     per_var = {}
     for name in _common_vars(forecast, truth):
       geo, by_region = _det_pass(forecast, truth, name, region, skipna)
@@ -440,7 +456,7 @@ class WindVectorMSE(Metric):
   _index = _lib.METRIC_INDEX['mse']
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    forecast, truth = _inputs(forecast, truth)
     geo, by_region = _wind_pass(forecast, truth, self.u_name, self.v_name,
                                 region, skipna)
     _, rkey = _region_set_for(region)
@@ -519,7 +535,7 @@ class ACC(Metric):
   climatology: t.Any = None
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    forecast, truth = _inputs(forecast, truth)
     climatology = xl.as_dataset(self.climatology)
     per_var = {}
     _get_climatology_chunk(climatology, truth)  # KeyError like the reference
@@ -638,7 +654,7 @@ class EnsembleMetric(Metric):
   _truth_first = True
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    forecast, truth = _inputs(forecast, truth)
     _get_n_ensemble(forecast, self.ensemble_dim)  # raises like the reference
     per_var = {}
     for name in _common_vars(forecast, truth):
@@ -766,7 +782,7 @@ class _SpatialMetric(Metric):
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
     del skipna  # Ignored
-    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    forecast, truth = _inputs(forecast, truth)
     out = xl.Dataset()
     for name in _common_vars(forecast, truth):
       pins = (forecast[name].data, truth[name].data)
@@ -791,7 +807,7 @@ class _SpatialMetric(Metric):
 
   def compute(self, forecast, truth, region=None, skipna=False):
     """Temporal mean of the map, fused: no per-time map is materialised."""
-    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+    forecast, truth = _inputs(forecast, truth)
     if 'time' in forecast.dims:
       avg_dim = 'time'
     elif 'init_time' in forecast.dims:
@@ -865,3 +881,108 @@ def compute_spread_skill_ratio(results: xl.Dataset) -> xl.Dataset:
       out.data_vars[name] = xl.DataArray(
           a / b, tuple(d for d in da.dims if d != 'metric'), out.coords, name)
   return out
+
+
+# ---------------------------------------------------------------------------
+# Tier 2: Gaussian forecasts (metrics.py:849-937) and the energy score
+# (metrics.py:1402-1517)
+# ---------------------------------------------------------------------------
+def _gauss_pass(forecast, truth, name, region, skipna):
+  mvar, svar, tvar = forecast[name], forecast[f'{name}_std'], truth[name]
+  pins = [mvar.data, svar.data, tvar.data]
+  key = _result_key('gauss', pins, region, skipna)
+  hit = _RESULTS.get(key)
+  if hit is not None:
+    return hit
+  geo, prepared = _geometry(forecast, mvar, [svar, tvar])
+  tables = [_slab_table(geo.out_dims, geo.out_shape, p[1], p[0].shape[:-2])
+            for p in prepared]
+  by_region, _ = _run_pass(_lib.MODE_GAUSS, geo, [p[0] for p in prepared],
+                           tables, region, skipna)
+  value = (geo, by_region)
+  _RESULTS.put(key, tuple(pins), value)
+  return value
+
+
+class _GaussianMetric(Metric):
+  _row = 0
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = _inputs(forecast, truth)
+    per_var = {}
+    for name in [v for v in forecast.keys() if f'{v}_std' in forecast.keys()]:
+      if name not in truth:
+        raise KeyError(name)
+      geo, by_region = _gauss_pass(forecast, truth, name, region, skipna)
+      _, rkey = _region_set_for(region)
+      per_var[name] = (geo.out_dims, by_region[rkey][self._row])
+    return _assemble(forecast, per_var)
+
+
+@dataclasses.dataclass
+class GaussianCRPS(_GaussianMetric):
+  """The analytical CRPS of a Gaussian forecast given as `<var>` (mean) and
+  `<var>_std` (metrics.py:849-905)."""
+  _row = 0
+
+
+@dataclasses.dataclass
+class GaussianVariance(_GaussianMetric):
+  """The variance of a Gaussian forecast (metrics.py:908-937)."""
+  _row = 1
+
+
+@dataclasses.dataclass
+class EnergyScoreSkill(EnsembleMetric):
+  """E||X - Y||: member-wise area-weighted L2 norms, averaged over members
+  (metrics.py:1501-1517).  Each member is one slab set of the fused
+  deterministic pass -- no new kernel."""
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = _inputs(forecast, truth)
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    rmse = RMSESqrtBeforeTimeAvg().compute_chunk(forecast, truth, region=region,
+                                                 skipna=skipna)
+    return rmse.mean(self.ensemble_dim, skipna=skipna)
+
+
+@dataclasses.dataclass
+class EnergyScoreSpread(EnsembleMetric):
+  """E||X - X'|| from the N-1 adjacent member differences
+  (metrics.py:1468-1498)."""
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = _inputs(forecast, truth)
+    n_ensemble = _get_n_ensemble(forecast, self.ensemble_dim)
+    if n_ensemble == 1:
+      base = RMSESqrtBeforeTimeAvg().compute_chunk(
+          forecast, truth, region=region, skipna=skipna).mean(
+              self.ensemble_dim, skipna=skipna)
+      return base.map(lambda v: xl.DataArray(np.zeros_like(v.values), v.dims,
+                                             v.coords, v.name))
+    key = ('escore_slices', id(forecast))
+    hit = _ALIGNED.get(key)
+    if hit is None:
+      relabel = lambda ds: xl.Dataset(
+          dict(ds.data_vars),
+          {**ds.coords,
+           self.ensemble_dim: np.arange(ds.sizes[self.ensemble_dim])})
+      hit = (relabel(forecast.isel(**{self.ensemble_dim: slice(None, -1)})),
+             relabel(forecast.isel(**{self.ensemble_dim: slice(1, None)})))
+      _ALIGNED.put(key, (forecast,), hit)
+    lo, hi = hit
+    rmse = RMSESqrtBeforeTimeAvg().compute_chunk(lo, hi, region=region,
+                                                 skipna=skipna)
+    return rmse.mean(self.ensemble_dim, skipna=skipna)
+
+
+@dataclasses.dataclass
+class EnergyScore(EnsembleMetric):
+  """ES = E||X - Y|| - 0.5 E||X - X'|| (metrics.py:1402-1465)."""
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    skill = EnergyScoreSkill(self.ensemble_dim).compute_chunk(
+        forecast, truth, region=region, skipna=skipna)
+    spread = EnergyScoreSpread(self.ensemble_dim).compute_chunk(
+        forecast, truth, region=region, skipna=skipna)
+    return skill - 0.5 * spread

@@ -322,6 +322,37 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
   return out
 
 
+def _index_or_slice(idx: np.ndarray):
+  """A contiguous ascending run becomes a slice (a view, no copy)."""
+  if len(idx) and np.array_equal(idx, np.arange(idx[0], idx[0] + len(idx))):
+    return slice(int(idx[0]), int(idx[0]) + len(idx))
+  return idx
+
+
+def align_inner(a: Dataset, b: Dataset, exclude=()) -> tuple:
+  """xarray's default arithmetic join for `a (op) b`: every dimension
+  coordinate the two share keeps the labels present in both (left order).
+  Returns the inputs themselves when nothing needs aligning."""
+  sel_a, sel_b = {}, {}
+  for d, ca in a.coords.items():
+    cb = b.coords.get(d)
+    if (cb is None or d in exclude or isinstance(ca, DataArray)
+        or isinstance(cb, DataArray) or d not in a.dims or d not in b.dims):
+      continue
+    ca, cb = np.asarray(ca), np.asarray(cb)
+    if ca.ndim != 1 or cb.ndim != 1:
+      continue
+    if ca.shape == cb.shape and np.array_equal(ca, cb):
+      continue
+    pos_b = {v: i for i, v in enumerate(cb.tolist())}
+    keep = [(i, pos_b[v]) for i, v in enumerate(ca.tolist()) if v in pos_b]
+    sel_a[d] = _index_or_slice(np.array([i for i, _ in keep], dtype=np.int64))
+    sel_b[d] = _index_or_slice(np.array([j for _, j in keep], dtype=np.int64))
+  if not sel_a:
+    return a, b
+  return a.isel(**sel_a), b.isel(**sel_b)
+
+
 # -- optional bridges to real xarray -----------------------------------------
 def from_xarray(ds) -> Dataset:
   coords = {}
