@@ -30,8 +30,9 @@ def needs_rebuild() -> bool:
   if not os.path.exists(LIB_PATH):
     return True
   t = os.path.getmtime(LIB_PATH)
-  deps = sources() + [os.path.join(CSRC, 'common.hpp'),
-                      os.path.join(ROOT, 'include', 'wb2hip.h')]
+  deps = sources() + [os.path.join(CSRC, h) for h in
+                      ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc')
+                      ] + [os.path.join(ROOT, 'include', 'wb2hip.h')]
   return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

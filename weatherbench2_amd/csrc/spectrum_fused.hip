@@ -23,6 +23,13 @@
 #include "common.hpp"
 #include "wb2hip.h"
 
+#ifndef WB2_FFT_TW_POWERS
+#define WB2_FFT_TW_POWERS 1
+#endif
+#ifndef WB2_FFT_TW_GLOBAL
+#define WB2_FFT_TW_GLOBAL 0   // 1: read the pass twiddles from global/L1, not LDS
+#endif
+
 namespace wb2 {
 namespace fused {
 
@@ -88,9 +95,21 @@ __device__ __forceinline__ void butterfly<5>(cf (&a)[5]) {
   a[3] = m2 - n2;
 }
 
+#ifndef WB2_FFT_ODD_FIRST
+#define WB2_FFT_ODD_FIRST 0
+#endif
+#ifndef WB2_FFT_MIN_WAVES
+#define WB2_FFT_MIN_WAVES 1
+#endif
 constexpr int pick_radix(int remaining) {
+#if WB2_FFT_ODD_FIRST
+  // odd radices first: their strided LDS writes (NS small) are conflict-free
+  return remaining % 5 == 0 ? 5 : remaining % 3 == 0 ? 3
+       : remaining % 4 == 0 ? 4 : remaining % 2 == 0 ? 2 : 0;
+#else
   return remaining % 4 == 0 ? 4 : remaining % 2 == 0 ? 2
        : remaining % 3 == 0 ? 3 : remaining % 5 == 0 ? 5 : 0;
+#endif
 }
 constexpr bool supported_half(int n2) {
   int r = n2;
@@ -126,8 +145,19 @@ __device__ __forceinline__ void stockham_pass(cf* __restrict__ z,
     if (j < T) {
       const int k = j % NS;
       if constexpr (NS > 1) {
+#if WB2_FFT_TW_POWERS
+        // one table read per butterfly; higher powers by multiplication
+        const cf w1 = twz[k * TWS];
+        cf w = w1;
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+          v[rd][r] = cmul(v[rd][r], w);
+          if (r + 1 < R) w = cmul(w, w1);
+        }
+#else
 #pragma unroll
         for (int r = 1; r < R; ++r) v[rd][r] = cmul(v[rd][r], twz[k * r * TWS]);
+#endif
       }
       butterfly<R>(v[rd]);
     }
@@ -168,7 +198,7 @@ struct FusedParams {
 };
 
 template <int N2>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     fused_spectrum_kernel(const FusedParams p) {
   constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = 4;
   constexpr int NH = N2 / 2 + 1;  // bin pairs (k, N2 - k), k = 0..N2/2
@@ -202,7 +232,11 @@ __global__ void __launch_bounds__(256)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if WB2_FFT_TW_GLOBAL
+    stockham_all<N2, 1>(z, p.twz, lane);
+#else
     stockham_all<N2, 1>(z, s_twz, lane);
+#endif
     // ---- recombination + power for the bin pairs (k, N2 - k) ----
     const double c = p.circ[(unsigned)(row % p.n_lat)];
     double* orow = p.out + row * NB;
