@@ -290,3 +290,47 @@ def test_full_size_properties():
   mp, _ = engine.stream_reduce(pl, _lib.MODE_DET, [f[perm].contiguous(), t],
                                [None, perm.to(torch.int64)], n_lev, False)
   assert torch.equal(mp[0], m1[0][:, perm])
+
+
+def test_baseline_config0_64x32_weighted_rmse(gm):
+  """BASELINE configs[0]: 64x32 equiangular grid WITHOUT poles, one level, one
+  init time, float64 N(0,1) truth (seed 0) / forecast (seed 1): WeightedRMSE."""
+  lat = np.linspace(-87.1875, 87.1875, 32)
+  lon = np.linspace(0, 360, 64, endpoint=False)
+  dims = ('time', 'longitude', 'latitude')
+  coords = {'time': np.array(['2020-01-01'], dtype='datetime64[ns]'),
+            'latitude': lat, 'longitude': lon}
+  truth = DS({'z': NA(np.random.RandomState(0).normal(size=(1, 64, 32)), dims)},
+             coords)
+  forecast = DS({'z': NA(np.random.RandomState(1).normal(size=(1, 64, 32)),
+                         dims)}, coords)
+  want = om.RMSESqrtBeforeTimeAvg().compute(forecast, truth)
+  g = helpers.to_gpu_dataset
+  got = gm.RMSESqrtBeforeTimeAvg().compute(g(forecast), g(truth))
+  helpers.assert_close(got['z'].values, want['z'].data, rtol=1e-12)
+  mse = gm.MSE().compute(g(forecast), g(truth))
+  helpers.assert_close(np.sqrt(mse['z'].values), want['z'].data, rtol=1e-12)
+
+
+def test_more_than_32767_slabs(gm):
+  """Low-resolution in-memory evaluation has very many (time, lead, level)
+  slabs: the (y, z) launch grid must cover n_outer > 32767 exactly."""
+  rs = np.random.RandomState(3)
+  n_time, n_lev, n_lon, n_lat = 2731, 13, 8, 5   # 35503 slabs
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  dims = ('time', 'level', 'longitude', 'latitude')
+  coords = {'time': np.arange(n_time), 'level': np.arange(n_lev),
+            'latitude': lat, 'longitude': lon}
+  f = DS({'z': NA(rs.standard_normal((n_time, n_lev, n_lon, n_lat)
+                                     ).astype(np.float32), dims)}, coords)
+  t = DS({'z': NA(rs.standard_normal((n_time, n_lev, n_lon, n_lat)
+                                     ).astype(np.float32), dims)}, coords)
+  g = helpers.to_gpu_dataset
+  for oc, gc in ((om.MSE(), gm.MSE()), (om.Bias(), gm.Bias())):
+    want = oc.compute_chunk(f, t)
+    got = gc.compute_chunk(g(f), g(t))
+    helpers.assert_close(got['z'].values, want['z'].data, rtol=1e-9, atol=1e-12)
+  want = om.SpatialMAE().compute_chunk(f, t)
+  got = gm.SpatialMAE().compute_chunk(g(f), g(t))
+  np.testing.assert_array_equal(got['z'].values, want['z'].data)

@@ -191,13 +191,15 @@ __global__ void __launch_bounds__(256)
   const int row0 = p.chunk_row0[chunk];
   const int nrow = p.chunk_nrow[chunk];
   const long long* dummy = reinterpret_cast<const long long*>(p.chunk_row0);
-  const long long es_v = (p.ens_slab ? p.ens_slab : dummy)[p.ens_slab ? o : 0];
+  const bool o_ok = o < p.n_outer;  // the (y, z) grid may overshoot n_outer
+  const long long es_v =
+      (p.ens_slab ? p.ens_slab : dummy)[(p.ens_slab && o_ok) ? o : 0];
   const long long ts_v =
-      (p.truth_slab ? p.truth_slab : dummy)[p.truth_slab ? o : 0];
+      (p.truth_slab ? p.truth_slab : dummy)[(p.truth_slab && o_ok) ? o : 0];
   const long long es = p.ens_slab ? es_v : o, ts = p.truth_slab ? ts_v : o;
   const int col0 = tile * kWave + lane;
   const bool active = tile < p.n_ctile && col0 < p.n_col;
-  if (nrow <= 0 || tile >= p.n_ctile) return;
+  if (nrow <= 0 || tile >= p.n_ctile || !o_ok) return;
   const int M = MS > 0 ? MS : p.n_member;
 
   double acc[NWF][1][K];
@@ -329,9 +331,8 @@ int wb2_ens_partials(int dtype, int skipna, const void* ens,
                   n_seg > 0 && n_ts >= n_seg,
               "bad sizes");
   WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
-  WB2_REQUIRE(n_outer < 32768 || n_outer % 32768 == 0,
-              "n_outer=%lld: above 32767 slabs n_outer must be a multiple of "
-              "32768 (split the call)", (long long)n_outer);
+  WB2_REQUIRE(n_outer < (1ll << 31), "n_outer=%lld too large",
+              (long long)n_outer);
   WB2_REQUIRE(n_ctile == (n_col + kWave - 1) / kWave,
               "n_ctile=%d does not match ceil(n_col / 64)", n_ctile);
   if (n_outer == 0) return 0;

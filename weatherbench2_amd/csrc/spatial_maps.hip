@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(256) spatial_maps_kernel(const SpatialParams p
   const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (q >= p.n_point) return;
   const long long o = blockIdx.y + (long long)blockIdx.z * gridDim.y;
+  if (o >= p.n_time) return;  // n_time carries n_outer here
   const long long fs = p.f_slab ? p.f_slab[o] : o;
   const long long ts = p.t_slab ? p.t_slab[o] : o;
   T f[VEC], t[VEC], d[VEC], d2[VEC], ad[VEC];
@@ -89,6 +90,7 @@ __global__ void __launch_bounds__(256)
   const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (q >= p.n_point) return;
   const long long j = blockIdx.y + (long long)blockIdx.z * gridDim.y;
+  if (j >= p.n_rest) return;
   double s[3][VEC], c[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
@@ -177,9 +179,6 @@ int wb2_spatial_maps(int dtype, const void* forecast, const int64_t* f_slab,
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(forecast && truth, "null pointer argument");
   WB2_REQUIRE(n_outer >= 0 && n_point > 0, "bad sizes");
-  WB2_REQUIRE(n_outer < 32768 || n_outer % 32768 == 0,
-              "n_outer=%lld: above 32767 slabs n_outer must be a multiple of "
-              "32768", (long long)n_outer);
   if (n_outer == 0) return 0;
   SpatialParams p{};
   p.f = forecast;
@@ -190,6 +189,7 @@ int wb2_spatial_maps(int dtype, const void* forecast, const int64_t* f_slab,
   p.out[1] = mse;
   p.out[2] = mae;
   p.n_point = n_point;
+  p.n_time = n_outer;
   const int vec = pick_vec(dtype, n_point, forecast, truth, p.out);
   const dim3 grid = grid_for(n_point, vec, n_outer);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -212,7 +212,6 @@ int wb2_spatial_accumulate(int dtype, int skipna, const void* forecast,
   WB2_REQUIRE(forecast && truth && sum && (count || !skipna),
               "null pointer argument");
   WB2_REQUIRE(n_time >= 0 && n_rest > 0 && n_point > 0, "bad sizes");
-  WB2_REQUIRE(n_rest < 32768 || n_rest % 32768 == 0, "n_rest too ragged");
   if (n_time == 0) return 0;
   SpatialParams p{};
   p.f = forecast;

@@ -228,12 +228,12 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
     // unconditional (chunk tables are >= 8 ints, i.e. >= 4 readable int64).
     const long long* tab =
         p.slab[i] ? p.slab[i] : reinterpret_cast<const long long*>(p.chunk_row0);
-    const long long v = tab[p.slab[i] ? o : 0];
+    const long long v = tab[(p.slab[i] && o < p.n_outer) ? o : 0];
     slab_idx[i] = p.slab[i] ? v : o;
   }
   const int col0 = tile * TILE + lane * VEC;
   const bool active = tile < p.n_ctile && col0 < p.n_col;
-  if (nrow <= 0 || tile >= p.n_ctile) return;  // wave-uniform
+  if (nrow <= 0 || tile >= p.n_ctile || o >= p.n_outer) return;  // wave-uniform
 
   double acc[NWF][VEC][K];
 #pragma unroll
@@ -539,9 +539,7 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
   const int nwave = threads / kWave;
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
-  const long long gz = (p.n_outer + gy - 1) / gy;
-  if (gy * gz != p.n_outer)
-    return fail("n_outer=%lld is not a multiple of 32768", p.n_outer);
+  const long long gz = (p.n_outer + gy - 1) / gy;  // kernel guards o < n_outer
   const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
   hipLaunchKernelGGL((stream_partials_kernel<T, VEC, MODE, SKIPNA, WF>), grid,
                      dim3(threads), 0, stream, p);
@@ -637,9 +635,8 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
               (long long)n_outer, n_row, n_col, n_chunk, n_seg);
   if (n_outer == 0) return 0;
   WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
-  WB2_REQUIRE(n_outer < 32768 || n_outer % 32768 == 0,
-              "n_outer=%lld: above 32767 slabs n_outer must be a multiple of "
-              "32768 (split the call)", (long long)n_outer);
+  WB2_REQUIRE(n_outer < (1ll << 31), "n_outer=%lld too large",
+              (long long)n_outer);
   StreamParams p{};
   const int nin = mode_nin(mode);
   bool aligned = true;
