@@ -505,6 +505,180 @@ class EnergyScore(EnsembleMetric):
         forecast, truth, region, skipna)
 
 
+# ---------------------------------------------------------------------------
+# Tier 2: threshold metrics (metrics.py:940-1158 Gaussian, :1524-1891 ensemble)
+# ---------------------------------------------------------------------------
+def _where01(cond: NA) -> NA:
+  """xr.where(cond, 1.0, 0.0) -> float64."""
+  return NA(np.where(cond.data, 1.0, 0.0), cond.dims)
+
+
+def _ds_binary(a: DS, b: DS, fn) -> DS:
+  from oracle.named import align_inner
+  a, b = align_inner(a, b)
+  names = [k for k in a.keys() if k in b.keys()]
+  return DS({k: fn(a[k], b[k]) for k in names}, {**b.coords, **a.coords})
+
+
+def _gauss_vars(forecast: DS):
+  return [v for v in forecast.keys() if f'{v}_std' in forecast.keys()]
+
+
+def _norm_threshold(forecast: DS, threshold: DS, var: str) -> NA:
+  # threshold - forecast: dims of the threshold come first
+  return (threshold[var] - forecast[var]) / forecast[f'{var}_std']
+
+
+def _cdf(x: NA) -> NA:
+  from scipy import stats
+  return NA(stats.norm.cdf(x.data), x.dims)
+
+
+def compute_gaussian_brier_score(forecast, truth, threshold):
+  """metrics.py:975-1000."""
+  tp = _ds_binary(truth, threshold, lambda a, b: _where01(a > b))
+  fp = DS({v: 1 - _cdf(_norm_threshold(forecast, threshold, v))
+           for v in _gauss_vars(forecast)}, forecast.coords)
+  return (fp - tp) ** 2
+
+
+def compute_gaussian_ignorance_score(forecast, truth, threshold):
+  """metrics.py:1043-1066."""
+  tp = _ds_binary(truth, threshold, lambda a, b: _where01(a > b))
+  out = {}
+  for v in _gauss_vars(forecast):
+    cdf = _cdf(_norm_threshold(forecast, threshold, v))
+    with np.errstate(all='ignore'):
+      a, b, dims = NA._align(tp[v], cdf)
+      out[v] = NA(-np.where(a, np.log(1 - b), np.log(b)), dims)
+  return DS(out, forecast.coords)
+
+
+def compute_gaussian_rps_part(forecast, truth, threshold):
+  """metrics.py:1104-1121."""
+  te = _ds_binary(truth, threshold, lambda a, b: _where01(a < b))
+  fc = DS({v: _cdf(_norm_threshold(forecast, threshold, v))
+           for v in _gauss_vars(forecast)}, forecast.coords)
+  return (fc - te) ** 2
+
+
+def _nan_where_null(x: NA, values: NA) -> NA:
+  a, b, dims = NA._align(x, values)
+  return NA(np.where(np.isnan(a), np.nan, b), dims)
+
+
+def compute_brier_score(forecast, truth, threshold, ensemble_dim, debias,
+                        skipna):
+  """metrics.py:1524-1560."""
+  tp = _ds_binary(truth, threshold,
+                  lambda a, b: _nan_where_null(a, _where01(a > b)))
+  fp = _ds_binary(forecast, threshold,
+                  lambda a, b: _nan_where_null(a, _where01(a > b)))
+  if debias:
+    return debiased_ensemble_mean_mse(fp, tp, ensemble_dim, skipna)
+  return (fp.mean(ensemble_dim, skipna=skipna) - tp) ** 2
+
+
+def compute_ignorance_score(forecast, truth, threshold, ensemble_dim, skipna):
+  """metrics.py:1720-1738."""
+  tp = _ds_binary(truth, threshold, lambda a, b: _where01(a > b))
+  fp = _ds_binary(forecast, threshold, lambda a, b: _where01(a > b)).mean(
+      ensemble_dim, skipna=skipna)
+  out = {}
+  for v in fp.keys():
+    with np.errstate(all='ignore'):
+      a, b, dims = NA._align(tp[v], fp[v])
+      out[v] = NA(-np.where(a, np.log(b), np.log(1 - b)), dims)
+  return DS(out, fp.coords)
+
+
+def compute_rps_part(forecast, truth, threshold, ensemble_dim, skipna):
+  """metrics.py:1791-1802."""
+  te = _ds_binary(truth, threshold, lambda a, b: _where01(a < b))
+  fe = _ds_binary(forecast, threshold, lambda a, b: _where01(a < b)).mean(
+      ensemble_dim, skipna=skipna)
+  return (fe - te) ** 2
+
+
+@dataclasses.dataclass
+class ThresholdMetric(Metric):
+  thresholds: t.Sequence = ()
+  _score = None
+  _sum_over_quantile = False
+
+  def _score_fn(self, skipna):
+    return self._score
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    """metrics.py:947-972 (_map_over_thresholds, spatial_agg=True)."""
+    scores = []
+    for threshold in self.thresholds:
+      threshold_ds = threshold.compute(truth)
+      score = self._score_fn(skipna)(forecast, truth, threshold_ds)
+      score = spatial_average(score, region=region, skipna=skipna)
+      scores.append(score)
+    out = DS({k: NA(np.stack([s[k].data for s in scores]),
+                    ('quantile',) + scores[0][k].dims)
+              for k in scores[0].keys()},
+             {**scores[0].coords,
+              'quantile': np.array([th.quantile for th in self.thresholds])})
+    if self._sum_over_quantile:
+      coords = {k: c for k, c in out.coords.items() if k != 'quantile'}
+      out = DS({k: v.sum('quantile') for k, v in out.items()}, coords)
+    return out
+
+
+@dataclasses.dataclass
+class GaussianBrierScore(ThresholdMetric):
+  _score = staticmethod(compute_gaussian_brier_score)
+
+
+@dataclasses.dataclass
+class GaussianIgnoranceScore(ThresholdMetric):
+  _score = staticmethod(compute_gaussian_ignorance_score)
+
+
+@dataclasses.dataclass
+class GaussianRPS(ThresholdMetric):
+  _score = staticmethod(compute_gaussian_rps_part)
+  _sum_over_quantile = True
+
+
+@dataclasses.dataclass
+class _EnsembleThresholdMetric(ThresholdMetric):
+  ensemble_dim: str = REALIZATION
+
+
+@dataclasses.dataclass
+class EnsembleBrierScore(_EnsembleThresholdMetric):
+  def _score_fn(self, skipna):
+    return lambda f, t_, th: compute_brier_score(
+        f, t_, th, self.ensemble_dim, False, skipna)
+
+
+@dataclasses.dataclass
+class DebiasedEnsembleBrierScore(_EnsembleThresholdMetric):
+  def _score_fn(self, skipna):
+    return lambda f, t_, th: compute_brier_score(
+        f, t_, th, self.ensemble_dim, True, skipna)
+
+
+@dataclasses.dataclass
+class EnsembleIgnoranceScore(_EnsembleThresholdMetric):
+  def _score_fn(self, skipna):
+    return lambda f, t_, th: compute_ignorance_score(
+        f, t_, th, self.ensemble_dim, skipna)
+
+
+@dataclasses.dataclass
+class EnsembleRPS(_EnsembleThresholdMetric):
+  _sum_over_quantile = True
+
+  def _score_fn(self, skipna):
+    return lambda f, t_, th: compute_rps_part(
+        f, t_, th, self.ensemble_dim, skipna)
+
+
 def crps_brute_force(forecast: DS, truth: DS, skipna: bool) -> dict:
   """The reference TEST's O(M^2) eFAIR CRPS (metrics_test.py:896-920)."""
 

@@ -1,0 +1,162 @@
+"""Pins the oracle's threshold-metric family against the reference's own
+known-answer tests (metrics_test.py:366-535, 985-1030, 1290-1388).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import fixtures
+from oracle import metrics_np as metrics
+from oracle import thresholds_np as thresholds
+from oracle.named import DS, NA
+
+KW = dict(variables_3d=[], time_start='2022-01-01', time_stop='2022-01-02')
+
+
+def _clim_like(truth, expand, rename=None, add=0.0):
+  """truth.isel(time=0, drop=True).expand_dims(...).rename(...)"""
+  ds = (truth + add).isel(time=0)
+  for dim, coord in reversed(list(expand.items())):
+    ds = ds.expand_dims(dim, coord=coord)
+  return ds.rename_vars(rename) if rename else ds
+
+
+def _merge(*dss):
+  out, coords = {}, {}
+  for d in dss:
+    out.update(d.vars)
+    coords.update(d.coords)
+  return DS(out, coords)
+
+
+def gaussian_case(error):
+  forecast = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature', '2m_temperature_std'], lead_stop='1 day',
+      **KW)
+  truth = fixtures.mock_truth_data(variables_2d=['2m_temperature'], **KW) + 1.0
+  forecast = forecast + 1.0 + error
+  doy = {'dayofyear': 1 + np.arange(366)}
+  clim = _merge(_clim_like(truth, doy),
+                _clim_like(truth, doy,
+                           {'2m_temperature': '2m_temperature_std'}))
+  qclim = _clim_like(truth, {'quantile': np.array([0.8]), **doy},
+                     {'2m_temperature': '2m_temperature_quantile'})
+  return forecast, truth, clim, qclim
+
+
+@pytest.mark.parametrize('error,e1,e2', [(0.02, 0.04421, 0.257883),
+                                         (1e6, 0.70786, 0.707861)])
+def test_gaussian_brier_score(error, e1, e2):
+  forecast, truth, clim, qclim = gaussian_case(error)
+  th = thresholds.GaussianQuantileThreshold(climatology=clim, quantile=0.8)
+  res = metrics.GaussianBrierScore(thresholds=[th]).compute(forecast, truth)
+  np.testing.assert_allclose(res['2m_temperature'].data, [[e1, e1]], rtol=1e-4)
+  th = thresholds.QuantileThreshold(climatology=qclim, quantile=0.8)
+  res = metrics.GaussianBrierScore(thresholds=[th]).compute(forecast, truth)
+  np.testing.assert_allclose(res['2m_temperature'].data, [[e2, e2]], rtol=1e-4)
+
+
+@pytest.mark.parametrize('error,expected', [(0.02, 0.236055), (1e6, 1.841019)])
+def test_gaussian_ignorance_score(error, expected):
+  forecast, truth, clim, _ = gaussian_case(error)
+  th = thresholds.GaussianQuantileThreshold(climatology=clim, quantile=0.8)
+  res = metrics.GaussianIgnoranceScore(thresholds=[th]).compute(forecast, truth)
+  np.testing.assert_allclose(res['2m_temperature'].data,
+                             [[expected, expected]], rtol=1e-4)
+
+
+def rps_climatology(truth0):
+  doy = {'dayofyear': 1 + np.arange(366)}
+  parts = []
+  for q, add in ((0.33, 0.0), (0.66, 1.0), (1.0, 2.0)):
+    parts.append(_clim_like(truth0, {'quantile': np.array([q]), **doy},
+                            {'2m_temperature': '2m_temperature_quantile'}, add))
+  data = np.concatenate([p['2m_temperature_quantile'].data for p in parts], 0)
+  coords = dict(parts[0].coords)
+  coords['quantile'] = np.array([0.33, 0.66, 1.0])
+  return DS({'2m_temperature_quantile':
+             NA(data, parts[0]['2m_temperature_quantile'].dims)}, coords)
+
+
+@pytest.mark.parametrize('error,expected', [(0.02, 0.295746), (1e6, 0.758203)])
+def test_gaussian_rps(error, expected):
+  forecast = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature', '2m_temperature_std'], lead_stop='1 day',
+      **KW)
+  truth0 = fixtures.mock_truth_data(variables_2d=['2m_temperature'], **KW)
+  clim = rps_climatology(truth0)
+  truth = truth0 + 1.0
+  forecast = forecast + 1.0 + error
+  ths = [thresholds.QuantileThreshold(climatology=clim, quantile=q)
+         for q in (0.33, 0.66, 1.0)]
+  res = metrics.GaussianRPS(thresholds=ths).compute(forecast, truth)
+  np.testing.assert_allclose(res['2m_temperature'].data, [expected, expected],
+                             rtol=1e-4)
+
+
+def ensemble_case(error, ens_delta):
+  kw = dict(variables_2d=['2m_temperature'], **KW)
+  forecast = fixtures.mock_forecast_data(ensemble_size=4, lead_stop='1 day',
+                                         **kw)
+  truth = fixtures.mock_truth_data(**kw) + 1.0
+  forecast = forecast + 1.0 + error
+  delta = NA(ens_delta * np.arange(-2, 2).astype(float), ('realization',))
+  forecast = forecast + DS({'2m_temperature': delta})
+  doy = {'dayofyear': 1 + np.arange(366)}
+  clim = _merge(_clim_like(truth, doy),
+                _clim_like(truth, doy,
+                           {'2m_temperature': '2m_temperature_std'}))
+  return forecast, truth, clim
+
+
+@pytest.mark.parametrize('error,ens_delta,expected',
+                         [(0.0, 0.1, 0.0), (0.0, 1.0, 0.25), (-10.0, 0.1, 1.0)])
+def test_ensemble_brier_score(error, ens_delta, expected):
+  forecast, truth, clim = ensemble_case(error, ens_delta)
+  th = thresholds.GaussianQuantileThreshold(climatology=clim, quantile=0.2)
+  res = metrics.EnsembleBrierScore(thresholds=[th]).compute(forecast, truth)
+  np.testing.assert_allclose(res['2m_temperature'].data,
+                             [[expected, expected]], rtol=1e-4, atol=1e-12)
+
+
+@pytest.mark.parametrize('error,expected', [(0.0, 0.0), (-10.0, np.inf)])
+def test_ensemble_ignorance_score(error, expected):
+  forecast, truth, clim = ensemble_case(error, 0.0)
+  th = thresholds.GaussianQuantileThreshold(climatology=clim, quantile=0.2)
+  res = metrics.EnsembleIgnoranceScore(thresholds=[th]).compute(forecast, truth)
+  np.testing.assert_allclose(res['2m_temperature'].data,
+                             [[expected, expected]], rtol=1e-4)
+
+
+@pytest.mark.parametrize('error,expected', [(0.02, 0.0), (-2.0, 2.0)])
+def test_ensemble_rps(error, expected):
+  kw = dict(variables_2d=['2m_temperature'], **KW)
+  forecast = fixtures.mock_forecast_data(ensemble_size=4, lead_stop='1 day',
+                                         **kw)
+  truth0 = fixtures.mock_truth_data(**kw)
+  clim = rps_climatology(truth0)
+  truth = truth0 + 1.5
+  forecast = forecast + 1.0 + error
+  ths = [thresholds.QuantileThreshold(climatology=clim, quantile=q)
+         for q in (0.33, 0.66, 1.0)]
+  res = metrics.EnsembleRPS(thresholds=ths).compute(forecast, truth)
+  np.testing.assert_allclose(res['2m_temperature'].data, [expected, expected],
+                             rtol=1e-4, atol=1e-12)
+
+
+def test_debiased_brier_matches_large_ensemble_in_expectation():
+  # metrics_test.py:1111-1170 (statistical): debiasing a 2-member Brier score
+  # approaches the 500-member score.
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=500, spatial_resolution_in_degrees=20)
+  doy = {'dayofyear': 1 + np.arange(366)}
+  zero = truth.zeros_like()
+  clim = _merge(_clim_like(zero, doy),
+                _clim_like(zero + 1.0, doy, {'geopotential': 'geopotential_std'}))
+  th = thresholds.GaussianQuantileThreshold(climatology=clim, quantile=0.7)
+  small = forecast.isel(realization=slice(2))
+  big = metrics.EnsembleBrierScore(thresholds=[th]).compute_chunk(forecast, truth)
+  biased = metrics.EnsembleBrierScore(thresholds=[th]).compute_chunk(small, truth)
+  debiased = metrics.DebiasedEnsembleBrierScore(thresholds=[th]).compute_chunk(
+      small, truth)
+  b, s, d = (x['geopotential'].data.mean() for x in (big, biased, debiased))
+  assert s - b > 0.05          # the small ensemble is visibly biased
+  assert abs(d - b) < 0.02     # and debiasing removes it
