@@ -52,6 +52,10 @@ extern "C" {
                              * (partials come from wb2_ens_partials)              */
 
 #define WB2_MODE_GAUSS 4    /* mean,std,truth        -> GaussianCRPS, GaussianVariance  metrics.py:849-937 */
+#define WB2_MODE_GAUSS_THR 5 /* mean,std,truth,thr   -> Gaussian Brier / ignorance / RPS part  metrics.py:975-1158 */
+#define WB2_MODE_ENS_THR 6  /* members,truth,thr     -> ensemble Brier / debiased Brier / ignorance /
+                             *                          RPS part  metrics.py:1524-1891
+                             * (partials come from wb2_ens_threshold_partials)              */
 
 /* number of metrics written by wb2_det_combine, in this order */
 #define WB2_NMETRIC 5
@@ -60,9 +64,19 @@ extern "C" {
 #define WB2_METRIC_MAE 2
 #define WB2_METRIC_BIAS 3
 #define WB2_METRIC_ACC 4
-/* WB2_MODE_GAUSS reuses the first two metric rows */
+/* Modes >= WB2_MODE_GAUSS are "generic": their slots are [q_0..q_{KQ-1}] plus,
+ * with skipna, the matching notnull weights [n_0..n_{KQ-1}], and
+ * wb2_det_combine writes the KQ spatial means into metrics rows 0..KQ-1
+ * (`metrics` must then hold KQ rows, not WB2_NMETRIC). */
 #define WB2_GAUSS_CRPS 0
 #define WB2_GAUSS_VARIANCE 1
+#define WB2_GAUSS_THR_BRIER 0
+#define WB2_GAUSS_THR_IGNORANCE 1
+#define WB2_GAUSS_THR_RPS_PART 2
+#define WB2_ENS_THR_BRIER 0
+#define WB2_ENS_THR_DEBIASED_BRIER 1
+#define WB2_ENS_THR_IGNORANCE 2
+#define WB2_ENS_THR_RPS_PART 3
 
 /* metrics written by wb2_ens_combine, in this order */
 #define WB2_NMETRIC_ENS 8
@@ -83,6 +97,8 @@ const char* wb2_last_error(void);
  *   DET_ACC  : the above + S(w fa ta) S(w fa^2) S(w ta^2)               [+ 3 more notnull sums]
  *   WIND     : S(w (du^2+dv^2))                                         [+ 1]
  *   GAUSS    : S(w crps) S(w std^2)                                     [+ 2]
+ *   GAUSS_THR: S(w brier) S(w ignorance) S(w rps_part)                  [+ 3]
+ *   ENS_THR  : S(w brier) S(w debiased) S(w ignorance) S(w rps_part)    [+ 4]
  * The bracketed sums-of-weights exist only when skipna != 0 (xarray computes
  * them always, but without NaNs they are data independent: metrics.py:161-163). */
 int wb2_num_slots(int mode, int skipna);
@@ -191,6 +207,25 @@ int wb2_ens_partials(int dtype, int skipna, const void* ens,
                      int32_t n_ctile, const int32_t* seg_col0,
                      const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
                      double* partials, void* stream);
+
+/*
+ * Ensemble threshold metrics: one read of the members (+ truth + threshold)
+ * gives, per grid point, the exceedance counts behind EnsembleBrierScore,
+ * DebiasedEnsembleBrierScore, EnsembleIgnoranceScore and the EnsembleRPS part
+ * (metrics.py:1524-1560, 1720-1738, 1791-1802); any M >= 1, no sorting.
+ * Slots/partials as for WB2_MODE_ENS_THR; fold with
+ * wb2_det_combine(WB2_MODE_ENS_THR, ...).  `threshold` is [n_slab][n_row][n_col]
+ * in the data dtype, resolved through thr_slab like truth.
+ */
+int wb2_ens_threshold_partials(
+    int dtype, int skipna, const void* ens, const int64_t* ens_slab,
+    const void* truth, const int64_t* truth_slab, const void* threshold,
+    const int64_t* thr_slab, int32_t n_member, int64_t member_stride,
+    int64_t n_outer, int32_t n_row, int32_t n_col, const double* w_row,
+    const double* w_col, const double* wfield, const int32_t* chunk_row0,
+    const int32_t* chunk_nrow, int32_t n_chunk, int32_t n_ctile,
+    const int32_t* seg_col0, const int32_t* seg_eoff, int32_t n_seg,
+    int32_t n_ts, double* partials, void* stream);
 
 /* Region fold + finalisation for the ensemble pass (same tables as
  * wb2_det_combine); metrics is double[WB2_NMETRIC_ENS][n_region][n_outer]. */

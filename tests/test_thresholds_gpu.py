@@ -1,0 +1,165 @@
+"""GPU parity of the threshold-metric family (-m gpu): reference known answers
+(metrics_test.py:366-535, 985-1030, 1290-1388) and random data vs the oracle."""
+import numpy as np
+import pytest
+
+from oracle import fixtures
+from oracle import metrics_np as om
+from oracle import regions_np as oreg
+from oracle import thresholds_np as oth
+from oracle.named import DS, NA
+from tests import helpers
+from tests.test_oracle_thresholds import (ensemble_case, gaussian_case,
+                                          rps_climatology, _clim_like, _merge,
+                                          KW)
+
+pytestmark = pytest.mark.gpu
+
+g = helpers.to_gpu_dataset
+
+
+def _gth(cls_name, climatology, quantile):
+  from weatherbench2_amd import thresholds as gth
+  return getattr(gth, cls_name)(climatology=g(climatology), quantile=quantile)
+
+
+@pytest.mark.parametrize('error,e1,e2', [(0.02, 0.04421, 0.257883),
+                                         (1e6, 0.70786, 0.707861)])
+def test_gaussian_brier_known_answers(error, e1, e2):
+  from weatherbench2_amd import metrics as gm
+  forecast, truth, clim, qclim = gaussian_case(error)
+  th = _gth('GaussianQuantileThreshold', clim, 0.8)
+  res = gm.GaussianBrierScore(thresholds=[th]).compute(g(forecast), g(truth))
+  np.testing.assert_allclose(res['2m_temperature'].values, [[e1, e1]],
+                             rtol=1e-4)
+  assert res.attrs['threshold_method'] == 'GaussianQuantileThreshold'
+  th = _gth('QuantileThreshold', qclim, 0.8)
+  res = gm.GaussianBrierScore(thresholds=[th]).compute(g(forecast), g(truth))
+  np.testing.assert_allclose(res['2m_temperature'].values, [[e2, e2]],
+                             rtol=1e-4)
+
+
+@pytest.mark.parametrize('error,expected', [(0.02, 0.236055), (1e6, 1.841019)])
+def test_gaussian_ignorance_known_answers(error, expected):
+  from weatherbench2_amd import metrics as gm
+  forecast, truth, clim, _ = gaussian_case(error)
+  th = _gth('GaussianQuantileThreshold', clim, 0.8)
+  res = gm.GaussianIgnoranceScore(thresholds=[th]).compute(g(forecast),
+                                                           g(truth))
+  np.testing.assert_allclose(res['2m_temperature'].values,
+                             [[expected, expected]], rtol=1e-4)
+
+
+@pytest.mark.parametrize('error,expected', [(0.02, 0.295746), (1e6, 0.758203)])
+def test_gaussian_rps_known_answers(error, expected):
+  from weatherbench2_amd import metrics as gm
+  forecast = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature', '2m_temperature_std'], lead_stop='1 day',
+      **KW)
+  truth0 = fixtures.mock_truth_data(variables_2d=['2m_temperature'], **KW)
+  clim = rps_climatology(truth0)
+  truth = truth0 + 1.0
+  forecast = forecast + 1.0 + error
+  ths = [_gth('QuantileThreshold', clim, q) for q in (0.33, 0.66, 1.0)]
+  res = gm.GaussianRPS(thresholds=ths).compute(g(forecast), g(truth))
+  np.testing.assert_allclose(res['2m_temperature'].values,
+                             [expected, expected], rtol=1e-4)
+
+
+@pytest.mark.parametrize('error,ens_delta,expected',
+                         [(0.0, 0.1, 0.0), (0.0, 1.0, 0.25), (-10.0, 0.1, 1.0)])
+def test_ensemble_brier_known_answers(error, ens_delta, expected):
+  from weatherbench2_amd import metrics as gm
+  forecast, truth, clim = ensemble_case(error, ens_delta)
+  th = _gth('GaussianQuantileThreshold', clim, 0.2)
+  res = gm.EnsembleBrierScore(thresholds=[th]).compute(g(forecast), g(truth))
+  np.testing.assert_allclose(res['2m_temperature'].values,
+                             [[expected, expected]], rtol=1e-4, atol=1e-12)
+  assert res.attrs['ensemble_size'] == 4
+
+
+@pytest.mark.parametrize('error,expected', [(0.0, 0.0), (-10.0, np.inf)])
+def test_ensemble_ignorance_known_answers(error, expected):
+  from weatherbench2_amd import metrics as gm
+  forecast, truth, clim = ensemble_case(error, 0.0)
+  th = _gth('GaussianQuantileThreshold', clim, 0.2)
+  res = gm.EnsembleIgnoranceScore(thresholds=[th]).compute(g(forecast),
+                                                           g(truth))
+  np.testing.assert_allclose(res['2m_temperature'].values,
+                             [[expected, expected]], rtol=1e-4)
+
+
+@pytest.mark.parametrize('error,expected', [(0.02, 0.0), (-2.0, 2.0)])
+def test_ensemble_rps_known_answers(error, expected):
+  from weatherbench2_amd import metrics as gm
+  kw = dict(variables_2d=['2m_temperature'], **KW)
+  forecast = fixtures.mock_forecast_data(ensemble_size=4, lead_stop='1 day',
+                                         **kw)
+  truth0 = fixtures.mock_truth_data(**kw)
+  clim = rps_climatology(truth0)
+  truth = truth0 + 1.5
+  forecast = forecast + 1.0 + error
+  ths = [_gth('QuantileThreshold', clim, q) for q in (0.33, 0.66, 1.0)]
+  res = gm.EnsembleRPS(thresholds=ths).compute(g(forecast), g(truth))
+  np.testing.assert_allclose(res['2m_temperature'].values,
+                             [expected, expected], rtol=1e-4, atol=1e-12)
+
+
+def _random_case(ensemble_size=None, nan_frac=0.0):
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, spatial_resolution_in_degrees=10,
+      lead_stop='2 day')
+  doy = {'dayofyear': 1 + np.arange(366)}
+  zero = truth.zeros_like()
+  clim = _merge(_clim_like(zero + 0.1, doy),
+                _clim_like(zero + 0.9, doy,
+                           {'geopotential': 'geopotential_std'}))
+  if nan_frac:
+    forecast = fixtures.insert_nan(forecast, nan_frac, seed=9)
+    truth = fixtures.insert_nan(truth, nan_frac / 2, seed=10)
+  return truth, forecast, clim
+
+
+@pytest.mark.parametrize('skipna', [False, True])
+def test_gaussian_family_random_vs_oracle(skipna):
+  from weatherbench2_amd import metrics as gm
+  truth, mean, clim = _random_case()
+  _, std = fixtures.get_random_truth_and_forecast(
+      spatial_resolution_in_degrees=10, lead_stop='2 day', seed=5)
+  dims = mean['geopotential'].dims
+  forecast = DS({'geopotential': mean['geopotential'],
+                 'geopotential_std': NA(np.abs(std['geopotential'].data) + 0.2,
+                                        dims)}, mean.coords)
+  if skipna:
+    forecast = fixtures.insert_nan(forecast, 0.05, seed=3)
+  oths = [oth.GaussianQuantileThreshold(clim, q) for q in (0.3, 0.8)]
+  gths = [_gth('GaussianQuantileThreshold', clim, q) for q in (0.3, 0.8)]
+  region = oreg.SliceRegion(lat_slice=slice(-40, 50))
+  for name in ('GaussianBrierScore', 'GaussianIgnoranceScore', 'GaussianRPS'):
+    want = getattr(om, name)(thresholds=oths).compute_chunk(
+        forecast, truth, region=region, skipna=skipna)
+    got = getattr(gm, name)(thresholds=gths).compute_chunk(
+        g(forecast), g(truth), region=helpers.to_gpu_region(region),
+        skipna=skipna)
+    assert got['geopotential'].dims == want['geopotential'].dims, name
+    helpers.assert_close(got['geopotential'].values, want['geopotential'].data,
+                         rtol=1e-9, atol=1e-12, err_msg=name)
+
+
+@pytest.mark.parametrize('skipna', [False, True])
+@pytest.mark.parametrize('ensemble_size', [1, 2, 7, 33])
+def test_ensemble_family_random_vs_oracle(ensemble_size, skipna):
+  from weatherbench2_amd import metrics as gm
+  truth, forecast, clim = _random_case(ensemble_size,
+                                       nan_frac=0.05 if skipna else 0.0)
+  oths = [oth.GaussianQuantileThreshold(clim, q) for q in (0.2, 0.6)]
+  gths = [_gth('GaussianQuantileThreshold', clim, q) for q in (0.2, 0.6)]
+  for name in ('EnsembleBrierScore', 'DebiasedEnsembleBrierScore',
+               'EnsembleIgnoranceScore', 'EnsembleRPS'):
+    want = getattr(om, name)(thresholds=oths).compute_chunk(
+        forecast, truth, skipna=skipna)
+    got = getattr(gm, name)(thresholds=gths).compute_chunk(
+        g(forecast), g(truth), skipna=skipna)
+    assert got['geopotential'].dims == want['geopotential'].dims, name
+    helpers.assert_close(got['geopotential'].values, want['geopotential'].data,
+                         rtol=1e-9, atol=1e-12, err_msg=name)

@@ -261,6 +261,157 @@ __global__ void __launch_bounds__(256)
       p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
 }
 
+// ---------------------------------------------------------------------------
+// Ensemble threshold metrics (metrics.py:1524-1891): exceedance counts only.
+// Slots: 0 Brier, 1 debiased Brier, 2 ignorance, 3 RPS part [+ 4 notnull].
+// ---------------------------------------------------------------------------
+struct EnsThrParams {
+  EnsParams e;
+  const void* thr;
+  const long long* thr_slab;
+};
+
+template <typename T, bool SKIPNA, bool WF>
+__global__ void __launch_bounds__(256)
+    ens_threshold_kernel(const EnsThrParams q) {
+  const EnsParams& p = q.e;
+  constexpr int K = SKIPNA ? 8 : 4, NWF = WF ? 2 : 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int nwave = blockDim.x / kWave;
+  const unsigned bx = blockIdx.x;
+  const unsigned tblk = bx / (unsigned)p.n_chunk;
+  const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
+  const long long o = (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  const int tile = (int)tblk * nwave + wave;
+  const int row0 = p.chunk_row0[chunk];
+  const int nrow = p.chunk_nrow[chunk];
+  const int col0 = tile * kWave + lane;
+  const bool active = tile < p.n_ctile && col0 < p.n_col;
+  if (nrow <= 0 || tile >= p.n_ctile || o >= p.n_outer) return;
+  const long long es = p.ens_slab ? p.ens_slab[o] : o;
+  const long long ts = p.truth_slab ? p.truth_slab[o] : o;
+  const long long hs = q.thr_slab ? q.thr_slab[o] : o;
+  const int M = p.n_member;
+  const double nan = __builtin_nan("");
+
+  double acc[NWF][1][K];
+#pragma unroll
+  for (int w = 0; w < NWF; ++w)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[w][0][k] = 0.0;
+
+  if (active) {
+    const long long slab_elems = (long long)p.n_row * p.n_col;
+    const T* xb = static_cast<const T*>(p.ens) + es * slab_elems +
+                  (long long)row0 * p.n_col + col0;
+    const T* tb = static_cast<const T*>(p.truth) + ts * slab_elems +
+                  (long long)row0 * p.n_col + col0;
+    const T* hb = static_cast<const T*>(q.thr) + hs * slab_elems +
+                  (long long)row0 * p.n_col + col0;
+    const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + col0
+                           : nullptr;
+    for (int r = 0; r < nrow; ++r) {
+      const long long off = (long long)r * p.n_col;
+      const T t = __builtin_nontemporal_load(tb + off);
+      const T thr = __builtin_nontemporal_load(hb + off);
+      int gt = 0, lt = 0, nn = 0;  // members above / below / not NaN
+      int m = 0;
+      for (; m + 4 <= M; m += 4) {  // four loads in flight
+        T x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          x[u] = __builtin_nontemporal_load(xb + (m + u) * p.member_stride + off);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          gt += x[u] > thr ? 1 : 0;
+          lt += x[u] < thr ? 1 : 0;
+          nn += is_nan(x[u]) ? 0 : 1;
+        }
+      }
+      for (; m < M; ++m) {
+        const T x = __builtin_nontemporal_load(xb + m * p.member_stride + off);
+        gt += x > thr ? 1 : 0;
+        lt += x < thr ? 1 : 0;
+        nn += is_nan(x) ? 0 : 1;
+      }
+      // metrics.py:1535-1560: probabilities are NaN where the input is NaN
+      // (a NaN threshold makes the comparison false, like xr.where does)
+      const double tp_b = is_nan(t) ? nan : (t > thr ? 1.0 : 0.0);
+      const int n = SKIPNA ? nn : M;
+      double pm = (double)gt / (double)n;           // n == 0 -> NaN
+      if (!SKIPNA && nn != M) pm = nan;
+      const double eb = pm - tp_b;
+      const double brier = eb * eb;
+      // var(ddof=1) of the 0/1 member probabilities (two-pass form)
+      double var = ((double)gt * (1.0 - pm) * (1.0 - pm) +
+                    (double)(n - gt) * pm * pm) / (double)(n - 1);
+      if (n <= 1) var = nan;
+      const double debiased = brier - var / (double)M;
+      // metrics.py:1728-1738 / 1799-1802: plain comparisons (NaN -> 0)
+      const double pe = (double)gt / (double)M, pl = (double)lt / (double)M;
+      const double ign = -((t > thr) ? log(pe) : log(1.0 - pe));
+      const double dr = pl - ((t < thr) ? 1.0 : 0.0);
+      const double v[4] = {brier, debiased, ign, dr * dr};
+      const double wr = p.w_row[row0 + r];
+      double wf = 1.0;
+      if constexpr (WF) wf = wfp[off];
+      const bool inside = !WF || wf > 0.0;
+      const double w2 = inside ? wr * wf : 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double xk = v[k], ck = 1.0;
+        if constexpr (SKIPNA) {
+          const bool ok = !is_nan(v[k]);
+          xk = ok ? v[k] : 0.0;
+          ck = ok ? 1.0 : 0.0;
+        }
+        acc[0][0][k] = __builtin_fma(wr, xk, acc[0][0][k]);
+        if constexpr (SKIPNA)
+          acc[0][0][4 + k] = __builtin_fma(wr, ck, acc[0][0][4 + k]);
+        if constexpr (WF) {
+          acc[1][0][k] = __builtin_fma(w2, inside ? xk : 0.0, acc[1][0][k]);
+          if constexpr (SKIPNA)
+            acc[1][0][4 + k] =
+                __builtin_fma(w2, inside ? ck : 0.0, acc[1][0][4 + k]);
+        }
+      }
+    }
+    if (p.w_col) {
+      const double wc = p.w_col[col0];
+#pragma unroll
+      for (int w = 0; w < NWF; ++w)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[w][0][k] *= wc;
+    }
+  }
+  fold_tile_to_segs<NWF, 1, K>(
+      acc, lane, tile, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg, p.n_ts,
+      p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
+}
+
+template <typename T>
+int launch_ens_threshold(const EnsThrParams& q, bool skipna, bool wf,
+                         hipStream_t stream) {
+  const EnsParams& p = q.e;
+  int nwave = p.n_ctile < 4 ? p.n_ctile : 4;
+  const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
+  const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
+  const long long gz = (p.n_outer + gy - 1) / gy;
+  const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
+  const dim3 block(nwave * kWave);
+#define WB2_L(S, W) \
+  hipLaunchKernelGGL((ens_threshold_kernel<T, S, W>), grid, block, 0, stream, q)
+  if (skipna) {
+    if (wf) WB2_L(true, true); else WB2_L(true, false);
+  } else {
+    if (wf) WB2_L(false, true); else WB2_L(false, false);
+  }
+#undef WB2_L
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int NPAD, int MS>
 int launch_ens(const EnsParams& p, bool skipna, bool wf, hipStream_t stream) {
   int nwave = p.n_ctile < 4 ? p.n_ctile : 4;
@@ -362,6 +513,59 @@ int wb2_ens_partials(int dtype, int skipna, const void* ens,
   if (dtype == WB2_F32)
     return launch_ens_npad<float>(p, skipna != 0, wfield != nullptr, s);
   return launch_ens_npad<double>(p, skipna != 0, wfield != nullptr, s);
+}
+
+int wb2_ens_threshold_partials(
+    int dtype, int skipna, const void* ens, const int64_t* ens_slab,
+    const void* truth, const int64_t* truth_slab, const void* threshold,
+    const int64_t* thr_slab, int32_t n_member, int64_t member_stride,
+    int64_t n_outer, int32_t n_row, int32_t n_col, const double* w_row,
+    const double* w_col, const double* wfield, const int32_t* chunk_row0,
+    const int32_t* chunk_nrow, int32_t n_chunk, int32_t n_ctile,
+    const int32_t* seg_col0, const int32_t* seg_eoff, int32_t n_seg,
+    int32_t n_ts, double* partials, void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE(ens && truth && threshold && w_row && chunk_row0 && chunk_nrow &&
+                  seg_col0 && seg_eoff && partials,
+              "null pointer argument");
+  WB2_REQUIRE(n_member >= 1, "n_member=%d", n_member);
+  WB2_REQUIRE(n_outer >= 0 && n_outer < (1ll << 31) && n_row > 0 && n_col > 0 &&
+                  n_chunk > 0 && n_seg > 0 && n_ts >= n_seg,
+              "bad sizes");
+  WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
+  WB2_REQUIRE(n_ctile == (n_col + kWave - 1) / kWave,
+              "n_ctile=%d does not match ceil(n_col / 64)", n_ctile);
+  if (n_outer == 0) return 0;
+  EnsThrParams q{};
+  EnsParams& p = q.e;
+  p.ens = ens;
+  p.truth = truth;
+  p.ens_slab = reinterpret_cast<const long long*>(ens_slab);
+  p.truth_slab = reinterpret_cast<const long long*>(truth_slab);
+  p.w_row = w_row;
+  p.w_col = w_col;
+  p.wfield = wfield;
+  p.chunk_row0 = chunk_row0;
+  p.chunk_nrow = chunk_nrow;
+  p.seg_col0 = seg_col0;
+  p.seg_eoff = seg_eoff;
+  p.partials = partials;
+  p.member_stride = member_stride;
+  p.n_outer = n_outer;
+  p.n_member = n_member;
+  p.n_row = n_row;
+  p.n_col = n_col;
+  p.n_chunk = n_chunk;
+  p.n_ctile = n_ctile;
+  p.n_seg = n_seg;
+  p.n_ts = n_ts;
+  q.thr = threshold;
+  q.thr_slab = reinterpret_cast<const long long*>(thr_slab);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    return launch_ens_threshold<float>(q, skipna != 0, wfield != nullptr, s);
+  return launch_ens_threshold<double>(q, skipna != 0, wfield != nullptr, s);
 }
 
 }  // extern "C"

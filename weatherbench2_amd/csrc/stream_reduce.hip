@@ -66,6 +66,10 @@ template <bool S>
 struct ModeTraits<WB2_MODE_GAUSS, S> {
   static constexpr int NIN = 3, KQ = 2, K = KQ + (S ? 2 : 0);
 };
+template <bool S>
+struct ModeTraits<WB2_MODE_GAUSS_THR, S> {
+  static constexpr int NIN = 4, KQ = 3, K = KQ + (S ? 3 : 0);
+};
 
 // One grid point: inputs -> the K values whose weighted sums we need.  With
 // SKIPNA, NaN numerators become 0 and the trailing slots carry notnull() as
@@ -74,7 +78,31 @@ template <int MODE, bool SKIPNA, typename T>
 __device__ __forceinline__ void eval_slots(
     const T (&in)[ModeTraits<MODE, SKIPNA>::NIN],
     double (&x)[ModeTraits<MODE, SKIPNA>::K]) {
-  if constexpr (MODE == WB2_MODE_GAUSS) {
+  if constexpr (MODE == WB2_MODE_GAUSS_THR) {
+    // metrics.py:975-1000 (Brier), :1043-1066 (ignorance), :1104-1121 (RPS
+    // part): in = (mean, std, truth, threshold).  xr.where(truth > thr, 1., 0.)
+    // maps a NaN truth to 0; the normalised threshold is formed in the input
+    // dtype and scipy's norm.cdf promotes it to float64.
+    const T mean = in[0], sd = in[1], y = in[2], thr = in[3];
+    const T nt = (thr - mean) / sd;
+    const double z = (double)nt;
+    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
+    const bool above = y > thr, below = y < thr;
+    const double tp = above ? 1.0 : 0.0, te = below ? 1.0 : 0.0;
+    const double db = (1.0 - cdf) - tp;
+    const double dr = cdf - te;
+    const double v[3] = {db * db, -(above ? log(1.0 - cdf) : log(cdf)), dr * dr};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if constexpr (SKIPNA) {
+        const bool ok = !is_nan(v[k]);
+        x[k] = ok ? v[k] : 0.0;
+        x[3 + k] = ok ? 1.0 : 0.0;
+      } else {
+        x[k] = v[k];
+      }
+    }
+  } else if constexpr (MODE == WB2_MODE_GAUSS) {
     // metrics.py:895-905, 925-927: in = (mean, std, truth).  The normalised
     // difference is formed in the input dtype; scipy's norm.cdf / norm.pdf
     // promote it to float64, and so does everything downstream.
@@ -464,13 +492,13 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
       m[WB2_ENS_DEBIASED_MSE * stride] = s[5] / n_deb;
       continue;
     }
-    if (p.mode == WB2_MODE_GAUSS) {
+    if (p.mode >= WB2_MODE_GAUSS) {
+      // generic modes: slots [q_0..q_{KQ-1} | n_0..n_{KQ-1}] -> KQ plain means
+      const int kq = p.skipna ? K / 2 : K;
       const long long stride = (long long)p.n_region * p.n_outer;
       double* m = p.metrics + (long long)r * p.n_outer + o;
-      m[WB2_GAUSS_CRPS * stride] = s[0] / (p.skipna ? nan_if_zero(s[2]) : wsum);
-      m[WB2_GAUSS_VARIANCE * stride] =
-          s[1] / (p.skipna ? nan_if_zero(s[3]) : wsum);
-      for (int i = 2; i < WB2_NMETRIC; ++i) m[i * stride] = nan;
+      for (int i = 0; i < kq; ++i)
+        m[i * stride] = s[i] / (p.skipna ? nan_if_zero(s[kq + i]) : wsum);
       continue;
     }
     if (p.mode == WB2_MODE_WIND) {
@@ -571,6 +599,7 @@ int launch_stream_mode(const StreamParams& p, int mode, bool vec, bool skipna,
     WB2_MODE_CASE(WB2_MODE_DET_ACC)
     WB2_MODE_CASE(WB2_MODE_WIND)
     WB2_MODE_CASE(WB2_MODE_GAUSS)
+    WB2_MODE_CASE(WB2_MODE_GAUSS_THR)
   }
 #undef WB2_MODE_CASE
   return fail("unknown mode %d", mode);
@@ -589,7 +618,8 @@ int threads_for(int n_col, int vec) {
 }
 
 int mode_nin(int mode) {
-  return mode == WB2_MODE_DET ? 2 : mode == WB2_MODE_WIND ? 4 : 3;
+  return mode == WB2_MODE_DET ? 2
+         : (mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS_THR) ? 4 : 3;
 }
 
 }  // namespace
@@ -603,6 +633,8 @@ int wb2_num_slots(int mode, int skipna) {
     case WB2_MODE_DET_ACC: return skipna ? 10 : 6;
     case WB2_MODE_WIND: return skipna ? 2 : 1;
     case WB2_MODE_GAUSS: return skipna ? 4 : 2;
+    case WB2_MODE_GAUSS_THR: return skipna ? 6 : 3;
+    case WB2_MODE_ENS_THR: return skipna ? 8 : 4;
   }
   return wb2::fail("unknown mode %d", mode);
 }
@@ -623,7 +655,8 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         double* partials, void* stream) {
   using namespace wb2;
   WB2_REQUIRE(mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC ||
-                  mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS,
+                  mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS ||
+                  mode == WB2_MODE_GAUSS_THR,
               "unknown mode %d", mode);
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && seg_eoff &&
@@ -685,7 +718,7 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
                     const double* region_wsum, int32_t n_region, double* sums,
                     double* metrics, void* stream) {
   using namespace wb2;
-  WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_GAUSS, "unknown mode %d", mode);
+  WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_ENS_THR, "unknown mode %d", mode);
   WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
                   region_wf && region_wsum,
               "null pointer argument");

@@ -98,7 +98,8 @@ def stream_reduce(plan: ReductionPlan, mode: int,
               'wb2_stream_partials')
   if K1_EVENTS is not None:
     K1_EVENTS[1].record()
-  metrics = torch.empty((_lib.NMETRIC, plan.n_region, n_outer),
+  metrics = torch.empty((_lib.GENERIC_KQ.get(mode, _lib.NMETRIC),
+                         plan.n_region, n_outer),
                         dtype=torch.float64, device=dev)
   sums = (torch.empty((n_outer, plan.n_region, k), dtype=torch.float64,
                       device=dev) if want_sums else None)
@@ -271,3 +272,45 @@ def spatial_accumulate(forecast: torch.Tensor, f_slab, truth: torch.Tensor,
       _lib.ptr(f_slab), _lib.ptr(truth), _lib.ptr(t_slab), n_time, n_rest,
       n_point, _lib.ptr(total), _lib.ptr(count),
       current_stream_ptr(forecast.device)), 'wb2_spatial_accumulate')
+
+
+def ensemble_threshold_reduce(plan: ReductionPlan, ens: torch.Tensor,
+                              member_stride: int, n_member: int, ens_slab,
+                              truth: torch.Tensor, truth_slab,
+                              thr: torch.Tensor, thr_slab, n_outer: int,
+                              skipna: bool):
+  """Exceedance-count kernel + region fold: metrics[4, n_region, n_outer] =
+  (Brier, debiased Brier, ignorance, RPS part)."""
+  lib = _lib.load()
+  dev = plan.device
+  dtype = ens.dtype
+  if dtype not in _DTYPES or truth.dtype != dtype or thr.dtype != dtype:
+    raise TypeError('members, truth and threshold must share one dtype')
+  for x in (ens, truth, thr):
+    if x.device != dev or not x.is_contiguous():
+      raise ValueError('inputs must be contiguous on the plan device')
+  mode = _lib.MODE_ENS_THR
+  k = lib.wb2_num_slots(mode, int(skipna))
+  tile = lib.wb2_ens_tile_cols(plan.n_col)
+  n_ctile = -(-plan.n_col // tile)
+  seg_eoff, n_ts = plan.seg_entries(tile)
+  stream = current_stream_ptr(dev)
+  partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
+                         dtype=torch.float64, device=dev)
+  _lib.check(lib.wb2_ens_threshold_partials(
+      _DTYPES[dtype], int(skipna), _lib.ptr(ens), _lib.ptr(ens_slab),
+      _lib.ptr(truth), _lib.ptr(truth_slab), _lib.ptr(thr), _lib.ptr(thr_slab),
+      n_member, member_stride, n_outer, plan.n_row, plan.n_col,
+      _lib.ptr(plan.w_row), _lib.ptr(plan.w_col), _lib.ptr(plan.wfield),
+      _lib.ptr(plan.chunk_row0), _lib.ptr(plan.chunk_nrow), plan.n_chunk,
+      n_ctile, _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
+      _lib.ptr(partials), stream), 'wb2_ens_threshold_partials')
+  metrics = torch.empty((_lib.GENERIC_KQ[mode], plan.n_region, n_outer),
+                        dtype=torch.float64, device=dev)
+  _lib.check(lib.wb2_det_combine(
+      mode, int(skipna), _lib.ptr(partials), n_outer, plan.n_chunk, plan.nwf,
+      plan.n_seg, _lib.ptr(seg_eoff), n_ts, _lib.ptr(plan.band_chunk0),
+      plan.n_band, _lib.ptr(plan.coef_band), _lib.ptr(plan.coef_seg),
+      _lib.ptr(plan.region_wf), _lib.ptr(plan.region_wsum), plan.n_region,
+      None, _lib.ptr(metrics), stream), 'wb2_det_combine')
+  return metrics

@@ -321,7 +321,7 @@ def _run_pass(mode, geo, arrays, tables, region, skipna):
            for tb in tables]
   metrics, _ = engine.stream_reduce(pl, mode, flat, slabs, geo.n_outer, skipna)
   host = metrics.cpu().numpy().reshape(
-      (_lib.NMETRIC, pl.n_region) + geo.out_shape)
+      (metrics.shape[0], pl.n_region) + geo.out_shape)
   return {name: host[:, i] for i, name in enumerate(pl.region_names)}, rkey
 
 
@@ -986,3 +986,231 @@ class EnergyScore(EnsembleMetric):
     spread = EnergyScoreSpread(self.ensemble_dim).compute_chunk(
         forecast, truth, region=region, skipna=skipna)
     return skill - 0.5 * spread
+
+
+# ---------------------------------------------------------------------------
+# Tier 2: threshold metrics (metrics.py:940-1158 Gaussian, 1524-1891 ensemble)
+# ---------------------------------------------------------------------------
+def _stack_quantiles(forecast, per_threshold: list, quantiles, method: str,
+                     sum_over_quantile: bool) -> xl.Dataset:
+  """metrics.py:966-972: concat over a new leading `quantile` dim (+ attrs)."""
+  out = xl.Dataset()
+  first = per_threshold[0]
+  for name, (dims, _) in first.items():
+    out.coords.update(_result_coords(forecast, dims))
+  if not sum_over_quantile:
+    out.coords['quantile'] = np.array(list(quantiles), dtype=np.float64)
+  for name, (dims, _) in first.items():
+    data = np.stack([np.asarray(p[name][1], dtype=np.float64)
+                     for p in per_threshold])
+    if sum_over_quantile:
+      out.data_vars[name] = xl.DataArray(data.sum(0), dims, out.coords, name)
+    else:
+      out.data_vars[name] = xl.DataArray(data, ('quantile',) + tuple(dims),
+                                         out.coords, name)
+  return out.assign_attrs(threshold_method=method)
+
+
+def _gauss_threshold_pass(forecast, truth, threshold_ds, name, region, skipna):
+  mvar, svar = forecast[name], forecast[f'{name}_std']
+  tvar, hvar = truth[name], threshold_ds[name]
+  geo, prepared = _geometry(forecast, mvar, [svar, tvar, hvar])
+  tables = [_slab_table(geo.out_dims, geo.out_shape, p[1], p[0].shape[:-2])
+            for p in prepared]
+  by_region, _ = _run_pass(_lib.MODE_GAUSS_THR, geo, [p[0] for p in prepared],
+                           tables, region, skipna)
+  return geo, by_region
+
+
+@dataclasses.dataclass
+class ThresholdMetric(Metric):
+  """Base of the threshold metrics (metrics.py:940-972): one score per
+  threshold, stacked along `quantile`."""
+
+  thresholds: t.Sequence = ()
+  _row = 0
+  _sum_over_quantile = False
+  # dims of the LEFT operand come first in xarray: scores whose outermost
+  # operand is derived from truth / the threshold are truth-first.
+  _truth_first = True
+
+
+def _truth_first_order(dims, values, truth_dims):
+  tdims = [d for d in truth_dims if d in dims]
+  order = tuple(tdims + [d for d in dims if d not in tdims])
+  if order == tuple(dims):
+    return dims, values
+  return order, np.transpose(values, [dims.index(d) for d in order])
+
+
+class _GaussianThresholdMetric(ThresholdMetric):
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = _inputs(forecast, truth)
+    per_threshold = []
+    for threshold in self.thresholds:
+      threshold_ds = threshold.compute(truth)
+      per_var = {}
+      for name in [v for v in forecast.keys()
+                   if f'{v}_std' in forecast.keys()]:
+        geo, by_region = _gauss_threshold_pass(forecast, truth, threshold_ds,
+                                               name, region, skipna)
+        _, rkey = _region_set_for(region)
+        per_var[name] = _truth_first_order(
+            geo.out_dims, by_region[rkey][self._row], truth[name].dims)
+      per_threshold.append(per_var)
+    return _stack_quantiles(forecast, per_threshold,
+                            [th.quantile for th in self.thresholds],
+                            type(self.thresholds[0]).__name__,
+                            self._sum_over_quantile)
+
+
+@dataclasses.dataclass
+class GaussianBrierScore(_GaussianThresholdMetric):
+  """Brier score of a Gaussian forecast (metrics.py:1003-1040)."""
+  _row = 0
+
+
+@dataclasses.dataclass
+class GaussianIgnoranceScore(_GaussianThresholdMetric):
+  """Ignorance (log) score of a Gaussian forecast (metrics.py:1069-1101)."""
+  _row = 1
+
+
+@dataclasses.dataclass
+class GaussianRPS(_GaussianThresholdMetric):
+  """Ranked probability score of a Gaussian forecast: the per-threshold
+  (cdf - truth_ecdf)^2 summed over the thresholds (metrics.py:1124-1158)."""
+  _row = 2
+  _sum_over_quantile = True
+
+
+def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
+                        region, skipna):
+  fvar, tvar, hvar = forecast[name], truth[name], threshold_ds[name]
+  if ensemble_dim not in fvar.dims:
+    raise ValueError(f'{ensemble_dim=} not found in {fvar.dims=}')
+  fdata, frest, layout = _spatial_last(fvar, None)
+  tdata, trest, _ = _spatial_last(tvar, layout)
+  hdata, hrest, _ = _spatial_last(hvar, layout)
+  fsizes = dict(zip(frest, fdata.shape[:-2]))
+  n_member = fsizes[ensemble_dim]
+  out_dims = [d for d in frest if d != ensemble_dim]
+  sizes = {d: fsizes[d] for d in out_dims}
+  for rest, data in ((trest, tdata), (hrest, hdata)):
+    for d, n in zip(rest, data.shape[:-2]):
+      if d not in out_dims:
+        out_dims.append(d)
+        sizes[d] = n
+  out_dims = tuple(out_dims)
+  out_shape = tuple(sizes[d] for d in out_dims)
+  geo = _Geometry(layout, out_dims, out_shape,
+                  _coord_values(forecast, 'latitude'),
+                  _coord_values(forecast, 'longitude'))
+  stride, strides = 1, {}
+  for d in reversed(frest):
+    strides[d] = stride
+    stride *= fsizes[d]
+  ens_table = np.zeros(out_shape, dtype=np.int64)
+  for d in frest:
+    if d == ensemble_dim:
+      continue
+    shape = [1] * len(out_shape)
+    shape[out_dims.index(d)] = fsizes[d]
+    ens_table = ens_table + (np.arange(fsizes[d], dtype=np.int64)
+                             * strides[d]).reshape(shape)
+  ens_table = np.ascontiguousarray(ens_table).ravel()
+  identity = np.array_equal(ens_table, np.arange(ens_table.size))
+  t_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
+  h_table = _slab_table(out_dims, out_shape, hrest, hdata.shape[:-2])
+  device = engine.require_gpu()
+  regions, _ = _region_set_for(region)
+  n_row = len(geo.latitude if layout == plan_lib.LATLON else geo.longitude)
+  pl = plan_lib.cached_plan(geo.latitude, geo.longitude, layout, regions,
+                            device, plan_lib.auto_rows_per_chunk(n_row,
+                                                                 geo.n_outer))
+  tens = [_to_device(x, device) for x in (fdata, tdata, hdata)]
+  dtype = tens[0].dtype
+  for x in tens[1:]:
+    dtype = torch.promote_types(dtype, x.dtype)
+  if dtype not in (torch.float32, torch.float64):
+    dtype = torch.float64
+  tens = [x if x.dtype == dtype else x.to(dtype) for x in tens]
+  for x in tens:
+    _check_grid(geo, x)
+  to_dev = lambda tb: None if tb is None else torch.from_numpy(tb).to(device)
+  slab_elems = pl.n_row * pl.n_col
+  metrics = engine.ensemble_threshold_reduce(
+      pl, tens[0], strides[ensemble_dim] * slab_elems, n_member,
+      None if identity else to_dev(ens_table),
+      tens[1].reshape(-1, pl.n_row, pl.n_col), to_dev(t_table),
+      tens[2].reshape(-1, pl.n_row, pl.n_col), to_dev(h_table), geo.n_outer,
+      skipna)
+  host = metrics.cpu().numpy().reshape((4, pl.n_region) + out_shape)
+  return geo, {nm: host[:, i] for i, nm in enumerate(pl.region_names)}
+
+
+@dataclasses.dataclass
+class _EnsembleThresholdMetric(ThresholdMetric):
+  ensemble_dim: str = REALIZATION
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = _inputs(forecast, truth)
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    per_threshold = []
+    for threshold in self.thresholds:
+      threshold_ds = threshold.compute(truth)
+      per_var = {}
+      for name in _common_vars(forecast, truth):
+        key = _result_key(('ens_thr', self.ensemble_dim, id(threshold)),
+                          [forecast[name].data, truth[name].data], region,
+                          skipna)
+        hit = _RESULTS.get(key)
+        if hit is None:
+          hit = _ens_threshold_pass(forecast, truth, threshold_ds, name,
+                                    self.ensemble_dim, region, skipna)
+          _RESULTS.put(key, (forecast[name].data, truth[name].data, threshold),
+                       hit)
+        geo, by_region = hit
+        _, rkey = _region_set_for(region)
+        dims, values = geo.out_dims, by_region[rkey][self._row]
+        if self._truth_first:
+          dims, values = _truth_first_order(dims, values, truth[name].dims)
+        per_var[name] = (dims, values)
+      per_threshold.append(per_var)
+    return _stack_quantiles(forecast, per_threshold,
+                            [th.quantile for th in self.thresholds],
+                            type(self.thresholds[0]).__name__,
+                            self._sum_over_quantile)
+
+  def compute(self, forecast, truth, region=None, skipna=False):
+    forecast = xl.as_dataset(forecast)
+    result = super().compute(forecast, truth, region=region, skipna=skipna)
+    return result.assign_attrs(ensemble_size=forecast.sizes[self.ensemble_dim])
+
+
+@dataclasses.dataclass
+class EnsembleBrierScore(_EnsembleThresholdMetric):
+  """Brier score of an ensemble forecast (metrics.py:1563-1617)."""
+  _row = 0
+  _truth_first = False
+
+
+@dataclasses.dataclass
+class DebiasedEnsembleBrierScore(_EnsembleThresholdMetric):
+  """Debiased ensemble Brier score (metrics.py:1644-1704)."""
+  _row = 1
+
+
+@dataclasses.dataclass
+class EnsembleIgnoranceScore(_EnsembleThresholdMetric):
+  """Ignorance score of an ensemble forecast (metrics.py:1741-1788)."""
+  _row = 2
+
+
+@dataclasses.dataclass
+class EnsembleRPS(_EnsembleThresholdMetric):
+  """Ranked probability score of an ensemble forecast (metrics.py:1805-1868)."""
+  _row = 3
+  _sum_over_quantile = True
+  _truth_first = False
