@@ -53,6 +53,8 @@ extern "C" {
 
 #define WB2_MODE_GAUSS 4    /* mean,std,truth        -> GaussianCRPS, GaussianVariance  metrics.py:849-937 */
 #define WB2_MODE_GAUSS_THR 5 /* mean,std,truth,thr   -> Gaussian Brier / ignorance / RPS part  metrics.py:975-1158 */
+#define WB2_MODE_SEEPS 7     /* forecast,truth,wet-threshold + aux p1 field + scalar dry threshold
+                             * -> SEEPS  metrics.py:417-524 (always NaN-skipping)             */
 #define WB2_MODE_ENS_THR 6  /* members,truth,thr     -> ensemble Brier / debiased Brier / ignorance /
                              *                          RPS part  metrics.py:1524-1891
                              * (partials come from wb2_ens_threshold_partials)              */
@@ -99,6 +101,7 @@ const char* wb2_last_error(void);
  *   GAUSS    : S(w crps) S(w std^2)                                     [+ 2]
  *   GAUSS_THR: S(w brier) S(w ignorance) S(w rps_part)                  [+ 3]
  *   ENS_THR  : S(w brier) S(w debiased) S(w ignorance) S(w rps_part)    [+ 4]
+ *   SEEPS    : S(w seeps)                                               [+ 1]
  * The bracketed sums-of-weights exist only when skipna != 0 (xarray computes
  * them always, but without NaNs they are data independent: metrics.py:161-163). */
 int wb2_num_slots(int mode, int skipna);
@@ -149,6 +152,21 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         const int32_t* seg_col0, const int32_t* seg_eoff,
                         int32_t n_seg, int32_t n_ts,
                         double* partials, void* stream);
+
+/* As wb2_stream_partials, plus the mode-specific extras:
+ *  aux     DEV double[n_row*n_col] or NULL  (WB2_MODE_SEEPS: the climatological
+ *          dry fraction p1, NaN where it is masked out, metrics.py:504-506)
+ *  scalar  (WB2_MODE_SEEPS: the dry threshold in data units, metrics.py:449) */
+int wb2_stream_partials_ex(int mode, int dtype, int skipna,
+                           const void* const* in, const int64_t* const* slab,
+                           int64_t n_outer, int32_t n_row, int32_t n_col,
+                           const double* w_row, const double* w_col,
+                           const double* wfield, const double* aux,
+                           double scalar, const int32_t* chunk_row0,
+                           const int32_t* chunk_nrow, int32_t n_chunk,
+                           int32_t n_ctile, const int32_t* seg_col0,
+                           const int32_t* seg_eoff, int32_t n_seg,
+                           int32_t n_ts, double* partials, void* stream);
 
 /*
  * K2: fold the partials into per-region sums and finalise the metrics.

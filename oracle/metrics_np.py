@@ -679,6 +679,84 @@ class EnsembleRPS(_EnsembleThresholdMetric):
         f, t_, th, self.ensemble_dim, skipna)
 
 
+# ---------------------------------------------------------------------------
+# Tier 2: SEEPS (metrics.py:417-524)
+# ---------------------------------------------------------------------------
+@dataclasses.dataclass
+class SpatialSEEPS(Metric):
+  climatology: DS = None
+  dry_threshold_mm: float = 0.25
+  precip_name: str = 'total_precipitation_24hr'
+  min_p1: float = 0.1
+  max_p1: float = 0.85
+
+  @property
+  def p1(self) -> NA:
+    return self.climatology[f'{self.precip_name}_seeps_dry_fraction'].mean(
+        ('hour', 'dayofyear'))
+
+  def _valid_time(self, ds: DS) -> NA:
+    vt = ds.coords['valid_time']
+    return vt if isinstance(vt, NA) else NA(vt, ('time',))
+
+  @staticmethod
+  def _lift(x: NA, dims) -> np.ndarray:
+    """x's data broadcastable against an array laid out as `dims`."""
+    perm = [d for d in dims if d in x.dims]
+    data = np.transpose(x.data, [x.dims.index(d) for d in perm])
+    return data.reshape([x.sizes[d] if d in x.dims else 1 for d in dims])
+
+  def _convert_precip_to_seeps_cat(self, ds: DS):
+    """metrics.py:444-468 -> [dry, light, heavy] as 0/1 floats, NaN kept."""
+    wet_threshold = self.climatology[f'{self.precip_name}_seeps_threshold']
+    dry_threshold = self.dry_threshold_mm / 1000.0
+    da = ds[self.precip_name]
+    vt = self._valid_time(ds)
+    doy, hour = _dayofyear_hour(vt.data)
+    doy_pos = {v: i for i, v in enumerate(
+        self.climatology.coord('dayofyear').tolist())}
+    hour_pos = {v: i for i, v in enumerate(
+        self.climatology.coord('hour').tolist())}
+    di = np.vectorize(doy_pos.__getitem__)(doy)
+    hi = np.vectorize(hour_pos.__getitem__)(hour)
+    rest = tuple(d for d in wet_threshold.dims if d not in ('dayofyear',
+                                                            'hour'))
+    wet = NA(wet_threshold.transpose('dayofyear', 'hour', *rest).data[di, hi],
+             vt.dims + rest)
+    x = da.data
+    w = self._lift(wet, da.dims)
+    with np.errstate(invalid='ignore'):
+      conds = [x < dry_threshold, np.logical_and(x > dry_threshold, x < w),
+               x >= w]
+    return [NA(np.where(np.isnan(x), np.nan, c.astype('int').astype(float)),
+               da.dims) for c in conds]
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    fc = self._convert_precip_to_seeps_cat(forecast)
+    tc = self._convert_precip_to_seeps_cat(truth)
+    p1 = self.p1
+    matrix = [[0 * p1, 1 / (1 - p1), 4 / (1 - p1)],
+              [1 / p1, 0 * p1, 3 / (1 - p1)],
+              [1 / p1 + 3 / (2 + p1), 3 / (2 + p1), 0 * p1]]
+    result = None
+    for i in range(3):
+      for j in range(3):
+        term = (fc[i] * tc[j]) * (0.5 * matrix[i][j])
+        result = term if result is None else result + term
+    p1l = self._lift(p1, result.dims)
+    keep = np.logical_and(p1l < self.max_p1, p1l > self.min_p1)
+    result = NA(np.where(keep, result.data, np.nan), result.dims)
+    coords = {k: c for k, c in forecast.coords.items()}
+    return DS({self.precip_name: result}, coords)
+
+
+@dataclasses.dataclass
+class SEEPS(SpatialSEEPS):
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    result = super().compute_chunk(forecast, truth, region)
+    return spatial_average(result, region=region, skipna=True)
+
+
 def crps_brute_force(forecast: DS, truth: DS, skipna: bool) -> dict:
   """The reference TEST's O(M^2) eFAIR CRPS (metrics_test.py:896-920)."""
 

@@ -191,7 +191,9 @@ class DS:
     self.vars = {}
     for k, v in (data_vars or {}).items():
       self.vars[k] = v if isinstance(v, NA) else NA(v[1], v[0])
-    self.coords = {k: np.asarray(v) for k, v in (coords or {}).items()}
+    # 1-D index coordinates are plain arrays; multi-dim ones (valid_time) stay NA
+    self.coords = {k: (v if isinstance(v, NA) else np.asarray(v))
+                   for k, v in (coords or {}).items()}
 
   # mapping-ish
   def keys(self): return self.vars.keys()
@@ -233,11 +235,14 @@ class DS:
   def isel(self, **indexers):
     coords = dict(self.coords)
     for dim, idx in indexers.items():
-      if dim in coords:
+      if dim in coords and not isinstance(coords[dim], NA):
         if np.ndim(idx) == 0 and not isinstance(idx, slice):
           coords.pop(dim)
         else:
           coords[dim] = coords[dim][idx]
+    for k, c in list(coords.items()):
+      if isinstance(c, NA):
+        coords[k] = c.isel(**indexers)
     return DS({k: v.isel(**indexers) for k, v in self.vars.items()}, coords)
 
   def expand_dims(self, dim, size=1, coord=None):

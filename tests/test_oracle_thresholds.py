@@ -160,3 +160,48 @@ def test_debiased_brier_matches_large_ensemble_in_expectation():
   b, s, d = (x['geopotential'].data.mean() for x in (big, biased, debiased))
   assert s - b > 0.05          # the small ensemble is visibly biased
   assert abs(d - b) < 0.02     # and debiasing removes it
+
+
+def seeps_case():
+  """metrics_test.py:1393-1421: by-init forecast with a 2-D valid_time."""
+  kw = dict(variables_3d=[], variables_2d=['total_precipitation_24hr'],
+            time_start='2022-01-01', time_stop='2022-01-11')
+  forecast = fixtures.mock_forecast_data(lead_stop='0 day', **kw)
+  fv = forecast['total_precipitation_24hr']
+  dims = tuple('init_time' if d == 'time' else d for d in fv.dims)
+  coords = dict(forecast.coords)
+  coords['init_time'] = coords.pop('time')
+  lead = coords['prediction_timedelta']
+  coords['valid_time'] = NA(coords['init_time'][:, None] + lead[None, :],
+                            ('init_time', 'prediction_timedelta'))
+  forecast = DS({'total_precipitation_24hr': NA(fv.data, dims)}, coords)
+  truth = fixtures.mock_truth_data(**kw)
+  # truth.sel(time=forecast.valid_time): dims (init_time, prediction_timedelta, ...)
+  tv = truth['total_precipitation_24hr']
+  tl = NA(tv.data[:, None], ('init_time', 'prediction_timedelta') + tv.dims[1:])
+  tcoords = {k: v for k, v in coords.items()}
+  truth_like_forecast = DS({'total_precipitation_24hr': tl}, tcoords)
+  clim0 = truth.isel(time=0)
+  base = clim0['total_precipitation_24hr']
+  mk = lambda add: NA(np.broadcast_to((base.data + add)[None, None],
+                                      (4, 366) + base.shape).copy(),
+                      ('hour', 'dayofyear') + base.dims)
+  ccoords = {k: v for k, v in clim0.coords.items()}
+  ccoords['hour'] = np.arange(0, 24, 6)
+  ccoords['dayofyear'] = 1 + np.arange(366)
+  climatology = DS({
+      'total_precipitation_24hr': mk(0.0),
+      'total_precipitation_24hr_seeps_dry_fraction': mk(np.float32(0.4)),
+      'total_precipitation_24hr_seeps_threshold': mk(np.float32(1.0))},
+      ccoords)
+  return forecast, truth_like_forecast, climatology
+
+
+def test_seeps_expected_values():
+  forecast, truth, climatology = seeps_case()
+  seeps = metrics.SEEPS(climatology=climatology)
+  r1 = seeps.compute(forecast, truth)
+  np.testing.assert_allclose(r1['total_precipitation_24hr'].data, 0, atol=1e-4)
+  r2 = seeps.compute(forecast + 0.5, truth)
+  np.testing.assert_allclose(r2['total_precipitation_24hr'].data, 1.25,
+                             atol=1e-4)

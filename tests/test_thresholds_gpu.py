@@ -163,3 +163,46 @@ def test_ensemble_family_random_vs_oracle(ensemble_size, skipna):
     assert got['geopotential'].dims == want['geopotential'].dims, name
     helpers.assert_close(got['geopotential'].values, want['geopotential'].data,
                          rtol=1e-9, atol=1e-12, err_msg=name)
+
+
+def _to_gpu_with_valid_time(ds):
+  from weatherbench2_amd import xarray_lite as xl
+  out = g(ds)
+  return out
+
+
+def test_seeps_known_answers_and_random():
+  # metrics_test.py:1391-1436 + random precipitation vs the oracle
+  from tests.test_oracle_thresholds import seeps_case
+  from weatherbench2_amd import metrics as gm
+  forecast, truth, climatology = seeps_case()
+  seeps = gm.SEEPS(climatology=g(climatology))
+  r1 = seeps.compute(g(forecast), g(truth))
+  np.testing.assert_allclose(r1['total_precipitation_24hr'].values, 0,
+                             atol=1e-4)
+  r2 = seeps.compute(g(forecast + 0.5), g(truth))
+  np.testing.assert_allclose(r2['total_precipitation_24hr'].values, 1.25,
+                             atol=1e-4)
+  # random fields, a varying dry fraction (some points masked out), NaNs
+  rs = np.random.RandomState(0)
+  name = 'total_precipitation_24hr'
+  rand = lambda shape: (rs.gamma(0.3, 2.0, size=shape) * 1e-2).astype(
+      np.float32)
+  f2 = DS({name: NA(rand(forecast[name].shape), forecast[name].dims)},
+          forecast.coords)
+  t2 = DS({name: NA(rand(truth[name].shape), truth[name].dims)}, truth.coords)
+  f2 = fixtures.insert_nan(f2, 0.02, seed=1)
+  f2 = f2.copy(data={name: f2[name].data.astype(np.float32)})
+  base = climatology[name]
+  frac = rs.uniform(0.0, 1.0, size=base.shape[2:]).astype(np.float32)
+  thr = (rs.uniform(0.002, 0.02, size=base.shape)).astype(np.float32)
+  clim2 = DS({name: base,
+              name + '_seeps_dry_fraction': NA(
+                  np.broadcast_to(frac, base.shape).copy(), base.dims),
+              name + '_seeps_threshold': NA(thr, base.dims)},
+             climatology.coords)
+  want = om.SEEPS(climatology=clim2).compute_chunk(f2, t2)
+  got = gm.SEEPS(climatology=g(clim2)).compute_chunk(g(f2), g(t2))
+  assert got[name].dims == want[name].dims
+  helpers.assert_close(got[name].values, want[name].data, rtol=1e-9,
+                       atol=1e-12)

@@ -17,8 +17,9 @@ from weatherbench2_amd import build as _build
 
 WB2_F32, WB2_F64 = 0, 1
 MODE_DET, MODE_DET_ACC, MODE_WIND, MODE_ENS, MODE_GAUSS = 0, 1, 2, 3, 4
-MODE_GAUSS_THR, MODE_ENS_THR = 5, 6
-GENERIC_KQ = {MODE_GAUSS: 2, MODE_GAUSS_THR: 3, MODE_ENS_THR: 4}
+MODE_GAUSS_THR, MODE_ENS_THR, MODE_SEEPS = 5, 6, 7
+GENERIC_KQ = {MODE_GAUSS: 2, MODE_GAUSS_THR: 3, MODE_ENS_THR: 4,
+              MODE_SEEPS: 1}
 NMETRIC = 5
 NMETRIC_ENS = 8
 METRIC_INDEX = {'mse': 0, 'rmse': 1, 'mae': 2, 'bias': 3, 'acc': 4}
@@ -38,6 +39,10 @@ _SIGNATURES = {
     'wb2_stream_partials': (_int, [
         _int, _int, _int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i32, _i32,
         _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'wb2_stream_partials_ex': (_int, [
+        _int, _int, _int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i32, _i32,
+        _vp, _vp, _vp, _vp, _c.c_double, _vp, _vp, _i32, _i32, _vp, _vp, _i32,
+        _i32, _vp, _vp]),
     'wb2_det_combine': (_int, [
         _int, _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp,
         _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -39,6 +39,8 @@ struct StreamParams {
   const double* w_row;
   const double* w_col;
   const double* wfield;
+  const double* aux;   // mode-specific 2-D field [n_row][n_col] (SEEPS: p1)
+  double scalar;       // mode-specific scalar (SEEPS: dry threshold)
   const int* chunk_row0;
   const int* chunk_nrow;
   const int* seg_col0;
@@ -70,6 +72,10 @@ template <bool S>
 struct ModeTraits<WB2_MODE_GAUSS_THR, S> {
   static constexpr int NIN = 4, KQ = 3, K = KQ + (S ? 3 : 0);
 };
+template <bool S>
+struct ModeTraits<WB2_MODE_SEEPS, S> {
+  static constexpr int NIN = 3, KQ = 1, K = KQ + (S ? 1 : 0);
+};
 
 // One grid point: inputs -> the K values whose weighted sums we need.  With
 // SKIPNA, NaN numerators become 0 and the trailing slots carry notnull() as
@@ -77,8 +83,37 @@ struct ModeTraits<WB2_MODE_GAUSS_THR, S> {
 template <int MODE, bool SKIPNA, typename T>
 __device__ __forceinline__ void eval_slots(
     const T (&in)[ModeTraits<MODE, SKIPNA>::NIN],
-    double (&x)[ModeTraits<MODE, SKIPNA>::K]) {
-  if constexpr (MODE == WB2_MODE_GAUSS_THR) {
+    double (&x)[ModeTraits<MODE, SKIPNA>::K], double aux = 0.0,
+    double scalar = 0.0) {
+  if constexpr (MODE == WB2_MODE_SEEPS) {
+    // metrics.py:444-507: in = (forecast, truth, wet threshold at valid time),
+    // aux = climatological dry fraction p1 (NaN where masked out), scalar = dry
+    // threshold.  Categories: dry x < dry; light dry < x < wet; heavy x >= wet
+    // (x == dry is in none: zero contingency row, score 0); NaN stays NaN.
+    const T f = in[0], y = in[1], wet = in[2], dry = (T)scalar;
+    auto cat = [&](T v) {
+      return v < dry ? 0 : ((v > dry && v < wet) ? 1 : (v >= wet ? 2 : 3));
+    };
+    const int fc = cat(f), tc = cat(y);
+    const T p1 = (T)aux, one = (T)1;
+    // 0.5 * scoring matrix [forecast_cat][truth_cat], in the dtype of p1
+    T m = (T)0;
+    if (fc == 0 && tc == 1) m = one / (one - p1);
+    if (fc == 0 && tc == 2) m = (T)4 / (one - p1);
+    if (fc == 1 && tc == 0) m = one / p1;
+    if (fc == 1 && tc == 2) m = (T)3 / (one - p1);
+    if (fc == 2 && tc == 0) m = one / p1 + (T)3 / ((T)2 + p1);
+    if (fc == 2 && tc == 1) m = (T)3 / ((T)2 + p1);
+    double v = (double)((T)0.5 * m);
+    if (is_nan(f) || is_nan(y) || is_nan(aux)) v = __builtin_nan("");
+    if constexpr (SKIPNA) {
+      const bool ok = !is_nan(v);
+      x[0] = ok ? v : 0.0;
+      x[1] = ok ? 1.0 : 0.0;
+    } else {
+      x[0] = v;
+    }
+  } else if constexpr (MODE == WB2_MODE_GAUSS_THR) {
     // metrics.py:975-1000 (Brier), :1043-1066 (ignorance), :1104-1121 (RPS
     // part): in = (mean, std, truth, threshold).  xr.where(truth > thr, 1., 0.)
     // maps a NaN truth to 0; the normalised threshold is formed in the input
@@ -283,7 +318,7 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
     const double* wrp = p.w_row + row0;
 
     auto consume = [&](const T (&v)[NIN][VEC], const double (&wf)[VEC],
-                       double wr) {
+                       double wr, const double* auxrow) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         T in[NIN];
@@ -296,7 +331,11 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
         for (int i = 0; i < NIN; ++i) sdiag += in[i];
         acc[0][e][0] += (double)sdiag;
 #else
-        eval_slots<MODE, SKIPNA, T>(in, x);
+        if constexpr (MODE == WB2_MODE_SEEPS) {
+          eval_slots<MODE, SKIPNA, T>(in, x, auxrow[e], p.scalar);
+        } else {
+          eval_slots<MODE, SKIPNA, T>(in, x);
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k)
           acc[0][e][k] = __builtin_fma(wr, x[k], acc[0][e][k]);
@@ -336,7 +375,11 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
       // this hipcc sinks half of them below the arithmetic (register heuristics).
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < U; ++u) consume(v[u], wf[u], wr[u]);
+      for (int u = 0; u < U; ++u)
+        consume(v[u], wf[u], wr[u],
+                MODE == WB2_MODE_SEEPS
+                    ? p.aux + (long long)(row0 + r + u) * p.n_col + col0
+                    : nullptr);
     }
 #pragma clang loop unroll(disable)
     for (; r < nrow; ++r) {
@@ -351,7 +394,10 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) wf[e] = 1.0;
       }
-      consume(v, wf, wrp[r]);
+      consume(v, wf, wrp[r],
+              MODE == WB2_MODE_SEEPS
+                  ? p.aux + (long long)(row0 + r) * p.n_col + col0
+                  : nullptr);
     }
     if (p.w_col) {  // only when columns are latitudes (lon-lat layout)
 #pragma unroll
@@ -600,6 +646,7 @@ int launch_stream_mode(const StreamParams& p, int mode, bool vec, bool skipna,
     WB2_MODE_CASE(WB2_MODE_WIND)
     WB2_MODE_CASE(WB2_MODE_GAUSS)
     WB2_MODE_CASE(WB2_MODE_GAUSS_THR)
+    WB2_MODE_CASE(WB2_MODE_SEEPS)
   }
 #undef WB2_MODE_CASE
   return fail("unknown mode %d", mode);
@@ -635,6 +682,7 @@ int wb2_num_slots(int mode, int skipna) {
     case WB2_MODE_GAUSS: return skipna ? 4 : 2;
     case WB2_MODE_GAUSS_THR: return skipna ? 6 : 3;
     case WB2_MODE_ENS_THR: return skipna ? 8 : 4;
+    case WB2_MODE_SEEPS: return skipna ? 2 : 1;
   }
   return wb2::fail("unknown mode %d", mode);
 }
@@ -653,11 +701,30 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         int32_t n_ctile, const int32_t* seg_col0,
                         const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
                         double* partials, void* stream) {
+  return wb2_stream_partials_ex(mode, dtype, skipna, in, slab, n_outer, n_row,
+                                n_col, w_row, w_col, wfield, nullptr, 0.0,
+                                chunk_row0, chunk_nrow, n_chunk, n_ctile,
+                                seg_col0, seg_eoff, n_seg, n_ts, partials,
+                                stream);
+}
+
+int wb2_stream_partials_ex(int mode, int dtype, int skipna,
+                           const void* const* in, const int64_t* const* slab,
+                           int64_t n_outer, int32_t n_row, int32_t n_col,
+                           const double* w_row, const double* w_col,
+                           const double* wfield, const double* aux,
+                           double scalar, const int32_t* chunk_row0,
+                           const int32_t* chunk_nrow, int32_t n_chunk,
+                           int32_t n_ctile, const int32_t* seg_col0,
+                           const int32_t* seg_eoff, int32_t n_seg,
+                           int32_t n_ts, double* partials, void* stream) {
   using namespace wb2;
   WB2_REQUIRE(mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC ||
                   mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS ||
-                  mode == WB2_MODE_GAUSS_THR,
+                  mode == WB2_MODE_GAUSS_THR || mode == WB2_MODE_SEEPS,
               "unknown mode %d", mode);
+  WB2_REQUIRE(mode != WB2_MODE_SEEPS || aux != nullptr,
+              "WB2_MODE_SEEPS needs the p1 field in `aux`");
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && seg_eoff &&
                   partials,
@@ -685,6 +752,8 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
   p.w_row = w_row;
   p.w_col = w_col;
   p.wfield = wfield;
+  p.aux = aux;
+  p.scalar = scalar;
   p.chunk_row0 = chunk_row0;
   p.chunk_nrow = chunk_nrow;
   p.seg_col0 = seg_col0;
@@ -718,7 +787,7 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
                     const double* region_wsum, int32_t n_region, double* sums,
                     double* metrics, void* stream) {
   using namespace wb2;
-  WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_ENS_THR, "unknown mode %d", mode);
+  WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_SEEPS, "unknown mode %d", mode);
   WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
                   region_wf && region_wsum,
               "null pointer argument");

@@ -53,7 +53,8 @@ def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
 def stream_reduce(plan: ReductionPlan, mode: int,
                   inputs: t.Sequence[torch.Tensor],
                   slabs: t.Sequence[t.Optional[torch.Tensor]], n_outer: int,
-                  skipna: bool, want_sums: bool = False):
+                  skipna: bool, want_sums: bool = False,
+                  aux: t.Optional[torch.Tensor] = None, scalar: float = 0.0):
   """Runs K1 + K2.  `inputs[i]` is [n_slab_i, n_row, n_col] on the plan's device.
 
   Returns (metrics[NMETRIC, n_region, n_outer], sums[n_outer, n_region, K] or
@@ -88,10 +89,11 @@ def stream_reduce(plan: ReductionPlan, mode: int,
                          dtype=torch.float64, device=dev)
   if K1_EVENTS is not None:
     K1_EVENTS[0].record()
-  _lib.check(lib.wb2_stream_partials(
+  _lib.check(lib.wb2_stream_partials_ex(
       mode, code, int(skipna), _lib.ptr_array(inputs), _lib.ptr_array(slabs),
       n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
-      _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
+      _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(aux),
+      float(scalar), _lib.ptr(plan.chunk_row0),
       _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
       _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
       _lib.ptr(partials), stream),

@@ -251,10 +251,11 @@ def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
   """int64[n_outer]: which climatology slab each output slab subtracts."""
   import pandas as pd
   if 'init_time' in forecast.dims:
-    time_dims = ('init_time', 'lead_time')
     vt = forecast.coords['valid_time']
-    vt = vt.transpose(*time_dims).values if isinstance(
-        vt, xl.DataArray) else np.asarray(vt)
+    if not isinstance(vt, xl.DataArray):
+      raise ValueError('valid_time must be a coordinate over (init_time, lead)')
+    time_dims = tuple(vt.dims)  # e.g. (init_time, lead_time / prediction_timedelta)
+    vt = vt.values
   else:
     time_dims = ('time',)
     vt = _coord_values(forecast, 'time')
@@ -299,7 +300,7 @@ def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
 # ---------------------------------------------------------------------------
 # the fused passes
 # ---------------------------------------------------------------------------
-def _run_pass(mode, geo, arrays, tables, region, skipna):
+def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
   """Uploads (if needed), launches, returns {region_key: metrics[NMETRIC, ...]}."""
   device = engine.require_gpu()
   regions, rkey = _region_set_for(region)
@@ -319,7 +320,10 @@ def _run_pass(mode, geo, arrays, tables, region, skipna):
   flat = [x.reshape(-1, pl.n_row, pl.n_col) for x in tensors]
   slabs = [None if tb is None else torch.from_numpy(tb).to(device)
            for tb in tables]
-  metrics, _ = engine.stream_reduce(pl, mode, flat, slabs, geo.n_outer, skipna)
+  if aux is not None:
+    aux = torch.as_tensor(np.ascontiguousarray(aux, dtype=np.float64)).to(device)
+  metrics, _ = engine.stream_reduce(pl, mode, flat, slabs, geo.n_outer, skipna,
+                                    aux=aux, scalar=scalar)
   host = metrics.cpu().numpy().reshape(
       (metrics.shape[0], pl.n_region) + geo.out_shape)
   return {name: host[:, i] for i, name in enumerate(pl.region_names)}, rkey
@@ -1214,3 +1218,50 @@ class EnsembleRPS(_EnsembleThresholdMetric):
   _row = 3
   _sum_over_quantile = True
   _truth_first = False
+
+
+@dataclasses.dataclass
+class SEEPS(Metric):
+  """Spatially averaged Stable Equitable Error in Probability Space
+  (metrics.py:417-524).
+
+  Attributes as in the reference: `climatology` holds
+  `<precip_name>_seeps_threshold` [same units as the data] and
+  `<precip_name>_seeps_dry_fraction` over (hour, dayofyear, lat, lon).
+  NaNs are always skipped (the p1 mask makes that mandatory, :513, 523).
+  """
+
+  climatology: t.Any = None
+  dry_threshold_mm: float = 0.25
+  precip_name: str = 'total_precipitation_24hr'
+  min_p1: float = 0.1
+  max_p1: float = 0.85
+
+  def _p1(self, climatology) -> xl.DataArray:
+    frac = climatology[f'{self.precip_name}_seeps_dry_fraction']
+    return frac.mean(('hour', 'dayofyear'))
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    del skipna  # Ignored, must be effectively True because of p1 mask.
+    forecast, truth = _inputs(forecast, truth)
+    climatology = xl.as_dataset(self.climatology)
+    name = self.precip_name
+    fvar, tvar = forecast[name], truth[name]
+    wvar = climatology[f'{name}_seeps_threshold']
+    geo, prepared = _geometry(forecast, fvar, [tvar])
+    tables = [_slab_table(geo.out_dims, geo.out_shape, p[1], p[0].shape[:-2])
+              for p in prepared]
+    wrest = tuple(d for d in wvar.dims if d not in _SPATIAL)
+    wdata, _, _ = _spatial_last(wvar, geo.layout)
+    prepared.append((wdata, wrest))
+    tables.append(_climatology_slabs(climatology, wvar, forecast, geo, wrest))
+    p1 = self._p1(climatology)
+    want = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
+    p1v = p1.transpose(*want).values
+    with np.errstate(invalid='ignore'):
+      keep = np.logical_and(p1v < self.max_p1, p1v > self.min_p1)
+    aux = np.where(keep, p1v.astype(np.float64), np.nan)
+    by_region, rkey = _run_pass(
+        _lib.MODE_SEEPS, geo, [p[0] for p in prepared], tables, region, True,
+        aux=aux, scalar=self.dry_threshold_mm / 1000.0)
+    return _assemble(forecast, {name: (geo.out_dims, by_region[rkey][0])})
