@@ -81,24 +81,26 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict:
   metrics = {'mse': om.MSE(), 'rmse': om.RMSESqrtBeforeTimeAvg(),
              'mae': om.MAE(), 'bias': om.Bias(), 'acc': om.ACC(clim)}
   regions = helpers.predefined_regions(oracle=True)
+  # ~10-20 s of CPU work: whole units (all metrics x all regions) until the
+  # budget is used; every repetition re-evaluates from the raw arrays.
   t0 = time.perf_counter()
-  done = 0
-  for rname, region in regions.items():
-    for m in metrics.values():
-      m.compute_chunk(f, t, region=region)
-    done += 1
-    if time.perf_counter() - t0 > seconds_budget:
+  units = 0
+  while True:
+    for region in regions.values():
+      for m in metrics.values():
+        m.compute_chunk(f, t, region=region)
+    units += 1
+    dt = time.perf_counter() - t0
+    if dt >= 10.0 or dt >= seconds_budget:
       break
-  dt = time.perf_counter() - t0
-  # evals/s for the FULL metric x region set, extrapolated from `done` regions
-  full = dt * len(regions) / done
   return {
-      'value': n_lev * N_LAT * N_LON / full, 'unit': 'grid-point-evals/s',
+      'value': units * n_lev * N_LAT * N_LON / dt, 'unit': 'grid-point-evals/s',
       'cores': 1, 'kind': 'port',
       'sample': (f'NumPy oracle (xarray-semantics restatement; the reference '
-                 f'itself needs xarray, absent here), 1 process, {n_lev} levels x '
-                 f'721 x 1440 f32, 5 metrics x {done}/{len(regions)} regions '
-                 f'timed in {dt:.1f} s, scaled to all regions; host has '
+                 f'itself needs xarray, absent here), 1 process, {units} unit(s) '
+                 f'of {n_lev} levels x 721 x 1440 f32, 5 metrics x '
+                 f'{len(regions)} regions evaluated one (metric, region) at a '
+                 f'time like evaluation.py:408-435, {dt:.1f} s; host has '
                  f'{os.cpu_count()} logical cores'),
   }
 

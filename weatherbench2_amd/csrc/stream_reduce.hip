@@ -221,6 +221,9 @@ __device__ __forceinline__ void eval_slots(
 #ifndef WB2_DIAG
 #define WB2_DIAG 0  // 1: skip the fold/store epilogue, 2: trivial arithmetic
 #endif
+#ifndef WB2_PIPELINE
+#define WB2_PIPELINE 0  // 1: double-buffered batches (next loads before this fold)
+#endif
 #ifndef WB2_MIN_WAVES
 #define WB2_MIN_WAVES 1
 #endif
@@ -352,35 +355,73 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
       }
     };
 
-    int r = 0;
-#pragma clang loop unroll(disable)
-    for (; r + U <= nrow; r += U) {
+    // A batch = U rows.  issue() puts the batch's loads in flight, eat() folds
+    // it into the accumulators.
+    struct Batch {
       T v[U][NIN][VEC];
       double wf[U][VEC];
       double wr[U];
+    };
+    auto issue = [&](Batch& bt, int r) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int i = 0; i < NIN; ++i)
-          load_vec<T, VEC>(base[i] + (long long)(r + u) * p.n_col, v[u][i]);
+          load_vec<T, VEC>(base[i] + (long long)(r + u) * p.n_col, bt.v[u][i]);
         if constexpr (WF) {
-          load_wf<VEC>(wfp + (long long)(r + u) * p.n_col, wf[u]);
+          load_wf<VEC>(wfp + (long long)(r + u) * p.n_col, bt.wf[u]);
         } else {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) wf[u][e] = 1.0;
+          for (int e = 0; e < VEC; ++e) bt.wf[u][e] = 1.0;
         }
-        wr[u] = wrp[r + u];
+        bt.wr[u] = wrp[r + u];
       }
-      // Keep every load of the batch in flight before the first use: without
-      // this hipcc sinks half of them below the arithmetic (register heuristics).
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto eat = [&](const Batch& bt, int r) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        consume(v[u], wf[u], wr[u],
+        consume(bt.v[u], bt.wf[u], bt.wr[u],
                 MODE == WB2_MODE_SEEPS
                     ? p.aux + (long long)(row0 + r + u) * p.n_col + col0
                     : nullptr);
+    };
+    int r = 0;
+#if WB2_PIPELINE
+    // Software pipeline: the next batch is already in flight while the current
+    // one is being folded, so a wave never sits between batches with nothing
+    // outstanding.  Invariant at the loop head: `a` holds batch bi (in flight).
+    // The sched_barriers keep hipcc from sinking loads below the arithmetic.
+    {
+      const int nb = nrow / U;
+      Batch a, b;
+      if (nb > 0) issue(a, 0);
+      int bi = 0;
+#pragma clang loop unroll(disable)
+      for (; bi + 1 < nb; bi += 2) {
+        issue(b, (bi + 1) * U);
+        __builtin_amdgcn_sched_barrier(0);
+        eat(a, bi * U);
+        if (bi + 2 < nb) issue(a, (bi + 2) * U);
+        __builtin_amdgcn_sched_barrier(0);
+        eat(b, (bi + 1) * U);
+      }
+      if (bi < nb) {
+        __builtin_amdgcn_sched_barrier(0);
+        eat(a, bi * U);
+      }
+      r = nb * U;
     }
+#else
+#pragma clang loop unroll(disable)
+    for (; r + U <= nrow; r += U) {
+      Batch bt;
+      issue(bt, r);
+      // Keep every load of the batch in flight before the first use: without
+      // this hipcc sinks half of them below the arithmetic (register heuristics).
+      __builtin_amdgcn_sched_barrier(0);
+      eat(bt, r);
+    }
+#endif
 #pragma clang loop unroll(disable)
     for (; r < nrow; ++r) {
       T v[NIN][VEC];
