@@ -245,6 +245,22 @@ int wb2_ens_threshold_partials(
     const int32_t* seg_col0, const int32_t* seg_eoff, int32_t n_seg,
     int32_t n_ts, double* partials, void* stream);
 
+/* As wb2_ens_partials, additionally storing the six pointwise values
+ * (skill, spread, (t-mean)^2, var, std^2, debiased; NaN where undefined) to
+ * maps[6][n_outer][n_row*n_col] (fp64, may be NULL): the Spatial* ensemble
+ * metrics, metrics.py:718-772, 1244-1266, 1366-1399. */
+int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
+                          const int64_t* ens_slab, const void* truth,
+                          const int64_t* truth_slab, int32_t n_member,
+                          int64_t member_stride, int64_t n_outer,
+                          int32_t n_row, int32_t n_col, const double* w_row,
+                          const double* w_col, const double* wfield,
+                          const int32_t* chunk_row0, const int32_t* chunk_nrow,
+                          int32_t n_chunk, int32_t n_ctile,
+                          const int32_t* seg_col0, const int32_t* seg_eoff,
+                          int32_t n_seg, int32_t n_ts, double* partials,
+                          double* maps, void* stream);
+
 /* Region fold + finalisation for the ensemble pass (same tables as
  * wb2_det_combine); metrics is double[WB2_NMETRIC_ENS][n_region][n_outer]. */
 int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,

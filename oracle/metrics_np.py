@@ -369,6 +369,43 @@ class SpatialCRPSSkill(EnsembleMetric):
     return pointwise_crps_skill(forecast, truth, self.ensemble_dim, skipna)
 
 
+@dataclasses.dataclass
+class SpatialCRPS(EnsembleMetric):
+  """metrics.py:718-739."""
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    return SpatialCRPSSkill(self.ensemble_dim).compute_chunk(
+        forecast, truth, region, skipna
+    ) - 0.5 * SpatialCRPSSpread(self.ensemble_dim).compute_chunk(
+        forecast, truth, region, skipna)
+
+
+@dataclasses.dataclass
+class SpatialEnsembleVariance(EnsembleMetric):
+  """metrics.py:1244-1266."""
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    n_ensemble = _get_n_ensemble(forecast, self.ensemble_dim)
+    if n_ensemble == 1:
+      return forecast.zeros_like().mean(self.ensemble_dim, skipna=skipna)
+    return forecast.var(self.ensemble_dim, ddof=1, skipna=skipna)
+
+
+@dataclasses.dataclass
+class SpatialEnsembleMeanMSE(EnsembleMetric):
+  """metrics.py:1366-1381."""
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    return (truth - forecast.mean(self.ensemble_dim, skipna=skipna)) ** 2
+
+
+@dataclasses.dataclass
+class DebiasedSpatialEnsembleMeanMSE(EnsembleMetric):
+  """metrics.py:1384-1399."""
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    return debiased_ensemble_mean_mse(forecast, truth, self.ensemble_dim,
+                                      skipna)
+
+
 def _zeros_like_spatial_mean(forecast, ensemble_dim, region, skipna):
   """metrics.py:1196-1204 / 1228-1235 (the n_ensemble == 1 branch)."""
   return spatial_average(forecast, region, skipna).mean(

@@ -183,3 +183,39 @@ def test_quarter_degree_50_members_properties():
   m3, _ = engine.ensemble_reduce(pl, x[perm].contiguous(), 2 * n_lat * n_lon,
                                  m, None, t, None, 2, False)
   assert torch.equal(m3[idx['crps_spread']], m1[idx['crps_spread']])
+
+
+SPATIAL = ['SpatialCRPS', 'SpatialCRPSSpread', 'SpatialCRPSSkill',
+           'SpatialEnsembleVariance', 'SpatialEnsembleMeanMSE',
+           'DebiasedSpatialEnsembleMeanMSE']
+
+
+@pytest.mark.parametrize('skipna', [False, True])
+@pytest.mark.parametrize('ensemble_size', [1, 3, 10])
+def test_spatial_ensemble_maps(gm, ensemble_size, skipna):
+  """metrics.py:718-772, 1244-1266, 1366-1399: pointwise maps + time mean."""
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, lead_stop='1 day')
+  truth, forecast = _cast(truth, np.float32), _cast(forecast, np.float32)
+  if skipna:
+    forecast = _cast(fixtures.insert_nan(forecast, 0.1, seed=2), np.float32)
+  g = helpers.to_gpu_dataset
+  for name in SPATIAL:
+    want = getattr(om, name)().compute_chunk(forecast, truth, skipna=skipna)
+    got = getattr(gm, name)().compute_chunk(g(forecast), g(truth),
+                                            skipna=skipna)
+    w, o = want['geopotential'], got['geopotential']
+    assert o.dims == w.dims, (name, o.dims, w.dims)
+    assert o.values.dtype == w.data.dtype, (name, o.values.dtype, w.data.dtype)
+    helpers.assert_close(o.values, w.data, rtol=3e-6, atol=1e-6, err_msg=name)
+    mean = getattr(gm, name)().compute(g(forecast), g(truth), skipna=skipna)
+    ax = w.dims.index('time')
+    with np.errstate(all='ignore'):
+      import warnings
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref = (np.nanmean if skipna else np.mean)(w.data.astype(np.float64),
+                                                  axis=ax)
+    helpers.assert_close(mean['geopotential'].values, ref, rtol=3e-6, atol=1e-6,
+                         err_msg=name + '.compute')
+    assert mean.attrs['ensemble_size'] == ensemble_size

@@ -44,6 +44,7 @@ struct EnsParams {
   const int* seg_col0;
   const int* seg_eoff;
   double* partials;
+  double* maps;  // optional [6][n_outer][n_row*n_col]: the pointwise values
   long long member_stride;
   long long n_outer;
   int n_member, n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
@@ -237,6 +238,23 @@ __global__ void __launch_bounds__(256)
       __builtin_amdgcn_sched_barrier(0);
       double v[K];
       ens_point<T, NPAD, MS, SKIPNA>(x, t, M, v);
+      if (p.maps) {
+        // Spatial* metrics (metrics.py:718-772, 1244-1266, 1366-1399): the
+        // pointwise values themselves; with SKIPNA slots 6.. flag the NaNs.
+        const long long at = o * slab_elems + (long long)(row0 + r) * p.n_col +
+                             col0;
+        const long long plane = p.n_outer * slab_elems;
+        const double qnan = __builtin_nan("");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double out_v = v[k];
+          if constexpr (SKIPNA) {
+            constexpr int flag[6] = {6, 7, 6, 8, 8, 9};
+            out_v = v[flag[k]] != 0.0 ? v[k] : qnan;
+          }
+          __builtin_nontemporal_store(out_v, p.maps + k * plane + at);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < K; ++k)
         acc[0][0][k] = __builtin_fma(wr, v[k], acc[0][0][k]);
@@ -472,6 +490,24 @@ int wb2_ens_partials(int dtype, int skipna, const void* ens,
                      int32_t n_ctile, const int32_t* seg_col0,
                      const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
                      double* partials, void* stream) {
+  return wb2_ens_partials_maps(dtype, skipna, ens, ens_slab, truth, truth_slab,
+                               n_member, member_stride, n_outer, n_row, n_col,
+                               w_row, w_col, wfield, chunk_row0, chunk_nrow,
+                               n_chunk, n_ctile, seg_col0, seg_eoff, n_seg,
+                               n_ts, partials, nullptr, stream);
+}
+
+int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
+                          const int64_t* ens_slab, const void* truth,
+                          const int64_t* truth_slab, int32_t n_member,
+                          int64_t member_stride, int64_t n_outer,
+                          int32_t n_row, int32_t n_col, const double* w_row,
+                          const double* w_col, const double* wfield,
+                          const int32_t* chunk_row0, const int32_t* chunk_nrow,
+                          int32_t n_chunk, int32_t n_ctile,
+                          const int32_t* seg_col0, const int32_t* seg_eoff,
+                          int32_t n_seg, int32_t n_ts, double* partials,
+                          double* maps, void* stream) {
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(ens && truth && w_row && chunk_row0 && chunk_nrow && seg_col0 &&
@@ -500,6 +536,7 @@ int wb2_ens_partials(int dtype, int skipna, const void* ens,
   p.seg_col0 = seg_col0;
   p.seg_eoff = seg_eoff;
   p.partials = partials;
+  p.maps = maps;
   p.member_stride = member_stride;
   p.n_outer = n_outer;
   p.n_member = n_member;

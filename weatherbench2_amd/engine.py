@@ -119,7 +119,8 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
                     member_stride: int, n_member: int,
                     ens_slab: t.Optional[torch.Tensor], truth: torch.Tensor,
                     truth_slab: t.Optional[torch.Tensor], n_outer: int,
-                    skipna: bool, want_sums: bool = False):
+                    skipna: bool, want_sums: bool = False,
+                    maps: t.Optional[torch.Tensor] = None):
   """Runs K3 + the region fold.  `ens` holds the members member-major with
   `member_stride` elements between members; `truth` is [n_slab, n_row, n_col].
 
@@ -145,14 +146,17 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
                          dtype=torch.float64, device=dev)
   if K1_EVENTS is not None:
     K1_EVENTS[0].record()
-  _lib.check(lib.wb2_ens_partials(
+  if maps is not None and (maps.dtype != torch.float64 or maps.numel() !=
+                           6 * n_outer * plan.n_row * plan.n_col):
+    raise ValueError('maps must be float64[6, n_outer, n_row * n_col]')
+  _lib.check(lib.wb2_ens_partials_maps(
       _DTYPES[dtype], int(skipna), _lib.ptr(ens), _lib.ptr(ens_slab),
       _lib.ptr(truth), _lib.ptr(truth_slab), n_member, member_stride, n_outer,
       plan.n_row, plan.n_col, _lib.ptr(plan.w_row), _lib.ptr(plan.w_col),
       _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
       _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
       _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
-      _lib.ptr(partials), stream), 'wb2_ens_partials')
+      _lib.ptr(partials), _lib.ptr(maps), stream), 'wb2_ens_partials_maps')
   if K1_EVENTS is not None:
     K1_EVENTS[1].record()
   metrics = torch.empty((_lib.NMETRIC_ENS, plan.n_region, n_outer),

@@ -567,11 +567,13 @@ def _get_n_ensemble(ds: xl.Dataset, ensemble_dim: str,
   return n_ensemble
 
 
-def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna):
-  """All ensemble metrics of one variable for the active regions."""
+def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
+              want_maps: bool = False):
+  """All ensemble metrics of one variable for the active regions (and, with
+  `want_maps`, the six pointwise maps as a device tensor)."""
   fvar, tvar = forecast[name], truth[name]
   pins = [fvar.data, tvar.data]
-  key = _result_key('ens:' + ensemble_dim, pins, region, skipna)
+  key = _result_key(('ens', ensemble_dim, want_maps), pins, region, skipna)
   hit = _RESULTS.get(key)
   if hit is not None:
     return hit
@@ -627,12 +629,14 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna):
   _check_grid(geo, tten)
   slab_elems = pl.n_row * pl.n_col
   to_dev = lambda tb: None if tb is None else torch.from_numpy(tb).to(device)
+  maps = (torch.empty((6, geo.n_outer, slab_elems), dtype=torch.float64,
+                      device=device) if want_maps else None)
   try:
     metrics, _ = engine.ensemble_reduce(
         pl, ften, strides[ensemble_dim] * slab_elems, n_member,
         None if identity else to_dev(ens_table),
         tten.reshape(-1, pl.n_row, pl.n_col), to_dev(truth_table),
-        geo.n_outer, skipna)
+        geo.n_outer, skipna, maps=maps)
   except _lib.Wb2HipError as e:
     if 'not supported by the register sort' in str(e):
       raise NotImplementedError(str(e)) from e
@@ -641,6 +645,9 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna):
       (_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
   value = (geo, {nm: host[:, i] for i, nm in enumerate(pl.region_names)},
            n_member)
+  if want_maps:
+    value = value + (maps.reshape((6,) + out_shape + (pl.n_row, pl.n_col)),
+                     ften.dtype)
   _RESULTS.put(key, tuple(pins), value)
   return value
 
@@ -663,7 +670,8 @@ class EnsembleMetric(Metric):
     per_var = {}
     for name in _common_vars(forecast, truth):
       geo, by_region, n_member = _ens_pass(forecast, truth, name,
-                                           self.ensemble_dim, region, skipna)
+                                           self.ensemble_dim, region,
+                                           skipna)[:3]
       _, rkey = _region_set_for(region)
       values = by_region[rkey][_lib.ENS_METRIC_INDEX[self._metric]]
       if self._zero_if_single and n_member == 1:
@@ -1265,3 +1273,116 @@ class SEEPS(Metric):
         _lib.MODE_SEEPS, geo, [p[0] for p in prepared], tables, region, True,
         aux=aux, scalar=self.dry_threshold_mm / 1000.0)
     return _assemble(forecast, {name: (geo.out_dims, by_region[rkey][0])})
+
+
+# ---------------------------------------------------------------------------
+# Spatial* ensemble metrics (metrics.py:718-772, 1244-1266, 1366-1399): the
+# pointwise maps of the fused ensemble pass, kept on the device
+# ---------------------------------------------------------------------------
+_ENS_MAP_SLOT = {'skill': 0, 'spread': 1, 'mse': 2, 'var': 3, 'debiased': 5}
+
+
+@dataclasses.dataclass
+class _SpatialEnsembleMetric(EnsembleMetric):
+  _slot = ''
+  _truth_first = True
+  _zero_if_single = False
+
+  def _map(self, maps, dtype, n_member):
+    m = maps[_ENS_MAP_SLOT[self._slot]]
+    if self._zero_if_single and n_member == 1:
+      return torch.zeros_like(m, dtype=dtype)  # zeros_like(forecast): input dtype
+    # everything but the rank-weighted spread lives in the input dtype
+    return m if self._slot == 'spread' else m.to(dtype)
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = _inputs(forecast, truth)
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    out = xl.Dataset()
+    for name in _common_vars(forecast, truth):
+      geo, _, n_member, maps, dtype = _ens_pass(
+          forecast, truth, name, self.ensemble_dim, None, skipna,
+          want_maps=True)
+      spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
+      dims = tuple(geo.out_dims) + tuple(spatial)
+      data = self._map(maps, dtype, n_member)
+      if self._truth_first:
+        tdims = [d for d in truth[name].dims if d in dims]
+        order = tuple(tdims + [d for d in dims if d not in tdims])
+        data = data.permute(*[dims.index(d) for d in order])
+        dims = order
+      out.coords.update(_spatial_coords(forecast, dims))
+      out.data_vars[name] = xl.DataArray(data, dims, out.coords, name)
+    return out
+
+  def compute(self, forecast, truth, region=None, skipna=False):
+    """Temporal mean of the map, accumulated on the device."""
+    forecast_ds = xl.as_dataset(forecast)
+    avg_dim = 'time' if 'time' in forecast_ds.dims else 'init_time'
+    if avg_dim not in forecast_ds.dims:
+      raise ValueError(
+          'Forecast has neither valid_time or init_time dimension '
+          f'{forecast_ds}')
+    chunk = self.compute_chunk(forecast, truth, region=region, skipna=skipna)
+    out = xl.Dataset(coords={k: v for k, v in chunk.coords.items()
+                             if k != avg_dim},
+                     attrs={'ensemble_size':
+                            forecast_ds.sizes[self.ensemble_dim]})
+    for name, da in chunk.data_vars.items():
+      axis = da.dims.index(avg_dim)
+      values = da.data.to(torch.float64).contiguous()
+      shape = tuple(n for i, n in enumerate(values.shape) if i != axis)
+      total = torch.zeros(shape, dtype=torch.float64, device=values.device)
+      count = torch.zeros_like(total)
+      engine.time_accumulate(values, axis, skipna, total, count)
+      mean = (total / count).to(da.data.dtype)
+      out.data_vars[name] = xl.DataArray(
+          mean, tuple(d for d in da.dims if d != avg_dim), out.coords, name)
+    return out
+
+
+@dataclasses.dataclass
+class SpatialCRPSSkill(_SpatialEnsembleMetric):
+  """CRPSSkill without spatial averaging (metrics.py:757-772)."""
+  _slot = 'skill'
+
+
+@dataclasses.dataclass
+class SpatialCRPSSpread(_SpatialEnsembleMetric):
+  """CRPSSpread without spatial averaging (metrics.py:742-754)."""
+  _slot = 'spread'
+  _truth_first = False
+  _zero_if_single = True
+
+
+@dataclasses.dataclass
+class SpatialCRPS(_SpatialEnsembleMetric):
+  """CRPS without spatial averaging: skill - 0.5 spread (metrics.py:718-739)."""
+  _slot = 'skill'
+
+  def _map(self, maps, dtype, n_member):
+    skill = maps[_ENS_MAP_SLOT['skill']].to(dtype)
+    if n_member == 1:
+      return skill  # spread is zeros_like(forecast): stays in the input dtype
+    # float32 skill - 0.5 * float64 spread -> float64, like numpy promotes
+    return skill.to(torch.float64) - 0.5 * maps[_ENS_MAP_SLOT['spread']]
+
+
+@dataclasses.dataclass
+class SpatialEnsembleVariance(_SpatialEnsembleMetric):
+  """Ensemble variance without spatial averaging (metrics.py:1244-1266)."""
+  _slot = 'var'
+  _truth_first = False
+  _zero_if_single = True
+
+
+@dataclasses.dataclass
+class SpatialEnsembleMeanMSE(_SpatialEnsembleMetric):
+  """(truth - ensemble mean)^2 as a map (metrics.py:1366-1381)."""
+  _slot = 'mse'
+
+
+@dataclasses.dataclass
+class DebiasedSpatialEnsembleMeanMSE(_SpatialEnsembleMetric):
+  """Debiased (truth - ensemble mean)^2 as a map (metrics.py:1384-1399)."""
+  _slot = 'debiased'
