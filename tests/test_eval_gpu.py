@@ -76,3 +76,35 @@ def test_evaluate_chunks_equals_full_time_mean():
         want = metric.compute(forecast, truth, region=region, skipna=skipna)
         helpers.assert_close(got['geopotential'].values[mi, ri],
                              want['geopotential'].data, rtol=1e-9, atol=1e-12)
+
+
+def test_threaded_callers_share_the_caches_safely():
+  """Beam's DirectRunner calls compute_chunk from worker threads."""
+  import threading
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      spatial_resolution_in_degrees=10)
+  g = helpers.to_gpu_dataset
+  chunks = [(g(forecast.isel(time=slice(i, i + 1))),
+             g(truth.isel(time=slice(i, i + 1)))) for i in range(8)]
+  want = [om.MSE().compute_chunk(forecast.isel(time=slice(i, i + 1)),
+                                 truth.isel(time=slice(i, i + 1)))
+          ['geopotential'].data for i in range(8)]
+  got, errors = [None] * 8, []
+
+  def work(i):
+    try:
+      for _ in range(3):
+        got[i] = gm.MSE().compute_chunk(*chunks[i])['geopotential'].values
+        gm.MAE().compute_chunk(*chunks[i])
+    except Exception as e:  # pragma: no cover
+      errors.append(e)
+
+  threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+  for th in threads:
+    th.start()
+  for th in threads:
+    th.join()
+  assert not errors, errors
+  for a, b in zip(got, want):
+    helpers.assert_close(a, b, rtol=1e-9, atol=1e-12)

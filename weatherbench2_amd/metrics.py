@@ -27,6 +27,8 @@ from __future__ import annotations
 
 import contextlib
 import dataclasses
+import functools
+import threading
 import typing as t
 
 import numpy as np
@@ -68,6 +70,19 @@ def _region_set_for(region) -> tuple[dict, str]:
   return {'__requested__': region}, '__requested__'
 
 
+# Beam's DirectRunner may call compute_chunk from several threads (ctypes
+# releases the GIL): fused passes and their caches are serialised per process.
+_PASS_LOCK = threading.RLock()
+
+
+def _serialized(fn):
+  @functools.wraps(fn)
+  def wrapper(*args, **kwargs):
+    with _PASS_LOCK:
+      return fn(*args, **kwargs)
+  return wrapper
+
+
 class _LRU:
 
   def __init__(self, maxsize):
@@ -75,20 +90,23 @@ class _LRU:
     self.items: list = []  # (key, pins, value), most recent last
 
   def get(self, key):
-    for i, (k, _, v) in enumerate(self.items):
-      if k == key:
-        self.items.append(self.items.pop(i))
-        return v
-    return None
+    with _PASS_LOCK:
+      for i, (k, _, v) in enumerate(self.items):
+        if k == key:
+          self.items.append(self.items.pop(i))
+          return v
+      return None
 
   def put(self, key, pins, value):
-    self.items = [it for it in self.items if it[0] != key]
-    self.items.append((key, pins, value))
-    while len(self.items) > self.maxsize:
-      self.items.pop(0)
+    with _PASS_LOCK:
+      self.items = [it for it in self.items if it[0] != key]
+      self.items.append((key, pins, value))
+      while len(self.items) > self.maxsize:
+        self.items.pop(0)
 
   def clear(self):
-    self.items.clear()
+    with _PASS_LOCK:
+      self.items.clear()
 
 
 _RESULTS = _LRU(8)    # fused pass results
@@ -96,6 +114,7 @@ _DEVICE = _LRU(12)    # host array -> device tensor uploads
 _ALIGNED = _LRU(4)    # (forecast, truth) -> label-aligned views
 
 
+@_serialized
 def _inputs(forecast, truth) -> tuple:
   """Datasets as the reference's `forecast - truth` would see them: converted
   at the boundary and inner-joined on their shared dimension coordinates.  The
@@ -335,6 +354,7 @@ def _result_key(kind, arrays, region_key_obj, skipna):
           tuple((k, id(v)) for k, v in regions.items()), bool(skipna))
 
 
+@_serialized
 def _det_pass(forecast, truth, name, region, skipna, climatology=None):
   """All five deterministic metrics of one variable, for the active regions."""
   fvar, tvar = forecast[name], truth[name]
@@ -432,6 +452,7 @@ class _DetMetric(Metric):
     return _assemble(forecast, per_var)
 
 
+@_serialized
 def _wind_pass(forecast, truth, u_name, v_name, region, skipna):
   fu, fv, tu, tv = (forecast[u_name], forecast[v_name], truth[u_name],
                     truth[v_name])
@@ -567,6 +588,7 @@ def _get_n_ensemble(ds: xl.Dataset, ensemble_dim: str,
   return n_ensemble
 
 
+@_serialized
 def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
               want_maps: bool = False):
   """All ensemble metrics of one variable for the active regions (and, with
@@ -899,6 +921,7 @@ def compute_spread_skill_ratio(results: xl.Dataset) -> xl.Dataset:
 # Tier 2: Gaussian forecasts (metrics.py:849-937) and the energy score
 # (metrics.py:1402-1517)
 # ---------------------------------------------------------------------------
+@_serialized
 def _gauss_pass(forecast, truth, name, region, skipna):
   mvar, svar, tvar = forecast[name], forecast[f'{name}_std'], truth[name]
   pins = [mvar.data, svar.data, tvar.data]
@@ -1023,6 +1046,7 @@ def _stack_quantiles(forecast, per_threshold: list, quantiles, method: str,
   return out.assign_attrs(threshold_method=method)
 
 
+@_serialized
 def _gauss_threshold_pass(forecast, truth, threshold_ds, name, region, skipna):
   mvar, svar = forecast[name], forecast[f'{name}_std']
   tvar, hvar = truth[name], threshold_ds[name]
@@ -1097,6 +1121,7 @@ class GaussianRPS(_GaussianThresholdMetric):
   _sum_over_quantile = True
 
 
+@_serialized
 def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
                         region, skipna):
   fvar, tvar, hvar = forecast[name], truth[name], threshold_ds[name]
