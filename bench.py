@@ -60,6 +60,21 @@ def predefined_regions():
   }
 
 
+def measured_traffic(workload: str, **match):
+  """HBM bytes per launch of the dominant kernel as measured with rocprofv3
+  PMC counters for exactly this launch size (profiles/r01_pmc_traffic.*), or
+  None when the run uses a different configuration."""
+  try:
+    table = json.load(open(os.path.join(ROOT, 'profiles',
+                                        'r01_pmc_traffic.json')))
+    entry = table[workload]
+    if all(entry.get(k) == v for k, v in match.items()):
+      return entry['traffic_bytes']
+  except (OSError, KeyError, ValueError):
+    pass
+  return None
+
+
 def cpu_baseline(seconds_budget: float = 20.0) -> dict:
   """Times the NumPy oracle (the restated reference path: one metric x one
   region at a time, like evaluation.py:408-435) on this box's host cores."""
@@ -237,7 +252,7 @@ def main():
       'ms_per_step': dt / args.steps * 1e3,
       'gpu_ms_per_step': g0.elapsed_time(g1) / args.steps,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-      'dtype': 'f32 elementwise, f64 accumulate', 'data': 'synthetic',
+      'dtype': 'f32 (elementwise) + f64 (sums)', 'data': 'synthetic',
       'config': {
           'workload': ('BASELINE configs[1]: 721x1440x13 f32, deterministic '
                        'MSE+RMSE+MAE+Bias+ACC, 13 predefined slice regions, '
@@ -253,7 +268,8 @@ def main():
           'frac_of_measured_copy_6290': achieved / 6290.0,
           'kernel_ms': k1_avg_s * 1e3,
           'algorithmic_bytes_per_launch': pts_step * BYTES_PER_PT,
-          'traffic': None,
+          'traffic': measured_traffic('deterministic', units_per_launch=units,
+                                      regions=nr),
       },
   }
   if rank == 0:
@@ -350,7 +366,11 @@ def secondary(args):
                    'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBPS, 'kernel_ms': k_s * 1e3,
                    'algorithmic_bytes_per_launch': pts * bytes_per_pt,
-                   'traffic': None}}))
+                   'traffic': (measured_traffic('ensemble', slabs_per_launch=13,
+                                                members=args.members)
+                               if args.workload == 'ensemble' else
+                               measured_traffic('spectrum',
+                                                units_per_launch=8))}}))
 
 
 if __name__ == '__main__':

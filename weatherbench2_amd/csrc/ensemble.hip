@@ -175,8 +175,12 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   }
 }
 
+#ifndef WB2_ENS_MIN_WAVES
+#define WB2_ENS_MIN_WAVES 1
+#endif
+
 template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
     ens_partials_kernel(const EnsParams p) {
   constexpr int K = SKIPNA ? 10 : 6, NWF = WF ? 2 : 1;
   constexpr int NM = MS > 0 ? MS : NPAD;
