@@ -152,11 +152,28 @@ def main():
   if args.gpus != world:
     if world == 1 and args.gpus > 1:
       raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run')
+  if os.environ.get('WB2_BENCH_SAME_GPU'):  # smoke test of N > 1 on one GPU
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
+  # RCCL ("nccl") is the production backend; WB2_BENCH_DIST_BACKEND=gloo exists
+  # only so the N > 1 control flow can be smoke-tested on a 1-GPU box.
+  backend = os.environ.get('WB2_BENCH_DIST_BACKEND', 'nccl')
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=dev)
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=dev)
+    else:
+      dist.init_process_group(backend)
+
+  def all_reduce(tensor, op=None):
+    op = op or dist.ReduceOp.SUM
+    if backend == 'nccl':
+      dist.all_reduce(tensor, op=op)
+      return tensor
+    host = tensor.cpu()
+    dist.all_reduce(host, op=op)
+    return host.to(tensor.device)
 
   lat = np.linspace(-90, 90, N_LAT)
   lon = np.linspace(0, 360, N_LON, endpoint=False)
@@ -210,7 +227,7 @@ def main():
   # which costs tens of ms and is not part of the hot path.
   _ = (total / count).sum().item()
   if world > 1:
-    dist.all_reduce(torch.stack([total, count]))
+    all_reduce(torch.stack([total, count]))
   total.zero_()
   count.zero_()
   torch.cuda.synchronize()
@@ -225,8 +242,7 @@ def main():
     step(args.warmup + i, True)
   g1.record()
   if world > 1:
-    packed = torch.stack([total, count])
-    dist.all_reduce(packed)  # RCCL over xGMI: the only exchange of the path
+    packed = all_reduce(torch.stack([total, count]))  # the path's only exchange
     total, count = packed[0], packed[1]
   mean = total / count
   torch.cuda.synchronize()
@@ -235,8 +251,8 @@ def main():
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   if world > 1:
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev),
+                      dist.ReduceOp.MAX)
     dt = float(tmax.item())
   assert torch.isfinite(mean).all()
 
