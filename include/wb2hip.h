@@ -245,6 +245,29 @@ int wb2_ens_threshold_partials(
     const int32_t* seg_col0, const int32_t* seg_eoff, int32_t n_seg,
     int32_t n_ts, double* partials, void* stream);
 
+/*
+ * RankHistogram (metrics.py:1894-2042): truth's rank among the n_member
+ * members of each sample, binned by (n_member + 1) / n_bins, as float64.
+ * Sample (o, pt): members at ens[(m * member_stride) + ens_slab[o] * n_point + pt]
+ * (member_stride in ELEMENTS), truth at truth[truth_slab[o] * n_point + pt];
+ * NULL tables mean identity.  rank = #{x_m < t}; ties (x_m == t) are broken
+ * uniformly at random from a counter-based hash of (seed, o, pt) when
+ * break_ties != 0 (the reference perturbs with NumPy's RNG, :1955-1980 --
+ * same distribution, different stream), else truth goes first.  NaN members
+ * rank highest.
+ *   acc_row == NULL: out[n_outer][n_point][n_bins] is fully written (one-hot).
+ *   acc_row != NULL: out[acc_row[o]][n_point][n_bins] += 1 per sample (the
+ *                    caller zero-fills `out`; the temporal mean of Metric.compute
+ *                    :117-138 is then out / n_time).
+ * Fails when (n_member + 1) % n_bins != 0 (:1933-1938).
+ */
+int wb2_rank_histogram(int dtype, const void* ens, const int64_t* ens_slab,
+                       const void* truth, const int64_t* truth_slab,
+                       int32_t n_member, int64_t member_stride, int64_t n_outer,
+                       int64_t n_point, int32_t n_bins, int break_ties,
+                       uint64_t seed, const int64_t* acc_row, double* out,
+                       void* stream);
+
 /* As wb2_ens_partials, additionally storing the six pointwise values
  * (skill, spread, (t-mean)^2, var, std^2, debiased; NaN where undefined) to
  * maps[6][n_outer][n_row*n_col] (fp64, may be NULL): the Spatial* ensemble

@@ -794,6 +794,84 @@ class SEEPS(SpatialSEEPS):
     return spatial_average(result, region=region, skipna=True)
 
 
+# ---------------------------------------------------------------------------
+# Tier 2: RankHistogram (metrics.py:1894-2042), central_reliability (:2045-2126)
+# ---------------------------------------------------------------------------
+class RankHistogram(EnsembleMetric):
+  """One-hot encoding of truth's rank among the members (bins dim last)."""
+
+  def __init__(self, ensemble_dim=REALIZATION, num_bins=None,
+               break_ties_randomly=True, seed=None):
+    super().__init__(ensemble_dim=ensemble_dim)
+    self.num_bins = num_bins
+    self._break_ties_randomly = break_ties_randomly
+    self._seed = seed
+
+  def _num_bins_actual(self, ensemble_size):
+    default_n_bins = ensemble_size + 1
+    if self.num_bins is None:
+      return default_n_bins
+    if default_n_bins % self.num_bins:
+      raise ValueError(
+          f'Cannot bin data with {ensemble_size=} into {self.num_bins} bins')
+    return self.num_bins
+
+  def _perturb(self, data: np.ndarray, idx: int) -> np.ndarray:
+    """metrics.py:1955-1980."""
+    if data.shape[idx] < 2:
+      return data
+    with np.errstate(all='ignore'):
+      diffs = np.diff(np.sort(data, axis=idx), axis=idx)
+      diffs = np.where(diffs == 0, np.inf, diffs)
+      min_diff = diffs.min(axis=idx, keepdims=True)
+      size = np.where(min_diff < np.inf, min_diff / 2, 1)
+    perturbation = np.random.default_rng(self._seed).uniform(
+        size=data.shape, low=-size / 2, high=size / 2)
+    return data + perturbation
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    out = {}
+    for name in [k for k in forecast.keys() if k in truth.keys()]:
+      f = forecast[name]
+      ax = f.dims.index(self.ensemble_dim)
+      rest = tuple(d for d in f.dims if d != self.ensemble_dim)
+      fd = np.moveaxis(f.data, ax, 0)
+      td = NA._align(NA(np.zeros(fd.shape[1:]), rest), truth[name])[1]
+      td = np.broadcast_to(td, fd.shape[1:])
+      combined = np.concatenate([td[None], fd], axis=0)  # truth prepended
+      if self._break_ties_randomly:
+        combined = self._perturb(combined, 0)
+      ensemble_size = fd.shape[0]
+      num_bins = self._num_bins_actual(ensemble_size)
+      order = np.argsort(combined, axis=0)
+      ranks = np.argmin(order, axis=0)  # where the truth (index 0) ended up
+      factor = (ensemble_size + 1) // num_bins
+      if factor != 1:
+        ranks = ranks // factor
+      out[name] = NA(np.eye(num_bins)[ranks], rest + ('bins',))
+    coords = {k: c for k, c in forecast.coords.items() if k != self.ensemble_dim}
+    coords['bins'] = np.arange(num_bins)
+    return DS(out, coords)
+
+
+def central_reliability(hist: np.ndarray) -> tuple:
+  """metrics.py:2045-2126 on an array whose LAST axis is `bins`.
+  Returns (probs[..., prob_index], desired_prob[prob_index])."""
+  n_bins = hist.shape[-1]
+  if n_bins < 3:
+    raise ValueError(f'Too few bins. {n_bins=} but should be >= 3')
+  left = hist[..., :n_bins // 2]
+  right = hist[..., n_bins // 2 + n_bins % 2:]
+  probs = np.cumsum(left[..., ::-1] + right, axis=-1)
+  desired = np.ones(probs.shape[-1])
+  if n_bins % 2:
+    center = hist[..., n_bins // 2]
+    probs = np.concatenate([center[..., None], center[..., None] + probs], -1)
+    desired = np.concatenate(([0.5], desired))
+  desired = np.cumsum(desired)
+  return probs, desired / desired[-1]
+
+
 def crps_brute_force(forecast: DS, truth: DS, skipna: bool) -> dict:
   """The reference TEST's O(M^2) eFAIR CRPS (metrics_test.py:896-920)."""
 

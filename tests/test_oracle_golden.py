@@ -339,3 +339,55 @@ def test_spectrum_last_bin_doubled_even_n():
   x = np.array([[1.0, -1.0, 1.0, -1.0]])  # pure Nyquist, N = 4
   p = spectrum_np.simple_power(x)
   np.testing.assert_allclose(p[0], [0, 0, 2.0])
+
+
+@pytest.mark.parametrize('ensemble_size,num_bins', [(1, None), (10, None),
+                                                    (2, None), (9, 5)])
+def test_rank_histogram_well_and_mis_calibrated(ensemble_size, num_bins):
+  # metrics_test.py:540-600
+  num_bins = ensemble_size + 1 if num_bins is None else num_bins
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, time_start='2019-12-01',
+      time_stop='2019-12-10', levels=(0, 1, 2, 3, 4))
+  data = forecast['geopotential'].data.copy()
+  lev = forecast['geopotential'].dims.index('level')
+  sl = lambda i: tuple(i if a == lev else slice(None) for a in range(data.ndim))
+  data[sl(1)] *= 0.1
+  data[sl(2)] *= 10
+  data[sl(3)] -= 1
+  data[sl(4)] += 1
+  forecast = forecast.copy(data={'geopotential': data})
+  one_hot = metrics.RankHistogram(num_bins=num_bins).compute_chunk(forecast,
+                                                                   truth)
+  v = one_hot['geopotential']
+  assert v.sizes == {**{d: s for d, s in forecast.sizes.items()
+                        if d != 'realization'}, 'bins': num_bins}
+  avg = tuple(d for d in v.dims if d not in ('bins', 'level'))
+  sample_size = np.prod([v.sizes[d] for d in avg])
+  rtol = 5 * np.sqrt((num_bins - 1) / sample_size)
+  hist = v.mean(avg).transpose('level', 'bins').data
+  np.testing.assert_allclose(1 / num_bins, hist[0], rtol=rtol)
+  if num_bins > 2:
+    convex, concave = hist[1], hist[2]
+    assert (np.diff(convex[:len(convex) // 2 + 1]) < 0).all()
+    assert (np.diff(convex[len(convex) // 2:]) > 0).all()
+    assert (np.diff(concave[:len(concave) // 2 + 1]) > 0).all()
+    assert (np.diff(concave[len(concave) // 2:]) < 0).all()
+  assert (np.diff(hist[3]) > 0).all()
+  assert (np.diff(hist[4]) < 0).all()
+
+
+@pytest.mark.parametrize('n_bins', [3, 4, 10, 11])
+def test_central_reliability_perfectly_calibrated(n_bins):
+  # metrics_test.py:666-700
+  hist = np.ones((n_bins,)) / n_bins
+  probs, desired = metrics.central_reliability(hist)
+  expected = np.ones((n_bins // 2,))
+  if n_bins % 2:
+    expected = np.concatenate(([0.5], expected))
+  expected = np.cumsum(expected) / np.sum(expected)
+  assert len(desired) == n_bins // 2 + n_bins % 2
+  np.testing.assert_allclose(probs, expected)
+  np.testing.assert_allclose(desired, expected)
+  with pytest.raises(ValueError):
+    metrics.central_reliability(np.ones(2) / 2)

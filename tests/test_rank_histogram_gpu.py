@@ -1,0 +1,216 @@
+"""GPU parity of RankHistogram (-m gpu) and host parity of central_reliability.
+
+Tie-free inputs: the counting kernel must equal the reference's
+argsort-of-perturbed-values rank exactly (the oracle restates that with NumPy's
+RNG).  Tied inputs: the reference's own statistical tests
+(metrics_test.py:538-650), since tie breaking is random by definition.
+"""
+import numpy as np
+import pytest
+
+from oracle import fixtures
+from oracle import metrics_np as om
+from oracle.named import DS, NA
+from tests import helpers
+
+
+def _values(da):
+  v = da.data
+  return v.cpu().numpy() if hasattr(v, 'cpu') else np.asarray(v)
+
+
+def _as(ds, dtype):
+  return ds.copy(data={k: v.data.astype(dtype) for k, v in ds.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ensemble_size,num_bins,dtype', [
+    (1, None, np.float32), (2, None, np.float64), (10, None, np.float32),
+    (9, 5, np.float32), (50, None, np.float32), (50, 17, np.float64),
+    (127, 64, np.float32)])
+def test_one_hot_matches_oracle_without_ties(ensemble_size, num_bins, dtype):
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, spatial_resolution_in_degrees=15,
+      time_start='2019-12-01', time_stop='2019-12-04', levels=(0, 1, 2))
+  truth, forecast = _as(truth, dtype), _as(forecast, dtype)
+  want = om.RankHistogram(num_bins=num_bins, seed=3).compute_chunk(
+      forecast, truth)
+  g = helpers.to_gpu_dataset
+  got = gm.RankHistogram(num_bins=num_bins, seed=3).compute_chunk(
+      g(forecast), g(truth))
+  for name in want.keys():
+    w = want[name].transpose(*got[name].dims)
+    a = _values(got[name])
+    assert a.dtype == np.float64
+    np.testing.assert_array_equal(a, w.data)
+    np.testing.assert_array_equal(a.sum(-1), 1.0)
+  np.testing.assert_array_equal(got.coords['bins'],
+                                np.arange(num_bins or ensemble_size + 1))
+
+
+@pytest.mark.gpu
+def test_nan_members_and_truth_rank_highest():
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=6, spatial_resolution_in_degrees=20,
+      time_start='2019-12-01', time_stop='2019-12-03', levels=(0,))
+  forecast = fixtures.insert_nan(forecast, 0.2, seed=4)
+  g = helpers.to_gpu_dataset
+  # without perturbation NumPy's sort puts NaNs last and the rest is tie-free
+  want = om.RankHistogram(break_ties_randomly=False).compute_chunk(
+      forecast, truth)
+  got = gm.RankHistogram(break_ties_randomly=False).compute_chunk(
+      g(forecast), g(truth), skipna=True)
+  w = want['geopotential'].transpose(*got['geopotential'].dims)
+  np.testing.assert_array_equal(_values(got['geopotential']), w.data)
+  # NaN truth: above every non-NaN member
+  tdata = truth['geopotential'].data.copy()
+  tdata[...] = np.nan
+  nan_truth = truth.copy(data={'geopotential': tdata})
+  got = gm.RankHistogram().compute_chunk(g(forecast), g(nan_truth))
+  fd = forecast['geopotential']
+  ax = fd.dims.index('realization')
+  n_ok = (~np.isnan(fd.data)).sum(ax)
+  rest = tuple(d for d in fd.dims if d != 'realization')
+  ranks = _values(got['geopotential']).argmax(-1)
+  order = [rest.index(d) for d in got['geopotential'].dims[:-1]]
+  np.testing.assert_array_equal(ranks, np.transpose(n_ok, order))
+
+
+@pytest.mark.gpu
+def test_compute_is_temporal_mean_of_chunks():
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=5, spatial_resolution_in_degrees=15,
+      time_start='2019-12-01', time_stop='2019-12-08', levels=(0, 1))
+  g = helpers.to_gpu_dataset
+  metric = gm.RankHistogram(num_bins=3, seed=0)
+  chunk = metric.compute_chunk(g(forecast), g(truth))['geopotential']
+  mean = metric.compute(g(forecast), g(truth))
+  assert mean.attrs['ensemble_size'] == 5
+  da = mean['geopotential']
+  assert 'time' not in da.dims and da.dims[-1] == 'bins'
+  want = _values(chunk).mean(chunk.dims.index('time'))
+  np.testing.assert_allclose(_values(da), want, rtol=0, atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_ties_are_broken_uniformly_and_reproducibly():
+  # metrics_test.py:603-650: forecast == truth == 0 everywhere
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=4, spatial_resolution_in_degrees=10,
+      time_start='2019-12-01', time_stop='2019-12-21', levels=(0, 1))
+  truth, forecast = truth * 0.0, forecast * 0.0
+  g = helpers.to_gpu_dataset
+  a = gm.RankHistogram(seed=11).compute_chunk(g(forecast), g(truth))
+  b = gm.RankHistogram(seed=11).compute_chunk(g(forecast), g(truth))
+  c = gm.RankHistogram(seed=12).compute_chunk(g(forecast), g(truth))
+  va, vb, vc = (_values(x['geopotential']) for x in (a, b, c))
+  np.testing.assert_array_equal(va, vb)
+  assert (va != vc).any()
+  flat = va.reshape(-1, 5)
+  hist = flat.mean(0)
+  rtol = 5 * np.sqrt(4 / flat.shape[0])
+  np.testing.assert_allclose(hist, 0.2, rtol=rtol)
+  # neighbouring samples must not share their draw
+  ranks = flat.argmax(-1)
+  assert abs(np.corrcoef(ranks[:-1], ranks[1:])[0, 1]) < 0.02
+  # partially tied: two of four members equal the truth -> rank in {lo..lo+2}
+  first = gm.RankHistogram(break_ties_randomly=False).compute_chunk(
+      g(forecast), g(truth))
+  np.testing.assert_array_equal(
+      _values(first['geopotential']).reshape(-1, 5).argmax(-1), 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ensemble_size,num_bins', [(1, None), (10, None),
+                                                    (9, 5)])
+def test_well_and_mis_calibrated_levels(ensemble_size, num_bins):
+  # metrics_test.py:540-600 through compute() (device-side temporal mean)
+  from weatherbench2_amd import metrics as gm
+  num_bins = ensemble_size + 1 if num_bins is None else num_bins
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, time_start='2019-12-01',
+      time_stop='2019-12-10', levels=(0, 1, 2, 3, 4))
+  data = forecast['geopotential'].data.copy()
+  lev = forecast['geopotential'].dims.index('level')
+  sl = lambda i: tuple(i if a == lev else slice(None)
+                       for a in range(data.ndim))
+  data[sl(1)] *= 0.1
+  data[sl(2)] *= 10
+  data[sl(3)] -= 1
+  data[sl(4)] += 1
+  forecast = forecast.copy(data={'geopotential': data})
+  g = helpers.to_gpu_dataset
+  mean = gm.RankHistogram(num_bins=num_bins).compute(g(forecast), g(truth))
+  da = mean['geopotential']
+  v = _values(da)
+  keep = (da.dims.index('level'), da.dims.index('bins'))
+  others = tuple(i for i in range(v.ndim) if i not in keep)
+  hist = v.mean(others)
+  if keep[0] > keep[1]:
+    hist = hist.T
+  n_time = forecast.sizes['time']
+  sample_size = v.size / v.shape[keep[0]] / num_bins * n_time
+  rtol = 5 * np.sqrt((num_bins - 1) / sample_size)
+  np.testing.assert_allclose(hist[0], 1 / num_bins, rtol=rtol)
+  if num_bins > 2:
+    convex, concave = hist[1], hist[2]
+    assert (np.diff(convex[:len(convex) // 2 + 1]) < 0).all()
+    assert (np.diff(convex[len(convex) // 2:]) > 0).all()
+    assert (np.diff(concave[:len(concave) // 2 + 1]) > 0).all()
+    assert (np.diff(concave[len(concave) // 2:]) < 0).all()
+  assert (np.diff(hist[3]) > 0).all()
+  assert (np.diff(hist[4]) < 0).all()
+  # perfectly calibrated level: the reliability curve is the diagonal
+  if num_bins >= 3:
+    from weatherbench2_amd import xarray_lite as xl
+    rel = gm.central_reliability(xl.DataArray(
+        hist[0], ('bins',), {'bins': np.arange(num_bins)}, 'z'))
+    np.testing.assert_allclose(rel.values, rel.coords['desired_prob'],
+                               atol=3 * rtol)
+
+
+@pytest.mark.gpu
+def test_bad_bin_count_raises():
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=4, spatial_resolution_in_degrees=30)
+  g = helpers.to_gpu_dataset
+  with pytest.raises(ValueError, match='Cannot bin data'):
+    gm.RankHistogram(num_bins=3).compute_chunk(g(forecast), g(truth))
+
+
+# ---- host logic, no GPU needed ---------------------------------------------
+@pytest.mark.parametrize('n_bins', [3, 4, 10, 11])
+def test_central_reliability_matches_oracle(n_bins):
+  from weatherbench2_amd import metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  rng = np.random.default_rng(n_bins)
+  hist = rng.random((2, n_bins, 3))
+  hist /= hist.sum(1, keepdims=True)
+  da = xl.DataArray(hist, ('level', 'bins', 'region'),
+                    {'level': np.arange(2), 'bins': np.arange(n_bins)}, 'z')
+  got = gm.central_reliability(da)
+  probs, desired = om.central_reliability(np.moveaxis(hist, 1, -1))
+  assert got.dims == (('desired_prob', 'level', 'region') if n_bins % 2
+                      else ('level', 'desired_prob', 'region'))
+  np.testing.assert_allclose(
+      np.moveaxis(np.asarray(got.values), got.dims.index('desired_prob'), -1),
+      probs, rtol=1e-15)
+  np.testing.assert_allclose(got.coords['desired_prob'], desired, rtol=1e-15)
+  assert np.asarray(got.values).max() <= 1 + 1e-12
+  # Dataset in, Dataset out
+  ds = gm.central_reliability(xl.Dataset({'z': da}, da.coords))
+  np.testing.assert_array_equal(np.asarray(ds['z'].values),
+                                np.asarray(got.values))
+
+
+def test_central_reliability_too_few_bins():
+  from weatherbench2_amd import metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  with pytest.raises(ValueError, match='Too few bins'):
+    gm.central_reliability(xl.DataArray(np.ones(2) / 2, ('bins',),
+                                        {'bins': np.arange(2)}, 'z'))

@@ -30,6 +30,7 @@ ENS_METRIC_INDEX = {'crps': 0, 'crps_spread': 1, 'crps_skill': 2,
 
 _c = ctypes
 _vp, _i32, _i64, _int = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_int
+_u64 = _c.c_uint64
 
 _SIGNATURES = {
     'wb2_version': (_int, []),
@@ -57,6 +58,9 @@ _SIGNATURES = {
     'wb2_ens_threshold_partials': (_int, [
         _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32,
         _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'wb2_rank_histogram': (_int, [
+        _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _int, _u64, _vp,
+        _vp, _vp]),
     'wb2_ens_combine': (_int, [
         _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
         _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -1,0 +1,181 @@
+// K6 of libwb2hip.so: the rank histogram of an ensemble forecast.
+//
+// Replaces (reference = /root/reference/weatherbench2/metrics.py):
+//   RankHistogram.compute_chunk        :1982-2042
+//     combined = concat([truth, forecast], ensemble_dim)          :2001-2014
+//     _perturb_by_min_ensemble_diff (random tie breaking)         :1955-1980
+//     ranks = argmin(argsort(combined))  -> truth's position      :2024-2027
+//     _bin_ranks: rank // ((M + 1) // num_bins)                   :1941-1953
+//     np.eye(num_bins)[ranks]  (float64 one-hot, `bins` last)     :2031-2038
+//   and its temporal mean (Metric.compute :117-138).
+//
+// The sort is not needed: truth's position among the members is
+//   lo = #{x_m < t},  eq = #{x_m == t},  rank in [lo, lo + eq].
+// Without ties (eq == 0) this IS the reference's rank, bit for bit: its
+// perturbation is at most a quarter of the smallest gap, so it cannot reorder
+// distinct values.  With ties the reference draws NumPy-RNG perturbations,
+// which makes the truth's place among the eq + 1 equal values uniform; here
+// that uniform draw comes from a counter-based hash of (seed, sample index),
+// statistically equivalent and reproducible, but not NumPy's bit stream.
+// break_ties=0 puts the truth first among equals (the reference leaves that
+// case to an unstable argsort).  NaN members rank above everything; a NaN truth
+// ranks above every non-NaN member (:1909-1912).
+//
+// One lane per grid point: M + 1 coalesced loads, integer compares.  Output:
+//   one-hot   (acc_row == null)  each wave writes its 64 x n_bins doubles as
+//             one contiguous, coalesced run (bins fetched across lanes).
+//   counts    (acc_row != null)  one fp64 atomic add of 1.0 per sample into the
+//             time-collapsed histogram; integer-valued sums are exact in any
+//             order, so the result is deterministic.
+// HBM bound: (M + 1) * sizeof(T) read + n_bins * 8 written per sample.
+
+#include "common.hpp"
+#include "wb2hip.h"
+
+namespace wb2 {
+namespace {
+
+struct RankParams {
+  const void* ens;
+  const void* truth;
+  const long long* ens_slab;
+  const long long* truth_slab;
+  const long long* acc_row;
+  double* out;
+  long long member_stride, n_outer, n_point;
+  unsigned long long seed;
+  int n_member, n_bins, factor, break_ties;
+};
+
+// splitmix64 finaliser: a counter-based stream, one draw per sample
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long wave_pt0 =
+      ((long long)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+  const long long pt = wave_pt0 + lane;
+  const long long o = blockIdx.y + (long long)blockIdx.z * gridDim.y;
+  if (o >= p.n_outer || wave_pt0 >= p.n_point) return;  // wave-uniform
+  const bool active = pt < p.n_point;
+  const long long es = p.ens_slab ? p.ens_slab[o] : o;
+  const long long ts = p.truth_slab ? p.truth_slab[o] : o;
+  const int M = p.n_member;
+
+  int bin = 0;
+  if (active) {
+    const T* xb = static_cast<const T*>(p.ens) + es * p.n_point + pt;
+    const T t = __builtin_nontemporal_load(
+        static_cast<const T*>(p.truth) + ts * p.n_point + pt);
+    int lo = 0, eq = 0, nn = 0;
+    int m = 0;
+    for (; m + 4 <= M; m += 4) {  // four loads in flight
+      T x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        x[u] = __builtin_nontemporal_load(xb + (m + u) * p.member_stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        lo += x[u] < t ? 1 : 0;
+        eq += x[u] == t ? 1 : 0;
+        nn += is_nan(x[u]) ? 0 : 1;
+      }
+    }
+    for (; m < M; ++m) {
+      const T x = __builtin_nontemporal_load(xb + m * p.member_stride);
+      lo += x < t ? 1 : 0;
+      eq += x == t ? 1 : 0;
+      nn += is_nan(x) ? 0 : 1;
+    }
+    int rank = is_nan(t) ? nn : lo;
+    if (eq > 0 && p.break_ties) {
+      const unsigned long long h =
+          mix64(p.seed ^ mix64((unsigned long long)(o * p.n_point + pt)));
+      // uniform integer in [0, eq]: high bits of a 32x32 multiply
+      rank += (int)(((h >> 32) * (unsigned long long)(eq + 1)) >> 32);
+    }
+    bin = rank / p.factor;
+  }
+
+  if (p.acc_row) {
+    if (active)
+      atomicAdd(p.out + (p.acc_row[o] * p.n_point + pt) * p.n_bins + bin, 1.0);
+    return;
+  }
+  // one-hot: this wave owns out[o][wave_pt0 .. +64)[0 .. n_bins), contiguous
+  const long long npt = p.n_point - wave_pt0 < kWave ? p.n_point - wave_pt0
+                                                     : kWave;
+  double* dst = p.out + (o * p.n_point + wave_pt0) * p.n_bins;
+  const int total = (int)npt * p.n_bins;
+  const int dq = kWave / p.n_bins, dr = kWave % p.n_bins;
+  int src = lane / p.n_bins, b = lane % p.n_bins;
+  for (int i = lane; i - lane < total; i += kWave) {  // wave-uniform trip count
+    const int their = __shfl(bin, src & (kWave - 1), kWave);
+    if (i < total) __builtin_nontemporal_store(their == b ? 1.0 : 0.0, dst + i);
+    src += dq;
+    b += dr;
+    if (b >= p.n_bins) {
+      b -= p.n_bins;
+      ++src;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace wb2
+
+extern "C" int wb2_rank_histogram(int dtype, const void* ens,
+                                  const int64_t* ens_slab, const void* truth,
+                                  const int64_t* truth_slab, int32_t n_member,
+                                  int64_t member_stride, int64_t n_outer,
+                                  int64_t n_point, int32_t n_bins,
+                                  int break_ties, uint64_t seed,
+                                  const int64_t* acc_row, double* out,
+                                  void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64,
+              "dtype must be WB2_F32 or WB2_F64, got %d", dtype);
+  WB2_REQUIRE(ens && truth && out, "ens, truth and out must not be null");
+  WB2_REQUIRE(n_member >= 1 && n_outer >= 0 && n_point >= 0,
+              "bad sizes: n_member=%d n_outer=%lld n_point=%lld", n_member,
+              (long long)n_outer, (long long)n_point);
+  // metrics.py:1933-1938
+  WB2_REQUIRE(n_bins >= 1 && (n_member + 1) % n_bins == 0,
+              "Cannot bin data with ensemble_size=%d into %d bins", n_member,
+              n_bins);
+  WB2_REQUIRE((long long)n_point * n_bins < (1ll << 31) * kWave,
+              "n_point * n_bins too large");
+  if (n_outer == 0 || n_point == 0) return 0;
+  RankParams p;
+  p.ens = ens;
+  p.truth = truth;
+  p.ens_slab = reinterpret_cast<const long long*>(ens_slab);
+  p.truth_slab = reinterpret_cast<const long long*>(truth_slab);
+  p.acc_row = reinterpret_cast<const long long*>(acc_row);
+  p.out = out;
+  p.member_stride = member_stride;
+  p.n_outer = n_outer;
+  p.n_point = n_point;
+  p.seed = seed;
+  p.n_member = n_member;
+  p.n_bins = n_bins;
+  p.factor = (n_member + 1) / n_bins;
+  p.break_ties = break_ties;
+  const long long gy = n_outer < 32768 ? n_outer : 32768;
+  const long long gz = (n_outer + gy - 1) / gy;
+  WB2_REQUIRE(gz <= 65535, "n_outer=%lld too large", (long long)n_outer);
+  const dim3 grid((unsigned)((n_point + 255) / 256), (unsigned)gy, (unsigned)gz);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    hipLaunchKernelGGL(rank_histogram_kernel<float>, grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(rank_histogram_kernel<double>, grid, dim3(256), 0, s, p);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}

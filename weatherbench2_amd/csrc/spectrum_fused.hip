@@ -232,10 +232,15 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifndef WB2_FFT_DIAG
+#define WB2_FFT_DIAG 0  // 1: skip the FFT passes, 2: skip the epilogue stores
+#endif
+#if WB2_FFT_DIAG != 1
 #if WB2_FFT_TW_GLOBAL
     stockham_all<N2, 1>(z, p.twz, lane);
 #else
     stockham_all<N2, 1>(z, s_twz, lane);
+#endif
 #endif
     // ---- recombination + power for the bin pairs (k, N2 - k) ----
     const double c = p.circ[(unsigned)(row % p.n_lat)];
@@ -257,10 +262,14 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
         const float p1 = x1.x * x1.x + x1.y * x1.y;
         const float p2 = x2.x * x2.x + x2.y * x2.y;
         // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
+#if WB2_FFT_DIAG == 2
+        if (p1 + p2 == 1.2345f) orow[k] = p1;
+#else
         __builtin_nontemporal_store(((double)p1 * (k == 0 ? 1.0 : 2.0)) * c,
                                     orow + k);
         if (2 * k != N2)
           __builtin_nontemporal_store(((double)p2 * 2.0) * c, orow + N2 - k);
+#endif
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

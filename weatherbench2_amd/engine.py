@@ -320,3 +320,30 @@ def ensemble_threshold_reduce(plan: ReductionPlan, ens: torch.Tensor,
       _lib.ptr(plan.region_wf), _lib.ptr(plan.region_wsum), plan.n_region,
       None, _lib.ptr(metrics), stream), 'wb2_det_combine')
   return metrics
+
+
+def rank_histogram(ens: torch.Tensor, member_stride: int, n_member: int,
+                   ens_slab, truth: torch.Tensor, truth_slab, n_outer: int,
+                   n_point: int, n_bins: int, break_ties: bool, seed: int,
+                   acc_row=None, n_acc: int = 0) -> torch.Tensor:
+  """wb2_rank_histogram: one-hot [n_outer, n_point, n_bins] (float64), or with
+  `acc_row` the per-row counts [n_acc, n_point, n_bins]."""
+  lib = _lib.load()
+  dev = ens.device
+  if ens.dtype not in _DTYPES or truth.dtype != ens.dtype:
+    raise TypeError('members and truth must share a float32/float64 dtype')
+  for x in (ens, truth):
+    if x.device != dev or not x.is_contiguous():
+      raise ValueError('inputs must be contiguous on one device')
+  if acc_row is None:
+    out = torch.empty((n_outer, n_point, n_bins), dtype=torch.float64,
+                      device=dev)
+  else:
+    out = torch.zeros((n_acc, n_point, n_bins), dtype=torch.float64,
+                      device=dev)
+  _lib.check(lib.wb2_rank_histogram(
+      _DTYPES[ens.dtype], _lib.ptr(ens), _lib.ptr(ens_slab), _lib.ptr(truth),
+      _lib.ptr(truth_slab), n_member, member_stride, n_outer, n_point, n_bins,
+      int(break_ties), seed & 0xFFFFFFFFFFFFFFFF, _lib.ptr(acc_row),
+      _lib.ptr(out), current_stream_ptr(dev)), 'wb2_rank_histogram')
+  return out

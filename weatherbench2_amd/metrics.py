@@ -28,6 +28,7 @@ from __future__ import annotations
 import contextlib
 import dataclasses
 import functools
+import os
 import threading
 import typing as t
 
@@ -588,17 +589,9 @@ def _get_n_ensemble(ds: xl.Dataset, ensemble_dim: str,
   return n_ensemble
 
 
-@_serialized
-def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
-              want_maps: bool = False):
-  """All ensemble metrics of one variable for the active regions (and, with
-  `want_maps`, the six pointwise maps as a device tensor)."""
-  fvar, tvar = forecast[name], truth[name]
-  pins = [fvar.data, tvar.data]
-  key = _result_key(('ens', ensemble_dim, want_maps), pins, region, skipna)
-  hit = _RESULTS.get(key)
-  if hit is not None:
-    return hit
+def _ens_layout(forecast, fvar, tvar, ensemble_dim):
+  """Device tensors + slab tables of one ensemble variable: member m of outer
+  index o is slab  m * stride_member + ens_table[o]  of the forecast array."""
   if ensemble_dim not in fvar.dims:
     raise ValueError(f'{ensemble_dim=} not found in {fvar.dims=}')
   fdata, frest, layout = _spatial_last(fvar, None)
@@ -636,11 +629,6 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   truth_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
 
   device = engine.require_gpu()
-  regions, _ = _region_set_for(region)
-  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
-  pl = plan_lib.cached_plan(
-      geo.latitude, geo.longitude, geo.layout, regions, device,
-      plan_lib.auto_rows_per_chunk(n_row, geo.n_outer))
   ften, tten = _to_device(fdata, device), _to_device(tdata, device)
   dtype = torch.promote_types(ften.dtype, tten.dtype)
   if dtype not in (torch.float32, torch.float64):
@@ -649,15 +637,37 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   tten = tten if tten.dtype == dtype else tten.to(dtype)
   _check_grid(geo, ften)
   _check_grid(geo, tten)
-  slab_elems = pl.n_row * pl.n_col
   to_dev = lambda tb: None if tb is None else torch.from_numpy(tb).to(device)
+  return (geo, ften, tten, None if identity else to_dev(ens_table),
+          to_dev(truth_table), strides[ensemble_dim], n_member, device)
+
+
+@_serialized
+def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
+              want_maps: bool = False):
+  """All ensemble metrics of one variable for the active regions (and, with
+  `want_maps`, the six pointwise maps as a device tensor)."""
+  fvar, tvar = forecast[name], truth[name]
+  pins = [fvar.data, tvar.data]
+  key = _result_key(('ens', ensemble_dim, want_maps), pins, region, skipna)
+  hit = _RESULTS.get(key)
+  if hit is not None:
+    return hit
+  geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device = (
+      _ens_layout(forecast, fvar, tvar, ensemble_dim))
+  out_shape = geo.out_shape
+  regions, _ = _region_set_for(region)
+  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
+  pl = plan_lib.cached_plan(
+      geo.latitude, geo.longitude, geo.layout, regions, device,
+      plan_lib.auto_rows_per_chunk(n_row, geo.n_outer))
+  slab_elems = pl.n_row * pl.n_col
   maps = (torch.empty((6, geo.n_outer, slab_elems), dtype=torch.float64,
                       device=device) if want_maps else None)
   try:
     metrics, _ = engine.ensemble_reduce(
-        pl, ften, strides[ensemble_dim] * slab_elems, n_member,
-        None if identity else to_dev(ens_table),
-        tten.reshape(-1, pl.n_row, pl.n_col), to_dev(truth_table),
+        pl, ften, member_slabs * slab_elems, n_member, ens_table,
+        tten.reshape(-1, pl.n_row, pl.n_col), truth_table,
         geo.n_outer, skipna, maps=maps)
   except _lib.Wb2HipError as e:
     if 'not supported by the register sort' in str(e):
@@ -1411,3 +1421,150 @@ class SpatialEnsembleMeanMSE(_SpatialEnsembleMetric):
 class DebiasedSpatialEnsembleMeanMSE(_SpatialEnsembleMetric):
   """Debiased (truth - ensemble mean)^2 as a map (metrics.py:1384-1399)."""
   _slot = 'debiased'
+
+
+# ---------------------------------------------------------------------------
+# RankHistogram / central_reliability (metrics.py:1894-2126)
+# ---------------------------------------------------------------------------
+class RankHistogram(EnsembleMetric):
+  """Histogram of truth's rank among the ensemble members (metrics.py:1894-2042).
+
+  compute_chunk returns the float64 one-hot encoding with a trailing `bins`
+  dim; compute() accumulates the temporal mean on the device without
+  materialising the per-time one-hots.  Ranks come from wb2_rank_histogram
+  (counting, no sort): identical to the reference wherever truth differs from
+  every member; ties are broken uniformly at random from a counter-based
+  stream keyed on `seed` (the reference perturbs with NumPy's RNG -- same
+  distribution, different stream; `seed=None` draws a fresh key per call).
+  NaNs rank highest and `skipna` is ignored, like the reference.
+  """
+
+  def __init__(self, ensemble_dim: str = REALIZATION,
+               num_bins: t.Optional[int] = None,
+               break_ties_randomly: bool = True,
+               seed: t.Optional[int] = None):
+    super().__init__(ensemble_dim=ensemble_dim)
+    self.num_bins = num_bins
+    self._break_ties_randomly = break_ties_randomly
+    self._seed = seed
+
+  def _num_bins_actual(self, ensemble_size: int) -> int:
+    """metrics.py:1927-1939 (same message)."""
+    default_n_bins = ensemble_size + 1
+    if self.num_bins is None:
+      return default_n_bins
+    if default_n_bins % self.num_bins:
+      raise ValueError(
+          f'Cannot bin data with {ensemble_size=} into {self.num_bins} bins')
+    return self.num_bins
+
+  @_serialized
+  def _histogram(self, forecast, truth, name, avg_dim=None):
+    fvar, tvar = forecast[name], truth[name]
+    geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device = (
+        _ens_layout(forecast, fvar, tvar, self.ensemble_dim))
+    n_bins = self._num_bins_actual(n_member)
+    n_point = ften.shape[-2] * ften.shape[-1]
+    seed = self._seed
+    if seed is None:
+      seed = int.from_bytes(os.urandom(8), 'little')
+    dims, shape = geo.out_dims, geo.out_shape
+    acc_row, n_acc = None, 0
+    if avg_dim is not None:
+      axis = dims.index(avg_dim)
+      kept = tuple(n for i, n in enumerate(shape) if i != axis)
+      n_acc = int(np.prod(kept, dtype=np.int64))
+      rows = np.arange(n_acc, dtype=np.int64).reshape(kept)
+      rows = np.broadcast_to(np.expand_dims(rows, axis), shape)
+      acc_row = torch.from_numpy(np.ascontiguousarray(rows).ravel()).to(device)
+      dims = tuple(d for d in dims if d != avg_dim)
+      out_shape = kept
+    else:
+      out_shape = shape
+    hist = engine.rank_histogram(
+        ften, member_slabs * n_point, n_member, ens_table,
+        tten.reshape(-1, n_point), truth_table, geo.n_outer, n_point, n_bins,
+        self._break_ties_randomly, seed, acc_row, n_acc)
+    if avg_dim is not None:
+      hist /= shape[axis]
+    spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
+    hist = hist.reshape(tuple(out_shape) + tuple(ften.shape[-2:]) + (n_bins,))
+    return hist, tuple(dims) + tuple(spatial) + ('bins',), n_bins
+
+  def _dataset(self, forecast, truth, avg_dim=None):
+    forecast, truth = _inputs(forecast, truth)
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    out = xl.Dataset()
+    for name in _common_vars(forecast, truth):
+      hist, dims, n_bins = self._histogram(forecast, truth, name, avg_dim)
+      out.coords.update(_spatial_coords(forecast, dims[:-1]))
+      out.coords['bins'] = np.arange(n_bins)
+      out.data_vars[name] = xl.DataArray(hist, dims, out.coords, name)
+    return out
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    """One-hot encoding of rank on a chunk of forecast/truth."""
+    return self._dataset(forecast, truth)
+
+  def compute(self, forecast, truth, region=None, skipna=False):
+    """Rank histogram: the temporal mean of the one-hot encoding."""
+    forecast_ds = xl.as_dataset(forecast)
+    avg_dim = 'time' if 'time' in forecast_ds.dims else 'init_time'
+    if avg_dim not in forecast_ds.dims:
+      raise ValueError(
+          'Forecast has neither valid_time or init_time dimension '
+          f'{forecast_ds}')
+    out = self._dataset(forecast, truth, avg_dim)
+    return out.assign_attrs(
+        ensemble_size=forecast_ds.sizes[self.ensemble_dim])
+
+
+def central_reliability(hist):
+  """Reliability of central prediction intervals (metrics.py:2045-2126).
+
+  `hist` is a DataArray/Dataset with a `bins` dim (RankHistogram's temporal
+  and/or spatial mean).  Returns the cumulative probability of the intervals
+  grown outward from the centre bin(s), on a new `prob_index` dim with the
+  `desired_prob` coordinate.  Tiny host work on an already reduced histogram.
+  """
+  hist = xl.as_dataset(hist) if not isinstance(hist, xl.DataArray) else hist
+  if isinstance(hist, xl.Dataset):
+    out = xl.Dataset(attrs=dict(hist.attrs))
+    for name, da in hist.data_vars.items():
+      r = central_reliability(da)
+      out.coords.update(r.coords)
+      out.data_vars[name] = r
+    return out
+  if 'bins' not in hist.dims:
+    raise ValueError(f"hist has no 'bins' dim: {hist.dims}")
+  n_bins = hist.sizes['bins']
+  if n_bins < 3:
+    raise ValueError(f'Too few bins. {n_bins=} but should be >= 3')
+  axis = hist.dims.index('bins')
+  values = hist.data
+  if isinstance(values, torch.Tensor):
+    values = values.cpu().numpy()
+  values = np.moveaxis(np.asarray(values), axis, -1)
+  left = values[..., :n_bins // 2]
+  right = values[..., n_bins // 2 + n_bins % 2:]
+  probs = np.cumsum(left[..., ::-1] + right, axis=-1)
+  desired = np.ones(probs.shape[-1])
+  if n_bins % 2:
+    center = values[..., n_bins // 2][..., None]
+    probs = np.concatenate([center, center + probs], axis=-1)
+    desired = np.concatenate(([0.5], desired))
+  desired = np.cumsum(desired)
+  desired = desired / desired[-1]
+  # reference dim order: the new dim replaces `bins` for even n_bins; for odd
+  # n_bins the xr.concat with the centre bin puts it first (:2100-2106).  The
+  # final swap_dims names it `desired_prob` (:2126).
+  rest = tuple(d for d in hist.dims if d != 'bins')
+  if n_bins % 2:
+    probs = np.moveaxis(probs, -1, 0)
+    dims = ('desired_prob',) + rest
+  else:
+    probs = np.moveaxis(probs, -1, axis)
+    dims = tuple('desired_prob' if d == 'bins' else d for d in hist.dims)
+  coords = {k: v for k, v in hist.coords.items() if k != 'bins'}
+  coords['desired_prob'] = desired
+  return xl.DataArray(probs, dims, coords, hist.name)
