@@ -246,6 +246,32 @@ int wb2_ens_threshold_partials(
     int32_t n_ts, double* partials, void* stream);
 
 /*
+ * Spatial* threshold metrics (SpatialEnsembleBrierScore,
+ * SpatialDebiasedEnsembleBrierScore, SpatialEnsembleIgnoranceScore,
+ * SpatialEnsembleRPS; metrics.py:1615-1638, 1697-1719, 1780-1802, 1870-1891):
+ * the four per-point scores of wb2_ens_threshold_partials, unreduced, to
+ * maps[4][n_outer][n_point] (fp64; Brier, debiased Brier, ignorance, RPS
+ * part).  Slab addressing as in wb2_rank_histogram (n_point = n_row * n_col).
+ */
+int wb2_ens_threshold_maps(int dtype, int skipna, const void* ens,
+                           const int64_t* ens_slab, const void* truth,
+                           const int64_t* truth_slab, const void* threshold,
+                           const int64_t* thr_slab, int32_t n_member,
+                           int64_t member_stride, int64_t n_outer,
+                           int64_t n_point, double* maps, void* stream);
+
+/*
+ * SpatialSEEPS (metrics.py:418-509): the per-point SEEPS score (NaN where the
+ * forecast, truth or masked dry fraction is NaN) to out[n_outer][n_point]
+ * (fp64).  in = {forecast, truth, wet threshold} in `dtype`, each resolved
+ * through its slab table (NULL = identity); aux = p1[n_point] with NaN where
+ * p1 is outside (min_p1, max_p1); scalar = dry threshold in data units.
+ */
+int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
+                  int64_t n_outer, int64_t n_point, const double* aux,
+                  double scalar, double* out, void* stream);
+
+/*
  * RankHistogram (metrics.py:1894-2042): truth's rank among the n_member
  * members of each sample, binned by (n_member + 1) / n_bins, as float64.
  * Sample (o, pt): members at ens[(m * member_stride) + ens_slab[o] * n_point + pt]

@@ -642,17 +642,19 @@ class ThresholdMetric(Metric):
   thresholds: t.Sequence = ()
   _score = None
   _sum_over_quantile = False
+  _spatial_agg = True
 
   def _score_fn(self, skipna):
     return self._score
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    """metrics.py:947-972 (_map_over_thresholds, spatial_agg=True)."""
+    """metrics.py:947-972 (_map_over_thresholds)."""
     scores = []
     for threshold in self.thresholds:
       threshold_ds = threshold.compute(truth)
       score = self._score_fn(skipna)(forecast, truth, threshold_ds)
-      score = spatial_average(score, region=region, skipna=skipna)
+      if self._spatial_agg:
+        score = spatial_average(score, region=region, skipna=skipna)
       scores.append(score)
     out = DS({k: NA(np.stack([s[k].data for s in scores]),
                     ('quantile',) + scores[0][k].dims)
@@ -714,6 +716,30 @@ class EnsembleRPS(_EnsembleThresholdMetric):
   def _score_fn(self, skipna):
     return lambda f, t_, th: compute_rps_part(
         f, t_, th, self.ensemble_dim, skipna)
+
+
+@dataclasses.dataclass
+class SpatialEnsembleBrierScore(EnsembleBrierScore):
+  """metrics.py:1615-1638."""
+  _spatial_agg = False
+
+
+@dataclasses.dataclass
+class SpatialDebiasedEnsembleBrierScore(DebiasedEnsembleBrierScore):
+  """metrics.py:1697-1719."""
+  _spatial_agg = False
+
+
+@dataclasses.dataclass
+class SpatialEnsembleIgnoranceScore(EnsembleIgnoranceScore):
+  """metrics.py:1780-1802."""
+  _spatial_agg = False
+
+
+@dataclasses.dataclass
+class SpatialEnsembleRPS(EnsembleRPS):
+  """metrics.py:1870-1891."""
+  _spatial_agg = False
 
 
 # ---------------------------------------------------------------------------

@@ -58,6 +58,11 @@ _SIGNATURES = {
     'wb2_ens_threshold_partials': (_int, [
         _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32,
         _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'wb2_ens_threshold_maps': (_int, [
+        _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp,
+        _vp]),
+    'wb2_seeps_map': (_int, [_int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i64,
+                             _vp, _c.c_double, _vp, _vp]),
     'wb2_rank_histogram': (_int, [
         _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _int, _u64, _vp,
         _vp, _vp]),

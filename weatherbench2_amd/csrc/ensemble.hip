@@ -293,6 +293,56 @@ struct EnsThrParams {
   const long long* thr_slab;
 };
 
+// One grid point of the ensemble threshold metrics: v = (Brier, debiased
+// Brier, ignorance, RPS part).  `xb` points at member 0 of this point.
+template <typename T, bool SKIPNA>
+__device__ __forceinline__ void ens_thr_point(const T* xb,
+                                              long long member_stride, int M,
+                                              T t, T thr, double (&v)[4]) {
+  const double nan = __builtin_nan("");
+  int gt = 0, lt = 0, nn = 0;  // members above / below / not NaN
+  int m = 0;
+  for (; m + 4 <= M; m += 4) {  // four loads in flight
+    T x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      x[u] = __builtin_nontemporal_load(xb + (m + u) * member_stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gt += x[u] > thr ? 1 : 0;
+      lt += x[u] < thr ? 1 : 0;
+      nn += is_nan(x[u]) ? 0 : 1;
+    }
+  }
+  for (; m < M; ++m) {
+    const T x = __builtin_nontemporal_load(xb + m * member_stride);
+    gt += x > thr ? 1 : 0;
+    lt += x < thr ? 1 : 0;
+    nn += is_nan(x) ? 0 : 1;
+  }
+  // metrics.py:1535-1560: probabilities are NaN where the input is NaN
+  // (a NaN threshold makes the comparison false, like xr.where does)
+  const double tp_b = is_nan(t) ? nan : (t > thr ? 1.0 : 0.0);
+  const int n = SKIPNA ? nn : M;
+  double pm = (double)gt / (double)n;           // n == 0 -> NaN
+  if (!SKIPNA && nn != M) pm = nan;
+  const double eb = pm - tp_b;
+  const double brier = eb * eb;
+  // var(ddof=1) of the 0/1 member probabilities (two-pass form)
+  double var = ((double)gt * (1.0 - pm) * (1.0 - pm) +
+                (double)(n - gt) * pm * pm) / (double)(n - 1);
+  if (n <= 1) var = nan;
+  const double debiased = brier - var / (double)M;
+  // metrics.py:1728-1738 / 1799-1802: plain comparisons (NaN -> 0)
+  const double pe = (double)gt / (double)M, pl = (double)lt / (double)M;
+  const double ign = -((t > thr) ? log(pe) : log(1.0 - pe));
+  const double dr = pl - ((t < thr) ? 1.0 : 0.0);
+  v[0] = brier;
+  v[1] = debiased;
+  v[2] = ign;
+  v[3] = dr * dr;
+}
+
 template <typename T, bool SKIPNA, bool WF>
 __global__ void __launch_bounds__(256)
     ens_threshold_kernel(const EnsThrParams q) {
@@ -315,7 +365,6 @@ __global__ void __launch_bounds__(256)
   const long long ts = p.truth_slab ? p.truth_slab[o] : o;
   const long long hs = q.thr_slab ? q.thr_slab[o] : o;
   const int M = p.n_member;
-  const double nan = __builtin_nan("");
 
   double acc[NWF][1][K];
 #pragma unroll
@@ -337,44 +386,8 @@ __global__ void __launch_bounds__(256)
       const long long off = (long long)r * p.n_col;
       const T t = __builtin_nontemporal_load(tb + off);
       const T thr = __builtin_nontemporal_load(hb + off);
-      int gt = 0, lt = 0, nn = 0;  // members above / below / not NaN
-      int m = 0;
-      for (; m + 4 <= M; m += 4) {  // four loads in flight
-        T x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          x[u] = __builtin_nontemporal_load(xb + (m + u) * p.member_stride + off);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          gt += x[u] > thr ? 1 : 0;
-          lt += x[u] < thr ? 1 : 0;
-          nn += is_nan(x[u]) ? 0 : 1;
-        }
-      }
-      for (; m < M; ++m) {
-        const T x = __builtin_nontemporal_load(xb + m * p.member_stride + off);
-        gt += x > thr ? 1 : 0;
-        lt += x < thr ? 1 : 0;
-        nn += is_nan(x) ? 0 : 1;
-      }
-      // metrics.py:1535-1560: probabilities are NaN where the input is NaN
-      // (a NaN threshold makes the comparison false, like xr.where does)
-      const double tp_b = is_nan(t) ? nan : (t > thr ? 1.0 : 0.0);
-      const int n = SKIPNA ? nn : M;
-      double pm = (double)gt / (double)n;           // n == 0 -> NaN
-      if (!SKIPNA && nn != M) pm = nan;
-      const double eb = pm - tp_b;
-      const double brier = eb * eb;
-      // var(ddof=1) of the 0/1 member probabilities (two-pass form)
-      double var = ((double)gt * (1.0 - pm) * (1.0 - pm) +
-                    (double)(n - gt) * pm * pm) / (double)(n - 1);
-      if (n <= 1) var = nan;
-      const double debiased = brier - var / (double)M;
-      // metrics.py:1728-1738 / 1799-1802: plain comparisons (NaN -> 0)
-      const double pe = (double)gt / (double)M, pl = (double)lt / (double)M;
-      const double ign = -((t > thr) ? log(pe) : log(1.0 - pe));
-      const double dr = pl - ((t < thr) ? 1.0 : 0.0);
-      const double v[4] = {brier, debiased, ign, dr * dr};
+      double v[4];
+      ens_thr_point<T, SKIPNA>(xb + off, p.member_stride, M, t, thr, v);
       const double wr = p.w_row[row0 + r];
       double wf = 1.0;
       if constexpr (WF) wf = wfp[off];
@@ -410,6 +423,43 @@ __global__ void __launch_bounds__(256)
   fold_tile_to_segs<NWF, 1, K>(
       acc, lane, tile, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg, p.n_ts,
       p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
+}
+
+// Pointwise maps of the same four scores (Spatial* threshold metrics,
+// metrics.py:1615-1638, 1697-1719, 1780-1802, 1870-1891): one lane per grid
+// point, no weights / regions (the reference ignores `region` here).
+struct EnsThrMapParams {
+  const void* ens;
+  const void* truth;
+  const void* thr;
+  const long long* ens_slab;
+  const long long* truth_slab;
+  const long long* thr_slab;
+  double* maps;  // [4][n_outer][n_point]
+  long long member_stride, n_outer, n_point;
+  int n_member;
+};
+
+template <typename T, bool SKIPNA>
+__global__ void __launch_bounds__(256)
+    ens_threshold_maps_kernel(const EnsThrMapParams p) {
+  const long long pt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long o = blockIdx.y + (long long)blockIdx.z * gridDim.y;
+  if (pt >= p.n_point || o >= p.n_outer) return;
+  const long long es = p.ens_slab ? p.ens_slab[o] : o;
+  const long long ts = p.truth_slab ? p.truth_slab[o] : o;
+  const long long hs = p.thr_slab ? p.thr_slab[o] : o;
+  const T t = __builtin_nontemporal_load(static_cast<const T*>(p.truth) +
+                                         ts * p.n_point + pt);
+  const T thr = __builtin_nontemporal_load(static_cast<const T*>(p.thr) +
+                                           hs * p.n_point + pt);
+  double v[4];
+  ens_thr_point<T, SKIPNA>(static_cast<const T*>(p.ens) + es * p.n_point + pt,
+                           p.member_stride, p.n_member, t, thr, v);
+  const long long plane = p.n_outer * p.n_point;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    __builtin_nontemporal_store(v[k], p.maps + k * plane + o * p.n_point + pt);
 }
 
 template <typename T>
@@ -607,6 +657,47 @@ int wb2_ens_threshold_partials(
   if (dtype == WB2_F32)
     return launch_ens_threshold<float>(q, skipna != 0, wfield != nullptr, s);
   return launch_ens_threshold<double>(q, skipna != 0, wfield != nullptr, s);
+}
+
+int wb2_ens_threshold_maps(int dtype, int skipna, const void* ens,
+                           const int64_t* ens_slab, const void* truth,
+                           const int64_t* truth_slab, const void* threshold,
+                           const int64_t* thr_slab, int32_t n_member,
+                           int64_t member_stride, int64_t n_outer,
+                           int64_t n_point, double* maps, void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE(ens && truth && threshold && maps, "null pointer argument");
+  WB2_REQUIRE(n_member >= 1, "n_member=%d", n_member);
+  WB2_REQUIRE(n_outer >= 0 && n_point >= 0, "bad sizes");
+  if (n_outer == 0 || n_point == 0) return 0;
+  EnsThrMapParams p{};
+  p.ens = ens;
+  p.truth = truth;
+  p.thr = threshold;
+  p.ens_slab = reinterpret_cast<const long long*>(ens_slab);
+  p.truth_slab = reinterpret_cast<const long long*>(truth_slab);
+  p.thr_slab = reinterpret_cast<const long long*>(thr_slab);
+  p.maps = maps;
+  p.member_stride = member_stride;
+  p.n_outer = n_outer;
+  p.n_point = n_point;
+  p.n_member = n_member;
+  const long long gy = n_outer < 32768 ? n_outer : 32768;
+  const long long gz = (n_outer + gy - 1) / gy;
+  WB2_REQUIRE(gz <= 65535, "n_outer=%lld too large", (long long)n_outer);
+  const dim3 grid((unsigned)((n_point + 255) / 256), (unsigned)gy, (unsigned)gz);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define WB2_L(T, S) \
+  hipLaunchKernelGGL((ens_threshold_maps_kernel<T, S>), grid, dim3(256), 0, s, p)
+  if (dtype == WB2_F32) {
+    if (skipna) WB2_L(float, true); else WB2_L(float, false);
+  } else {
+    if (skipna) WB2_L(double, true); else WB2_L(double, false);
+  }
+#undef WB2_L
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
 }
 
 }  // extern "C"

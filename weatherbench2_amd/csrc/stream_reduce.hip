@@ -698,6 +698,34 @@ int vec_width(int dtype, int n_col, bool aligned16) {
   return (aligned16 && n_col % w == 0) ? w : 1;
 }
 
+// SpatialSEEPS (metrics.py:418-509): the per-point score of mode SEEPS as a
+// float64 map, no spatial reduction.  One lane per grid point.
+struct SeepsMapParams {
+  const void* in[3];           // forecast, truth, wet threshold
+  const long long* slab[3];
+  const double* aux;           // p1 [n_point], NaN where masked
+  double scalar;               // dry threshold
+  double* out;                 // [n_outer][n_point]
+  long long n_outer, n_point;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) seeps_map_kernel(const SeepsMapParams p) {
+  const long long pt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long o = blockIdx.y + (long long)blockIdx.z * gridDim.y;
+  if (pt >= p.n_point || o >= p.n_outer) return;
+  T in[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const long long sl = p.slab[i] ? p.slab[i][o] : o;
+    in[i] = __builtin_nontemporal_load(static_cast<const T*>(p.in[i]) +
+                                       sl * p.n_point + pt);
+  }
+  double x[1];
+  eval_slots<WB2_MODE_SEEPS, false, T>(in, x, p.aux[pt], p.scalar);
+  __builtin_nontemporal_store(x[0], p.out + o * p.n_point + pt);
+}
+
 // One wave per column tile; up to 8 tiles share a workgroup.
 int threads_for(int n_col, int vec) {
   const int lanes = (n_col + vec - 1) / vec;
@@ -897,6 +925,38 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                      dim3(256), 0, static_cast<hipStream_t>(stream), values,
                      (long long)n_lead, (long long)n_time, (long long)n_tail,
                      skipna, sum, count);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
+                  int64_t n_outer, int64_t n_point, const double* aux,
+                  double scalar, double* out, void* stream) {
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE(in && in[0] && in[1] && in[2] && aux && out,
+              "null pointer argument");
+  WB2_REQUIRE(n_outer >= 0 && n_point >= 0, "bad sizes");
+  if (n_outer == 0 || n_point == 0) return 0;
+  SeepsMapParams p{};
+  for (int i = 0; i < 3; ++i) {
+    p.in[i] = in[i];
+    p.slab[i] = slab ? reinterpret_cast<const long long*>(slab[i]) : nullptr;
+  }
+  p.aux = aux;
+  p.scalar = scalar;
+  p.out = out;
+  p.n_outer = n_outer;
+  p.n_point = n_point;
+  const long long gy = n_outer < 32768 ? n_outer : 32768;
+  const long long gz = (n_outer + gy - 1) / gy;
+  WB2_REQUIRE(gz <= 65535, "n_outer=%lld too large", (long long)n_outer);
+  const dim3 grid((unsigned)((n_point + 255) / 256), (unsigned)gy, (unsigned)gz);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    hipLaunchKernelGGL(seeps_map_kernel<float>, grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(seeps_map_kernel<double>, grid, dim3(256), 0, s, p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -347,3 +347,49 @@ def rank_histogram(ens: torch.Tensor, member_stride: int, n_member: int,
       int(break_ties), seed & 0xFFFFFFFFFFFFFFFF, _lib.ptr(acc_row),
       _lib.ptr(out), current_stream_ptr(dev)), 'wb2_rank_histogram')
   return out
+
+
+def ensemble_threshold_maps(ens: torch.Tensor, member_stride: int,
+                            n_member: int, ens_slab, truth: torch.Tensor,
+                            truth_slab, thr: torch.Tensor, thr_slab,
+                            n_outer: int, n_point: int,
+                            skipna: bool) -> torch.Tensor:
+  """wb2_ens_threshold_maps: [4, n_outer, n_point] float64 (Brier, debiased
+  Brier, ignorance, RPS part), unreduced."""
+  lib = _lib.load()
+  dev = ens.device
+  if ens.dtype not in _DTYPES or truth.dtype != ens.dtype or (
+      thr.dtype != ens.dtype):
+    raise TypeError('members, truth and threshold must share one dtype')
+  for x in (ens, truth, thr):
+    if x.device != dev or not x.is_contiguous():
+      raise ValueError('inputs must be contiguous on one device')
+  maps = torch.empty((4, n_outer, n_point), dtype=torch.float64, device=dev)
+  _lib.check(lib.wb2_ens_threshold_maps(
+      _DTYPES[ens.dtype], int(skipna), _lib.ptr(ens), _lib.ptr(ens_slab),
+      _lib.ptr(truth), _lib.ptr(truth_slab), _lib.ptr(thr), _lib.ptr(thr_slab),
+      n_member, member_stride, n_outer, n_point, _lib.ptr(maps),
+      current_stream_ptr(dev)), 'wb2_ens_threshold_maps')
+  return maps
+
+
+def seeps_map(inputs: t.Sequence[torch.Tensor],
+              slabs: t.Sequence[t.Optional[torch.Tensor]], n_outer: int,
+              n_point: int, aux: torch.Tensor, scalar: float) -> torch.Tensor:
+  """wb2_seeps_map: [n_outer, n_point] float64 per-point SEEPS."""
+  lib = _lib.load()
+  dev = inputs[0].device
+  dtype = inputs[0].dtype
+  if dtype not in _DTYPES:
+    raise TypeError(f'unsupported dtype {dtype}')
+  for x in inputs:
+    if x.dtype != dtype or x.device != dev or not x.is_contiguous():
+      raise ValueError('inputs must share dtype/device and be contiguous')
+  if aux.dtype != torch.float64 or aux.numel() != n_point:
+    raise ValueError('aux must be float64[n_point]')
+  out = torch.empty((n_outer, n_point), dtype=torch.float64, device=dev)
+  _lib.check(lib.wb2_seeps_map(
+      _DTYPES[dtype], _lib.ptr_array(inputs), _lib.ptr_array(slabs), n_outer,
+      n_point, _lib.ptr(aux), float(scalar), _lib.ptr(out),
+      current_stream_ptr(dev)), 'wb2_seeps_map')
+  return out

@@ -1131,9 +1131,9 @@ class GaussianRPS(_GaussianThresholdMetric):
   _sum_over_quantile = True
 
 
-@_serialized
-def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
-                        region, skipna):
+def _ens_threshold_layout(forecast, truth, threshold_ds, name, ensemble_dim):
+  """Device tensors and slab tables (members, truth, threshold) of one
+  variable; the threshold may carry any subset of the output dims."""
   fvar, tvar, hvar = forecast[name], truth[name], threshold_ds[name]
   if ensemble_dim not in fvar.dims:
     raise ValueError(f'{ensemble_dim=} not found in {fvar.dims=}')
@@ -1171,11 +1171,6 @@ def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
   t_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
   h_table = _slab_table(out_dims, out_shape, hrest, hdata.shape[:-2])
   device = engine.require_gpu()
-  regions, _ = _region_set_for(region)
-  n_row = len(geo.latitude if layout == plan_lib.LATLON else geo.longitude)
-  pl = plan_lib.cached_plan(geo.latitude, geo.longitude, layout, regions,
-                            device, plan_lib.auto_rows_per_chunk(n_row,
-                                                                 geo.n_outer))
   tens = [_to_device(x, device) for x in (fdata, tdata, hdata)]
   dtype = tens[0].dtype
   for x in tens[1:]:
@@ -1186,15 +1181,42 @@ def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
   for x in tens:
     _check_grid(geo, x)
   to_dev = lambda tb: None if tb is None else torch.from_numpy(tb).to(device)
+  tables = [None if identity else to_dev(ens_table), to_dev(t_table),
+            to_dev(h_table)]
+  return geo, tens, tables, strides[ensemble_dim], n_member, device
+
+
+@_serialized
+def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
+                        region, skipna):
+  geo, tens, tables, member_slabs, n_member, device = _ens_threshold_layout(
+      forecast, truth, threshold_ds, name, ensemble_dim)
+  regions, _ = _region_set_for(region)
+  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
+  pl = plan_lib.cached_plan(geo.latitude, geo.longitude, geo.layout, regions,
+                            device, plan_lib.auto_rows_per_chunk(n_row,
+                                                                 geo.n_outer))
   slab_elems = pl.n_row * pl.n_col
   metrics = engine.ensemble_threshold_reduce(
-      pl, tens[0], strides[ensemble_dim] * slab_elems, n_member,
-      None if identity else to_dev(ens_table),
-      tens[1].reshape(-1, pl.n_row, pl.n_col), to_dev(t_table),
-      tens[2].reshape(-1, pl.n_row, pl.n_col), to_dev(h_table), geo.n_outer,
-      skipna)
-  host = metrics.cpu().numpy().reshape((4, pl.n_region) + out_shape)
+      pl, tens[0], member_slabs * slab_elems, n_member, tables[0],
+      tens[1].reshape(-1, pl.n_row, pl.n_col), tables[1],
+      tens[2].reshape(-1, pl.n_row, pl.n_col), tables[2], geo.n_outer, skipna)
+  host = metrics.cpu().numpy().reshape((4, pl.n_region) + geo.out_shape)
   return geo, {nm: host[:, i] for i, nm in enumerate(pl.region_names)}
+
+
+@_serialized
+def _ens_threshold_maps(forecast, truth, threshold_ds, name, ensemble_dim,
+                        skipna):
+  """The four pointwise score maps [4, *out_shape, n_row, n_col] (device)."""
+  geo, tens, tables, member_slabs, n_member, _ = _ens_threshold_layout(
+      forecast, truth, threshold_ds, name, ensemble_dim)
+  n_point = tens[0].shape[-2] * tens[0].shape[-1]
+  maps = engine.ensemble_threshold_maps(
+      tens[0], member_slabs * n_point, n_member, tables[0],
+      tens[1].reshape(-1, n_point), tables[1],
+      tens[2].reshape(-1, n_point), tables[2], geo.n_outer, n_point, skipna)
+  return geo, maps.reshape((4,) + geo.out_shape + tuple(tens[0].shape[-2:]))
 
 
 @dataclasses.dataclass
@@ -1284,9 +1306,8 @@ class SEEPS(Metric):
     frac = climatology[f'{self.precip_name}_seeps_dry_fraction']
     return frac.mean(('hour', 'dayofyear'))
 
-  def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    del skipna  # Ignored, must be effectively True because of p1 mask.
-    forecast, truth = _inputs(forecast, truth)
+  def _prepare(self, forecast, truth):
+    """(geo, [forecast, truth, wet threshold], slab tables, masked p1)."""
     climatology = xl.as_dataset(self.climatology)
     name = self.precip_name
     fvar, tvar = forecast[name], truth[name]
@@ -1304,10 +1325,17 @@ class SEEPS(Metric):
     with np.errstate(invalid='ignore'):
       keep = np.logical_and(p1v < self.max_p1, p1v > self.min_p1)
     aux = np.where(keep, p1v.astype(np.float64), np.nan)
+    return geo, [p[0] for p in prepared], tables, aux
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    del skipna  # Ignored, must be effectively True because of p1 mask.
+    forecast, truth = _inputs(forecast, truth)
+    geo, arrays, tables, aux = self._prepare(forecast, truth)
     by_region, rkey = _run_pass(
-        _lib.MODE_SEEPS, geo, [p[0] for p in prepared], tables, region, True,
+        _lib.MODE_SEEPS, geo, arrays, tables, region, True,
         aux=aux, scalar=self.dry_threshold_mm / 1000.0)
-    return _assemble(forecast, {name: (geo.out_dims, by_region[rkey][0])})
+    return _assemble(forecast, {self.precip_name:
+                                (geo.out_dims, by_region[rkey][0])})
 
 
 # ---------------------------------------------------------------------------
@@ -1315,6 +1343,36 @@ class SEEPS(Metric):
 # pointwise maps of the fused ensemble pass, kept on the device
 # ---------------------------------------------------------------------------
 _ENS_MAP_SLOT = {'skill': 0, 'spread': 1, 'mse': 2, 'var': 3, 'debiased': 5}
+
+
+def _device_temporal_mean(metric, forecast, truth, region, skipna,
+                          ensemble_dim=None) -> xl.Dataset:
+  """Metric.compute (metrics.py:117-138) for map-valued metrics whose chunk
+  result lives on the device: (sum, count) over the time dim via
+  wb2_time_accumulate, no host round trip of the per-time maps."""
+  forecast_ds = xl.as_dataset(forecast)
+  avg_dim = 'time' if 'time' in forecast_ds.dims else 'init_time'
+  if avg_dim not in forecast_ds.dims:
+    raise ValueError(
+        'Forecast has neither valid_time or init_time dimension '
+        f'{forecast_ds}')
+  chunk = metric.compute_chunk(forecast, truth, region=region, skipna=skipna)
+  attrs = dict(chunk.attrs)
+  if ensemble_dim is not None:
+    attrs['ensemble_size'] = forecast_ds.sizes[ensemble_dim]
+  out = xl.Dataset(coords={k: v for k, v in chunk.coords.items()
+                           if k != avg_dim}, attrs=attrs)
+  for name, da in chunk.data_vars.items():
+    axis = da.dims.index(avg_dim)
+    values = da.data.to(torch.float64).contiguous()
+    shape = tuple(n for i, n in enumerate(values.shape) if i != axis)
+    total = torch.zeros(shape, dtype=torch.float64, device=values.device)
+    count = torch.zeros_like(total)
+    engine.time_accumulate(values, axis, skipna, total, count)
+    mean = (total / count).to(da.data.dtype)
+    out.data_vars[name] = xl.DataArray(
+        mean, tuple(d for d in da.dims if d != avg_dim), out.coords, name)
+  return out
 
 
 @dataclasses.dataclass
@@ -1352,28 +1410,8 @@ class _SpatialEnsembleMetric(EnsembleMetric):
 
   def compute(self, forecast, truth, region=None, skipna=False):
     """Temporal mean of the map, accumulated on the device."""
-    forecast_ds = xl.as_dataset(forecast)
-    avg_dim = 'time' if 'time' in forecast_ds.dims else 'init_time'
-    if avg_dim not in forecast_ds.dims:
-      raise ValueError(
-          'Forecast has neither valid_time or init_time dimension '
-          f'{forecast_ds}')
-    chunk = self.compute_chunk(forecast, truth, region=region, skipna=skipna)
-    out = xl.Dataset(coords={k: v for k, v in chunk.coords.items()
-                             if k != avg_dim},
-                     attrs={'ensemble_size':
-                            forecast_ds.sizes[self.ensemble_dim]})
-    for name, da in chunk.data_vars.items():
-      axis = da.dims.index(avg_dim)
-      values = da.data.to(torch.float64).contiguous()
-      shape = tuple(n for i, n in enumerate(values.shape) if i != axis)
-      total = torch.zeros(shape, dtype=torch.float64, device=values.device)
-      count = torch.zeros_like(total)
-      engine.time_accumulate(values, axis, skipna, total, count)
-      mean = (total / count).to(da.data.dtype)
-      out.data_vars[name] = xl.DataArray(
-          mean, tuple(d for d in da.dims if d != avg_dim), out.coords, name)
-    return out
+    return _device_temporal_mean(self, forecast, truth, region, skipna,
+                                 self.ensemble_dim)
 
 
 @dataclasses.dataclass
@@ -1422,6 +1460,119 @@ class DebiasedSpatialEnsembleMeanMSE(_SpatialEnsembleMetric):
   """Debiased (truth - ensemble mean)^2 as a map (metrics.py:1384-1399)."""
   _slot = 'debiased'
 
+
+
+# ---------------------------------------------------------------------------
+# Spatial* threshold metrics and SpatialSEEPS: unreduced float64 maps on the
+# device (`region` is ignored, like the reference: spatial_agg=False)
+# ---------------------------------------------------------------------------
+@dataclasses.dataclass
+class _SpatialEnsembleThresholdMetric(ThresholdMetric):
+  ensemble_dim: str = REALIZATION
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = _inputs(forecast, truth)
+    _get_n_ensemble(forecast, self.ensemble_dim)
+    out = xl.Dataset()
+    names = _common_vars(forecast, truth)
+    stacks = {name: [] for name in names}
+    for threshold in self.thresholds:
+      threshold_ds = threshold.compute(truth)
+      for name in names:
+        geo, maps = _ens_threshold_maps(forecast, truth, threshold_ds, name,
+                                        self.ensemble_dim, skipna)
+        spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
+        dims = tuple(geo.out_dims) + tuple(spatial)
+        data = maps[self._row]
+        if self._truth_first:
+          tdims = [d for d in truth[name].dims if d in dims]
+          order = tuple(tdims + [d for d in dims if d not in tdims])
+          data = data.permute(*[dims.index(d) for d in order])
+          dims = order
+        stacks[name].append((dims, data))
+    for name in names:
+      dims = stacks[name][0][0]
+      data = torch.stack([d for _, d in stacks[name]])
+      out.coords.update(_spatial_coords(forecast, dims))
+      if self._sum_over_quantile:
+        out.data_vars[name] = xl.DataArray(data.sum(0), dims, out.coords, name)
+      else:
+        out.coords['quantile'] = np.array(
+            [th.quantile for th in self.thresholds], dtype=np.float64)
+        out.data_vars[name] = xl.DataArray(data, ('quantile',) + tuple(dims),
+                                           out.coords, name)
+    return out.assign_attrs(
+        threshold_method=type(self.thresholds[0]).__name__)
+
+  def compute(self, forecast, truth, region=None, skipna=False):
+    return _device_temporal_mean(self, forecast, truth, region, skipna,
+                                 self.ensemble_dim)
+
+
+@dataclasses.dataclass
+class SpatialEnsembleBrierScore(_SpatialEnsembleThresholdMetric):
+  """Spatial map of ensemble Brier score (metrics.py:1615-1638)."""
+  _row = 0
+  _truth_first = False
+
+
+@dataclasses.dataclass
+class SpatialDebiasedEnsembleBrierScore(_SpatialEnsembleThresholdMetric):
+  """Spatial map of ensemble debiased Brier score (metrics.py:1697-1719)."""
+  _row = 1
+
+
+@dataclasses.dataclass
+class SpatialEnsembleIgnoranceScore(_SpatialEnsembleThresholdMetric):
+  """Spatial map of ensemble ignorance score (metrics.py:1780-1802)."""
+  _row = 2
+
+
+@dataclasses.dataclass
+class SpatialEnsembleRPS(_SpatialEnsembleThresholdMetric):
+  """Spatial map of ensemble RPS (metrics.py:1870-1891)."""
+  _row = 3
+  _sum_over_quantile = True
+  _truth_first = False
+
+
+@dataclasses.dataclass
+class SpatialSEEPS(SEEPS):
+  """SEEPS without spatial averaging (metrics.py:418-509): float64 map."""
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    del region, skipna
+    forecast, truth = _inputs(forecast, truth)
+    geo, arrays, tables, aux = self._prepare(forecast, truth)
+    device = engine.require_gpu()
+    tensors = [_to_device(a, device) for a in arrays]
+    dtype = torch.result_type(tensors[0], tensors[1])
+    dtype = torch.promote_types(dtype, tensors[2].dtype)
+    if dtype not in (torch.float32, torch.float64):
+      dtype = torch.float64
+    tensors = [x if x.dtype == dtype else x.to(dtype) for x in tensors]
+    for x in tensors:
+      _check_grid(geo, x)
+    n_point = tensors[0].shape[-2] * tensors[0].shape[-1]
+    slabs = [None if tb is None else torch.from_numpy(tb).to(device)
+             for tb in tables]
+    aux_dev = torch.as_tensor(
+        np.ascontiguousarray(aux, dtype=np.float64)).to(device).reshape(-1)
+    out_map = engine.seeps_map(
+        [x.reshape(-1, n_point) for x in tensors], slabs, geo.n_outer, n_point,
+        aux_dev, self.dry_threshold_mm / 1000.0)
+    spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
+    dims = tuple(geo.out_dims) + tuple(spatial)
+    out = xl.Dataset()
+    out.coords.update(_spatial_coords(forecast, dims))
+    out.data_vars[self.precip_name] = xl.DataArray(
+        out_map.reshape(geo.out_shape + tuple(tensors[0].shape[-2:])), dims,
+        out.coords, self.precip_name)
+    return out
+
+  def compute(self, forecast, truth, region=None, skipna=False):
+    # the reference's Metric.compute passes skipna on to the time mean
+    return _device_temporal_mean(self, forecast, truth, region, skipna)
 
 # ---------------------------------------------------------------------------
 # RankHistogram / central_reliability (metrics.py:1894-2126)
