@@ -75,48 +75,52 @@ def measured_traffic(workload: str, **match):
   return None
 
 
-def cpu_baseline(seconds_budget: float = 20.0) -> dict:
+def cpu_baseline(seconds: float = 10.0, processes: int = 0) -> dict:
   """Times the NumPy oracle (the restated reference path: one metric x one
-  region at a time, like evaluation.py:408-435) on this box's host cores."""
-  from oracle import metrics_np as om
-  from oracle.named import DS, NA
-  from tests import helpers
-  n_lev = N_LEV
-  rs = np.random.RandomState(0)
-  lat = np.linspace(-90, 90, N_LAT)
-  lon = np.linspace(0, 360, N_LON, endpoint=False)
-  dims = ('time', 'level', 'latitude', 'longitude')
-  coords = {'time': np.array(['2020-01-01T00'], dtype='datetime64[ns]'),
-            'level': np.arange(n_lev), 'latitude': lat, 'longitude': lon}
-  mk = lambda: rs.standard_normal((1, n_lev, N_LAT, N_LON)).astype(np.float32)
-  f, t = DS({'z': NA(mk(), dims)}, coords), DS({'z': NA(mk(), dims)}, coords)
-  clim = DS({'z': NA(mk(), ('dayofyear',) + dims[1:])},
-            {'dayofyear': np.array([1]), 'level': coords['level'],
-             'latitude': lat, 'longitude': lon})
-  metrics = {'mse': om.MSE(), 'rmse': om.RMSESqrtBeforeTimeAvg(),
-             'mae': om.MAE(), 'bias': om.Bias(), 'acc': om.ACC(clim)}
-  regions = helpers.predefined_regions(oracle=True)
-  # ~10-20 s of CPU work: whole units (all metrics x all regions) until the
-  # budget is used; every repetition re-evaluates from the raw arrays.
-  t0 = time.perf_counter()
-  units = 0
-  while True:
-    for region in regions.values():
-      for m in metrics.values():
-        m.compute_chunk(f, t, region=region)
-    units += 1
-    dt = time.perf_counter() - t0
-    if dt >= 10.0 or dt >= seconds_budget:
-      break
+  region at a time, like evaluation.py:408-435) on this box's host cores:
+  first one process, then `processes` at once ("(i) 1 process,
+  (ii) nproc processes over init-time shards"); `value` is the aggregate of
+  the multi-process leg.  Runs oracle/cpu_baseline.py in subprocesses (no
+  torch, no product code in them)."""
+  import subprocess
+  import sys
+  ncpu = os.cpu_count() or 1
+  if processes <= 0:
+    processes = max(1, min(ncpu // 2, 32))  # physical cores, memory-bound work
+  cmd = [sys.executable, '-m', 'oracle.cpu_baseline', '--seconds', str(seconds)]
+  env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1',
+             MKL_NUM_THREADS='1')
+
+  def launch(n):
+    procs = [subprocess.Popen(cmd + ['--seed', str(i)], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, text=True)
+             for i in range(n)]
+    outs = []
+    for pr in procs:
+      stdout, _ = pr.communicate(timeout=seconds * 20 + 120)
+      if pr.returncode != 0:
+        raise RuntimeError('oracle.cpu_baseline failed')
+      outs.append(json.loads(stdout.strip().splitlines()[-1]))
+    return outs
+
+  one = launch(1)[0]
+  rate_1 = one['points'] / one['seconds']
+  many = launch(processes) if processes > 1 else [one]
+  rate_n = sum(o['points'] / o['seconds'] for o in many)
   return {
-      'value': units * n_lev * N_LAT * N_LON / dt, 'unit': 'grid-point-evals/s',
-      'cores': 1, 'kind': 'port',
+      'value': rate_n, 'unit': 'grid-point-evals/s', 'cores': len(many),
+      'kind': 'port', 'value_1core': rate_1,
       'sample': (f'NumPy oracle (xarray-semantics restatement; the reference '
-                 f'itself needs xarray, absent here), 1 process, {units} unit(s) '
-                 f'of {n_lev} levels x 721 x 1440 f32, 5 metrics x '
-                 f'{len(regions)} regions evaluated one (metric, region) at a '
-                 f'time like evaluation.py:408-435, {dt:.1f} s; host has '
-                 f'{os.cpu_count()} logical cores'),
+                 f'itself needs xarray, absent here): whole units of '
+                 f'{N_LEV} levels x 721 x 1440 f32, {one["metrics"]} metrics x '
+                 f'{one["regions"]} regions evaluated one (metric, region) at '
+                 f'a time like evaluation.py:408-435; 1 process did '
+                 f'{one["units"]} unit(s) in {one["seconds"]:.1f} s, then '
+                 f'{len(many)} single-threaded processes at once did '
+                 f'{sum(o["units"] for o in many)} units in '
+                 f'{max(o["seconds"] for o in many):.1f} s (own data each, like '
+                 f'Beam workers over init-time shards); host has {ncpu} '
+                 f'logical cores'),
   }
 
 
@@ -132,6 +136,10 @@ def main():
   ap.add_argument('--rows-per-chunk', type=int, default=0,
                   help='0 = plan.auto_rows_per_chunk (32 at the default batch)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--pcie', action='store_true',
+                  help='also time the step with its inputs arriving from '
+                       'pinned host memory (reported as pcie_inclusive, never '
+                       'as value)')
   ap.add_argument('--workload', default='deterministic',
                   choices=['deterministic', 'ensemble', 'spectrum'],
                   help='deterministic = BASELINE configs[1] (the headline '
@@ -288,6 +296,40 @@ def main():
                                       regions=nr),
       },
   }
+  if rank == 0 and world == 1 and args.pcie:
+    # The same step when the boundary hands over HOST buffers: forecast, truth
+    # and climatology units cross PCIe (pinned memory, one copy stream) before
+    # the fused pass.  Reported beside `value`, never as it.
+    n_el = n_outer * N_LAT * N_LON
+    host = [torch.empty((n_el,), dtype=torch.float32).pin_memory()
+            for _ in range(3)]
+    for h in host:
+      h.normal_()
+    stage = [torch.empty((n_outer, N_LAT, N_LON), dtype=torch.float32,
+                         device=dev) for _ in range(3)]
+    reps = 5
+
+    def host_step():
+      for h, d in zip(host, stage):
+        d.view(-1).copy_(h, non_blocking=True)
+      m, _ = engine.stream_reduce(pl, _lib.MODE_DET_ACC, stage,
+                                  [None, None, None], n_outer, skipna=False)
+      engine.time_accumulate(m.view(_lib.NMETRIC * nr, units, N_LEV), 1, False,
+                             total, count)
+    engine.K1_EVENTS = None
+    host_step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+      host_step()
+    torch.cuda.synchronize()
+    dt_h = (time.perf_counter() - t1) / reps
+    out['pcie_inclusive'] = {
+        'value': pts_step / dt_h, 'unit': 'grid-point-evals/s',
+        'ms_per_step': dt_h * 1e3,
+        'h2d_GBps': pts_step * BYTES_PER_PT / dt_h / 1e9,
+        'note': 'inputs start in pinned host memory; serial copy + compute',
+    }
   if rank == 0:
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()

@@ -108,3 +108,40 @@ def test_threaded_callers_share_the_caches_safely():
   assert not errors, errors
   for a, b in zip(got, want):
     helpers.assert_close(a, b, rtol=1e-9, atol=1e-12)
+
+
+def test_evaluate_chunks_with_map_valued_metrics_stays_on_device():
+  """Spatial* maps and rank histograms flow through the metric
+  loop and the running (sum, count) mean without leaving the device."""
+  import torch
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      spatial_resolution_in_degrees=10, ensemble_size=4)
+  forecast = fixtures.insert_nan(forecast, 0.002, seed=2)
+  g = helpers.to_gpu_dataset
+  n_time = forecast.sizes['time']
+  chunks = [(g(forecast.isel(time=slice(i, i + 2))),
+             g(truth.isel(time=slice(i, i + 2)))) for i in range(0, n_time, 2)]
+  for skipna in (False, True):
+    cfg = config.Eval(metrics={
+        'crps': gm.SpatialCRPS(), 'mse': gm.SpatialEnsembleMeanMSE()})
+    one = evaluation._metric_and_region_loop(chunks[0][0], chunks[0][1], cfg,
+                                             skipna, compute_chunk=True)
+    assert isinstance(one['geopotential'].data, torch.Tensor)
+    assert one['geopotential'].data.is_cuda
+    got = evaluation.evaluate_chunks(chunks, cfg, skipna=skipna)
+    da = got['geopotential']
+    assert da.dims[0] == 'metric' and 'time' not in da.dims
+    for mi, metric in enumerate((om.SpatialCRPS(),
+                                 om.SpatialEnsembleMeanMSE())):
+      want = metric.compute(forecast, truth, skipna=skipna)['geopotential']
+      have = xl_take(da, mi)
+      w = want.transpose(*have[0]).data
+      helpers.assert_close(have[1], w, rtol=2e-6, atol=1e-7)
+
+
+def xl_take(da, metric_index):
+  """(dims, values) of one metric of a merged result."""
+  ax = da.dims.index('metric')
+  dims = tuple(d for d in da.dims if d != 'metric')
+  return dims, np.take(np.asarray(da.values), metric_index, axis=ax)

@@ -107,13 +107,22 @@ class RunningMean:
       axis = da.dims.index(self.dim)
       dims = tuple(d for d in da.dims if d != self.dim)
       shape = tuple(n for d, n in zip(da.dims, da.shape) if d != self.dim)
+      raw = da.data
+      if isinstance(raw, torch.Tensor):
+        # map-valued results (Spatial* metrics, rank histograms) already live
+        # on the device: accumulate there, no host round trip
+        if self.device is None and raw.is_cuda:
+          self.device = raw.device
+        values = raw.to(torch.float64)
+      else:
+        values = torch.as_tensor(np.ascontiguousarray(da.values),
+                                 dtype=torch.float64)
       total, count = self._tensors(name, dims, shape)
-      values = torch.as_tensor(np.ascontiguousarray(da.values),
-                               dtype=torch.float64)
       if self.device is not None and torch.device(self.device).type == 'cuda':
-        engine.time_accumulate(values.to(self.device), axis, self.skipna,
-                               total, count)
+        engine.time_accumulate(values.to(self.device).contiguous(), axis,
+                               self.skipna, total, count)
       else:  # host accumulators (CPU tests of the sharding logic)
+        values = values.cpu()
         ok = ~torch.isnan(values) if self.skipna else torch.ones_like(
             values, dtype=torch.bool)
         total += torch.where(ok, values, torch.zeros_like(values)).sum(axis)

@@ -105,8 +105,13 @@ class DataArray:
     out = self
     for name, labels in reversed(list(dim.items())):
       n = 1 if labels is None else len(np.atleast_1d(labels))
-      data = out.values[None] if n == 1 else np.broadcast_to(
-          out.values[None], (n,) + out.shape).copy()
+      if _is_torch(out.data):  # device-resident maps stay on the device
+        data = out.data.unsqueeze(0)
+        if n != 1:
+          data = data.expand((n,) + out.shape).contiguous()
+      else:
+        data = out.values[None] if n == 1 else np.broadcast_to(
+            out.values[None], (n,) + out.shape).copy()
       coords = dict(out.coords)
       if labels is not None:
         coords[name] = np.atleast_1d(labels)
@@ -274,7 +279,12 @@ def concat(datasets: t.Sequence[Dataset], dim: str) -> Dataset:
   out = Dataset(coords=coords, attrs=first.attrs)
   for k, v in first.data_vars.items():
     ax = v.dims.index(dim)
-    data = np.concatenate([d.data_vars[k].values for d in datasets], axis=ax)
+    parts = [d.data_vars[k] for d in datasets]
+    if all(_is_torch(x.data) for x in parts):
+      import torch
+      data = torch.cat([x.data for x in parts], dim=ax)
+    else:
+      data = np.concatenate([x.values for x in parts], axis=ax)
     out.data_vars[k] = DataArray(data, v.dims, coords, k)
   return out
 
@@ -303,7 +313,14 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
     ax = ref.dims.index('metric')
     shape = list(ref.shape)
     shape[ax] = len(labels)
-    data = np.full(shape, np.nan, dtype=np.float64)
+    holders = [d.data_vars[name] for d in datasets if name in d.data_vars]
+    on_device = all(_is_torch(v.data) for v in holders)
+    if on_device:  # map-valued results: merge where they live
+      import torch
+      data = torch.full(shape, float('nan'), dtype=torch.float64,
+                        device=ref.data.device)
+    else:
+      data = np.full(shape, np.nan, dtype=np.float64)
     for d in datasets:
       if name not in d.data_vars:
         continue
@@ -312,12 +329,13 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
         if sorted(v.dims) != sorted(ref.dims):
           raise ValueError(f'{name}: cannot merge dims {v.dims} with {ref.dims}')
         v = v.transpose(*ref.dims)
+      values = v.data if on_device else v.values
       for i, m in enumerate(np.atleast_1d(d.coords['metric'])):
         sl = [slice(None)] * len(shape)
         sl[ax] = labels.index(m)
         src = [slice(None)] * len(shape)
         src[ax] = i
-        data[tuple(sl)] = v.values[tuple(src)]
+        data[tuple(sl)] = values[tuple(src)]
     out.data_vars[name] = DataArray(data, ref.dims, coords, name)
   return out
 
