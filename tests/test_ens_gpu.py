@@ -219,3 +219,40 @@ def test_spatial_ensemble_maps(gm, ensemble_size, skipna):
     helpers.assert_close(mean['geopotential'].values, ref, rtol=3e-6, atol=1e-6,
                          err_msg=name + '.compute')
     assert mean.attrs['ensemble_size'] == ensemble_size
+
+
+def test_perfect_prediction_zero_ensemble_mean_rmse(gm):
+  # metrics_test.py:842-851
+  truth, _ = fixtures.get_random_truth_and_forecast(ensemble_size=10)
+  forecast = truth.expand_dims('realization', size=1)
+  g = helpers.to_gpu_dataset
+  rmse = gm.EnsembleMeanRMSESqrtBeforeTimeAvg().compute_chunk(g(forecast),
+                                                              g(truth))
+  np.testing.assert_allclose(rmse['geopotential'].values, 0.0, atol=1e-12)
+
+
+def test_gaussian_crps_is_the_limit_of_ensemble_crps(gm):
+  # metrics_test.py:306-343 with the largest ensemble the register sort takes
+  # (128 members): the eFAIR CRPS is unbiased, so the mean over 19 times x 2
+  # leads x 19 x 36 points already agrees to a few percent.
+  from oracle.named import DS
+  kw = dict(variables_3d=[], time_start='2022-01-01')
+  forecast = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature', '2m_temperature_std'],
+      time_stop='2022-01-02', lead_stop='1 day', **kw)
+  ens = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature'], time_stop='2022-01-02',
+      lead_stop='1 day', ensemble_size=128, **kw)
+  truth = fixtures.mock_truth_data(variables_2d=['2m_temperature'],
+                                   time_stop='2022-01-20', **kw)
+  forecast = DS({'2m_temperature': forecast['2m_temperature'] + 0.1,
+                 '2m_temperature_std': forecast['2m_temperature_std'] + 1.0},
+                forecast.coords)
+  e = ens['2m_temperature']
+  noise = np.random.RandomState(0).randn(*e.shape).astype(np.float32)
+  ens = ens.copy(data={'2m_temperature': e.data + noise + np.float32(0.1)})
+  g = helpers.to_gpu_dataset
+  gaussian = gm.GaussianCRPS().compute(g(forecast), g(truth))
+  ensemble = gm.CRPS().compute(g(ens), g(truth))
+  np.testing.assert_allclose(gaussian['2m_temperature'].values,
+                             ensemble['2m_temperature'].values, rtol=3e-2)

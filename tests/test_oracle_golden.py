@@ -391,3 +391,78 @@ def test_central_reliability_perfectly_calibrated(n_bins):
   np.testing.assert_allclose(desired, expected)
   with pytest.raises(ValueError):
     metrics.central_reliability(np.ones(2) / 2)
+
+
+_RELIABILITY_VECTORS = [
+    # metrics_test.py:700-779 (hist, expected_prob, desired_prob)
+    ([0.2, 0.1, 0.7], [0.1, 1.0], [1 / 3, 1.0]),
+    ([0.2, 0.0, 0.1, 0.1, 0.6], [0.1, 0.2, 1.0], [1 / 5, 3 / 5, 1.0]),
+    ([0.1, 0.1, 0.5, 0.3], [0.6, 1.0], [1 / 2, 1.0]),
+    ([0.1, 0.1, 0.3, 0.2, 0.0, 0.3], [0.5, 0.6, 1.0], [1 / 3, 2 / 3, 1.0]),
+]
+
+
+@pytest.mark.parametrize('hist,expected,desired', _RELIABILITY_VECTORS)
+def test_central_reliability_particular_histograms(hist, expected, desired):
+  probs, want = metrics.central_reliability(np.array(hist))
+  np.testing.assert_allclose(probs, expected, rtol=1e-12)
+  np.testing.assert_allclose(want, desired, rtol=1e-12)
+
+
+def _censored_case(ensemble_size, cutoff_below):
+  """metrics_test.py:612-630: truth/forecast with a point mass at 0."""
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, time_start='2019-12-01',
+      time_stop='2019-12-20')
+  comp = np.less_equal if cutoff_below else np.greater_equal
+  cens = lambda ds: ds.copy(data={
+      k: np.where(comp(v.data, 0), 0, v.data) for k, v in ds.items()})
+  return cens(truth), cens(forecast)
+
+
+@pytest.mark.parametrize('cutoff_below', [True, False])
+@pytest.mark.parametrize('ensemble_size', [1, 2, 3, 10])
+def test_rank_histogram_repeated_entries_get_random_bin(ensemble_size,
+                                                        cutoff_below):
+  # metrics_test.py:603-650
+  num_bins = ensemble_size + 1
+  truth, forecast = _censored_case(ensemble_size, cutoff_below)
+  v = metrics.RankHistogram(num_bins=num_bins, seed=802701).compute_chunk(
+      forecast, truth)['geopotential']
+  sample_size = v.data.size / num_bins
+  rtol = 5 * (num_bins - 1) / np.sqrt(sample_size)
+  hist = v.data.reshape(-1, num_bins).mean(0)
+  np.testing.assert_allclose(hist, 1 / num_bins, rtol=rtol)
+
+
+def test_perfect_prediction_zero_ensemble_mean_rmse():
+  # metrics_test.py:842-851
+  truth, _ = fixtures.get_random_truth_and_forecast(ensemble_size=10)
+  forecast = truth.expand_dims('realization', size=1)
+  rmse = metrics.EnsembleMeanRMSESqrtBeforeTimeAvg().compute_chunk(forecast,
+                                                                   truth)
+  np.testing.assert_allclose(rmse['geopotential'].data, 0.0, atol=1e-12)
+
+
+def test_gaussian_crps_is_the_limit_of_ensemble_crps():
+  # metrics_test.py:306-343 (2000 members instead of 5000: rtol 2e-2 holds)
+  kw = dict(variables_3d=[], time_start='2022-01-01')
+  forecast = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature', '2m_temperature_std'],
+      time_stop='2022-01-02', lead_stop='1 day', **kw)
+  ens = fixtures.mock_forecast_data(
+      variables_2d=['2m_temperature'], time_stop='2022-01-02',
+      lead_stop='1 day', ensemble_size=2000, **kw)
+  truth = fixtures.mock_truth_data(variables_2d=['2m_temperature'],
+                                   time_stop='2022-01-20', **kw)
+  from oracle.named import DS, NA
+  forecast = DS({'2m_temperature': forecast['2m_temperature'] + 0.1,
+                 '2m_temperature_std': forecast['2m_temperature_std'] + 1.0},
+                forecast.coords)
+  e = ens['2m_temperature']
+  noise = np.random.RandomState(0).randn(*e.shape).astype(np.float32)
+  ens = ens.copy(data={'2m_temperature': e.data + noise + np.float32(0.1)})
+  gaussian = metrics.GaussianCRPS().compute(forecast, truth)
+  ensemble = metrics.CRPS().compute(ens, truth)
+  np.testing.assert_allclose(gaussian['2m_temperature'].data,
+                             ensemble['2m_temperature'].data, rtol=2e-2)

@@ -117,6 +117,35 @@ def test_ensemble_brier_score(error, ens_delta, expected):
                              [[expected, expected]], rtol=1e-4, atol=1e-12)
 
 
+def nan_cases():
+  """metrics_test.py:1035-1075: the score-0 case with NaN along the first
+  latitude of the forecast / the first longitude of the truth."""
+  forecast, truth, clim = ensemble_case(0.0, 0.1)
+  name = '2m_temperature'
+
+  def blank(ds, dim):
+    da = ds[name]
+    data = da.data.copy()
+    sl = [slice(None)] * data.ndim
+    sl[da.dims.index(dim)] = 0
+    data[tuple(sl)] = np.nan
+    return ds.copy(data={name: data})
+  return (forecast, truth, clim, blank(forecast, 'latitude'),
+          blank(truth, 'longitude'))
+
+
+@pytest.mark.parametrize('skipna', [True, False])
+def test_brier_nan_propagates_to_output_unless_skipna(skipna):
+  forecast, truth, clim, forecast_nan, truth_nan = nan_cases()
+  th = thresholds.GaussianQuantileThreshold(climatology=clim, quantile=0.2)
+  expected = [[0.0, 0.0]] if skipna else [[np.nan, np.nan]]
+  for f, t in ((forecast_nan, truth), (forecast, truth_nan)):
+    res = metrics.EnsembleBrierScore(thresholds=[th]).compute(
+        f, t, skipna=skipna)
+    np.testing.assert_allclose(res['2m_temperature'].data, expected,
+                               atol=1e-12)
+
+
 @pytest.mark.parametrize('error,expected', [(0.0, 0.0), (-10.0, np.inf)])
 def test_ensemble_ignorance_score(error, expected):
   forecast, truth, clim = ensemble_case(error, 0.0)
@@ -205,3 +234,47 @@ def test_seeps_expected_values():
   r2 = seeps.compute(forecast + 0.5, truth)
   np.testing.assert_allclose(r2['total_precipitation_24hr'].data, 1.25,
                              atol=1e-4)
+
+
+def brier_integral_case(n_quantiles=200):
+  """metrics_test.py:1207-1260: 2 members, level-dependent bias, thresholds =
+  standard-normal quantiles (constant in space/time)."""
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=2, spatial_resolution_in_degrees=60,
+      time_start='2019-01-01', time_stop='2019-01-04',
+      time_resolution='12 hours', lead_start='0 day', lead_stop='0 day',
+      levels=[500, 700, 850])
+  fv = forecast['geopotential']
+  shift = np.array([-1, 0, 1], dtype=fv.data.dtype).reshape(
+      [3 if d == 'level' else 1 for d in fv.dims])
+  forecast = forecast.copy(data={
+      'geopotential': fv.data + np.abs(fv.data) ** 0.2 + shift})
+  doy = {'dayofyear': 1 + np.arange(366)}
+  zero = truth.zeros_like()
+  clim = _merge(_clim_like(zero, doy),
+                _clim_like(zero + 1.0, doy,
+                           {'geopotential': 'geopotential_std'}))
+  quantiles = np.linspace(0, 1, num=n_quantiles + 2)[1:-1]
+  return truth, forecast, clim, quantiles
+
+
+def trapezoid_over_thresholds(bs, values):
+  """bs[quantile, ...] integrated over the threshold VALUES (xarray's
+  .integrate('threshold'): trapezoidal rule)."""
+  dv = np.diff(values).reshape((-1,) + (1,) * (bs.ndim - 1))
+  return ((bs[1:] + bs[:-1]) * 0.5 * dv).sum(0)
+
+
+def test_integral_of_debiased_brier_score_is_crps():
+  # metrics_test.py:1207-1288
+  from scipy import stats
+  truth, forecast, clim, quantiles = brier_integral_case()
+  ths = [thresholds.GaussianQuantileThreshold(climatology=clim, quantile=q)
+         for q in quantiles]
+  bs = metrics.DebiasedEnsembleBrierScore(thresholds=ths).compute(
+      forecast, truth)['geopotential']
+  assert bs.dims[0] == 'quantile'
+  integral = trapezoid_over_thresholds(bs.data, stats.norm.ppf(quantiles))
+  crps = metrics.CRPS().compute(forecast, truth)['geopotential']
+  want = crps.transpose(*bs.dims[1:]).data
+  np.testing.assert_allclose(integral, want, rtol=10 / len(quantiles))

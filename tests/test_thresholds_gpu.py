@@ -78,6 +78,21 @@ def test_ensemble_brier_known_answers(error, ens_delta, expected):
   assert res.attrs['ensemble_size'] == 4
 
 
+@pytest.mark.parametrize('skipna', [True, False])
+def test_brier_nan_propagates_to_output_unless_skipna(skipna):
+  # metrics_test.py:1035-1108
+  from tests.test_oracle_thresholds import nan_cases
+  from weatherbench2_amd import metrics as gm
+  forecast, truth, clim, forecast_nan, truth_nan = nan_cases()
+  th = _gth('GaussianQuantileThreshold', clim, 0.2)
+  expected = [[0.0, 0.0]] if skipna else [[np.nan, np.nan]]
+  for f, t in ((forecast_nan, truth), (forecast, truth_nan)):
+    res = gm.EnsembleBrierScore(thresholds=[th]).compute(g(f), g(t),
+                                                        skipna=skipna)
+    np.testing.assert_allclose(res['2m_temperature'].values, expected,
+                               atol=1e-12)
+
+
 @pytest.mark.parametrize('error,expected', [(0.0, 0.0), (-10.0, np.inf)])
 def test_ensemble_ignorance_known_answers(error, expected):
   from weatherbench2_amd import metrics as gm
@@ -292,3 +307,21 @@ def test_spatial_seeps_vs_oracle():
     warnings.simplefilter('ignore')
     wm = np.nanmean(w, axis)
   helpers.assert_close(_dev_values(mean), wm, rtol=1e-6, atol=1e-14)
+
+
+def test_integral_of_debiased_brier_score_is_crps():
+  # metrics_test.py:1207-1288 on the GPU path: 200 thresholds x CRPS
+  from scipy import stats
+  from tests.test_oracle_thresholds import (brier_integral_case,
+                                            trapezoid_over_thresholds)
+  from weatherbench2_amd import metrics as gm
+  truth, forecast, clim, quantiles = brier_integral_case()
+  ths = [_gth('GaussianQuantileThreshold', clim, q) for q in quantiles]
+  bs = gm.DebiasedEnsembleBrierScore(thresholds=ths).compute(
+      g(forecast), g(truth))['geopotential']
+  assert bs.dims[0] == 'quantile'
+  integral = trapezoid_over_thresholds(np.asarray(bs.values),
+                                       stats.norm.ppf(quantiles))
+  crps = gm.CRPS().compute(g(forecast), g(truth))['geopotential']
+  want = np.asarray(crps.transpose(*bs.dims[1:]).values)
+  np.testing.assert_allclose(integral, want, rtol=10 / len(quantiles))
