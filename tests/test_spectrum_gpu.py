@@ -193,3 +193,159 @@ def test_fused_fft_matches_rocfft_path(n_lon):
                  timeout=300)
   rocfft = np.load(out)
   assert _row_rel_err(fused, rocfft) < 2e-6
+
+
+# ---- the rest of derived_variables_test.py:219-520 --------------------------
+EARTH_RADIUS_M = 1000 * (6357 + 6378) / 2  # schema.py:59
+
+
+def make_multispectral_dataset(spatial_resolution_in_degrees=5, latitude=None,
+                               min_wavelength_lon=50, max_wavelength_lon=100,
+                               constant_to_add=0.0):
+  """derived_variables_test.py:47-80: smooth (in spectral space) data on the
+  mock grid (prediction_timedelta, time, level, longitude, latitude)."""
+  res = spatial_resolution_in_degrees
+  lat = np.linspace(-90, 90, round(180 / res) + 1)
+  lon = np.linspace(0, 360, round(360 / res), endpoint=False)
+  level = np.array([500, 700, 850])
+  if latitude is not None:
+    if isinstance(latitude, slice):
+      lat = lat[(lat >= latitude.start) & (lat <= latitude.stop)]
+    else:
+      lat = lat[np.isclose(lat, latitude)]
+  assert res < min_wavelength_lon / 2
+  x = np.zeros((2, 1, 3, len(lon), len(lat)))
+  n_signals = 100
+  for wl in np.linspace(min_wavelength_lon, max_wavelength_lon, num=n_signals):
+    x += (np.cos(2 * np.pi * lon / wl)[None, None, None, :, None]
+          * np.exp(-wl / max_wavelength_lon)
+          * np.sin(level / 500)[None, None, :, None, None]
+          * np.cos(lat / 100)[None, None, None, None, :]) / n_signals
+  x += constant_to_add * np.abs(x).mean()
+  dims = ('prediction_timedelta', 'time', 'level', 'longitude', 'latitude')
+  return xl.Dataset({'geopotential': xl.DataArray(x, dims)},
+                    {'latitude': lat, 'longitude': lon, 'level': level,
+                     'prediction_timedelta': np.arange(2), 'time': np.arange(1)})
+
+
+def test_lon_spacing_m_correct_at_equator(dv):
+  # derived_variables_test.py:229-244
+  res = 30
+  lat = np.linspace(-90, 90, 7)
+  lon = np.linspace(0, 360, 12, endpoint=False)
+  ds = _dataset(np.zeros((7, 12)), ('latitude', 'longitude'), lat, lon)
+  zes = dv.ZonalEnergySpectrum('z')
+  circum = EARTH_RADIUS_M * 2 * np.pi
+  np.testing.assert_allclose(zes._circumference(lat)[3], circum)
+  np.testing.assert_allclose(zes.lon_spacing_m(ds)[3], circum * res / 360)
+
+
+def test_data_has_right_shape_dims_and_coordinates(dv):
+  # derived_variables_test.py:246-288
+  ds = make_multispectral_dataset(spatial_resolution_in_degrees=10)
+  ds = xl.Dataset({'geopotential': ds['geopotential']},
+                  {k: v for k, v in ds.coords.items()})
+  spectrum = dv.ZonalEnergySpectrum('geopotential').compute(ds)
+  expected = dict(ds.sizes)
+  expected['zonal_wavenumber'] = ds.sizes['longitude'] // 2 + 1
+  del expected['longitude']
+  assert dict(spectrum.sizes) == expected
+  freq = spectrum.coords['frequency']
+  assert freq.dims == ('zonal_wavenumber', 'latitude')
+  # skip the poles (cos(90 deg) ~ 1e-17: the spacing collapses)
+  f = freq.values[:, 1:-1]
+  assert (np.diff(f, axis=0) > 0).all()
+  np.testing.assert_array_equal(f[0], 0)
+  with np.errstate(divide='ignore'):
+    np.testing.assert_array_equal(spectrum.coords['wavelength'].values,
+                                  1 / freq.values)
+  mid = f.shape[1] // 2
+  assert (np.diff(f[1:, mid:], axis=1) > 0).all()
+  assert (np.diff(f[1:, :mid + 1], axis=1) < 0).all()
+
+
+@pytest.mark.parametrize('add_constant', [False, True])
+def test_resolved_frequencies_are_mostly_independent_of_discretization(
+    dv, add_constant):
+  # derived_variables_test.py:322-407: fails for a different DFT normalisation
+  latitude = 30
+  lo, hi = 50, 100
+  kw = dict(latitude=latitude, min_wavelength_lon=lo, max_wavelength_lon=hi,
+            constant_to_add=50 if add_constant else 0)
+  zes = dv.ZonalEnergySpectrum('geopotential')
+  spec = {}
+  for res in (5, 20):
+    s = zes.compute(make_multispectral_dataset(
+        spatial_resolution_in_degrees=res, **kw))
+    ax = s.dims.index('zonal_wavenumber')
+    spec[res] = (s.coords['frequency'].values[:, 0],
+                 np.moveaxis(np.asarray(s.values), ax, 0))
+  wavelength_m = lambda wl: ((wl / 360) * (2 * np.pi * EARTH_RADIUS_M)
+                             * np.cos(np.pi * latitude / 180))
+  rs = np.random.RandomState(0)
+  test_frequencies = sorted(1 / wavelength_m(
+      rs.uniform(low=1.1 * lo, high=0.9 * hi, size=30)))
+  test_frequencies.append(0)
+  nearest = lambda fr, f: int(np.argmin(np.abs(fr - f)))
+  f5, s5 = spec[5]
+  f20, s20 = spec[20]
+  for i, f in enumerate(test_frequencies):
+    err = np.abs(s5[nearest(f5, f)] - s20[nearest(f20, f)])
+    idx = nearest(f20, f)
+    below, above = max(0, idx - 1), min(len(f20) - 1, idx + 1)
+    bound = np.abs(s20[below] - s20[above])
+    assert (err < bound).all(), f'Failed at {i=} {f=}'
+
+
+def _sel_lat(da, lat_value, dim):
+  """(frequency values, data[..., dim]) of one latitude, `dim` moved last."""
+  j = int(np.argmin(np.abs(np.asarray(da.coords['latitude']) - lat_value)))
+  v = np.moveaxis(np.asarray(da.values),
+                  (da.dims.index('latitude'), da.dims.index(dim)), (-2, -1))
+  return j, v[..., j, :]
+
+
+def test_interpolate_frequencies_default_args(dv):
+  # derived_variables_test.py:437-477
+  ds = make_multispectral_dataset(spatial_resolution_in_degrees=5,
+                                  latitude=slice(-30, 30))
+  spectrum = dv.ZonalEnergySpectrum('geopotential').compute(ds)
+  interpolated = dv.interpolate_spectral_frequencies(
+      spectrum, wavenumber_dim='zonal_wavenumber')
+  assert set(interpolated.dims) == (
+      {'frequency'} | set(spectrum.dims) - {'zonal_wavenumber'})
+  # latitude 0 has the narrowest frequency range = the default grid: unchanged
+  j0, s0 = _sel_lat(spectrum, 0, 'zonal_wavenumber')
+  _, i0 = _sel_lat(interpolated, 0, 'frequency')
+  np.testing.assert_allclose(
+      interpolated.coords['frequency'],
+      spectrum.coords['frequency'].values[:, j0], rtol=1e-12)
+  np.testing.assert_allclose(i0, s0, rtol=1e-9, atol=1e-12)
+  _, s5 = _sel_lat(spectrum, 5, 'zonal_wavenumber')
+  _, i5 = _sel_lat(interpolated, 5, 'frequency')
+  np.testing.assert_allclose(i5, s5, rtol=0.15, atol=1e-12)
+  with np.errstate(divide='ignore'):
+    np.testing.assert_allclose(interpolated.coords['wavelength'].values,
+                               1 / np.asarray(interpolated.coords['frequency']))
+
+
+def test_interpolate_frequencies_use_5_degree_values(dv):
+  # derived_variables_test.py:479-520
+  ds = make_multispectral_dataset(spatial_resolution_in_degrees=1.0,
+                                  latitude=slice(-30, 30))
+  spectrum = dv.ZonalEnergySpectrum('geopotential').compute(ds)
+  ref_lat, ks = 5, slice(3, 8)
+  j, s_ref = _sel_lat(spectrum, ref_lat, 'zonal_wavenumber')
+  freqs = spectrum.coords['frequency'].values[ks, j]
+  interpolated = dv.interpolate_spectral_frequencies(
+      spectrum, wavenumber_dim='zonal_wavenumber', frequencies=freqs)
+  assert set(interpolated.dims) == (
+      {'frequency'} | set(spectrum.dims) - {'zonal_wavenumber'})
+  _, i_ref = _sel_lat(interpolated, ref_lat, 'frequency')
+  np.testing.assert_allclose(i_ref, s_ref[..., ks], rtol=1e-9, atol=1e-12)
+  _, s_next = _sel_lat(spectrum, ref_lat + 1, 'zonal_wavenumber')
+  _, i_next = _sel_lat(interpolated, ref_lat + 1, 'frequency')
+  np.testing.assert_allclose(i_next, s_next[..., ks], rtol=0.1, atol=1e-12)
+  with pytest.raises(ValueError):
+    dv.interpolate_spectral_frequencies(spectrum, 'zonal_wavenumber',
+                                        frequencies=np.ones((2, 2)))

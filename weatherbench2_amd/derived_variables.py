@@ -125,3 +125,61 @@ class ZonalEnergySpectrum(DerivedVariable):
       result = xl.DataArray(np.ascontiguousarray(result.data), ref_dims,
                             coords, self.variable_name)
     return result
+
+
+def interpolate_spectral_frequencies(
+    spectrum: xl.DataArray,
+    wavenumber_dim: str,
+    frequencies: t.Optional[t.Sequence[float]] = None,
+    method: str = 'linear',
+) -> xl.DataArray:
+  """Interpolate frequencies in `spectrum` to common values
+  (derived_variables.py:629-683).
+
+  `spectrum` is what ZonalEnergySpectrum.compute returns: its `frequency`
+  coordinate depends on latitude (the circles shrink towards the poles), so
+  spectra of different latitudes are only comparable after this step.  Host
+  post-processing of an already reduced result: linear interpolation per
+  latitude, NaN outside that latitude's frequency range (xarray's `interp`
+  default), `frequency` replaces `wavenumber_dim` in place.
+  """
+  if method != 'linear':
+    raise NotImplementedError("only method='linear' is implemented")
+  freq = spectrum.coords.get('frequency')
+  if not isinstance(freq, xl.DataArray) or set(freq.dims) != {
+      wavenumber_dim, 'latitude'}:
+    raise ValueError(
+        f'spectrum.frequency.dims={getattr(freq, "dims", None)} was not a '
+        f'permutation of ("{wavenumber_dim}", "latitude")')
+  fr = np.asarray(freq.transpose(wavenumber_dim, 'latitude').values)
+  if frequencies is None:
+    freq_min = fr.max(axis=1).min()
+    freq_max = fr.min(axis=1).max()
+    frequencies = np.linspace(freq_min, freq_max,
+                              num=spectrum.sizes[wavenumber_dim])
+  if isinstance(frequencies, xl.DataArray):
+    frequencies = frequencies.values
+  frequencies = np.asarray(frequencies, dtype=np.float64)
+  if frequencies.ndim != 1:
+    raise ValueError(f'Expected 1-D frequencies, found {frequencies.shape=}')
+  ax_w = spectrum.dims.index(wavenumber_dim)
+  ax_l = spectrum.dims.index('latitude')
+  values = np.moveaxis(np.asarray(spectrum.values), (ax_l, ax_w), (-2, -1))
+  out = np.empty(values.shape[:-1] + (len(frequencies),), dtype=np.float64)
+  flat_in = values.reshape(-1, values.shape[-2], values.shape[-1])
+  flat_out = out.reshape(-1, values.shape[-2], len(frequencies))
+  for j in range(values.shape[-2]):
+    xp = fr[:, j]
+    for i in range(flat_in.shape[0]):
+      flat_out[i, j] = np.interp(frequencies, xp, flat_in[i, j],
+                                 left=np.nan, right=np.nan)
+  out = np.moveaxis(out, (-2, -1), (ax_l, ax_w))
+  dims = tuple('frequency' if d == wavenumber_dim else d
+               for d in spectrum.dims)
+  coords = {k: v for k, v in spectrum.coords.items()
+            if k not in (wavenumber_dim, 'frequency', 'wavelength')}
+  coords['frequency'] = frequencies
+  with np.errstate(divide='ignore'):
+    # interp does not deal well with the infinite wavelength: reset it (:676)
+    coords['wavelength'] = xl.DataArray(1 / frequencies, ('frequency',))
+  return xl.DataArray(out, dims, coords, spectrum.name)
