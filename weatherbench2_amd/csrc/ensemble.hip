@@ -52,19 +52,77 @@ struct EnsParams {
 
 // v_min_f32 / v_max_f32 (NaNs never reach the network: they are replaced first
 // or the result is overridden).
+#ifndef WB2_ENS_ASM_MINMAX
+#define WB2_ENS_ASM_MINMAX 1  // 0: __builtin_fmin/fmax (adds one canonicalize per member)
+#endif
+#ifndef WB2_ENS_BUFFER_LOADS
+#define WB2_ENS_BUFFER_LOADS 1  // 0: global loads with a 64-bit VALU address per member
+#endif
+#if WB2_ENS_ASM_MINMAX
+// The instructions themselves: fminf/fmaxf make hipcc canonicalise every loaded
+// value first (a v_max_f32 x, x, x per member) because of signalling NaNs,
+// which this kernel never looks at.
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#else
 __device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
+#endif
 
-template <int NPAD, typename T>
+// Member loads: the M addresses of a grid point differ by a wave-uniform
+// stride, so a raw buffer load (SGPR base per member, one constant per-lane byte
+// offset) needs no vector address arithmetic at all, where a global load costs
+// a 64-bit VALU add per member.
+template <typename T>
+__device__ __forceinline__ T member_load(const T* uniform_base, int lane_bytes) {
+#if WB2_ENS_BUFFER_LOADS
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(uniform_base), 0, 0x7fffffff, 0x00020000);
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(
+        T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, 0, 0));
+  } else {
+    return __builtin_bit_cast(
+        T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, 0, 0));
+  }
+#else
+  return __builtin_nontemporal_load(
+      reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) +
+                                 lane_bytes));
+#endif
+}
+
+// Sorts x[0..LIMIT) (slots >= LIMIT hold +inf padding and never move: every
+// comparator that touches one of them is a no-op and is pruned at compile time,
+// e.g. 403 instead of 543 comparators for 50 members in the 64-network).
+template <int NPAD, int LIMIT, typename T>
 __device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
-#define WB2_CE(i, j)                  \
-  {                                   \
-    const T lo_ = vmin(x[i], x[j]);   \
-    const T hi_ = vmax(x[i], x[j]);   \
-    x[i] = lo_;                       \
-    x[j] = hi_;                       \
+#define WB2_CE(i, j)                    \
+  if constexpr ((j) < LIMIT) {          \
+    const T lo_ = vmin(x[i], x[j]);     \
+    const T hi_ = vmax(x[i], x[j]);     \
+    x[i] = lo_;                         \
+    x[j] = hi_;                         \
   }
   if constexpr (NPAD == 2) { WB2_SORT_NETWORK_2 }
   if constexpr (NPAD == 4) { WB2_SORT_NETWORK_4 }
@@ -140,7 +198,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
         x[m] = (!live(m) || (SKIPNA && is_nan(x[m]))) ? inf : x[m];
       }
     }
-    sort_network<NPAD>(x);
+    sort_network<NPAD, NM>(x);
     double s = 0.0;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -215,8 +273,10 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
 
   if (active) {
     const long long slab_elems = (long long)p.n_row * p.n_col;
-    const T* xb = static_cast<const T*>(p.ens) + es * slab_elems +
-                  (long long)row0 * p.n_col + col0;
+    // wave-uniform row base (SGPRs) + this lane's byte offset inside the row
+    const T* xrow0 = static_cast<const T*>(p.ens) + es * slab_elems +
+                     (long long)row0 * p.n_col;
+    const int lane_bytes = col0 * (int)sizeof(T);
     const T* tb = static_cast<const T*>(p.truth) + ts * slab_elems +
                   (long long)row0 * p.n_col + col0;
     const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + col0
@@ -225,12 +285,13 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
     for (int r = 0; r < nrow; ++r) {
       T x[NPAD];
       const long long off = (long long)r * p.n_col;
+      const T* xrow = xrow0 + off;
 #pragma unroll
       for (int m = 0; m < NPAD; ++m) {
         if (m < NM) {
           // runtime M: slots >= M re-read the last member (cache hit, ignored)
           const int mm = MS > 0 ? m : (m < M ? m : M - 1);
-          x[m] = __builtin_nontemporal_load(xb + mm * p.member_stride + off);
+          x[m] = member_load<T>(xrow + mm * p.member_stride, lane_bytes);
         } else {
           x[m] = (T)0;
         }
