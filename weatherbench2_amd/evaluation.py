@@ -23,6 +23,7 @@ Mirrors (reference = /root/reference/weatherbench2/evaluation.py):
 """
 from __future__ import annotations
 
+import contextlib
 import typing as t
 
 import numpy as np
@@ -48,13 +49,26 @@ def _metric_and_region_loop(
 
   results = []
   regions = eval_config.regions
-  with metrics_lib.fused_regions(regions):
+  acc = next((m for m in eval_config.metrics.values()
+              if isinstance(m, metrics_lib.ACC) and m.climatology is not None),
+             None)
+  with contextlib.ExitStack() as stack:
+    stack.enter_context(metrics_lib.fused_regions(regions))
+    if acc is not None:
+      stack.enter_context(metrics_lib.fused_climatology(acc.climatology))
     for name, metric in eval_config.metrics.items():
       if compute_chunk or not eval_config.temporal_mean:
         eval_fn = metric.compute_chunk
       else:
         eval_fn = metric.compute
-      if regions is not None:
+      if regions is not None and isinstance(metric, metrics_lib.Metric):
+        # our metrics answer for every region at once (leading `region` dim)
+        regions_fn = (metric.compute_chunk_regions
+                      if eval_fn == metric.compute_chunk
+                      else metric.compute_regions)
+        result = xl.as_dataset(regions_fn(
+            forecast, truth, regions, skipna)).expand_dims({'metric': [name]})
+      elif regions is not None:
         tmp_results = []
         for region_name, region in regions.items():
           tmp_result = xl.as_dataset(eval_fn(
