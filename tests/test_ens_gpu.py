@@ -232,9 +232,8 @@ def test_perfect_prediction_zero_ensemble_mean_rmse(gm):
 
 
 def test_gaussian_crps_is_the_limit_of_ensemble_crps(gm):
-  # metrics_test.py:306-343 with the largest ensemble the register sort takes
-  # (128 members): the eFAIR CRPS is unbiased, so the mean over 19 times x 2
-  # leads x 19 x 36 points already agrees to a few percent.
+  # metrics_test.py:306-343 (2000 members, the streaming kernel; the
+  # reference test draws 5000 for the same 2e-2 tolerance)
   from oracle.named import DS
   kw = dict(variables_3d=[], time_start='2022-01-01')
   forecast = fixtures.mock_forecast_data(
@@ -242,7 +241,7 @@ def test_gaussian_crps_is_the_limit_of_ensemble_crps(gm):
       time_stop='2022-01-02', lead_stop='1 day', **kw)
   ens = fixtures.mock_forecast_data(
       variables_2d=['2m_temperature'], time_stop='2022-01-02',
-      lead_stop='1 day', ensemble_size=128, **kw)
+      lead_stop='1 day', ensemble_size=2000, **kw)
   truth = fixtures.mock_truth_data(variables_2d=['2m_temperature'],
                                    time_stop='2022-01-20', **kw)
   forecast = DS({'2m_temperature': forecast['2m_temperature'] + 0.1,
@@ -255,4 +254,49 @@ def test_gaussian_crps_is_the_limit_of_ensemble_crps(gm):
   gaussian = gm.GaussianCRPS().compute(g(forecast), g(truth))
   ensemble = gm.CRPS().compute(g(ens), g(truth))
   np.testing.assert_allclose(gaussian['2m_temperature'].values,
-                             ensemble['2m_temperature'].values, rtol=3e-2)
+                             ensemble['2m_temperature'].values, rtol=2e-2)
+
+
+@pytest.mark.parametrize('ensemble_size,dtype,skipna', [
+    (129, np.float32, False), (200, np.float32, True), (333, np.float32, False),
+    (65, np.float64, False), (100, np.float64, True)])
+def test_large_ensembles_take_the_streaming_path(gm, ensemble_size, dtype,
+                                                 skipna):
+  """More members than the register sort holds (128 float32 / 64 float64):
+  the sort-free kernel (pairwise |x_i - x_j| blocks + rank correction) must
+  give the same eight metrics, incl. the reference's NaN quirks with skipna
+  (ranks from the full ensemble, metrics.py:804-813) and spatial maps."""
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, lead_stop='1 day',
+      spatial_resolution_in_degrees=20)
+  truth, forecast = _cast(truth, dtype), _cast(forecast, dtype)
+  if skipna:
+    forecast = _cast(fixtures.insert_nan(forecast, 0.02, seed=3), dtype)
+    truth = _cast(fixtures.insert_nan(truth, 0.05, seed=4), dtype)
+  else:  # one NaN member must poison exactly one point
+    vals = forecast['geopotential'].data.copy()
+    vals[(ensemble_size - 1,) + (0,) * (vals.ndim - 1)] = np.nan
+    forecast = forecast.copy(data={'geopotential': vals})
+  g = helpers.to_gpu_dataset
+  regions = {'global': None,
+             'box': oreg.SliceRegion(lat_slice=slice(-30, 60),
+                                     lon_slice=slice(30, 200))}
+  g_regions = {k: helpers.to_gpu_region(v) for k, v in regions.items()}
+  tol = dict(rtol=2e-6, atol=1e-7) if dtype == np.float32 else dict(
+      rtol=1e-9, atol=1e-12)
+  with gm.fused_regions(g_regions):
+    for oname, gname in PAIRS:
+      for rname, region in regions.items():
+        want = getattr(om, oname)().compute_chunk(forecast, truth,
+                                                  region=region, skipna=skipna)
+        got = getattr(gm, gname)().compute_chunk(
+            g(forecast), g(truth), region=g_regions[rname], skipna=skipna)
+        helpers.assert_close(got['geopotential'].values,
+                             want['geopotential'].data,
+                             err_msg=f'{oname}/{rname}/M={ensemble_size}',
+                             **tol)
+  want = om.SpatialCRPS().compute_chunk(forecast, truth, skipna=skipna)
+  got = gm.SpatialCRPS().compute_chunk(g(forecast), g(truth), skipna=skipna)
+  da = got['geopotential']
+  v = da.data.cpu().numpy() if hasattr(da.data, 'cpu') else np.asarray(da.data)
+  helpers.assert_close(v, want['geopotential'].transpose(*da.dims).data, **tol)

@@ -89,6 +89,18 @@ __device__ __forceinline__ double vmin(double a, double b) { return __builtin_fm
 __device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
 #endif
 
+// max(|d|, 0): |d|, or 0 when d is NaN (v_max returns the non-NaN operand).
+__device__ __forceinline__ float abs_or_zero(float d) {
+  float r;
+  asm("v_max_f32 %0, |%1|, 0" : "=v"(r) : "v"(d));
+  return r;
+}
+__device__ __forceinline__ double abs_or_zero(double d) {
+  double r;
+  asm("v_max_f64 %0, |%1|, 0" : "=v"(r) : "v"(d));
+  return r;
+}
+
 // Member loads: the M addresses of a grid point differ by a wave-uniform
 // stride, so a raw buffer load (SGPR base per member, one constant per-lane byte
 // offset) needs no vector address arithmetic at all, where a global load costs
@@ -237,6 +249,114 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
 #define WB2_ENS_MIN_WAVES 1
 #endif
 
+// Ensembles too large for the register sort (M > 128 float32 / 64 float64):
+// the same six values from three streaming passes over the members (cache
+// resident after the first) -- no sort at all.  The rank-weighted sum is
+//   sum_i (2 r_i - M - 1) x_i = P - (M - n) * sum_valid x_i,
+//   P = sum_{i<j valid} |x_i - x_j|     (r: ranks in the full ensemble, NaN last)
+// and P is accumulated blockwise: 32 members in VGPRs against every later
+// member.  max(|d|, 0) drops the pairs that involve a NaN member (v_max returns
+// the non-NaN operand) and the padding of the last block alike; without skipna
+// a NaN member makes the result NaN, as in ens_point.
+template <typename T, bool SKIPNA>
+__device__ __forceinline__ void ens_point_large(
+    const T* xrow, long long member_stride, int lane_bytes, const int M,
+    const T t, double (&out)[SKIPNA ? 10 : 6]) {
+  constexpr int B = 32;
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  T sum = 0, sk = 0;
+  double sx = 0.0;  // fp64 sum of the valid members (rank correction term)
+  int n = 0;
+  bool bad = false;
+#pragma unroll 4
+  for (int m = 0; m < M; ++m) {
+    const T x = member_load<T>(xrow + m * member_stride, lane_bytes);
+    const bool isn = is_nan(x);
+    const bool use = SKIPNA ? !isn : true;
+    sum += use ? x : (T)0;
+    sk += use ? abs_of(t - x) : (T)0;
+    if constexpr (SKIPNA) sx += use ? (double)x : 0.0;
+    n += use ? 1 : 0;
+    bad = bad || isn;
+  }
+  const int cnt = SKIPNA ? n : M;
+  const T mean = sum / (T)cnt;
+  T sq = 0;
+#pragma unroll 4
+  for (int m = 0; m < M; ++m) {
+    const T x = member_load<T>(xrow + m * member_stride, lane_bytes);
+    const bool use = SKIPNA ? !is_nan(x) : true;
+    const T d = x - mean;
+    sq += use ? d * d : (T)0;
+  }
+  T var = sq / (T)(cnt - 1);
+  if (SKIPNA && cnt <= 1) var = nan;
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  const T deb = mse - var / (T)M;
+  T skill = sk / (T)cnt;
+  if (SKIPNA && is_nan(t)) skill = nan;
+
+  double pairs = 0.0;  // P
+  for (int a0 = 0; a0 < M; a0 += B) {
+    T xa[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int m = a0 + i < M ? a0 + i : M - 1;  // wave-uniform clamp
+      const T x = member_load<T>(xrow + m * member_stride, lane_bytes);
+      xa[i] = a0 + i < M ? x : nan;
+    }
+    // pairs inside the block: the full B x B table counts each one twice
+    double own = 0.0;
+    const int a1 = a0 + B < M ? a0 + B : M;
+    for (int b = a0; b < a1; ++b) {
+      const T xb = member_load<T>(xrow + b * member_stride, lane_bytes);
+      T acc = 0;
+#pragma unroll
+      for (int i = 0; i < B; ++i) acc += abs_or_zero(xa[i] - xb);
+      own += (double)acc;
+    }
+    double cross = 0.0;
+    for (int b = a1; b < M; ++b) {
+      const T xb = member_load<T>(xrow + b * member_stride, lane_bytes);
+      T acc = 0;
+#pragma unroll
+      for (int i = 0; i < B; ++i) acc += abs_or_zero(xa[i] - xb);
+      cross += (double)acc;
+    }
+    pairs += 0.5 * own + cross;
+  }
+  double spread = 0.0;
+  if (M >= 2) {
+    const double s = pairs - (SKIPNA ? (double)(M - n) * sx : 0.0);
+    spread = 2.0 * (s / (double)cnt) / (double)(M - 1);
+    if (!SKIPNA && bad) spread = (double)nan;
+  }
+  if constexpr (!SKIPNA) {
+    out[0] = (double)skill;
+    out[1] = spread;
+    out[2] = (double)mse;
+    out[3] = (double)var;
+    out[4] = (double)(sd * sd);
+    out[5] = (double)deb;
+  } else {
+    const bool ok_skill = !is_nan(skill), ok_spread = !is_nan(spread),
+               ok_mse = !is_nan(mse), ok_var = !is_nan(var),
+               ok_deb = !is_nan(deb);
+    out[0] = ok_skill ? (double)skill : 0.0;
+    out[1] = ok_spread ? spread : 0.0;
+    out[2] = ok_mse ? (double)mse : 0.0;
+    out[3] = ok_var ? (double)var : 0.0;
+    out[4] = ok_var ? (double)(sd * sd) : 0.0;
+    out[5] = ok_deb ? (double)deb : 0.0;
+    out[6] = ok_skill ? 1.0 : 0.0;
+    out[7] = ok_spread ? 1.0 : 0.0;
+    out[8] = ok_var ? 1.0 : 0.0;
+    out[9] = ok_deb ? 1.0 : 0.0;
+  }
+}
+
 template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
 __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
     ens_partials_kernel(const EnsParams p) {
@@ -283,26 +403,30 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
                            : nullptr;
 #pragma clang loop unroll(disable)
     for (int r = 0; r < nrow; ++r) {
-      T x[NPAD];
       const long long off = (long long)r * p.n_col;
       const T* xrow = xrow0 + off;
-#pragma unroll
-      for (int m = 0; m < NPAD; ++m) {
-        if (m < NM) {
-          // runtime M: slots >= M re-read the last member (cache hit, ignored)
-          const int mm = MS > 0 ? m : (m < M ? m : M - 1);
-          x[m] = member_load<T>(xrow + mm * p.member_stride, lane_bytes);
-        } else {
-          x[m] = (T)0;
-        }
-      }
       const T t = __builtin_nontemporal_load(tb + off);
       const double wr = p.w_row[row0 + r];
       double wf = 1.0;
       if constexpr (WF) wf = wfp[off];
-      __builtin_amdgcn_sched_barrier(0);
       double v[K];
-      ens_point<T, NPAD, MS, SKIPNA>(x, t, M, v);
+      if constexpr (NPAD == 0) {  // any M: streaming passes, no sort
+        ens_point_large<T, SKIPNA>(xrow, p.member_stride, lane_bytes, M, t, v);
+      } else {
+        T x[NPAD];
+#pragma unroll
+        for (int m = 0; m < NPAD; ++m) {
+          if (m < NM) {
+            // runtime M: slots >= M re-read the last member (cache hit, ignored)
+            const int mm = MS > 0 ? m : (m < M ? m : M - 1);
+            x[m] = member_load<T>(xrow + mm * p.member_stride, lane_bytes);
+          } else {
+            x[m] = (T)0;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ens_point<T, NPAD, MS, SKIPNA>(x, t, M, v);
+      }
       if (p.maps) {
         // Spatial* metrics (metrics.py:718-772, 1244-1266, 1366-1399): the
         // pointwise values themselves; with SKIPNA slots 6.. flag the NaNs.
@@ -579,8 +703,7 @@ int launch_ens_npad(const EnsParams& p, bool skipna, bool wf,
   if constexpr (sizeof(T) == 4) {
     if (m <= 128) return launch_ens<T, 128, 0>(p, skipna, wf, stream);
   }
-  return fail("n_member=%d is not supported by the register sort (max 128 for "
-              "float32, 64 for float64)", m);
+  return launch_ens<T, 0, 0>(p, skipna, wf, stream);  // any size, no sort
 }
 
 }  // namespace

@@ -806,15 +806,10 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   slab_elems = pl.n_row * pl.n_col
   maps = (torch.empty((6, geo.n_outer, slab_elems), dtype=torch.float64,
                       device=device) if want_maps else None)
-  try:
-    metrics, _ = engine.ensemble_reduce(
-        pl, ften, member_slabs * slab_elems, n_member, ens_table,
-        tten.reshape(-1, pl.n_row, pl.n_col), truth_table,
-        geo.n_outer, skipna, maps=maps)
-  except _lib.Wb2HipError as e:
-    if 'not supported by the register sort' in str(e):
-      raise NotImplementedError(str(e)) from e
-    raise
+  metrics, _ = engine.ensemble_reduce(
+      pl, ften, member_slabs * slab_elems, n_member, ens_table,
+      tten.reshape(-1, pl.n_row, pl.n_col), truth_table,
+      geo.n_outer, skipna, maps=maps)
   host = metrics.cpu().numpy().reshape(
       (_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
   value = (geo, {nm: host[:, i] for i, nm in enumerate(pl.region_names)},
