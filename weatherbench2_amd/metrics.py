@@ -59,12 +59,44 @@ class _Announced(threading.local):
 _ANNOUNCED = _Announced()
 
 
+def _field_key(region):
+  """Identity of the 2-D weight field a region brings along (land-sea masks);
+  None for pure latitude/longitude regions.  One fused pass carries at most
+  one such field, so regions are grouped by it."""
+  kind = type(region).__name__
+  if kind == 'LandRegion':
+    mask = getattr(region.land_sea_mask, 'data', region.land_sea_mask)
+    if isinstance(mask, np.ndarray):  # same buffer = same field
+      ident = (mask.__array_interface__['data'][0], mask.shape, mask.strides)
+    else:
+      ident = id(mask)
+    return (ident, getattr(region, 'threshold', None))
+  if kind == 'CombinedRegion':
+    keys = tuple(k for k in (_field_key(r) for r in region.regions)
+                 if k is not None)
+    return keys or None
+  return None
+
+
 @contextlib.contextmanager
 def fused_regions(regions: t.Optional[dict]):
-  """Announce the regions a loop is about to iterate so one pass serves all."""
+  """Announce the regions a loop is about to iterate so one pass serves all
+  (one pass per distinct 2-D weight field: field-free regions ride along with
+  the first group)."""
   active = dict(regions) if regions else {'__none__': None}
-  sig = tuple((k, id(v)) for k, v in active.items())
-  _ANNOUNCED.regions.append((active, sig))
+  keys = {k: _field_key(v) for k, v in active.items()}
+  distinct = []
+  for fk in keys.values():
+    if fk is not None and fk not in distinct:
+      distinct.append(fk)
+  groups, member = [], {}
+  for gi, fk in enumerate(distinct or [None]):
+    group = {k: v for k, v in active.items()
+             if keys[k] == fk or (gi == 0 and keys[k] is None)}
+    for k in group:
+      member[k] = gi
+    groups.append((group, tuple((k, id(v)) for k, v in group.items())))
+  _ANNOUNCED.regions.append((active, groups, member))
   try:
     yield
   finally:
@@ -90,12 +122,28 @@ def _region_set_for(region) -> tuple[dict, str]:
 
 def _region_set_sig(region) -> tuple[dict, str, tuple]:
   if _ANNOUNCED.regions:
-    active, sig = _ANNOUNCED.regions[-1]
+    active, groups, member = _ANNOUNCED.regions[-1]
     for k, v in active.items():
       if v is region:
-        return active, k, sig
+        group, sig = groups[member[k]]
+        return group, k, sig
   return ({'__requested__': region}, '__requested__',
           (('__requested__', id(region)),))
+
+
+def _fused(pass_fn, region, regions: t.Optional[dict]):
+  """pass_fn(region) -> (geo, by_region, ...) for the requested region -- or,
+  on the all-regions path (inside `_all_regions(regions)`), for one
+  representative of every field group, with the by_region dicts merged."""
+  if regions is None:
+    return pass_fn(region)
+  _, groups, _ = _ANNOUNCED.regions[-1]
+  out, merged = None, {}
+  for group, _ in groups:
+    res = pass_fn(next(iter(group.values())))
+    merged.update(res[1])
+    out = out or res
+  return (out[0], merged) + tuple(out[2:])
 
 
 # Beam's DirectRunner may call compute_chunk from several threads (ctypes
@@ -455,12 +503,12 @@ def _pick(by_region: dict, region, index, regions: t.Optional[dict]):
 
 @contextlib.contextmanager
 def _all_regions(regions: t.Optional[dict]):
-  """(first region, regions) inside an announcement of exactly `regions`."""
+  """An announcement of exactly `regions` (no-op for a single-region call)."""
   if regions is None:
-    yield None
+    yield
   else:
     with fused_regions(regions):
-      yield next(iter(regions.values()))
+      yield
 
 
 def _assemble(forecast, per_var: dict,
@@ -546,10 +594,11 @@ class _DetMetric(Metric):
               regions: t.Optional[dict] = None) -> xl.Dataset:
     forecast, truth = _inputs(forecast, truth)
     per_var = {}
-    with _all_regions(regions) as first:
-      region = region if regions is None else first
+    with _all_regions(regions):
       for name in _common_vars(forecast, truth):
-        geo, by_region = _det_pass(forecast, truth, name, region, skipna)
+        geo, by_region = _fused(
+            lambda r, name=name: _det_pass(forecast, truth, name, r, skipna),
+            region, regions)
         lead, values = _pick(by_region, region, self._index, regions)
         per_var[name] = (lead + geo.out_dims, values)
     return _assemble(forecast, per_var, regions)
@@ -592,10 +641,10 @@ class WindVectorMSE(Metric):
   def compute_chunk(self, forecast, truth, region=None, skipna=False,
                     regions: t.Optional[dict] = None):
     forecast, truth = _inputs(forecast, truth)
-    with _all_regions(regions) as first:
-      region = region if regions is None else first
-      geo, by_region = _wind_pass(forecast, truth, self.u_name, self.v_name,
-                                  region, skipna)
+    with _all_regions(regions):
+      geo, by_region = _fused(
+          lambda r: _wind_pass(forecast, truth, self.u_name, self.v_name, r,
+                               skipna), region, regions)
       lead, values = _pick(by_region, region, self._index, regions)
     return _assemble(forecast, {self.vector_name: (lead + geo.out_dims,
                                                    values)}, regions)
@@ -699,11 +748,11 @@ class ACC(Metric):
     climatology = xl.as_dataset(self.climatology)
     per_var = {}
     _get_climatology_chunk(climatology, truth)  # KeyError like the reference
-    with _all_regions(regions) as first:
-      region = region if regions is None else first
+    with _all_regions(regions):
       for name in _common_vars(forecast, truth):
-        geo, by_region = _det_pass(forecast, truth, name, region, skipna,
-                                   climatology)
+        geo, by_region = _fused(
+            lambda r, name=name: _det_pass(forecast, truth, name, r, skipna,
+                                           climatology), region, regions)
         lead, values = _pick(by_region, region, _lib.METRIC_INDEX['acc'],
                              regions)
         per_var[name] = (lead + geo.out_dims, values)
@@ -838,12 +887,12 @@ class EnsembleMetric(Metric):
     forecast, truth = _inputs(forecast, truth)
     _get_n_ensemble(forecast, self.ensemble_dim)  # raises like the reference
     per_var = {}
-    with _all_regions(regions) as first:
-      region = region if regions is None else first
+    with _all_regions(regions):
       for name in _common_vars(forecast, truth):
-        geo, by_region, n_member = _ens_pass(forecast, truth, name,
-                                             self.ensemble_dim, region,
-                                             skipna)[:3]
+        geo, by_region, n_member = _fused(
+            lambda r, name=name: _ens_pass(forecast, truth, name,
+                                           self.ensemble_dim, r, skipna)[:3],
+            region, regions)
         lead, values = _pick(by_region, region,
                              _lib.ENS_METRIC_INDEX[self._metric], regions)
         if self._zero_if_single and n_member == 1:
