@@ -215,6 +215,12 @@ __device__ __forceinline__ void eval_slots(
 #ifndef WB2_U_ROWS
 #define WB2_U_ROWS 2
 #endif
+#ifndef WB2_U_ROWS_NARROW
+#define WB2_U_ROWS_NARROW 8   // rows per batch when a lane's load is < 16 bytes
+#endif
+#ifndef WB2_F32_VEC
+#define WB2_F32_VEC 4         // float32 columns per lane (16-byte loads)
+#endif
 #ifndef WB2_NT_LOADS
 #define WB2_NT_LOADS 1
 #endif
@@ -270,8 +276,9 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
     stream_partials_kernel(const StreamParams p) {
   using M = ModeTraits<MODE, SKIPNA>;
   constexpr int NIN = M::NIN, K = M::K, NWF = WF ? 2 : 1;
-  constexpr int U =
-      (sizeof(T) * VEC >= 16) ? (NIN >= 4 ? WB2_U_ROWS / 2 : WB2_U_ROWS) : 8;
+  constexpr int U = (sizeof(T) * VEC >= 16)
+                        ? (NIN >= 4 ? WB2_U_ROWS / 2 : WB2_U_ROWS)
+                        : WB2_U_ROWS_NARROW;
   constexpr int TILE = kWave * VEC;
 
   const int lane = threadIdx.x & (kWave - 1);
@@ -694,7 +701,7 @@ int launch_stream_mode(const StreamParams& p, int mode, bool vec, bool skipna,
 }
 
 int vec_width(int dtype, int n_col, bool aligned16) {
-  const int w = dtype == WB2_F32 ? 4 : 2;
+  const int w = dtype == WB2_F32 ? WB2_F32_VEC : 2;
   return (aligned16 && n_col % w == 0) ? w : 1;
 }
 
@@ -841,7 +848,7 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
   p.n_seg = n_seg;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == WB2_F32)
-    return launch_stream_mode<float, 4>(p, mode, vec > 1, skipna != 0,
+    return launch_stream_mode<float, WB2_F32_VEC>(p, mode, vec > 1, skipna != 0,
                                         wfield != nullptr, threads, s);
   return launch_stream_mode<double, 2>(p, mode, vec > 1, skipna != 0,
                                        wfield != nullptr, threads, s);
