@@ -246,6 +246,32 @@ int wb2_ens_threshold_partials(
     int32_t n_ts, double* partials, void* stream);
 
 /*
+ * Means / raw moments along one axis of a [n_lead][n_red][n_tail] view: the
+ * compute core of scripts/compute_ensemble_mean.py:111-141 (xbeam.Mean over
+ * realization), scripts/compute_averages.py:125-167 (v * lat_weights, mean over
+ * averaging dims) and scripts/compute_statistical_moments.py:52-80 (means of
+ * notnull(x), x, x**2).  For every (lead, tail):
+ *   sum   = sum_r w_red[r] * x[l][r][t]          over the valid r
+ *   sumsq = sum_r w_red[r] * (x * x)             (x * x in the input dtype;
+ *                                                 NULL = not wanted)
+ *   count = number of valid r                    (valid: !isnan(x), or every r
+ *                                                 when skipna == 0)
+ * in fp64.  w_red == NULL means all ones; otherwise w_red holds n_red /
+ * w_repeat weights, each applying to w_repeat consecutive r (w_repeat = 1440
+ * for latitude weights over a merged (latitude, longitude) axis, 1 for one
+ * weight per element).  Deterministic: the reduced axis is cut into n_split
+ * slices (wb2_axis_moments_splits() proposes a count) whose partials are
+ * combined in slice order; `workspace` holds 3 * n_split * n_lead * n_tail
+ * doubles.
+ */
+int wb2_axis_moments_splits(int64_t n_lead, int64_t n_red, int64_t n_tail,
+                            int64_t w_repeat);
+int wb2_axis_moments(int dtype, const void* x, int64_t n_lead, int64_t n_red,
+                     int64_t n_tail, const double* w_red, int64_t w_repeat,
+                     int skipna, int n_split, double* workspace, double* sum,
+                     double* sumsq, double* count, void* stream);
+
+/*
  * Spatial* threshold metrics (SpatialEnsembleBrierScore,
  * SpatialDebiasedEnsembleBrierScore, SpatialEnsembleIgnoranceScore,
  * SpatialEnsembleRPS; metrics.py:1615-1638, 1697-1719, 1780-1802, 1870-1891):

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
 SOURCES = ('common.cpp', 'stream_reduce.hip', 'ensemble.hip', 'spectrum.hip',
-           'spectrum_fused.hip', 'spatial_maps.hip', 'rank_histogram.hip')
+           'spectrum_fused.hip', 'spatial_maps.hip', 'rank_histogram.hip',
+           'axis_reduce.hip')
 
 
 def _hipcc() -> str:

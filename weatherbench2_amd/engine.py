@@ -393,3 +393,34 @@ def seeps_map(inputs: t.Sequence[torch.Tensor],
       n_point, _lib.ptr(aux), float(scalar), _lib.ptr(out),
       current_stream_ptr(dev)), 'wb2_seeps_map')
   return out
+
+
+def axis_moments(x: torch.Tensor, n_lead: int, n_red: int, n_tail: int,
+                 w_red: t.Optional[torch.Tensor], skipna: bool,
+                 want_sq: bool = False, w_repeat: int = 1):
+  """wb2_axis_moments on a contiguous [n_lead, n_red, n_tail] view of `x`:
+  (sum, sumsq or None, count) as float64 tensors of n_lead * n_tail.  `w_red`
+  holds n_red / w_repeat weights, each shared by w_repeat consecutive r."""
+  lib = _lib.load()
+  dev = x.device
+  if x.dtype not in _DTYPES or not x.is_contiguous():
+    raise ValueError('x must be a contiguous float32/float64 device tensor')
+  if x.numel() != n_lead * n_red * n_tail:
+    raise ValueError('shape mismatch')
+  if w_red is not None and (w_red.dtype != torch.float64
+                            or w_red.numel() * w_repeat != n_red):
+    raise ValueError('w_red must be float64[n_red / w_repeat]')
+  n_out = n_lead * n_tail
+  n_split = lib.wb2_axis_moments_splits(n_lead, n_red, n_tail,
+                                        w_repeat if w_red is not None else 1)
+  work = torch.empty((3 * n_split * max(n_out, 1),), dtype=torch.float64,
+                     device=dev)
+  total = torch.empty((n_out,), dtype=torch.float64, device=dev)
+  count = torch.empty_like(total)
+  sq = torch.empty_like(total) if want_sq else None
+  _lib.check(lib.wb2_axis_moments(
+      _DTYPES[x.dtype], _lib.ptr(x), n_lead, n_red, n_tail, _lib.ptr(w_red),
+      w_repeat, int(skipna), n_split, _lib.ptr(work), _lib.ptr(total),
+      _lib.ptr(sq), _lib.ptr(count), current_stream_ptr(dev)),
+             'wb2_axis_moments')
+  return total, sq, count
