@@ -419,9 +419,11 @@ def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
     aux = torch.as_tensor(np.ascontiguousarray(aux, dtype=np.float64)).to(device)
   metrics, _ = engine.stream_reduce(pl, mode, flat, slabs, geo.n_outer, skipna,
                                     aux=aux, scalar=scalar)
-  host = metrics.cpu().numpy().reshape(
-      (metrics.shape[0], pl.n_region) + geo.out_shape)
-  return {name: host[:, i] for i, name in enumerate(pl.region_names)}, rkey
+  # results stay on the device (tiny fp64 tensors): nothing here waits for the
+  # GPU, so a caller streaming chunks keeps the queue full; `.values` of the
+  # returned DataArrays is where the copy (and the sync) happens
+  dev = metrics.reshape((metrics.shape[0], pl.n_region) + geo.out_shape)
+  return {name: dev[:, i] for i, name in enumerate(pl.region_names)}, rkey
 
 
 def _result_key(kind, arrays, region_key_obj, skipna):
@@ -492,13 +494,26 @@ def _result_coords(forecast: xl.Dataset, out_dims) -> dict:
   return coords
 
 
+def _stack(arrays):
+  """np.stack / torch.stack: fused results are device tensors."""
+  if isinstance(arrays[0], torch.Tensor):
+    return torch.stack(list(arrays))
+  return np.stack([np.asarray(a, dtype=np.float64) for a in arrays])
+
+
+def _transpose(values, axes):
+  if isinstance(values, torch.Tensor):
+    return values.permute(*axes)
+  return np.transpose(values, axes)
+
+
 def _pick(by_region: dict, region, index, regions: t.Optional[dict]):
   """The requested region's row of a fused result -- or, for the all-regions
   fast path, every announced region stacked along a leading `region` dim."""
   if regions is None:
     _, rkey = _region_set_for(region)
     return (), by_region[rkey][index]
-  return ('region',), np.stack([by_region[k][index] for k in regions])
+  return ('region',), _stack([by_region[k][index] for k in regions])
 
 
 @contextlib.contextmanager
@@ -520,8 +535,11 @@ def _assemble(forecast, per_var: dict,
   for name, (dims, arr) in per_var.items():
     out.coords.update(_result_coords(forecast, dims))
   for name, (dims, arr) in per_var.items():
-    out.data_vars[name] = xl.DataArray(np.array(arr, dtype=np.float64), dims,
-                                       out.coords, name)
+    if isinstance(arr, torch.Tensor):
+      data = arr.to(torch.float64)
+    else:
+      data = np.array(arr, dtype=np.float64)
+    out.data_vars[name] = xl.DataArray(data, dims, out.coords, name)
   return out
 
 
@@ -859,9 +877,8 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
       pl, ften, member_slabs * slab_elems, n_member, ens_table,
       tten.reshape(-1, pl.n_row, pl.n_col), truth_table,
       geo.n_outer, skipna, maps=maps)
-  host = metrics.cpu().numpy().reshape(
-      (_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
-  value = (geo, {nm: host[:, i] for i, nm in enumerate(pl.region_names)},
+  dev = metrics.reshape((_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
+  value = (geo, {nm: dev[:, i] for i, nm in enumerate(pl.region_names)},
            n_member)
   if want_maps:
     value = value + (maps.reshape((6,) + out_shape + (pl.n_row, pl.n_col)),
@@ -896,13 +913,15 @@ class EnsembleMetric(Metric):
         lead, values = _pick(by_region, region,
                              _lib.ENS_METRIC_INDEX[self._metric], regions)
         if self._zero_if_single and n_member == 1:
-          values = np.zeros_like(values)
+          values = (torch.zeros_like(values)
+                    if isinstance(values, torch.Tensor)
+                    else np.zeros_like(values))
         dims = lead + geo.out_dims
         if self._truth_first:
           tdims = [d for d in truth[name].dims if d in dims]
           order = lead + tuple(
               tdims + [d for d in dims if d not in tdims and d not in lead])
-          values = np.transpose(values, [dims.index(d) for d in order])
+          values = _transpose(values, [dims.index(d) for d in order])
           dims = order
         per_var[name] = (dims, values)
     return _assemble(forecast, per_var, regions)
@@ -1254,8 +1273,7 @@ def _stack_quantiles(forecast, per_threshold: list, quantiles, method: str,
   if not sum_over_quantile:
     out.coords['quantile'] = np.array(list(quantiles), dtype=np.float64)
   for name, (dims, _) in first.items():
-    data = np.stack([np.asarray(p[name][1], dtype=np.float64)
-                     for p in per_threshold])
+    data = _stack([p[name][1] for p in per_threshold])
     if sum_over_quantile:
       out.data_vars[name] = xl.DataArray(data.sum(0), dims, out.coords, name)
     else:
@@ -1294,7 +1312,7 @@ def _truth_first_order(dims, values, truth_dims):
   order = tuple(tdims + [d for d in dims if d not in tdims])
   if order == tuple(dims):
     return dims, values
-  return order, np.transpose(values, [dims.index(d) for d in order])
+  return order, _transpose(values, [dims.index(d) for d in order])
 
 
 class _GaussianThresholdMetric(ThresholdMetric):
@@ -1409,8 +1427,8 @@ def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
       pl, tens[0], member_slabs * slab_elems, n_member, tables[0],
       tens[1].reshape(-1, pl.n_row, pl.n_col), tables[1],
       tens[2].reshape(-1, pl.n_row, pl.n_col), tables[2], geo.n_outer, skipna)
-  host = metrics.cpu().numpy().reshape((4, pl.n_region) + geo.out_shape)
-  return geo, {nm: host[:, i] for i, nm in enumerate(pl.region_names)}
+  dev = metrics.reshape((4, pl.n_region) + geo.out_shape)
+  return geo, {nm: dev[:, i] for i, nm in enumerate(pl.region_names)}
 
 
 @_serialized
