@@ -77,6 +77,9 @@ class ZonalEnergySpectrum(DerivedVariable):
     """Zonal power at each wavenumber.  `time_mean_dim` (an extension) fuses
     the mean over that dim, as scripts/compute_zonal_energy_spectrum.py:234
     does afterwards with xbeam.Mean."""
+    if xl.is_xarray(dataset):
+      return xl.like_input(self.compute(xl.as_dataset(dataset), time_mean_dim,
+                                        skipna), dataset)
     dataset = xl.as_dataset(dataset)
     spacing = self.lon_spacing_m(dataset)
     da = dataset[self.variable_name]

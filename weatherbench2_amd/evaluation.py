@@ -41,6 +41,7 @@ def _metric_and_region_loop(
     compute_chunk: bool = False,
 ) -> xl.Dataset:
   """Compute metric results looping over metrics and regions in eval config."""
+  given_forecast, given_truth = forecast, truth
   forecast = xl.as_dataset(forecast)
   truth = xl.as_dataset(truth)
   for name, dv in eval_config.derived_variables.items():
@@ -81,7 +82,7 @@ def _metric_and_region_loop(
             forecast=forecast, truth=truth, skipna=skipna)).expand_dims(
                 {'metric': [name]})
       results.append(result)
-  return xl.merge(results)
+  return xl.like_input(xl.merge(results), given_forecast, given_truth)
 
 
 class RunningMean:

@@ -550,9 +550,28 @@ def _common_vars(forecast, truth):
 # ---------------------------------------------------------------------------
 # Metric classes (metrics.py:84-414)
 # ---------------------------------------------------------------------------
+def _returns_like_input(fn):
+  """xarray in -> xarray out at the public entry points (xarray_lite.like_input);
+  calls between metrics pass lite Datasets and skip the conversion."""
+  @functools.wraps(fn)
+  def wrapper(self, forecast, truth, *args, **kwargs):
+    return xl.like_input(fn(self, forecast, truth, *args, **kwargs), forecast,
+                         truth)
+  wrapper._wb2_like_input = True
+  return wrapper
+
+
 @dataclasses.dataclass
 class Metric:
   """Base class for metrics (metrics.py:84-138)."""
+
+  def __init_subclass__(cls, **kwargs):
+    super().__init_subclass__(**kwargs)
+    for name in ('compute_chunk', 'compute', 'compute_chunk_regions',
+                 'compute_regions'):
+      fn = cls.__dict__.get(name)
+      if callable(fn) and not getattr(fn, '_wb2_like_input', False):
+        setattr(cls, name, _returns_like_input(fn))
 
   def compute_chunk(self, forecast, truth, region: t.Optional[Region] = None,
                     skipna: bool = False) -> xl.Dataset:
@@ -561,7 +580,7 @@ class Metric:
   def compute(self, forecast, truth, region: t.Optional[Region] = None,
               skipna: bool = False) -> xl.Dataset:
     """Evaluate this metric on datasets with full temporal coverages."""
-    forecast = xl.as_dataset(forecast)
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     if 'time' in forecast.dims:
       avg_dim = 'time'
     elif 'init_time' in forecast.dims:
@@ -585,6 +604,7 @@ class Metric:
     return self._fan_out(self.compute, forecast, truth, regions, skipna)
 
   def _fan_out(self, fn, forecast, truth, regions, skipna):
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     with fused_regions(regions):
       parts = [xl.as_dataset(fn(forecast=forecast, truth=truth, region=region,
                                 skipna=skipna)).expand_dims({'region': [name]})
@@ -593,7 +613,7 @@ class Metric:
 
   def _mean_regions(self, forecast, truth, regions, skipna):
     """Metric.compute on the stacked result (same checks, same mean)."""
-    forecast = xl.as_dataset(forecast)
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     if 'time' in forecast.dims:
       avg_dim = 'time'
     elif 'init_time' in forecast.dims:
@@ -603,6 +623,11 @@ class Metric:
           f'Forecast has neither valid_time or init_time dimension {forecast}')
     return self.compute_chunk_regions(forecast, truth, regions,
                                       skipna).mean(avg_dim, skipna=skipna)
+
+
+for _name in ('compute', 'compute_chunk_regions', 'compute_regions'):
+  setattr(Metric, _name, _returns_like_input(Metric.__dict__[_name]))
+del _name
 
 
 class _DetMetric(Metric):
@@ -928,7 +953,7 @@ class EnsembleMetric(Metric):
 
   def compute(self, forecast, truth, region=None, skipna=False):
     """Evaluate this metric on datasets with full temporal coverages."""
-    forecast = xl.as_dataset(forecast)
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     result = super().compute(forecast, truth, region=region, skipna=skipna)
     return result.assign_attrs(ensemble_size=forecast.sizes[self.ensemble_dim])
 
@@ -1904,6 +1929,14 @@ def central_reliability(hist):
   grown outward from the centre bin(s), on a new `prob_index` dim with the
   `desired_prob` coordinate.  Tiny host work on an already reduced histogram.
   """
+  if xl.is_xarray(hist):
+    given = hist
+    if not hasattr(hist, 'data_vars'):  # an xarray.DataArray
+      name = hist.name or 'hist'
+      return xl.like_input(
+          central_reliability(xl.as_dataset(hist.to_dataset(name=name))[name]),
+          given)
+    return xl.like_input(central_reliability(xl.as_dataset(hist)), given)
   hist = xl.as_dataset(hist) if not isinstance(hist, xl.DataArray) else hist
   if isinstance(hist, xl.Dataset):
     out = xl.Dataset(attrs=dict(hist.attrs))

@@ -14,6 +14,7 @@ Dataset IO, Beam and the CLI flags around these cores are out of scope.
 """
 from __future__ import annotations
 
+import functools
 import typing as t
 
 import numpy as np
@@ -22,6 +23,14 @@ import torch
 from weatherbench2_amd import engine
 from weatherbench2_amd import plan as plan_lib
 from weatherbench2_amd import xarray_lite as xl
+
+
+def _like_input(fn):
+  """xarray in -> xarray out (xarray_lite.like_input)."""
+  @functools.wraps(fn)
+  def wrapper(dataset, *args, **kwargs):
+    return xl.like_input(fn(dataset, *args, **kwargs), dataset)
+  return wrapper
 
 
 def _moments(da: xl.DataArray, dims: t.Sequence[str], skipna: bool,
@@ -81,6 +90,7 @@ def _coords_without(ds: xl.Dataset, dims) -> dict:
   return out
 
 
+@_like_input
 def mean(dataset, dims: t.Sequence[str], skipna: bool = False) -> xl.Dataset:
   """`dataset.mean(dims, skipna)`: variables lacking a dim are averaged over
   the ones they have; results keep the input dtype, like xarray."""
@@ -97,6 +107,7 @@ def mean(dataset, dims: t.Sequence[str], skipna: bool = False) -> xl.Dataset:
   return out
 
 
+@_like_input
 def ensemble_mean(dataset, realization_name: str = 'realization',
                   skipna: bool = False) -> xl.Dataset:
   """The ensemble mean of every variable (compute_ensemble_mean.py:134)."""
@@ -106,6 +117,7 @@ def ensemble_mean(dataset, realization_name: str = 'realization',
   return mean(ds, (realization_name,), skipna)
 
 
+@_like_input
 def averages(dataset, averaging_dims: t.Sequence[str],
              skipna: bool = False) -> xl.Dataset:
   """Averages over `averaging_dims` (compute_averages.py:139-160).  Latitude is
@@ -135,6 +147,7 @@ def averages(dataset, averaging_dims: t.Sequence[str],
   return out
 
 
+@_like_input
 def statistical_moments(dataset,
                         reduce_dims=('latitude', 'longitude')) -> xl.Dataset:
   """`<var>_zeroth` (fraction of non-NaN points), `<var>_first` (mean) and

@@ -394,6 +394,11 @@ def to_xarray(ds: Dataset):
                      coords=coords, attrs=ds.attrs)
 
 
+def is_xarray(obj) -> bool:
+  """True for a real xarray.Dataset / DataArray (never without xarray)."""
+  return _xr is not None and isinstance(obj, (_xr.Dataset, _xr.DataArray))
+
+
 def as_dataset(obj) -> Dataset:
   """Accepts a lite Dataset or (when importable) a real xarray.Dataset."""
   if isinstance(obj, Dataset):
@@ -401,3 +406,25 @@ def as_dataset(obj) -> Dataset:
   if _xr is not None and isinstance(obj, _xr.Dataset):
     return from_xarray(obj)
   raise TypeError(f'expected a Dataset, got {type(obj)}')
+
+
+def like_input(result, *inputs):
+  """The protocol's return convention: callers that hand in xarray objects
+  (the reference's own `_metric_and_region_loop`, evaluation.py:408-435, goes
+  on to call `.expand_dims` / `xr.concat` on what it gets back) receive xarray
+  objects; lite in, lite out."""
+  if not any(is_xarray(x) for x in inputs):
+    return result
+  if isinstance(result, Dataset):
+    return to_xarray(result)
+  if isinstance(result, DataArray):
+    coords = {}
+    for k, c in result.coords.items():
+      if isinstance(c, DataArray):
+        if all(d in result.dims for d in c.dims):
+          coords[k] = (c.dims, c.values)
+      elif k in result.dims:
+        coords[k] = (k, np.asarray(c))
+    return _xr.DataArray(result.values, dims=result.dims, coords=coords,
+                         name=result.name)
+  return result
