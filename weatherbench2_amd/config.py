@@ -1,74 +1,59 @@
-"""Evaluation configuration: field-compatible with weatherbench2/config.py.
+"""`config.Eval`: the plug-in point of the metric x region loop.
 
-`Eval` (config.py:96-137) is the plug-in point of the reference: its `metrics`
-and `regions` dicts carry the operator objects into the metric x region loop.
-The dataclasses below keep the reference's field names and defaults so that an
-existing configuration can be built unchanged with GPU metric objects as the
-values of `Eval.metrics`.  `Selection` / `Paths` / `Data` (config.py:28-93)
-describe dataset opening, which stays on the host and is out of scope here;
-they are mirrored only so `Data`-carrying code keeps importing.
+The reference's `Eval` (weatherbench2/config.py:96-137) carries the operator
+objects -- `metrics: {name: Metric}`, `regions: {name: Region}`,
+`derived_variables: {name: DerivedVariable}` -- into
+`evaluation._metric_and_region_loop`.  This module provides a dataclass with the
+same field names, order and defaults, so an existing configuration is built
+unchanged with GPU metric objects as the values of `metrics`; a reference
+`config.Eval` instance works just as well (the loop only reads attributes).
+The dataset-opening half of the reference's config (`Selection`, `Paths`,
+`Data`, config.py:28-93) belongs to the IO layer, which is out of scope.
 """
 from __future__ import annotations
 
 import dataclasses
 import typing as t
 
+_REQUIRED = dataclasses.MISSING
 
-@dataclasses.dataclass
-class Selection:
-  """Which variables / levels / times to evaluate (config.py:28-55)."""
-
-  variables: t.Sequence[str]
-  time_slice: slice
-  levels: t.Optional[t.Sequence[int]] = None
-  lat_slice: t.Optional[slice] = dataclasses.field(
-      default_factory=lambda: slice(None, None))
-  lon_slice: t.Optional[slice] = dataclasses.field(
-      default_factory=lambda: slice(None, None))
-  aux_variables: t.Optional[t.Sequence[str]] = None
-
-
-@dataclasses.dataclass
-class Paths:
-  """Dataset locations (config.py:58-74)."""
-
-  forecast: str
-  obs: str
-  output_dir: str
-  output_file_prefix: t.Optional[str] = ''
-  climatology: t.Optional[str] = None
+# (field, default) in the reference's order; only the first three and
+# `temporal_mean` are read on this path, the rest are accepted and kept so that
+# code written against the reference's Eval keeps constructing it.
+_EVAL_FIELDS: tuple = (
+    ('metrics', _REQUIRED),                       # {name: Metric}
+    ('regions', None),                            # {name: Region} or None
+    ('evaluate_persistence', False),
+    ('evaluate_climatology', False),
+    ('evaluate_probabilistic_climatology', False),
+    ('probabilistic_climatology_start_year', None),
+    ('probabilistic_climatology_end_year', None),
+    ('probabilistic_climatology_hour_interval', None),
+    ('against_analysis', False),
+    ('derived_variables', dict),                  # factory: fresh dict
+    ('temporal_mean', True),                      # average over (init_)time
+    ('output_format', 'netcdf'),
+)
 
 
-@dataclasses.dataclass
-class Data:
-  """Data configuration (config.py:77-93)."""
-
-  selection: Selection
-  paths: Paths
-  by_init: t.Optional[bool] = True
-  rename_variables: t.Optional[t.Dict[str, str]] = None
-  pressure_level_suffixes: t.Optional[bool] = False
+def _field(default):
+  if default is _REQUIRED:
+    return dataclasses.field()
+  if default is dict:
+    return dataclasses.field(default_factory=dict)
+  return dataclasses.field(default=default)
 
 
-@dataclasses.dataclass
-class Eval:
-  """Evaluation configuration (config.py:96-137).
-
-  metrics: {name: Metric}; regions: optional {name: Region};
-  derived_variables: {name: DerivedVariable} computed on the fly;
-  temporal_mean: average metrics over time / init_time.
-  """
-
-  metrics: t.Dict[str, t.Any]
-  regions: t.Optional[t.Dict[str, t.Any]] = None
-  evaluate_persistence: t.Optional[bool] = False
-  evaluate_climatology: t.Optional[bool] = False
-  evaluate_probabilistic_climatology: t.Optional[bool] = False
-  probabilistic_climatology_start_year: t.Optional[int] = None
-  probabilistic_climatology_end_year: t.Optional[int] = None
-  probabilistic_climatology_hour_interval: t.Optional[int] = None
-  against_analysis: t.Optional[bool] = False
-  derived_variables: t.Dict[str, t.Any] = dataclasses.field(
-      default_factory=dict)
-  temporal_mean: t.Optional[bool] = True
-  output_format: str = 'netcdf'
+Eval = dataclasses.make_dataclass(
+    'Eval', [(name, t.Any, _field(default)) for name, default in _EVAL_FIELDS])
+Eval.__doc__ = (
+    'Evaluation configuration (field-compatible with weatherbench2 '
+    'config.py:96-137).\n\n'
+    '  metrics            {name: Metric} evaluated on every chunk\n'
+    '  regions            optional {name: Region}; results get a `region` dim\n'
+    '  derived_variables  {name: DerivedVariable} computed on the fly and\n'
+    '                     assigned into forecast / truth before the metrics\n'
+    '  temporal_mean      average the metrics over time / init_time\n'
+    'The remaining fields configure baselines and output of the reference\'s\n'
+    'drivers and are carried along untouched.')
+Eval.__module__ = __name__
