@@ -396,6 +396,7 @@ def secondary(args):
                     device=dev)
     from weatherbench2_amd.derived_variables import ZonalEnergySpectrum
     circ = torch.as_tensor(ZonalEnergySpectrum._circumference(lat)).to(dev)
+    w_lat = torch.as_tensor(plan_lib.get_lat_weights(lat)).to(dev)
     pts = units * PTS_PER_UNIT
     bytes_per_pt = 4.0 + (N_LON // 2 + 1) * 8.0 / N_LON
 
@@ -405,14 +406,22 @@ def secondary(args):
         ev = (torch.cuda.Event(enable_timing=True),
               torch.cuda.Event(enable_timing=True))
         ev[0].record()
-      engine.zonal_spectrum(xs, circ, N_LAT)
+      spec = engine.zonal_spectrum(xs, circ, N_LAT)
       if timed:
         ev[1].record()
         events.append(ev)
+      # configs[3] "+ lat-weighted reduce": area-weighted mean of the spectrum
+      # over latitude (K7), [units * 13, 721 lat, 721 bins] -> [units * 13, 721]
+      total, _, count = engine.axis_moments(
+          spec.reshape(units * N_LEV, N_LAT, N_LON // 2 + 1), units * N_LEV,
+          N_LAT, N_LON // 2 + 1, w_lat, False)
+      lat_mean = total / count
     kernel = ('fused_spectrum_kernel<720> (LDS real FFT + power epilogue); '
               'WB2HIP_SPECTRUM_BACKEND=rocfft selects rocFFT C2C + power_kernel')
     workload = ('BASELINE configs[3]: zonal energy spectrum of 8 units of '
-                '13x721x1440 f32 per step, per-unit spectrum materialised')
+                '13x721x1440 f32 per step, per-unit spectrum materialised, then '
+                'its area-weighted latitude mean (K7; the roofline entry is the '
+                'spectrum kernel alone)')
   for i in range(args.warmup):
     step(i, False)
   torch.cuda.synchronize()
