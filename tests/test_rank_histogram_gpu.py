@@ -252,3 +252,32 @@ def test_repeated_entries_get_random_bin(ensemble_size, cutoff_below):
   rtol = 5 * (num_bins - 1) / np.sqrt(sample_size)
   np.testing.assert_allclose(v.reshape(-1, num_bins).mean(0), 1 / num_bins,
                              rtol=rtol)
+
+
+@pytest.mark.gpu
+def test_rank_histogram_c_abi_edge_shapes():
+  """n_point not a multiple of the wave size, more bins than lanes, one
+  member, float64 -- straight through engine.rank_histogram."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda', 0)
+  gen = torch.Generator(device=dev).manual_seed(2)
+  for dtype in (torch.float32, torch.float64):
+    for n_member, n_bins, n_outer, n_point in [(1, 2, 1, 1), (3, 4, 2, 65),
+                                               (7, 2, 3, 130), (99, 100, 1, 77),
+                                               (127, 64, 2, 64)]:
+      ens = torch.randn((n_member, n_outer, n_point), device=dev, dtype=dtype,
+                        generator=gen)
+      truth = torch.randn((n_outer, n_point), device=dev, dtype=dtype,
+                          generator=gen)
+      out = engine.rank_histogram(ens, n_outer * n_point, n_member, None,
+                                  truth, None, n_outer, n_point, n_bins, True, 5)
+      rank = (ens < truth[None]).sum(0) // ((n_member + 1) // n_bins)
+      want = torch.nn.functional.one_hot(rank, n_bins).double()
+      torch.testing.assert_close(out, want, rtol=0, atol=0)
+      # accumulate mode over the outer axis
+      rows = torch.zeros((n_outer,), dtype=torch.int64, device=dev)
+      acc = engine.rank_histogram(ens, n_outer * n_point, n_member, None,
+                                  truth, None, n_outer, n_point, n_bins, True,
+                                  5, rows, 1)
+      torch.testing.assert_close(acc[0], want.sum(0), rtol=0, atol=0)

@@ -165,3 +165,48 @@ def test_quarter_degree_field_means_split_the_reduced_axis():
   assert m.data.dtype == torch.float32
   torch.testing.assert_close(m.data, ens.double().mean(0).float(), rtol=1e-6,
                              atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_axis_moments_edge_shapes():
+  """Ragged sizes through the C ABI: unaligned views, tails that are not a
+  multiple of the vector width, single-element axes, float64, empty reduce."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda', 0)
+  gen = torch.Generator(device=dev).manual_seed(3)
+  for dtype in (torch.float32, torch.float64):
+    for n_lead, n_red, n_tail in [(1, 1, 1), (3, 7, 1), (2, 5, 3), (1, 129, 67),
+                                  (5, 4099, 1), (2, 33, 1026), (1, 1, 4096)]:
+      big = torch.randn((n_lead * n_red * n_tail + 1,), device=dev, dtype=dtype,
+                        generator=gen)
+      for off in (0, 1):  # off = 1: not 16-byte aligned -> scalar loads
+        x = big[off:off + n_lead * n_red * n_tail]
+        x = x.clone() if off == 0 else x
+        xs = x.reshape(n_lead, n_red, n_tail)
+        xs_nan = xs.clone()
+        xs_nan[..., ::3, :] = float('nan') if n_red > 2 else xs_nan[..., ::3, :]
+        w = torch.rand((n_red,), device=dev, dtype=torch.float64,
+                       generator=gen)
+        for data, skipna in ((xs, False), (xs_nan, True)):
+          flat = data.reshape(-1)
+          if off == 1:  # keep the misaligned storage
+            big[1:1 + flat.numel()] = flat
+            flat = big[1:1 + flat.numel()]
+          s, q, c = engine.axis_moments(flat, n_lead, n_red, n_tail, w, skipna,
+                                        True)
+          d = data.double()
+          ok = ~torch.isnan(d) if skipna else torch.ones_like(d, dtype=torch.bool)
+          z = torch.where(ok, d, torch.zeros_like(d))
+          ws = w[None, :, None]
+          torch.testing.assert_close(s.reshape(n_lead, n_tail), (z * ws).sum(1),
+                                     rtol=1e-12, atol=1e-12)
+          z2 = torch.where(ok, (data * data).double(), torch.zeros_like(d))
+          torch.testing.assert_close(q.reshape(n_lead, n_tail), (z2 * ws).sum(1),
+                                     rtol=1e-12, atol=1e-12)
+          torch.testing.assert_close(c.reshape(n_lead, n_tail),
+                                     ok.double().sum(1), rtol=0, atol=0)
+  # nothing to reduce: sums 0, counts 0 (mean = NaN like an empty xarray mean)
+  empty = torch.empty((0,), device=dev)
+  s, _, c = engine.axis_moments(empty, 4, 0, 1, None, True)
+  assert float(s.abs().sum()) == 0.0 and float(c.sum()) == 0.0
