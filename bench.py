@@ -141,10 +141,13 @@ def main():
                        'pinned host memory (reported as pcie_inclusive, never '
                        'as value)')
   ap.add_argument('--workload', default='deterministic',
-                  choices=['deterministic', 'ensemble', 'spectrum'],
+                  choices=['deterministic', 'ensemble', 'spectrum',
+                           'spectrum_mean'],
                   help='deterministic = BASELINE configs[1] (the headline '
-                       'metric); ensemble / spectrum = configs[2] / [3], used '
-                       'for profiles/ and DESIGN.md')
+                       'metric); ensemble / spectrum = configs[2] / [3], '
+                       'spectrum_mean = the time-mean pipeline of the spectrum '
+                       'script with the mean fused; used for profiles/ and '
+                       'DESIGN.md')
   ap.add_argument('--members', type=int, default=50)
   args = ap.parse_args()
   if args.workload != 'deterministic':
@@ -399,6 +402,8 @@ def secondary(args):
     w_lat = torch.as_tensor(plan_lib.get_lat_weights(lat)).to(dev)
     pts = units * PTS_PER_UNIT
     bytes_per_pt = 4.0 + (N_LON // 2 + 1) * 8.0 / N_LON
+    if args.workload == 'spectrum_mean':
+      bytes_per_pt = 4.0 + (N_LON // 2 + 1) * 8.0 / N_LON / units
 
     def step(i, timed):
       xs = x[(i % pool) * units:(i % pool + 1) * units]
@@ -406,6 +411,14 @@ def secondary(args):
         ev = (torch.cuda.Event(enable_timing=True),
               torch.cuda.Event(enable_timing=True))
         ev[0].record()
+      if args.workload == 'spectrum_mean':
+        # the script's pipeline (compute_zonal_energy_spectrum.py:234): the
+        # time mean of the spectrum, fused -- the 8 units act as 8 times
+        engine.zonal_spectrum(xs, circ, N_LAT, n_time=units)
+        if timed:
+          ev[1].record()
+          events.append(ev)
+        return
       spec = engine.zonal_spectrum(xs, circ, N_LAT)
       if timed:
         ev[1].record()
@@ -416,7 +429,9 @@ def secondary(args):
           spec.reshape(units * N_LEV, N_LAT, N_LON // 2 + 1), units * N_LEV,
           N_LAT, N_LON // 2 + 1, w_lat, False)
       lat_mean = total / count
-    kernel = ('fused_spectrum_kernel<720> (LDS real FFT + power epilogue); '
+    kernel = ('fused_spectrum_kernel<720,TIME> (LDS real FFT, time mean in '
+              'registers)' if args.workload == 'spectrum_mean' else
+              'fused_spectrum_kernel<720> (LDS real FFT + power epilogue); '
               'WB2HIP_SPECTRUM_BACKEND=rocfft selects rocFFT C2C + power_kernel')
     workload = ('BASELINE configs[3]: zonal energy spectrum of 8 units of '
                 '13x721x1440 f32 per step, per-unit spectrum materialised, then '

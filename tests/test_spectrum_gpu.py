@@ -129,6 +129,32 @@ def test_fused_time_mean(dv):
   np.testing.assert_allclose(fused.values, per_time.mean(axis=0), rtol=1e-12)
 
 
+@pytest.mark.parametrize('n_lon', [64, 256, 1440])
+@pytest.mark.parametrize('skipna', [True, False])
+def test_fused_kernel_time_mean(n_lon, skipna):
+  """The LDS-FFT kernel with the time mean fused (sums in registers, one store
+  per output row) == the mean of the per-time spectra it writes otherwise,
+  incl. NaN rows with and without skipna."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda')
+  gen = torch.Generator(device=dev).manual_seed(n_lon)
+  n_time, n_lev, n_lat = 5, 3, 7
+  x = torch.randn((n_time, n_lev, n_lat, n_lon), generator=gen, device=dev)
+  x[1, 0, 2, 5] = float('nan')     # one NaN poisons that row's spectrum
+  x[3, 2, :, :] = float('nan')     # a whole level at one time
+  x[:, 1, 4, 0] = float('nan')     # a row that is NaN at every time
+  lat = np.linspace(-75, 75, n_lat)
+  circ = torch.as_tensor(spectrum_np.circumference(lat)).to(dev)
+  per_time = engine.zonal_spectrum(x, circ, n_lat)
+  fused = engine.zonal_spectrum(x, circ, n_lat, n_time=n_time, skipna=skipna)
+  assert fused.shape == (n_lev, n_lat, n_lon // 2 + 1)
+  want = (torch.nanmean(per_time, dim=0) if skipna else per_time.mean(0))
+  torch.testing.assert_close(fused, want, rtol=1e-12, atol=0, equal_nan=True)
+  assert torch.isnan(fused[1, 4]).all()
+  assert torch.isnan(fused[0, 2]).all() != skipna
+
+
 def test_full_size_unit_parseval_and_determinism():
   """BASELINE config 4: 13 x 721 x 1440 float32."""
   import torch

@@ -34,8 +34,8 @@ namespace wb2 {
 bool fused_spectrum_supported(int dtype, int n_lon);
 size_t fused_spectrum_table_bytes(int n_lon);
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
-                       const double* circ, int n_lat, double* out, void* tables,
-                       hipStream_t s);
+                       const double* circ, int n_lat, long long n_time,
+                       int skipna, double* out, void* tables, hipStream_t s);
 
 namespace {
 
@@ -257,9 +257,9 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   void* spec = ws;
   void* fft_work = ws + align_up(p->complex_bytes);
   void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
-  if (p->fused && n_time == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+  if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0)
     return fused_spectrum_run(static_cast<const float*>(x), p->n_rows, p->n_lon,
-                              circumference, n_lat, out, tw, s);
+                              circumference, n_lat, n_time, skipna, out, tw, s);
   hipfftResult rc = hipfftSetStream(p->fft, s);
   if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
     rc = hipfftSetWorkArea(p->fft, fft_work);

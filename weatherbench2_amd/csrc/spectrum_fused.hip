@@ -29,6 +29,9 @@
 #ifndef WB2_FFT_TW_GLOBAL
 #define WB2_FFT_TW_GLOBAL 0   // 1: read the pass twiddles from global/L1, not LDS
 #endif
+#ifndef WB2_FFT_FIRST_FROM_GLOBAL
+#define WB2_FFT_FIRST_FROM_GLOBAL 1  // 0: stage the row in LDS, then all passes
+#endif
 
 namespace wb2 {
 namespace fused {
@@ -193,15 +196,23 @@ struct FusedParams {
   const cf* twn;   // [N2/2+1]  exp(-2 pi i k / N)
   const double* circ;
   double* out;
-  long long n_rows;
+  long long n_rows;   // input rows
+  long long n_time;   // TIME: input rows are [n_time][n_rows / n_time]
   int n_lat;
+  int skipna;
 };
 
-template <int N2>
+// TIME: the mean over the leading time axis is fused (the time mean of
+// scripts/compute_zonal_energy_spectrum.py:234): a wave owns one OUTPUT row,
+// transforms its n_time input rows in time order with the bin powers summed in
+// registers (fp64, NaN spectra skipped with skipna like xbeam.Mean) and stores
+// the mean once -- 4 B read per grid point and almost nothing written.
+template <int N2, bool TIME>
 __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     fused_spectrum_kernel(const FusedParams p) {
   constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = 4;
   constexpr int NH = N2 / 2 + 1;  // bin pairs (k, N2 - k), k = 0..N2/2
+  constexpr int NIT = (NH + kWave - 1) / kWave;
   __shared__ cf s_twz[N2];
   __shared__ cf s_twn[NH];
   __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][N2];
@@ -213,8 +224,71 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   cf* z = s_z[wave];
   const float inv_n = 1.0f / (float)N;
   const long long stride = (long long)gridDim.x * NWAVE;
-  for (long long row = (long long)blockIdx.x * NWAVE + wave; row < p.n_rows;
-       row += stride) {
+  const long long nt = TIME ? p.n_time : 1;
+  const long long rows_out = p.n_rows / nt;
+  for (long long orow_i = (long long)blockIdx.x * NWAVE + wave;
+       orow_i < rows_out; orow_i += stride) {
+   double sum1[NIT], sum2[NIT];
+   int cnt1[NIT], cnt2[NIT];
+#pragma unroll
+   for (int i = 0; i < NIT; ++i) {
+     sum1[i] = sum2[i] = 0.0;
+     cnt1[i] = cnt2[i] = 0;
+   }
+   const double c = p.circ[(unsigned)(orow_i % p.n_lat)];
+   double* orow = p.out + orow_i * NB;
+   for (long long t = 0; t < nt; ++t) {
+    const long long row = t * rows_out + orow_i;
+#ifndef WB2_FFT_DIAG
+#define WB2_FFT_DIAG 0  // 1: skip the FFT passes, 2: skip the epilogue stores
+#endif
+#if WB2_FFT_FIRST_FROM_GLOBAL && WB2_FFT_DIAG != 1 && !WB2_FFT_TW_GLOBAL
+    // ---- first pass straight from HBM: every lane fetches the R inputs of its
+    // butterflies itself (8-byte loads, consecutive lanes = consecutive complex
+    // points), transforms them and writes the R outputs as ONE contiguous run:
+    // no staging copy of the row in LDS, no strided (bank-conflicting) writes of
+    // the NS = 1 pass.
+    {
+      constexpr int R = pick_radix(N2);
+      constexpr int T = N2 / R;
+      constexpr int ROUNDS = (T + kWave - 1) / kWave;
+      const cf* src = reinterpret_cast<const cf*>(p.x + row * N);
+      cf v[ROUNDS][R];
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int j = lane + rd * kWave;
+        if (j < T) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            v[rd][r] = __builtin_nontemporal_load(src + j + r * T);
+        }
+      }
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int j = lane + rd * kWave;
+        if (j < T) {
+          butterfly<R>(v[rd]);
+          if constexpr (R % 2 == 0) {
+            f4* dst = reinterpret_cast<f4*>(z + j * R);
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+              f4 w;
+              w.x = v[rd][2 * h].x;
+              w.y = v[rd][2 * h].y;
+              w.z = v[rd][2 * h + 1].x;
+              w.w = v[rd][2 * h + 1].y;
+              dst[h] = w;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) z[j * R + r] = v[rd][r];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      stockham_all<N2, R>(z, s_twz, lane);
+    }
+#else
     // ---- load: 16-byte nontemporal loads, two complex points per lane ----
     const f4* src = reinterpret_cast<const f4*>(p.x + row * N);
     f4* zq = reinterpret_cast<f4*>(z);
@@ -232,9 +306,6 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifndef WB2_FFT_DIAG
-#define WB2_FFT_DIAG 0  // 1: skip the FFT passes, 2: skip the epilogue stores
-#endif
 #if WB2_FFT_DIAG != 1
 #if WB2_FFT_TW_GLOBAL
     stockham_all<N2, 1>(z, p.twz, lane);
@@ -242,11 +313,10 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     stockham_all<N2, 1>(z, s_twz, lane);
 #endif
 #endif
+#endif
     // ---- recombination + power for the bin pairs (k, N2 - k) ----
-    const double c = p.circ[(unsigned)(row % p.n_lat)];
-    double* orow = p.out + row * NB;
 #pragma unroll
-    for (int i = 0; i < (NH + kWave - 1) / kWave; ++i) {
+    for (int i = 0; i < NIT; ++i) {
       const int k = lane + i * kWave;
       if (k < NH) {
         const cf a = z[k];
@@ -262,17 +332,39 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
         const float p1 = x1.x * x1.x + x1.y * x1.y;
         const float p2 = x2.x * x2.x + x2.y * x2.y;
         // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
+        const double v1 = ((double)p1 * (k == 0 ? 1.0 : 2.0)) * c;
+        const double v2 = ((double)p2 * 2.0) * c;
+        if constexpr (TIME) {
+          const bool k1 = !(p.skipna && is_nan(v1));
+          const bool k2 = !(p.skipna && is_nan(v2));
+          sum1[i] += k1 ? v1 : 0.0;
+          sum2[i] += k2 ? v2 : 0.0;
+          cnt1[i] += k1 ? 1 : 0;
+          cnt2[i] += k2 ? 1 : 0;
+        } else {
 #if WB2_FFT_DIAG == 2
-        if (p1 + p2 == 1.2345f) orow[k] = p1;
+          if (p1 + p2 == 1.2345f) orow[k] = p1;
 #else
-        __builtin_nontemporal_store(((double)p1 * (k == 0 ? 1.0 : 2.0)) * c,
-                                    orow + k);
-        if (2 * k != N2)
-          __builtin_nontemporal_store(((double)p2 * 2.0) * c, orow + N2 - k);
+          __builtin_nontemporal_store(v1, orow + k);
+          if (2 * k != N2) __builtin_nontemporal_store(v2, orow + N2 - k);
 #endif
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+   }  // time
+   if constexpr (TIME) {
+#pragma unroll
+     for (int i = 0; i < NIT; ++i) {
+       const int k = lane + i * kWave;
+       if (k < NH) {
+         __builtin_nontemporal_store(sum1[i] / (double)cnt1[i], orow + k);
+         if (2 * k != N2)
+           __builtin_nontemporal_store(sum2[i] / (double)cnt2[i],
+                                       orow + N2 - k);
+       }
+     }
+   }
   }
 }
 
@@ -293,10 +385,15 @@ __global__ void fused_twiddle_kernel(cf* twz, cf* twn, int n2) {
 
 template <int N2>
 int launch(const FusedParams& p, hipStream_t s) {
-  long long blocks = (p.n_rows + 3) / 4;
+  const long long rows_out = p.n_time > 0 ? p.n_rows / p.n_time : p.n_rows;
+  long long blocks = (rows_out + 3) / 4;
   if (blocks > 2048) blocks = 2048;  // row-strided waves beyond that
-  hipLaunchKernelGGL((fused_spectrum_kernel<N2>), dim3((unsigned)blocks),
-                     dim3(256), 0, s, p);
+  if (p.n_time > 0)
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, true>),
+                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, false>),
+                       dim3((unsigned)blocks), dim3(256), 0, s, p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -319,15 +416,15 @@ size_t fused_spectrum_table_bytes(int n_lon) {
 }
 
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
-                       const double* circ, int n_lat, double* out,
-                       void* tables, hipStream_t s) {
+                       const double* circ, int n_lat, long long n_time,
+                       int skipna, double* out, void* tables, hipStream_t s) {
   using namespace fused;
   const int n2 = n_lon / 2;
   cf* twz = static_cast<cf*>(tables);
   cf* twn = twz + n2;
   hipLaunchKernelGGL(fused_twiddle_kernel, dim3((unsigned)((n2 + 255) / 256)),
                      dim3(256), 0, s, twz, twn, n2);
-  FusedParams p{x, twz, twn, circ, out, n_rows, n_lat};
+  FusedParams p{x, twz, twn, circ, out, n_rows, n_time, n_lat, skipna};
   switch (n2) {
 #define WB2_CASE(N2) case N2: return launch<N2>(p, s);
     WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
