@@ -461,7 +461,7 @@ def secondary(args):
                    'traffic': (measured_traffic('ensemble', slabs_per_launch=13,
                                                 members=args.members)
                                if args.workload == 'ensemble' else
-                               measured_traffic('spectrum',
+                               measured_traffic(args.workload,
                                                 units_per_launch=8))}}))
 
 

@@ -13,5 +13,8 @@ for w in deterministic ensemble spectrum; do
 done
 timeout 200 python bench.py --workload ensemble --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_ens.json
 timeout 200 python bench.py --workload spectrum --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_spec.json
+timeout 200 python bench.py --workload spectrum_mean --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_spec_mean.json
+timeout 300 python bench.py --pcie 2>/dev/null | tail -1 > gpurun_out/bench_det.json
+timeout 200 python tools/api_throughput.py 2>&1 | grep -v amdgpu | head -5 > gpurun_out/api_throughput.txt
 timeout 200 python tools/axis_bench.py 2>&1 | grep -v amdgpu > gpurun_out/axis_bench.txt
-cat gpurun_out/bench_ens.json | cut -c1-200; cat gpurun_out/bench_spec.json | cut -c1-200; cat gpurun_out/axis_bench.txt
+cat gpurun_out/bench_det.json | cut -c1-300; cat gpurun_out/api_throughput.txt; cat gpurun_out/bench_spec_mean.json | cut -c1-200; cat gpurun_out/bench_ens.json | cut -c1-200; cat gpurun_out/bench_spec.json | cut -c1-200; cat gpurun_out/axis_bench.txt
