@@ -75,6 +75,21 @@ def measured_traffic(workload: str, **match):
   return None
 
 
+def ramp(step_fn, ms: float) -> None:
+  """Untimed clock ramp: the same step, repeated until `ms` of wall time have
+  passed (synchronising every few steps), before the W warmup steps.  The timed
+  region of a default run lasts ~0.1 s, a 20-step one ~10 ms -- far too short to
+  pull an idle MI355X out of its low-power clocks on its own."""
+  import torch
+  if ms <= 0:
+    return
+  t0 = time.perf_counter()
+  while (time.perf_counter() - t0) * 1e3 < ms:
+    for _ in range(8):
+      step_fn()
+    torch.cuda.synchronize()
+
+
 def cpu_baseline(seconds: float = 10.0, processes: int = 0) -> dict:
   """Times the NumPy oracle (the restated reference path: one metric x one
   region at a time, like evaluation.py:408-435) on this box's host cores:
@@ -127,8 +142,13 @@ def cpu_baseline(seconds: float = 10.0, processes: int = 0) -> dict:
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--ramp-ms', type=float, default=60.0,
+                  help='before the W warmup steps, keep running the same step '
+                       'untimed for this long so that the GPU has left its idle '
+                       'clocks (a 20-step timed region is only ~10 ms; measured: '
+                       '+7 %% throughput once ramped); 0 disables')
   ap.add_argument('--units', type=int, default=16,
                   help='(init, lead) units per step and per GPU')
   ap.add_argument('--pool', type=int, default=48,
@@ -231,6 +251,7 @@ def main():
     engine.time_accumulate(metrics.view(_lib.NMETRIC * nr, units, N_LEV), 1,
                            False, total, count)
 
+  ramp(lambda: step(0, False), args.ramp_ms)
   for i in range(args.warmup):
     step(i, False)
   # Touch every op of the timed region once: on a cold box the first use of a
@@ -437,6 +458,7 @@ def secondary(args):
                 '13x721x1440 f32 per step, per-unit spectrum materialised, then '
                 'its area-weighted latitude mean (K7; the roofline entry is the '
                 'spectrum kernel alone)')
+  ramp(lambda: step(0, False), args.ramp_ms)
   for i in range(args.warmup):
     step(i, False)
   torch.cuda.synchronize()

@@ -6,7 +6,7 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 export TMPDIR=/tmp
 for w in deterministic ensemble spectrum; do
   extra=""; [ $w != deterministic ] && extra="--workload $w"
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$w -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline $extra > $GRAFT_REPO_ROOT/gpurun_out/prof_$w.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$w -o run -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $extra > $GRAFT_REPO_ROOT/gpurun_out/prof_$w.log 2>&1)
   f=$(find gpurun_out/prof_$w -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f" > gpurun_out/stats_$w.csv
   tail -1 gpurun_out/prof_$w.log | cut -c1-300
   rm -rf gpurun_out/prof_$w

@@ -33,6 +33,7 @@ namespace wb2 {
 // spectrum_fused.hip: single-kernel path (LDS FFT + fused epilogue)
 bool fused_spectrum_supported(int dtype, int n_lon);
 size_t fused_spectrum_table_bytes(int n_lon);
+int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s);
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
                        int skipna, double* out, void* tables, hipStream_t s);
@@ -48,6 +49,7 @@ struct SpectrumPlan {
   size_t fft_work_bytes = 0;
   bool packed = false;       // even n_lon: C2C on n_lon/2 points + own recombination
   bool fused = false;        // spectrum_fused.hip handles (dtype, n_lon)
+  void* tables = nullptr;    // fused path: twiddle tables, owned by the plan
 };
 
 // native 2-vectors (re, im): accepted by the nontemporal builtins
@@ -216,6 +218,20 @@ int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
   const char* backend = std::getenv("WB2HIP_SPECTRUM_BACKEND");
   p->fused = fused_spectrum_supported(dtype, n_lon) &&
              !(backend && std::strcmp(backend, "rocfft") == 0);
+  if (p->fused) {
+    // the twiddle tables are generated once, here (device of the calling
+    // thread), instead of by an extra kernel in front of every transform
+    hipError_t e = hipMalloc(&p->tables, fused_spectrum_table_bytes(n_lon));
+    if (e == hipSuccess && fused_spectrum_tables(p->tables, n_lon, nullptr) != 0)
+      e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      if (p->tables) (void)hipFree(p->tables);
+      hipfftDestroy(p->fft);
+      delete p;
+      return fail("twiddle table setup failed: %s", hipGetErrorString(e));
+    }
+  }
   *plan_out = p;
   return 0;
 }
@@ -224,6 +240,7 @@ int wb2_spectrum_plan_destroy(void* plan) {
   auto* p = static_cast<wb2::SpectrumPlan*>(plan);
   if (!p) return 0;
   hipfftDestroy(p->fft);
+  if (p->tables) (void)hipFree(p->tables);
   delete p;
   return 0;
 }
@@ -259,7 +276,8 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
   if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0)
     return fused_spectrum_run(static_cast<const float*>(x), p->n_rows, p->n_lon,
-                              circumference, n_lat, n_time, skipna, out, tw, s);
+                              circumference, n_lat, n_time, skipna, out,
+                              p->tables, s);
   hipfftResult rc = hipfftSetStream(p->fft, s);
   if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
     rc = hipfftSetWorkArea(p->fft, fft_work);

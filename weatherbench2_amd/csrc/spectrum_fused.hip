@@ -415,15 +415,25 @@ size_t fused_spectrum_table_bytes(int n_lon) {
   return (size_t)(n_lon / 2 + n_lon / 4 + 1) * sizeof(fused::cf);
 }
 
+// Fills the two twiddle tables (fused_spectrum_table_bytes(n_lon) bytes at
+// `tables`); the plan does this once at creation and owns the memory.
+int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s) {
+  using namespace fused;
+  const int n2 = n_lon / 2;
+  cf* twz = static_cast<cf*>(tables);
+  hipLaunchKernelGGL(fused_twiddle_kernel, dim3((unsigned)((n2 + 255) / 256)),
+                     dim3(256), 0, s, twz, twz + n2, n2);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
                        int skipna, double* out, void* tables, hipStream_t s) {
   using namespace fused;
   const int n2 = n_lon / 2;
-  cf* twz = static_cast<cf*>(tables);
+  cf* twz = static_cast<cf*>(tables);  // filled once by fused_spectrum_tables
   cf* twn = twz + n2;
-  hipLaunchKernelGGL(fused_twiddle_kernel, dim3((unsigned)((n2 + 255) / 256)),
-                     dim3(256), 0, s, twz, twn, n2);
   FusedParams p{x, twz, twn, circ, out, n_rows, n_time, n_lat, skipna};
   switch (n2) {
 #define WB2_CASE(N2) case N2: return launch<N2>(p, s);
