@@ -76,18 +76,24 @@ def measured_traffic(workload: str, **match):
 
 
 def ramp(step_fn, ms: float) -> None:
-  """Untimed clock ramp: the same step, repeated until `ms` of wall time have
-  passed (synchronising every few steps), before the W warmup steps.  The timed
-  region of a default run lasts ~0.1 s, a 20-step one ~10 ms -- far too short to
-  pull an idle MI355X out of its low-power clocks on its own."""
+  """Untimed clock ramp: the same step, enqueued back to back for `ms` of wall
+  time before the W warmup steps, WITHOUT draining the queue (the host only
+  waits for events a few batches behind).  A per-launch trace shows why: after
+  any idle gap the kernels run 5-8 % slower for ~15 ms, and a 20-step timed
+  region lasts ~10 ms."""
   import torch
   if ms <= 0:
     return
   t0 = time.perf_counter()
+  pending = []
   while (time.perf_counter() - t0) * 1e3 < ms:
     for _ in range(8):
       step_fn()
-    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    ev.record()
+    pending.append(ev)
+    if len(pending) > 4:  # stay <= 32 steps ahead of the GPU
+      pending.pop(0).synchronize()
 
 
 def cpu_baseline(seconds: float = 10.0, processes: int = 0) -> dict:
@@ -251,15 +257,18 @@ def main():
     engine.time_accumulate(metrics.view(_lib.NMETRIC * nr, units, N_LEV), 1,
                            False, total, count)
 
-  ramp(lambda: step(0, False), args.ramp_ms)
-  for i in range(args.warmup):
-    step(i, False)
   # Touch every op of the timed region once: on a cold box the first use of a
   # torch kernel (the final division, the all-reduce) loads its code object,
   # which costs tens of ms and is not part of the hot path.
+  step(0, False)
   _ = (total / count).sum().item()
   if world > 1:
     all_reduce(torch.stack([total, count]))
+  # From here to the timed region the GPU never runs dry: ramp and warmup are
+  # enqueued back to back and the only wait is the contract's synchronize.
+  ramp(lambda: step(0, False), args.ramp_ms)
+  for i in range(args.warmup):
+    step(i, False)
   total.zero_()
   count.zero_()
   torch.cuda.synchronize()
@@ -289,6 +298,8 @@ def main():
   assert torch.isfinite(mean).all()
 
   k1_ms = [a.elapsed_time(b) for a, b in k1_events]
+  if os.environ.get('WB2_BENCH_TRACE'):  # per-launch durations (diagnostics)
+    print('k1_ms', ' '.join(f'{x:.3f}' for x in k1_ms), file=sys.stderr)
   k1_avg_s = float(np.mean(k1_ms)) / 1e3
   pts_step = units * PTS_PER_UNIT
   achieved = pts_step * BYTES_PER_PT / k1_avg_s / 1e9
