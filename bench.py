@@ -399,7 +399,8 @@ def secondary(args):
     n_slab = 13            # one unit of 13 levels per step
     pool = 4               # 4 x 13 x 50 x 4.15 MB = 10.8 GB >> Infinity Cache
     pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(),
-                             dev, rows_per_chunk=args.rows_per_chunk or 16)
+                             dev, rows_per_chunk=(args.rows_per_chunk or
+                                                  plan_lib.ENSEMBLE_ROWS_PER_CHUNK))
     ens = torch.randn((m, pool * n_slab, N_LAT, N_LON), generator=gen,
                       device=dev)
     truth = torch.randn((pool * n_slab, N_LAT, N_LON), generator=gen,

@@ -891,10 +891,9 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
       _ens_layout(forecast, fvar, tvar, ensemble_dim))
   out_shape = geo.out_shape
   regions, _ = _region_set_for(region)
-  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
   pl = plan_lib.cached_plan(
       geo.latitude, geo.longitude, geo.layout, regions, device,
-      plan_lib.auto_rows_per_chunk(n_row, geo.n_outer))
+      plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
   slab_elems = pl.n_row * pl.n_col
   maps = (torch.empty((6, geo.n_outer, slab_elems), dtype=torch.float64,
                       device=device) if want_maps else None)
@@ -1443,10 +1442,8 @@ def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
   geo, tens, tables, member_slabs, n_member, device = _ens_threshold_layout(
       forecast, truth, threshold_ds, name, ensemble_dim)
   regions, _ = _region_set_for(region)
-  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
   pl = plan_lib.cached_plan(geo.latitude, geo.longitude, geo.layout, regions,
-                            device, plan_lib.auto_rows_per_chunk(n_row,
-                                                                 geo.n_outer))
+                            device, plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
   slab_elems = pl.n_row * pl.n_col
   metrics = engine.ensemble_threshold_reduce(
       pl, tens[0], member_slabs * slab_elems, n_member, tables[0],

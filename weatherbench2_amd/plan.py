@@ -33,8 +33,13 @@ LONLAT = 'lonlat'  # slabs are (longitude, latitude): rows = longitude
 DEFAULT_ROWS_PER_CHUNK = 16
 
 
+ENSEMBLE_ROWS_PER_CHUNK = 8  # K3 (VALU-bound, 64 columns per wave): measured
+                             # 4.96 TB/s at 4-8 rows, 4.59 at 16, 4.07 at 32
+
+
 def auto_rows_per_chunk(n_row: int, n_outer: int) -> int:
-  """Rows per workgroup-chunk for a launch of `n_outer` slabs.
+  """Rows per workgroup-chunk of the streaming kernel K1 for a launch of
+  `n_outer` slabs (the ensemble kernels use ENSEMBLE_ROWS_PER_CHUNK).
 
   Measured on MI355X (profiles/r01_rows_per_chunk.md): 24-32 rows per chunk
   is best once the launch has thousands of workgroups (bigger chunks amortise
