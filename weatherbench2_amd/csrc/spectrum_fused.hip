@@ -29,6 +29,9 @@
 #ifndef WB2_FFT_TW_GLOBAL
 #define WB2_FFT_TW_GLOBAL 0   // 1: read the pass twiddles from global/L1, not LDS
 #endif
+#ifndef WB2_FFT_MAX_BLOCKS
+#define WB2_FFT_MAX_BLOCKS 2048   // persistent workgroups (4 waves each)
+#endif
 #ifndef WB2_FFT_FIRST_FROM_GLOBAL
 #define WB2_FFT_FIRST_FROM_GLOBAL 1  // 0: stage the row in LDS, then all passes
 #endif
@@ -387,7 +390,7 @@ template <int N2>
 int launch(const FusedParams& p, hipStream_t s) {
   const long long rows_out = p.n_time > 0 ? p.n_rows / p.n_time : p.n_rows;
   long long blocks = (rows_out + 3) / 4;
-  if (blocks > 2048) blocks = 2048;  // row-strided waves beyond that
+  if (blocks > WB2_FFT_MAX_BLOCKS) blocks = WB2_FFT_MAX_BLOCKS;  // row-strided waves beyond that
   if (p.n_time > 0)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, true>),
                        dim3((unsigned)blocks), dim3(256), 0, s, p);
