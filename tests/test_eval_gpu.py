@@ -244,3 +244,28 @@ def test_loop_with_several_land_sea_masks():
                                       skipna=skipna)
         helpers.assert_close(one['geopotential'].values,
                              want['geopotential'].data, rtol=1e-9, atol=1e-12)
+
+
+def test_loop_computes_derived_variables_first():
+  """evaluation.py:402-405: derived variables are computed on the fly and
+  assigned INTO forecast / truth (the reference mutates its arguments too)."""
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      spatial_resolution_in_degrees=10)
+  g = helpers.to_gpu_dataset
+  gf, gt = g(forecast), g(truth)
+
+  class Doubled:  # a user-defined DerivedVariable (duck-typed protocol)
+    base_variables = ['geopotential']
+
+    def compute(self, dataset):
+      return dataset['geopotential'] * 2.0
+
+  cfg = config.Eval(metrics={'mse': gm.MSE()},
+                    derived_variables={'doubled': Doubled()})
+  got = evaluation._metric_and_region_loop(gf, gt, cfg, False,
+                                           compute_chunk=True)
+  assert 'doubled' in gf.keys() and 'doubled' in gt.keys()
+  want = om.MSE().compute_chunk(forecast, truth)['geopotential'].data
+  helpers.assert_close(got['geopotential'].values[0], want, rtol=1e-9)
+  helpers.assert_close(got['doubled'].values[0], 4.0 * want, rtol=1e-9)

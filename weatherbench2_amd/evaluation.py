@@ -42,11 +42,14 @@ def _metric_and_region_loop(
 ) -> xl.Dataset:
   """Compute metric results looping over metrics and regions in eval config."""
   given_forecast, given_truth = forecast, truth
-  forecast = xl.as_dataset(forecast)
-  truth = xl.as_dataset(truth)
+  # Derived variables are computed on what the caller handed in and assigned
+  # into it, like the reference does (:402-405): reference DerivedVariable
+  # objects keep seeing xarray Datasets, ours see either kind.
   for name, dv in eval_config.derived_variables.items():
     forecast[name] = dv.compute(forecast)
     truth[name] = dv.compute(truth)
+  forecast = xl.as_dataset(forecast)
+  truth = xl.as_dataset(truth)
 
   results = []
   regions = eval_config.regions
