@@ -87,3 +87,45 @@ def test_shard_bounds_cover_everything():
       assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
       sizes = [hi - lo for lo, hi in spans]
       assert max(sizes) - min(sizes) <= 1
+
+
+def test_select_truth_at_valid_time_matches_label_lookup():
+  """evaluation.py:474-475 on host arrays (the device path is the same code
+  with torch.index_select; exercised in tests/test_eval_gpu.py)."""
+  import numpy as np
+  import pytest
+  from weatherbench2_amd import evaluation, xarray_lite as xl
+  t0 = np.datetime64('2020-01-01T00', 'ns')
+  time = t0 + np.arange(10) * np.timedelta64(12, 'h')
+  init = time[[0, 2, 3]]
+  lead = np.arange(3) * np.timedelta64(24, 'h')
+  rs = np.random.RandomState(0)
+  truth = xl.Dataset(
+      {'z': xl.DataArray(rs.rand(2, 10, 4, 5), ('level', 'time', 'latitude',
+                                                'longitude')),
+       'orog': xl.DataArray(rs.rand(4, 5), ('latitude', 'longitude'))},
+      {'level': np.array([500, 850]), 'time': time,
+       'latitude': np.linspace(-45, 45, 4), 'longitude': np.arange(5) * 72.0})
+  forecast = xl.Dataset(
+      {'z': xl.DataArray(rs.rand(3, 3, 2, 4, 5),
+                         ('init_time', 'prediction_timedelta', 'level',
+                          'latitude', 'longitude'))},
+      {'init_time': init, 'prediction_timedelta': lead,
+       'level': np.array([500, 850]), 'latitude': truth.coords['latitude'],
+       'longitude': truth.coords['longitude']})
+  got = evaluation.select_truth_at_valid_time(truth, forecast)
+  assert got['z'].dims == ('level', 'init_time', 'prediction_timedelta',
+                           'latitude', 'longitude')
+  assert 'time' not in got.coords and got['orog'].dims == ('latitude',
+                                                           'longitude')
+  for i in range(3):
+    for l in range(3):
+      k = int(np.where(time == init[i] + lead[l])[0][0])
+      np.testing.assert_array_equal(got['z'].values[:, i, l],
+                                    truth['z'].values[:, k])
+  np.testing.assert_array_equal(got.coords['valid_time'].values,
+                                init[:, None] + lead[None, :])
+  late = xl.Dataset(dict(forecast.data_vars),
+                    {**forecast.coords, 'init_time': init + np.timedelta64(9, 'D')})
+  with pytest.raises(KeyError):
+    evaluation.select_truth_at_valid_time(truth, late)

@@ -17,6 +17,9 @@ Mirrors (reference = /root/reference/weatherbench2/evaluation.py):
       (wb2_time_accumulate), combined across ranks with ONE all-reduce -- RCCL
       over xGMI when the process group is NCCL, gloo in the CPU tests.
 
+  truth.sel(time=forecast.valid_time)         :474-475
+      `select_truth_at_valid_time`: the by-init truth gather, on the device.
+
   evaluate_in_memory's per-config driver      :441-517
       `evaluate_chunks`: init-time chunks sharded contiguously over ranks
       (SURVEY.md 8e), one fused pass per chunk, one all-reduce at the end.
@@ -86,6 +89,57 @@ def _metric_and_region_loop(
                 {'metric': [name]})
       results.append(result)
   return xl.like_input(xl.merge(results), given_forecast, given_truth)
+
+
+def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
+                               init_dim: str = 'init_time',
+                               lead_dim: str = 'prediction_timedelta'):
+  """`truth.sel(time=forecast.valid_time)` (evaluation.py:474-475) for a
+  by-init forecast: truth gets the forecast's (init_time, lead) dims.
+
+  The gather runs where the truth lives (one `index_select` on the device for
+  device-resident arrays: a single extra HBM pass over the selected slabs, no
+  host round trip); labels missing from `truth.time` raise KeyError like
+  `.sel`.  Through the engine (`engine.stream_reduce` with slab tables, what
+  bench.py does) the same gather costs nothing at all.
+  """
+  import torch
+  given = (truth, forecast)
+  truth, forecast = xl.as_dataset(truth), xl.as_dataset(forecast)
+  init = np.asarray(forecast.coords[init_dim])
+  lead = np.asarray(forecast.coords[lead_dim])
+  valid = forecast.coords.get('valid_time')
+  if isinstance(valid, xl.DataArray) and set(valid.dims) == {init_dim, lead_dim}:
+    valid = np.asarray(valid.transpose(init_dim, lead_dim).values)
+  else:
+    valid = init[:, None] + lead[None, :]
+  have = np.asarray(truth.coords[time_dim])
+  pos = {v: i for i, v in enumerate(have.tolist())}
+  try:
+    index = np.array([pos[v] for v in valid.ravel().tolist()], dtype=np.int64)
+  except KeyError as e:
+    raise KeyError(f'not all valid times found in truth.{time_dim}: {e}') from e
+  coords = {k: v for k, v in truth.coords.items()
+            if k != time_dim and not (isinstance(v, xl.DataArray)
+                                      and time_dim in v.dims)}
+  coords[init_dim] = init
+  coords[lead_dim] = lead
+  coords['valid_time'] = xl.DataArray(valid, (init_dim, lead_dim))
+  out = xl.Dataset(coords=coords, attrs=dict(truth.attrs))
+  for name, da in truth.data_vars.items():
+    if time_dim not in da.dims:
+      out.data_vars[name] = da
+      continue
+    ax = da.dims.index(time_dim)
+    shape = da.shape[:ax] + valid.shape + da.shape[ax + 1:]
+    if isinstance(da.data, torch.Tensor):
+      idx = torch.as_tensor(index, device=da.data.device)
+      data = torch.index_select(da.data, ax, idx).reshape(shape)
+    else:
+      data = np.take(np.asarray(da.data), index, axis=ax).reshape(shape)
+    dims = da.dims[:ax] + (init_dim, lead_dim) + da.dims[ax + 1:]
+    out.data_vars[name] = xl.DataArray(data, dims, coords, name)
+  return xl.like_input(out, *given)
 
 
 class RunningMean:
