@@ -129,3 +129,20 @@ def test_select_truth_at_valid_time_matches_label_lookup():
                     {**forecast.coords, 'init_time': init + np.timedelta64(9, 'D')})
   with pytest.raises(KeyError):
     evaluation.select_truth_at_valid_time(truth, late)
+
+
+def test_make_latitude_increasing():
+  # evaluation.py:41-47
+  import numpy as np
+  from weatherbench2_amd import evaluation, xarray_lite as xl
+  lat = np.array([60.0, 20.0, -20.0, -60.0])
+  x = np.arange(2 * 4 * 3, dtype=np.float32).reshape(2, 4, 3)
+  ds = xl.Dataset({'z': xl.DataArray(x, ('time', 'latitude', 'longitude')),
+                   's': xl.DataArray(np.ones(2), ('time',))},
+                  {'time': np.arange(2), 'latitude': lat,
+                   'longitude': np.arange(3) * 120.0})
+  out = evaluation.make_latitude_increasing(ds)
+  np.testing.assert_array_equal(out.coords['latitude'], lat[::-1])
+  np.testing.assert_array_equal(out['z'].values, x[:, ::-1])
+  np.testing.assert_array_equal(out['s'].values, np.ones(2))
+  assert evaluation.make_latitude_increasing(out) is out  # already increasing

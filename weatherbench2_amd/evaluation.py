@@ -91,6 +91,31 @@ def _metric_and_region_loop(
   return xl.like_input(xl.merge(results), given_forecast, given_truth)
 
 
+def make_latitude_increasing(dataset):
+  """Flips the latitude axis if it is decreasing (evaluation.py:41-47), where
+  the data lives (`torch.flip` for device arrays): the latitude weights of
+  metrics.py:40-60 require increasing latitudes."""
+  import torch
+  ds = xl.as_dataset(dataset)
+  lat = np.asarray(ds.coords['latitude'])
+  if not (len(lat) > 1 and (np.diff(lat) < 0).all()):
+    return dataset
+  coords = dict(ds.coords)
+  coords['latitude'] = lat[::-1].copy()
+  out = xl.Dataset(coords=coords, attrs=dict(ds.attrs))
+  for name, da in ds.data_vars.items():
+    if 'latitude' not in da.dims:
+      out.data_vars[name] = da
+      continue
+    ax = da.dims.index('latitude')
+    if isinstance(da.data, torch.Tensor):
+      data = torch.flip(da.data, (ax,))
+    else:
+      data = np.flip(np.asarray(da.data), ax)
+    out.data_vars[name] = xl.DataArray(data, da.dims, coords, name)
+  return xl.like_input(out, dataset)
+
+
 def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
                                init_dim: str = 'init_time',
                                lead_dim: str = 'prediction_timedelta'):
