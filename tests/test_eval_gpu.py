@@ -313,3 +313,34 @@ def test_by_init_evaluation_with_device_truth_gather():
     dims = got['z'].dims[1:]
     helpers.assert_close(got['z'].values[mi], want.transpose(*dims).data,
                          rtol=1e-9, atol=1e-12)
+
+
+def test_caches_notice_in_place_updates_of_a_reused_buffer():
+  """A pipeline that refills ONE device buffer per chunk must not get the
+  previous chunk's cached result (the caches key on the tensor's version)."""
+  import torch
+  from weatherbench2_amd import metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  dev = torch.device('cuda', 0)
+  lat, lon = np.linspace(-80, 80, 9), np.arange(16) * 22.5
+  coords = {'time': np.arange(2), 'latitude': lat, 'longitude': lon}
+  dims = ('time', 'latitude', 'longitude')
+  gen = torch.Generator(device=dev).manual_seed(0)
+  f = torch.randn((2, 9, 16), device=dev, generator=gen)
+  t = torch.randn((2, 9, 16), device=dev, generator=gen)
+  forecast = xl.Dataset({'z': xl.DataArray(f, dims)}, coords)
+  truth = xl.Dataset({'z': xl.DataArray(t, dims)}, coords)
+  first = gm.Bias().compute_chunk(forecast, truth)['z'].values.copy()
+  again = gm.Bias().compute_chunk(forecast, truth)['z'].values
+  np.testing.assert_array_equal(first, again)          # cache hit
+  f.add_(1.0)                                          # refill in place
+  shifted = gm.Bias().compute_chunk(forecast, truth)['z'].values
+  np.testing.assert_allclose(shifted, first + 1.0, rtol=1e-6)
+  # host arrays: a changed buffer is noticed through the sampled fingerprint
+  fh, th = f.cpu().numpy().copy(), t.cpu().numpy().copy()
+  fo = xl.Dataset({'z': xl.DataArray(fh, dims)}, coords)
+  to = xl.Dataset({'z': xl.DataArray(th, dims)}, coords)
+  b0 = gm.Bias().compute_chunk(fo, to)['z'].values.copy()
+  fh += 2.0
+  b1 = gm.Bias().compute_chunk(fo, to)['z'].values
+  np.testing.assert_allclose(b1, b0 + 2.0, rtol=1e-6)

@@ -211,10 +211,29 @@ def clear_caches():
   _ALIGNED.clear()
 
 
+def _stamp(a) -> tuple:
+  """Cache identity of an input array: the object plus a cheap guard against
+  IN-PLACE changes between calls (a reused chunk buffer).  Torch tensors carry
+  a version counter that every in-place op bumps; for NumPy arrays 64 strided
+  samples are hashed (the reference's own cache compares whole arrays,
+  utils.py:322-350 -- far too slow at 54 MB per level here).  Not a proof of
+  equality: code that rewrites a NumPy buffer in place with near-identical
+  data should call `clear_caches()`."""
+  if isinstance(a, torch.Tensor):
+    return (id(a), a._version, a.data_ptr())
+  if isinstance(a, np.ndarray) and a.size:
+    step = max(1, a.size // 64)
+    flat = a.reshape(-1) if a.flags.c_contiguous else a.flat  # no copy
+    sample = np.asarray(flat[::step])[:64]
+    return (id(a), a.__array_interface__['data'][0], hash(sample.tobytes()),
+            hash(np.asarray(flat[a.size - 1:]).tobytes()))
+  return (id(a),)
+
+
 def _to_device(data, device) -> torch.Tensor:
   if isinstance(data, torch.Tensor) and data.device == device:
     return data
-  key = id(data)
+  key = _stamp(data)
   hit = _DEVICE.get(key)
   if hit is not None:
     return hit
@@ -428,7 +447,7 @@ def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
 
 def _result_key(kind, arrays, region_key_obj, skipna):
   sig = _region_set_sig(region_key_obj)[2]
-  return (kind, tuple(id(a) for a in arrays), sig, bool(skipna))
+  return (kind, tuple(_stamp(a) for a in arrays), sig, bool(skipna))
 
 
 @_serialized
@@ -442,7 +461,7 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
   key = _result_key('det', pins[:2], region, skipna)
   hit = _RESULTS.get(key)
   # A cached ACC pass also answers MSE/RMSE/MAE/Bias queries.
-  if hit is not None and (cvar is None or hit['clim'] == id(cvar.data)):
+  if hit is not None and (cvar is None or hit['clim'] == _stamp(cvar.data)):
     return hit['geo'], hit['by_region']
   announced = False
   if cvar is None and _ANNOUNCED.climatology:
@@ -477,7 +496,7 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
                            skipna)
   _RESULTS.put(key, tuple(pins), {
       'geo': geo, 'by_region': by_region,
-      'clim': None if cvar is None else id(cvar.data)})
+      'clim': None if cvar is None else _stamp(cvar.data)})
   return geo, by_region
 
 
