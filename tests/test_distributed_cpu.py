@@ -146,3 +146,40 @@ def test_make_latitude_increasing():
   np.testing.assert_array_equal(out['z'].values, x[:, ::-1])
   np.testing.assert_array_equal(out['s'].values, np.ones(2))
   assert evaluation.make_latitude_increasing(out) is out  # already increasing
+
+
+def test_strided_views_become_slab_tables_not_copies():
+  """metrics._physical_slabs: overlapping windows / expanded broadcasts keep
+  their storage and get a physical slab table (host logic, no GPU needed)."""
+  import numpy as np
+  import torch
+  from weatherbench2_amd import evaluation, metrics as gm
+  n_row, n_col = 3, 4
+  base = torch.arange(10 * 2 * n_row * n_col, dtype=torch.float32).reshape(
+      10, 2, n_row, n_col)                      # (time, level, lat, lon)
+  index = np.array([[0, 2, 4], [3, 5, 7]])      # a=0, b=3, c=2
+  view = evaluation._affine_time_view(base, 0, index)
+  assert view is not None and view.shape == (2, 3, 2, n_row, n_col)
+  assert view.untyped_storage().data_ptr() == base.untyped_storage().data_ptr()
+  for i in range(2):
+    for l in range(3):
+      assert torch.equal(view[i, l], base[index[i, l]])
+  x, table = gm._physical_slabs(view, None, n_row, n_col)
+  assert x is view                                   # handed over as it is
+  want = (index[:, :, None] * 2 + np.arange(2)[None, None, :]).ravel()
+  np.testing.assert_array_equal(table, want)
+  # a logical table (e.g. a broadcast over another dim) composes with it
+  logical = np.array([5, 0, 11], dtype=np.int64)
+  _, composed = gm._physical_slabs(view, logical, n_row, n_col)
+  np.testing.assert_array_equal(composed, want[logical])
+  # expanded broadcast: stride 0
+  e = base[:1].expand(4, 2, n_row, n_col)
+  x, table = gm._physical_slabs(e, None, n_row, n_col)
+  assert x is e
+  np.testing.assert_array_equal(table, np.tile(np.arange(2), 4))
+  # slabs that are not intact (transposed) are copied
+  t = base.transpose(-1, -2)
+  x, table = gm._physical_slabs(t, None, n_col, n_row)
+  assert x.is_contiguous() and table is None
+  # irregular index: no affine view
+  assert evaluation._affine_time_view(base, 0, np.array([[0, 2, 5]])) is None

@@ -271,9 +271,13 @@ def test_loop_computes_derived_variables_first():
   helpers.assert_close(got['doubled'].values[0], 4.0 * want, rtol=1e-9)
 
 
-def test_by_init_evaluation_with_device_truth_gather():
+@pytest.mark.parametrize('inits,zero_copy', [((0, 2, 4), True),
+                                              ((0, 2, 3), False)])
+def test_by_init_evaluation_with_device_truth_gather(inits, zero_copy):
   """evaluation.py:474-477: truth.sel(time=forecast.valid_time) then the loop,
-  with device-resident arrays end to end (index_select on the device)."""
+  with device-resident arrays end to end: regular init/lead steps give an
+  overlapping strided VIEW that the passes read through slab tables (no copy),
+  irregular ones one index_select on the device."""
   import torch
   from weatherbench2_amd import config, evaluation, metrics as gm
   from weatherbench2_amd import xarray_lite as xl
@@ -281,7 +285,7 @@ def test_by_init_evaluation_with_device_truth_gather():
   rs = np.random.RandomState(4)
   t0 = np.datetime64('2020-01-01T00', 'ns')
   time = t0 + np.arange(12) * np.timedelta64(12, 'h')
-  init, lead = time[[0, 2, 4]], np.arange(4) * np.timedelta64(24, 'h')
+  init, lead = time[list(inits)], np.arange(4) * np.timedelta64(24, 'h')
   lat, lon = np.linspace(-80, 80, 9), np.arange(16) * 22.5
   t_np = rs.standard_normal((12, 2, 9, 16)).astype(np.float32)
   f_np = rs.standard_normal((3, 4, 2, 9, 16)).astype(np.float32)
@@ -296,6 +300,9 @@ def test_by_init_evaluation_with_device_truth_gather():
       {**base, 'init_time': init, 'prediction_timedelta': lead})
   sel = evaluation.select_truth_at_valid_time(truth, forecast)
   assert sel['z'].data.is_cuda
+  shares = (sel['z'].data.untyped_storage().data_ptr()
+            == truth['z'].data.untyped_storage().data_ptr())
+  assert shares == zero_copy and sel['z'].data.is_contiguous() != zero_copy
   cfg = config.Eval(metrics={'mse': gm.MSE(), 'bias': gm.Bias()})
   got = evaluation._metric_and_region_loop(forecast, sel, cfg, False)
   # oracle on host copies of the same selection

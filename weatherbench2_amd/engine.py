@@ -50,6 +50,19 @@ def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
   return ten.contiguous()
 
 
+def _slabs_intact(x: torch.Tensor) -> bool:
+  """Contiguous, or a strided view whose 2-D slabs are contiguous and whose
+  outer strides are whole slabs (addressed through a slab table)."""
+  if x.is_contiguous():
+    return True
+  if x.dim() < 2:
+    return False
+  st = x.stride()
+  se = x.shape[-1] * x.shape[-2]
+  return st[-1] == 1 and st[-2] == x.shape[-1] and all(
+      s >= 0 and s % se == 0 for s in st[:-2])
+
+
 def stream_reduce(plan: ReductionPlan, mode: int,
                   inputs: t.Sequence[torch.Tensor],
                   slabs: t.Sequence[t.Optional[torch.Tensor]], n_outer: int,
@@ -67,14 +80,17 @@ def stream_reduce(plan: ReductionPlan, mode: int,
   if dtype not in _DTYPES:
     raise TypeError(f'unsupported dtype {dtype}')
   for x in inputs:
-    if x.dtype != dtype or x.device != dev or not x.is_contiguous():
-      raise ValueError('inputs must share dtype/device and be contiguous')
+    if x.dtype != dtype or x.device != dev or not _slabs_intact(x):
+      raise ValueError('inputs must share dtype/device and keep every '
+                       '(n_row, n_col) slab contiguous')
     if tuple(x.shape[-2:]) != (plan.n_row, plan.n_col):
       raise ValueError(f'slab shape {tuple(x.shape[-2:])} != plan '
                        f'({plan.n_row}, {plan.n_col})')
   for s, x in zip(slabs, inputs):
-    if s is None and x.shape[0] != n_outer:
-      raise ValueError('input without a slab table must have n_outer slabs')
+    if s is None and (not x.is_contiguous() or
+                      x.numel() != n_outer * plan.n_row * plan.n_col):
+      raise ValueError('an input without a slab table must be n_outer '
+                       'contiguous slabs')
     if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
       raise ValueError('slab tables are int64[n_outer]')
   code = _DTYPES[dtype]

@@ -116,17 +116,41 @@ def make_latitude_increasing(dataset):
   return xl.like_input(out, dataset)
 
 
+def _affine_time_view(data, ax: int, index: np.ndarray):
+  """index[i, l] == a + b*i + c*l (regularly spaced inits and leads): the
+  selection is an overlapping strided VIEW of `data` (dims `ax` -> (i, l)),
+  which the fused passes read through a slab table without copying; None if
+  the index is not affine or the tensor is not contiguous."""
+  import torch
+  if not data.is_contiguous() or index.ndim != 2:
+    return None
+  n_i, n_l = index.shape
+  a = int(index[0, 0])
+  b = int(index[1, 0] - a) if n_i > 1 else 0
+  c = int(index[0, 1] - a) if n_l > 1 else 0
+  if b < 0 or c < 0:
+    return None
+  want = a + b * np.arange(n_i)[:, None] + c * np.arange(n_l)[None, :]
+  if not np.array_equal(want, index):
+    return None
+  st = list(data.stride())
+  size = list(data.shape[:ax]) + [n_i, n_l] + list(data.shape[ax + 1:])
+  stride = st[:ax] + [b * st[ax], c * st[ax]] + st[ax + 1:]
+  return torch.as_strided(data, size, stride,
+                          data.storage_offset() + a * st[ax])
+
+
 def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
                                init_dim: str = 'init_time',
                                lead_dim: str = 'prediction_timedelta'):
   """`truth.sel(time=forecast.valid_time)` (evaluation.py:474-475) for a
   by-init forecast: truth gets the forecast's (init_time, lead) dims.
 
-  The gather runs where the truth lives (one `index_select` on the device for
-  device-resident arrays: a single extra HBM pass over the selected slabs, no
-  host round trip); labels missing from `truth.time` raise KeyError like
-  `.sel`.  Through the engine (`engine.stream_reduce` with slab tables, what
-  bench.py does) the same gather costs nothing at all.
+  For device-resident truth with regularly spaced init and lead times the
+  result is an overlapping strided VIEW (no copy: the fused passes resolve it
+  through their slab tables, metrics._physical_slabs); irregular selections
+  fall back to one `index_select` on the device.  Labels missing from
+  `truth.time` raise KeyError like `.sel`.
   """
   import torch
   given = (truth, forecast)
@@ -158,8 +182,12 @@ def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
     ax = da.dims.index(time_dim)
     shape = da.shape[:ax] + valid.shape + da.shape[ax + 1:]
     if isinstance(da.data, torch.Tensor):
-      idx = torch.as_tensor(index, device=da.data.device)
-      data = torch.index_select(da.data, ax, idx).reshape(shape)
+      view = _affine_time_view(da.data, ax, index.reshape(valid.shape))
+      if view is not None:  # regular init / lead steps: no copy at all
+        data = view
+      else:
+        idx = torch.as_tensor(index, device=da.data.device)
+        data = torch.index_select(da.data, ax, idx).reshape(shape)
     else:
       data = np.take(np.asarray(da.data), index, axis=ax).reshape(shape)
     dims = da.dims[:ax] + (init_dim, lead_dim) + da.dims[ax + 1:]

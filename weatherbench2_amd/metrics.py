@@ -411,6 +411,32 @@ def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
   return np.ascontiguousarray(table).ravel()
 
 
+def _physical_slabs(x: torch.Tensor, table, n_row: int, n_col: int):
+  """(tensor for the engine, slab table) of an input whose logical layout is
+  [..., n_row, n_col] with `table` indexing its slabs as if it were contiguous.
+
+  Contiguous tensors are simply flattened.  A strided VIEW whose 2-D slabs are
+  intact (overlapping `as_strided` windows -- evaluation.
+  select_truth_at_valid_time --, `expand`ed broadcasts, slices with a step) is
+  handed over as it is: the table is rewritten to physical slab offsets from
+  the view's strides, so the selection costs no copy at all."""
+  if x.is_contiguous():
+    return x.reshape(-1, n_row, n_col), table
+  se = n_row * n_col
+  st, sh = x.stride(), tuple(x.shape)
+  ok = (x.dim() >= 2 and st[-1] == 1 and st[-2] == n_col
+        and all(s >= 0 and s % se == 0 for s in st[:-2]))
+  if not ok:
+    return x.contiguous().reshape(-1, n_row, n_col), table
+  phys = np.zeros(sh[:-2], dtype=np.int64)
+  for ax, (n, s) in enumerate(zip(sh[:-2], st[:-2])):
+    shape = [1] * (len(sh) - 2)
+    shape[ax] = n
+    phys = phys + (np.arange(n, dtype=np.int64) * (s // se)).reshape(shape)
+  phys = np.ascontiguousarray(phys).ravel()
+  return x, (phys if table is None else phys[table])
+
+
 # ---------------------------------------------------------------------------
 # the fused passes
 # ---------------------------------------------------------------------------
@@ -431,7 +457,8 @@ def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
   tensors = [x if x.dtype == dtype else x.to(dtype) for x in tensors]
   for x in tensors:
     _check_grid(geo, x)
-  flat = [x.reshape(-1, pl.n_row, pl.n_col) for x in tensors]
+  flat, tables = zip(*[_physical_slabs(x, tb, pl.n_row, pl.n_col)
+                       for x, tb in zip(tensors, tables)])
   slabs = [None if tb is None else torch.from_numpy(tb).to(device)
            for tb in tables]
   if aux is not None:
