@@ -1,0 +1,228 @@
+"""Seeded differential fuzzing of the fused passes against the oracle (-m gpu):
+random grid sizes (odd widths take the scalar-load path), dim orders, dtypes,
+NaN patterns, skipna, region sets (label slices, lists of slices,
+extra-tropics, land masks with thresholds, combinations), truth broadcast
+over extra forecast dims -- 160 deterministic cases + 60 ensemble cases."""
+import numpy as np
+import pytest
+
+from oracle import metrics_np as om
+from oracle import regions_np as oreg
+from oracle.named import DS, NA
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(rs):
+  n_lat = int(rs.randint(2, 24))
+  n_lon = int(rs.randint(2, 48))
+  lat = np.sort(rs.uniform(-89, 89, n_lat)) if rs.rand() < 0.3 else (
+      np.linspace(-90, 90, n_lat))
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  return lat, lon
+
+
+def _random_region(rs, lat, lon):
+  kind = rs.randint(0, 6)
+  def lat_slice():
+    a, b = np.sort(rs.uniform(-95, 95, 2))
+    return slice(float(a), float(b))
+  def lon_slice():
+    a, b = np.sort(rs.uniform(-10, 370, 2))
+    return slice(float(a), float(b))
+  def land():
+    frac = np.clip(rs.rand(len(lat), len(lon)) * 1.6 - 0.3, 0, 1)
+    thr = None if rs.rand() < 0.5 else 0.5
+    return oreg.LandRegion(NA(frac, ('latitude', 'longitude')), lat, lon, thr)
+  if kind == 0:
+    return oreg.SliceRegion()
+  if kind == 1:
+    return oreg.SliceRegion(lat_slice=lat_slice(), lon_slice=lon_slice())
+  if kind == 2:
+    return oreg.SliceRegion(lat_slice=[lat_slice(), lat_slice()],
+                            lon_slice=[lon_slice(), lon_slice()])
+  if kind == 3:
+    return oreg.ExtraTropicalRegion()
+  if kind == 4:
+    return land()
+  return oreg.CombinedRegion([oreg.SliceRegion(lat_slice=lat_slice()), land()])
+
+
+def _dataset(rs, dims, sizes, coords, dtype, nan_frac):
+  shape = tuple(sizes[d] for d in dims)
+  x = rs.standard_normal(shape).astype(dtype)
+  if nan_frac:
+    x[rs.rand(*shape) < nan_frac] = np.nan
+  return DS({'z': NA(x, dims)}, {d: coords[d] for d in dims})
+
+
+@pytest.mark.parametrize('seed', range(160))
+def test_deterministic_family_fuzz(seed):
+  from weatherbench2_amd import metrics as gm
+  rs = np.random.RandomState(1000 + seed)
+  lat, lon = _grid(rs)
+  sizes = {'time': int(rs.randint(1, 4)), 'level': int(rs.randint(1, 4)),
+           'prediction_timedelta': int(rs.randint(1, 3)),
+           'latitude': len(lat), 'longitude': len(lon)}
+  t0 = np.datetime64('2020-03-01T00', 'ns')
+  coords = {'time': t0 + np.arange(sizes['time']) * np.timedelta64(6, 'h'),
+            'level': np.array([500, 700, 850])[:sizes['level']],
+            'prediction_timedelta': (np.arange(sizes['prediction_timedelta'])
+                                     * np.timedelta64(6, 'h')),
+            'latitude': lat, 'longitude': lon}
+  spatial = (['latitude', 'longitude'] if rs.rand() < 0.6
+             else ['longitude', 'latitude'])
+  outer = ['prediction_timedelta', 'time', 'level']
+  rs.shuffle(outer)
+  fdims = tuple(outer) + tuple(spatial)
+  touter = [d for d in outer if d != 'prediction_timedelta']
+  rs.shuffle(touter)
+  tdims = tuple(touter) + tuple(spatial)
+  dtype = np.float32 if rs.rand() < 0.6 else np.float64
+  skipna = bool(rs.rand() < 0.5)
+  nan_frac = 0.08 if rs.rand() < 0.5 else 0.0
+  forecast = _dataset(rs, fdims, sizes, coords, dtype, nan_frac)
+  truth = _dataset(rs, tdims, sizes, coords, dtype, nan_frac / 2)
+  regions = {f'r{i}': _random_region(rs, lat, lon) for i in range(3)}
+  # several distinct masks in one set are grouped by the product itself
+  g = helpers.to_gpu_dataset
+  g_regions = {k: helpers.to_gpu_region(v) for k, v in regions.items()}
+  pairs = [(om.MSE(), gm.MSE()), (om.MAE(), gm.MAE()), (om.Bias(), gm.Bias()),
+           (om.RMSESqrtBeforeTimeAvg(), gm.RMSESqrtBeforeTimeAvg())]
+  if rs.rand() < 0.5:
+    cdims = ('hour', 'dayofyear', 'level') + tuple(spatial)
+    csizes = {'hour': 4, 'dayofyear': 3, **sizes}
+    ccoords = {'hour': np.array([0, 6, 12, 18]),
+               'dayofyear': np.array([60, 61, 62]), **coords}
+    clim = _dataset(rs, cdims, csizes, ccoords, dtype, 0.0)
+    pairs.append((om.ACC(clim), gm.ACC(g(clim))))
+  rtol = 2e-5 if dtype == np.float32 else 1e-9
+  with gm.fused_regions(g_regions):
+    for oc, gc in pairs:
+      for rname, region in regions.items():
+        want = oc.compute_chunk(forecast, truth, region=region,
+                                skipna=skipna)['z']
+        got = gc.compute_chunk(g(forecast), g(truth), region=g_regions[rname],
+                               skipna=skipna)['z']
+        assert got.dims == want.dims, (seed, type(oc).__name__, rname)
+        helpers.assert_close(
+            got.values, want.data, rtol=rtol, atol=1e-6 if dtype == np.float32
+            else 1e-12, err_msg=f'seed={seed} {type(oc).__name__} {rname} '
+            f'{fdims} {dtype.__name__} skipna={skipna}')
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_ensemble_family_fuzz(seed):
+  from weatherbench2_amd import metrics as gm
+  rs = np.random.RandomState(2000 + seed)
+  lat, lon = _grid(rs)
+  m = int(rs.choice([1, 2, 3, 6, 17, 33, 70, 140]))
+  sizes = {'realization': m, 'time': int(rs.randint(1, 3)),
+           'level': int(rs.randint(1, 3)), 'latitude': len(lat),
+           'longitude': len(lon)}
+  coords = {'realization': np.arange(m), 'time': np.arange(sizes['time']),
+            'level': np.arange(sizes['level']), 'latitude': lat,
+            'longitude': lon}
+  spatial = (['latitude', 'longitude'] if rs.rand() < 0.6
+             else ['longitude', 'latitude'])
+  outer = ['realization', 'time', 'level']
+  rs.shuffle(outer)
+  fdims = tuple(outer) + tuple(spatial)
+  tdims = tuple(d for d in outer if d != 'realization') + tuple(spatial)
+  dtype = np.float32 if rs.rand() < 0.6 else np.float64
+  skipna = bool(rs.rand() < 0.5)
+  nan_frac = 0.05 if skipna else 0.0
+  forecast = _dataset(rs, fdims, sizes, coords, dtype, nan_frac)
+  truth = _dataset(rs, tdims, sizes, coords, dtype, nan_frac / 2)
+  regions = {f'r{i}': _random_region(rs, lat, lon) for i in range(2)}
+  g = helpers.to_gpu_dataset
+  g_regions = {k: helpers.to_gpu_region(v) for k, v in regions.items()}
+  names = ('CRPS', 'CRPSSpread', 'CRPSSkill', 'EnsembleMeanMSE',
+           'EnsembleVariance', 'DebiasedEnsembleMeanMSE')
+  rtol = 2e-5 if dtype == np.float32 else 1e-9
+  with gm.fused_regions(g_regions):
+    for name in names:
+      for rname, region in regions.items():
+        want = getattr(om, name)().compute_chunk(forecast, truth,
+                                                 region=region,
+                                                 skipna=skipna)['z']
+        got = getattr(gm, name)().compute_chunk(
+            g(forecast), g(truth), region=g_regions[rname], skipna=skipna)['z']
+        assert got.dims == want.dims, (seed, name, rname)
+        helpers.assert_close(
+            got.values, want.data, rtol=rtol,
+            atol=1e-6 if dtype == np.float32 else 1e-12,
+            err_msg=f'seed={seed} {name} {rname} M={m} {fdims} '
+            f'{dtype.__name__} skipna={skipna}')
+
+
+def _values(da):
+  v = da.data
+  return v.cpu().numpy() if hasattr(v, 'cpu') else np.asarray(v)
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_maps_gaussian_and_rank_histogram_fuzz(seed):
+  """The map-valued and tier-2 families on random layouts: Spatial{MSE,MAE,
+  Bias}, SpatialCRPS / SpatialEnsembleVariance, GaussianCRPS / Variance and
+  the (tie-free) rank histogram."""
+  from weatherbench2_amd import metrics as gm
+  rs = np.random.RandomState(3000 + seed)
+  lat, lon = _grid(rs)
+  m = int(rs.choice([2, 3, 5, 9, 20]))
+  sizes = {'realization': m, 'time': int(rs.randint(1, 4)),
+           'level': int(rs.randint(1, 3)), 'latitude': len(lat),
+           'longitude': len(lon)}
+  coords = {'realization': np.arange(m), 'time': np.arange(sizes['time']),
+            'level': np.arange(sizes['level']), 'latitude': lat,
+            'longitude': lon}
+  spatial = (['latitude', 'longitude'] if rs.rand() < 0.6
+             else ['longitude', 'latitude'])
+  outer = ['time', 'level']
+  rs.shuffle(outer)
+  ddims = tuple(outer) + tuple(spatial)
+  eouter = ['realization', 'time', 'level']
+  rs.shuffle(eouter)
+  edims = tuple(eouter) + tuple(spatial)
+  dtype = np.float32 if rs.rand() < 0.6 else np.float64
+  skipna = bool(rs.rand() < 0.5)
+  nan_frac = 0.05 if skipna else 0.0
+  tol = dict(rtol=2e-5, atol=1e-6) if dtype == np.float32 else dict(
+      rtol=1e-9, atol=1e-12)
+  g = helpers.to_gpu_dataset
+  tag = f'seed={seed} {dtype.__name__} skipna={skipna}'
+  # deterministic maps
+  forecast = _dataset(rs, ddims, sizes, coords, dtype, nan_frac)
+  truth = _dataset(rs, ddims, sizes, coords, dtype, 0.0)
+  for name in ('SpatialMSE', 'SpatialMAE', 'SpatialBias'):
+    want = getattr(om, name)().compute_chunk(forecast, truth)['z']
+    got = getattr(gm, name)().compute_chunk(g(forecast), g(truth))['z']
+    assert set(got.dims) == set(want.dims)
+    helpers.assert_close(_values(got), want.transpose(*got.dims).data,
+                         err_msg=f'{name} {tag}', **tol)
+  # ensemble maps + rank histogram
+  ens = _dataset(rs, edims, sizes, coords, dtype, nan_frac)
+  for name in ('SpatialCRPS', 'SpatialEnsembleVariance'):
+    want = getattr(om, name)().compute_chunk(ens, truth, skipna=skipna)['z']
+    got = getattr(gm, name)().compute_chunk(g(ens), g(truth),
+                                            skipna=skipna)['z']
+    helpers.assert_close(_values(got), want.transpose(*got.dims).data,
+                         err_msg=f'{name} {tag} M={m}', **tol)
+  clean = _dataset(rs, edims, sizes, coords, dtype, 0.0)
+  want = om.RankHistogram(break_ties_randomly=False).compute_chunk(
+      clean, truth)['z']
+  got = gm.RankHistogram(break_ties_randomly=False).compute_chunk(
+      g(clean), g(truth))['z']
+  np.testing.assert_array_equal(_values(got), want.transpose(*got.dims).data,
+                                err_msg=f'RankHistogram {tag} M={m}')
+  # Gaussian family: mean / std variables
+  mean = _dataset(rs, ddims, sizes, coords, dtype, nan_frac)
+  std = _dataset(rs, ddims, sizes, coords, dtype, 0.0)
+  gf = DS({'z': mean['z'], 'z_std': NA(np.abs(std['z'].data) + dtype(0.1),
+                                       std['z'].dims)}, mean.coords)
+  for name in ('GaussianCRPS', 'GaussianVariance'):
+    want = getattr(om, name)().compute_chunk(gf, truth, skipna=skipna)['z']
+    got = getattr(gm, name)().compute_chunk(g(gf), g(truth), skipna=skipna)['z']
+    assert got.dims == want.dims
+    helpers.assert_close(got.values, want.data, err_msg=f'{name} {tag}', **tol)

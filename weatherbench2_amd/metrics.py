@@ -948,6 +948,10 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
       tten.reshape(-1, pl.n_row, pl.n_col), truth_table,
       geo.n_outer, skipna, maps=maps)
   dev = metrics.reshape((_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
+  # total weight of each region: a spatial average of zeros is 0/0 = NaN over
+  # an empty region (CRPSSpread with one member, metrics.py:689-693, 783-784)
+  geo.region_wsum = dict(zip(pl.region_names,
+                             (float(w) for w in pl.region_wsum_host)))
   value = (geo, {nm: dev[:, i] for i, nm in enumerate(pl.region_names)},
            n_member)
   if want_maps:
@@ -964,6 +968,9 @@ class EnsembleMetric(Metric):
   ensemble_dim: str = REALIZATION
   _metric = ''
   _zero_if_single = False  # metrics.py:1196-1204, 1228-1235, 783-784
+  # zeros_like(spatial average) is 0 everywhere (:1197-1204); the spatial
+  # average OF zeros (CRPSSpread, :689-693) is NaN where a region has no weight
+  _zero_is_spatial_average = False
   # xarray puts the dims of the LEFT operand first: metrics built from
   # `truth - forecast...` (skill, CRPS, mean MSE/RMSE, debiased) come out in
   # truth-first order, the ones built from the forecast alone in forecast order.
@@ -986,6 +993,20 @@ class EnsembleMetric(Metric):
           values = (torch.zeros_like(values)
                     if isinstance(values, torch.Tensor)
                     else np.zeros_like(values))
+          if self._zero_is_spatial_average:
+            # _spatial_average(zeros): 0 / sum(w) -- NaN over an empty region
+            names = list(regions) if regions is not None else [
+                _region_set_for(region)[1]]
+            empty = [geo.region_wsum[k] == 0.0 for k in names]
+            if any(empty):
+              values = values.clone() if isinstance(
+                  values, torch.Tensor) else values.copy()
+              if regions is not None:
+                for i, e in enumerate(empty):
+                  if e:
+                    values[i] = float('nan')
+              else:
+                values[...] = float('nan')
         dims = lead + geo.out_dims
         if self._truth_first:
           tdims = [d for d in truth[name].dims if d in dims]
@@ -1032,6 +1053,7 @@ class CRPSSpread(EnsembleMetric):
   """E|X - X'| (metrics.py:678-694); zero for one member (:783-784)."""
   _metric = 'crps_spread'
   _zero_if_single = True
+  _zero_is_spatial_average = True
   _truth_first = False
 
 
