@@ -226,3 +226,72 @@ def test_maps_gaussian_and_rank_histogram_fuzz(seed):
     got = getattr(gm, name)().compute_chunk(g(gf), g(truth), skipna=skipna)['z']
     assert got.dims == want.dims
     helpers.assert_close(got.values, want.data, err_msg=f'{name} {tag}', **tol)
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_threshold_family_fuzz(seed):
+  """Gaussian and ensemble threshold metrics with a climatological Gaussian
+  quantile threshold on random layouts (thresholds.py:151-187; metrics.py:
+  975-1158, 1524-1891)."""
+  from oracle import thresholds_np as oth
+  from weatherbench2_amd import metrics as gm
+  from weatherbench2_amd import thresholds as gth
+  rs = np.random.RandomState(4000 + seed)
+  lat, lon = _grid(rs)
+  m = int(rs.choice([1, 2, 4, 7, 31]))
+  n_time = int(rs.randint(1, 4))
+  t0 = np.datetime64('2021-02-27T00', 'ns')
+  sizes = {'realization': m, 'time': n_time, 'level': int(rs.randint(1, 3)),
+           'latitude': len(lat), 'longitude': len(lon), 'dayofyear': 6}
+  coords = {'realization': np.arange(m),
+            'time': t0 + np.arange(n_time) * np.timedelta64(24, 'h'),
+            'level': np.array([500, 850])[:sizes['level']], 'latitude': lat,
+            'longitude': lon, 'dayofyear': 57 + np.arange(6)}
+  spatial = (['latitude', 'longitude'] if rs.rand() < 0.6
+             else ['longitude', 'latitude'])
+  outer = ['time', 'level']
+  rs.shuffle(outer)
+  ddims = tuple(outer) + tuple(spatial)
+  eouter = ['realization', 'time', 'level']
+  rs.shuffle(eouter)
+  edims = tuple(eouter) + tuple(spatial)
+  cdims = ('dayofyear', 'level') + tuple(spatial)
+  dtype = np.float32 if rs.rand() < 0.5 else np.float64
+  skipna = bool(rs.rand() < 0.5)
+  nan_frac = 0.05 if skipna else 0.0
+  truth = _dataset(rs, ddims, sizes, coords, dtype, nan_frac / 2)
+  cm = _dataset(rs, cdims, sizes, coords, dtype, 0.0)['z']
+  cs = _dataset(rs, cdims, sizes, coords, dtype, 0.0)['z']
+  clim = DS({'z': NA(cm.data * dtype(0.3), cdims),
+             'z_std': NA(np.abs(cs.data) * dtype(0.5) + dtype(0.5), cdims)},
+            {d: coords[d] for d in cdims})
+  g = helpers.to_gpu_dataset
+  qs = (0.25, 0.7)
+  oths = [oth.GaussianQuantileThreshold(clim, q) for q in qs]
+  gths = [gth.GaussianQuantileThreshold(climatology=g(clim), quantile=q)
+          for q in qs]
+  region = _random_region(rs, lat, lon)
+  g_region = helpers.to_gpu_region(region)
+  tol = dict(rtol=3e-5, atol=2e-6) if dtype == np.float32 else dict(
+      rtol=1e-9, atol=1e-12)
+  tag = f'seed={seed} {dtype.__name__} skipna={skipna} M={m}'
+  ens = _dataset(rs, edims, sizes, coords, dtype, nan_frac)
+  for name in ('EnsembleBrierScore', 'DebiasedEnsembleBrierScore',
+               'EnsembleIgnoranceScore', 'EnsembleRPS'):
+    want = getattr(om, name)(thresholds=oths).compute_chunk(
+        ens, truth, region=region, skipna=skipna)['z']
+    got = getattr(gm, name)(thresholds=gths).compute_chunk(
+        g(ens), g(truth), region=g_region, skipna=skipna)['z']
+    assert got.dims == want.dims, (name, tag)
+    helpers.assert_close(got.values, want.data, err_msg=f'{name} {tag}', **tol)
+  mean = _dataset(rs, ddims, sizes, coords, dtype, nan_frac)
+  std = _dataset(rs, ddims, sizes, coords, dtype, 0.0)
+  gf = DS({'z': mean['z'], 'z_std': NA(np.abs(std['z'].data) + dtype(0.2),
+                                       std['z'].dims)}, mean.coords)
+  for name in ('GaussianBrierScore', 'GaussianIgnoranceScore', 'GaussianRPS'):
+    want = getattr(om, name)(thresholds=oths).compute_chunk(
+        gf, truth, region=region, skipna=skipna)['z']
+    got = getattr(gm, name)(thresholds=gths).compute_chunk(
+        g(gf), g(truth), region=g_region, skipna=skipna)['z']
+    assert got.dims == want.dims, (name, tag)
+    helpers.assert_close(got.values, want.data, err_msg=f'{name} {tag}', **tol)

@@ -1407,7 +1407,21 @@ def _truth_first_order(dims, values, truth_dims):
   return order, _transpose(values, [dims.index(d) for d in order])
 
 
+def _order_by(dims, values, precedence):
+  """Reorders (dims, values) like xarray broadcasting would: dims in order of
+  first appearance over the operand dim tuples in `precedence`."""
+  order = []
+  for operand in precedence:
+    order += [d for d in operand if d in dims and d not in order]
+  order += [d for d in dims if d not in order]
+  order = tuple(order)
+  if order == tuple(dims):
+    return dims, values
+  return order, _transpose(values, [dims.index(d) for d in order])
+
+
 class _GaussianThresholdMetric(ThresholdMetric):
+  _truth_leads = False
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
     forecast, truth = _inputs(forecast, truth)
@@ -1420,8 +1434,19 @@ class _GaussianThresholdMetric(ThresholdMetric):
         geo, by_region = _gauss_threshold_pass(forecast, truth, threshold_ds,
                                                name, region, skipna)
         _, rkey = _region_set_for(region)
-        per_var[name] = _truth_first_order(
-            geo.out_dims, by_region[rkey][self._row], truth[name].dims)
+        # xarray keeps the dims of the LEFT operand first.  Brier / RPS are
+        # ((threshold - mean) / std -> cdf) - truth_indicator: threshold dims,
+        # then the forecast's, then the truth's (:990-1000, 1111-1121); the
+        # ignorance score is xr.where(truth_indicator, ...): truth (with the
+        # threshold it was compared to) first (:1057-1066).
+        thr, mean, std = (threshold_ds[name].dims, forecast[name].dims,
+                          forecast[f'{name}_std'].dims)
+        if self._truth_leads:
+          precedence = (truth[name].dims, thr, mean, std)
+        else:
+          precedence = (thr, mean, std, truth[name].dims)
+        per_var[name] = _order_by(geo.out_dims, by_region[rkey][self._row],
+                                  precedence)
       per_threshold.append(per_var)
     return _stack_quantiles(forecast, per_threshold,
                             [th.quantile for th in self.thresholds],
@@ -1439,6 +1464,7 @@ class GaussianBrierScore(_GaussianThresholdMetric):
 class GaussianIgnoranceScore(_GaussianThresholdMetric):
   """Ignorance (log) score of a Gaussian forecast (metrics.py:1069-1101)."""
   _row = 1
+  _truth_leads = True
 
 
 @dataclasses.dataclass
@@ -1558,9 +1584,16 @@ class _EnsembleThresholdMetric(ThresholdMetric):
                        hit)
         geo, by_region = hit
         _, rkey = _region_set_for(region)
-        dims, values = geo.out_dims, by_region[rkey][self._row]
-        if self._truth_first:
-          dims, values = _truth_first_order(dims, values, truth[name].dims)
+        # dims in xarray's left-operand-first order (:1524-1560, 532-565,
+        # 1722-1738, 1805-1817): forecast-led for the plain Brier score and
+        # the RPS part, truth-led (with its threshold) for the debiased Brier
+        # and the ignorance score
+        fdims = tuple(d for d in forecast[name].dims if d != self.ensemble_dim)
+        tdims, hdims = truth[name].dims, threshold_ds[name].dims
+        precedence = ((tdims, hdims, fdims) if self._truth_first
+                      else (fdims, hdims, tdims))
+        dims, values = _order_by(geo.out_dims, by_region[rkey][self._row],
+                                 precedence)
         per_var[name] = (dims, values)
       per_threshold.append(per_var)
     return _stack_quantiles(forecast, per_threshold,
