@@ -2,7 +2,8 @@
 random grid sizes (odd widths take the scalar-load path), dim orders, dtypes,
 NaN patterns, skipna, region sets (label slices, lists of slices,
 extra-tropics, land masks with thresholds, combinations), truth broadcast
-over extra forecast dims -- 160 deterministic cases + 60 ensemble cases."""
+over extra forecast dims -- 160 deterministic + 60 ensemble cases here, then maps / Gaussian / rank
+histogram (40), threshold family (30), spectrum (24) and reductions (30)."""
 import numpy as np
 import pytest
 
@@ -295,3 +296,107 @@ def test_threshold_family_fuzz(seed):
         g(gf), g(truth), region=g_region, skipna=skipna)['z']
     assert got.dims == want.dims, (name, tag)
     helpers.assert_close(got.values, want.data, err_msg=f'{name} {tag}', **tol)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_spectrum_fuzz(seed):
+  """ZonalEnergySpectrum on random row lengths (even / odd, fused and rocFFT
+  paths), dim orders, dtypes and NaN rows, plain and with the fused time
+  mean."""
+  from oracle import spectrum_np
+  from weatherbench2_amd import derived_variables as dv
+  from weatherbench2_amd import xarray_lite as xl
+  rs = np.random.RandomState(5000 + seed)
+  n_lon = int(rs.choice([6, 9, 15, 16, 30, 45, 64, 72, 100, 128, 240, 360]))
+  n_lat = int(rs.randint(1, 9))
+  lat = np.sort(rs.uniform(-85, 85, n_lat))
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  n_time, n_lev = int(rs.randint(1, 4)), int(rs.randint(1, 3))
+  dtype = np.float32 if rs.rand() < 0.6 else np.float64
+  x = rs.standard_normal((n_time, n_lev, n_lat, n_lon)).astype(dtype)
+  canon = ('time', 'level', 'latitude', 'longitude')
+  perm = list(range(4))
+  rs.shuffle(perm)
+  dims = tuple(canon[i] for i in perm)
+  ds = xl.Dataset({'z': xl.DataArray(np.ascontiguousarray(
+      np.transpose(x, perm)), dims)},
+                  {'time': np.arange(n_time), 'level': np.arange(n_lev),
+                   'latitude': lat, 'longitude': lon})
+  want, freq, _ = spectrum_np.zonal_energy_spectrum(x, lat, lon, lat_axis=2,
+                                                    lon_axis=3)
+  got = dv.ZonalEnergySpectrum('z').compute(ds)
+  assert got.dims == tuple(d for d in dims if d != 'longitude') + (
+      'zonal_wavenumber',)
+  g = np.asarray(got.transpose('time', 'level', 'latitude',
+                               'zonal_wavenumber').values)
+  scale = np.abs(want).sum(-1, keepdims=True)
+  tol = 3e-6 if dtype == np.float32 else 1e-12
+  assert np.max(np.abs(g - want) / np.where(scale > 0, scale, 1)) < tol, (
+      seed, n_lon, dims, dtype)
+  np.testing.assert_allclose(got.coords['frequency'].values, freq, rtol=1e-12)
+  # time mean with a NaN row
+  if n_time > 1:
+    xn = x.copy()
+    xn[0, 0, 0, 0] = np.nan
+    dsn = xl.Dataset({'z': xl.DataArray(np.ascontiguousarray(
+        np.transpose(xn, perm)), dims)}, ds.coords)
+    wn, _, _ = spectrum_np.zonal_energy_spectrum(xn, lat, lon, lat_axis=2,
+                                                 lon_axis=3)
+    for skipna in (True, False):
+      fused = dv.ZonalEnergySpectrum('z').compute(dsn, time_mean_dim='time',
+                                                  skipna=skipna)
+      f = np.asarray(fused.transpose('level', 'latitude',
+                                     'zonal_wavenumber').values)
+      import warnings
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        w = np.nanmean(wn, 0) if skipna else wn.mean(0)
+      sc = np.nansum(np.abs(w), -1, keepdims=True)
+      err = np.abs(f - w) / np.where(sc > 0, sc, 1)
+      assert np.array_equal(np.isnan(f), np.isnan(w)), (seed, skipna)
+      if np.isfinite(err).any():  # (a single all-NaN row has nothing to compare)
+        assert np.nanmax(err) < tol, (seed, n_lon, skipna)
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_reductions_fuzz(seed):
+  """reductions.averages / ensemble_mean / statistical_moments on random dim
+  orders and reduction sets (merged, non-adjacent, weighted, NaNs)."""
+  from oracle import reductions_np as ored
+  from weatherbench2_amd import reductions
+  rs = np.random.RandomState(6000 + seed)
+  lat, lon = _grid(rs)
+  sizes = {'realization': int(rs.randint(1, 5)), 'time': int(rs.randint(1, 5)),
+           'level': int(rs.randint(1, 4)), 'latitude': len(lat),
+           'longitude': len(lon)}
+  coords = {'realization': np.arange(sizes['realization']),
+            'time': np.arange(sizes['time']),
+            'level': np.arange(sizes['level']), 'latitude': lat,
+            'longitude': lon}
+  dims = list(sizes)
+  rs.shuffle(dims)
+  dims = tuple(dims)
+  dtype = np.float32 if rs.rand() < 0.6 else np.float64
+  skipna = bool(rs.rand() < 0.5)
+  ds = _dataset(rs, dims, sizes, coords, dtype, 0.06 if skipna else 0.0)
+  g = helpers.to_gpu_dataset
+  k = int(rs.randint(1, 4))
+  red = list(rs.choice(list(sizes), size=k, replace=False))
+  tol = dict(rtol=3e-6, atol=1e-6) if dtype == np.float32 else dict(
+      rtol=1e-12, atol=1e-12)
+  want = ored.averages(ds, red, skipna=skipna)['z']
+  got = reductions.averages(g(ds), red, skipna=skipna)['z']
+  assert set(got.dims) == set(want.dims)
+  helpers.assert_close(_values(got), want.transpose(*got.dims).data,
+                       err_msg=f'seed={seed} averages over {red} of {dims}',
+                       **tol)
+  want = ored.ensemble_mean(ds, skipna=skipna)['z']
+  got = reductions.ensemble_mean(g(ds), skipna=skipna)['z']
+  helpers.assert_close(_values(got), want.transpose(*got.dims).data,
+                       err_msg=f'seed={seed} ensemble_mean {dims}', **tol)
+  want = ored.statistical_moments(ds)
+  got = reductions.statistical_moments(g(ds))
+  for key in ('z_zeroth', 'z_first', 'z_second'):
+    helpers.assert_close(_values(got[key]),
+                         want[key].transpose(*got[key].dims).data,
+                         err_msg=f'seed={seed} {key} {dims}', **tol)
