@@ -50,11 +50,14 @@ def _random_region(rs, lat, lon):
   return oreg.CombinedRegion([oreg.SliceRegion(lat_slice=lat_slice()), land()])
 
 
-def _dataset(rs, dims, sizes, coords, dtype, nan_frac):
+def _dataset(rs, dims, sizes, coords, dtype, nan_frac, inf_frac=0.0):
   shape = tuple(sizes[d] for d in dims)
   x = rs.standard_normal(shape).astype(dtype)
   if nan_frac:
     x[rs.rand(*shape) < nan_frac] = np.nan
+  if inf_frac:  # a few +-inf: inf - inf = NaN, inf ** 2 = inf, like NumPy
+    hit = rs.rand(*shape) < inf_frac
+    x[hit] = np.where(rs.rand(int(hit.sum())) < 0.5, np.inf, -np.inf)
   return DS({'z': NA(x, dims)}, {d: coords[d] for d in dims})
 
 
@@ -83,8 +86,9 @@ def test_deterministic_family_fuzz(seed):
   dtype = np.float32 if rs.rand() < 0.6 else np.float64
   skipna = bool(rs.rand() < 0.5)
   nan_frac = 0.08 if rs.rand() < 0.5 else 0.0
-  forecast = _dataset(rs, fdims, sizes, coords, dtype, nan_frac)
-  truth = _dataset(rs, tdims, sizes, coords, dtype, nan_frac / 2)
+  inf_frac = 0.02 if rs.rand() < 0.2 else 0.0
+  forecast = _dataset(rs, fdims, sizes, coords, dtype, nan_frac, inf_frac)
+  truth = _dataset(rs, tdims, sizes, coords, dtype, nan_frac / 2, inf_frac / 2)
   regions = {f'r{i}': _random_region(rs, lat, lon) for i in range(3)}
   # several distinct masks in one set are grouped by the product itself
   g = helpers.to_gpu_dataset
