@@ -183,3 +183,19 @@ def test_strided_views_become_slab_tables_not_copies():
   assert x.is_contiguous() and table is None
   # irregular index: no affine view
   assert evaluation._affine_time_view(base, 0, np.array([[0, 2, 5]])) is None
+
+
+def test_public_get_lat_weights_matches_the_reference_known_answer():
+  # metrics_test.py:63-82 through the product's public function
+  import numpy as np
+  from weatherbench2_amd import metrics as gm, xarray_lite as xl
+  lat = np.array([-75.0, -45.0, -15.0, 15.0, 45.0, 75.0])
+  ds = xl.Dataset({'z': xl.DataArray(np.zeros((6, 2)), ('latitude',
+                                                         'longitude'))},
+                  {'latitude': lat, 'longitude': np.array([0.0, 180.0])})
+  w = gm.get_lat_weights(ds)
+  assert w.dims == ('latitude',)
+  expected = 3 * np.array([1 - np.sqrt(3) / 2, (np.sqrt(3) - 1) / 2, 0.5, 0.5,
+                           (np.sqrt(3) - 1) / 2, 1 - np.sqrt(3) / 2])
+  np.testing.assert_allclose(w.values, expected, rtol=1e-12)
+  np.testing.assert_allclose(w.values.mean(), 1.0)

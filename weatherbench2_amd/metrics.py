@@ -596,6 +596,18 @@ def _common_vars(forecast, truth):
 # ---------------------------------------------------------------------------
 # Metric classes (metrics.py:84-414)
 # ---------------------------------------------------------------------------
+def get_lat_weights(ds) -> xl.DataArray:
+  """Latitude/area weights of a dataset's latitude coordinate, normalised to
+  mean 1 (metrics.py:55-60; same signature: a Dataset in, a DataArray over
+  `latitude` out).  Host work, bit-identical NumPy ops (`plan.get_lat_weights`)."""
+  given = ds
+  ds = xl.as_dataset(ds)
+  lat = np.asarray(ds.coords['latitude'])
+  out = xl.DataArray(plan_lib.get_lat_weights(lat), ('latitude',),
+                     {'latitude': lat}, 'latitude')
+  return xl.like_input(out, given)
+
+
 def _returns_like_input(fn):
   """xarray in -> xarray out at the public entry points (xarray_lite.like_input);
   calls between metrics pass lite Datasets and skip the conversion."""
