@@ -3,7 +3,8 @@ random grid sizes (odd widths take the scalar-load path), dim orders, dtypes,
 NaN patterns, skipna, region sets (label slices, lists of slices,
 extra-tropics, land masks with thresholds, combinations), truth broadcast
 over extra forecast dims -- 160 deterministic + 60 ensemble cases here, then maps / Gaussian / rank
-histogram (40), threshold family (30), spectrum (24) and reductions (30)."""
+histogram (40), threshold family (30), spectrum (24), reductions (30) and
+SEEPS with values exactly on the category boundaries (20)."""
 import numpy as np
 import pytest
 
@@ -404,3 +405,57 @@ def test_reductions_fuzz(seed):
     helpers.assert_close(_values(got[key]),
                          want[key].transpose(*got[key].dims).data,
                          err_msg=f'seed={seed} {key} {dims}', **tol)
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_seeps_fuzz(seed):
+  """SEEPS / SpatialSEEPS on random precipitation with values sitting EXACTLY
+  on the dry and wet thresholds (the category boundaries of metrics.py:
+  444-460), NaNs, masked dry fractions and random regions."""
+  from weatherbench2_amd import metrics as gm
+  rs = np.random.RandomState(7000 + seed)
+  lat, lon = _grid(rs)
+  name = 'total_precipitation_24hr'
+  n_time = int(rs.randint(1, 4))
+  t0 = np.datetime64('2022-03-01T00', 'ns')
+  time = t0 + np.arange(n_time) * np.timedelta64(24, 'h')
+  spatial = (('latitude', 'longitude') if rs.rand() < 0.6
+             else ('longitude', 'latitude'))
+  sshape = tuple(len(lat) if d == 'latitude' else len(lon) for d in spatial)
+  dtype = np.float32
+  dry = np.float32(0.25 / 1000.0)
+  wet = (rs.uniform(0.002, 0.02, size=(4, 3) + sshape)).astype(dtype)
+  frac = rs.uniform(0.0, 1.0, size=(4, 3) + sshape).astype(dtype)
+
+  def precip():
+    x = (rs.gamma(0.3, 2.0, size=(n_time,) + sshape) * 1e-2).astype(dtype)
+    pick = rs.rand(*x.shape)
+    x = np.where(pick < 0.1, dry, x)                      # exactly dry
+    x = np.where((pick >= 0.1) & (pick < 0.2), wet[0, 0][None], x)  # exactly wet
+    x = np.where(pick > 0.97, np.nan, x)
+    return x.astype(dtype)
+  dims = ('time',) + spatial
+  coords = {'time': time, 'latitude': lat, 'longitude': lon,
+            'valid_time': NA(time, ('time',))}  # SEEPS reads da.valid_time
+  forecast = DS({name: NA(precip(), dims)}, coords)
+  truth = DS({name: NA(precip(), dims)}, coords)
+  cdims = ('hour', 'dayofyear') + spatial
+  clim = DS({name + '_seeps_threshold': NA(wet, cdims),
+             name + '_seeps_dry_fraction': NA(frac, cdims)},
+            {'hour': np.array([0, 6, 12, 18]),
+             'dayofyear': np.array([60, 61, 62]), 'latitude': lat,
+             'longitude': lon})
+  g = helpers.to_gpu_dataset
+  region = _random_region(rs, lat, lon)
+  want = om.SEEPS(climatology=clim).compute_chunk(forecast, truth,
+                                                  region=region)[name]
+  got = gm.SEEPS(climatology=g(clim)).compute_chunk(
+      g(forecast), g(truth), region=helpers.to_gpu_region(region))[name]
+  assert got.dims == want.dims
+  helpers.assert_close(got.values, want.data, rtol=2e-6, atol=1e-7,
+                       err_msg=f'seed={seed} SEEPS')
+  wmap = om.SpatialSEEPS(climatology=clim).compute_chunk(forecast, truth)[name]
+  gmap = gm.SpatialSEEPS(climatology=g(clim)).compute_chunk(g(forecast),
+                                                            g(truth))[name]
+  helpers.assert_close(_values(gmap), wmap.transpose(*gmap.dims).data,
+                       rtol=2e-6, atol=1e-7, err_msg=f'seed={seed} SpatialSEEPS')
