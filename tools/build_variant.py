@@ -1,0 +1,41 @@
+"""Builds an A/B variant of libwb2hip.so for kernel tuning on the GPU box.
+
+  python tools/build_variant.py NAME SOURCE.hip [-DFLAG=V ...]
+
+compiles SOURCE with the extra flags and links it with the default objects of
+every other translation unit into build/variants/libwb2hip_NAME.so (git-ignored,
+travels with gpurun).  Select it with WB2HIP_LIB=<path> (see _lib.lib_path).
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from weatherbench2_amd import build as b  # noqa: E402
+
+
+def main():
+  name, src = sys.argv[1], sys.argv[2]
+  extra = sys.argv[3:]
+  b.build(force=False, verbose=False)  # default objects in build/obj
+  obj_dir = os.path.join(ROOT, 'build', 'obj')
+  var_dir = os.path.join(ROOT, 'build', 'variants')
+  os.makedirs(var_dir, exist_ok=True)
+  flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
+           '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + b.CSRC]
+  obj = os.path.join(var_dir, f'{name}.o')
+  subprocess.run([b._hipcc()] + flags + extra +
+                 ['-c', os.path.join(b.CSRC, src), '-o', obj], check=True)
+  objs = [obj if os.path.basename(s) == src else
+          os.path.join(obj_dir, os.path.basename(s) + '.o')
+          for s in b.sources()]
+  out = os.path.join(var_dir, f'libwb2hip_{name}.so')
+  subprocess.run([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC',
+                  '-o', out] + objs + ['-L/opt/rocm/lib', '-lhipfft'],
+                 check=True)
+  print(out)
+
+
+if __name__ == '__main__':
+  main()

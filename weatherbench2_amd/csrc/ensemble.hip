@@ -168,26 +168,58 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   T sum = 0, sk = 0;
   int n = 0;          // valid members (SKIPNA)
   bool bad = false;   // any NaN member (!SKIPNA)
+  // Exact member count, no NaN skipping, float32: the differences t - x and
+  // x - mean and the squares are taken two members at a time with packed fp32
+  // instructions (same IEEE operations, so bit-identical to the scalar form);
+  // the sums stay sequential in member order like numpy's, and one unordered
+  // compare per member PAIR finds the NaNs.
+  constexpr bool PACKED = MS > 0 && !SKIPNA && sizeof(T) == 4 && MS % 2 == 0;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  T sq = 0;
+  T mean;
+  if constexpr (PACKED) {
 #pragma unroll
-  for (int m = 0; m < NM; ++m) {
-    const bool isn = is_nan(x[m]);
-    const bool use = live(m) && (SKIPNA ? !isn : true);
-    sum += use ? x[m] : (T)0;
-    sk += use ? abs_of(t - x[m]) : (T)0;
-    n += use ? 1 : 0;
-    bad = bad || (live(m) && isn);
+    for (int m = 0; m < NM; m += 2) {
+      const f2 xx = {(float)x[m], (float)x[m + 1]};
+      const f2 d = f2{(float)t, (float)t} - xx;
+      sum += x[m];
+      sum += x[m + 1];
+      sk += abs_of((T)d.x);
+      sk += abs_of((T)d.y);
+      bad = bad || __builtin_isunordered(x[m], x[m + 1]);
+    }
+    mean = sum / (T)M;
+#pragma unroll
+    for (int m = 0; m < NM; m += 2) {
+      const f2 xx = {(float)x[m], (float)x[m + 1]};
+      const f2 d = xx - f2{(float)mean, (float)mean};
+      const f2 q = d * d;
+      sq += (T)q.x;
+      sq += (T)q.y;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const bool isn = is_nan(x[m]);
+      const bool use = live(m) && (SKIPNA ? !isn : true);
+      sum += use ? x[m] : (T)0;
+      sk += use ? abs_of(t - x[m]) : (T)0;
+      n += use ? 1 : 0;
+      bad = bad || (live(m) && isn);
+    }
   }
   const int cnt = SKIPNA ? n : M;
   // metrics.py:562-565 / :824 -- numpy mean / var(ddof=1) / mean(abs) over the
   // leading (member) axis: sequential, in the input dtype (nan* variants reduce
   // over the valid members only).
-  const T mean = sum / (T)cnt;
-  T sq = 0;
+  if constexpr (!PACKED) {
+    mean = sum / (T)cnt;
 #pragma unroll
-  for (int m = 0; m < NM; ++m) {
-    const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
-    const T d = x[m] - mean;
-    sq += use ? d * d : (T)0;
+    for (int m = 0; m < NM; ++m) {
+      const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
+      const T d = x[m] - mean;
+      sq += use ? d * d : (T)0;
+    }
   }
   T var = sq / (T)(cnt - 1);
   if (SKIPNA && cnt <= 1) var = nan;
@@ -218,7 +250,13 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
       s = __builtin_fma((double)(2 * (m + 1) - M - 1), use ? (double)x[m] : 0.0,
                         s);
     }
-    spread = 2.0 * (s / (double)cnt) / (double)(M - 1);
+    if constexpr (MS > 0 && !SKIPNA) {
+      // compile-time member count: 2 / (M (M - 1)) is one constant (<= 2 ulp of
+      // fp64 away from the two divisions, far inside the summation noise)
+      spread = s * (2.0 / ((double)MS * (double)(MS - 1)));
+    } else {
+      spread = 2.0 * (s / (double)cnt) / (double)(M - 1);
+    }
     if (!SKIPNA && bad) spread = (double)nan;  // a NaN member poisons the mean
   }
   if constexpr (!SKIPNA) {

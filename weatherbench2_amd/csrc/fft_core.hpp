@@ -1,0 +1,368 @@
+// Per-lane building blocks of the LDS real FFT of K4f (spectrum_fused.hip).
+//
+// Everything here is __host__ __device__ and free of wave intrinsics, so the
+// exact code the kernel runs per lane can also be executed on the CPU by a
+// lane-by-lane emulation (tools/fft_host_check.hip, tests/test_fft_core_cpu.py):
+// index maps, twiddle tables, composite butterflies and the real-FFT
+// recombination are checked against numpy without a GPU.
+//
+// Arithmetic contract (ZonalEnergySpectrum.compute,
+// /root/reference/weatherbench2/derived_variables.py:592-626): np.fft.rfft(x,
+// norm='forward') of a float32 row is a complex64 transform; here the row is
+// transformed as N/2 complex points z[m] = x[2m] + i x[2m+1] with a Stockham
+// FFT in float32 and recombined, see recombine_pair().
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace wb2 {
+namespace fftcore {
+
+#define WB2_HD __host__ __device__ __forceinline__
+
+typedef float cf __attribute__((ext_vector_type(2)));   // (re, im)
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLanes = 64;  // a wavefront on gfx950
+
+// ---- compile-time cos / sin of 2 pi m / r (Taylor series on (-pi, pi]) ------
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double taylor_sin(double x) {
+  double term = x, sum = x;
+  for (int n = 1; n < 20; ++n) {
+    term *= -x * x / (double)((2 * n) * (2 * n + 1));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double taylor_cos(double x) {
+  double term = 1.0, sum = 1.0;
+  for (int n = 1; n < 20; ++n) {
+    term *= -x * x / (double)((2 * n - 1) * (2 * n));
+    sum += term;
+  }
+  return sum;
+}
+constexpr int reduce_turn(int m, int r) {
+  int mm = ((m % r) + r) % r;
+  if (2 * mm > r) mm -= r;
+  return mm;
+}
+constexpr double unit_cos(int m, int r) {
+  return taylor_cos(2.0 * kPi * (double)reduce_turn(m, r) / (double)r);
+}
+constexpr double unit_sin(int m, int r) {
+  return taylor_sin(2.0 * kPi * (double)reduce_turn(m, r) / (double)r);
+}
+
+// ---- compile-time loop -------------------------------------------------------
+template <int I>
+struct Idx {
+  static constexpr int value = I;
+};
+template <int I, int N, typename F>
+WB2_HD void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(Idx<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---- complex helpers ---------------------------------------------------------
+WB2_HD cf dup_x(cf a) { return __builtin_shufflevector(a, a, 0, 0); }
+WB2_HD cf dup_y(cf a) { return __builtin_shufflevector(a, a, 1, 1); }
+WB2_HD cf vfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+WB2_HD cf splat(float s) { return cf{s, s}; }
+// Multiplications by -i / +i as ONE packed multiply of the swapped operand with a
+// literal sign pair: a half-negated vector (a.y, -a.x) costs hipcc a v_xor and
+// a v_mov, while swaps (op_sel) and literal operands are free.
+WB2_HD cf swap_xy(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
+WB2_HD cf mul_neg_i(cf a) { return swap_xy(a) * cf{1.0f, -1.0f}; }  // a * (-i)
+WB2_HD cf mul_pos_i(cf a) { return swap_xy(a) * cf{-1.0f, 1.0f}; }  // a * (+i)
+// m + s * (-i) * d  for a real scalar s: one packed FMA
+WB2_HD cf add_neg_i(cf m, cf d, float s) {
+  return vfma(swap_xy(d), cf{s, -s}, m);
+}
+
+// a * w: one packed multiply + one packed FMA (w and its rotation i*w are
+// separate operands; for compile-time w both are literals)
+WB2_HD cf cmul(cf a, cf w) {
+  const cf wr = {-w.y, w.x};
+  return vfma(dup_y(a), wr, dup_x(a) * w);
+}
+
+// a * exp(-2 pi i M / R) for compile-time M, R
+template <int M, int R>
+WB2_HD cf mul_w(cf a) {
+  constexpr int m = ((M % R) + R) % R;
+  if constexpr (m == 0) {
+    return a;
+  } else if constexpr (4 * m == R) {
+    return mul_neg_i(a);
+  } else if constexpr (2 * m == R) {
+    return -a;
+  } else if constexpr (4 * m == 3 * R) {
+    return mul_pos_i(a);
+  } else {
+    constexpr float c = (float)unit_cos(m, R), s = (float)(-unit_sin(m, R));
+    const cf w = {c, s}, wr = {-s, c};
+    return vfma(dup_y(a), wr, dup_x(a) * w);
+  }
+}
+
+// ---- butterflies: in-place DFT of R points, X[k] = sum_n a[n] exp(-2 pi i nk/R)
+template <int R>
+struct Radix;
+
+template <>
+struct Radix<2> {
+  static WB2_HD void run(cf (&a)[2]) {
+    const cf t = a[0] - a[1];
+    a[0] = a[0] + a[1];
+    a[1] = t;
+  }
+};
+template <>
+struct Radix<3> {
+  static WB2_HD void run(cf (&a)[3]) {
+    constexpr float c = 0.86602540378443864676f;  // sin(pi/3)
+    const cf s = a[1] + a[2], d = a[1] - a[2];
+    const cf m = vfma(splat(-0.5f), s, a[0]);
+    a[0] = a[0] + s;
+    a[1] = add_neg_i(m, d, c);
+    a[2] = add_neg_i(m, d, -c);
+  }
+};
+template <>
+struct Radix<4> {
+  static WB2_HD void run(cf (&a)[4]) {
+    const cf t0 = a[0] + a[2], t1 = a[0] - a[2], t2 = a[1] + a[3];
+    const cf d = a[1] - a[3];
+    a[0] = t0 + t2;
+    a[1] = add_neg_i(t1, d, 1.0f);
+    a[2] = t0 - t2;
+    a[3] = add_neg_i(t1, d, -1.0f);
+  }
+};
+template <>
+struct Radix<5> {
+  static WB2_HD void run(cf (&a)[5]) {
+    constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const cf s14 = a[1] + a[4], d14 = a[1] - a[4];
+    const cf s23 = a[2] + a[3], d23 = a[2] - a[3];
+    const cf m1 = vfma(splat(c2), s23, vfma(splat(c1), s14, a[0]));
+    const cf m2 = vfma(splat(c1), s23, vfma(splat(c2), s14, a[0]));
+    const cf q1 = vfma(splat(s2), d23, splat(s1) * d14);
+    const cf q2 = vfma(splat(-s1), d23, splat(s2) * d14);
+    a[0] = a[0] + s14 + s23;
+    a[1] = add_neg_i(m1, q1, 1.0f);
+    a[4] = add_neg_i(m1, q1, -1.0f);
+    a[2] = add_neg_i(m2, q2, 1.0f);
+    a[3] = add_neg_i(m2, q2, -1.0f);
+  }
+};
+
+// R = A * B (Cooley-Tukey inside the registers of one lane): input index
+// n = B n1 + n2, output index k = k1 + A k2,
+//   X[k1 + A k2] = sum_n2 W_B^(n2 k2) W_R^(n2 k1) sum_n1 a[B n1 + n2] W_A^(n1 k1)
+template <int A, int B>
+struct Composite {
+  static WB2_HD void run(cf (&a)[A * B]) {
+    cf y[B][A];
+    static_for<0, B>([&](auto n2c) {
+      constexpr int n2 = decltype(n2c)::value;
+      cf t[A];
+#pragma unroll
+      for (int n1 = 0; n1 < A; ++n1) t[n1] = a[B * n1 + n2];
+      Radix<A>::run(t);
+      static_for<0, A>([&](auto k1c) {
+        constexpr int k1 = decltype(k1c)::value;
+        y[n2][k1] = mul_w<n2 * k1, A * B>(t[k1]);
+      });
+    });
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) {
+      cf u[B];
+#pragma unroll
+      for (int n2 = 0; n2 < B; ++n2) u[n2] = y[n2][k1];
+      Radix<B>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < B; ++k2) a[k1 + A * k2] = u[k2];
+    }
+  }
+};
+template <> struct Radix<6> : Composite<2, 3> {};
+template <> struct Radix<8> : Composite<2, 4> {};
+template <> struct Radix<10> : Composite<2, 5> {};
+template <> struct Radix<12> : Composite<4, 3> {};
+template <> struct Radix<16> : Composite<4, 4> {};
+
+// ---- pass plans: N2 = product of up to three radices --------------------------
+// Chosen so that every pass has at most a few rounds of <= 64 butterflies and
+// (for the sizes that matter: 0.25 / 0.5 degree grids) nearly full lanes:
+// 720 = 12 x 12 x 5 -> 60, 60 and 3 x 48 lanes.
+template <int N2>
+struct Plan;
+#define WB2_FFT_PLAN(N2_, A_, B_, C_)              \
+  template <>                                      \
+  struct Plan<N2_> {                               \
+    static constexpr int R0 = A_, R1 = B_, R2 = C_; \
+    static_assert(A_ * B_ * C_ == N2_, "plan");    \
+  };
+WB2_FFT_PLAN(32, 4, 8, 1)
+WB2_FFT_PLAN(64, 8, 8, 1)
+WB2_FFT_PLAN(120, 4, 5, 6)
+WB2_FFT_PLAN(128, 4, 4, 8)
+WB2_FFT_PLAN(180, 5, 6, 6)
+WB2_FFT_PLAN(256, 4, 8, 8)
+WB2_FFT_PLAN(360, 6, 6, 10)
+WB2_FFT_PLAN(512, 8, 8, 8)
+WB2_FFT_PLAN(720, 12, 12, 5)
+#undef WB2_FFT_PLAN
+
+// ---- one Stockham pass of radix R; NS = product of the radices already done ---
+// Butterfly j (0 <= j < T = N2 / R), k = j mod NS:
+//   inputs   v[r] = src[j + r T] * exp(-2 pi i k r / (NS R))      r = 0..R-1
+//   outputs  dst[(j / NS) NS R + k + t NS] = DFT_R(v)[t]          t = 0..R-1
+// A lane owns the butterflies j = lane + 64 rd.  twz[m] = exp(-2 pi i m / N2).
+template <int N2, int R, int NS>
+struct Pass {
+  static constexpr int T = N2 / R;
+  static constexpr int ROUNDS = (T + kLanes - 1) / kLanes;
+  static constexpr int TWS = N2 / (NS * R);
+  static constexpr int NTW = R > 1 ? R - 1 : 1;
+  // distinct twiddle rows of this pass (k = j mod NS takes min(NS, T) values)
+  static constexpr int KP = NS < T ? NS : T;
+
+  static WB2_HD bool live(int lane, int rd) {
+    return (rd + 1) * kLanes <= T || lane + rd * kLanes < T;
+  }
+
+  // the R - 1 non-trivial twiddles of each of this lane's butterflies
+  static WB2_HD void load_twiddles(const cf* __restrict__ twz, int lane,
+                                   cf (&tw)[ROUNDS][NTW]) {
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      const int j = lane + rd * kLanes;
+      const int k = (j < T ? j : 0) % NS;
+#pragma unroll
+      for (int r = 1; r < R; ++r) tw[rd][r - 1] = twz[k * r * TWS];
+    }
+  }
+
+  // Compact table of this pass: tbl[(r - 1) KP + k] = exp(-2 pi i k r / (NS R)),
+  // filled cooperatively (`tid` of `nthread`), read back per lane and round.
+  static WB2_HD void fill_table(const cf* __restrict__ twz, cf* __restrict__ tbl,
+                                int tid, int nthread) {
+    for (int i = tid; i < (R - 1) * KP; i += nthread) {
+      const int r = i / KP + 1, k = i % KP;
+      tbl[i] = twz[k * r * TWS];
+    }
+  }
+  static WB2_HD int table_row(int lane, int rd) {
+    const int j = lane + rd * kLanes;
+    return (j < T ? j : 0) % NS;
+  }
+  static WB2_HD void load_twiddles_table(const cf* __restrict__ tbl,
+                                         const int (&row)[ROUNDS],
+                                         cf (&tw)[ROUNDS][NTW]) {
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+      for (int r = 1; r < R; ++r) tw[rd][r - 1] = tbl[(r - 1) * KP + row[rd]];
+  }
+
+  // Lanes without a butterfly in a round re-read the last one's inputs (in
+  // range, never stored): unconditional loads keep the wave free of exec
+  // branches and of the zero-fills hipcc adds for half-defined registers.
+  template <typename Load>  // Load: index -> cf
+  static WB2_HD void load(const Load& src, int lane, cf (&v)[ROUNDS][R]) {
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      const int j0 = lane + rd * kLanes;
+      const int j = (rd + 1) * kLanes <= T ? j0 : (j0 < T ? j0 : T - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[rd][r] = src(j + r * T);
+    }
+  }
+
+  static WB2_HD void twiddle(cf (&v)[ROUNDS][R], const cf (&tw)[ROUNDS][NTW]) {
+    if constexpr (NS > 1) {
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd)
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[rd][r] = cmul(v[rd][r], tw[rd][r - 1]);
+    }
+  }
+
+  static WB2_HD void butterflies(cf (&v)[ROUNDS][R]) {
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) Radix<R>::run(v[rd]);
+  }
+
+  static WB2_HD void store(cf* __restrict__ z, int lane,
+                           const cf (&v)[ROUNDS][R]) {
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      const int j = lane + rd * kLanes;
+      if (live(lane, rd)) {
+        if constexpr (NS == 1 && R % 2 == 0) {
+          // the R outputs of a first-pass butterfly are one contiguous run
+          f4* dst = reinterpret_cast<f4*>(z + j * R);
+#pragma unroll
+          for (int h = 0; h < R / 2; ++h) {
+            f4 w;
+            w.x = v[rd][2 * h].x;
+            w.y = v[rd][2 * h].y;
+            w.z = v[rd][2 * h + 1].x;
+            w.w = v[rd][2 * h + 1].y;
+            dst[h] = w;
+          }
+        } else {
+          const int k = j % NS;
+          const int j0 = (j / NS) * NS * R + k;
+#pragma unroll
+          for (int t = 0; t < R; ++t) z[j0 + t * NS] = v[rd][t];
+        }
+      }
+    }
+  }
+};
+
+// ---- real-FFT recombination ----------------------------------------------------
+// Z = FFT_{N2}(x[2m] + i x[2m+1]).  With a = Z[k], b = Z[N2 - k] (Z[N2] = Z[0]):
+//   E = (a + conj b) / 2,  O = (a - conj b) / (2i),  X[k] = E + W^k O,
+//   X[N2 - k] = conj(E - W^k O),  W = exp(-2 pi i / N).
+// `wq` = W^k * (-i) * (0.5 / N) and `half_inv_n` = 0.5 / N carry the factor 1/2
+// and the 1/N of norm='forward'; returns |X[k]|^2 and |X[N2-k]|^2 (float32,
+// like real(f_k * conj(f_k)) of a complex64 transform).
+WB2_HD void recombine_pair(cf a, cf b, cf wq, float half_inv_n, float& p1,
+                           float& p2) {
+  const cf u = vfma(b, cf{1.0f, -1.0f}, a);  // a + conj b
+  const cf v = vfma(b, cf{-1.0f, 1.0f}, a);  // a - conj b
+  const cf wv = cmul(v, wq);
+  const cf x1 = vfma(splat(half_inv_n), u, wv);
+  const cf x2 = vfma(splat(half_inv_n), u, -wv);
+  p1 = x1.x * x1.x + x1.y * x1.y;
+  p2 = x2.x * x2.x + x2.y * x2.y;
+}
+
+// The two tables a plan keeps (evaluated in fp64, rounded once):
+//   twz[j] = exp(-2 pi i j / N2)                    j = 0 .. N2-1
+//   twq[k] = exp(-2 pi i k / N) * (-i) * (0.5 / N)  k = 0 .. N2/2
+WB2_HD void table_entry_z(int j, int n2, double cs, double sn, cf& out) {
+  (void)j;
+  (void)n2;
+  out.x = (float)cs;
+  out.y = (float)(-sn);
+}
+WB2_HD void table_entry_q(int n2, double cs, double sn, cf& out) {
+  // (cs - i sn) * (-i) = -sn - i cs
+  const double s = 0.5 / (2.0 * (double)n2);
+  out.x = (float)(-sn * s);
+  out.y = (float)(-cs * s);
+}
+
+}  // namespace fftcore
+}  // namespace wb2

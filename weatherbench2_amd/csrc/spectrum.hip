@@ -274,7 +274,8 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   void* spec = ws;
   void* fft_work = ws + align_up(p->complex_bytes);
   void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
-  if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+  // (the fused time mean keeps its per-bin sample counts in 16 bits)
+  if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_time < 65536)
     return fused_spectrum_run(static_cast<const float*>(x), p->n_rows, p->n_lon,
                               circumference, n_lat, n_time, skipna, out,
                               p->tables, s);
