@@ -44,6 +44,12 @@
 #ifndef WB2_FFT_PREFETCH
 #define WB2_FFT_PREFETCH 1   // 1: issue the next row's HBM loads before pass 1
 #endif
+#ifndef WB2_FFT_DIAG
+// timing diagnostics only (wrong results): 1 / 2 skip LDS pass 1 / 2, 4 replace
+// the recombination epilogue by a token read, 8 skip pass 0's butterflies and
+// stores, 16 no global stores in the materialising kernel
+#define WB2_FFT_DIAG 0
+#endif
 #ifndef WB2_FFT_TW_LDS
 // inter-pass twiddles from an LDS table instead of VGPRs: bit 0 / 1 = pass 1 / 2
 // of the materialising kernel, bit 2 / 3 = pass 1 / 2 of the TIME kernel
@@ -250,8 +256,12 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
 #else
         fetch(t * rows_out + orow_i, v);
 #endif
+#if WB2_FFT_DIAG & 8
+        sum1[0] += (double)(v[0][0].x + v[0][R0 - 1].y);
+#else
         P0::butterflies(v);
         P0::store(z, lane, v);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
 #if WB2_FFT_PREFETCH
@@ -262,8 +272,19 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
         fetch(nrow, pf);
       }
 #endif
+#if !(WB2_FFT_DIAG & 1)
       t1.run(z, lane, s_tw1);
+#endif
+#if !(WB2_FFT_DIAG & 2)
       if constexpr (R2 > 1) t2.run(z, lane, s_tw2);
+#endif
+#if WB2_FFT_DIAG & 4
+      {
+        const cf a = z[lane];
+        sum1[0] += (double)a.x * c2;
+        if (!TIME && a.x == 1.2345f) orow[lane] = sum1[0];
+      }
+#else
       // ---- recombination + power for the bin pairs (k, N2 - k)
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
@@ -283,11 +304,16 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
             sum2[i] += k2 ? v2 : 0.0;
             cnt[i] += (k1 ? 1 : 0) + (k2 ? 0x10000 : 0);
           } else {
+#if WB2_FFT_DIAG & 16
+            if (p1 == 1.2345f) orow[k] = v1 + v2;
+#else
             __builtin_nontemporal_store(v1, orow + k);
             if (2 * k != N2) __builtin_nontemporal_store(v2, orow + N2 - k);
+#endif
           }
         }
       }
+#endif
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // time
     if constexpr (TIME) {
