@@ -56,7 +56,10 @@ struct EnsParams {
 #define WB2_ENS_ASM_MINMAX 1  // 0: __builtin_fmin/fmax (adds one canonicalize per member)
 #endif
 #ifndef WB2_ENS_PACKED_STATS
-#define WB2_ENS_PACKED_STATS 1  // 0: scalar member statistics (A/B runs)
+// 1: member statistics two members at a time with packed fp32 instructions
+// (measured round 2: 7 % fewer VALU instructions but 130 VGPRs instead of 83,
+// i.e. 3 waves per SIMD instead of 5 -- slower; so is double-buffering the rows)
+#define WB2_ENS_PACKED_STATS 0
 #endif
 #ifndef WB2_ENS_BUFFER_LOADS
 #define WB2_ENS_BUFFER_LOADS 1  // 0: global loads with a 64-bit VALU address per member
@@ -200,6 +203,17 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
       const f2 q = d * d;
       sq += (T)q.x;
       sq += (T)q.y;
+    }
+  } else if constexpr (MS > 0 && !SKIPNA && MS % 2 == 0) {
+    // exact member count without NaN skipping: one unordered compare per member
+    // PAIR finds the NaNs
+#pragma unroll
+    for (int m = 0; m < NM; m += 2) {
+      sum += x[m];
+      sk += abs_of(t - x[m]);
+      sum += x[m + 1];
+      sk += abs_of(t - x[m + 1]);
+      bad = bad || __builtin_isunordered(x[m], x[m + 1]);
     }
   } else {
 #pragma unroll
@@ -399,15 +413,10 @@ __device__ __forceinline__ void ens_point_large(
   }
 }
 
-#ifndef WB2_ENS_PREFETCH
-#define WB2_ENS_PREFETCH 1  // exact-M float32 instantiations: double-buffered rows
-#endif
-
 template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
 __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
     ens_partials_kernel(const EnsParams p) {
   constexpr int K = SKIPNA ? 10 : 6, NWF = WF ? 2 : 1;
-  constexpr bool PF = WB2_ENS_PREFETCH && MS > 0 && !SKIPNA && sizeof(T) == 4;
   constexpr int NM = MS > 0 ? MS : NPAD;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -448,27 +457,32 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
                   (long long)row0 * p.n_col + col0;
     const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + col0
                            : nullptr;
-    // the members of row r of this lane's column -> x (all loads issued before
-    // anything consumes them)
-    auto load_members = [&](int r, T (&x)[NPAD > 0 ? NPAD : 1]) {
-      const T* xrow = xrow0 + (long long)r * p.n_col;
-#pragma unroll
-      for (int m = 0; m < NPAD; ++m) {
-        if (m < NM) {
-          // runtime M: slots >= M re-read the last member (cache hit, ignored)
-          const int mm = MS > 0 ? m : (m < M ? m : M - 1);
-          x[m] = member_load<T>(xrow + mm * p.member_stride, lane_bytes);
-        } else {
-          x[m] = (T)0;
-        }
-      }
-    };
-    // v (the K pointwise values of row r) -> optional maps + the weighted sums
-    auto accumulate = [&](int r, const double (&v)[K]) {
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < nrow; ++r) {
       const long long off = (long long)r * p.n_col;
+      const T* xrow = xrow0 + off;
+      const T t = __builtin_nontemporal_load(tb + off);
       const double wr = p.w_row[row0 + r];
       double wf = 1.0;
       if constexpr (WF) wf = wfp[off];
+      double v[K];
+      if constexpr (NPAD == 0) {  // any M: streaming passes, no sort
+        ens_point_large<T, SKIPNA>(xrow, p.member_stride, lane_bytes, M, t, v);
+      } else {
+        T x[NPAD];
+#pragma unroll
+        for (int m = 0; m < NPAD; ++m) {
+          if (m < NM) {
+            // runtime M: slots >= M re-read the last member (cache hit, ignored)
+            const int mm = MS > 0 ? m : (m < M ? m : M - 1);
+            x[m] = member_load<T>(xrow + mm * p.member_stride, lane_bytes);
+          } else {
+            x[m] = (T)0;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ens_point<T, NPAD, MS, SKIPNA>(x, t, M, v);
+      }
       if (p.maps) {
         // Spatial* metrics (metrics.py:718-772, 1244-1266, 1366-1399): the
         // pointwise values themselves; with SKIPNA slots 6.. flag the NaNs.
@@ -495,50 +509,6 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
 #pragma unroll
         for (int k = 0; k < K; ++k)
           acc[1][0][k] = __builtin_fma(w2, inside ? v[k] : 0.0, acc[1][0][k]);
-      }
-    };
-    if constexpr (NPAD > 0 && PF) {
-      // Double-buffered rows: the 50-odd member loads of row r + 1 are in flight
-      // while row r is reduced and sorted, so a wave never sits idle on memory
-      // between rows (the kernel is VALU-bound: what matters is that the SIMD
-      // always has a wave with its operands in registers).
-      T xa[NPAD], xb[NPAD];
-      load_members(0, xa);
-      T ta = __builtin_nontemporal_load(tb), tbv;
-#pragma clang loop unroll(disable)
-      for (int r = 0; r < nrow; r += 2) {
-        const int r1 = r + 1 < nrow ? r + 1 : nrow - 1;
-        load_members(r1, xb);
-        tbv = __builtin_nontemporal_load(tb + (long long)r1 * p.n_col);
-        __builtin_amdgcn_sched_barrier(0);
-        double v[K];
-        ens_point<T, NPAD, MS, SKIPNA>(xa, ta, M, v);
-        accumulate(r, v);
-        if (r + 1 < nrow) {
-          const int r2 = r + 2 < nrow ? r + 2 : nrow - 1;
-          load_members(r2, xa);
-          ta = __builtin_nontemporal_load(tb + (long long)r2 * p.n_col);
-          __builtin_amdgcn_sched_barrier(0);
-          ens_point<T, NPAD, MS, SKIPNA>(xb, tbv, M, v);
-          accumulate(r + 1, v);
-        }
-      }
-    } else {
-#pragma clang loop unroll(disable)
-      for (int r = 0; r < nrow; ++r) {
-        const long long off = (long long)r * p.n_col;
-        const T t = __builtin_nontemporal_load(tb + off);
-        double v[K];
-        if constexpr (NPAD == 0) {  // any M: streaming passes, no sort
-          ens_point_large<T, SKIPNA>(xrow0 + off, p.member_stride, lane_bytes, M,
-                                     t, v);
-        } else {
-          T x[NPAD];
-          load_members(r, x);
-          __builtin_amdgcn_sched_barrier(0);
-          ens_point<T, NPAD, MS, SKIPNA>(x, t, M, v);
-        }
-        accumulate(r, v);
       }
     }
     if (p.w_col) {

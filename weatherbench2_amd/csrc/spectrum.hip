@@ -34,9 +34,11 @@ namespace wb2 {
 bool fused_spectrum_supported(int dtype, int n_lon);
 size_t fused_spectrum_table_bytes(int n_lon);
 int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s);
+size_t fused_spectrum_sched_bytes();
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
-                       int skipna, double* out, void* tables, hipStream_t s);
+                       int skipna, double* out, void* tables, void* sched,
+                       hipStream_t s);
 
 namespace {
 
@@ -251,8 +253,11 @@ int64_t wb2_spectrum_plan_workspace(void* plan) {
   size_t tw = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
   if (p->fused && wb2::fused_spectrum_table_bytes(p->n_lon) > tw)
     tw = wb2::fused_spectrum_table_bytes(p->n_lon);
+  // + the row-scheduling counters of the fused kernel (per call, so concurrent
+  // calls on different streams never share them)
   return (int64_t)(wb2::align_up(p->complex_bytes) +
-                   wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw));
+                   wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw) +
+                   wb2::align_up(wb2::fused_spectrum_sched_bytes()));
 }
 
 int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
@@ -274,11 +279,15 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   void* spec = ws;
   void* fft_work = ws + align_up(p->complex_bytes);
   void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
+  size_t tw_bytes = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
+  if (p->fused && fused_spectrum_table_bytes(p->n_lon) > tw_bytes)
+    tw_bytes = fused_spectrum_table_bytes(p->n_lon);
+  void* sched = static_cast<char*>(tw) + align_up(tw_bytes);
   // (the fused time mean keeps its per-bin sample counts in 16 bits)
   if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_time < 65536)
     return fused_spectrum_run(static_cast<const float*>(x), p->n_rows, p->n_lon,
                               circumference, n_lat, n_time, skipna, out,
-                              p->tables, s);
+                              p->tables, sched, s);
   hipfftResult rc = hipfftSetStream(p->fft, s);
   if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
     rc = hipfftSetWorkArea(p->fft, fft_work);

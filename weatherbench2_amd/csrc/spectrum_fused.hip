@@ -42,7 +42,12 @@
 #define WB2_FFT_ASM_CMUL 1   // 0: let hipcc build (-w.y, w.x) per twiddle (2 extra VALU)
 #endif
 #ifndef WB2_FFT_PREFETCH
-#define WB2_FFT_PREFETCH 1   // 1: issue the next row's HBM loads before pass 1
+// issue the next row's HBM loads before pass 1 of the current row (2 R0 extra
+// VGPRs): bit 0 = materialising kernel, bit 1 = TIME kernel
+#define WB2_FFT_PREFETCH 1
+#endif
+#ifndef WB2_FFT_DYNAMIC
+#define WB2_FFT_DYNAMIC 1   // 0: static row-strided split over the waves
 #endif
 #ifndef WB2_FFT_DIAG
 // timing diagnostics only (wrong results): 1 / 2 skip LDS pass 1 / 2, 4 replace
@@ -123,11 +128,23 @@ struct FusedParams {
   const cf* twq;   // [N2/2+1]  exp(-2 pi i k / N) * (-i) * (0.5 / N)
   const double* circ;
   double* out;
+  unsigned* sched;    // dynamic row scheduling: 8 counters, 64 B apart, zeroed
   long long n_rows;   // input rows
   long long n_time;   // TIME: input rows are [n_time][n_rows / n_time]
   int n_lat;
   int skipna;
 };
+
+// Output rows are handed out dynamically in units of kUnitRows consecutive rows
+// (TIME: one output row = n_time transforms): a wave that finishes early pulls
+// the next unit instead of idling -- with ~3 output rows per resident wave a
+// static split loses a quarter of the machine to rounding.  One counter per XCD
+// (workgroup b runs on XCD b mod 8; only speed depends on that), counter c hands
+// out the units c, c + 8, ...; the next unit is requested one unit ahead so the
+// atomic's latency never shows.
+constexpr int kSchedStride = 16;  // uints between counters (64 B)
+template <bool TIME>
+constexpr int unit_rows() { return TIME ? 1 : 8; }
 
 // A later pass (NS > 1) over the wave's slab: strided reads, twiddle multiplies,
 // butterflies, in-place writes.
@@ -200,6 +217,7 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = 4;
   constexpr int NH = N2 / 2 + 1;  // bin pairs (k, N2 - k), k = 0..N2/2
   constexpr int NIT = (NH + kWave - 1) / kWave;
+  constexpr bool PF = (WB2_FFT_PREFETCH & (TIME ? 2 : 1)) != 0;
   constexpr bool TW1_LDS = (WB2_FFT_TW_LDS & (TIME ? 4 : 1)) != 0;
   constexpr bool TW2_LDS = R2 > 1 && (WB2_FFT_TW_LDS & (TIME ? 8 : 2)) != 0;
   __shared__ cf s_twq[NH];
@@ -218,23 +236,51 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   __syncthreads();
   cf* z = s_z[wave];
   const float half_inv_n = 0.5f / (float)N;
-  const long long stride = (long long)gridDim.x * NWAVE;
   const long long nt = TIME ? p.n_time : 1;
   const long long rows_out = p.n_rows / nt;
-  long long orow_i = (long long)blockIdx.x * NWAVE + wave;
+  long long orow_i;
+#if WB2_FFT_DYNAMIC
+  constexpr int UNIT = unit_rows<TIME>();
+  const int xcd = blockIdx.x & 7;
+  unsigned tok = 0;
+  auto request = [&]() {
+    if (lane == 0) tok = atomicAdd(p.sched + xcd * kSchedStride, 1u);
+  };
+  auto granted = [&]() -> long long {  // first row of the unit just granted
+    return ((long long)__builtin_amdgcn_readfirstlane(tok) * 8 + xcd) * UNIT;
+  };
+  request();
+  orow_i = granted();
   if (orow_i >= rows_out) return;
+  long long unit_end = orow_i + UNIT < rows_out ? orow_i + UNIT : rows_out;
+  request();
+#else
+  const long long stride = (long long)gridDim.x * NWAVE;
+  orow_i = (long long)blockIdx.x * NWAVE + wave;
+  if (orow_i >= rows_out) return;
+#endif
   auto fetch = [&](long long row, cf (&v)[P0::ROUNDS][R0]) {
     const cf* src = reinterpret_cast<const cf*>(p.x + row * N);
     P0::load([&](int i) { return __builtin_nontemporal_load(src + i); }, lane,
              v);
   };
-#if WB2_FFT_PREFETCH
-  // the HBM loads of row i + 1 are in flight while row i goes through its LDS
-  // passes (2 R0 extra VGPRs)
-  cf pf[P0::ROUNDS][R0];
-  fetch(orow_i, pf);
+  // PF: the HBM loads of row i + 1 are in flight while row i goes through its
+  // LDS passes (2 R0 extra VGPRs)
+  cf pf[PF ? P0::ROUNDS : 1][PF ? R0 : 1];
+  if constexpr (PF) fetch(orow_i, pf);
+  while (true) {
+    long long onext;  // the output row after this one (>= rows_out: none)
+#if WB2_FFT_DYNAMIC
+    if (orow_i + 1 < unit_end) {
+      onext = orow_i + 1;
+    } else {
+      onext = granted();
+      unit_end = onext + UNIT < rows_out ? onext + UNIT : rows_out;
+      if (onext < rows_out) request();
+    }
+#else
+    onext = orow_i + stride;
 #endif
-  for (; orow_i < rows_out; orow_i += stride) {
     double sum1[NIT], sum2[NIT];
     int cnt[NIT];  // TIME + skipna: valid spectra, bin k (low half) / N2 - k
 #pragma unroll
@@ -248,14 +294,14 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     for (long long t = 0; t < nt; ++t) {
       {  // ---- pass 0: HBM -> butterflies -> contiguous runs in the slab
         cf v[P0::ROUNDS][R0];
-#if WB2_FFT_PREFETCH
+        if constexpr (PF) {
 #pragma unroll
-        for (int rd = 0; rd < P0::ROUNDS; ++rd)
+          for (int rd = 0; rd < P0::ROUNDS; ++rd)
 #pragma unroll
-          for (int r = 0; r < R0; ++r) v[rd][r] = pf[rd][r];
-#else
-        fetch(t * rows_out + orow_i, v);
-#endif
+            for (int r = 0; r < R0; ++r) v[rd][r] = pf[rd][r];
+        } else {
+          fetch(t * rows_out + orow_i, v);
+        }
 #if WB2_FFT_DIAG & 8
         sum1[0] += (double)(v[0][0].x + v[0][R0 - 1].y);
 #else
@@ -264,14 +310,12 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-#if WB2_FFT_PREFETCH
-      {
+      if constexpr (PF) {
         long long nrow = t * rows_out + orow_i;  // no next row: harmless re-read
         if (t + 1 < nt) nrow += rows_out;
-        else if (orow_i + stride < rows_out) nrow = orow_i + stride;
+        else if (onext < rows_out) nrow = onext;
         fetch(nrow, pf);
       }
-#endif
 #if !(WB2_FFT_DIAG & 1)
       t1.run(z, lane, s_tw1);
 #endif
@@ -329,6 +373,8 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
         }
       }
     }
+    if (onext >= rows_out) break;
+    orow_i = onext;
   }
 }
 
@@ -345,13 +391,43 @@ __global__ void fused_twiddle_kernel(cf* twz, cf* twq, int n2) {
   }
 }
 
+// Resident workgroups of a kernel on this device (occupancy x CUs), cached.
+template <typename K>
+int resident_blocks(K kernel) {
+  static int cached = 0;  // benign race: every thread computes the same value
+  if (cached > 0) return cached;
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) !=
+          hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) !=
+          hipSuccess ||
+      per_cu <= 0 || cus <= 0)
+    return WB2_FFT_MAX_BLOCKS;
+  cached = per_cu * cus;
+  return cached;
+}
+
 template <int N2>
 int launch(const FusedParams& p, hipStream_t s) {
   const long long rows_out = p.n_time > 0 ? p.n_rows / p.n_time : p.n_rows;
   long long blocks = (rows_out + 3) / 4;
-  if (blocks > WB2_FFT_MAX_BLOCKS) blocks = WB2_FFT_MAX_BLOCKS;  // row-strided waves beyond that
   WB2_REQUIRE(p.n_time < 65536, "fused time mean: n_time=%lld exceeds 65535",
               p.n_time);
+#if WB2_FFT_DYNAMIC
+  // exactly the resident set (a multiple of 8: one share per XCD counter); every
+  // wave keeps pulling units until its counter runs dry
+  const long long cap = p.n_time > 0
+                            ? resident_blocks(fused_spectrum_kernel<N2, true>)
+                            : resident_blocks(fused_spectrum_kernel<N2, false>);
+  const int unit = p.n_time > 0 ? unit_rows<true>() : unit_rows<false>();
+  blocks = (rows_out + 4 * unit - 1) / (4 * unit);
+  if (blocks > cap) blocks = cap;
+  blocks = (blocks + 7) / 8 * 8;
+  WB2_HIP_OK(hipMemsetAsync(p.sched, 0, 8 * kSchedStride * sizeof(unsigned), s));
+#else
+  if (blocks > WB2_FFT_MAX_BLOCKS) blocks = WB2_FFT_MAX_BLOCKS;  // row-strided waves beyond that
+#endif
   if (p.n_time > 0)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, true>),
                        dim3((unsigned)blocks), dim3(256), 0, s, p);
@@ -391,14 +467,20 @@ int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s) {
   return 0;
 }
 
+size_t fused_spectrum_sched_bytes() {
+  return 8 * fused::kSchedStride * sizeof(unsigned);
+}
+
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
-                       int skipna, double* out, void* tables, hipStream_t s) {
+                       int skipna, double* out, void* tables, void* sched,
+                       hipStream_t s) {
   using namespace fused;
   const int n2 = n_lon / 2;
   cf* twz = static_cast<cf*>(tables);  // filled once by fused_spectrum_tables
   cf* twq = twz + n2;
-  FusedParams p{x, twz, twq, circ, out, n_rows, n_time, n_lat, skipna};
+  FusedParams p{x,      twz,    twq,   circ, out, static_cast<unsigned*>(sched),
+                n_rows, n_time, n_lat, skipna};
   switch (n2) {
 #define WB2_CASE(N2) case N2: return launch<N2>(p, s);
     WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
