@@ -5,15 +5,29 @@
 A "step" = one fused pass of the deterministic suite (MSE + RMSE + MAE + Bias +
 ACC for the 13 predefined slice regions of scripts/evaluate.py:345-374) over a
 batch of `--units` (init, lead) units of 13 x 721 x 1440 float32 points each,
-i.e. BASELINE config 2, followed by the running init-time mean.  Forecast,
+i.e. BASELINE configs[1], followed by the running init-time mean.  Forecast,
 truth and climatology are synthetic N(0,1) and already resident in HBM when the
 timed region starts; truth and climatology slabs are gathered by index tables
 exactly like the product path does for valid_time / (dayofyear, hour).  Units
 are drawn round-robin from a pool much larger than the 256 MiB Infinity Cache.
 
-For N > 1 (torchrun, one rank per GPU) every rank evaluates its own shard of
-init-times (weak scaling) and the only exchange is one RCCL all-reduce of the
-[sum, count] accumulators at the end (evaluation.py:740-744's xbeam.Mean).
+N > 1: one rank per GPU, every rank evaluates its own shard of init-times (weak
+scaling) and the only exchange is one RCCL all-reduce of the [sum, count]
+accumulators at the end (evaluation.py:740-744's xbeam.Mean).  Launched by
+`torch.distributed.run` (RANK / WORLD_SIZE in the environment) the script is
+one rank; WITHOUT that environment `--gpus N` spawns the N ranks itself.
+
+`value` is always the deterministic suite (so the N = 1, 2, 4, 8 values form one
+scaling curve); the same JSON line carries, measured in the same process:
+  full_suite      BASELINE configs[4]: deterministic + probabilistic (50-member
+                  K3) suites over the same number of units per step, sharded
+                  the same way, both [sum, count] sets all-reduced;
+  map_allreduce   N > 1: the bandwidth-relevant all-reduce of Spatial* maps;
+  api             N = 1: the same 16-unit chunk through the drop-in API
+                  (_metric_and_region_loop, 5 metrics x 13 regions);
+  pcie_inclusive  N = 1, --pcie: inputs arriving from pinned host memory
+                  through the pipelined feeder (never `value`);
+  cpu_baseline    N = 1: the NumPy oracle on this box's host cores.
 
 Prints ONE JSON line (rank 0).
 """
@@ -22,6 +36,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -61,17 +77,18 @@ def predefined_regions():
 
 
 def measured_traffic(workload: str, **match):
-  """HBM bytes per launch of the dominant kernel as measured with rocprofv3
-  PMC counters for exactly this launch size (profiles/r01_pmc_traffic.*), or
-  None when the run uses a different configuration."""
-  try:
-    table = json.load(open(os.path.join(ROOT, 'profiles',
-                                        'r01_pmc_traffic.json')))
-    entry = table[workload]
-    if all(entry.get(k) == v for k, v in match.items()):
-      return entry['traffic_bytes']
-  except (OSError, KeyError, ValueError):
-    pass
+  """HBM bytes per launch of the dominant kernel as measured EARLIER with
+  rocprofv3 PMC counters for exactly this launch size (profiles/*pmc_traffic*,
+  not collected in this run), or None when the run uses a different
+  configuration."""
+  for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    try:
+      table = json.load(open(os.path.join(ROOT, 'profiles', name)))
+      entry = table[workload]
+      if all(entry.get(k) == v for k, v in match.items()):
+        return entry['traffic_bytes']
+    except (OSError, KeyError, ValueError):
+      pass
   return None
 
 
@@ -96,18 +113,45 @@ def ramp(step_fn, ms: float) -> None:
       pending.pop(0).synchronize()
 
 
-def cpu_baseline(seconds: float = 10.0, processes: int = 0) -> dict:
+class KernelTimer:
+  """HIP-event pairs around the dominant kernel, recorded on the launch stream
+  through engine's profiling hook."""
+
+  def __init__(self):
+    self.pairs = []
+    self.current = None
+
+  def __call__(self, when, kernel):
+    import torch
+    if when == 'begin':
+      self.current = (torch.cuda.Event(enable_timing=True),
+                      torch.cuda.Event(enable_timing=True))
+      self.current[0].record()
+    else:
+      self.current[1].record()
+      self.pairs.append(self.current)
+
+  def mean_ms(self):
+    return float(np.mean([a.elapsed_time(b) for a, b in self.pairs]))
+
+
+def cpu_baseline(seconds: float = 8.0) -> dict:
   """Times the NumPy oracle (the restated reference path: one metric x one
-  region at a time, like evaluation.py:408-435) on this box's host cores:
-  first one process, then `processes` at once ("(i) 1 process,
-  (ii) nproc processes over init-time shards"); `value` is the aggregate of
-  the multi-process leg.  Runs oracle/cpu_baseline.py in subprocesses (no
-  torch, no product code in them)."""
-  import subprocess
-  import sys
+  region at a time, like evaluation.py:408-435) on this box's host cores: one
+  process, then one process per PHYSICAL core, then one per logical core
+  (SURVEY 8d: "(i) 1 process, (ii) nproc processes over init-time shards");
+  `value` is the best aggregate.  Runs oracle/cpu_baseline.py in subprocesses
+  (no torch, no product code in them).  The process counts are capped by the
+  host's free memory (~0.6 GB per process)."""
   ncpu = os.cpu_count() or 1
-  if processes <= 0:
-    processes = max(1, min(ncpu // 2, 32))  # physical cores, memory-bound work
+  avail = None
+  try:
+    for line in open('/proc/meminfo'):
+      if line.startswith('MemAvailable:'):
+        avail = int(line.split()[1]) * 1024
+  except OSError:
+    pass
+  cap = ncpu if avail is None else max(1, int(0.5 * avail / 0.6e9))
   cmd = [sys.executable, '-m', 'oracle.cpu_baseline', '--seconds', str(seconds)]
   env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1',
              MKL_NUM_THREADS='1')
@@ -118,34 +162,44 @@ def cpu_baseline(seconds: float = 10.0, processes: int = 0) -> dict:
              for i in range(n)]
     outs = []
     for pr in procs:
-      stdout, _ = pr.communicate(timeout=seconds * 20 + 120)
+      stdout, _ = pr.communicate(timeout=seconds * 30 + 180)
       if pr.returncode != 0:
         raise RuntimeError('oracle.cpu_baseline failed')
       outs.append(json.loads(stdout.strip().splitlines()[-1]))
     return outs
 
-  one = launch(1)[0]
-  rate_1 = one['points'] / one['seconds']
-  many = launch(processes) if processes > 1 else [one]
-  rate_n = sum(o['points'] / o['seconds'] for o in many)
+  counts = sorted({1, min(cap, max(1, ncpu // 2)), min(cap, ncpu)})
+  legs = []
+  for n in counts:
+    outs = launch(n)
+    legs.append({'processes': n,
+                 'value': sum(o['points'] / o['seconds'] for o in outs),
+                 'units': sum(o['units'] for o in outs),
+                 'seconds': max(o['seconds'] for o in outs),
+                 'metrics': outs[0]['metrics'], 'regions': outs[0]['regions']})
+  best = max(legs, key=lambda l: l['value'])
+  one = legs[0]
   return {
-      'value': rate_n, 'unit': 'grid-point-evals/s', 'cores': len(many),
-      'kind': 'port', 'value_1core': rate_1,
+      'value': best['value'], 'unit': 'grid-point-evals/s',
+      'cores': best['processes'], 'kind': 'port', 'value_1core': one['value'],
+      'legs': [{'processes': l['processes'], 'value': l['value']} for l in legs],
+      'logical_cores': ncpu,
       'sample': (f'NumPy oracle (xarray-semantics restatement; the reference '
                  f'itself needs xarray, absent here): whole units of '
                  f'{N_LEV} levels x 721 x 1440 f32, {one["metrics"]} metrics x '
                  f'{one["regions"]} regions evaluated one (metric, region) at '
-                 f'a time like evaluation.py:408-435; 1 process did '
-                 f'{one["units"]} unit(s) in {one["seconds"]:.1f} s, then '
-                 f'{len(many)} single-threaded processes at once did '
-                 f'{sum(o["units"] for o in many)} units in '
-                 f'{max(o["seconds"] for o in many):.1f} s (own data each, like '
-                 f'Beam workers over init-time shards); host has {ncpu} '
-                 f'logical cores'),
+                 f'a time like evaluation.py:408-435; single-threaded '
+                 f'processes with their own data (like Beam workers over '
+                 f'init-time shards) ran for ~{seconds:.0f} s each at '
+                 + ', '.join(f'{l["processes"]} proc: {l["units"]} units in '
+                             f'{l["seconds"]:.1f} s' for l in legs)
+                 + f'; host has {ncpu} logical cores'
+                 + ('' if cap >= ncpu else f' (capped at {cap} processes by '
+                    f'free host memory)')),
   }
 
 
-def main():
+def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=200)
@@ -162,6 +216,10 @@ def main():
   ap.add_argument('--rows-per-chunk', type=int, default=0,
                   help='0 = plan.auto_rows_per_chunk (32 at the default batch)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-full-suite', action='store_true',
+                  help='skip the configs[4] (deterministic + probabilistic) leg')
+  ap.add_argument('--no-api', action='store_true',
+                  help='skip the drop-in API leg (N = 1 only)')
   ap.add_argument('--pcie', action='store_true',
                   help='also time the step with its inputs arriving from '
                        'pinned host memory (reported as pcie_inclusive, never '
@@ -175,9 +233,40 @@ def main():
                        'script with the mean fused; used for profiles/ and '
                        'DESIGN.md')
   ap.add_argument('--members', type=int, default=50)
-  args = ap.parse_args()
+  return ap.parse_args()
+
+
+def self_launch(args) -> int:
+  """`python bench.py --gpus N` outside torch.distributed.run: start the N
+  ranks (one process per GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's
+  JSON line."""
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  procs = []
+  for rank in range(args.gpus):
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+               WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port), WB2_BENCH_SELF_LAUNCHED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs.append(subprocess.Popen(
+        [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+  out, _ = procs[0].communicate()
+  rc = procs[0].returncode
+  for pr in procs[1:]:
+    rc = max(rc, pr.wait())
+  sys.stdout.write(out)
+  sys.stdout.flush()
+  return rc
+
+
+def main():
+  args = parse_args()
   if args.workload != 'deterministic':
     return secondary(args)
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    sys.exit(self_launch(args))
 
   import torch
   import torch.distributed as dist
@@ -187,8 +276,7 @@ def main():
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if args.gpus != world:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run')
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
   if os.environ.get('WB2_BENCH_SAME_GPU'):  # smoke test of N > 1 on one GPU
     local_rank = 0
   torch.cuda.set_device(local_rank)
@@ -212,12 +300,21 @@ def main():
     dist.all_reduce(host, op=op)
     return host.to(tensor.device)
 
+  def per_rank(value: float) -> list:
+    """[value of rank 0, ..., value of rank world-1] on every rank."""
+    if world == 1:
+      return [value]
+    mine = torch.zeros(world, dtype=torch.float64, device=dev)
+    mine[rank] = value
+    return [float(x) for x in all_reduce(mine).tolist()]
+
   lat = np.linspace(-90, 90, N_LAT)
   lon = np.linspace(0, 360, N_LON, endpoint=False)
   units, pool = args.units, max(args.pool, args.units)
   if not args.rows_per_chunk:
     args.rows_per_chunk = plan_lib.auto_rows_per_chunk(N_LAT, units * N_LEV)
-  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(), dev,
+  regions = predefined_regions()
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev,
                            rows_per_chunk=args.rows_per_chunk)
   gen = torch.Generator(device=dev).manual_seed(1234 + rank)
   mk = lambda: torch.randn((pool * N_LEV, N_LAT, N_LON), generator=gen,
@@ -239,17 +336,11 @@ def main():
     return fu.contiguous(), tu.contiguous(), cu.contiguous()
 
   all_tables = [tables(s) for s in range(args.warmup + args.steps)]
-  k1_events = []
+  k1_timer = KernelTimer()
 
   def step(i, timed):
     fu, tu, cu = all_tables[i]
-    if timed:
-      e0 = torch.cuda.Event(enable_timing=True)
-      e1 = torch.cuda.Event(enable_timing=True)
-      engine.K1_EVENTS = (e0, e1)
-      k1_events.append((e0, e1))
-    else:
-      engine.K1_EVENTS = None
+    engine.set_launch_hook(k1_timer if timed else None)
     metrics, _ = engine.stream_reduce(
         pl, _lib.MODE_DET_ACC, [fpool, tpool, cpool], [fu, tu, cu], n_outer,
         skipna=False)
@@ -264,40 +355,54 @@ def main():
   _ = (total / count).sum().item()
   if world > 1:
     all_reduce(torch.stack([total, count]))
+
+  def timed_region(step_fn, n_steps, accumulators):
+    """The contract's bracket: barrier + synchronize on both sides, exactly
+    n_steps steps and the path's one all-reduce inside; returns (max-over-ranks
+    seconds, this rank's seconds, GPU ms between the bracketing events)."""
+    for a in accumulators:
+      a.zero_()
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+    g0 = torch.cuda.Event(enable_timing=True)
+    g1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    g0.record()
+    for i in range(n_steps):
+      step_fn(i)
+    g1.record()
+    means = []
+    if world > 1:  # the path's only exchange: every [sum, count] pair, once
+      packed = all_reduce(torch.stack(list(accumulators)))
+      accumulators = list(packed)
+    for s_, c_ in zip(accumulators[0::2], accumulators[1::2]):
+      means.append(s_ / c_)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+      dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev),
+                            dist.ReduceOp.MAX).item())
+    for m in means:
+      assert torch.isfinite(m).all()
+    return dt, own, g0.elapsed_time(g1)
+
   # From here to the timed region the GPU never runs dry: ramp and warmup are
   # enqueued back to back and the only wait is the contract's synchronize.
   ramp(lambda: step(0, False), args.ramp_ms)
   for i in range(args.warmup):
     step(i, False)
-  total.zero_()
-  count.zero_()
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  g0 = torch.cuda.Event(enable_timing=True)
-  g1 = torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  g0.record()
-  for i in range(args.steps):
-    step(args.warmup + i, True)
-  g1.record()
-  if world > 1:
-    packed = all_reduce(torch.stack([total, count]))  # the path's only exchange
-    total, count = packed[0], packed[1]
-  mean = total / count
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  dt = time.perf_counter() - t0
-  if world > 1:
-    tmax = all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev),
-                      dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-  assert torch.isfinite(mean).all()
+  dt, own_dt, gpu_ms = timed_region(lambda i: step(args.warmup + i, True),
+                                    args.steps, [total, count])
+  engine.set_launch_hook(None)
+  rank_ms = per_rank(own_dt / args.steps * 1e3)
 
-  k1_ms = [a.elapsed_time(b) for a, b in k1_events]
+  k1_ms = [a.elapsed_time(b) for a, b in k1_timer.pairs]
   if os.environ.get('WB2_BENCH_TRACE'):  # per-launch durations (diagnostics)
     print('k1_ms', ' '.join(f'{x:.3f}' for x in k1_ms), file=sys.stderr)
   k1_avg_s = float(np.mean(k1_ms)) / 1e3
@@ -309,7 +414,7 @@ def main():
       'unit': 'grid-point-evals/s',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': dt / args.steps * 1e3,
-      'gpu_ms_per_step': g0.elapsed_time(g1) / args.steps,
+      'gpu_ms_per_step': gpu_ms / args.steps,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32 (elementwise) + f64 (sums)', 'data': 'synthetic',
       'config': {
@@ -319,6 +424,15 @@ def main():
           'units_per_step_per_gpu': units, 'pool_units': pool,
           'regions': nr, 'rows_per_chunk': args.rows_per_chunk,
           'parallelism': f'init-time shards x{world}, 1 all-reduce of [sum,count]',
+          'launcher': ('self-spawned ranks' if os.environ.get(
+              'WB2_BENCH_SELF_LAUNCHED') else
+                       'torch.distributed.run' if world > 1 else 'single process'),
+      },
+      'ranks': {
+          'world_size_seen': dist.get_world_size() if world > 1 else 1,
+          'backend': ('rccl (torch "nccl")' if backend == 'nccl' else backend)
+                     if world > 1 else None,
+          'ms_per_step_per_rank': rank_ms,
       },
       'roofline': {
           'bound': 'hbm', 'kernel': 'stream_partials_kernel<float,4,DET_ACC>',
@@ -329,42 +443,34 @@ def main():
           'algorithmic_bytes_per_launch': pts_step * BYTES_PER_PT,
           'traffic': measured_traffic('deterministic', units_per_launch=units,
                                       regions=nr),
+          'traffic_source': ('rocprofv3 FETCH_SIZE of an earlier run of this '
+                             'launch size (profiles/), not collected now'),
       },
   }
-  if rank == 0 and world == 1 and args.pcie:
-    # The same step when the boundary hands over HOST buffers: forecast, truth
-    # and climatology units cross PCIe (pinned memory, one copy stream) before
-    # the fused pass.  Reported beside `value`, never as it.
-    n_el = n_outer * N_LAT * N_LON
-    host = [torch.empty((n_el,), dtype=torch.float32).pin_memory()
-            for _ in range(3)]
-    for h in host:
-      h.normal_()
-    stage = [torch.empty((n_outer, N_LAT, N_LON), dtype=torch.float32,
-                         device=dev) for _ in range(3)]
-    reps = 5
 
-    def host_step():
-      for h, d in zip(host, stage):
-        d.view(-1).copy_(h, non_blocking=True)
-      m, _ = engine.stream_reduce(pl, _lib.MODE_DET_ACC, stage,
-                                  [None, None, None], n_outer, skipna=False)
-      engine.time_accumulate(m.view(_lib.NMETRIC * nr, units, N_LEV), 1, False,
-                             total, count)
-    engine.K1_EVENTS = None
-    host_step()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(reps):
-      host_step()
-    torch.cuda.synchronize()
-    dt_h = (time.perf_counter() - t1) / reps
-    out['pcie_inclusive'] = {
-        'value': pts_step / dt_h, 'unit': 'grid-point-evals/s',
-        'ms_per_step': dt_h * 1e3,
-        'h2d_GBps': pts_step * BYTES_PER_PT / dt_h / 1e9,
-        'note': 'inputs start in pinned host memory; serial copy + compute',
-    }
+  # ---- the un-ramped figure: the same K steps right after an idle queue ------
+  torch.cuda.synchronize()
+  time.sleep(0.05)
+  dt_cold, _, _ = timed_region(lambda i: step(args.warmup + i, False),
+                               args.steps, [total, count])
+  out['unramped'] = {
+      'value': world * pts_step * args.steps / dt_cold,
+      'ms_per_step': dt_cold / args.steps * 1e3,
+      'note': 'same K steps started from an idle queue (no ramp, no warmup)'}
+
+  # ---- BASELINE configs[4]: deterministic + probabilistic suites, sharded ----
+  if not args.no_full_suite:
+    out['full_suite'] = full_suite(args, dev, pl, step, (total, count),
+                                   timed_region, per_rank, world, rank)
+  if world > 1:
+    out['map_allreduce'] = map_allreduce(dev, all_reduce, world, backend)
+  if rank == 0 and world == 1 and not args.no_api:
+    try:
+      out['api'] = api_leg(dev, regions, units)
+    except Exception as e:  # never lose the GPU line to a secondary leg
+      out['api'] = {'error': f'{type(e).__name__}: {e}'}
+  if rank == 0 and world == 1 and args.pcie:
+    out['pcie_inclusive'] = pcie_leg(dev, pl, units, nr, total, count)
   if rank == 0:
     if world == 1 and not args.no_cpu_baseline:
       try:
@@ -380,7 +486,220 @@ def main():
                        f'{type(e).__name__}: {e})')}
     print(json.dumps(out))
   if world > 1:
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def full_suite(args, dev, pl_det, det_step, det_acc, timed_region, per_rank,
+               world, rank) -> dict:
+  """BASELINE configs[4]: every step pushes `units` (init, lead) units through
+  the deterministic suite AND `units` 50-member ensemble units through the
+  probabilistic suite (scripts/evaluate.py:496-520: crps, crps_spread,
+  crps_skill, ensemble_mean_mse, debiased, variance -- one K3 pass), each rank
+  on its own init-time shard; both [sum, count] pairs meet in ONE all-reduce."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  m = args.members
+  units = args.units
+  ens_pool = 3  # 3 x 13 x 50 x 4.15 MB = 8.1 GB >> Infinity Cache
+  pl_ens = plan_lib.build_plan(
+      np.linspace(-90, 90, N_LAT), np.linspace(0, 360, N_LON, endpoint=False),
+      plan_lib.LATLON, predefined_regions(), dev,
+      rows_per_chunk=plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+  gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+  ens = torch.randn((m, ens_pool * N_LEV, N_LAT, N_LON), generator=gen,
+                    device=dev)
+  etruth = torch.randn((ens_pool * N_LEV, N_LAT, N_LON), generator=gen,
+                       device=dev)
+  stride = ens_pool * N_LEV * N_LAT * N_LON
+  lev = torch.arange(N_LEV, device=dev, dtype=torch.int64)
+  nr = pl_ens.n_region
+  etotal = torch.zeros((_lib.NMETRIC_ENS * nr, N_LEV), dtype=torch.float64,
+                       device=dev)
+  ecount = torch.zeros_like(etotal)
+  n_steps = min(args.steps, 20)
+  etabs = []
+  for s in range(n_steps + 2):
+    u = (s * units + torch.arange(units, device=dev)) % ens_pool
+    etabs.append(((u[:, None] * N_LEV + lev[None]).reshape(-1).contiguous(),
+                  (((u + 1) % ens_pool)[:, None] * N_LEV + lev[None]
+                   ).reshape(-1).contiguous()))
+  k3_timer = KernelTimer()
+
+  def ens_step(i, timed=True):
+    et, tt = etabs[i]
+    engine.set_launch_hook(k3_timer if timed else None)
+    metrics, _ = engine.ensemble_reduce(pl_ens, ens, stride, m, et, etruth, tt,
+                                        units * N_LEV, False)
+    engine.set_launch_hook(None)
+    engine.time_accumulate(metrics.view(_lib.NMETRIC_ENS * nr, units, N_LEV), 1,
+                           False, etotal, ecount)
+
+  def both(i):
+    det_step(args.warmup + i, False)
+    ens_step(i)
+
+  ens_step(n_steps, False)
+  ens_step(n_steps + 1, False)
+  dt, own, _ = timed_region(both, n_steps, [det_acc[0], det_acc[1], etotal,
+                                            ecount])
+  pts_step = units * PTS_PER_UNIT
+  k3_s = k3_timer.mean_ms() / 1e3
+  bytes_k3 = pts_step * (m + 1) * 4.0
+  return {
+      'workload': ('BASELINE configs[4]: per step and per GPU '
+                   f'{units} units through the deterministic suite + {units} '
+                   f'{m}-member units through the probabilistic suite (K3), 13 '
+                   'regions, init-time shards, one all-reduce of both '
+                   '[sum,count] pairs'),
+      'value': world * pts_step * n_steps / dt, 'unit': 'grid-point-evals/s',
+      'steps': n_steps, 'ms_per_step': dt / n_steps * 1e3,
+      'ms_per_step_per_rank': per_rank(own / n_steps * 1e3),
+      'ensemble_kernel': {
+          'kernel': f'ens_partials_kernel<float,64,{m if m == 50 else 0}>',
+          'kernel_ms': k3_s * 1e3, 'achieved': bytes_k3 / k3_s / 1e9,
+          'frac': bytes_k3 / k3_s / 1e9 / HBM_PEAK_GBPS, 'unit': 'GB/s',
+          'algorithmic_bytes_per_launch': bytes_k3},
+  }
+
+
+def map_allreduce(dev, all_reduce, world, backend) -> dict:
+  """the only bandwidth-relevant exchange of the path, the
+  all-reduce of the (sum, count) accumulators of Spatial* maps: one variable x
+  4 leads x 13 levels x 721 x 1440 fp64 x 2 = 864 MB per rank."""
+  import torch
+  import torch.distributed as dist
+  n = 2 * 4 * N_LEV * N_LAT * N_LON
+  maps = torch.ones((n,), dtype=torch.float64, device=dev)
+  all_reduce(maps)  # warm-up (communicator set-up, code objects)
+  torch.cuda.synchronize()
+  dist.barrier()
+  reps = 3
+  t0 = time.perf_counter()
+  for _ in range(reps):
+    maps = all_reduce(maps)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / reps
+  nbytes = n * 8
+  return {'bytes_per_rank': nbytes, 'ms': dt * 1e3,
+          'algbw_GBps': nbytes / dt / 1e9,
+          'busbw_GBps': nbytes / dt / 1e9 * 2 * (world - 1) / world,
+          'backend': backend,
+          'what': 'all-reduce of SpatialMSE/MAE/Bias-style (sum, count) maps: '
+                  '4 leads x 13 levels x 721 x 1440 fp64 x 2'}
+
+
+def api_leg(dev, regions, units) -> dict:
+  """What a caller of the DROP-IN API gets: a device-resident chunk of `units`
+  (init, lead) units pushed through evaluation._metric_and_region_loop
+  (evaluation.py:388-438 signature; 5 metrics x 13 regions) per call, fresh
+  Dataset objects every call (no cross-call result reuse)."""
+  import torch
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  n_lead = 4
+  n_time = max(1, units // n_lead)
+  lat = np.linspace(-90, 90, N_LAT)
+  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  times = np.datetime64('2020-01-01T00') + np.arange(n_time) * np.timedelta64(
+      12, 'h')
+  leads = np.arange(n_lead) * np.timedelta64(6, 'h')
+  g = torch.Generator(device=dev).manual_seed(0)
+  dims = ('time', 'prediction_timedelta', 'level', 'latitude', 'longitude')
+  coords = {'time': times.astype('datetime64[ns]'),
+            'prediction_timedelta': leads.astype('timedelta64[ns]'),
+            'level': np.arange(N_LEV), 'latitude': lat, 'longitude': lon}
+  shape = (n_time, n_lead, N_LEV, N_LAT, N_LON)
+  n_var = 4  # distinct forecast chunks >> Infinity Cache
+  fs = [torch.randn(shape, device=dev, generator=g) for _ in range(n_var)]
+  t = torch.randn(shape, device=dev, generator=g)
+  truth = xl.Dataset({'z': xl.DataArray(t, dims)}, coords)
+  clim = xl.Dataset(
+      {'z': xl.DataArray(torch.randn((4, 3, N_LEV, N_LAT, N_LON), device=dev,
+                                     generator=g),
+                         ('hour', 'dayofyear', 'level', 'latitude',
+                          'longitude'))},
+      {'hour': np.array([0, 6, 12, 18]), 'dayofyear': np.array([1, 2, 3]),
+       'level': np.arange(N_LEV), 'latitude': lat, 'longitude': lon})
+  cfg = config.Eval(metrics={'mse': gm.MSE(), 'acc': gm.ACC(climatology=clim),
+                             'bias': gm.Bias(), 'mae': gm.MAE(),
+                             'rmse': gm.RMSESqrtBeforeTimeAvg()},
+                    regions=regions)
+  mean = evaluation.RunningMean('time', False, dev)
+
+  def call(i):
+    f = xl.Dataset({'z': xl.DataArray(fs[i % n_var], dims)}, coords)
+    mean.add(evaluation._metric_and_region_loop(f, truth, cfg, False,
+                                                compute_chunk=True))
+
+  for i in range(6):
+    call(i)
+  torch.cuda.synchronize()
+  reps = 40
+  t0 = time.perf_counter()
+  for i in range(reps):
+    call(i)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / reps
+  pts = n_time * n_lead * PTS_PER_UNIT
+  return {'value': pts / dt, 'unit': 'grid-point-evals/s',
+          'ms_per_step': dt * 1e3, 'units_per_call': n_time * n_lead,
+          'what': ('evaluation._metric_and_region_loop(forecast, truth, Eval('
+                   '5 metrics, 13 regions), compute_chunk=True) + RunningMean.add '
+                   'on a device-resident chunk, fresh Datasets per call')}
+
+
+def pcie_leg(dev, pl, units, nr, total, count) -> dict:
+  """The same step when the boundary hands over HOST buffers, through the
+  pipelined feeder (pinned ring + copy stream: the transfer of chunk i + 1
+  overlaps the pass over chunk i): (i) forecast, truth and climatology all
+  cross PCIe; (ii) only the forecast does, truth / climatology stay resident in
+  HBM and are gathered through slab tables.  Reported beside `value`."""
+  import torch
+  from weatherbench2_amd import _lib, engine, feeder
+  n_outer = units * N_LEV
+  shape = (n_outer, N_LAT, N_LON)
+  n_el = n_outer * N_LAT * N_LON
+  host = [torch.empty((n_el,), dtype=torch.float32).pin_memory()
+          for _ in range(3)]
+  for h in host:
+    h.normal_()
+  resident = [torch.randn(shape, device=dev) for _ in range(2)]
+  pts_step = units * PTS_PER_UNIT
+  result = {}
+  for name, n_streams in (('all_inputs_over_pcie', 3),
+                          ('forecast_over_pcie_truth_clim_resident', 1)):
+    feeders = [feeder.ChunkFeeder(shape, torch.float32, dev, depth=2)
+               for _ in range(n_streams)]
+    reps = 6
+    for f_, h in zip(feeders, host):
+      f_.submit(h)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(reps):
+      xs = []
+      for f_, h in zip(feeders, host):
+        if i + 1 < reps:
+          f_.submit(h)          # chunk i + 1 starts to move ...
+      for f_ in feeders:
+        xs.append(f_.acquire())
+      xs += resident[:3 - n_streams]
+      m, _ = engine.stream_reduce(pl, _lib.MODE_DET_ACC, xs,
+                                  [None, None, None], n_outer, skipna=False)
+      engine.time_accumulate(m.view(_lib.NMETRIC * nr, units, N_LEV), 1, False,
+                             total, count)
+      for f_ in feeders:
+        f_.release()            # ... while this pass runs
+    torch.cuda.synchronize()
+    dt_h = (time.perf_counter() - t1) / reps
+    result[name] = {
+        'value': pts_step / dt_h, 'unit': 'grid-point-evals/s',
+        'ms_per_step': dt_h * 1e3,
+        'h2d_GBps': pts_step * 4.0 * n_streams / dt_h / 1e9}
+    del feeders
+  result['note'] = ('inputs start in pinned host memory; double-buffered '
+                    'ChunkFeeder on a copy stream (weatherbench2_amd/feeder.py)')
+  return result
 
 
 def secondary(args):
@@ -394,6 +713,7 @@ def secondary(args):
   lon = np.linspace(0, 360, N_LON, endpoint=False)
   gen = torch.Generator(device=dev).manual_seed(99)
   events = []
+  timer = KernelTimer()
   if args.workload == 'ensemble':
     m = args.members
     n_slab = 13            # one unit of 13 levels per step
@@ -412,13 +732,7 @@ def secondary(args):
     bytes_per_pt = (m + 1) * 4.0
 
     def step(i, timed):
-      if timed:
-        ev = (torch.cuda.Event(enable_timing=True),
-              torch.cuda.Event(enable_timing=True))
-        engine.K1_EVENTS = ev
-        events.append(ev)
-      else:
-        engine.K1_EVENTS = None
+      engine.set_launch_hook(timer if timed else None)
       tab = tabs[i % pool]
       engine.ensemble_reduce(pl, ens, stride, m, tab, truth, tab, n_slab, False)
     kernel = f'ens_partials_kernel<float,64,{m if m == 50 else 0}>'
@@ -466,7 +780,12 @@ def secondary(args):
               'registers)' if args.workload == 'spectrum_mean' else
               'fused_spectrum_kernel<720> (LDS real FFT + power epilogue); '
               'WB2HIP_SPECTRUM_BACKEND=rocfft selects rocFFT C2C + power_kernel')
-    workload = ('BASELINE configs[3]: zonal energy spectrum of 8 units of '
+    workload = ('the time-mean pipeline of scripts/compute_zonal_energy_'
+                'spectrum.py:234 on 8 units of 13x721x1440 f32 per step: '
+                'spectrum and its mean over the 8 units in ONE kernel (4 B/pt '
+                'read, one 721-bin spectrum per row written)'
+                if args.workload == 'spectrum_mean' else
+                'BASELINE configs[3]: zonal energy spectrum of 8 units of '
                 '13x721x1440 f32 per step, per-unit spectrum materialised, then '
                 'its area-weighted latitude mean (K7; the roofline entry is the '
                 'spectrum kernel alone)')
@@ -479,7 +798,9 @@ def secondary(args):
     step(args.warmup + i, True)
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  k_s = float(np.mean([a.elapsed_time(b) for a, b in events])) / 1e3
+  engine.set_launch_hook(None)
+  pairs = events or timer.pairs
+  k_s = float(np.mean([a.elapsed_time(b) for a, b in pairs])) / 1e3
   achieved = pts * bytes_per_pt / k_s / 1e9
   print(json.dumps({
       'metric': 'grid-point-evals/sec (721x1440x13)',

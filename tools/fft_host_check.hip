@@ -51,10 +51,13 @@ double check(unsigned seed) {
   for (int i = 0; i < N; ++i)
     x[i] = (float)(rand() / (double)RAND_MAX - 0.5) * 4.0f +
            (float)std::cos(2.0 * kPi * 7 * i / N);
-  run_pass<Pass<N2, PL::R0, 1>, PL::R0, true>(z, twz, x.data());
-  run_pass<Pass<N2, PL::R1, PL::R0>, PL::R1, false>(z, twz, x.data());
-  if constexpr (PL::R2 > 1)
-    run_pass<Pass<N2, PL::R2, PL::R0 * PL::R1>, PL::R2, false>(z, twz, x.data());
+  using P0 = Pass<N2, PL::R0, 1, 1, 0, PL::PAD0>;
+  using P1 = Pass<N2, PL::R1, PL::R0, PL::R0, PL::PAD0, PL::PAD1>;
+  using P2 = Pass<N2, PL::R2, PL::R0 * PL::R1, PL::R0 * PL::R1, PL::PAD1, 0>;
+  z.assign(slab_slots<N2>(), cf{0.0f, 0.0f});
+  run_pass<P0, PL::R0, true>(z, twz, x.data());
+  run_pass<P1, PL::R1, false>(z, twz, x.data());
+  if constexpr (PL::R2 > 1) run_pass<P2, PL::R2, false>(z, twz, x.data());
   std::vector<double> got(N2 + 1, -1.0), ref(N2 + 1);
   const float half_inv_n = 0.5f / (float)N;
   constexpr int NIT = (NH + kLanes - 1) / kLanes;

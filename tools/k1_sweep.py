@@ -31,7 +31,7 @@ def child():
         tu = (((u + 7) % pool)[:, None] * 13 + lev[None]).reshape(-1).contiguous()
         cu = (((u * 5 + 3) % pool)[:, None] * 13 + lev[None]).reshape(-1).contiguous()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        engine.K1_EVENTS = (e0, e1)
+        engine.set_launch_hook(lambda w, k, e=(e0, e1): e[0 if w == "begin" else 1].record())
         engine.stream_reduce(pl, _lib.MODE_DET_ACC, [f, t, c], [fu, tu, cu], units * 13, False)
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))

@@ -204,21 +204,35 @@ template <> struct Radix<16> : Composite<4, 4> {};
 // 720 = 12 x 12 x 5 -> 60, 60 and 3 x 48 lanes.
 template <int N2>
 struct Plan;
-#define WB2_FFT_PLAN(N2_, A_, B_, C_)              \
-  template <>                                      \
-  struct Plan<N2_> {                               \
-    static constexpr int R0 = A_, R1 = B_, R2 = C_; \
-    static_assert(A_ * B_ * C_ == N2_, "plan");    \
+// PAD0 / PAD1: complex slots of padding after every R0 outputs of pass 0 / every
+// R0 R1 outputs of pass 1 in the LDS slab, chosen so that the strided 16-byte
+// and 8-byte writes of those passes hit distinct banks (720: rows of 12 -> 14
+// complex = 28 dwords, blocks of 144 -> 156; measured 18 % of the LDS cycles
+// were bank conflicts without them).  The last pass always writes compactly.
+#define WB2_FFT_PLAN(N2_, A_, B_, C_, PAD0_, PAD1_)          \
+  template <>                                                \
+  struct Plan<N2_> {                                         \
+    static constexpr int R0 = A_, R1 = B_, R2 = C_;          \
+    static constexpr int PAD0 = PAD0_, PAD1 = (C_ > 1) ? PAD1_ : 0; \
+    static_assert(A_ * B_ * C_ == N2_, "plan");              \
+    static_assert(PAD0_ % 2 == 0, "16-byte aligned runs");   \
   };
-WB2_FFT_PLAN(32, 4, 8, 1)
-WB2_FFT_PLAN(64, 8, 8, 1)
-WB2_FFT_PLAN(120, 4, 5, 6)
-WB2_FFT_PLAN(128, 4, 4, 8)
-WB2_FFT_PLAN(180, 5, 6, 6)
-WB2_FFT_PLAN(256, 4, 8, 8)
-WB2_FFT_PLAN(360, 6, 6, 10)
-WB2_FFT_PLAN(512, 8, 8, 8)
-WB2_FFT_PLAN(720, 12, 12, 5)
+WB2_FFT_PLAN(32, 4, 8, 1, 0, 0)
+WB2_FFT_PLAN(64, 8, 8, 1, 0, 0)
+WB2_FFT_PLAN(120, 4, 5, 6, 0, 0)
+WB2_FFT_PLAN(128, 4, 4, 8, 0, 0)
+WB2_FFT_PLAN(180, 5, 6, 6, 0, 0)
+WB2_FFT_PLAN(256, 4, 8, 8, 0, 0)
+WB2_FFT_PLAN(360, 6, 6, 10, 0, 0)
+WB2_FFT_PLAN(512, 8, 8, 8, 0, 0)
+#ifndef WB2_FFT_PAD720
+#define WB2_FFT_PAD720 1
+#endif
+#if WB2_FFT_PAD720
+WB2_FFT_PLAN(720, 12, 12, 5, 2, 12)
+#else
+WB2_FFT_PLAN(720, 12, 12, 5, 0, 0)
+#endif
 #undef WB2_FFT_PLAN
 
 // ---- one Stockham pass of radix R; NS = product of the radices already done ---
@@ -226,9 +240,18 @@ WB2_FFT_PLAN(720, 12, 12, 5)
 //   inputs   v[r] = src[j + r T] * exp(-2 pi i k r / (NS R))      r = 0..R-1
 //   outputs  dst[(j / NS) NS R + k + t NS] = DFT_R(v)[t]          t = 0..R-1
 // A lane owns the butterflies j = lane + 64 rd.  twz[m] = exp(-2 pi i m / N2).
-template <int N2, int R, int NS>
+// Slab layout: logical index L of the pass's INPUT lives at
+//   (L / IN_BLOCK) (IN_BLOCK + IN_PAD) + L mod IN_BLOCK
+// and its OUTPUT blocks of NS R points are OUT_PAD slots apart (0 = compact).
+template <int N2, int R, int NS, int IN_BLOCK = 1, int IN_PAD = 0,
+          int OUT_PAD = 0>
 struct Pass {
   static constexpr int T = N2 / R;
+  static_assert(IN_PAD == 0 || T % IN_BLOCK == 0, "padded input layout");
+  static constexpr int IN_STEP =  // slots between the inputs r and r + 1
+      IN_PAD == 0 ? T : (T / IN_BLOCK) * (IN_BLOCK + IN_PAD);
+  // slab slots this pass's output needs
+  static constexpr int OUT_SLOTS = (N2 / (NS * R)) * (NS * R + OUT_PAD);
   static constexpr int ROUNDS = (T + kLanes - 1) / kLanes;
   static constexpr int TWS = N2 / (NS * R);
   static constexpr int NTW = R > 1 ? R - 1 : 1;
@@ -282,8 +305,10 @@ struct Pass {
     for (int rd = 0; rd < ROUNDS; ++rd) {
       const int j0 = lane + rd * kLanes;
       const int j = (rd + 1) * kLanes <= T ? j0 : (j0 < T ? j0 : T - 1);
+      const int base =
+          IN_PAD == 0 ? j : (j / IN_BLOCK) * (IN_BLOCK + IN_PAD) + j % IN_BLOCK;
 #pragma unroll
-      for (int r = 0; r < R; ++r) v[rd][r] = src(j + r * T);
+      for (int r = 0; r < R; ++r) v[rd][r] = src(base + r * IN_STEP);
     }
   }
 
@@ -309,7 +334,7 @@ struct Pass {
       if (live(lane, rd)) {
         if constexpr (NS == 1 && R % 2 == 0) {
           // the R outputs of a first-pass butterfly are one contiguous run
-          f4* dst = reinterpret_cast<f4*>(z + j * R);
+          f4* dst = reinterpret_cast<f4*>(z + j * (R + OUT_PAD));
 #pragma unroll
           for (int h = 0; h < R / 2; ++h) {
             f4 w;
@@ -321,7 +346,7 @@ struct Pass {
           }
         } else {
           const int k = j % NS;
-          const int j0 = (j / NS) * NS * R + k;
+          const int j0 = (j / NS) * (NS * R + OUT_PAD) + k;
 #pragma unroll
           for (int t = 0; t < R; ++t) z[j0 + t * NS] = v[rd][t];
         }
@@ -329,6 +354,15 @@ struct Pass {
     }
   }
 };
+
+// Slab slots a wave needs for a row of N2 complex points (largest layout).
+template <int N2>
+constexpr int slab_slots() {
+  using PL = Plan<N2>;
+  constexpr int a = (N2 / PL::R0) * (PL::R0 + PL::PAD0);
+  constexpr int b = (N2 / (PL::R0 * PL::R1)) * (PL::R0 * PL::R1 + PL::PAD1);
+  return a > b ? (a > N2 ? a : N2) : (b > N2 ? b : N2);
+}
 
 // ---- real-FFT recombination ----------------------------------------------------
 // Z = FFT_{N2}(x[2m] + i x[2m+1]).  With a = Z[k], b = Z[N2 - k] (Z[N2] = Z[0]):

@@ -46,8 +46,12 @@
 // VGPRs): bit 0 = materialising kernel, bit 1 = TIME kernel
 #define WB2_FFT_PREFETCH 1
 #endif
+#ifndef WB2_FFT_WIDE_STORE
+#define WB2_FFT_WIDE_STORE 1  // materialising kernel: 16-byte stores of adjacent bins
+#endif
 #ifndef WB2_FFT_DYNAMIC
-#define WB2_FFT_DYNAMIC 1   // 0: static row-strided split over the waves
+#define WB2_FFT_DYNAMIC 0   // 1: rows handed out through per-XCD atomic counters
+                            // (measured round 2: slower, see profiles/r02_k4_notes.md)
 #endif
 #ifndef WB2_FFT_DIAG
 // timing diagnostics only (wrong results): 1 / 2 skip LDS pass 1 / 2, 4 replace
@@ -58,7 +62,7 @@
 #ifndef WB2_FFT_TW_LDS
 // inter-pass twiddles from an LDS table instead of VGPRs: bit 0 / 1 = pass 1 / 2
 // of the materialising kernel, bit 2 / 3 = pass 1 / 2 of the TIME kernel
-#define WB2_FFT_TW_LDS 8
+#define WB2_FFT_TW_LDS 0
 #endif
 
 namespace wb2 {
@@ -211,22 +215,23 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     fused_spectrum_kernel(const FusedParams p) {
   using PL = Plan<N2>;
   constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2;
-  using P0 = Pass<N2, R0, 1>;
-  using P1 = Pass<N2, R1, R0>;
-  using P2 = Pass<N2, R2, R0 * R1>;
+  using P0 = Pass<N2, R0, 1, 1, 0, PL::PAD0>;
+  using P1 = Pass<N2, R1, R0, R0, PL::PAD0, PL::PAD1>;
+  using P2 = Pass<N2, R2, R0 * R1, R0 * R1, PL::PAD1, 0>;
   constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = 4;
   constexpr int NH = N2 / 2 + 1;  // bin pairs (k, N2 - k), k = 0..N2/2
   constexpr int NIT = (NH + kWave - 1) / kWave;
   constexpr bool PF = (WB2_FFT_PREFETCH & (TIME ? 2 : 1)) != 0;
   constexpr bool TW1_LDS = (WB2_FFT_TW_LDS & (TIME ? 4 : 1)) != 0;
   constexpr bool TW2_LDS = R2 > 1 && (WB2_FFT_TW_LDS & (TIME ? 8 : 2)) != 0;
-  __shared__ cf s_twq[NH];
+  __shared__ __attribute__((aligned(16))) cf s_twq[NH + 1];
   __shared__ cf s_tw1[TW1_LDS ? (R1 - 1) * P1::KP : 1];
   __shared__ cf s_tw2[TW2_LDS ? (R2 - 1) * P2::KP : 1];
-  __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][N2];
+  __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][slab_slots<N2>()];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  for (int i = threadIdx.x; i < NH; i += blockDim.x) s_twq[i] = p.twq[i];
+  for (int i = threadIdx.x; i <= NH; i += blockDim.x)
+    s_twq[i] = p.twq[i < NH ? i : NH - 1];
   if constexpr (TW1_LDS) P1::fill_table(p.twz, s_tw1, threadIdx.x, blockDim.x);
   if constexpr (TW2_LDS) P2::fill_table(p.twz, s_tw2, threadIdx.x, blockDim.x);
   PassTwiddles<P1, R1, TW1_LDS> t1;
@@ -329,6 +334,44 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
         if (!TIME && a.x == 1.2345f) orow[lane] = sum1[0];
       }
 #else
+      if constexpr (!TIME && WB2_FFT_WIDE_STORE) {
+        // ---- materialising kernel: a lane owns the ADJACENT bins k0, k0 + 1
+        // (and their mirrors N2 - k0, N2 - k0 - 1), so the fp64 spectrum leaves
+        // in 16-byte stores (1 KiB per wave instruction instead of 512 B)
+        static_assert(N2 % 4 == 0, "adjacent-bin epilogue needs N2/2 even");
+        typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+        constexpr int NIT2 = (NH + 2 * kWave - 1) / (2 * kWave);
+#pragma unroll
+        for (int i = 0; i < NIT2; ++i) {
+          const int k0 = 2 * lane + i * 2 * kWave;
+          if (k0 <= N2 / 2) {
+            const f4 a01 = *reinterpret_cast<const f4*>(z + k0);
+            const cf a0 = {a01.x, a01.y}, a1 = {a01.z, a01.w};
+            const cf b0 = z[(i == 0 && k0 == 0) ? 0 : N2 - k0];
+            const cf b1 = z[N2 - k0 - 1];
+            const f4 w01 = *reinterpret_cast<const f4*>(s_twq + k0);
+            float p1a, p2a, p1b, p2b;
+            recombine_pair(a0, b0, cf{w01.x, w01.y}, half_inv_n, p1a, p2a);
+            recombine_pair(a1, b1, cf{w01.z, w01.w}, half_inv_n, p1b, p2b);
+            // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
+            const double v1a = (double)p1a * ((i == 0 && k0 == 0) ? c : c2);
+            const double v1b = (double)p1b * c2;
+            const double v2a = (double)p2a * c2, v2b = (double)p2b * c2;
+#if WB2_FFT_DIAG & 16
+            if (p1a == 1.2345f) orow[k0] = v1a + v1b + v2a + v2b;
+#else
+            if (k0 < N2 / 2) {
+              __builtin_nontemporal_store(d2{v1a, v1b},
+                                          reinterpret_cast<d2*>(orow + k0));
+              __builtin_nontemporal_store(
+                  d2{v2b, v2a}, reinterpret_cast<d2*>(orow + N2 - k0 - 1));
+            } else {  // k0 == N2 / 2: its own mirror; bin k0 + 1 belongs to k0 - 2
+              __builtin_nontemporal_store(v1a, orow + k0);
+            }
+#endif
+          }
+        }
+      } else {
       // ---- recombination + power for the bin pairs (k, N2 - k)
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
@@ -356,6 +399,7 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
 #endif
           }
         }
+      }
       }
 #endif
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

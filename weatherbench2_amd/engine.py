@@ -15,9 +15,18 @@ from weatherbench2_amd.plan import ReductionPlan
 
 _DTYPES = {torch.float32: _lib.WB2_F32, torch.float64: _lib.WB2_F64}
 
-# bench.py hook: (start, stop) torch.cuda.Event pair recorded around the K1
-# launch on the stream it is launched on (the current torch stream).
-K1_EVENTS = None
+_STAGED_UPLOAD_MIN_BYTES = 1 << 20
+
+# Profiling hook (bench.py, tools/): called as hook('begin' | 'end', kernel) on
+# the launch stream around the dominant kernel of a pass.  None in production.
+_LAUNCH_HOOK = None
+
+
+def set_launch_hook(hook):
+  """Installs (or clears, with None) the profiling hook; returns the old one."""
+  global _LAUNCH_HOOK
+  old, _LAUNCH_HOOK = _LAUNCH_HOOK, hook
+  return old
 
 
 def current_stream_ptr(device) -> int:
@@ -38,6 +47,13 @@ def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
   elif isinstance(x, np.ndarray):
     if not x.dtype.isnative:
       x = x.astype(x.dtype.newbyteorder('='))
+    if (device.type == 'cuda' and x.nbytes >= _STAGED_UPLOAD_MIN_BYTES
+        and (dtype is None or torch.from_numpy(np.empty(0, x.dtype)).dtype
+             == dtype)):
+      # big host chunks cross PCIe through the pinned staging ring on the copy
+      # stream (feeder.py) instead of a pageable, synchronous cudaMemcpy
+      from weatherbench2_amd import feeder
+      return feeder.upload(x, device)
     ten = torch.from_numpy(np.ascontiguousarray(x))
   elif hasattr(x, '__dlpack__'):
     ten = torch.from_dlpack(x)
@@ -103,8 +119,8 @@ def stream_reduce(plan: ReductionPlan, mode: int,
   seg_eoff, n_ts = plan.seg_entries(tile)
   partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
                          dtype=torch.float64, device=dev)
-  if K1_EVENTS is not None:
-    K1_EVENTS[0].record()
+  if _LAUNCH_HOOK is not None:
+    _LAUNCH_HOOK('begin', 'stream_partials')
   _lib.check(lib.wb2_stream_partials_ex(
       mode, code, int(skipna), _lib.ptr_array(inputs), _lib.ptr_array(slabs),
       n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
@@ -114,8 +130,8 @@ def stream_reduce(plan: ReductionPlan, mode: int,
       _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
       _lib.ptr(partials), stream),
               'wb2_stream_partials')
-  if K1_EVENTS is not None:
-    K1_EVENTS[1].record()
+  if _LAUNCH_HOOK is not None:
+    _LAUNCH_HOOK('end', 'stream_partials')
   metrics = torch.empty((_lib.GENERIC_KQ.get(mode, _lib.NMETRIC),
                          plan.n_region, n_outer),
                         dtype=torch.float64, device=dev)
@@ -160,8 +176,8 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
   stream = current_stream_ptr(dev)
   partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
                          dtype=torch.float64, device=dev)
-  if K1_EVENTS is not None:
-    K1_EVENTS[0].record()
+  if _LAUNCH_HOOK is not None:
+    _LAUNCH_HOOK('begin', 'ens_partials')
   if maps is not None and (maps.dtype != torch.float64 or maps.numel() !=
                            6 * n_outer * plan.n_row * plan.n_col):
     raise ValueError('maps must be float64[6, n_outer, n_row * n_col]')
@@ -173,8 +189,8 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
       _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
       _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
       _lib.ptr(partials), _lib.ptr(maps), stream), 'wb2_ens_partials_maps')
-  if K1_EVENTS is not None:
-    K1_EVENTS[1].record()
+  if _LAUNCH_HOOK is not None:
+    _LAUNCH_HOOK('end', 'ens_partials')
   metrics = torch.empty((_lib.NMETRIC_ENS, plan.n_region, n_outer),
                         dtype=torch.float64, device=dev)
   sums = (torch.empty((n_outer, plan.n_region, k), dtype=torch.float64,
