@@ -135,7 +135,7 @@ class KernelTimer:
     return float(np.mean([a.elapsed_time(b) for a, b in self.pairs]))
 
 
-def cpu_baseline(seconds: float = 8.0) -> dict:
+def cpu_baseline(seconds: float = 6.0) -> dict:
   """Times the NumPy oracle (the restated reference path: one metric x one
   region at a time, like evaluation.py:408-435) on this box's host cores: one
   process, then one process per PHYSICAL core, then one per logical core
@@ -168,7 +168,10 @@ def cpu_baseline(seconds: float = 8.0) -> dict:
       outs.append(json.loads(stdout.strip().splitlines()[-1]))
     return outs
 
-  counts = sorted({1, min(cap, max(1, ncpu // 2)), min(cap, ncpu)})
+  # 1 process, 32 (where round 1 found the memory-bandwidth knee), one per
+  # physical core, one per logical core
+  counts = sorted({1, min(cap, 32, ncpu), min(cap, max(1, ncpu // 2)),
+                   min(cap, ncpu)})
   legs = []
   for n in counts:
     outs = launch(n)
@@ -191,8 +194,8 @@ def cpu_baseline(seconds: float = 8.0) -> dict:
                  f'a time like evaluation.py:408-435; single-threaded '
                  f'processes with their own data (like Beam workers over '
                  f'init-time shards) ran for ~{seconds:.0f} s each at '
-                 + ', '.join(f'{l["processes"]} proc: {l["units"]} units in '
-                             f'{l["seconds"]:.1f} s' for l in legs)
+                 + ', '.join(f'{l["processes"]} proc: {l["units"]:.2f} units '
+                             f'in {l["seconds"]:.1f} s' for l in legs)
                  + f'; host has {ncpu} logical cores'
                  + ('' if cap >= ncpu else f' (capped at {cap} processes by '
                     f'free host memory)')),
@@ -354,7 +357,7 @@ def main():
   step(0, False)
   _ = (total / count).sum().item()
   if world > 1:
-    all_reduce(torch.stack([total, count]))
+    all_reduce(torch.cat([total.reshape(-1), count.reshape(-1)]))
 
   def timed_region(step_fn, n_steps, accumulators):
     """The contract's bracket: barrier + synchronize on both sides, exactly
@@ -375,8 +378,12 @@ def main():
     g1.record()
     means = []
     if world > 1:  # the path's only exchange: every [sum, count] pair, once
-      packed = all_reduce(torch.stack(list(accumulators)))
-      accumulators = list(packed)
+      shapes = [a.shape for a in accumulators]
+      packed = all_reduce(torch.cat([a.reshape(-1) for a in accumulators]))
+      accumulators, off = [], 0
+      for sh in shapes:
+        accumulators.append(packed[off:off + sh.numel()].reshape(sh))
+        off += sh.numel()
     for s_, c_ in zip(accumulators[0::2], accumulators[1::2]):
       means.append(s_ / c_)
     torch.cuda.synchronize()
@@ -628,6 +635,9 @@ def api_leg(dev, regions, units) -> dict:
   mean = evaluation.RunningMean('time', False, dev)
 
   def call(i):
+    # a new chunk every call: fresh Dataset objects AND no result reuse (the
+    # n_var forecast tensors come round again; results are cached per chunk)
+    gm.clear_caches()
     f = xl.Dataset({'z': xl.DataArray(fs[i % n_var], dims)}, coords)
     mean.add(evaluation._metric_and_region_loop(f, truth, cfg, False,
                                                 compute_chunk=True))

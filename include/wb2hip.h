@@ -411,6 +411,40 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
                        int32_t n_lat, int64_t n_time, int skipna, double* out,
                        void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Host-side helpers and the path's one exchange step (csrc/comm.cpp)
+ * ------------------------------------------------------------------------- */
+
+/* Latitude / area weights, normalised to mean 1: replaces get_lat_weights
+ * (weatherbench2/metrics.py:35-60).  `latitude` (HOST, increasing, degrees) and
+ * `out` (HOST, n values) have element type `dtype`; the arithmetic runs in that
+ * type like NumPy's does (metrics.py:41, 57: the weights inherit the coordinate
+ * dtype).  float64: the C library's sin -- bit-identical to NumPy where NumPy
+ * calls libm, else within 1-2 ulp; float32: NumPy's SIMD sinf differs from libm's
+ * in the last ulp, which the cell-area difference sin(upper) - sin(lower)
+ * amplifies next to the poles (<= 5e-5 relative there).  The Python host keeps
+ * using NumPy itself (plan.get_lat_weights). */
+int wb2_lat_weights(int dtype, const void* latitude, int64_t n, void* out);
+
+/* RCCL communicator for callers that do not use torch.distributed: rank 0 makes
+ * a 128-byte id (wb2_comm_unique_id), distributes it by any means (file, MPI,
+ * socket), every rank calls wb2_comm_init_rank with the device it computes on
+ * current (hipSetDevice).  `*comm_out` is an ncclComm_t. */
+int wb2_comm_unique_id(void* id128);
+int wb2_comm_init_rank(const void* id128, int32_t n_ranks, int32_t rank,
+                       void** comm_out);
+int wb2_comm_destroy(void* comm);
+
+/* The all-reduce of the temporal mean over init-time shards: replaces the
+ * combiner of xbeam.Mean (weatherbench2/evaluation.py:735-744) across ranks.
+ * sum[n], count[n] (DEV, float64, e.g. the accumulators of wb2_time_accumulate)
+ * are summed IN PLACE over all ranks of `comm` (an ncclComm_t, from
+ * wb2_comm_init_rank or any other RCCL initialisation) as one grouped RCCL
+ * operation on `stream`; the caller then divides sum / count.  Every rank must
+ * call it with the same n. */
+int wb2_time_mean_allreduce(double* sum, double* count, int64_t n, void* comm,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,36 @@ def test_seg_entry_tables():
       assert eoff[s + 1] - eoff[s] == len(tiles)
       count += len(tiles)
     assert n_ts == count
+
+
+def test_lat_weights_export_matches_numpy():
+  """wb2_lat_weights (host code, no GPU): metrics.py:35-60 in C for non-Python
+  callers; the reference's known answer (metrics_test.py:63-82) and NumPy."""
+  import ctypes
+  from weatherbench2_amd import _lib, plan
+  lib = _lib.load()
+  lat = np.array([-75.0, -45.0, -15.0, 15.0, 45.0, 75.0])
+  out = np.empty_like(lat)
+  assert lib.wb2_lat_weights(_lib.WB2_F64, lat.ctypes.data, lat.size,
+                             out.ctypes.data) == 0
+  s3 = np.sqrt(3.0)
+  np.testing.assert_allclose(
+      out, 3 * np.array([1 - s3 / 2, (s3 - 1) / 2, 0.5, 0.5, (s3 - 1) / 2,
+                         1 - s3 / 2]), rtol=1e-14)
+  for lat in (np.linspace(-90, 90, 721), np.linspace(-87.1875, 87.1875, 32)):
+    out = np.empty_like(lat)
+    assert lib.wb2_lat_weights(_lib.WB2_F64, lat.ctypes.data, lat.size,
+                               out.ctypes.data) == 0
+    np.testing.assert_allclose(out, plan.get_lat_weights(lat), rtol=1e-13)
+    lat32 = lat.astype(np.float32)
+    out32 = np.empty_like(lat32)
+    assert lib.wb2_lat_weights(_lib.WB2_F32, lat32.ctypes.data, lat32.size,
+                               out32.ctypes.data) == 0
+    assert out32.dtype == np.float32
+    np.testing.assert_allclose(out32, plan.get_lat_weights(lat32), rtol=1e-4,
+                               atol=1e-7)
+  # decreasing latitudes are an error, like the reference's assertion
+  dec = np.linspace(90, -90, 5)
+  assert lib.wb2_lat_weights(_lib.WB2_F64, dec.ctypes.data, 5,
+                             np.empty(5).ctypes.data) < 0
+  assert b'not increasing' in lib.wb2_last_error()

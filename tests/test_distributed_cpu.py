@@ -116,8 +116,12 @@ def test_select_truth_at_valid_time_matches_label_lookup():
   got = evaluation.select_truth_at_valid_time(truth, forecast)
   assert got['z'].dims == ('level', 'init_time', 'prediction_timedelta',
                            'latitude', 'longitude')
-  assert 'time' not in got.coords and got['orog'].dims == ('latitude',
-                                                           'longitude')
+  # like xarray's vectorised .sel: `time` stays as a coordinate over the
+  # indexer's dims (thresholds.py:140 reads the day of year from it)
+  assert got.coords['time'].dims == ('init_time', 'prediction_timedelta')
+  np.testing.assert_array_equal(got.coords['time'].values,
+                                got.coords['valid_time'].values)
+  assert got['orog'].dims == ('latitude', 'longitude')
   for i in range(3):
     for l in range(3):
       k = int(np.where(time == init[i] + lead[l])[0][0])

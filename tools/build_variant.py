@@ -32,7 +32,7 @@ def main():
           for s in b.sources()]
   out = os.path.join(var_dir, f'libwb2hip_{name}.so')
   subprocess.run([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC',
-                  '-o', out] + objs + ['-L/opt/rocm/lib', '-lhipfft'],
+                  '-o', out] + objs + ['-L/opt/rocm/lib', '-lhipfft', '-ldl'],
                  check=True)
   print(out)
 

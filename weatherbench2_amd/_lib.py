@@ -83,6 +83,11 @@ _SIGNATURES = {
     'wb2_spectrum_plan_workspace': (_i64, [_vp]),
     'wb2_zonal_spectrum': (_int, [_vp, _vp, _vp, _i32, _i64, _int, _vp, _vp,
                                   _vp]),
+    'wb2_lat_weights': (_int, [_int, _vp, _i64, _vp]),
+    'wb2_comm_unique_id': (_int, [_vp]),
+    'wb2_comm_init_rank': (_int, [_vp, _i32, _i32, _c.POINTER(_vp)]),
+    'wb2_comm_destroy': (_int, [_vp]),
+    'wb2_time_mean_allreduce': (_int, [_vp, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
-SOURCES = ('common.cpp', 'stream_reduce.hip', 'ensemble.hip', 'spectrum.hip',
+SOURCES = ('common.cpp', 'comm.cpp', 'stream_reduce.hip', 'ensemble.hip', 'spectrum.hip',
            'spectrum_fused.hip', 'spatial_maps.hip', 'rank_histogram.hip',
            'axis_reduce.hip')
 
@@ -33,7 +33,7 @@ def needs_rebuild() -> bool:
   t = os.path.getmtime(LIB_PATH)
   deps = sources() + [os.path.join(CSRC, h) for h in
                       ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc',
-                       'fft_core.hpp')
+                       'fft_core.hpp', 'trace.hpp')
                       ] + [os.path.join(ROOT, 'include', 'wb2hip.h')]
   return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -66,6 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
           ] + objs
   if any(s.endswith('spectrum.hip') for s in sources()):
     link += ['-L/opt/rocm/lib', '-lhipfft']
+  link += ['-ldl']
   if verbose:
     print('[wb2hip build]', ' '.join(link), file=sys.stderr)
   subprocess.run(link, check=True)

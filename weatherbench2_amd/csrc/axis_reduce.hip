@@ -19,6 +19,7 @@
 //               (coalesced), then a fixed-order wave + LDS tree.
 
 #include "common.hpp"
+#include "trace.hpp"
 #include "wb2hip.h"
 
 namespace wb2 {
@@ -271,6 +272,7 @@ int wb2_axis_moments(int dtype, const void* x, int64_t n_lead, int64_t n_red,
                      int64_t n_tail, const double* w_red, int64_t w_repeat,
                      int skipna, int n_split, double* workspace, double* sum,
                      double* sumsq, double* count, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(n_lead >= 0 && n_red >= 0 && n_tail >= 0, "bad sizes");

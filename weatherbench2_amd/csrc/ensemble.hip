@@ -22,6 +22,7 @@
 //        [skipna: 6 n(skill,mse), 7 n(spread), 8 n(var,std^2), 9 n(debiased)]
 
 #include "common.hpp"
+#include "trace.hpp"
 #include "reduce_common.hpp"
 #include "sort_networks.inc"
 #include "wb2hip.h"
@@ -784,6 +785,7 @@ int wb2_ens_partials(int dtype, int skipna, const void* ens,
                      int32_t n_ctile, const int32_t* seg_col0,
                      const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
                      double* partials, void* stream) {
+  WB2_TRACE();
   return wb2_ens_partials_maps(dtype, skipna, ens, ens_slab, truth, truth_slab,
                                n_member, member_stride, n_outer, n_row, n_col,
                                w_row, w_col, wfield, chunk_row0, chunk_nrow,
@@ -802,6 +804,7 @@ int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
                           const int32_t* seg_col0, const int32_t* seg_eoff,
                           int32_t n_seg, int32_t n_ts, double* partials,
                           double* maps, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(ens && truth && w_row && chunk_row0 && chunk_nrow && seg_col0 &&
@@ -855,6 +858,7 @@ int wb2_ens_threshold_partials(
     const int32_t* chunk_nrow, int32_t n_chunk, int32_t n_ctile,
     const int32_t* seg_col0, const int32_t* seg_eoff, int32_t n_seg,
     int32_t n_ts, double* partials, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(ens && truth && threshold && w_row && chunk_row0 && chunk_nrow &&
@@ -905,6 +909,7 @@ int wb2_ens_threshold_maps(int dtype, int skipna, const void* ens,
                            const int64_t* thr_slab, int32_t n_member,
                            int64_t member_stride, int64_t n_outer,
                            int64_t n_point, double* maps, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(ens && truth && threshold && maps, "null pointer argument");

@@ -30,6 +30,7 @@
 // HBM bound: (M + 1) * sizeof(T) read + n_bins * 8 written per sample.
 
 #include "common.hpp"
+#include "trace.hpp"
 #include "wb2hip.h"
 
 namespace wb2 {
@@ -138,6 +139,7 @@ extern "C" int wb2_rank_histogram(int dtype, const void* ens,
                                   int break_ties, uint64_t seed,
                                   const int64_t* acc_row, double* out,
                                   void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64,
               "dtype must be WB2_F32 or WB2_F64, got %d", dtype);

@@ -18,6 +18,7 @@
 // Pure streams (HBM bound); elementwise arithmetic in the input dtype.
 
 #include "common.hpp"
+#include "trace.hpp"
 #include "wb2hip.h"
 
 namespace wb2 {
@@ -175,6 +176,7 @@ int wb2_spatial_maps(int dtype, const void* forecast, const int64_t* f_slab,
                      const void* truth, const int64_t* t_slab, int64_t n_outer,
                      int64_t n_point, void* bias, void* mse, void* mae,
                      void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(forecast && truth, "null pointer argument");
@@ -207,6 +209,7 @@ int wb2_spatial_accumulate(int dtype, int skipna, const void* forecast,
                            const int64_t* t_slab, int64_t n_time,
                            int64_t n_rest, int64_t n_point, double* sum,
                            double* count, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(forecast && truth && sum && (count || !skipna),

@@ -21,6 +21,7 @@
 // (float32 power * int64 -> float64).
 
 #include "common.hpp"
+#include "trace.hpp"
 #include "wb2hip.h"
 
 #include <hipfft/hipfft.h>
@@ -181,6 +182,7 @@ extern "C" {
 
 int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
                              void** plan_out) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(plan_out, "null plan_out");
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
@@ -239,6 +241,7 @@ int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
 }
 
 int wb2_spectrum_plan_destroy(void* plan) {
+  WB2_TRACE();
   auto* p = static_cast<wb2::SpectrumPlan*>(plan);
   if (!p) return 0;
   hipfftDestroy(p->fft);
@@ -263,6 +266,7 @@ int64_t wb2_spectrum_plan_workspace(void* plan) {
 int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
                        int32_t n_lat, int64_t n_time, int skipna, double* out,
                        void* workspace, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   auto* p = static_cast<SpectrumPlan*>(plan);
   WB2_REQUIRE(p && x && circumference && out && workspace,

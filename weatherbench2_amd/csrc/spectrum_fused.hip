@@ -43,8 +43,9 @@
 #endif
 #ifndef WB2_FFT_PREFETCH
 // issue the next row's HBM loads before pass 1 of the current row (2 R0 extra
-// VGPRs): bit 0 = materialising kernel, bit 1 = TIME kernel
-#define WB2_FFT_PREFETCH 1
+// VGPRs): bit 0 = materialising kernel, bit 1 = TIME kernel.  Measured round 2:
+// no gain (the waves of a CU already overlap each other's loads), so off.
+#define WB2_FFT_PREFETCH 0
 #endif
 #ifndef WB2_FFT_WIDE_STORE
 #define WB2_FFT_WIDE_STORE 1  // materialising kernel: 16-byte stores of adjacent bins

@@ -23,6 +23,7 @@
 // and every sum is accumulated in fp64 like the promoted einsum.
 
 #include "common.hpp"
+#include "trace.hpp"
 #include "reduce_common.hpp"
 #include "wb2hip.h"
 
@@ -777,6 +778,7 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         int32_t n_ctile, const int32_t* seg_col0,
                         const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
                         double* partials, void* stream) {
+  WB2_TRACE();
   return wb2_stream_partials_ex(mode, dtype, skipna, in, slab, n_outer, n_row,
                                 n_col, w_row, w_col, wfield, nullptr, 0.0,
                                 chunk_row0, chunk_nrow, n_chunk, n_ctile,
@@ -794,6 +796,7 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
                            int32_t n_ctile, const int32_t* seg_col0,
                            const int32_t* seg_eoff, int32_t n_seg,
                            int32_t n_ts, double* partials, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC ||
                   mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS ||
@@ -862,6 +865,7 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
                     const double* coef_seg, const int32_t* region_wf,
                     const double* region_wsum, int32_t n_region, double* sums,
                     double* metrics, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_SEEPS, "unknown mode %d", mode);
   WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
@@ -914,6 +918,7 @@ int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,
                     const int32_t* region_wf, const double* region_wsum,
                     int32_t n_region, double* sums, double* metrics,
                     void* stream) {
+  WB2_TRACE();
   return wb2_det_combine(WB2_MODE_ENS, skipna, partials, n_outer, n_chunk, nwf,
                          n_seg, seg_eoff, n_ts, band_chunk0, n_band, coef_band,
                          coef_seg, region_wf, region_wsum, n_region, sums,
@@ -923,6 +928,7 @@ int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,
 int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         int64_t n_tail, int skipna, double* sum, double* count,
                         void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(values && sum && count, "null pointer argument");
   WB2_REQUIRE(n_lead >= 0 && n_time >= 0 && n_tail >= 0, "bad sizes");
@@ -939,6 +945,7 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
 int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
                   int64_t n_outer, int64_t n_point, const double* aux,
                   double scalar, double* out, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_REQUIRE(in && in[0] && in[1] && in[2] && aux && out,

@@ -5,6 +5,8 @@ every FLOP of the hot path runs in libwb2hip.so.
 """
 from __future__ import annotations
 
+import os
+import threading
 import typing as t
 
 import numpy as np
@@ -33,11 +35,46 @@ def current_stream_ptr(device) -> int:
   return torch.cuda.current_stream(device).cuda_stream
 
 
+class _ThreadStreams(threading.local):
+
+  def __init__(self):
+    self.streams: dict = {}
+
+
+_THREAD_STREAMS = _ThreadStreams()
+
+
+def _adopt_thread_stream(device: torch.device) -> None:
+  """Worker threads (Beam's DirectRunner calls compute_chunk from several,
+  evaluation.py:583-599; ctypes releases the GIL) get a HIP stream of their own
+  as their torch *current* stream the first time they reach the GPU path:
+  everything such a thread launches, allocates and reads back is then ordered
+  on its stream, and the passes of different threads overlap on the device
+  instead of queueing on the shared default stream.  The new stream starts
+  after whatever the default stream had queued at that moment (inputs made
+  resident by the main thread).  The main thread keeps the caller's stream.
+  WB2HIP_THREAD_STREAMS=0 disables."""
+  if threading.current_thread() is threading.main_thread():
+    return
+  key = (device.type, device.index)
+  if key in _THREAD_STREAMS.streams:
+    return
+  if os.environ.get('WB2HIP_THREAD_STREAMS', '1') == '0':
+    _THREAD_STREAMS.streams[key] = None
+    return
+  own = torch.cuda.Stream(device=device)
+  own.wait_stream(torch.cuda.default_stream(device))
+  torch.cuda.set_stream(own)
+  _THREAD_STREAMS.streams[key] = own
+
+
 def require_gpu() -> torch.device:
   if not torch.cuda.is_available():
     raise _lib.Wb2HipError(
         'no HIP device visible: the MI355X path has no CPU fallback')
-  return torch.device('cuda', torch.cuda.current_device())
+  device = torch.device('cuda', torch.cuda.current_device())
+  _adopt_thread_stream(device)
+  return device
 
 
 def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
@@ -64,6 +101,59 @@ def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
   if ten.device != device:
     ten = ten.to(device, non_blocking=True)
   return ten.contiguous()
+
+
+class _TableUploads(threading.local):
+  """Per-thread, per-device: content cache of uploaded int64 tables + a small
+  pinned ring for the misses."""
+
+  def __init__(self):
+    self.cache: dict = {}   # (device, bytes) -> device tensor
+    self.ring: dict = {}    # device -> [pinned slots, events, next]
+
+
+_TABLES = _TableUploads()
+_TABLE_SLOT_BYTES = 1 << 18
+
+
+def upload_table(table: np.ndarray, device) -> torch.Tensor:
+  """int64 slab table -> device tensor WITHOUT stalling the queue.
+
+  `torch.from_numpy(t).to(device)` is a synchronous pageable copy: with kernels
+  queued ahead the host blocks until the GPU has drained, once per table and
+  call.  Tables recur (same chunk geometry, same valid times), so they are
+  cached by content; a miss goes through a pinned slot with an asynchronous
+  copy on the current stream."""
+  table = np.ascontiguousarray(table, dtype=np.int64)
+  st = _TABLES
+  key = (str(device), table.shape, table.tobytes())
+  hit = st.cache.get(key)
+  if hit is not None:
+    return hit
+  nbytes = table.nbytes
+  if nbytes > _TABLE_SLOT_BYTES or nbytes == 0:
+    dev = torch.from_numpy(table).to(device)
+  else:
+    ring = st.ring.get(str(device))
+    if ring is None:
+      ring = st.ring[str(device)] = [
+          [torch.empty(_TABLE_SLOT_BYTES // 8, dtype=torch.int64).pin_memory()
+           for _ in range(8)], [None] * 8, 0]
+    slots, events, nxt = ring
+    ring[2] = (nxt + 1) % len(slots)
+    if events[nxt] is not None:
+      events[nxt].synchronize()
+    slot = slots[nxt][:table.size]
+    slot.numpy()[...] = table.reshape(-1)
+    dev = torch.empty(table.shape, dtype=torch.int64, device=device)
+    dev.view(-1).copy_(slot, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    events[nxt] = ev
+  if len(st.cache) >= 512:
+    st.cache.clear()
+  st.cache[key] = dev
+  return dev
 
 
 def _slabs_intact(x: torch.Tensor) -> bool:
@@ -229,7 +319,9 @@ class _SpectrumPlans:
 
   def get(self, dtype_code: int, n_lon: int, n_rows: int):
     import ctypes
-    key = (dtype_code, n_lon, n_rows, torch.cuda.current_device())
+    # per thread: a plan's hipFFT handle is bound to a stream while it runs
+    key = (dtype_code, n_lon, n_rows, torch.cuda.current_device(),
+           threading.get_ident())
     hit = self.plans.get(key)
     if hit is None:
       lib = _lib.load()
@@ -240,7 +332,7 @@ class _SpectrumPlans:
       nbytes = lib.wb2_spectrum_plan_workspace(handle)
       if nbytes < 0:
         _lib.check(-1, 'wb2_spectrum_plan_workspace')
-      if len(self.plans) >= 8:  # bounded: drop the oldest plan
+      if len(self.plans) >= 16:  # bounded: drop the oldest plan
         old_key = next(iter(self.plans))
         lib.wb2_spectrum_plan_destroy(self.plans.pop(old_key)[0])
       hit = (handle, int(nbytes))
@@ -456,3 +548,45 @@ def axis_moments(x: torch.Tensor, n_lead: int, n_red: int, n_tail: int,
       _lib.ptr(sq), _lib.ptr(count), current_stream_ptr(dev)),
              'wb2_axis_moments')
   return total, sq, count
+
+
+# ---------------------------------------------------------------------------
+# The path's one exchange step through the C ABI (RCCL directly, no
+# torch.distributed): for callers that bring their own rendezvous.
+# ---------------------------------------------------------------------------
+def comm_unique_id() -> bytes:
+  """128-byte RCCL id made by rank 0, to be handed to every rank."""
+  import ctypes
+  buf = ctypes.create_string_buffer(128)
+  _lib.check(_lib.load().wb2_comm_unique_id(buf), 'wb2_comm_unique_id')
+  return buf.raw
+
+
+def comm_init_rank(unique_id: bytes, n_ranks: int, rank: int):
+  """ncclComm_t (opaque handle) of this rank on the current device."""
+  import ctypes
+  if len(unique_id) != 128:
+    raise ValueError('unique_id must be the 128 bytes of comm_unique_id()')
+  handle = ctypes.c_void_p()
+  _lib.check(_lib.load().wb2_comm_init_rank(
+      ctypes.create_string_buffer(unique_id, 128), n_ranks, rank,
+      ctypes.byref(handle)), 'wb2_comm_init_rank')
+  return handle
+
+
+def comm_destroy(comm) -> None:
+  _lib.check(_lib.load().wb2_comm_destroy(comm), 'wb2_comm_destroy')
+
+
+def time_mean_allreduce(total: torch.Tensor, count: torch.Tensor, comm) -> None:
+  """In-place sum of the (sum, count) accumulators over the ranks of `comm`
+  (xbeam.Mean's combiner across init-time shards, evaluation.py:735-744), one
+  grouped RCCL operation on the current stream."""
+  for x in (total, count):
+    if x.dtype != torch.float64 or not x.is_contiguous() or not x.is_cuda:
+      raise ValueError('accumulators must be contiguous float64 device tensors')
+  if total.numel() != count.numel():
+    raise ValueError('sum / count size mismatch')
+  _lib.check(_lib.load().wb2_time_mean_allreduce(
+      _lib.ptr(total), _lib.ptr(count), total.numel(), comm,
+      current_stream_ptr(total.device)), 'wb2_time_mean_allreduce')

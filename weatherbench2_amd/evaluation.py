@@ -174,6 +174,9 @@ def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
   coords[init_dim] = init
   coords[lead_dim] = lead
   coords['valid_time'] = xl.DataArray(valid, (init_dim, lead_dim))
+  # xarray's vectorised .sel keeps the indexed coordinate, now over the
+  # indexer's dims: thresholds.py:140 reads truth['time'] from it
+  coords[time_dim] = xl.DataArray(valid, (init_dim, lead_dim))
   out = xl.Dataset(coords=coords, attrs=dict(truth.attrs))
   for name, da in truth.data_vars.items():
     if time_dim not in da.dims:
@@ -203,10 +206,13 @@ class RunningMean:
   one is initialised) and divides.
   """
 
-  def __init__(self, dim: str, skipna: bool = False, device=None):
+  def __init__(self, dim: str, skipna: bool = False, device=None, comm=None):
     self.dim = dim
     self.skipna = skipna
     self.device = device
+    # an RCCL communicator from engine.comm_init_rank: the exchange then goes
+    # through the C ABI (wb2_time_mean_allreduce) instead of torch.distributed
+    self.comm = comm
     self._acc: dict = {}     # var -> (sum, count, dims, shape)
     self._coords: dict = {}
 
@@ -224,7 +230,10 @@ class RunningMean:
     import torch
     from weatherbench2_amd import engine
     for k, c in chunk.coords.items():
-      if k != self.dim:
+      # coordinates that vary along the averaged dim go with it (valid_time of
+      # a by-init chunk), like xarray's mean
+      if k != self.dim and not (isinstance(c, xl.DataArray)
+                                and self.dim in c.dims):
         self._coords.setdefault(k, c)
     for name, da in chunk.data_vars.items():
       if self.dim not in da.dims:
@@ -258,7 +267,19 @@ class RunningMean:
     import torch.distributed as dist
     out = xl.Dataset(coords=self._coords)
     names = sorted(self._acc)
-    if dist.is_available() and dist.is_initialized() and (
+    if self.comm is not None and names:
+      from weatherbench2_amd import engine
+      flat_t = torch.cat([self._acc[n][0].reshape(-1) for n in names])
+      flat_c = torch.cat([self._acc[n][1].reshape(-1) for n in names])
+      engine.time_mean_allreduce(flat_t, flat_c, self.comm)
+      offset = 0
+      for n in names:
+        total, count, dims, shape = self._acc[n]
+        size = total.numel()
+        self._acc[n] = (flat_t[offset:offset + size].reshape(shape),
+                        flat_c[offset:offset + size].reshape(shape), dims, shape)
+        offset += size
+    elif dist.is_available() and dist.is_initialized() and (
         dist.get_world_size() > 1) and names:
       flat = torch.cat([torch.stack([self._acc[n][0], self._acc[n][1]]
                                     ).reshape(-1) for n in names])

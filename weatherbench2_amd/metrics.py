@@ -49,14 +49,43 @@ _SPATIAL = ('latitude', 'longitude')
 # region announcement + per-chunk result cache
 # ---------------------------------------------------------------------------
 class _Announced(threading.local):
-  """Per-thread stacks: what the enclosing loop announced it will ask for."""
+  """Per-thread stacks: what the enclosing loop announced it will ask for, plus
+  the per-chunk caches of that thread (Beam's DirectRunner may call
+  compute_chunk from several threads; nothing here is shared between them, so
+  no lock is needed and the passes of different threads overlap on the GPU)."""
 
   def __init__(self):
     self.regions: list = []       # (ordered {name: Region|None}, signature)
     self.climatology: list = []   # climatology Datasets of an ACC in the loop
+    self.depth = 0                # nesting of chunk scopes (fused_regions)
+    self.scoped: dict = {}        # cache name -> {key: (pins, value)}
+    self.memo: dict = {}          # per-scope memo (stamps, coordinate signatures)
+    self.groupings: list = []     # memo of fused_regions' grouping (identity)
+    self.lru: dict = {}           # cache name -> _LRU (calls outside any scope)
 
 
 _ANNOUNCED = _Announced()
+
+
+@contextlib.contextmanager
+def chunk_scope():
+  """Marks one pass of a metric x region loop over ONE (forecast, truth) chunk.
+
+  Inside the scope input arrays are taken not to change, so results, uploads
+  and aligned views are cached by identity without bound; everything is dropped
+  when the outermost scope exits -- the next chunk can reuse the same buffers
+  in place and never sees stale results (the reference's loop-local
+  `dataset_safe_lru_cache(maxsize=1)`, metrics.py:775-780, has the same
+  lifetime).  `fused_regions` opens a scope by itself."""
+  st = _ANNOUNCED
+  st.depth += 1
+  try:
+    yield
+  finally:
+    st.depth -= 1
+    if st.depth == 0:
+      st.scoped.clear()
+      st.memo.clear()
 
 
 def _field_key(region):
@@ -78,11 +107,16 @@ def _field_key(region):
   return None
 
 
-@contextlib.contextmanager
-def fused_regions(regions: t.Optional[dict]):
-  """Announce the regions a loop is about to iterate so one pass serves all
-  (one pass per distinct 2-D weight field: field-free regions ride along with
-  the first group)."""
+def _grouping(regions: t.Optional[dict]):
+  """(active, groups, member) of a region dict: one group per distinct 2-D
+  weight field.  Memoised per thread on the identity of the dict and of its
+  values (a loop announces the same dict a dozen times per chunk)."""
+  st = _ANNOUNCED
+  sig = (id(regions), tuple((k, id(v)) for k, v in regions.items())
+         if regions else None)
+  for known_sig, pinned, value in st.groupings:
+    if known_sig == sig and pinned is regions:
+      return value
   active = dict(regions) if regions else {'__none__': None}
   keys = {k: _field_key(v) for k, v in active.items()}
   distinct = []
@@ -96,9 +130,21 @@ def fused_regions(regions: t.Optional[dict]):
     for k in group:
       member[k] = gi
     groups.append((group, tuple((k, id(v)) for k, v in group.items())))
-  _ANNOUNCED.regions.append((active, groups, member))
+  value = (active, groups, member)
+  st.groupings.append((sig, regions, value))
+  del st.groupings[:-8]
+  return value
+
+
+@contextlib.contextmanager
+def fused_regions(regions: t.Optional[dict]):
+  """Announce the regions a loop is about to iterate so one pass serves all
+  (one pass per distinct 2-D weight field: field-free regions ride along with
+  the first group).  Also a `chunk_scope`: wrap exactly one chunk's loop."""
+  _ANNOUNCED.regions.append(_grouping(regions))
   try:
-    yield
+    with chunk_scope():
+      yield
   finally:
     _ANNOUNCED.regions.pop()
 
@@ -131,6 +177,9 @@ def _region_set_sig(region) -> tuple[dict, str, tuple]:
           (('__requested__', id(region)),))
 
 
+_ALL = '__all_regions__'  # by_region key: (stacked tensor, region names)
+
+
 def _fused(pass_fn, region, regions: t.Optional[dict]):
   """pass_fn(region) -> (geo, by_region, ...) for the requested region -- or,
   on the all-regions path (inside `_all_regions(regions)`), for one
@@ -138,59 +187,85 @@ def _fused(pass_fn, region, regions: t.Optional[dict]):
   if regions is None:
     return pass_fn(region)
   _, groups, _ = _ANNOUNCED.regions[-1]
+  if len(groups) == 1:  # the common case: one pass answers every region
+    return pass_fn(next(iter(groups[0][0].values())))
   out, merged = None, {}
   for group, _ in groups:
     res = pass_fn(next(iter(group.values())))
     merged.update(res[1])
     out = out or res
+  merged.pop(_ALL, None)  # the stacked tensor of ONE pass is not all regions
   return (out[0], merged) + tuple(out[2:])
 
 
-# Beam's DirectRunner may call compute_chunk from several threads (ctypes
-# releases the GIL): fused passes and their caches are serialised per process.
-_PASS_LOCK = threading.RLock()
-
-
 def _serialized(fn):
-  @functools.wraps(fn)
-  def wrapper(*args, **kwargs):
-    with _PASS_LOCK:
-      return fn(*args, **kwargs)
-  return wrapper
+  """Historical name: passes used to run under one process-wide lock.  Every
+  cache is per thread now and the kernels are stream-ordered, so this is the
+  identity (kept as a marker of the pass entry points)."""
+  return fn
 
 
 class _LRU:
+  """Small bounded cache for calls made outside any chunk scope."""
 
   def __init__(self, maxsize):
     self.maxsize = maxsize
     self.items: list = []  # (key, pins, value), most recent last
 
   def get(self, key):
-    with _PASS_LOCK:
-      for i, (k, _, v) in enumerate(self.items):
-        if k == key:
-          self.items.append(self.items.pop(i))
-          return v
-      return None
+    for i, (k, _, v) in enumerate(self.items):
+      if k == key:
+        self.items.append(self.items.pop(i))
+        return v
+    return None
 
   def put(self, key, pins, value):
-    with _PASS_LOCK:
-      self.items = [it for it in self.items if it[0] != key]
-      self.items.append((key, pins, value))
-      while len(self.items) > self.maxsize:
-        self.items.pop(0)
+    self.items = [it for it in self.items if it[0] != key]
+    self.items.append((key, pins, value))
+    while len(self.items) > self.maxsize:
+      self.items.pop(0)
 
   def clear(self):
-    with _PASS_LOCK:
-      self.items.clear()
+    self.items.clear()
 
 
-_RESULTS = _LRU(8)    # fused pass results
-_DEVICE = _LRU(12)    # host array -> device tensor uploads
-_ALIGNED = _LRU(4)    # (forecast, truth) -> label-aligned views
+class _Cache:
+  """Per-thread cache: unbounded and identity-keyed inside a chunk scope
+  (dropped when the scope ends), a small LRU outside."""
+
+  def __init__(self, name: str, maxsize: int):
+    self.name, self.maxsize = name, maxsize
+
+  def _lru(self) -> _LRU:
+    lru = _ANNOUNCED.lru.get(self.name)
+    if lru is None:
+      lru = _ANNOUNCED.lru[self.name] = _LRU(self.maxsize)
+    return lru
+
+  def get(self, key):
+    st = _ANNOUNCED
+    if st.depth > 0:
+      hit = st.scoped.get(self.name, {}).get(key)
+      return None if hit is None else hit[1]
+    return self._lru().get(key)
+
+  def put(self, key, pins, value):
+    st = _ANNOUNCED
+    if st.depth > 0:
+      st.scoped.setdefault(self.name, {})[key] = (pins, value)
+    else:
+      self._lru().put(key, pins, value)
+
+  def clear(self):
+    _ANNOUNCED.scoped.pop(self.name, None)
+    self._lru().clear()
 
 
-@_serialized
+_RESULTS = _Cache('results', 8)    # fused pass results
+_DEVICE = _Cache('device', 12)     # host array -> device tensor uploads
+_ALIGNED = _Cache('aligned', 4)    # (forecast, truth) -> label-aligned views
+
+
 def _inputs(forecast, truth) -> tuple:
   """Datasets as the reference's `forecast - truth` would see them: converted
   at the boundary and inner-joined on their shared dimension coordinates.  The
@@ -212,22 +287,55 @@ def clear_caches():
 
 
 def _stamp(a) -> tuple:
-  """Cache identity of an input array: the object plus a cheap guard against
-  IN-PLACE changes between calls (a reused chunk buffer).  Torch tensors carry
-  a version counter that every in-place op bumps; for NumPy arrays 64 strided
-  samples are hashed (the reference's own cache compares whole arrays,
-  utils.py:322-350 -- far too slow at 54 MB per level here).  Not a proof of
-  equality: code that rewrites a NumPy buffer in place with near-identical
-  data should call `clear_caches()`."""
+  """Cache identity of an input array.
+
+  Torch tensors carry a version counter that every in-place op bumps: (id,
+  version, pointer) is exact.  NumPy arrays have no such counter: inside a
+  chunk scope (where inputs do not change by contract and everything cached is
+  dropped at the end) identity + layout is the stamp; OUTSIDE a scope the whole
+  buffer is hashed (xxh3, GB/s -- comparable to the upload the cache saves), so
+  a caller that refills a buffer in place between two bare `compute_chunk`
+  calls can never get the previous chunk's result (the reference's
+  dataset_safe_lru_cache compares whole arrays too, utils.py:322-350)."""
   if isinstance(a, torch.Tensor):
     return (id(a), a._version, a.data_ptr())
-  if isinstance(a, np.ndarray) and a.size:
-    step = max(1, a.size // 64)
-    flat = a.reshape(-1) if a.flags.c_contiguous else a.flat  # no copy
-    sample = np.asarray(flat[::step])[:64]
-    return (id(a), a.__array_interface__['data'][0], hash(sample.tobytes()),
-            hash(np.asarray(flat[a.size - 1:]).tobytes()))
+  if isinstance(a, np.ndarray):
+    ident = (id(a), a.__array_interface__['data'][0], a.shape, a.strides,
+             a.dtype.str)
+    if _ANNOUNCED.depth > 0 or a.size == 0:
+      return ident
+    import xxhash
+    buf = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+    return ident + (xxhash.xxh3_64_intdigest(buf.reshape(-1).view(np.uint8)),)
   return (id(a),)
+
+
+def _coord_sig(*datasets) -> tuple:
+  """Identity of everything besides the data that shapes a result: variable
+  dims and the values of all coordinates (small arrays, hashed in full).
+  Memoised per Dataset object inside a chunk scope."""
+  st = _ANNOUNCED
+  out = []
+  for ds in datasets:
+    key = ('coord_sig', id(ds))
+    hit = st.memo.get(key) if st.depth > 0 else None
+    if hit is None or hit[0] is not ds:
+      parts = [tuple((k, v.dims) for k, v in ds.data_vars.items())]
+      for k, c in ds.coords.items():
+        if isinstance(c, xl.DataArray):
+          v, dims = np.asarray(c.values), tuple(c.dims)
+        else:
+          v, dims = np.asarray(c), None
+        if v.dtype == object:
+          parts.append((k, dims, tuple(v.ravel().tolist())))
+        else:
+          parts.append((k, dims, v.shape, v.dtype.str,
+                        np.ascontiguousarray(v).tobytes()))
+      hit = (ds, hash(tuple(parts)))
+      if st.depth > 0:
+        st.memo[key] = hit
+    out.append(hit[1])
+  return tuple(out)
 
 
 def _to_device(data, device) -> torch.Tensor:
@@ -360,10 +468,17 @@ def _label_positions(have: np.ndarray, want: np.ndarray, what: str):
     raise KeyError(f'{what} label {e} not found in climatology') from e
 
 
+_CLIM_TABLES: dict = {}  # content key -> table (bounded; see _climatology_slabs)
+
+
 def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
                        forecast: xl.Dataset, geo: _Geometry, crest: tuple):
-  """int64[n_outer]: which climatology slab each output slab subtracts."""
-  import pandas as pd
+  """int64[n_outer]: which climatology slab each output slab subtracts.
+
+  Pure label work on small coordinate arrays; memoised on their CONTENT (valid
+  times, levels, the climatology's dayofyear / hour / level labels, the output
+  layout), so a stream of chunks with recurring time stamps -- or the five
+  metrics of one loop -- builds each table once."""
   if 'init_time' in forecast.dims:
     vt = forecast.coords['valid_time']
     if not isinstance(vt, xl.DataArray):
@@ -373,6 +488,31 @@ def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
   else:
     time_dims = ('time',)
     vt = _coord_values(forecast, 'time')
+  vt = np.asarray(vt)
+
+  def label_bytes(ds, name):
+    if name not in ds.coords:
+      return None
+    v = _coord_values(ds, name)
+    return (v.dtype.str, v.shape, np.ascontiguousarray(v).tobytes())
+  key = (vt.dtype.str, vt.shape, np.ascontiguousarray(vt).tobytes(), time_dims,
+         geo.out_dims, geo.out_shape, crest,
+         tuple(cvar.sizes[d] for d in crest),
+         label_bytes(climatology, 'dayofyear'), label_bytes(climatology, 'hour'),
+         label_bytes(climatology, 'level'), label_bytes(forecast, 'level'))
+  hit = _CLIM_TABLES.get(key)
+  if hit is None:
+    hit = _climatology_slabs_build(climatology, cvar, forecast, geo, crest, vt,
+                                   time_dims)
+    if len(_CLIM_TABLES) >= 256:
+      _CLIM_TABLES.clear()
+    _CLIM_TABLES[key] = hit
+  return hit
+
+
+def _climatology_slabs_build(climatology, cvar, forecast, geo, crest, vt,
+                             time_dims):
+  import pandas as pd
   idx = pd.DatetimeIndex(np.asarray(vt).ravel())
   shape = np.shape(vt)
   doy = np.asarray(idx.dayofyear).reshape(shape)
@@ -459,7 +599,7 @@ def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
     _check_grid(geo, x)
   flat, tables = zip(*[_physical_slabs(x, tb, pl.n_row, pl.n_col)
                        for x, tb in zip(tensors, tables)])
-  slabs = [None if tb is None else torch.from_numpy(tb).to(device)
+  slabs = [None if tb is None else engine.upload_table(tb, device)
            for tb in tables]
   if aux is not None:
     aux = torch.as_tensor(np.ascontiguousarray(aux, dtype=np.float64)).to(device)
@@ -469,12 +609,18 @@ def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
   # GPU, so a caller streaming chunks keeps the queue full; `.values` of the
   # returned DataArrays is where the copy (and the sync) happens
   dev = metrics.reshape((metrics.shape[0], pl.n_region) + geo.out_shape)
-  return {name: dev[:, i] for i, name in enumerate(pl.region_names)}, rkey
+  by_region = {name: dev[:, i] for i, name in enumerate(pl.region_names)}
+  by_region[_ALL] = (dev, list(pl.region_names))
+  return by_region, rkey
 
 
-def _result_key(kind, arrays, region_key_obj, skipna):
+def _result_key(kind, arrays, region_key_obj, skipna, datasets=()):
+  """Key of a fused pass result: what was read (stamps of the arrays), how it
+  was laid out and labelled (dims + coordinate values of `datasets`), for which
+  regions, with which NaN rule."""
   sig = _region_set_sig(region_key_obj)[2]
-  return (kind, tuple(_stamp(a) for a in arrays), sig, bool(skipna))
+  return (kind, tuple(_stamp(a) for a in arrays), _coord_sig(*datasets), sig,
+          bool(skipna))
 
 
 @_serialized
@@ -485,7 +631,7 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
   if climatology is not None:
     cvar = _get_climatology_chunk(climatology, truth)[name]
   pins = [fvar.data, tvar.data] + ([cvar.data] if cvar is not None else [])
-  key = _result_key('det', pins[:2], region, skipna)
+  key = _result_key('det', pins[:2], region, skipna, (forecast, truth))
   hit = _RESULTS.get(key)
   # A cached ACC pass also answers MSE/RMSE/MAE/Bias queries.
   if hit is not None and (cvar is None or hit['clim'] == _stamp(cvar.data)):
@@ -559,6 +705,9 @@ def _pick(by_region: dict, region, index, regions: t.Optional[dict]):
   if regions is None:
     _, rkey = _region_set_for(region)
     return (), by_region[rkey][index]
+  whole = by_region.get(_ALL)
+  if whole is not None and whole[1] == list(regions):
+    return ('region',), whole[0][index]  # already [region, ...]: a view
   return ('region',), _stack([by_region[k][index] for k in regions])
 
 
@@ -716,7 +865,7 @@ def _wind_pass(forecast, truth, u_name, v_name, region, skipna):
   fu, fv, tu, tv = (forecast[u_name], forecast[v_name], truth[u_name],
                     truth[v_name])
   pins = [fu.data, tu.data, fv.data, tv.data]
-  key = _result_key('wind', pins, region, skipna)
+  key = _result_key('wind', pins, region, skipna, (forecast, truth))
   hit = _RESULTS.get(key)
   if hit is not None:
     return hit
@@ -929,7 +1078,7 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim):
   tten = tten if tten.dtype == dtype else tten.to(dtype)
   _check_grid(geo, ften)
   _check_grid(geo, tten)
-  to_dev = lambda tb: None if tb is None else torch.from_numpy(tb).to(device)
+  to_dev = lambda tb: None if tb is None else engine.upload_table(tb, device)
   return (geo, ften, tten, None if identity else to_dev(ens_table),
           to_dev(truth_table), strides[ensemble_dim], n_member, device)
 
@@ -941,7 +1090,8 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   `want_maps`, the six pointwise maps as a device tensor)."""
   fvar, tvar = forecast[name], truth[name]
   pins = [fvar.data, tvar.data]
-  key = _result_key(('ens', ensemble_dim, want_maps), pins, region, skipna)
+  key = _result_key(('ens', ensemble_dim, want_maps), pins, region, skipna,
+                    (forecast, truth))
   hit = _RESULTS.get(key)
   if hit is not None:
     return hit
@@ -1133,7 +1283,7 @@ def _spatial_inputs(forecast, truth, name, time_first: t.Optional[str] = None):
   tensors = [x if x.dtype == dtype else x.to(dtype) for x in tensors]
   for x in tensors:
     _check_grid(geo, x)
-  slabs = [None if tb is None else torch.from_numpy(tb).to(device)
+  slabs = [None if tb is None else engine.upload_table(tb, device)
            for tb in tables]
   spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
   n_point = len(geo.latitude) * len(geo.longitude)
@@ -1161,7 +1311,8 @@ class _SpatialMetric(Metric):
     out = xl.Dataset()
     for name in _common_vars(forecast, truth):
       pins = (forecast[name].data, truth[name].data)
-      key = ('spatial', id(pins[0]), id(pins[1]))
+      key = ('spatial', _stamp(pins[0]), _stamp(pins[1]),
+             _coord_sig(forecast, truth))
       hit = _RESULTS.get(key)
       if hit is None:
         (tensors, slabs, out_dims, out_shape, spatial, spatial_shape,
@@ -1193,7 +1344,8 @@ class _SpatialMetric(Metric):
     out = xl.Dataset()
     for name in _common_vars(forecast, truth):
       pins = (forecast[name].data, truth[name].data)
-      key = ('spatial_mean', id(pins[0]), id(pins[1]), bool(skipna))
+      key = ('spatial_mean', _stamp(pins[0]), _stamp(pins[1]),
+             _coord_sig(forecast, truth), bool(skipna))
       hit = _RESULTS.get(key)
       if hit is None:
         (tensors, slabs, out_dims, out_shape, spatial, spatial_shape,
@@ -1266,7 +1418,7 @@ def compute_spread_skill_ratio(results: xl.Dataset) -> xl.Dataset:
 def _gauss_pass(forecast, truth, name, region, skipna):
   mvar, svar, tvar = forecast[name], forecast[f'{name}_std'], truth[name]
   pins = [mvar.data, svar.data, tvar.data]
-  key = _result_key('gauss', pins, region, skipna)
+  key = _result_key('gauss', pins, region, skipna, (forecast, truth))
   hit = _RESULTS.get(key)
   if hit is not None:
     return hit
@@ -1536,7 +1688,7 @@ def _ens_threshold_layout(forecast, truth, threshold_ds, name, ensemble_dim):
   tens = [x if x.dtype == dtype else x.to(dtype) for x in tens]
   for x in tens:
     _check_grid(geo, x)
-  to_dev = lambda tb: None if tb is None else torch.from_numpy(tb).to(device)
+  to_dev = lambda tb: None if tb is None else engine.upload_table(tb, device)
   tables = [None if identity else to_dev(ens_table), to_dev(t_table),
             to_dev(h_table)]
   return geo, tens, tables, strides[ensemble_dim], n_member, device
@@ -1587,7 +1739,7 @@ class _EnsembleThresholdMetric(ThresholdMetric):
       for name in _common_vars(forecast, truth):
         key = _result_key(('ens_thr', self.ensemble_dim, id(threshold)),
                           [forecast[name].data, truth[name].data], region,
-                          skipna)
+                          skipna, (forecast, truth))
         hit = _RESULTS.get(key)
         if hit is None:
           hit = _ens_threshold_pass(forecast, truth, threshold_ds, name,
@@ -1915,7 +2067,7 @@ class SpatialSEEPS(SEEPS):
     for x in tensors:
       _check_grid(geo, x)
     n_point = tensors[0].shape[-2] * tensors[0].shape[-1]
-    slabs = [None if tb is None else torch.from_numpy(tb).to(device)
+    slabs = [None if tb is None else engine.upload_table(tb, device)
              for tb in tables]
     aux_dev = torch.as_tensor(
         np.ascontiguousarray(aux, dtype=np.float64)).to(device).reshape(-1)

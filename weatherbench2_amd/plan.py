@@ -20,6 +20,7 @@ set of regions this builds, once, and keeps resident on the device:
 from __future__ import annotations
 
 import dataclasses
+import threading
 import typing as t
 
 import numpy as np
@@ -237,6 +238,7 @@ def build_plan(latitude: np.ndarray, longitude: np.ndarray, layout: str,
 
 
 _PLAN_CACHE: dict = {}
+_PLAN_LOCK = threading.Lock()
 
 
 def cached_plan(latitude, longitude, layout, regions, device,
@@ -247,11 +249,13 @@ def cached_plan(latitude, longitude, layout, regions, device,
   rkey = tuple((k, id(v)) for k, v in (regions or {'global': None}).items())
   key = (latitude.tobytes(), str(latitude.dtype), longitude.tobytes(),
          str(longitude.dtype), layout, rkey, str(device), rows_per_chunk)
-  plan = _PLAN_CACHE.get(key)
-  if plan is None:
-    if len(_PLAN_CACHE) > 64:
-      _PLAN_CACHE.clear()
+  hit = _PLAN_CACHE.get(key)
+  if hit is None:
     plan = build_plan(latitude, longitude, layout, regions, device,
                       rows_per_chunk)
-    _PLAN_CACHE[key] = plan
-  return plan
+    with _PLAN_LOCK:
+      if len(_PLAN_CACHE) > 64:
+        _PLAN_CACHE.clear()
+      # the regions are kept alive with the plan: the key holds their id()s
+      _PLAN_CACHE[key] = hit = (plan, regions)
+  return hit[0]

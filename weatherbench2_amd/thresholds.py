@@ -35,19 +35,42 @@ def _positions(have: np.ndarray, want: np.ndarray, what: str) -> np.ndarray:
 
 def _time_gather(climatology: xl.Dataset, truth: xl.Dataset,
                  variables: dict) -> xl.Dataset:
-  """climatology.sel(level=…, dayofyear=…, [hour=…]) at the truth's times."""
+  """climatology.sel(level=..., dayofyear=..., [hour=...]) at the truth's times.
+
+  thresholds.py:131-142 / 166-178: the day of year comes from truth['time'],
+  the hour from truth[time_dim] with time_dim = 'time' if it is a dimension of
+  truth, else 'valid_time'.  For a by-init forecast the truth
+  (`truth.sel(time=forecast.valid_time)`, evaluation.py:474) has dims
+  (init_time, lead) and BOTH are 2-D coordinates over them; the gathered
+  threshold then gets those dims, exactly like xarray's vectorised `.sel`."""
   import pandas as pd
-  if 'time' not in truth.dims:
-    raise NotImplementedError(
-        'thresholds need a `time` dimension on truth (the reference indexes '
-        "truth['time'] unconditionally, thresholds.py:140)")
-  times = pd.DatetimeIndex(_coord(truth, 'time').ravel())
-  doy_idx = _positions(_coord(climatology, 'dayofyear'),
-                       np.asarray(times.dayofyear), 'dayofyear')
+  time_dim = 'time' if 'time' in truth.dims else 'valid_time'
+
+  def labels(name):
+    if name not in truth.coords:
+      raise KeyError(name)  # what the reference's truth[name] raises
+    c = truth.coords[name]
+    if isinstance(c, xl.DataArray):
+      return np.asarray(c.values), tuple(c.dims)
+    return np.asarray(c), (name,)
+  try:
+    day_labels, tdims = labels('time')
+  except KeyError:
+    if time_dim == 'time':
+      raise
+    day_labels, tdims = labels('valid_time')  # truth carries only valid_time
+  hour_labels, hdims = labels(time_dim)
+  if hdims != tdims:
+    hour_labels = np.transpose(hour_labels, [hdims.index(d) for d in tdims])
+  shape = day_labels.shape
+  doy = np.asarray(pd.DatetimeIndex(day_labels.ravel()).dayofyear)
+  doy_idx = _positions(_coord(climatology, 'dayofyear'), doy,
+                       'dayofyear').reshape(shape)
   has_hour = 'hour' in climatology.coords
   if has_hour:
-    hour_idx = _positions(_coord(climatology, 'hour'), np.asarray(times.hour),
-                          'hour')
+    hour = np.asarray(pd.DatetimeIndex(hour_labels.ravel()).hour)
+    hour_idx = _positions(_coord(climatology, 'hour'), hour,
+                          'hour').reshape(shape)
   level_idx = None
   if 'level' in truth.dims and 'level' in climatology.coords:
     level_idx = _positions(_coord(climatology, 'level'), _coord(truth, 'level'),
@@ -63,7 +86,7 @@ def _time_gather(climatology: xl.Dataset, truth: xl.Dataset,
       data = v.transpose('dayofyear', 'hour', *rest).values[doy_idx, hour_idx]
     else:
       data = v.transpose('dayofyear', *rest).values[doy_idx]
-    out.data_vars[dst] = xl.DataArray(data, ('time',) + rest, coords, dst)
+    out.data_vars[dst] = xl.DataArray(data, tdims + rest, coords, dst)
   return out
 
 

@@ -221,6 +221,12 @@ class Dataset:
           coords.pop(dim)
         else:
           coords[dim] = np.asarray(coords[dim])[idx]
+    # non-index coordinates over several dims (valid_time(init_time, lead), a
+    # 2-D `time` of by-init truth) are indexed along the same dims as the data
+    for name, c in list(coords.items()):
+      if isinstance(c, DataArray) and any(d in c.dims for d in indexers):
+        sub = c.isel(**{d: i for d, i in indexers.items() if d in c.dims})
+        coords[name] = DataArray(sub.data, sub.dims, {}, name)
     out = Dataset(coords=coords, attrs=self.attrs)
     for k, v in self.data_vars.items():
       w = v.isel(**indexers)
@@ -229,7 +235,10 @@ class Dataset:
 
   def mean(self, dim=None, skipna: bool = False):
     dims = (dim,) if isinstance(dim, str) else tuple(dim or ())
-    coords = {k: v for k, v in self.coords.items() if k not in dims}
+    # like xarray: coordinates that vary along a reduced dim go with it
+    coords = {k: v for k, v in self.coords.items()
+              if k not in dims and not (isinstance(v, DataArray)
+                                        and any(d in v.dims for d in dims))}
     out = Dataset(coords=coords, attrs=self.attrs)
     for k, v in self.data_vars.items():
       m = v.mean(dim, skipna=skipna)
