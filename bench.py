@@ -229,12 +229,15 @@ def parse_args():
                        'as value)')
   ap.add_argument('--workload', default='deterministic',
                   choices=['deterministic', 'ensemble', 'spectrum',
-                           'spectrum_mean'],
+                           'spectrum_materialized', 'spectrum_mean'],
                   help='deterministic = BASELINE configs[1] (the headline '
-                       'metric); ensemble / spectrum = configs[2] / [3], '
-                       'spectrum_mean = the time-mean pipeline of the spectrum '
-                       'script with the mean fused; used for profiles/ and '
-                       'DESIGN.md')
+                       'metric); ensemble / spectrum = configs[2] / [3] '
+                       '(spectrum + area-weighted latitude mean, fused); '
+                       'spectrum_materialized = ZonalEnergySpectrum.compute '
+                       '(per-latitude spectra written) followed by the same '
+                       'latitude mean; spectrum_mean = the time-mean pipeline of '
+                       'the spectrum script with the mean fused; used for '
+                       'profiles/ and DESIGN.md')
   ap.add_argument('--members', type=int, default=50)
   return ap.parse_args()
 
@@ -758,9 +761,18 @@ def secondary(args):
     circ = torch.as_tensor(ZonalEnergySpectrum._circumference(lat)).to(dev)
     w_lat = torch.as_tensor(plan_lib.get_lat_weights(lat)).to(dev)
     pts = units * PTS_PER_UNIT
-    bytes_per_pt = 4.0 + (N_LON // 2 + 1) * 8.0 / N_LON
+    n_bins = N_LON // 2 + 1
+    bytes_per_pt = 4.0 + n_bins * 8.0 / N_LON
     if args.workload == 'spectrum_mean':
-      bytes_per_pt = 4.0 + (N_LON // 2 + 1) * 8.0 / N_LON / units
+      bytes_per_pt = 4.0 + n_bins * 8.0 / N_LON / units
+    if args.workload == 'spectrum':
+      # fused latitude mean: 4 B/pt read + one partial spectrum per (field,
+      # latitude segment) written and re-read by the combine step
+      from weatherbench2_amd import _lib as _l
+      handle, _ = engine._SPECTRUM_PLANS.get(_l.WB2_F32, N_LON,
+                                             units * N_LEV * N_LAT)
+      n_seg = _l.load().wb2_zonal_spectrum_latmean_segments(handle, N_LAT)
+      bytes_per_pt = 4.0 + 2.0 * n_seg * n_bins * 8.0 / (N_LAT * N_LON)
 
     def step(i, timed):
       xs = x[(i % pool) * units:(i % pool + 1) * units]
@@ -776,29 +788,48 @@ def secondary(args):
           ev[1].record()
           events.append(ev)
         return
+      if args.workload == 'spectrum':
+        # configs[3]: spectrum + area-weighted latitude mean, per-latitude
+        # spectra never written: [units, 13, 721, 1440] -> [units, 13, 721 bins]
+        engine.zonal_spectrum_lat_mean(xs, circ, w_lat, N_LAT)
+        if timed:
+          ev[1].record()
+          events.append(ev)
+        return
       spec = engine.zonal_spectrum(xs, circ, N_LAT)
       if timed:
         ev[1].record()
         events.append(ev)
-      # configs[3] "+ lat-weighted reduce": area-weighted mean of the spectrum
-      # over latitude (K7), [units * 13, 721 lat, 721 bins] -> [units * 13, 721]
+      # the same latitude mean from the materialised spectrum (K7):
+      # [units * 13, 721 lat, 721 bins] -> [units * 13, 721]
       total, _, count = engine.axis_moments(
-          spec.reshape(units * N_LEV, N_LAT, N_LON // 2 + 1), units * N_LEV,
-          N_LAT, N_LON // 2 + 1, w_lat, False)
+          spec.reshape(units * N_LEV, N_LAT, n_bins), units * N_LEV,
+          N_LAT, n_bins, w_lat, False)
       lat_mean = total / count
-    kernel = ('fused_spectrum_kernel<720,TIME> (LDS real FFT, time mean in '
-              'registers)' if args.workload == 'spectrum_mean' else
-              'fused_spectrum_kernel<720> (LDS real FFT + power epilogue); '
-              'WB2HIP_SPECTRUM_BACKEND=rocfft selects rocFFT C2C + power_kernel')
-    workload = ('the time-mean pipeline of scripts/compute_zonal_energy_'
-                'spectrum.py:234 on 8 units of 13x721x1440 f32 per step: '
-                'spectrum and its mean over the 8 units in ONE kernel (4 B/pt '
-                'read, one 721-bin spectrum per row written)'
-                if args.workload == 'spectrum_mean' else
-                'BASELINE configs[3]: zonal energy spectrum of 8 units of '
-                '13x721x1440 f32 per step, per-unit spectrum materialised, then '
-                'its area-weighted latitude mean (K7; the roofline entry is the '
-                'spectrum kernel alone)')
+    kernel = {
+        'spectrum_mean': 'fused_spectrum_kernel<720,TIME_MEAN> (LDS real FFT, '
+                         'time mean in registers)',
+        'spectrum': 'fused_spectrum_kernel<720,LATSEG> + latseg_combine_kernel '
+                    '(LDS real FFT, weighted latitude sums in registers; the '
+                    'event pair brackets both)',
+        'spectrum_materialized': 'fused_spectrum_kernel<720,MATERIALISE> (LDS '
+                                 'real FFT + power epilogue); '
+                                 'WB2HIP_SPECTRUM_BACKEND=rocfft selects rocFFT '
+                                 'C2C + power_kernel'}[args.workload]
+    workload = {
+        'spectrum_mean': 'the time-mean pipeline of scripts/compute_zonal_energy_'
+                         'spectrum.py:234 on 8 units of 13x721x1440 f32 per '
+                         'step: spectrum and its mean over the 8 units in ONE '
+                         'kernel (4 B/pt read, one 721-bin spectrum per row '
+                         'written)',
+        'spectrum': 'BASELINE configs[3]: zonal energy spectrum of 8 units of '
+                    '13x721x1440 f32 per step + its area-weighted latitude '
+                    'mean, fused (per-latitude spectra never written)',
+        'spectrum_materialized': 'ZonalEnergySpectrum.compute on 8 units of '
+                                 '13x721x1440 f32 per step (per-latitude spectra '
+                                 'materialised, 8 B/pt), then their area-weighted '
+                                 'latitude mean (K7; the roofline entry is the '
+                                 'spectrum kernel alone)'}[args.workload]
   ramp(lambda: step(0, False), args.ramp_ms)
   for i in range(args.warmup):
     step(i, False)
@@ -826,8 +857,11 @@ def secondary(args):
                    'traffic': (measured_traffic('ensemble', slabs_per_launch=13,
                                                 members=args.members)
                                if args.workload == 'ensemble' else
-                               measured_traffic(args.workload,
-                                                units_per_launch=8))}}))
+                               measured_traffic(
+                                   {'spectrum_materialized': 'spectrum',
+                                    'spectrum': 'spectrum_latmean'}.get(
+                                        args.workload, args.workload),
+                                   units_per_launch=8))}}))
 
 
 if __name__ == '__main__':

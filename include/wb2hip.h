@@ -411,6 +411,23 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
                        int32_t n_lat, int64_t n_time, int skipna, double* out,
                        void* workspace, void* stream);
 
+/* BASELINE configs[3] in one pass: the latitude-weighted mean of the zonal energy
+ * spectrum WITHOUT materialising the per-latitude spectra,
+ *   out[field][k] = scale * sum_lat row_weight[lat] * S[field][lat][k],
+ * S = ZonalEnergySpectrum.compute (derived_variables.py:592-626) of the plan's
+ * rows viewed as [field][n_lat]; row_weight[n_lat] (DEV, float64) = latitude
+ * weight x circumference (the x circumference of :626 folded in), scale =
+ * 1 / sum(latitude weights) for the area-weighted mean.  Every (field, latitude
+ * segment) is reduced by one wave in registers into partial[field][n_seg][bins]
+ * (DEV scratch, float64), the segments are then added in order (deterministic).
+ * n_seg from wb2_zonal_spectrum_latmean_segments (0 = this plan has no fused
+ * path: use wb2_zonal_spectrum + wb2_axis_moments); out[field][n_lon/2+1] DEV. */
+int wb2_zonal_spectrum_latmean_segments(void* plan, int32_t n_lat);
+int wb2_zonal_spectrum_latmean(void* plan, const void* x,
+                               const double* row_weight, int32_t n_lat,
+                               int32_t n_seg, double scale, double* partial,
+                               double* out, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Host-side helpers and the path's one exchange step (csrc/comm.cpp)
  * ------------------------------------------------------------------------- */

@@ -12,8 +12,8 @@ mkdir -p /tmp/k4 && cd /tmp/k4
     -I$ROOT/include -I$ROOT/weatherbench2_amd/csrc \
     -c $ROOT/weatherbench2_amd/csrc/spectrum_fused.hip -o sf.o --save-temps 2>&1 | grep -v warning || true
 S=/tmp/k4/spectrum_fused-hip-amdgcn-amd-amdhsa-gfx950.s
-for v in 1 0; do
-  echo "== fused_spectrum_kernel<720, TIME=$v>"
-  grep "fused_spectrum_kernelILi720ELb${v}E.*\(num_vgpr\|numbered_sgpr\|private_seg_size\)," $S | sed 's/.*\.\(num_vgpr\|numbered_sgpr\|private_seg_size\)/  \1/'
-  python $ROOT/tools/isa_hist.py $S "fused_spectrum_kernelILi720ELb${v}E" --loop --dump /tmp/k4/new720_$v.s | head -${LINES_SHOWN:-14}
+for v in 2 1 0; do
+  echo "== fused_spectrum_kernel<720, MODE=$v> (0 materialise, 1 time mean, 2 latitude segments)"
+  grep "fused_spectrum_kernelILi720ELi${v}E.*\(num_vgpr\|numbered_sgpr\|private_seg_size\)," $S | sed 's/.*\.\(num_vgpr\|numbered_sgpr\|private_seg_size\)/  \1/'
+  python $ROOT/tools/isa_hist.py $S "fused_spectrum_kernelILi720ELi${v}E" --loop --dump /tmp/k4/new720_$v.s | head -${LINES_SHOWN:-14}
 done

@@ -5,14 +5,14 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r02
 O=$GRAFT_REPO_ROOT/gpurun_out/r02
 export TMPDIR=/tmp
-for w in deterministic ensemble spectrum spectrum_mean; do
+for w in deterministic ensemble spectrum spectrum_materialized spectrum_mean; do
   extra="--no-full-suite --no-api"; [ $w != deterministic ] && extra="--workload $w"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o run -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $extra > $O/prof_$w.log 2>&1)
   f=$(find $O/prof_$w -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f" > $O/r02_${w}_kernel_stats.csv
   tail -1 $O/prof_$w.log | cut -c1-200
   rm -rf $O/prof_$w
 done
-for w in deterministic ensemble spectrum spectrum_mean; do
+for w in deterministic ensemble spectrum spectrum_materialized spectrum_mean; do
   extra="--no-full-suite --no-api"; [ $w != deterministic ] && extra="--workload $w"
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${w}_$c -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --ramp-ms 0 --no-cpu-baseline $extra > /dev/null 2>&1)
@@ -35,5 +35,5 @@ PY
   done
 done 2>&1 | tee $O/r02_pmc_raw.txt
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_det.json
-for w in ensemble spectrum spectrum_mean; do timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_$w.json; done
+for w in ensemble spectrum spectrum_materialized spectrum_mean; do timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_$w.json; done
 ls $O

@@ -83,6 +83,9 @@ _SIGNATURES = {
     'wb2_spectrum_plan_workspace': (_i64, [_vp]),
     'wb2_zonal_spectrum': (_int, [_vp, _vp, _vp, _i32, _i64, _int, _vp, _vp,
                                   _vp]),
+    'wb2_zonal_spectrum_latmean_segments': (_int, [_vp, _i32]),
+    'wb2_zonal_spectrum_latmean': (_int, [_vp, _vp, _vp, _i32, _i32,
+                                          _c.c_double, _vp, _vp, _vp]),
     'wb2_lat_weights': (_int, [_int, _vp, _i64, _vp]),
     'wb2_comm_unique_id': (_int, [_vp]),
     'wb2_comm_init_rank': (_int, [_vp, _i32, _i32, _c.POINTER(_vp)]),

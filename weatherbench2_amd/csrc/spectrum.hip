@@ -35,11 +35,14 @@ namespace wb2 {
 bool fused_spectrum_supported(int dtype, int n_lon);
 size_t fused_spectrum_table_bytes(int n_lon);
 int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s);
-size_t fused_spectrum_sched_bytes();
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
-                       int skipna, double* out, void* tables, void* sched,
-                       hipStream_t s);
+                       int skipna, double* out, void* tables, hipStream_t s);
+int fused_spectrum_latmean_segments(long long n_rows, int n_lon, int n_lat);
+int fused_spectrum_latmean(const float* x, long long n_rows, int n_lon,
+                           const double* row_weight, int n_lat, int n_seg,
+                           double scale, double* partial, double* out,
+                           void* tables, hipStream_t s);
 
 namespace {
 
@@ -256,11 +259,8 @@ int64_t wb2_spectrum_plan_workspace(void* plan) {
   size_t tw = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
   if (p->fused && wb2::fused_spectrum_table_bytes(p->n_lon) > tw)
     tw = wb2::fused_spectrum_table_bytes(p->n_lon);
-  // + the row-scheduling counters of the fused kernel (per call, so concurrent
-  // calls on different streams never share them)
   return (int64_t)(wb2::align_up(p->complex_bytes) +
-                   wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw) +
-                   wb2::align_up(wb2::fused_spectrum_sched_bytes()));
+                   wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw));
 }
 
 int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
@@ -283,15 +283,11 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   void* spec = ws;
   void* fft_work = ws + align_up(p->complex_bytes);
   void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
-  size_t tw_bytes = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
-  if (p->fused && fused_spectrum_table_bytes(p->n_lon) > tw_bytes)
-    tw_bytes = fused_spectrum_table_bytes(p->n_lon);
-  void* sched = static_cast<char*>(tw) + align_up(tw_bytes);
   // (the fused time mean keeps its per-bin sample counts in 16 bits)
   if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_time < 65536)
     return fused_spectrum_run(static_cast<const float*>(x), p->n_rows, p->n_lon,
                               circumference, n_lat, n_time, skipna, out,
-                              p->tables, sched, s);
+                              p->tables, s);
   hipfftResult rc = hipfftSetStream(p->fft, s);
   if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
     rc = hipfftSetWorkArea(p->fft, fft_work);
@@ -337,6 +333,36 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
 #undef WB2_POWER
   WB2_HIP_OK(hipGetLastError());
   return 0;
+}
+
+
+int wb2_zonal_spectrum_latmean_segments(void* plan, int32_t n_lat) {
+  using namespace wb2;
+  auto* p = static_cast<SpectrumPlan*>(plan);
+  WB2_REQUIRE(p && n_lat > 0 && p->n_rows % n_lat == 0, "bad plan / n_lat");
+  if (!p->fused) return 0;  // 0: no fused latitude mean for this plan
+  return fused_spectrum_latmean_segments(p->n_rows, p->n_lon, n_lat);
+}
+
+int wb2_zonal_spectrum_latmean(void* plan, const void* x,
+                               const double* row_weight, int32_t n_lat,
+                               int32_t n_seg, double scale, double* partial,
+                               double* out, void* stream) {
+  using namespace wb2;
+  WB2_TRACE();
+  auto* p = static_cast<SpectrumPlan*>(plan);
+  WB2_REQUIRE(p && x && row_weight && partial && out, "null pointer argument");
+  WB2_REQUIRE(n_lat > 0 && p->n_rows % n_lat == 0,
+              "n_rows=%lld is not a multiple of n_lat=%d", p->n_rows, n_lat);
+  WB2_REQUIRE(n_seg >= 1 && n_seg <= n_lat, "n_seg=%d outside [1, n_lat]", n_seg);
+  WB2_REQUIRE(p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0,
+              "the fused latitude mean needs float32 rows of an instantiated "
+              "length, 16-byte aligned (materialise with wb2_zonal_spectrum and "
+              "reduce with wb2_axis_moments otherwise)");
+  return fused_spectrum_latmean(static_cast<const float*>(x), p->n_rows,
+                                p->n_lon, row_weight, n_lat, n_seg, scale,
+                                partial, out, p->tables,
+                                static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -41,29 +41,14 @@
 #ifndef WB2_FFT_ASM_CMUL
 #define WB2_FFT_ASM_CMUL 1   // 0: let hipcc build (-w.y, w.x) per twiddle (2 extra VALU)
 #endif
-#ifndef WB2_FFT_PREFETCH
-// issue the next row's HBM loads before pass 1 of the current row (2 R0 extra
-// VGPRs): bit 0 = materialising kernel, bit 1 = TIME kernel.  Measured round 2:
-// no gain (the waves of a CU already overlap each other's loads), so off.
-#define WB2_FFT_PREFETCH 0
-#endif
 #ifndef WB2_FFT_WIDE_STORE
 #define WB2_FFT_WIDE_STORE 1  // materialising kernel: 16-byte stores of adjacent bins
-#endif
-#ifndef WB2_FFT_DYNAMIC
-#define WB2_FFT_DYNAMIC 0   // 1: rows handed out through per-XCD atomic counters
-                            // (measured round 2: slower, see profiles/r02_k4_notes.md)
 #endif
 #ifndef WB2_FFT_DIAG
 // timing diagnostics only (wrong results): 1 / 2 skip LDS pass 1 / 2, 4 replace
 // the recombination epilogue by a token read, 8 skip pass 0's butterflies and
 // stores, 16 no global stores in the materialising kernel
 #define WB2_FFT_DIAG 0
-#endif
-#ifndef WB2_FFT_TW_LDS
-// inter-pass twiddles from an LDS table instead of VGPRs: bit 0 / 1 = pass 1 / 2
-// of the materialising kernel, bit 2 / 3 = pass 1 / 2 of the TIME kernel
-#define WB2_FFT_TW_LDS 0
 #endif
 
 namespace wb2 {
@@ -131,28 +116,19 @@ struct FusedParams {
   const float* x;
   const cf* twz;   // [N2]      exp(-2 pi i j / N2)
   const cf* twq;   // [N2/2+1]  exp(-2 pi i k / N) * (-i) * (0.5 / N)
-  const double* circ;
-  double* out;
-  unsigned* sched;    // dynamic row scheduling: 8 counters, 64 B apart, zeroed
+  const double* circ;  // MATERIALISE / TIME: circumference[n_lat];
+                       // LATSEG: row weight[n_lat] = circumference x latitude weight
+  double* out;         // MATERIALISE / TIME: spectra; LATSEG: partial[n_field][n_seg][N2+1]
   long long n_rows;   // input rows
   long long n_time;   // TIME: input rows are [n_time][n_rows / n_time]
   int n_lat;
+  int n_seg;          // LATSEG: latitude segments per field
   int skipna;
 };
 
-// Output rows are handed out dynamically in units of kUnitRows consecutive rows
-// (TIME: one output row = n_time transforms): a wave that finishes early pulls
-// the next unit instead of idling -- with ~3 output rows per resident wave a
-// static split loses a quarter of the machine to rounding.  One counter per XCD
-// (workgroup b runs on XCD b mod 8; only speed depends on that), counter c hands
-// out the units c, c + 8, ...; the next unit is requested one unit ahead so the
-// atomic's latency never shows.
-constexpr int kSchedStride = 16;  // uints between counters (64 B)
-template <bool TIME>
-constexpr int unit_rows() { return TIME ? 1 : 8; }
-
-// A later pass (NS > 1) over the wave's slab: strided reads, twiddle multiplies,
-// butterflies, in-place writes.
+// A later pass (NS > 1) over the wave's slab: strided reads, twiddle multiplies
+// (the twiddles of a lane depend on the lane only: VGPR-resident for the whole
+// kernel), butterflies, in-place writes.
 template <typename P, int R>
 __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
                                          const cf (&tw)[P::ROUNDS][P::NTW]) {
@@ -173,45 +149,21 @@ __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// The inter-pass twiddles of a lane depend on the lane only.  TWLDS = false:
-// they live in VGPRs for the whole kernel (2 (R - 1) registers per round);
-// TWLDS = true: they are re-read from a compact LDS table for every row (cheap:
-// 8-byte conflict-free reads) to keep the register count of the TIME variant at
-// three waves per SIMD.
-template <typename P, int R, bool TWLDS>
-struct PassTwiddles {
-  cf reg[P::ROUNDS][P::NTW];
-  int row[P::ROUNDS];
-  __device__ __forceinline__ void init(const cf* twz, int lane) {
-    if constexpr (TWLDS) {
-#pragma unroll
-      for (int rd = 0; rd < P::ROUNDS; ++rd) row[rd] = P::table_row(lane, rd);
-    } else {
-      P::load_twiddles(twz, lane, reg);
-    }
-  }
-  __device__ __forceinline__ void run(cf* z, int lane, const cf* tbl) {
-    if constexpr (TWLDS) {
-      int rr[P::ROUNDS];
-#pragma unroll
-      for (int rd = 0; rd < P::ROUNDS; ++rd) {
-        rr[rd] = row[rd];
-        asm volatile("" : "+v"(rr[rd]));  // keep the reads inside the row loop
-      }
-      cf tw[P::ROUNDS][P::NTW];
-      P::load_twiddles_table(tbl, rr, tw);
-      lds_pass<P, R>(z, lane, tw);
-    } else {
-      lds_pass<P, R>(z, lane, reg);
-    }
-  }
-};
+// What a wave does with the spectra of its rows:
+//   MATERIALISE  stores every row's spectrum (ZonalEnergySpectrum.compute);
+//   TIME         owns one OUTPUT row, transforms its n_time input rows in time
+//                order with the bin powers summed in registers (fp64, NaN spectra
+//                skipped with skipna like xbeam.Mean) and stores the mean once:
+//                the time mean of scripts/compute_zonal_energy_spectrum.py:234
+//                fused -- 4 B read per grid point and almost nothing written;
+//   LATSEG       owns one (field, latitude segment): sums weight[lat] x spectrum
+//                over the segment's consecutive rows in registers and stores one
+//                partial spectrum (BASELINE configs[3]: the area-weighted latitude
+//                mean of the spectrum without materialising it; the partials of a
+//                field are added in segment order by latseg_combine_kernel).
+enum { MATERIALISE = 0, TIME_MEAN = 1, LATSEG = 2 };
 
-// TIME: the mean over the leading time axis is fused: a wave owns one OUTPUT
-// row, transforms its n_time input rows in time order with the bin powers summed
-// in registers (fp64, NaN spectra skipped with skipna like xbeam.Mean) and stores
-// the mean once -- 4 B read per grid point and almost nothing written.
-template <int N2, bool TIME>
+template <int N2, int MODE>
 __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     fused_spectrum_kernel(const FusedParams p) {
   using PL = Plan<N2>;
@@ -222,71 +174,29 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = 4;
   constexpr int NH = N2 / 2 + 1;  // bin pairs (k, N2 - k), k = 0..N2/2
   constexpr int NIT = (NH + kWave - 1) / kWave;
-  constexpr bool PF = (WB2_FFT_PREFETCH & (TIME ? 2 : 1)) != 0;
-  constexpr bool TW1_LDS = (WB2_FFT_TW_LDS & (TIME ? 4 : 1)) != 0;
-  constexpr bool TW2_LDS = R2 > 1 && (WB2_FFT_TW_LDS & (TIME ? 8 : 2)) != 0;
+  constexpr bool REDUCE = MODE != MATERIALISE;
   __shared__ __attribute__((aligned(16))) cf s_twq[NH + 1];
-  __shared__ cf s_tw1[TW1_LDS ? (R1 - 1) * P1::KP : 1];
-  __shared__ cf s_tw2[TW2_LDS ? (R2 - 1) * P2::KP : 1];
   __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][slab_slots<N2>()];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   for (int i = threadIdx.x; i <= NH; i += blockDim.x)
     s_twq[i] = p.twq[i < NH ? i : NH - 1];
-  if constexpr (TW1_LDS) P1::fill_table(p.twz, s_tw1, threadIdx.x, blockDim.x);
-  if constexpr (TW2_LDS) P2::fill_table(p.twz, s_tw2, threadIdx.x, blockDim.x);
-  PassTwiddles<P1, R1, TW1_LDS> t1;
-  PassTwiddles<P2, R2, TW2_LDS> t2;
-  t1.init(p.twz, lane);
-  if constexpr (R2 > 1) t2.init(p.twz, lane);
+  // inter-pass twiddles: functions of the lane only, resident in VGPRs
+  cf tw1[P1::ROUNDS][P1::NTW], tw2[P2::ROUNDS][P2::NTW];
+  P1::load_twiddles(p.twz, lane, tw1);
+  if constexpr (R2 > 1) P2::load_twiddles(p.twz, lane, tw2);
   __syncthreads();
   cf* z = s_z[wave];
   const float half_inv_n = 0.5f / (float)N;
-  const long long nt = TIME ? p.n_time : 1;
-  const long long rows_out = p.n_rows / nt;
-  long long orow_i;
-#if WB2_FFT_DYNAMIC
-  constexpr int UNIT = unit_rows<TIME>();
-  const int xcd = blockIdx.x & 7;
-  unsigned tok = 0;
-  auto request = [&]() {
-    if (lane == 0) tok = atomicAdd(p.sched + xcd * kSchedStride, 1u);
-  };
-  auto granted = [&]() -> long long {  // first row of the unit just granted
-    return ((long long)__builtin_amdgcn_readfirstlane(tok) * 8 + xcd) * UNIT;
-  };
-  request();
-  orow_i = granted();
-  if (orow_i >= rows_out) return;
-  long long unit_end = orow_i + UNIT < rows_out ? orow_i + UNIT : rows_out;
-  request();
-#else
+  // output rows (MATERIALISE: = input rows; TIME: n_rows / n_time; LATSEG:
+  // (field, segment) pairs) and the input rows each one reduces
+  long long rows_out;
+  if constexpr (MODE == TIME_MEAN) rows_out = p.n_rows / p.n_time;
+  else if constexpr (MODE == LATSEG) rows_out = p.n_rows / p.n_lat * p.n_seg;
+  else rows_out = p.n_rows;
   const long long stride = (long long)gridDim.x * NWAVE;
-  orow_i = (long long)blockIdx.x * NWAVE + wave;
-  if (orow_i >= rows_out) return;
-#endif
-  auto fetch = [&](long long row, cf (&v)[P0::ROUNDS][R0]) {
-    const cf* src = reinterpret_cast<const cf*>(p.x + row * N);
-    P0::load([&](int i) { return __builtin_nontemporal_load(src + i); }, lane,
-             v);
-  };
-  // PF: the HBM loads of row i + 1 are in flight while row i goes through its
-  // LDS passes (2 R0 extra VGPRs)
-  cf pf[PF ? P0::ROUNDS : 1][PF ? R0 : 1];
-  if constexpr (PF) fetch(orow_i, pf);
-  while (true) {
-    long long onext;  // the output row after this one (>= rows_out: none)
-#if WB2_FFT_DYNAMIC
-    if (orow_i + 1 < unit_end) {
-      onext = orow_i + 1;
-    } else {
-      onext = granted();
-      unit_end = onext + UNIT < rows_out ? onext + UNIT : rows_out;
-      if (onext < rows_out) request();
-    }
-#else
-    onext = orow_i + stride;
-#endif
+  for (long long orow_i = (long long)blockIdx.x * NWAVE + wave;
+       orow_i < rows_out; orow_i += stride) {
     double sum1[NIT], sum2[NIT];
     int cnt[NIT];  // TIME + skipna: valid spectra, bin k (low half) / N2 - k
 #pragma unroll
@@ -294,20 +204,31 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
       sum1[i] = sum2[i] = 0.0;
       cnt[i] = 0;
     }
-    const double c = p.circ[(unsigned)(orow_i % p.n_lat)];
-    const double c2 = 2.0 * c;
+    long long nt = 1, row0 = orow_i, row_step = 0;
+    int lat0 = 0;
+    if constexpr (MODE == TIME_MEAN) {
+      nt = p.n_time;
+      row_step = rows_out;
+    } else if constexpr (MODE == LATSEG) {
+      const long long field = orow_i / p.n_seg;
+      const int seg = (int)(orow_i - field * p.n_seg);
+      lat0 = (int)((long long)seg * p.n_lat / p.n_seg);  // balanced split
+      nt = (long long)(seg + 1) * p.n_lat / p.n_seg - lat0;
+      row0 = field * p.n_lat + lat0;
+      row_step = 1;
+    }
+    double c = 0.0;
+    if constexpr (MODE != LATSEG) c = p.circ[(unsigned)(orow_i % p.n_lat)];
     double* orow = p.out + orow_i * NB;
     for (long long t = 0; t < nt; ++t) {
+      if constexpr (MODE == LATSEG) c = p.circ[lat0 + t];
+      const double c2 = 2.0 * c;
       {  // ---- pass 0: HBM -> butterflies -> contiguous runs in the slab
+        const cf* src =
+            reinterpret_cast<const cf*>(p.x + (row0 + t * row_step) * N);
         cf v[P0::ROUNDS][R0];
-        if constexpr (PF) {
-#pragma unroll
-          for (int rd = 0; rd < P0::ROUNDS; ++rd)
-#pragma unroll
-            for (int r = 0; r < R0; ++r) v[rd][r] = pf[rd][r];
-        } else {
-          fetch(t * rows_out + orow_i, v);
-        }
+        P0::load([&](int i) { return __builtin_nontemporal_load(src + i); },
+                 lane, v);
 #if WB2_FFT_DIAG & 8
         sum1[0] += (double)(v[0][0].x + v[0][R0 - 1].y);
 #else
@@ -316,26 +237,20 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-      if constexpr (PF) {
-        long long nrow = t * rows_out + orow_i;  // no next row: harmless re-read
-        if (t + 1 < nt) nrow += rows_out;
-        else if (onext < rows_out) nrow = onext;
-        fetch(nrow, pf);
-      }
 #if !(WB2_FFT_DIAG & 1)
-      t1.run(z, lane, s_tw1);
+      lds_pass<P1, R1>(z, lane, tw1);
 #endif
 #if !(WB2_FFT_DIAG & 2)
-      if constexpr (R2 > 1) t2.run(z, lane, s_tw2);
+      if constexpr (R2 > 1) lds_pass<P2, R2>(z, lane, tw2);
 #endif
 #if WB2_FFT_DIAG & 4
       {
         const cf a = z[lane];
         sum1[0] += (double)a.x * c2;
-        if (!TIME && a.x == 1.2345f) orow[lane] = sum1[0];
+        if (!REDUCE && a.x == 1.2345f) orow[lane] = sum1[0];
       }
 #else
-      if constexpr (!TIME && WB2_FFT_WIDE_STORE) {
+      if constexpr (!REDUCE && WB2_FFT_WIDE_STORE) {
         // ---- materialising kernel: a lane owns the ADJACENT bins k0, k0 + 1
         // (and their mirrors N2 - k0, N2 - k0 - 1), so the fp64 spectrum leaves
         // in 16-byte stores (1 KiB per wave instruction instead of 512 B)
@@ -373,54 +288,72 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
           }
         }
       } else {
-      // ---- recombination + power for the bin pairs (k, N2 - k)
+        // ---- recombination + power for the bin pairs (k, N2 - k)
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int k = lane + i * kWave;
-        if ((i + 1) * kWave <= NH || k < NH) {
-          const cf a = z[k];
-          const cf b = z[(i == 0 && k == 0) ? 0 : N2 - k];
-          float p1, p2;
-          recombine_pair(a, b, s_twq[k], half_inv_n, p1, p2);
-          // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
-          const double v1 = (double)p1 * ((i == 0 && k == 0) ? c : c2);
-          const double v2 = (double)p2 * c2;
-          if constexpr (TIME) {
-            const bool k1 = !(p.skipna && is_nan(v1));
-            const bool k2 = !(p.skipna && is_nan(v2));
-            sum1[i] += k1 ? v1 : 0.0;
-            sum2[i] += k2 ? v2 : 0.0;
-            cnt[i] += (k1 ? 1 : 0) + (k2 ? 0x10000 : 0);
-          } else {
+        for (int i = 0; i < NIT; ++i) {
+          const int k = lane + i * kWave;
+          if ((i + 1) * kWave <= NH || k < NH) {
+            const cf a = z[k];
+            const cf b = z[(i == 0 && k == 0) ? 0 : N2 - k];
+            float p1, p2;
+            recombine_pair(a, b, s_twq[k], half_inv_n, p1, p2);
+            // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
+            const double v1 = (double)p1 * ((i == 0 && k == 0) ? c : c2);
+            const double v2 = (double)p2 * c2;
+            if constexpr (MODE == TIME_MEAN) {
+              const bool k1 = !(p.skipna && is_nan(v1));
+              const bool k2 = !(p.skipna && is_nan(v2));
+              sum1[i] += k1 ? v1 : 0.0;
+              sum2[i] += k2 ? v2 : 0.0;
+              cnt[i] += (k1 ? 1 : 0) + (k2 ? 0x10000 : 0);
+            } else if constexpr (MODE == LATSEG) {
+              sum1[i] += v1;
+              sum2[i] += v2;
+            } else {
 #if WB2_FFT_DIAG & 16
-            if (p1 == 1.2345f) orow[k] = v1 + v2;
+              if (p1 == 1.2345f) orow[k] = v1 + v2;
 #else
-            __builtin_nontemporal_store(v1, orow + k);
-            if (2 * k != N2) __builtin_nontemporal_store(v2, orow + N2 - k);
+              __builtin_nontemporal_store(v1, orow + k);
+              if (2 * k != N2) __builtin_nontemporal_store(v2, orow + N2 - k);
 #endif
+            }
           }
         }
       }
-      }
 #endif
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }  // time
-    if constexpr (TIME) {
+    }  // reduced rows
+    if constexpr (REDUCE) {
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
         const int k = lane + i * kWave;
         if (k < NH) {
-          __builtin_nontemporal_store(sum1[i] / (double)(cnt[i] & 0xffff),
-                                      orow + k);
-          if (2 * k != N2)
-            __builtin_nontemporal_store(sum2[i] / (double)(cnt[i] >> 16),
-                                        orow + N2 - k);
+          double o1 = sum1[i], o2 = sum2[i];
+          if constexpr (MODE == TIME_MEAN) {
+            o1 /= (double)(cnt[i] & 0xffff);
+            o2 /= (double)(cnt[i] >> 16);
+          }
+          __builtin_nontemporal_store(o1, orow + k);
+          if (2 * k != N2) __builtin_nontemporal_store(o2, orow + N2 - k);
         }
       }
     }
-    if (onext >= rows_out) break;
-    orow_i = onext;
   }
+}
+
+// LATSEG second step: out[field][k] = scale * sum_seg partial[field][seg][k],
+// segments added in order (deterministic).
+__global__ void latseg_combine_kernel(const double* __restrict__ partial,
+                                      long long n_field, int n_seg, int n_bins,
+                                      double scale, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_field * n_bins) return;
+  const long long f = i / n_bins;
+  const int k = (int)(i - f * n_bins);
+  double s = 0.0;
+  for (int g = 0; g < n_seg; ++g)
+    s += partial[((long long)f * n_seg + g) * n_bins + k];
+  out[i] = s * scale;
 }
 
 __global__ void fused_twiddle_kernel(cf* twz, cf* twq, int n2) {
@@ -448,39 +381,43 @@ int resident_blocks(K kernel) {
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) !=
           hipSuccess ||
       per_cu <= 0 || cus <= 0)
-    return WB2_FFT_MAX_BLOCKS;
+    return 768;
   cached = per_cu * cus;
   return cached;
 }
 
 template <int N2>
-int launch(const FusedParams& p, hipStream_t s) {
-  const long long rows_out = p.n_time > 0 ? p.n_rows / p.n_time : p.n_rows;
+int launch(const FusedParams& p, int mode, hipStream_t s) {
+  long long rows_out = p.n_rows;
+  if (mode == TIME_MEAN) rows_out = p.n_rows / p.n_time;
+  if (mode == LATSEG) rows_out = p.n_rows / p.n_lat * p.n_seg;
   long long blocks = (rows_out + 3) / 4;
   WB2_REQUIRE(p.n_time < 65536, "fused time mean: n_time=%lld exceeds 65535",
               p.n_time);
-#if WB2_FFT_DYNAMIC
-  // exactly the resident set (a multiple of 8: one share per XCD counter); every
-  // wave keeps pulling units until its counter runs dry
-  const long long cap = p.n_time > 0
-                            ? resident_blocks(fused_spectrum_kernel<N2, true>)
-                            : resident_blocks(fused_spectrum_kernel<N2, false>);
-  const int unit = p.n_time > 0 ? unit_rows<true>() : unit_rows<false>();
-  blocks = (rows_out + 4 * unit - 1) / (4 * unit);
-  if (blocks > cap) blocks = cap;
-  blocks = (blocks + 7) / 8 * 8;
-  WB2_HIP_OK(hipMemsetAsync(p.sched, 0, 8 * kSchedStride * sizeof(unsigned), s));
-#else
   if (blocks > WB2_FFT_MAX_BLOCKS) blocks = WB2_FFT_MAX_BLOCKS;  // row-strided waves beyond that
-#endif
-  if (p.n_time > 0)
-    hipLaunchKernelGGL((fused_spectrum_kernel<N2, true>),
+  if (mode == TIME_MEAN)
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN>),
+                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else if (mode == LATSEG)
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, LATSEG>),
                        dim3((unsigned)blocks), dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((fused_spectrum_kernel<N2, false>),
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, MATERIALISE>),
                        dim3((unsigned)blocks), dim3(256), 0, s, p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
+}
+
+// Latitude segments per field such that all (field, segment) tasks are resident
+// at once (one task per wave, no second round).
+template <int N2>
+int latseg_segments(long long n_field, int n_lat) {
+  const long long waves =
+      4LL * resident_blocks(fused_spectrum_kernel<N2, LATSEG>);
+  long long n_seg = waves / (n_field > 0 ? n_field : 1);
+  if (n_seg < 1) n_seg = 1;
+  if (n_seg > n_lat) n_seg = n_lat;
+  return (int)n_seg;
 }
 
 }  // namespace fused
@@ -512,27 +449,63 @@ int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s) {
   return 0;
 }
 
-size_t fused_spectrum_sched_bytes() {
-  return 8 * fused::kSchedStride * sizeof(unsigned);
-}
-
 int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
-                       int skipna, double* out, void* tables, void* sched,
-                       hipStream_t s) {
+                       int skipna, double* out, void* tables, hipStream_t s) {
   using namespace fused;
   const int n2 = n_lon / 2;
   cf* twz = static_cast<cf*>(tables);  // filled once by fused_spectrum_tables
   cf* twq = twz + n2;
-  FusedParams p{x,      twz,    twq,   circ, out, static_cast<unsigned*>(sched),
-                n_rows, n_time, n_lat, skipna};
+  FusedParams p{x, twz, twq, circ, out, n_rows, n_time, n_lat, 0, skipna};
+  const int mode = n_time > 0 ? TIME_MEAN : MATERIALISE;
   switch (n2) {
-#define WB2_CASE(N2) case N2: return launch<N2>(p, s);
+#define WB2_CASE(N2) case N2: return launch<N2>(p, mode, s);
     WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
     WB2_CASE(256) WB2_CASE(360) WB2_CASE(512) WB2_CASE(720)
 #undef WB2_CASE
   }
   return fail("fused spectrum: n_lon=%d is not instantiated", n_lon);
+}
+
+int fused_spectrum_latmean_segments(long long n_rows, int n_lon, int n_lat) {
+  using namespace fused;
+  switch (n_lon / 2) {
+#define WB2_CASE(N2) case N2: return latseg_segments<N2>(n_rows / n_lat, n_lat);
+    WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
+    WB2_CASE(256) WB2_CASE(360) WB2_CASE(512) WB2_CASE(720)
+#undef WB2_CASE
+  }
+  return 1;
+}
+
+// out[field][bin] = scale * sum_lat row_weight[lat] * spectrum[field][lat][bin]
+// (row_weight = circumference x latitude weight), partial[n_field][n_seg][bins]
+// is scratch.
+int fused_spectrum_latmean(const float* x, long long n_rows, int n_lon,
+                           const double* row_weight, int n_lat, int n_seg,
+                           double scale, double* partial, double* out,
+                           void* tables, hipStream_t s) {
+  using namespace fused;
+  const int n2 = n_lon / 2;
+  cf* twz = static_cast<cf*>(tables);
+  cf* twq = twz + n2;
+  FusedParams p{x, twz, twq, row_weight, partial, n_rows, 0, n_lat, n_seg, 0};
+  int rc = -1;
+  switch (n2) {
+#define WB2_CASE(N2) case N2: rc = launch<N2>(p, LATSEG, s); break;
+    WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
+    WB2_CASE(256) WB2_CASE(360) WB2_CASE(512) WB2_CASE(720)
+#undef WB2_CASE
+    default:
+      return fail("fused spectrum: n_lon=%d is not instantiated", n_lon);
+  }
+  if (rc != 0) return rc;
+  const long long n_field = n_rows / n_lat, n = n_field * (n2 + 1);
+  hipLaunchKernelGGL(latseg_combine_kernel, dim3((unsigned)((n + 255) / 256)),
+                     dim3(256), 0, s, partial, n_field, n_seg, n2 + 1, scale,
+                     out);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
 }
 
 }  // namespace wb2

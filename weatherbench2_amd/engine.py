@@ -372,6 +372,47 @@ def zonal_spectrum(x: torch.Tensor, circumference: torch.Tensor, n_lat: int,
   return out
 
 
+def zonal_spectrum_lat_mean(x: torch.Tensor, circumference: torch.Tensor,
+                            lat_weights: torch.Tensor, n_lat: int) -> torch.Tensor:
+  """Area-weighted latitude mean of the zonal energy spectrum (BASELINE
+  configs[3]) of x: [..., n_lat, n_lon] -> float64 [..., n_lon//2+1]
+  = sum_lat w[lat] S[..., lat, :] / sum_lat w[lat].
+
+  One fused kernel when the plan has the LDS FFT (float32 rows of an
+  instantiated length): the per-latitude spectra are never written.  Otherwise
+  the spectrum is materialised and reduced with the axis kernel."""
+  lib = _lib.load()
+  if x.dtype not in _DTYPES or not x.is_contiguous():
+    raise ValueError('x must be a contiguous float32/float64 tensor')
+  n_lon = x.shape[-1]
+  if x.shape[-2] != n_lat:
+    raise ValueError('latitude must be the second-to-last dim')
+  n_rows = x.numel() // n_lon
+  n_field = n_rows // n_lat
+  n_bins = n_lon // 2 + 1
+  handle, nbytes = _SPECTRUM_PLANS.get(_DTYPES[x.dtype], n_lon, n_rows)
+  w = lat_weights.to(torch.float64)
+  n_seg = lib.wb2_zonal_spectrum_latmean_segments(handle, n_lat)
+  if n_seg < 0:
+    _lib.check(n_seg, 'wb2_zonal_spectrum_latmean_segments')
+  out_shape = tuple(x.shape[:-2]) + (n_bins,)
+  if n_seg == 0 or x.data_ptr() % 16:
+    spec = zonal_spectrum(x, circumference, n_lat)
+    total, _, count = axis_moments(spec.reshape(n_field, n_lat, n_bins), n_field,
+                                   n_lat, n_bins, w, False)
+    return (total / count).reshape(out_shape)
+  row_weight = (w * circumference.to(torch.float64)).contiguous()
+  # the normalisation stays on the device (no host sync): scale = 1, divide after
+  partial = torch.empty((n_field, n_seg, n_bins), dtype=torch.float64,
+                        device=x.device)
+  out = torch.empty((n_field, n_bins), dtype=torch.float64, device=x.device)
+  _lib.check(lib.wb2_zonal_spectrum_latmean(
+      handle, _lib.ptr(x), _lib.ptr(row_weight), n_lat, n_seg, 1.0,
+      _lib.ptr(partial), _lib.ptr(out), current_stream_ptr(x.device)),
+             'wb2_zonal_spectrum_latmean')
+  return (out / w.sum()).reshape(out_shape)
+
+
 def spatial_maps(forecast: torch.Tensor, f_slab, truth: torch.Tensor, t_slab,
                  n_outer: int, n_point: int, want=('bias', 'mse', 'mae')):
   """K5 per-time maps: returns {name: tensor[n_outer, n_point]} (input dtype)."""
