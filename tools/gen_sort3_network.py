@@ -3,7 +3,7 @@
 gfx950 has `v_min3_f32` / `v_med3_f32` / `v_max3_f32`: a 3-sorter costs 3 VALU
 instructions for 3 elements where three 2-sorters (`v_min_f32` + `v_max_f32`
 each) cost 6.  A 3-way odd-even merge sort (sort triples, 3-way merge the
-columns recursively, two clean-up layers of 3-sorters) therefore needs fewer
+columns recursively, a 7-instruction-per-row clean-up) therefore needs fewer
 instructions per element than Batcher's 2-way network.
 
   python tools/gen_sort3_network.py            # report + verification
@@ -82,10 +82,15 @@ def merge3(net, A, B, C):
   D = [merge3(net, A[r::3], B[r::3], C[r::3]) for r in range(3)]
   E = [D[r][i] for i in range(n) for r in range(3)]
   # Column r of the interleaved rows has ceil((z_L - r) / 3) zeros per list L:
-  # rows are (0,0,0) ... up to 3 dirty rows (0,0,1) / (0,1,1) ... (1,1,1); two
-  # layers of 3-sorters shifted by 2 and by 1 clean them (verified exhaustively
-  # on all sorted 0/1 inputs below).
-  _layer3(net, E, 2)
+  # rows are (0,0,0) ... up to 3 dirty rows (0,0,1) / (0,1,1) ... (1,1,1).  The
+  # cheapest clean-up found by search (7 instructions per row; none with 6 in
+  # this template family; full layers of 3-sorters need three = 9): col 1 of a
+  # row against col 0 of the next, col 2 against col 1 of the next, then
+  # 3-sorters on (3i+1, 3i+2, 3i+3) -- verified on all sorted 0/1 inputs below.
+  for i in range(n - 1):
+    net.s2(E[3 * i + 1], E[3 * i + 3])
+  for i in range(n - 1):
+    net.s2(E[3 * i + 2], E[3 * i + 4])
   _layer3(net, E, 1)
   return E
 

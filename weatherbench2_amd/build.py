@@ -32,7 +32,7 @@ def needs_rebuild() -> bool:
     return True
   t = os.path.getmtime(LIB_PATH)
   deps = sources() + [os.path.join(CSRC, h) for h in
-                      ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc',
+                      ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc', 'sort3_network_50.inc',
                        'fft_core.hpp', 'trace.hpp')
                       ] + [os.path.join(ROOT, 'include', 'wb2hip.h')]
   return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))

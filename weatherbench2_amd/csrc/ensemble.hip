@@ -25,6 +25,7 @@
 #include "trace.hpp"
 #include "reduce_common.hpp"
 #include "sort_networks.inc"
+#include "sort3_network_50.inc"
 #include "wb2hip.h"
 
 #include <limits>
@@ -153,6 +154,43 @@ __device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
 #undef WB2_CE
 }
 
+#ifndef WB2_ENS_SORT3
+#define WB2_ENS_SORT3 1  // 50 float32 members: the 2-/3-sorter program (677 instead of 806 VALU)
+#endif
+__device__ __forceinline__ void sort3_asm(float& a, float& b, float& c) {
+  float lo, mid, hi;
+  asm("v_min3_f32 %0, %3, %4, %5\n\t"
+      "v_med3_f32 %1, %3, %4, %5\n\t"
+      "v_max3_f32 %2, %3, %4, %5"
+      : "=&v"(lo), "=&v"(mid), "=&v"(hi)
+      : "v"(a), "v"(b), "v"(c));
+  a = lo;
+  b = mid;
+  c = hi;
+}
+// Sorting program for exactly 50 float32 values from 2-sorters and 3-sorters
+// (v_min3 / v_med3 / v_max3: three instructions order three values, where three
+// compare-exchanges cost six): two 27-sorters by 3-way odd-even merge sort + one
+// 2-way odd-even merge, pruned for the +inf padding -- 677 instructions instead
+// of the 806 of the pruned Batcher network.  Generated and verified (0-1
+// principle, exhaustively for the 27-sorter and every merge) by
+// tools/gen_sort3_network.py.  The values are never moved: rank r ends up in
+// register kSort3Order50[r].
+constexpr int kSort3Order50[50] = {WB2_SORT3_ORDER_50};
+__device__ __forceinline__ void sort3_network_50(float (&x)[64]) {
+#define WB2_S2(i, j)                      \
+  {                                       \
+    const float lo_ = vmin(x[i], x[j]);   \
+    const float hi_ = vmax(x[i], x[j]);   \
+    x[i] = lo_;                           \
+    x[j] = hi_;                           \
+  }
+#define WB2_S3(i, j, k) sort3_asm(x[i], x[j], x[k]);
+  WB2_SORT3_NETWORK_50
+#undef WB2_S2
+#undef WB2_S3
+}
+
 template <typename T>
 __device__ __forceinline__ T sqrt_of(T x);
 template <>
@@ -261,13 +299,23 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
         x[m] = (!live(m) || (SKIPNA && is_nan(x[m]))) ? inf : x[m];
       }
     }
-    sort_network<NPAD, NM>(x);
     double s = 0.0;
+    if constexpr (WB2_ENS_SORT3 && MS == 50 && NPAD == 64 && sizeof(T) == 4) {
+      sort3_network_50(x);
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const bool use = SKIPNA ? m < n : live(m);
-      s = __builtin_fma((double)(2 * (m + 1) - M - 1), use ? (double)x[m] : 0.0,
-                        s);
+      for (int m = 0; m < NM; ++m) {  // rank m lives in register kSort3Order50[m]
+        const bool use = SKIPNA ? m < n : true;
+        s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                          use ? (double)x[kSort3Order50[m]] : 0.0, s);
+      }
+    } else {
+      sort_network<NPAD, NM>(x);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const bool use = SKIPNA ? m < n : live(m);
+        s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                          use ? (double)x[m] : 0.0, s);
+      }
     }
     if constexpr (MS > 0 && !SKIPNA) {
       // compile-time member count: 2 / (M (M - 1)) is one constant (<= 2 ulp of
