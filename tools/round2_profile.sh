@@ -37,3 +37,8 @@ done 2>&1 | tee $O/r02_pmc_raw.txt
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_det.json
 for w in ensemble spectrum spectrum_materialized spectrum_mean; do timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02_bench_$w.json; done
 ls $O
+# roctx ranges: marker + kernel trace of a short run (no counters in this pass)
+(cd /tmp && timeout 300 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/markers -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-full-suite --no-api > /dev/null 2>&1)
+f=$(find $O/markers -name '*marker_api_trace.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep wb2_ "$f" | head -12) > $O/r02_marker_trace_excerpt.csv
+rm -rf $O/markers
+cat $O/r02_marker_trace_excerpt.csv | cut -c1-200
