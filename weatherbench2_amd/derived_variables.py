@@ -162,9 +162,10 @@ def zonal_energy_spectrum_area_mean(dataset, variable_name: str) -> xl.DataArray
   n_bins = len(np.asarray(dataset.coords['longitude'])) // 2 + 1
   circ = torch.as_tensor(zes._circumference(latitude).astype(np.float64)
                          ).to(device)
-  w = torch.as_tensor(np.asarray(plan_lib.get_lat_weights(latitude),
-                                 dtype=np.float64)).to(device)
-  out = engine.zonal_spectrum_lat_mean(x.contiguous(), circ, w, len(latitude))
+  w_host = np.asarray(plan_lib.get_lat_weights(latitude), dtype=np.float64)
+  w = torch.as_tensor(w_host).to(device)
+  out = engine.zonal_spectrum_lat_mean(x.contiguous(), circ, w, len(latitude),
+                                       weight_sum=float(np.sum(w_host)))
   coords = {k: v for k, v in dataset.coords.items()
             if k not in ('longitude', 'latitude')
             and not (isinstance(v, xl.DataArray)

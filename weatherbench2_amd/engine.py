@@ -373,14 +373,20 @@ def zonal_spectrum(x: torch.Tensor, circumference: torch.Tensor, n_lat: int,
 
 
 def zonal_spectrum_lat_mean(x: torch.Tensor, circumference: torch.Tensor,
-                            lat_weights: torch.Tensor, n_lat: int) -> torch.Tensor:
+                            lat_weights: torch.Tensor, n_lat: int,
+                            weight_sum: t.Optional[float] = None,
+                            row_weight: t.Optional[torch.Tensor] = None
+                            ) -> torch.Tensor:
   """Area-weighted latitude mean of the zonal energy spectrum (BASELINE
   configs[3]) of x: [..., n_lat, n_lon] -> float64 [..., n_lon//2+1]
   = sum_lat w[lat] S[..., lat, :] / sum_lat w[lat].
 
   One fused kernel when the plan has the LDS FFT (float32 rows of an
   instantiated length): the per-latitude spectra are never written.  Otherwise
-  the spectrum is materialised and reduced with the axis kernel."""
+  the spectrum is materialised and reduced with the axis kernel.  `weight_sum`
+  (= float(sum(w)), known on the host) and `row_weight` (= w * circumference,
+  float64 on the device) may be passed by callers that evaluate many chunks on
+  one grid: the call is then exactly two kernel launches."""
   lib = _lib.load()
   if x.dtype not in _DTYPES or not x.is_contiguous():
     raise ValueError('x must be a contiguous float32/float64 tensor')
@@ -401,16 +407,21 @@ def zonal_spectrum_lat_mean(x: torch.Tensor, circumference: torch.Tensor,
     total, _, count = axis_moments(spec.reshape(n_field, n_lat, n_bins), n_field,
                                    n_lat, n_bins, w, False)
     return (total / count).reshape(out_shape)
-  row_weight = (w * circumference.to(torch.float64)).contiguous()
-  # the normalisation stays on the device (no host sync): scale = 1, divide after
+  if row_weight is None:
+    row_weight = (w * circumference.to(torch.float64)).contiguous()
+  # without a host-side sum the normalisation stays on the device (no sync):
+  # scale = 1 in the kernel, one division afterwards
+  scale = 1.0 if weight_sum is None else 1.0 / float(weight_sum)
   partial = torch.empty((n_field, n_seg, n_bins), dtype=torch.float64,
                         device=x.device)
   out = torch.empty((n_field, n_bins), dtype=torch.float64, device=x.device)
   _lib.check(lib.wb2_zonal_spectrum_latmean(
-      handle, _lib.ptr(x), _lib.ptr(row_weight), n_lat, n_seg, 1.0,
+      handle, _lib.ptr(x), _lib.ptr(row_weight), n_lat, n_seg, scale,
       _lib.ptr(partial), _lib.ptr(out), current_stream_ptr(x.device)),
              'wb2_zonal_spectrum_latmean')
-  return (out / w.sum()).reshape(out_shape)
+  if weight_sum is None:
+    out = out / w.sum()
+  return out.reshape(out_shape)
 
 
 def spatial_maps(forecast: torch.Tensor, f_slab, truth: torch.Tensor, t_slab,
