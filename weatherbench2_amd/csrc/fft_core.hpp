@@ -361,10 +361,7 @@ constexpr int slab_slots() {
   using PL = Plan<N2>;
   constexpr int a = (N2 / PL::R0) * (PL::R0 + PL::PAD0);
   constexpr int b = (N2 / (PL::R0 * PL::R1)) * (PL::R0 * PL::R1 + PL::PAD1);
-  // N2 + 2 at least: the fused time mean parks a partial spectrum (N2 + 1
-  // doubles) of a wave in its slab (16-byte multiple)
-  constexpr int m = a > b ? a : b;
-  return m > N2 + 2 ? m : N2 + 2;
+  return a > b ? (a > N2 ? a : N2) : (b > N2 ? b : N2);
 }
 
 // ---- real-FFT recombination ----------------------------------------------------

@@ -177,12 +177,6 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   constexpr bool REDUCE = MODE != MATERIALISE;
   __shared__ __attribute__((aligned(16))) cf s_twq[NH + 1];
   __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][slab_slots<N2>()];
-  // TIME_MEAN: the four waves of a workgroup share ONE output row (each takes a
-  // quarter of the time steps) and meet here; bin counts of waves 1..3
-  __shared__ int s_cnt[MODE == TIME_MEAN ? NWAVE : 1][MODE == TIME_MEAN ? NH : 1];
-  static_assert(MODE != TIME_MEAN ||
-                    slab_slots<N2>() * sizeof(cf) >= (size_t)NB * sizeof(double),
-                "a slab must hold one partial spectrum");
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   for (int i = threadIdx.x; i <= NH; i += blockDim.x)
@@ -200,15 +194,8 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   if constexpr (MODE == TIME_MEAN) rows_out = p.n_rows / p.n_time;
   else if constexpr (MODE == LATSEG) rows_out = p.n_rows / p.n_lat * p.n_seg;
   else rows_out = p.n_rows;
-  // MATERIALISE / LATSEG: a wave per output row; TIME_MEAN: a WORKGROUP per
-  // output row (9373 rows over ~3000 resident waves is 3.05 rows per wave, i.e.
-  // a quarter of the machine idle in the last round; over ~770 workgroups it is
-  // 12.2 -- and the loop below is then uniform per workgroup, as its barriers need)
-  const long long stride =
-      (long long)gridDim.x * (MODE == TIME_MEAN ? 1 : NWAVE);
-  for (long long orow_i = MODE == TIME_MEAN
-                              ? (long long)blockIdx.x
-                              : (long long)blockIdx.x * NWAVE + wave;
+  const long long stride = (long long)gridDim.x * NWAVE;
+  for (long long orow_i = (long long)blockIdx.x * NWAVE + wave;
        orow_i < rows_out; orow_i += stride) {
     double sum1[NIT], sum2[NIT];
     int cnt[NIT];  // TIME + skipna: valid spectra, bin k (low half) / N2 - k
@@ -220,9 +207,7 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     long long nt = 1, row0 = orow_i, row_step = 0;
     int lat0 = 0;
     if constexpr (MODE == TIME_MEAN) {
-      const long long t_lo = (long long)wave * p.n_time / NWAVE;
-      nt = (long long)(wave + 1) * p.n_time / NWAVE - t_lo;
-      row0 = orow_i + t_lo * rows_out;
+      nt = p.n_time;
       row_step = rows_out;
     } else if constexpr (MODE == LATSEG) {
       const long long field = orow_i / p.n_seg;
@@ -338,52 +323,18 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
 #endif
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // reduced rows
-    if constexpr (MODE == TIME_MEAN) {
-      // waves 1..3 park their partial sums in their own (now idle) slab, wave 0
-      // adds them in wave order -- ((w0 + w1) + w2) + w3: deterministic -- and
-      // stores the mean
-      double* park = reinterpret_cast<double*>(z);
-      if (wave != 0) {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int k = lane + i * kWave;
-          if (k < NH) {
-            park[k] = sum1[i];
-            if (2 * k != N2) park[N2 - k] = sum2[i];
-            s_cnt[wave][k] = cnt[i];
-          }
-        }
-      }
-      __syncthreads();
-      if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int k = lane + i * kWave;
-          if (k < NH) {
-            double o1 = sum1[i], o2 = sum2[i];
-            int n12 = cnt[i];
-#pragma unroll
-            for (int w = 1; w < NWAVE; ++w) {
-              const double* other = reinterpret_cast<const double*>(s_z[w]);
-              o1 += other[k];
-              if (2 * k != N2) o2 += other[N2 - k];
-              n12 += s_cnt[w][k];
-            }
-            __builtin_nontemporal_store(o1 / (double)(n12 & 0xffff), orow + k);
-            if (2 * k != N2)
-              __builtin_nontemporal_store(o2 / (double)(n12 >> 16),
-                                          orow + N2 - k);
-          }
-        }
-      }
-      __syncthreads();  // the slabs are free again for the next output row
-    } else if constexpr (MODE == LATSEG) {
+    if constexpr (REDUCE) {
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
         const int k = lane + i * kWave;
         if (k < NH) {
-          __builtin_nontemporal_store(sum1[i], orow + k);
-          if (2 * k != N2) __builtin_nontemporal_store(sum2[i], orow + N2 - k);
+          double o1 = sum1[i], o2 = sum2[i];
+          if constexpr (MODE == TIME_MEAN) {
+            o1 /= (double)(cnt[i] & 0xffff);
+            o2 /= (double)(cnt[i] >> 16);
+          }
+          __builtin_nontemporal_store(o1, orow + k);
+          if (2 * k != N2) __builtin_nontemporal_store(o2, orow + N2 - k);
         }
       }
     }
@@ -451,16 +402,9 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
   long long rows_out = p.n_rows;
   if (mode == TIME_MEAN) rows_out = p.n_rows / p.n_time;
   if (mode == LATSEG) rows_out = p.n_rows / p.n_lat * p.n_seg;
-  long long blocks = mode == TIME_MEAN ? rows_out : (rows_out + 3) / 4;
-  // the packed 16-bit bin counts of the four waves are added: 4 x 16383 < 65536
+  long long blocks = (rows_out + 3) / 4;
   WB2_REQUIRE(p.n_time < 65536, "fused time mean: n_time=%lld exceeds 65535",
               p.n_time);
-  if (mode == TIME_MEAN) {
-    // exactly the resident set: every workgroup then walks ~rows_out / resident
-    // output rows (12.2 for 8 units on an MI355X) and they all finish together
-    const long long cap = resident_blocks(fused_spectrum_kernel<N2, TIME_MEAN>);
-    if (blocks > cap) blocks = cap;
-  }
   if (blocks > WB2_FFT_MAX_BLOCKS) blocks = WB2_FFT_MAX_BLOCKS;  // row-strided waves beyond that
   if (mode == TIME_MEAN)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN>),
