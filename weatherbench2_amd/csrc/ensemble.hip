@@ -57,12 +57,6 @@ struct EnsParams {
 #ifndef WB2_ENS_ASM_MINMAX
 #define WB2_ENS_ASM_MINMAX 1  // 0: __builtin_fmin/fmax (adds one canonicalize per member)
 #endif
-#ifndef WB2_ENS_PACKED_STATS
-// 1: member statistics two members at a time with packed fp32 instructions
-// (measured round 2: 7 % fewer VALU instructions but 130 VGPRs instead of 83,
-// i.e. 3 waves per SIMD instead of 5 -- slower; so is double-buffering the rows)
-#define WB2_ENS_PACKED_STATS 0
-#endif
 #ifndef WB2_ENS_BUFFER_LOADS
 #define WB2_ENS_BUFFER_LOADS 1  // 0: global loads with a 64-bit VALU address per member
 #endif
@@ -213,37 +207,9 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   T sum = 0, sk = 0;
   int n = 0;          // valid members (SKIPNA)
   bool bad = false;   // any NaN member (!SKIPNA)
-  // Exact member count, no NaN skipping, float32: the differences t - x and
-  // x - mean and the squares are taken two members at a time with packed fp32
-  // instructions (same IEEE operations, so bit-identical to the scalar form);
-  // the sums stay sequential in member order like numpy's, and one unordered
-  // compare per member PAIR finds the NaNs.
-  constexpr bool PACKED = WB2_ENS_PACKED_STATS && MS > 0 && !SKIPNA &&
-                          sizeof(T) == 4 && MS % 2 == 0;
-  typedef float f2 __attribute__((ext_vector_type(2)));
   T sq = 0;
   T mean;
-  if constexpr (PACKED) {
-#pragma unroll
-    for (int m = 0; m < NM; m += 2) {
-      const f2 xx = {(float)x[m], (float)x[m + 1]};
-      const f2 d = f2{(float)t, (float)t} - xx;
-      sum += x[m];
-      sum += x[m + 1];
-      sk += abs_of((T)d.x);
-      sk += abs_of((T)d.y);
-      bad = bad || __builtin_isunordered(x[m], x[m + 1]);
-    }
-    mean = sum / (T)M;
-#pragma unroll
-    for (int m = 0; m < NM; m += 2) {
-      const f2 xx = {(float)x[m], (float)x[m + 1]};
-      const f2 d = xx - f2{(float)mean, (float)mean};
-      const f2 q = d * d;
-      sq += (T)q.x;
-      sq += (T)q.y;
-    }
-  } else if constexpr (MS > 0 && !SKIPNA && MS % 2 == 0) {
+  if constexpr (MS > 0 && !SKIPNA && MS % 2 == 0) {
     // exact member count without NaN skipping: one unordered compare per member
     // PAIR finds the NaNs
 #pragma unroll
@@ -269,7 +235,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   // metrics.py:562-565 / :824 -- numpy mean / var(ddof=1) / mean(abs) over the
   // leading (member) axis: sequential, in the input dtype (nan* variants reduce
   // over the valid members only).
-  if constexpr (!PACKED) {
+  {
     mean = sum / (T)cnt;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
