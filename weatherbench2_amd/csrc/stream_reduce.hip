@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
   const double* part = p.partials + o * p.n_chunk * chunk_stride;
 
   // One thread per (band, weight field, seg, slot).  Its (chunk, entry) terms
-  // are independent loads: walk the flattened term index four at a time so four
+  // are independent loads: walk the flattened term index eight at a time so eight
   // loads are in flight per wait (the sum order stays fixed: deterministic).
   for (int idx = tid; idx < p.n_band * cell; idx += blockDim.x) {
     const int b = idx / cell, j = idx - b * cell;
@@ -518,6 +518,13 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
     };
     double v = 0.0;
     int i = 0;
+    for (; i + 8 <= n; i += 8) {  // eight loads in flight, adds in index order
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = term(i + u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
     for (; i + 4 <= n; i += 4) {
       const double t0 = term(i), t1 = term(i + 1), t2 = term(i + 2),
                    t3 = term(i + 3);

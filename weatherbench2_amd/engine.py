@@ -311,17 +311,17 @@ def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
              'wb2_time_accumulate')
 
 
-class _SpectrumPlans:
-  """hipFFT plans are expensive (rocFFT compiles kernels): cache by shape."""
+class _SpectrumPlans(threading.local):
+  """hipFFT plans are expensive (rocFFT compiles kernels): cache by shape.  One
+  cache per thread: a plan's hipFFT handle is bound to a stream while it runs,
+  and a thread only ever evicts plans of its own."""
 
   def __init__(self):
     self.plans = {}
 
   def get(self, dtype_code: int, n_lon: int, n_rows: int):
     import ctypes
-    # per thread: a plan's hipFFT handle is bound to a stream while it runs
-    key = (dtype_code, n_lon, n_rows, torch.cuda.current_device(),
-           threading.get_ident())
+    key = (dtype_code, n_lon, n_rows, torch.cuda.current_device())
     hit = self.plans.get(key)
     if hit is None:
       lib = _lib.load()
@@ -332,7 +332,7 @@ class _SpectrumPlans:
       nbytes = lib.wb2_spectrum_plan_workspace(handle)
       if nbytes < 0:
         _lib.check(-1, 'wb2_spectrum_plan_workspace')
-      if len(self.plans) >= 16:  # bounded: drop the oldest plan
+      if len(self.plans) >= 8:  # bounded: drop the oldest plan
         old_key = next(iter(self.plans))
         lib.wb2_spectrum_plan_destroy(self.plans.pop(old_key)[0])
       hit = (handle, int(nbytes))
