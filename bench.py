@@ -258,11 +258,30 @@ def self_launch(args) -> int:
     procs.append(subprocess.Popen(
         [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
         stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
-  out, _ = procs[0].communicate()
-  rc = procs[0].returncode
-  for pr in procs[1:]:
-    rc = max(rc, pr.wait())
-  sys.stdout.write(out)
+  # a rank that dies would leave the others waiting in a collective: watch all
+  # of them and take the job down with the first failure
+  import threading
+  out_box = []
+  reader = threading.Thread(
+      target=lambda: out_box.append(procs[0].stdout.read()), daemon=True)
+  reader.start()
+  rc = 0
+  while True:
+    codes = [pr.poll() for pr in procs]
+    failed = [c for c in codes if c not in (None, 0)]
+    if failed:
+      rc = failed[0]
+      for pr in procs:
+        if pr.poll() is None:
+          pr.kill()
+      break
+    if all(c == 0 for c in codes):
+      break
+    time.sleep(0.2)
+  for pr in procs:
+    pr.wait()
+  reader.join(timeout=10)
+  sys.stdout.write(out_box[0] if out_box else '')
   sys.stdout.flush()
   return rc
 

@@ -351,3 +351,41 @@ def test_caches_notice_in_place_updates_of_a_reused_buffer():
   fh += 2.0
   b1 = gm.Bias().compute_chunk(fo, to)['z'].values
   np.testing.assert_allclose(b1, b0 + 2.0, rtol=1e-6)
+
+
+def test_chunk_feeder_and_staged_upload_move_the_exact_bytes():
+  """feeder.upload (pinned slices on the copy stream, used for NumPy inputs of
+  the metrics) and feeder.ChunkFeeder (double-buffered chunk stream from NumPy
+  or pinned tensors): what arrives in HBM is byte-identical, chunk after chunk,
+  while passes over earlier chunks are still queued."""
+  import torch
+  from weatherbench2_amd import engine, feeder
+  dev = torch.device('cuda')
+  rs = np.random.RandomState(0)
+  big = rs.standard_normal((3, 721, 1440)).astype(np.float32)   # > one 64 MB... 12 MB
+  huge = rs.standard_normal((40, 721, 1440)).astype(np.float32)  # 166 MB: 3 slices
+  for arr in (big, huge, rs.standard_normal((5, 7)), np.arange(10, dtype=np.int64)):
+    got = feeder.upload(np.ascontiguousarray(arr), dev)
+    torch.cuda.synchronize()
+    assert got.dtype == torch.from_numpy(arr[:0].copy()).dtype
+    np.testing.assert_array_equal(got.cpu().numpy(), arr)
+  via_engine = engine.as_device_tensor(big, dev)
+  np.testing.assert_array_equal(via_engine.cpu().numpy(), big)
+  chunks = [rs.standard_normal((2, 64, 128)).astype(np.float32)
+            for _ in range(5)]
+  fd = feeder.ChunkFeeder((2, 64, 128), torch.float32, dev, depth=2)
+  sums = []
+  fd.submit(chunks[0])
+  for i in range(len(chunks)):
+    if i + 1 < len(chunks):
+      src = chunks[i + 1]
+      if i % 2:  # alternate NumPy / pinned-tensor sources
+        src = torch.from_numpy(src).pin_memory()
+      fd.submit(src)
+    x = fd.acquire()
+    sums.append(x.double().sum())   # queued work on the compute stream
+    got = x.clone()
+    fd.release()
+    np.testing.assert_array_equal(got.cpu().numpy(), chunks[i])
+  for s, c in zip(sums, chunks):
+    np.testing.assert_allclose(float(s), c.astype(np.float64).sum(), rtol=1e-12)
