@@ -309,7 +309,11 @@ def main():
   # RCCL ("nccl") is the production backend; WB2_BENCH_DIST_BACKEND=gloo exists
   # only so the N > 1 control flow can be smoke-tested on a 1-GPU box.
   backend = os.environ.get('WB2_BENCH_DIST_BACKEND', 'nccl')
-  if world > 1:
+  # a process group exists whenever a launcher set the rendezvous up -- also
+  # for ONE rank (python -m torch.distributed.run --nproc-per-node 1): the RCCL
+  # calls of the N > 1 path then run on a 1-GPU box too
+  ddp = world > 1 or ('WORLD_SIZE' in os.environ and 'MASTER_PORT' in os.environ)
+  if ddp:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if backend == 'nccl':
       dist.init_process_group('nccl', device_id=dev)
@@ -327,7 +331,7 @@ def main():
 
   def per_rank(value: float) -> list:
     """[value of rank 0, ..., value of rank world-1] on every rank."""
-    if world == 1:
+    if not ddp:
       return [value]
     mine = torch.zeros(world, dtype=torch.float64, device=dev)
     mine[rank] = value
@@ -378,7 +382,7 @@ def main():
   # which costs tens of ms and is not part of the hot path.
   step(0, False)
   _ = (total / count).sum().item()
-  if world > 1:
+  if ddp:
     all_reduce(torch.cat([total.reshape(-1), count.reshape(-1)]))
 
   def timed_region(step_fn, n_steps, accumulators):
@@ -388,7 +392,7 @@ def main():
     for a in accumulators:
       a.zero_()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
       dist.barrier()
     torch.cuda.synchronize()
     g0 = torch.cuda.Event(enable_timing=True)
@@ -399,7 +403,7 @@ def main():
       step_fn(i)
     g1.record()
     means = []
-    if world > 1:  # the path's only exchange: every [sum, count] pair, once
+    if ddp:  # the path's only exchange: every [sum, count] pair, once
       shapes = [a.shape for a in accumulators]
       packed = all_reduce(torch.cat([a.reshape(-1) for a in accumulators]))
       accumulators, off = [], 0
@@ -410,11 +414,11 @@ def main():
       means.append(s_ / c_)
     torch.cuda.synchronize()
     own = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
       dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
       dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev),
                             dist.ReduceOp.MAX).item())
     for m in means:
@@ -455,12 +459,12 @@ def main():
           'parallelism': f'init-time shards x{world}, 1 all-reduce of [sum,count]',
           'launcher': ('self-spawned ranks' if os.environ.get(
               'WB2_BENCH_SELF_LAUNCHED') else
-                       'torch.distributed.run' if world > 1 else 'single process'),
+                       'torch.distributed.run' if ddp else 'single process'),
       },
       'ranks': {
-          'world_size_seen': dist.get_world_size() if world > 1 else 1,
+          'world_size_seen': dist.get_world_size() if ddp else 1,
           'backend': ('rccl (torch "nccl")' if backend == 'nccl' else backend)
-                     if world > 1 else None,
+                     if ddp else None,
           'ms_per_step_per_rank': rank_ms,
       },
       'roofline': {
@@ -491,7 +495,7 @@ def main():
   if not args.no_full_suite:
     out['full_suite'] = full_suite(args, dev, pl, step, (total, count),
                                    timed_region, per_rank, world, rank)
-  if world > 1:
+  if ddp:
     out['map_allreduce'] = map_allreduce(dev, all_reduce, world, backend)
   if rank == 0 and world == 1 and not args.no_api:
     try:
@@ -514,7 +518,7 @@ def main():
                        f'{one["seconds"]:.1f} s (the multi-process leg failed: '
                        f'{type(e).__name__}: {e})')}
     print(json.dumps(out))
-  if world > 1:
+  if ddp:
     dist.barrier()
     dist.destroy_process_group()
 

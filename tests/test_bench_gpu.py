@@ -35,3 +35,33 @@ def test_self_launched_two_ranks_on_one_gpu():
   assert len(line['full_suite']['ms_per_step_per_rank']) == 2
   assert line['map_allreduce']['bytes_per_rank'] == 2 * 4 * 13 * 721 * 1440 * 8
   assert 'roofline' in line and line['roofline']['frac'] > 0
+
+
+def test_torchrun_single_rank_uses_rccl():
+  """The driver's launch line with ONE rank: the process group is RCCL
+  (torch "nccl"), so init with device_id, barrier, the [sum, count] all-reduce,
+  the MAX of the timings and the 864 MB map all-reduce all run through RCCL on
+  the 1-GPU box."""
+  import socket
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ)
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT',
+            'WB2_BENCH_SAME_GPU', 'WB2_BENCH_DIST_BACKEND'):
+    env.pop(k, None)
+  out = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+       '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
+       str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3',
+       '--warmup', '1', '--units', '2', '--pool', '4', '--ramp-ms', '0',
+       '--no-cpu-baseline', '--no-api'], env=env, cwd=ROOT, capture_output=True,
+      text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = json.loads([l for l in out.stdout.strip().splitlines()
+                     if l.startswith('{')][-1])
+  assert line['n_gpus'] == 1 and line['ranks']['world_size_seen'] == 1
+  assert line['ranks']['backend'].startswith('rccl')
+  assert line['config']['launcher'] == 'torch.distributed.run'
+  assert line['map_allreduce']['ms'] > 0
+  assert line['full_suite']['value'] > 0 and line['value'] > 0
