@@ -411,6 +411,25 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
                        int32_t n_lat, int64_t n_time, int skipna, double* out,
                        void* workspace, void* stream);
 
+/* wb2_rank_histogram with the reference's SEEDED tie breaking reproduced
+ * (metrics.py:1955-1980: np.random.default_rng(seed).uniform over the
+ * concatenated [truth, members] array): pcg_state_inc[4] (HOST) = the 128-bit
+ * state and increment of np.random.PCG64(seed) as (state hi, state lo, inc hi,
+ * inc lo); element (outer o, row r, col c, j) of the reference's concatenated
+ * array (j = 0 truth, j >= 1 member j - 1; n_point = n_row * n_col points per
+ * slab) has the C-order index
+ *   ref_outer_off[o] (DEV int64[n_outer]) + r ref_strides[0] + c ref_strides[1]
+ *   + j ref_strides[2]      (ref_strides: HOST int64[3]),
+ * which is where in NumPy's stream its perturbation comes from.  Everything else
+ * as wb2_rank_histogram with break_ties = 1. */
+int wb2_rank_histogram_seeded(
+    int dtype, const void* ens, const int64_t* ens_slab, const void* truth,
+    const int64_t* truth_slab, int32_t n_member, int64_t member_stride,
+    int64_t n_outer, int64_t n_point, int32_t n_col, int32_t n_bins,
+    const uint64_t* pcg_state_inc, const int64_t* ref_outer_off,
+    const int64_t* ref_strides, const int64_t* acc_row, double* out,
+    void* stream);
+
 /* BASELINE configs[3] in one pass: the latitude-weighted mean of the zonal energy
  * spectrum WITHOUT materialising the per-latitude spectra,
  *   out[field][k] = scale * sum_lat row_weight[lat] * S[field][lat][k],

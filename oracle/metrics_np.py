@@ -843,7 +843,9 @@ class RankHistogram(EnsembleMetric):
     return self.num_bins
 
   def _perturb(self, data: np.ndarray, idx: int) -> np.ndarray:
-    """metrics.py:1955-1980."""
+    """metrics.py:1955-1980.  `data` must be laid out like the reference's
+    concatenated array: `np.random.default_rng(seed).uniform(size=da.shape)`
+    consumes the stream in C order of THAT shape."""
     if data.shape[idx] < 2:
       return data
     with np.errstate(all='ignore'):
@@ -855,19 +857,45 @@ class RankHistogram(EnsembleMetric):
         size=data.shape, low=-size / 2, high=size / 2)
     return data + perturbation
 
+  @staticmethod
+  def _concat_dims(fdims, tdims, ensemble_dim):
+    """Dim order of `xr.concat([truth, forecast], dim=ensemble_dim)`
+    (metrics.py:2014) -- third-party behaviour, restated from xarray
+    (core/concat.py, `_dataset_concat.ensure_common_dims`):
+        common_dims = tuple(OrderedSet(d for v in vars for d in v.dims))
+        if dim not in common_dims: common_dims = (dim,) + common_dims
+    with vars = [truth variable, forecast variable]: the truth's dims come
+    first, then the forecast's dims not seen yet IN THE FORECAST'S ORDER -- the
+    ensemble dim (truth only has it as a scalar coordinate) and any dim only the
+    forecast has (e.g. a lead time the truth was not expanded over).  The
+    perturbation stream is consumed in C order of this layout."""
+    out = list(tdims)
+    for d in fdims:
+      if d not in out:
+        out.append(d)
+    if ensemble_dim not in out:
+      out.insert(0, ensemble_dim)
+    return tuple(out)
+
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
     out = {}
     for name in [k for k in forecast.keys() if k in truth.keys()]:
       f = forecast[name]
-      ax = f.dims.index(self.ensemble_dim)
-      rest = tuple(d for d in f.dims if d != self.ensemble_dim)
-      fd = np.moveaxis(f.data, ax, 0)
-      td = NA._align(NA(np.zeros(fd.shape[1:]), rest), truth[name])[1]
-      td = np.broadcast_to(td, fd.shape[1:])
-      combined = np.concatenate([td[None], fd], axis=0)  # truth prepended
+      t = truth[name]
+      cdims = self._concat_dims(f.dims, t.dims, self.ensemble_dim)
+      ax = cdims.index(self.ensemble_dim)
+      rest = tuple(d for d in cdims if d != self.ensemble_dim)
+      fd = f.transpose(*cdims).data                        # forecast in concat order
+      td = NA._align(NA(np.zeros([n for i, n in enumerate(fd.shape) if i != ax]),
+                        rest), t)[1]
+      td = np.broadcast_to(td, [n for i, n in enumerate(fd.shape) if i != ax])
+      td = np.expand_dims(td, ax).astype(
+          np.result_type(t.data.dtype, fd.dtype), copy=False)
+      combined = np.concatenate([td, fd], axis=ax)  # truth prepended
       if self._break_ties_randomly:
-        combined = self._perturb(combined, 0)
-      ensemble_size = fd.shape[0]
+        combined = self._perturb(combined, ax)
+      combined = np.moveaxis(combined, ax, 0)
+      ensemble_size = fd.shape[ax]
       num_bins = self._num_bins_actual(ensemble_size)
       order = np.argsort(combined, axis=0)
       ranks = np.argmin(order, axis=0)  # where the truth (index 0) ended up

@@ -281,3 +281,105 @@ def test_rank_histogram_c_abi_edge_shapes():
                                   truth, None, n_outer, n_point, n_bins, True,
                                   5, rows, 1)
       torch.testing.assert_close(acc[0], want.sum(0), rtol=0, atol=0)
+
+
+def _tied(ds, step, seed):
+  """Quantises the values so that ties between truth and members are common."""
+  return ds.copy(data={k: (np.round(v.data / step) * step).astype(v.data.dtype)
+                       for k, v in ds.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ensemble_size,num_bins,dtype,step', [
+    (1, None, np.float32, 1.0), (2, None, np.float64, 0.5),
+    (5, 3, np.float32, 0.5), (10, None, np.float32, 0.25),
+    (50, None, np.float32, 0.5), (50, 17, np.float64, 1.0)])
+def test_seeded_ties_reproduce_numpy_stream(ensemble_size, num_bins, dtype, step):
+  """With a seed the reference breaks ties with
+  np.random.default_rng(seed).uniform over the concatenated [truth, members]
+  array (metrics.py:1955-1980).  The kernel jumps PCG64 to each element's place
+  in that stream: one-hot outputs EQUAL the oracle's (which runs NumPy's RNG
+  itself) on heavily tied data -- the mock layout has a lead-time dim only the
+  forecast carries, so the member stride in the stream is not 1."""
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=ensemble_size, spatial_resolution_in_degrees=20,
+      time_start='2019-12-01', time_stop='2019-12-03', levels=(0, 1))
+  truth = _tied(_as(truth, dtype), step, 0)
+  forecast = _tied(_as(forecast, dtype), step, 1)
+  for seed in (0, 802701):
+    want = om.RankHistogram(num_bins=num_bins, seed=seed).compute_chunk(
+        forecast, truth)
+    g = helpers.to_gpu_dataset
+    got = gm.RankHistogram(num_bins=num_bins, seed=seed).compute_chunk(
+        g(forecast), g(truth))
+    for name in want.keys():
+      assert got[name].dims == want[name].dims
+      np.testing.assert_array_equal(_values(got[name]), want[name].data,
+                                    err_msg=f'seed {seed}')
+  # the ties are really there (otherwise this test would prove nothing)
+  f = forecast['geopotential']
+  t = NA._align(f, truth['geopotential'])[1]
+  assert (f.data == t).any(axis=f.dims.index('realization')).mean() > 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('layout', ['ens_last_dims_match', 'ens_middle'])
+def test_seeded_ties_other_layouts_nan_and_inf(layout):
+  """Truth with the forecast's dims (stride 1 between members in the stream) and
+  an ensemble dim in the middle; NaN members / truth and repeated infinities
+  switch the reference to its +-1/4 perturbation (min_diff is NaN), which can
+  reorder DISTINCT values: reproduced too."""
+  from weatherbench2_amd import metrics as gm
+  rs = np.random.RandomState(4)
+  n_t, n_m, n_lat, n_lon = 3, 7, 6, 9
+  lat = np.linspace(-75, 75, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  if layout == 'ens_last_dims_match':
+    fdims = ('time', 'latitude', 'longitude', 'realization')
+    tdims = ('time', 'latitude', 'longitude')
+  else:
+    fdims = ('time', 'realization', 'longitude', 'latitude')
+    tdims = ('time', 'longitude', 'latitude')
+  sizes = {'time': n_t, 'realization': n_m, 'latitude': n_lat,
+           'longitude': n_lon}
+  f = np.round(rs.standard_normal([sizes[d] for d in fdims]) * 2) / 4
+  t = np.round(rs.standard_normal([sizes[d] for d in tdims]) * 2) / 4
+  f = f.astype(np.float32)
+  t = t.astype(np.float32)
+  f[rs.rand(*f.shape) < 0.05] = np.nan
+  t[rs.rand(*t.shape) < 0.05] = np.nan
+  f[rs.rand(*f.shape) < 0.05] = np.inf
+  f[rs.rand(*f.shape) < 0.03] = -np.inf
+  t[rs.rand(*t.shape) < 0.03] = np.inf
+  coords = {'time': np.arange(n_t), 'realization': np.arange(n_m),
+            'latitude': lat, 'longitude': lon}
+  forecast = DS({'z': NA(f, fdims)}, coords)
+  truth = DS({'z': NA(t, tdims)}, {k: v for k, v in coords.items()
+                                   if k != 'realization'})
+  want = om.RankHistogram(seed=5).compute_chunk(forecast, truth)['z']
+  g = helpers.to_gpu_dataset
+  got = gm.RankHistogram(seed=5).compute_chunk(g(forecast), g(truth))['z']
+  assert got.dims == want.dims
+  a, w = _values(got), want.data
+  # NaN truths: among several NaNs np.argsort's order is unspecified -- the
+  # product takes the first NaN position; compare the rest exactly
+  t_full = np.broadcast_to(t, w.shape[:-1]) if layout == 'ens_last_dims_match' \
+      else np.broadcast_to(t, w.shape[:-1])
+  ok = ~np.isnan(t_full)
+  np.testing.assert_array_equal(a[ok], w[ok])
+  np.testing.assert_array_equal(a.sum(-1), 1.0)
+
+
+@pytest.mark.gpu
+def test_seeded_temporal_mean_matches_oracle():
+  from weatherbench2_amd import metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      ensemble_size=4, spatial_resolution_in_degrees=20,
+      time_start='2019-12-01', time_stop='2019-12-05', levels=(0,))
+  truth, forecast = _tied(truth, 0.5, 0), _tied(forecast, 0.5, 1)
+  want = om.RankHistogram(seed=9).compute(forecast, truth)['geopotential']
+  g = helpers.to_gpu_dataset
+  got = gm.RankHistogram(seed=9).compute(g(forecast), g(truth))['geopotential']
+  assert got.dims == want.dims
+  np.testing.assert_allclose(_values(got), want.data, rtol=0, atol=1e-15)

@@ -17,6 +17,20 @@
 // which makes the truth's place among the eq + 1 equal values uniform; here
 // that uniform draw comes from a counter-based hash of (seed, sample index),
 // statistically equivalent and reproducible, but not NumPy's bit stream.
+// With a SEED the reference's draw itself is reproduced (the `pcg` fields):
+// `np.random.default_rng(seed).uniform(size=da.shape, low=-s/2, high=s/2)` is
+// PCG64 consumed one 64-bit output per element in C order of the concatenated
+// array, so element k needs the generator advanced by k + 1 steps -- an O(log k)
+// jump of the 128-bit LCG -- and nothing else: every sample whose rank the
+// perturbation can change (a member equal to the truth, or a NaN / repeated
+// infinity, for which the reference falls back to a perturbation of +-1/4)
+// recomputes the reference's perturbation size s (half the smallest positive
+// gap among the M + 1 values, in the data dtype), perturbs its M + 1 values in
+// float64 exactly like `da + perturbation` and counts the members below the
+// truth.  All other samples are untouched by the perturbation (it is at most a
+// quarter of the smallest gap).  The element order of the concatenated array is
+// the host's business (`ref_*`: xarray's concat puts the ensemble dim after the
+// truth's dims, see metrics.RankHistogram).
 // break_ties=0 puts the truth first among equals (the reference leaves that
 // case to an unstable argsort).  NaN members rank above everything; a NaN truth
 // ranks above every non-NaN member (:1909-1912).
@@ -46,7 +60,97 @@ struct RankParams {
   long long member_stride, n_outer, n_point;
   unsigned long long seed;
   int n_member, n_bins, factor, break_ties;
+  // PCG64 emulation of the reference's seeded perturbation (ref_outer_off ==
+  // null: off).  Element (outer o, row r, col c, j) of the reference's
+  // concatenated array (j = 0: truth, j >= 1: member j - 1) has the C-order index
+  //   ref_outer_off[o] + r ref_row_stride + c ref_col_stride + j ref_member_stride.
+  const long long* ref_outer_off;
+  long long ref_row_stride, ref_col_stride, ref_member_stride;
+  int n_col;
+  unsigned long long pcg_state_hi, pcg_state_lo, pcg_inc_hi, pcg_inc_lo;
 };
+
+// ---- NumPy's PCG64 (PCG XSL RR 128/64): state = state * MULT + inc, output of
+// the NEW state; next_double = (next_uint64 >> 11) * 2^-53 --------------------
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 make_u128(unsigned long long hi,
+                                          unsigned long long lo) {
+  return ((u128)hi << 64) | (u128)lo;
+}
+__device__ __forceinline__ u128 pcg_mult() {
+  return make_u128(0x2360ED051FC65DA4ull, 0x4385DF649FCCF645ull);
+}
+// state after n steps (Brown's O(log n) LCG jump, as in pcg64_advance)
+__device__ u128 pcg_advance(u128 state, u128 inc, unsigned long long n) {
+  u128 acc_mult = 1, acc_plus = 0, cur_mult = pcg_mult(), cur_plus = inc;
+  while (n > 0) {
+    if (n & 1) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    n >>= 1;
+  }
+  return acc_mult * state + acc_plus;
+}
+__device__ __forceinline__ double pcg_double(u128 state) {
+  const unsigned long long hi = (unsigned long long)(state >> 64);
+  const unsigned long long lo = (unsigned long long)state;
+  const unsigned long long x = hi ^ lo;
+  const unsigned rot = (unsigned)(hi >> 58);
+  const unsigned long long r = (x >> rot) | (x << ((64 - rot) & 63));
+  return (double)(r >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// The reference's rank of the truth among its M members after
+// _perturb_by_min_ensemble_diff (metrics.py:1955-1980) + argsort/argmin
+// (:2024-2027), for ONE sample whose first element has index `elem0` in the
+// reference's stream.
+template <typename T>
+__device__ int perturbed_rank(const T* xb, long long member_stride, int M, T t,
+                              int nn, const RankParams& p, long long elem0) {
+  const T inf = __builtin_huge_val();
+  // perturbation size: half the smallest positive difference of the sorted
+  // values (= of any two values), NaN (-> 1) if the sorted differences contain
+  // a NaN: a NaN value, or inf - inf of two equal infinities
+  bool nan_rule = is_nan(t) || nn != M;
+  int n_pinf = t == inf ? 1 : 0, n_ninf = t == -inf ? 1 : 0;
+  T mn = inf;
+  for (int a = 0; a <= M; ++a) {
+    const T va = a == 0 ? t : xb[(a - 1) * member_stride];
+    if (a > 0) {
+      n_pinf += va == inf ? 1 : 0;
+      n_ninf += va == -inf ? 1 : 0;
+    }
+    for (int b = a + 1; b <= M; ++b) {
+      const T vb = xb[(b - 1) * member_stride];
+      const T d = abs_of(va - vb);
+      if (d > (T)0 && d < mn) mn = d;
+    }
+  }
+  nan_rule = nan_rule || n_pinf >= 2 || n_ninf >= 2;
+  const T size = (!nan_rule && mn < inf) ? mn / (T)2 : (T)1;
+  const T low = -size / (T)2, high = size / (T)2;
+  const double dlow = (double)low, range = (double)high - (double)low;
+  const u128 s0 = make_u128(p.pcg_state_hi, p.pcg_state_lo);
+  const u128 inc = make_u128(p.pcg_inc_hi, p.pcg_inc_lo);
+  u128 s = pcg_advance(s0, inc, (unsigned long long)elem0 + 1);
+  const double v0 = (double)t + (dlow + range * pcg_double(s));
+  int rank = 0;
+  for (int j = 1; j <= M; ++j) {
+    if (p.ref_member_stride == 1)
+      s = s * pcg_mult() + inc;
+    else
+      s = pcg_advance(s0, inc,
+                      (unsigned long long)(elem0 + j * p.ref_member_stride) + 1);
+    const double vj =
+        (double)xb[(j - 1) * member_stride] + (dlow + range * pcg_double(s));
+    rank += vj < v0 ? 1 : 0;
+  }
+  // NaN sorts last (np.argsort): a NaN truth ranks above every non-NaN member
+  return is_nan(t) ? nn : rank;
+}
 
 // splitmix64 finaliser: a counter-based stream, one draw per sample
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
@@ -74,7 +178,7 @@ __global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p)
     const T* xb = static_cast<const T*>(p.ens) + es * p.n_point + pt;
     const T t = __builtin_nontemporal_load(
         static_cast<const T*>(p.truth) + ts * p.n_point + pt);
-    int lo = 0, eq = 0, nn = 0;
+    int lo = 0, eq = 0, nn = 0, ninf = 0;
     int m = 0;
     for (; m + 4 <= M; m += 4) {  // four loads in flight
       T x[4];
@@ -86,6 +190,7 @@ __global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p)
         lo += x[u] < t ? 1 : 0;
         eq += x[u] == t ? 1 : 0;
         nn += is_nan(x[u]) ? 0 : 1;
+        ninf += abs_of(x[u]) == (T)__builtin_huge_val() ? 1 : 0;
       }
     }
     for (; m < M; ++m) {
@@ -93,9 +198,20 @@ __global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p)
       lo += x < t ? 1 : 0;
       eq += x == t ? 1 : 0;
       nn += is_nan(x) ? 0 : 1;
+      ninf += abs_of(x) == (T)__builtin_huge_val() ? 1 : 0;
     }
     int rank = is_nan(t) ? nn : lo;
-    if (eq > 0 && p.break_ties) {
+    if (p.break_ties && p.ref_outer_off) {
+      // seeded: the reference's own perturbation wherever it can matter
+      const bool special = eq > 0 || nn != M || is_nan(t) || ninf > 0 ||
+                           abs_of(t) == (T)__builtin_huge_val();
+      if (special) {
+        const long long row = pt / p.n_col, col = pt - row * p.n_col;
+        const long long elem0 = p.ref_outer_off[o] + row * p.ref_row_stride +
+                                col * p.ref_col_stride;
+        rank = perturbed_rank<T>(xb, p.member_stride, M, t, nn, p, elem0);
+      }
+    } else if (eq > 0 && p.break_ties) {
       const unsigned long long h =
           mix64(p.seed ^ mix64((unsigned long long)(o * p.n_point + pt)));
       // uniform integer in [0, eq]: high bits of a 32x32 multiply
@@ -131,6 +247,35 @@ __global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p)
 }  // namespace
 }  // namespace wb2
 
+static int rank_histogram_impl(int dtype, const void* ens,
+                               const int64_t* ens_slab, const void* truth,
+                               const int64_t* truth_slab, int32_t n_member,
+                               int64_t member_stride, int64_t n_outer,
+                               int64_t n_point, int32_t n_bins, int break_ties,
+                               uint64_t seed, const int64_t* acc_row,
+                               double* out, const int64_t* ref_outer_off,
+                               const int64_t* ref_strides, int32_t n_col,
+                               const uint64_t* pcg_state_inc, void* stream);
+
+extern "C" int wb2_rank_histogram_seeded(
+    int dtype, const void* ens, const int64_t* ens_slab, const void* truth,
+    const int64_t* truth_slab, int32_t n_member, int64_t member_stride,
+    int64_t n_outer, int64_t n_point, int32_t n_col, int32_t n_bins,
+    const uint64_t* pcg_state_inc, const int64_t* ref_outer_off,
+    const int64_t* ref_strides, const int64_t* acc_row, double* out,
+    void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(pcg_state_inc && ref_outer_off && ref_strides,
+              "null pointer argument");
+  WB2_REQUIRE(n_col >= 1 && n_point % n_col == 0, "n_point=%lld n_col=%d",
+              (long long)n_point, n_col);
+  return rank_histogram_impl(dtype, ens, ens_slab, truth, truth_slab, n_member,
+                             member_stride, n_outer, n_point, n_bins, 1, 0,
+                             acc_row, out, ref_outer_off, ref_strides, n_col,
+                             pcg_state_inc, stream);
+}
+
 extern "C" int wb2_rank_histogram(int dtype, const void* ens,
                                   const int64_t* ens_slab, const void* truth,
                                   const int64_t* truth_slab, int32_t n_member,
@@ -140,6 +285,21 @@ extern "C" int wb2_rank_histogram(int dtype, const void* ens,
                                   const int64_t* acc_row, double* out,
                                   void* stream) {
   WB2_TRACE();
+  return rank_histogram_impl(dtype, ens, ens_slab, truth, truth_slab, n_member,
+                             member_stride, n_outer, n_point, n_bins,
+                             break_ties, seed, acc_row, out, nullptr, nullptr, 1,
+                             nullptr, stream);
+}
+
+static int rank_histogram_impl(int dtype, const void* ens,
+                               const int64_t* ens_slab, const void* truth,
+                               const int64_t* truth_slab, int32_t n_member,
+                               int64_t member_stride, int64_t n_outer,
+                               int64_t n_point, int32_t n_bins, int break_ties,
+                               uint64_t seed, const int64_t* acc_row,
+                               double* out, const int64_t* ref_outer_off,
+                               const int64_t* ref_strides, int32_t n_col,
+                               const uint64_t* pcg_state_inc, void* stream) {
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64,
               "dtype must be WB2_F32 or WB2_F64, got %d", dtype);
@@ -169,6 +329,15 @@ extern "C" int wb2_rank_histogram(int dtype, const void* ens,
   p.n_bins = n_bins;
   p.factor = (n_member + 1) / n_bins;
   p.break_ties = break_ties;
+  p.ref_outer_off = reinterpret_cast<const long long*>(ref_outer_off);
+  p.ref_row_stride = ref_strides ? ref_strides[0] : 0;
+  p.ref_col_stride = ref_strides ? ref_strides[1] : 0;
+  p.ref_member_stride = ref_strides ? ref_strides[2] : 0;
+  p.n_col = n_col;
+  p.pcg_state_hi = pcg_state_inc ? pcg_state_inc[0] : 0;
+  p.pcg_state_lo = pcg_state_inc ? pcg_state_inc[1] : 0;
+  p.pcg_inc_hi = pcg_state_inc ? pcg_state_inc[2] : 0;
+  p.pcg_inc_lo = pcg_state_inc ? pcg_state_inc[3] : 0;
   const long long gy = n_outer < 32768 ? n_outer : 32768;
   const long long gz = (n_outer + gy - 1) / gy;
   WB2_REQUIRE(gz <= 65535, "n_outer=%lld too large", (long long)n_outer);

@@ -501,9 +501,15 @@ def ensemble_threshold_reduce(plan: ReductionPlan, ens: torch.Tensor,
 def rank_histogram(ens: torch.Tensor, member_stride: int, n_member: int,
                    ens_slab, truth: torch.Tensor, truth_slab, n_outer: int,
                    n_point: int, n_bins: int, break_ties: bool, seed: int,
-                   acc_row=None, n_acc: int = 0) -> torch.Tensor:
+                   acc_row=None, n_acc: int = 0, numpy_stream=None
+                   ) -> torch.Tensor:
   """wb2_rank_histogram: one-hot [n_outer, n_point, n_bins] (float64), or with
-  `acc_row` the per-row counts [n_acc, n_point, n_bins]."""
+  `acc_row` the per-row counts [n_acc, n_point, n_bins].
+
+  `numpy_stream` = (pcg_state, pcg_inc, ref_outer_off[n_outer] int64 device
+  tensor, (row, col, member) strides, n_col) switches to
+  wb2_rank_histogram_seeded: ties are broken with the very perturbations
+  np.random.default_rng(seed).uniform hands the reference."""
   lib = _lib.load()
   dev = ens.device
   if ens.dtype not in _DTYPES or truth.dtype != ens.dtype:
@@ -517,6 +523,20 @@ def rank_histogram(ens: torch.Tensor, member_stride: int, n_member: int,
   else:
     out = torch.zeros((n_acc, n_point, n_bins), dtype=torch.float64,
                       device=dev)
+  if numpy_stream is not None and break_ties:
+    import ctypes
+    state, inc, ref_off, strides, n_col = numpy_stream
+    mask = (1 << 64) - 1
+    pcg = (ctypes.c_uint64 * 4)(state >> 64, state & mask, inc >> 64, inc & mask)
+    st = (ctypes.c_int64 * 3)(*[int(v) for v in strides])
+    if ref_off.dtype != torch.int64 or ref_off.numel() != n_outer:
+      raise ValueError('ref_outer_off must be int64[n_outer]')
+    _lib.check(lib.wb2_rank_histogram_seeded(
+        _DTYPES[ens.dtype], _lib.ptr(ens), _lib.ptr(ens_slab), _lib.ptr(truth),
+        _lib.ptr(truth_slab), n_member, member_stride, n_outer, n_point,
+        int(n_col), n_bins, pcg, _lib.ptr(ref_off), st, _lib.ptr(acc_row),
+        _lib.ptr(out), current_stream_ptr(dev)), 'wb2_rank_histogram_seeded')
+    return out
   _lib.check(lib.wb2_rank_histogram(
       _DTYPES[ens.dtype], _lib.ptr(ens), _lib.ptr(ens_slab), _lib.ptr(truth),
       _lib.ptr(truth_slab), n_member, member_stride, n_outer, n_point, n_bins,

@@ -2097,9 +2097,12 @@ class RankHistogram(EnsembleMetric):
   dim; compute() accumulates the temporal mean on the device without
   materialising the per-time one-hots.  Ranks come from wb2_rank_histogram
   (counting, no sort): identical to the reference wherever truth differs from
-  every member; ties are broken uniformly at random from a counter-based
-  stream keyed on `seed` (the reference perturbs with NumPy's RNG -- same
-  distribution, different stream; `seed=None` draws a fresh key per call).
+  every member.  With a `seed` the reference's random tie breaking itself is
+  reproduced: the kernel jumps NumPy's PCG64 (`np.random.default_rng(seed)`) to
+  the position each element of the reference's concatenated [truth, members]
+  array has in the stream and applies the same perturbation
+  (metrics.py:1955-1980); `seed=None` (fresh entropy in the reference too)
+  draws from a counter-based stream with the same distribution.
   NaNs rank highest and `skipna` is ignored, like the reference.
   """
 
@@ -2122,6 +2125,41 @@ class RankHistogram(EnsembleMetric):
           f'Cannot bin data with {ensemble_size=} into {self.num_bins} bins')
     return self.num_bins
 
+  def _concat_dims(self, fvar, tvar) -> tuple:
+    """Dim order of the reference's `xr.concat([truth, forecast],
+    dim=ensemble_dim)` (metrics.py:2014): xarray lists the dims of the first
+    object, then the unseen dims of the next ones in their order
+    (core/concat.py, ensure_common_dims) -- the truth's dims, then the ensemble
+    dim, then whatever only the forecast has.  It fixes both the result's dim
+    order and the order in which the seeded perturbation stream is consumed."""
+    cdims = list(tvar.dims) + [d for d in fvar.dims if d not in tvar.dims]
+    return tuple(cdims)
+
+  def _numpy_stream(self, fvar, tvar, geo, n_member, device):
+    """Where in np.random.default_rng(seed)'s stream every element of the
+    reference's concatenated array gets its perturbation from (C order of the
+    concat layout), as strides for wb2_rank_histogram_seeded."""
+    cdims = self._concat_dims(fvar, tvar)
+    sizes = {**dict(tvar.sizes), **dict(fvar.sizes)}
+    sizes[self.ensemble_dim] = n_member + 1
+    stride, acc = {}, 1
+    for d in reversed(cdims):
+      stride[d] = acc
+      acc *= sizes[d]
+    off = np.zeros(geo.out_shape, dtype=np.int64)
+    for ax, (d, n) in enumerate(zip(geo.out_dims, geo.out_shape)):
+      shape = [1] * len(geo.out_shape)
+      shape[ax] = n
+      off = off + (np.arange(n, dtype=np.int64) * stride[d]).reshape(shape)
+    row_dim, col_dim = (_SPATIAL if geo.layout == plan_lib.LATLON
+                        else _SPATIAL[::-1])
+    state = np.random.PCG64(self._seed).state['state']
+    n_col = len(geo.longitude if geo.layout == plan_lib.LATLON
+                else geo.latitude)
+    return (int(state['state']), int(state['inc']),
+            engine.upload_table(np.ascontiguousarray(off).ravel(), device),
+            (stride[row_dim], stride[col_dim], stride[self.ensemble_dim]), n_col)
+
   @_serialized
   def _histogram(self, forecast, truth, name, avg_dim=None):
     fvar, tvar = forecast[name], truth[name]
@@ -2130,8 +2168,13 @@ class RankHistogram(EnsembleMetric):
     n_bins = self._num_bins_actual(n_member)
     n_point = ften.shape[-2] * ften.shape[-1]
     seed = self._seed
+    numpy_stream = None
     if seed is None:
       seed = int.from_bytes(os.urandom(8), 'little')
+    elif self._break_ties_randomly:
+      # a seeded run reproduces the reference's own draws (NumPy's PCG64)
+      numpy_stream = self._numpy_stream(fvar, tvar, geo, n_member, device)
+      seed = 0
     dims, shape = geo.out_dims, geo.out_shape
     acc_row, n_acc = None, 0
     if avg_dim is not None:
@@ -2148,12 +2191,21 @@ class RankHistogram(EnsembleMetric):
     hist = engine.rank_histogram(
         ften, member_slabs * n_point, n_member, ens_table,
         tten.reshape(-1, n_point), truth_table, geo.n_outer, n_point, n_bins,
-        self._break_ties_randomly, seed, acc_row, n_acc)
+        self._break_ties_randomly, seed, acc_row, n_acc,
+        numpy_stream=numpy_stream)
     if avg_dim is not None:
       hist /= shape[axis]
     spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
     hist = hist.reshape(tuple(out_shape) + tuple(ften.shape[-2:]) + (n_bins,))
-    return hist, tuple(dims) + tuple(spatial) + ('bins',), n_bins
+    have = tuple(dims) + tuple(spatial) + ('bins',)
+    # the reference's result has the dims of its concatenated array (minus the
+    # ensemble dim, `bins` last): a permuted VIEW where that order differs
+    want = tuple(d for d in self._concat_dims(fvar, tvar)
+                 if d not in (self.ensemble_dim, avg_dim)) + ('bins',)
+    if want != have and sorted(want) == sorted(have):
+      hist = hist.permute(*[have.index(d) for d in want])
+      have = want
+    return hist, have, n_bins
 
   def _dataset(self, forecast, truth, avg_dim=None):
     forecast, truth = _inputs(forecast, truth)
