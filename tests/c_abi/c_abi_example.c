@@ -3,7 +3,9 @@
  * for device memory and the entry points declared in include/wb2hip.h.
  * It evaluates latitude-weighted MSE / RMSE / MAE / Bias / ACC of a tiny
  * (2 slabs of 7 lat x 12 lon) float32 case for two regions (global and
- * |lat| >= 20) and compares with a straightforward double-precision loop.
+ * |lat| >= 20) and compares with a straightforward double-precision loop; then
+ * the latitude weights, the running temporal mean and its RCCL all-reduce (a
+ * one-rank communicator built here) -- the whole path without Python.
  *
  *   hipcc -x c -I include tests/c_abi/c_abi_example.c -L weatherbench2_amd -lwb2hip -o c_abi_example
  *   (run with LD_LIBRARY_PATH=weatherbench2_amd on a box with a GPU)
@@ -120,6 +122,50 @@ int main(void) {
     }
   }
   if (bad) return 1;
-  printf("c_abi_example ok: %d metrics x %d regions x %d slabs match\n", WB2_NMETRIC, N_REGION, N_OUTER);
+
+  /* the latitude weights through the C ABI (metrics.py:35-60) */
+  double lat_deg[N_LAT], w_abi[N_LAT];
+  for (int i = 0; i < N_LAT; ++i) lat_deg[i] = -90.0 + 30.0 * i;
+  CHECK_WB2(wb2_lat_weights(WB2_F64, lat_deg, N_LAT, w_abi));
+  for (int i = 0; i < N_LAT; ++i)
+    if (fabs(w_abi[i] - w[i]) > 1e-14 * (1.0 + fabs(w[i]))) {
+      fprintf(stderr, "wb2_lat_weights[%d]: %.17g vs %.17g\n", i, w_abi[i], w[i]);
+      return 1;
+    }
+
+  /* the temporal mean and the path's one exchange step, without torch:
+   * (sum, count) accumulated on the device (xbeam.Mean, evaluation.py:735-744),
+   * all-reduced over an RCCL communicator this program builds itself (one rank
+   * here; rank 0 of a real job would hand the 128-byte id to the others) */
+  const long long n_acc = (long long)WB2_NMETRIC * N_REGION;
+  double *d_sum = NULL, *d_cnt = NULL;
+  CHECK_HIP(hipMalloc((void**)&d_sum, sizeof(double) * n_acc));
+  CHECK_HIP(hipMalloc((void**)&d_cnt, sizeof(double) * n_acc));
+  CHECK_HIP(hipMemset(d_sum, 0, sizeof(double) * n_acc));
+  CHECK_HIP(hipMemset(d_cnt, 0, sizeof(double) * n_acc));
+  /* metrics[metric][region][outer]: mean over the N_OUTER slabs ("times") */
+  CHECK_WB2(wb2_time_accumulate(d_metrics, n_acc, N_OUTER, 1, 0, d_sum, d_cnt, NULL));
+  unsigned char id[128];
+  void* comm = NULL;
+  CHECK_WB2(wb2_comm_unique_id(id));
+  CHECK_WB2(wb2_comm_init_rank(id, 1, 0, &comm));
+  CHECK_WB2(wb2_time_mean_allreduce(d_sum, d_cnt, n_acc, comm, NULL));
+  CHECK_HIP(hipDeviceSynchronize());
+  double h_sum[WB2_NMETRIC * N_REGION], h_cnt[WB2_NMETRIC * N_REGION];
+  CHECK_HIP(hipMemcpy(h_sum, d_sum, sizeof h_sum, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost));
+  CHECK_WB2(wb2_comm_destroy(comm));
+  for (int q = 0; q < WB2_NMETRIC * N_REGION; ++q) {
+    double want_mean = 0.0;
+    for (int o = 0; o < N_OUTER; ++o) want_mean += m[q * N_OUTER + o];
+    want_mean /= N_OUTER;
+    if (h_cnt[q] != (double)N_OUTER ||
+        fabs(h_sum[q] / h_cnt[q] - want_mean) > 1e-13 * (1.0 + fabs(want_mean))) {
+      fprintf(stderr, "time mean %d: %.17g / %.17g vs %.17g\n", q, h_sum[q], h_cnt[q], want_mean);
+      return 1;
+    }
+  }
+  printf("c_abi_example ok: %d metrics x %d regions x %d slabs match; lat weights and the RCCL "
+         "time mean through the C ABI too\n", WB2_NMETRIC, N_REGION, N_OUTER);
   return 0;
 }

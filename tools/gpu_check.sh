@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/chk
-timeout 1200 python -m pytest tests/test_rank_histogram_gpu.py tests/test_fuzz_gpu.py tests/test_tier2_gpu.py -m gpu -q 2>&1 | tail -30 | tee gpurun_out/chk/pytest.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 | tee gpurun_out/chk/pytest.txt
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
