@@ -155,6 +155,40 @@ def test_fused_kernel_time_mean(n_lon, skipna):
   assert torch.isnan(fused[0, 2]).all() != skipna
 
 
+@pytest.mark.parametrize('skipna', [True, False])
+@pytest.mark.parametrize('n_lon,n_lev', [(1440, 13), (1440, 5), (256, 13)])
+def test_fused_time_mean_tail_is_bit_identical(n_lon, n_lev, skipna):
+  """More output rows than resident waves: the last partial round of the time
+  mean is taken apart into single transforms and averaged by a second kernel
+  (spectrum_fused.hip launch_time_mean).  Whether or not the split applies on
+  this device, every output row must be BIT-identical to the time-ordered fp64
+  sum of the materialised spectra divided by the count."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda')
+  gen = torch.Generator(device=dev).manual_seed(n_lon + n_lev)
+  n_time, n_lat = 3, 721
+  x = torch.randn((n_time, n_lev, n_lat, n_lon), generator=gen, device=dev)
+  x[1, 0, 2, 5] = float('nan')
+  x[2, n_lev - 1, 700:, :] = float('nan')    # rows that land in the tail
+  x[:, n_lev - 1, 720, 3] = float('nan')     # NaN at every time
+  lat = np.linspace(-90, 90, n_lat)
+  circ = torch.as_tensor(spectrum_np.circumference(lat)).to(dev)
+  per_time = engine.zonal_spectrum(x, circ, n_lat)
+  fused = engine.zonal_spectrum(x, circ, n_lat, n_time=n_time, skipna=skipna)
+  total = torch.zeros_like(per_time[0])
+  count = torch.zeros_like(per_time[0])
+  for t in range(n_time):
+    keep = ~torch.isnan(per_time[t]) if skipna else torch.ones_like(
+        per_time[t], dtype=torch.bool)
+    total = total + torch.where(keep, per_time[t], torch.zeros_like(total))
+    count = count + keep
+  want = total / count
+  assert torch.equal(torch.isnan(fused), torch.isnan(want))
+  assert torch.equal(torch.nan_to_num(fused), torch.nan_to_num(want))
+  assert torch.isnan(fused[n_lev - 1, 720]).all()
+
+
 def test_full_size_unit_parseval_and_determinism():
   """BASELINE config 4: 13 x 721 x 1440 float32."""
   import torch
