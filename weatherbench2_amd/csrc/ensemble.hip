@@ -148,6 +148,12 @@ __device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
 #undef WB2_CE
 }
 
+#ifndef WB2_ENS_DIV_CONST
+#define WB2_ENS_DIV_CONST 1  // compile-time member count: x / M as mul + 2 FMA (exact)
+#endif
+#ifndef WB2_ENS_PAIRED_SPREAD
+#define WB2_ENS_PAIRED_SPREAD 1  // 50 float32 members: rank-weighted sum over (hi, lo) pairs
+#endif
 #ifndef WB2_ENS_SORT3
 #define WB2_ENS_SORT3 1  // 50 float32 members: the 2-/3-sorter program (677 instead of 806 VALU)
 #endif
@@ -192,6 +198,29 @@ __device__ __forceinline__ float sqrt_of(float x) { return __builtin_sqrtf(x); }
 template <>
 __device__ __forceinline__ double sqrt_of(double x) { return __builtin_sqrt(x); }
 
+// x / C for a compile-time integer C in float32: Markstein's sequence, one
+// multiply and two FMAs instead of the ten instructions of the IEEE division,
+// with the IDENTICAL (correctly rounded) result: tools/check_div_const.py checks
+// all 2^23 mantissas in integer arithmetic (C = 49, 50 and others).  The proof
+// needs e = x - C q0 exact, i.e. not underflowed; whenever e is not a normal
+// number or zero (tiny x, inf, NaN) the IEEE division runs instead -- behind a
+// real branch (the empty asm keeps hipcc from speculating it).
+template <int C, typename T>
+__device__ __forceinline__ T div_const(T x) {
+  if constexpr (WB2_ENS_DIV_CONST && sizeof(T) == 4) {
+    constexpr float r = 1.0f / (float)C;
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-(float)C, q0, x);
+    // classes: -normal (8), -0 (32), +0 (64), +normal (256)
+    if (__builtin_expect(__builtin_amdgcn_classf(e, 8 | 32 | 64 | 256), 1))
+      return __builtin_fmaf(e, r, q0);
+    asm volatile("" ::: "memory");
+    return x / (float)C;
+  } else {
+    return x / (T)C;
+  }
+}
+
 // One grid point -> the K slot values (see header comment).  MS > 0: the member
 // count is the compile-time constant MS (exact network, no selects); MS == 0:
 // runtime M <= NPAD, slots >= M are neutralised with selects (straight-line code
@@ -220,6 +249,12 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
       sk += abs_of(t - x[m + 1]);
       bad = bad || __builtin_isunordered(x[m], x[m + 1]);
     }
+    // the flag is first needed after the sort: without this pin hipcc sinks the
+    // compares down there and keeps the unsorted ensemble alive next to the
+    // sorted one (131 instead of 87 VGPRs)
+    int pinned = bad ? 1 : 0;
+    asm volatile("" : "+v"(pinned));
+    bad = pinned != 0;
   } else {
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -236,7 +271,8 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   // leading (member) axis: sequential, in the input dtype (nan* variants reduce
   // over the valid members only).
   {
-    mean = sum / (T)cnt;
+    if constexpr (MS > 0 && !SKIPNA) mean = div_const<MS>(sum);
+    else mean = sum / (T)cnt;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
@@ -244,13 +280,18 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
       sq += use ? d * d : (T)0;
     }
   }
-  T var = sq / (T)(cnt - 1);
+  T var;
+  if constexpr (MS > 1 && !SKIPNA) var = div_const<MS - 1>(sq);
+  else var = sq / (T)(cnt - 1);
   if (SKIPNA && cnt <= 1) var = nan;
   const T sd = sqrt_of(var);
   const T err = t - mean;
   const T mse = err * err;
-  const T deb = mse - var / (T)M;
-  T skill = sk / (T)cnt;
+  T deb, skill;
+  if constexpr (MS > 0) deb = mse - div_const<MS>(var);
+  else deb = mse - var / (T)M;
+  if constexpr (MS > 0 && !SKIPNA) skill = div_const<MS>(sk);
+  else skill = sk / (T)cnt;
   if (SKIPNA && is_nan(t)) skill = nan;
   // metrics.py:804-813: 2 * mean_m((2 r_m - M - 1) x_m) / (M - 1) in fp64; ranks
   // come from the FULL ensemble with NaN last (np.argsort), so sort with
@@ -267,12 +308,37 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
     }
     double s = 0.0;
     if constexpr (WB2_ENS_SORT3 && MS == 50 && NPAD == 64 && sizeof(T) == 4) {
-      sort3_network_50(x);
+      sort3_network_50(x);  // rank m lives in register kSort3Order50[m]
+      if constexpr (WB2_ENS_PAIRED_SPREAD && !SKIPNA) {
+        // Ranks H + j and H + 1 - j (H = M / 2) carry the weights +-(2 j - 1):
+        //   sum_r (2 r - M - 1) x_(r) = sum_j (2 j - 1) (x_(H+j) - x_(H+1-j)),
+        // a sum of NON-NEGATIVE terms.  The differences are taken in float32
+        // (exact whenever the two members are within a factor of two, Sterbenz)
+        // and accumulated innermost pair first -- ascending magnitudes -- in two
+        // float32 FMA chains that meet in fp64: 53 instructions instead of the
+        // 100 of the fp64 form below, at most 1.1e-7 (rms 2.5e-8) away from it
+        // on ERA5-like, normal and log-normal ensembles -- the accuracy of one
+        // float32 rounding; the reference evaluates this sum in fp64
+        // (int64 x float32, metrics.py:806-812) and the parity tolerance for
+        // float32 ensembles is 1e-6.  inf / NaN members behave as there:
+        // inf - finite = inf, and inf - inf = NaN exactly when an infinity
+        // receives a non-positive weight.
+        constexpr int H = MS / 2;
+        float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-      for (int m = 0; m < NM; ++m) {  // rank m lives in register kSort3Order50[m]
-        const bool use = SKIPNA ? m < n : true;
-        s = __builtin_fma((double)(2 * (m + 1) - M - 1),
-                          use ? (double)x[kSort3Order50[m]] : 0.0, s);
+        for (int j = 1; j <= H; ++j) {
+          const float g = x[kSort3Order50[H + j - 1]] - x[kSort3Order50[H - j]];
+          if (j & 1) s1 = __builtin_fmaf((float)(2 * j - 1), g, s1);
+          else s0 = __builtin_fmaf((float)(2 * j - 1), g, s0);
+        }
+        s = (double)s0 + (double)s1;
+      } else {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const bool use = SKIPNA ? m < n : true;
+          s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                            use ? (double)x[kSort3Order50[m]] : 0.0, s);
+        }
       }
     } else {
       sort_network<NPAD, NM>(x);

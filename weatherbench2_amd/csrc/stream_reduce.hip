@@ -499,12 +499,19 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
   double* rsum = lds + p.n_band * cell;      // [n_region][K]
   const long long o = blockIdx.x;
   const int tid = threadIdx.x;
+  // the region coefficients are read in dependent loops below: from LDS (a
+  // global load per iteration cost ~10 us per slab, one workgroup per slab)
+  double* cseg = rsum + p.n_region * K * (1 + p.n_band);  // [n_region][n_seg]
+  double* cband = cseg + p.n_region * p.n_seg;            // [n_region][n_band]
+  for (int i = tid; i < p.n_region * p.n_seg; i += blockDim.x)
+    cseg[i] = p.coef_seg[i];
+  for (int i = tid; i < p.n_region * p.n_band; i += blockDim.x)
+    cband[i] = p.coef_band[i];
   const long long chunk_stride = (long long)p.nwf * p.n_ts * K;
   const double* part = p.partials + o * p.n_chunk * chunk_stride;
 
   // One thread per (band, weight field, seg, slot).  Its (chunk, entry) terms
-  // are independent loads: walk the flattened term index eight at a time so eight
-  // loads are in flight per wait (the sum order stays fixed: deterministic).
+  // are independent loads; the sum order is fixed (deterministic).
   for (int idx = tid; idx < p.n_band * cell; idx += blockDim.x) {
     const int b = idx / cell, j = idx - b * cell;
     const int w = j / (p.n_seg * K), sk = j - w * (p.n_seg * K);
@@ -512,28 +519,46 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
     const int e0 = p.seg_eoff[s], ne = p.seg_eoff[s + 1] - e0;
     const int c0 = p.band_chunk0[b], n = (p.band_chunk0[b + 1] - c0) * ne;
     const double* base = part + ((long long)w * p.n_ts) * K + k;
-    auto term = [&](int i) {
-      const int c = c0 + i / ne, e = e0 + i % ne;
-      return base[c * chunk_stride + (long long)e * K];
+    // The terms (chunk c, entry e) are walked with two counters -- no division
+    // per term: with i / ne and i % ne the kernel spent 27 us per ensemble slab
+    // on integer division alone, one workgroup per slab -- and loaded up to 32
+    // at a time before the adds, which stay in (chunk, entry) order.
+    const double* q = base + c0 * chunk_stride + (long long)e0 * K;
+    const long long wrap = chunk_stride - (long long)ne * K;
+    int e = 0;
+    auto next = [&]() {  // pointer increments only: this loop is instruction-bound
+      const double* r = q;
+      q += K;
+      if (++e == ne) {
+        e = 0;
+        q += wrap;
+      }
+      return r;
     };
     double v = 0.0;
     int i = 0;
-    for (; i + 8 <= n; i += 8) {  // eight loads in flight, adds in index order
-      double t[8];
+    for (; i + 32 <= n; i += 32) {
+      double t[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = term(i + u);
+      for (int u = 0; u < 32; ++u) t[u] = *next();
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += t[u];
+      for (int u = 0; u < 32; ++u) v += t[u];
+    }
+    for (; i + 16 <= n; i += 16) {
+      double t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = *next();
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v += t[u];
     }
     for (; i + 4 <= n; i += 4) {
-      const double t0 = term(i), t1 = term(i + 1), t2 = term(i + 2),
-                   t3 = term(i + 3);
-      v += t0;
-      v += t1;
-      v += t2;
-      v += t3;
+      double t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *next();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v += t[u];
     }
-    for (; i < n; ++i) v += term(i);
+    for (; i < n; ++i) v += *next();
     bandsum[idx] = v;
   }
   __syncthreads();
@@ -547,12 +572,12 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
     const int r = idx / (p.n_band * K), bk = idx - r * (p.n_band * K);
     const int b = bk / K, k = bk - b * K;
     const int wf = p.region_wf[r];
-    const double cb = p.coef_band[r * p.n_band + b];
+    const double cb = cband[r * p.n_band + b];
     double v = 0.0;
     if (cb != 0.0) {
       const double* row = bandsum + ((b * p.nwf + wf) * p.n_seg) * K + k;
       for (int s = 0; s < p.n_seg; ++s) {
-        const double cs = p.coef_seg[r * p.n_seg + s];
+        const double cs = cseg[r * p.n_seg + s];
         if (cs != 0.0) v += (cb * cs) * row[s * K];
       }
     }
@@ -563,7 +588,7 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
     const int r = idx / K, k = idx - r * K;
     double v = 0.0;
     for (int b = 0; b < p.n_band; ++b)
-      if (p.coef_band[r * p.n_band + b] != 0.0)
+      if (cband[r * p.n_band + b] != 0.0)
         v += rb[(r * p.n_band + b) * K + k];
     rsum[idx] = v;
     if (p.sums) p.sums[(o * p.n_region + r) * K + k] = v;
@@ -905,7 +930,8 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
   p.mode = mode;
   p.skipna = skipna != 0;
   const size_t lds = ((size_t)n_band * nwf * n_seg * p.K +
-                      (size_t)n_region * p.K * (1 + (size_t)n_band)) *
+                      (size_t)n_region * p.K * (1 + (size_t)n_band) +
+                      (size_t)n_region * ((size_t)n_seg + n_band)) *
                      sizeof(double);
   WB2_REQUIRE(lds <= 64 * 1024,
               "region decomposition too fine for the combine kernel's LDS "
