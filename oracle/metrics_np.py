@@ -230,12 +230,12 @@ def select_climatology(climatology_chunk: DS, forecast: DS) -> DS:
   doy, hour = _dayofyear_hour(valid)
   doy_pos = {v: i for i, v in enumerate(
       climatology_chunk.coord('dayofyear').tolist())}
-  doy_idx = np.vectorize(doy_pos.__getitem__)(doy)
+  doy_idx = np.vectorize(doy_pos.__getitem__, otypes=[np.int64])(doy)
   has_hour = 'hour' in climatology_chunk.coords
   if has_hour:
     hour_pos = {v: i for i, v in enumerate(
         climatology_chunk.coord('hour').tolist())}
-    hour_idx = np.vectorize(hour_pos.__getitem__)(hour)
+    hour_idx = np.vectorize(hour_pos.__getitem__, otypes=[np.int64])(hour)
   level_idx = None
   if 'level' in forecast.coords and 'level' in climatology_chunk.coords:
     pos = {v: i for i, v in enumerate(climatology_chunk.coord('level').tolist())}
@@ -780,8 +780,8 @@ class SpatialSEEPS(Metric):
         self.climatology.coord('dayofyear').tolist())}
     hour_pos = {v: i for i, v in enumerate(
         self.climatology.coord('hour').tolist())}
-    di = np.vectorize(doy_pos.__getitem__)(doy)
-    hi = np.vectorize(hour_pos.__getitem__)(hour)
+    di = np.vectorize(doy_pos.__getitem__, otypes=[np.int64])(doy)
+    hi = np.vectorize(hour_pos.__getitem__, otypes=[np.int64])(hour)
     rest = tuple(d for d in wet_threshold.dims if d not in ('dayofyear',
                                                             'hour'))
     wet = NA(wet_threshold.transpose('dayofyear', 'hour', *rest).data[di, hi],

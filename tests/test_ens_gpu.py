@@ -5,6 +5,7 @@ import pytest
 from oracle import fixtures
 from oracle import metrics_np as om
 from oracle import regions_np as oreg
+from oracle.named import DS
 from tests import helpers
 
 pytestmark = pytest.mark.gpu
@@ -219,6 +220,51 @@ def test_spatial_ensemble_maps(gm, ensemble_size, skipna):
     helpers.assert_close(mean['geopotential'].values, ref, rtol=3e-6, atol=1e-6,
                          err_msg=name + '.compute')
     assert mean.attrs['ensemble_size'] == ensemble_size
+
+
+@pytest.mark.parametrize('kind', ['z500', 'normal', 'lognormal', 'tiny_spread'])
+def test_exact_50_member_pointwise_spread_within_one_float32_rounding(gm, kind):
+  """The 50-member float32 instantiation sums the rank weights over (hi, lo)
+  rank pairs in float32 (ensemble.hip ens_point) where the
+  reference multiplies int64 ranks by float32 members in fp64
+  (metrics.py:806-812).  Pointwise, on ensembles of very different character,
+  the CRPS spread must stay within 3e-7 relative of the fp64 oracle (simulated
+  bound 1.1e-7) -- and bit-identical member statistics elsewhere: variance and
+  skill are the reference's own float32 operations, divisions included."""
+  rng = np.random.default_rng(11)
+  M, T, NLAT, NLON = 50, 2, 19, 36
+  shape = (M, T, NLAT, NLON)
+  if kind == 'z500':
+    f = 55000 + 300 * rng.standard_normal(shape[1:])[None] + \
+        100 * rng.standard_normal(shape)
+  elif kind == 'normal':
+    f = rng.standard_normal(shape)
+  elif kind == 'lognormal':
+    f = np.exp(2 * rng.standard_normal(shape))
+  else:  # members within a few ulps of each other
+    base = 280 + 20 * rng.standard_normal(shape[1:])[None]
+    f = base * (1 + 3e-7 * rng.standard_normal(shape))
+  f = f.astype(np.float32)
+  t = (f.mean(0) + f.std(0) * rng.standard_normal(shape[1:])).astype(np.float32)
+  lat = np.linspace(-85, 85, NLAT)
+  lon = np.linspace(0, 350, NLON)
+  coords = {'time': np.arange(T), 'latitude': lat, 'longitude': lon}
+  forecast = DS(
+      {'z': (('realization', 'time', 'latitude', 'longitude'), f)},
+      coords={'realization': np.arange(M), **coords})
+  truth = DS({'z': (('time', 'latitude', 'longitude'), t)},
+                           coords=coords)
+  g = helpers.to_gpu_dataset
+  want = om.SpatialCRPSSpread().compute_chunk(forecast, truth)['z'].data
+  got = gm.SpatialCRPSSpread().compute_chunk(g(forecast), g(truth))['z'].values
+  assert got.dtype == np.float64
+  scale = np.abs(want).max()
+  np.testing.assert_allclose(got, want, rtol=3e-7, atol=1e-30 * scale)
+  # the float32 statistics next to it stay operation-for-operation NumPy's
+  for name in ('SpatialEnsembleVariance', 'SpatialCRPSSkill'):
+    w = getattr(om, name)().compute_chunk(forecast, truth)['z'].data
+    o = getattr(gm, name)().compute_chunk(g(forecast), g(truth))['z'].values
+    np.testing.assert_array_equal(o, w, err_msg=name)
 
 
 def test_perfect_prediction_zero_ensemble_mean_rmse(gm):

@@ -26,6 +26,16 @@ int fail(const char* fmt, ...);
     if (!(cond)) return ::wb2::fail(__VA_ARGS__);    \
   } while (0)
 
+// A call over zero units (an empty chunk: no times, no levels, ...) is a legal
+// no-op whatever the data pointers are -- empty buffers have no address --, so
+// every entry point returns here BEFORE its null-pointer checks; a negative
+// count is an error.
+#define WB2_EMPTY_OK(n)                                             \
+  do {                                                              \
+    if ((n) < 0) return ::wb2::fail(#n "=%lld is negative", (long long)(n)); \
+    if ((n) == 0) return 0;                                         \
+  } while (0)
+
 // A wavefront is 64 lanes on gfx950.
 constexpr int kWave = 64;
 

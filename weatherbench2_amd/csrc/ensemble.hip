@@ -887,6 +887,7 @@ int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(ens && truth && w_row && chunk_row0 && chunk_nrow && seg_col0 &&
                   seg_eoff && partials,
               "null pointer argument");
@@ -941,6 +942,7 @@ int wb2_ens_threshold_partials(
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(ens && truth && threshold && w_row && chunk_row0 && chunk_nrow &&
                   seg_col0 && seg_eoff && partials,
               "null pointer argument");
@@ -992,6 +994,8 @@ int wb2_ens_threshold_maps(int dtype, int skipna, const void* ens,
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_EMPTY_OK(n_point);
   WB2_REQUIRE(ens && truth && threshold && maps, "null pointer argument");
   WB2_REQUIRE(n_member >= 1, "n_member=%d", n_member);
   WB2_REQUIRE(n_outer >= 0 && n_point >= 0, "bad sizes");

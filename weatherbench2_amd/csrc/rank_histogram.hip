@@ -266,6 +266,8 @@ extern "C" int wb2_rank_histogram_seeded(
     void* stream) {
   WB2_TRACE();
   using namespace wb2;
+  WB2_EMPTY_OK(n_outer);
+  WB2_EMPTY_OK(n_point);
   WB2_REQUIRE(pcg_state_inc && ref_outer_off && ref_strides,
               "null pointer argument");
   WB2_REQUIRE(n_col >= 1 && n_point % n_col == 0, "n_point=%lld n_col=%d",
@@ -303,6 +305,8 @@ static int rank_histogram_impl(int dtype, const void* ens,
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64,
               "dtype must be WB2_F32 or WB2_F64, got %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_EMPTY_OK(n_point);
   WB2_REQUIRE(ens && truth && out, "ens, truth and out must not be null");
   WB2_REQUIRE(n_member >= 1 && n_outer >= 0 && n_point >= 0,
               "bad sizes: n_member=%d n_outer=%lld n_point=%lld", n_member,

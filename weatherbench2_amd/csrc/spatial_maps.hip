@@ -179,9 +179,9 @@ int wb2_spatial_maps(int dtype, const void* forecast, const int64_t* f_slab,
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(forecast && truth, "null pointer argument");
-  WB2_REQUIRE(n_outer >= 0 && n_point > 0, "bad sizes");
-  if (n_outer == 0) return 0;
+  WB2_REQUIRE(n_point > 0, "bad sizes");
   SpatialParams p{};
   p.f = forecast;
   p.t = truth;
@@ -212,10 +212,11 @@ int wb2_spatial_accumulate(int dtype, int skipna, const void* forecast,
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_time);
+  WB2_EMPTY_OK(n_rest);
   WB2_REQUIRE(forecast && truth && sum && (count || !skipna),
               "null pointer argument");
-  WB2_REQUIRE(n_time >= 0 && n_rest > 0 && n_point > 0, "bad sizes");
-  if (n_time == 0) return 0;
+  WB2_REQUIRE(n_point > 0, "bad sizes");
   SpatialParams p{};
   p.f = forecast;
   p.t = truth;

@@ -837,6 +837,7 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
   WB2_REQUIRE(mode != WB2_MODE_SEEPS || aux != nullptr,
               "WB2_MODE_SEEPS needs the p1 field in `aux`");
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && seg_eoff &&
                   partials,
               "null pointer argument");
@@ -900,6 +901,7 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_SEEPS, "unknown mode %d", mode);
+  WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
                   region_wf && region_wsum,
               "null pointer argument");
@@ -963,8 +965,10 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         void* stream) {
   WB2_TRACE();
   using namespace wb2;
+  WB2_EMPTY_OK(n_lead);
+  WB2_EMPTY_OK(n_time);
+  WB2_EMPTY_OK(n_tail);
   WB2_REQUIRE(values && sum && count, "null pointer argument");
-  WB2_REQUIRE(n_lead >= 0 && n_time >= 0 && n_tail >= 0, "bad sizes");
   const long long n = n_lead * n_tail;
   if (n == 0 || n_time == 0) return 0;
   hipLaunchKernelGGL(time_accumulate_kernel, dim3((unsigned)((n + 255) / 256)),
@@ -981,9 +985,10 @@ int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_EMPTY_OK(n_point);
   WB2_REQUIRE(in && in[0] && in[1] && in[2] && aux && out,
               "null pointer argument");
-  WB2_REQUIRE(n_outer >= 0 && n_point >= 0, "bad sizes");
   if (n_outer == 0 || n_point == 0) return 0;
   SeepsMapParams p{};
   for (int i = 0; i < 3; ++i) {

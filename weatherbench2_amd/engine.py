@@ -355,8 +355,6 @@ def zonal_spectrum(x: torch.Tensor, circumference: torch.Tensor, n_lat: int,
     raise ValueError('x must be a contiguous float32/float64 tensor')
   n_lon = x.shape[-1]
   n_rows = x.numel() // n_lon
-  handle, nbytes = _SPECTRUM_PLANS.get(_DTYPES[x.dtype], n_lon, n_rows)
-  work = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
   n_bins = n_lon // 2 + 1
   if n_time > 0:
     if x.shape[0] != n_time:
@@ -365,6 +363,10 @@ def zonal_spectrum(x: torch.Tensor, circumference: torch.Tensor, n_lat: int,
   else:
     out_shape = tuple(x.shape[:-1]) + (n_bins,)
   out = torch.empty(out_shape, dtype=torch.float64, device=x.device)
+  if n_rows == 0:  # an empty chunk: nothing to transform (a plan needs rows)
+    return out
+  handle, nbytes = _SPECTRUM_PLANS.get(_DTYPES[x.dtype], n_lon, n_rows)
+  work = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
   _lib.check(lib.wb2_zonal_spectrum(
       handle, _lib.ptr(x), _lib.ptr(circumference), n_lat, n_time, int(skipna),
       _lib.ptr(out), _lib.ptr(work), current_stream_ptr(x.device)),
@@ -396,6 +398,9 @@ def zonal_spectrum_lat_mean(x: torch.Tensor, circumference: torch.Tensor,
   n_rows = x.numel() // n_lon
   n_field = n_rows // n_lat
   n_bins = n_lon // 2 + 1
+  if n_rows == 0:
+    return torch.empty(tuple(x.shape[:-2]) + (n_bins,), dtype=torch.float64,
+                       device=x.device)
   handle, nbytes = _SPECTRUM_PLANS.get(_DTYPES[x.dtype], n_lon, n_rows)
   w = lat_weights.to(torch.float64)
   n_seg = lib.wb2_zonal_spectrum_latmean_segments(handle, n_lat)

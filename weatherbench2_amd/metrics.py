@@ -272,7 +272,12 @@ def _inputs(forecast, truth) -> tuple:
   aligned pair is cached by identity so that every metric of a chunk sees the
   SAME array objects (the per-chunk result caches key on them)."""
   forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
-  key = (id(forecast), id(truth))
+
+  def members(ds):  # a Dataset object whose variables / coords were replaced
+    return tuple((k, id(v.data)) for k, v in ds.data_vars.items()) + tuple(
+        (k, id(c.data) if isinstance(c, xl.DataArray) else id(c))
+        for k, c in ds.coords.items())
+  key = (id(forecast), id(truth), members(forecast), members(truth))
   hit = _ALIGNED.get(key)
   if hit is None:
     hit = xl.align_inner(forecast, truth, exclude=_SPATIAL)
