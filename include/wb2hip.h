@@ -18,6 +18,9 @@
  *  - every pointer marked DEV is a device (HBM) pointer; `stream` is a
  *    hipStream_t passed as void* (NULL = the default stream).  All work is
  *    enqueued asynchronously on `stream`.
+ *  - a call over zero units (n_outer, n_point, n_time ... == 0: an empty chunk)
+ *    is a legal no-op and returns 0 whatever the data pointers are -- empty
+ *    buffers have no address; a negative count is an error.
  *  - a "slab" is one 2-D (n_row, n_col) field, n_col contiguous.  For the
  *    (…, latitude, longitude) layout of 0.25-degree ERA5 rows are latitudes; for
  *    the (…, longitude, latitude) layout of the low-resolution/mocked datasets
