@@ -292,6 +292,48 @@ def test_full_size_properties():
   assert torch.equal(mp[0], m1[0][:, perm])
 
 
+def test_resident_climatology_beyond_2_31_elements():
+  """the climatology stays resident in HBM (79 GB for one
+  0.25-degree variable) and is gathered by slab index.  Here 2100 slabs of
+  721 x 1440 float32 = 2.18e9 elements (8.7 GB): slab offsets need 64 bits.
+  Slabs below and above the 2^31-element mark must give the same ACC as the
+  same data addressed directly."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  dev = torch.device('cuda')
+  n_lat, n_lon, n_slab = 721, 1440, 2100
+  assert n_slab * n_lat * n_lon > 2 ** 31
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, {'global': None}, dev)
+  gen = torch.Generator(device=dev).manual_seed(99)
+  clim = torch.empty((n_slab, n_lat, n_lon), device=dev, dtype=torch.float32)
+  clim.normal_(generator=gen)
+  pick = torch.tensor([0, 1, 2067, 2068, 2069, 2099, 1033], device=dev,
+                      dtype=torch.int64)  # 2068 * 721 * 1440 > 2^31
+  n = pick.numel()
+  f = torch.randn((n, n_lat, n_lon), generator=gen, device=dev)
+  t = torch.randn((n, n_lat, n_lon), generator=gen, device=dev)
+  via_table, _ = engine.stream_reduce(pl, _lib.MODE_DET_ACC, [f, t, clim],
+                                      [None, None, pick], n, False)
+  direct, _ = engine.stream_reduce(pl, _lib.MODE_DET_ACC,
+                                   [f, t, clim[pick].contiguous()],
+                                   [None, None, None], n, False)
+  torch.cuda.synchronize()
+  assert torch.equal(via_table, direct)
+  # and the forecast side through a table into a large pool
+  pool_pick = torch.tensor([2099, 2068, 5, 2070, 0, 2080, 2090], device=dev,
+                           dtype=torch.int64)
+  a, _ = engine.stream_reduce(pl, _lib.MODE_DET, [clim, t], [pool_pick, None],
+                              n, False)
+  b, _ = engine.stream_reduce(pl, _lib.MODE_DET,
+                              [clim[pool_pick].contiguous(), t], [None, None],
+                              n, False)
+  assert torch.equal(torch.isnan(a), torch.isnan(b))  # (ACC slot: no climatology)
+  assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+  assert not torch.isnan(a[_lib.METRIC_INDEX['mse']]).any()
+
+
 def test_baseline_config0_64x32_weighted_rmse(gm):
   """BASELINE configs[0]: 64x32 equiangular grid WITHOUT poles, one level, one
   init time, float64 N(0,1) truth (seed 0) / forecast (seed 1): WeightedRMSE."""

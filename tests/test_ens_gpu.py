@@ -267,6 +267,35 @@ def test_exact_50_member_pointwise_spread_within_one_float32_rounding(gm, kind):
     np.testing.assert_array_equal(o, w, err_msg=name)
 
 
+def test_member_pool_beyond_4_gib():
+  """50 members x 45 slabs of 721 x 1440 float32 = 2.34e9 elements (9.3 GB):
+  slab offsets and member strides need 64 bits (the member loads are raw
+  buffer loads with 32-bit lane offsets: the base must carry the rest)."""
+  import torch
+  from weatherbench2_amd import engine, plan as plan_lib
+  dev = torch.device('cuda')
+  m, n_slab, n_lat, n_lon = 50, 45, 721, 1440
+  stride = n_slab * n_lat * n_lon
+  assert m * stride > 2 ** 31
+  pl = plan_lib.build_plan(
+      np.linspace(-90, 90, n_lat), np.linspace(0, 360, n_lon, endpoint=False),
+      plan_lib.LATLON, {'global': None}, dev,
+      rows_per_chunk=plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+  gen = torch.Generator(device=dev).manual_seed(5)
+  ens = torch.empty((m, n_slab, n_lat, n_lon), device=dev, dtype=torch.float32)
+  ens.normal_(generator=gen)
+  truth = torch.randn((n_slab, n_lat, n_lon), generator=gen, device=dev)
+  pick = torch.tensor([44, 0, 43, 21], device=dev, dtype=torch.int64)
+  n = pick.numel()
+  a, _ = engine.ensemble_reduce(pl, ens, stride, m, pick, truth, pick, n, False)
+  sub = ens[:, pick].contiguous()
+  b, _ = engine.ensemble_reduce(pl, sub, n * n_lat * n_lon, m, None,
+                                truth[pick].contiguous(), None, n, False)
+  torch.cuda.synchronize()
+  assert not torch.isnan(a).any()
+  assert torch.equal(a, b)
+
+
 def test_perfect_prediction_zero_ensemble_mean_rmse(gm):
   # metrics_test.py:842-851
   truth, _ = fixtures.get_random_truth_and_forecast(ensemble_size=10)
