@@ -11,4 +11,4 @@ print('value %.4g  ms/step %.4f  frac %.3f' % (d['value'], d['ms_per_step'], d['
 print('api', d['api']['ms_per_step'], 'full_suite', d['full_suite']['value'], d['full_suite']['ensemble_kernel']['frac'])
 print('cpu', d['cpu_baseline']['legs'])
 PY
-bash tools/round2_profile.sh 2>&1 | tail -45
+# (profiles: tools/round2_profile.sh, run separately)
