@@ -203,3 +203,58 @@ def test_public_get_lat_weights_matches_the_reference_known_answer():
                            (np.sqrt(3) - 1) / 2, 1 - np.sqrt(3) / 2])
   np.testing.assert_allclose(w.values, expected, rtol=1e-12)
   np.testing.assert_allclose(w.values.mean(), 1.0)
+
+
+def test_chunk_prefetch_keeps_order_overlaps_and_surfaces_errors():
+  """evaluation._prefetched: chunks[i] (the lazy sequence's IO) runs ahead on
+  one background thread, items come out in order, at most `depth` + 1 fetches
+  are outstanding, a failing fetch raises at its own position."""
+  import threading
+  import time
+  from weatherbench2_amd import evaluation
+
+  class Lazy:
+    def __init__(self, n, fail_at=None):
+      self.n, self.fail_at = n, fail_at
+      self.log, self.threads = [], set()
+
+    def __len__(self):
+      return self.n
+
+    def __getitem__(self, i):
+      self.threads.add(threading.current_thread().name)
+      self.log.append(('start', i))
+      time.sleep(0.02)
+      if i == self.fail_at:
+        raise OSError(f'chunk {i} unreadable')
+      self.log.append(('done', i))
+      return ('forecast', i), ('truth', i)
+
+  lazy = Lazy(8)
+  seen, consumed_at = [], {}
+  for f, t_ in evaluation._prefetched(lazy, 1, 7, 2):
+    assert f[1] == t_[1]
+    seen.append(f[1])
+    consumed_at[f[1]] = len(lazy.log)
+    time.sleep(0.03)  # "GPU work": fetches of later chunks proceed meanwhile
+  assert seen == [1, 2, 3, 4, 5, 6]
+  assert [i for kind, i in lazy.log if kind == 'start'] == [1, 2, 3, 4, 5, 6]
+  assert all(n.startswith('wb2hip-prefetch') for n in lazy.threads)
+  # overlap: when chunk 2 was handed out, the fetch of chunk 3 had started
+  started_before = {i for kind, i in lazy.log[:consumed_at[2]] if kind == 'start'}
+  assert 3 in started_before
+  # bounded: never more than depth + 1 = 3 fetches beyond the consumed chunk
+  for i in seen:
+    ahead = {j for kind, j in lazy.log[:consumed_at[i]] if kind == 'start'}
+    assert max(ahead) <= i + 3
+  # depth 0: plain in-thread iteration
+  lazy0 = Lazy(3)
+  assert [f[1] for f, _ in evaluation._prefetched(lazy0, 0, 3, 0)] == [0, 1, 2]
+  assert lazy0.threads == {threading.current_thread().name}
+  # an IO error surfaces at its chunk, after the earlier ones were delivered
+  bad = Lazy(6, fail_at=3)
+  got = []
+  with pytest.raises(OSError, match='chunk 3'):
+    for f, _ in evaluation._prefetched(bad, 0, 6, 2):
+      got.append(f[1])
+  assert got == [0, 1, 2]

@@ -306,11 +306,37 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
   return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _prefetched(chunks, lo: int, hi: int, depth: int):
+  """Yields chunks[lo], ..., chunks[hi - 1] in order, fetching up to `depth`
+  items ahead on ONE background thread (so the fetches themselves stay in
+  order -- sequences that read a file sequentially keep doing so)."""
+  if depth <= 0 or hi - lo <= 1:
+    for i in range(lo, hi):
+      yield chunks[i]
+    return
+  import collections
+  from concurrent import futures
+  with futures.ThreadPoolExecutor(
+      max_workers=1, thread_name_prefix='wb2hip-prefetch') as pool:
+    pending: collections.deque = collections.deque()
+    nxt = lo
+    try:
+      while nxt < hi or pending:
+        while nxt < hi and len(pending) <= depth:
+          pending.append(pool.submit(chunks.__getitem__, nxt))
+          nxt += 1
+        yield pending.popleft().result()
+    finally:
+      for fut in pending:
+        fut.cancel()
+
+
 def evaluate_chunks(
     chunks: t.Sequence[tuple],
     eval_config: config.Eval,
     skipna: bool = False,
     device=None,
+    prefetch: int = 2,
 ) -> xl.Dataset:
   """Evaluates (forecast, truth) chunks and returns the temporal mean.
 
@@ -319,6 +345,13 @@ def evaluate_chunks(
   contiguous shard, like Beam's workers do for
   `input_chunks=init_time=1,lead_time=1` (docs/source/official-evaluation.md),
   and the shards meet in one all-reduce.
+
+  `chunks[i]` is where a lazy sequence does its IO (the reference reads its
+  chunks on a thread pool around the same workers, evaluation.py:696-697):
+  with `prefetch` > 0 the next `prefetch` items are fetched by a background
+  thread while the GPU works on chunk i.  Evaluation order, and therefore the
+  result, does not depend on it; an exception raised by a fetch surfaces at the
+  chunk it belongs to.
   """
   import torch.distributed as dist
   world, rank = 1, 0
@@ -329,8 +362,7 @@ def evaluate_chunks(
                      'ranks (every rank must take part in the all-reduce)')
   lo, hi = shard_bounds(len(chunks), world, rank)
   mean: t.Optional[RunningMean] = None
-  for i in range(lo, hi):
-    forecast, truth = chunks[i]
+  for forecast, truth in _prefetched(chunks, lo, hi, prefetch):
     forecast = xl.as_dataset(forecast)
     result = _metric_and_region_loop(forecast, truth, eval_config, skipna,
                                      compute_chunk=True)
