@@ -3,9 +3,9 @@ set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-for w in deterministic ensemble spectrum_mean; do
+for w in ensemble spectrum spectrum_mean; do
   extra=""; [ $w != deterministic ] && extra="--workload $w"
-  (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq_$w -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline $extra > /dev/null 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq_$w -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --ramp-ms 0 $extra > /dev/null 2>&1)
   f=$(find gpurun_out/sq_$w -name '*counter_collection.csv' | head -1)
   python - "$f" $w <<'PY'
 import csv, sys, collections
