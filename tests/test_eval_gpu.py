@@ -389,3 +389,51 @@ def test_chunk_feeder_and_staged_upload_move_the_exact_bytes():
     np.testing.assert_array_equal(got.cpu().numpy(), chunks[i])
   for s, c in zip(sums, chunks):
     np.testing.assert_allclose(float(s), c.astype(np.float64).sum(), rtol=1e-12)
+
+
+def test_resident_climatology_and_truth_give_identical_results():
+  """evaluation.make_resident: climatology and truth uploaded
+  once, gathered on the device; the results are bit-identical to the same
+  evaluation from host arrays, the resident variables are device tensors and
+  the coordinates stay host labels."""
+  import torch
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  truth, forecast = fixtures.get_random_truth_and_forecast(
+      variables=('geopotential', 'temperature'), lead_stop='1 day')
+  kw = dict(variables_3d=list(truth.keys()), variables_2d=[],
+            spatial_resolution_in_degrees=180 / (
+                len(truth.coord('latitude')) - 1),
+            levels=tuple(truth.coord('level')))
+  clim = fixtures.random_like(
+      fixtures.mock_hourly_climatology_data(hour_interval=3, **kw), seed=7)
+  cast = lambda ds: ds.copy(data={k: v.data.astype(np.float32)
+                                  for k, v in ds.items()})
+  truth, forecast, clim = cast(truth), cast(forecast), cast(clim)
+  g = helpers.to_gpu_dataset
+  host_clim, host_truth = g(clim), g(truth)
+  res_clim = evaluation.make_resident(host_clim)
+  res_truth = evaluation.make_resident(host_truth, 'cuda')
+  for ds, host in ((res_clim, host_clim), (res_truth, host_truth)):
+    assert sorted(ds.keys()) == sorted(host.keys())
+    for k in ds.keys():
+      assert isinstance(ds[k].data, torch.Tensor) and ds[k].data.is_cuda
+      assert ds[k].dims == host[k].dims
+      np.testing.assert_array_equal(ds[k].values, host[k].values)
+    from weatherbench2_amd import xarray_lite as xl
+    assert all(not isinstance(c.data if isinstance(c, xl.DataArray) else c,
+                              torch.Tensor) for c in ds.coords.values())
+  regions = {'global': None,
+             'tropics': helpers.to_gpu_region(
+                 oreg.SliceRegion(lat_slice=slice(-20, 20)))}
+
+  def run(c, t_):
+    cfg = config.Eval(metrics={'acc': gm.ACC(climatology=c), 'mse': gm.MSE()},
+                      regions=regions)
+    return evaluation._metric_and_region_loop(g(forecast), t_, cfg, False,
+                                              compute_chunk=True)
+  want = run(host_clim, host_truth)
+  got = run(res_clim, res_truth)
+  for k in want.keys():
+    assert got[k].dims == want[k].dims
+    np.testing.assert_array_equal(np.asarray(got[k].values),
+                                  np.asarray(want[k].values))
