@@ -1,0 +1,131 @@
+"""Writes tests/golden/reference_vectors_v1.npz: outputs of the REFERENCE's own
+code (/root/reference/weatherbench2/{metrics,regions,derived_variables}.py,
+imported unmodified) on the seeded cases of reference_cases.py.
+
+xarray is absent in this container, so the reference runs on the mini-xarray
+of oracle/refshim/ (a NumPy restatement of the xarray semantics the reference
+touches, checked by running the reference's own 82 unit tests on it:
+oracle/refshim/run_reference_tests.py -> reference_selftest.txt).  Everything
+else -- every metric formula, region rule, climatology selection, rank and
+spectrum computation -- is the reference's real code.  The vectors pin the NumPy
+oracle (CPU) and the HIP path (GPU): tests/test_reference_vectors.py.
+
+Only runs where /root/reference exists (this container):
+    python tests/golden/make_reference_vectors.py
+"""
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SHIM = os.path.join(ROOT, 'oracle', 'refshim')
+REFERENCE = os.environ.get('WB2_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, SHIM)  # `import xarray` -> the mini-xarray
+
+import xarray as xr  # noqa: E402  (the stand-in)
+from weatherbench2 import config as ref_config  # noqa: E402
+from weatherbench2 import derived_variables as ref_dv  # noqa: E402
+from weatherbench2 import evaluation as ref_evaluation  # noqa: E402  (beam stubs)
+from weatherbench2 import metrics as ref_metrics  # noqa: E402
+from weatherbench2 import regions as ref_regions  # noqa: E402
+from weatherbench2 import thresholds as ref_thresholds  # noqa: E402
+
+from tests.golden import reference_cases as rc  # noqa: E402
+
+assert 'wb2shim' in xr.__version__
+assert ref_metrics.__file__.startswith(REFERENCE)
+
+
+def to_dataset(case, key):
+  arrays = case[key]
+  used = set()
+  for a in arrays.values():
+    used |= set(a['dims'])
+  coords = {k: v for k, v in case['coords'].items() if k in used}
+  for k, a in case.get('extra_coords', {}).items():  # e.g. valid_time(time)
+    if set(a['dims']) <= used:
+      coords[k] = (a['dims'], a['data'])
+  return xr.Dataset({k: (a['dims'], a['data']) for k, a in arrays.items()},
+                    coords)
+
+
+def context(case):
+  ctx = {'th': ref_thresholds}
+  for key in ('climatology', 'clim_q', 'clim_g'):
+    if key in case:
+      ctx[key] = to_dataset(case, key)
+  if 'lsm' in case:
+    ctx['lsm'] = xr.DataArray(
+        case['lsm']['data'], dims=case['lsm']['dims'],
+        coords={'latitude': case['coords']['latitude'],
+                'longitude': case['coords']['longitude']})
+  return ctx
+
+
+def store(out, key, ds):
+  for name in ds.data_vars:
+    da = ds[name]
+    out[f'{key}/{name}'] = np.asarray(da.data)
+    out[f'{key}/{name}/dims'] = np.array(list(da.dims), dtype='U32')
+
+
+def main():
+  out = {}
+  regions = rc.region_factories()
+  table = dict(rc.case_table(), **rc.tier2_table())
+  for cname, (build, metrics, rlabels, skipna, mode) in table.items():
+    case = build()
+    ctx = context(case)
+    forecast, truth = to_dataset(case, 'forecast'), to_dataset(case, 'truth')
+    for mlabel, mfac in metrics.items():
+      metric = mfac(ref_metrics, ctx)
+      for rlabel in rlabels:
+        region = regions[rlabel](ref_regions, ctx)
+        fn = metric.compute if mode == 'compute' else metric.compute_chunk
+        res = fn(forecast, truth, region=region, skipna=skipna)
+        store(out, f'{cname}/{mlabel}/{rlabel}', res)
+  for cname, build in rc.SPECTRUM_CASES.items():
+    case = build()
+    ds = to_dataset(case, 'dataset')
+    spec = ref_dv.ZonalEnergySpectrum('geopotential').compute(ds)
+    out[f'{cname}/spectrum'] = np.asarray(spec.data)
+    out[f'{cname}/spectrum/dims'] = np.array(list(spec.dims), dtype='U32')
+    for c in ('frequency', 'wavelength', 'zonal_wavenumber'):
+      out[f'{cname}/{c}'] = np.asarray(spec.coords[c].data)
+      out[f'{cname}/{c}/dims'] = np.array(list(spec.coords[c].dims),
+                                          dtype='U32')
+  # the reference's own metric x region loop (evaluation.py:388-438)
+  case = rc.loop_case(np.float32)
+  ctx = context(case)
+  regions = rc.region_factories()
+  for temporal_mean in (True, False):
+    cfg = ref_config.Eval(
+        metrics={k: f(ref_metrics, ctx) for k, f in rc.LOOP_METRICS.items()},
+        regions={r: regions[r](ref_regions, ctx) for r in rc.LOOP_REGIONS},
+        temporal_mean=temporal_mean)
+    res = ref_evaluation._metric_and_region_loop(
+        to_dataset(case, 'forecast'), to_dataset(case, 'truth'), cfg,
+        skipna=False)
+    key = f'loop_f32/temporal_mean_{int(temporal_mean)}'
+    store(out, key, res)
+    out[f'{key}/coord/metric'] = np.array(list(res.coords['metric'].data),
+                                          dtype='U32')
+    out[f'{key}/coord/metric/dims'] = np.array(['metric'], dtype='U32')
+    out[f'{key}/coord/region'] = np.array(list(res.coords['region'].data),
+                                          dtype='U32')
+    out[f'{key}/coord/region/dims'] = np.array(['region'], dtype='U32')
+  path = os.environ.get('WB2_VECTORS_OUT') or os.path.join(
+      HERE, 'reference_vectors_v1.npz')
+  np.savez_compressed(path, **out)
+  n_val = sum(v.size for k, v in out.items() if not k.endswith('/dims'))
+  print(f'wrote {path}: {len(out) // 2} arrays, {n_val} values, '
+        f'{os.path.getsize(path) / 1e3:.0f} kB')
+
+
+if __name__ == '__main__':
+  main()

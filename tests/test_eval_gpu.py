@@ -37,9 +37,12 @@ def test_metric_and_region_loop_matches_reference_layout():
                       temporal_mean=temporal_mean)
     got = evaluation._metric_and_region_loop(g(forecast), g(truth), cfg,
                                              skipna=False)
-    assert list(got.coords['metric']) == list(ometrics)
+    # xr.merge joins `metric` with an outer join (a sorted union); regions are
+    # concatenated in the order given
+    assert list(got.coords['metric']) == sorted(ometrics)
     assert list(got.coords['region']) == list(oregions)
-    for mi, (mname, metric) in enumerate(ometrics.items()):
+    for mname, metric in ometrics.items():
+      mi = list(got.coords['metric']).index(mname)
       for ri, (rname, region) in enumerate(oregions.items()):
         fn = metric.compute if temporal_mean else metric.compute_chunk
         want = fn(forecast, truth, region=region)
@@ -71,7 +74,10 @@ def test_evaluate_chunks_equals_full_time_mean():
     cfg = config.Eval(metrics={'rmse': gm.RMSESqrtBeforeTimeAvg(),
                                'bias': gm.Bias()}, regions=gregions)
     got = evaluation.evaluate_chunks(chunks, cfg, skipna=skipna, device='cuda')
-    for mi, metric in enumerate((om.RMSESqrtBeforeTimeAvg(), om.Bias())):
+    labels = list(got.coords['metric'])  # merged labels come out sorted
+    for name, metric in (('rmse', om.RMSESqrtBeforeTimeAvg()),
+                         ('bias', om.Bias())):
+      mi = labels.index(name)
       for ri, region in enumerate(regions.values()):
         want = metric.compute(forecast, truth, region=region, skipna=skipna)
         helpers.assert_close(got['geopotential'].values[mi, ri],
@@ -185,7 +191,9 @@ def test_loop_with_ensemble_metrics_and_foreign_metric_objects():
                                              skipna=False)
     assert len(calls) == len(gregions)
     assert got['geopotential'].dims[:2] == ('metric', 'region')
-    for mi, metric in enumerate(ometrics.values()):
+    assert list(got.coords['metric']) == sorted(ometrics)
+    for mname, metric in ometrics.items():
+      mi = list(got.coords['metric']).index(mname)
       for ri, region in enumerate(oregions.values()):
         fn = metric.compute if temporal_mean else metric.compute_chunk
         want = fn(forecast, truth, region=region)['geopotential']
@@ -228,7 +236,8 @@ def test_loop_with_several_land_sea_masks():
     got = evaluation._metric_and_region_loop(g(forecast), g(truth), cfg,
                                              skipna=skipna, compute_chunk=True)
     assert list(got.coords['region']) == list(oregions)
-    for mi, metric in enumerate(ometrics.values()):
+    for mname, metric in ometrics.items():
+      mi = list(got.coords['metric']).index(mname)
       for ri, (rname, region) in enumerate(oregions.items()):
         want = metric.compute_chunk(forecast, truth, region=region,
                                     skipna=skipna)
@@ -315,7 +324,8 @@ def test_by_init_evaluation_with_device_truth_gather(inits, zero_copy):
   o_fc = DS({'z': NA(f_np, ('init_time', 'prediction_timedelta', 'level',
                             'latitude', 'longitude'))},
             {**base, 'init_time': init, 'prediction_timedelta': lead})
-  for mi, metric in enumerate((om.MSE(), om.Bias())):
+  for name, metric in (('mse', om.MSE()), ('bias', om.Bias())):
+    mi = list(got.coords['metric']).index(name)  # merged labels are sorted
     want = metric.compute(o_fc, o_truth)['z']
     dims = got['z'].dims[1:]
     helpers.assert_close(got['z'].values[mi], want.transpose(*dims).data,

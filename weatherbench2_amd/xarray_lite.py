@@ -304,10 +304,19 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
   Variables missing from one operand are NaN-filled, like xarray's outer join.
   """
   labels: list = []
-  for d in datasets:
-    for m in np.atleast_1d(d.coords['metric']):
+  per_dataset = [list(np.atleast_1d(d.coords['metric'])) for d in datasets]
+  for ms in per_dataset:
+    for m in ms:
       if m not in labels:
         labels.append(m)
+  if any(ms != per_dataset[0] for ms in per_dataset):
+    # xarray's outer join is pandas' Index.union, which SORTS its result unless
+    # the indexes are equal: the merged `metric` coordinate of the reference
+    # comes out alphabetical, not in the order of Eval.metrics
+    try:
+      labels = sorted(labels)
+    except TypeError:  # labels that cannot be compared stay in order (pandas)
+      pass
   names: list = []
   for d in datasets:
     names += [k for k in d.data_vars if k not in names]
