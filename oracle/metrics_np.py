@@ -198,6 +198,7 @@ class SpatialBias(Metric):
 
 def _dayofyear_hour(times: np.ndarray):
   import pandas as pd
+  times = times.data if isinstance(times, NA) else times  # 2-D valid_time
   idx = pd.DatetimeIndex(np.asarray(times).ravel())
   shape = np.shape(times)
   return (np.asarray(idx.dayofyear).reshape(shape),

@@ -70,18 +70,25 @@ def context(case):
 def store(out, key, ds):
   for name in ds.data_vars:
     da = ds[name]
-    out[f'{key}/{name}'] = np.asarray(da.data)
+    out[f'{key}/{name}'] = np.asarray(da.data)  # dtype kept: part of the record
     out[f'{key}/{name}/dims'] = np.array(list(da.dims), dtype='U32')
 
 
 def main():
   out = {}
   regions = rc.region_factories()
-  table = dict(rc.case_table(), **rc.tier2_table())
+  table = dict(rc.case_table(), **rc.tier2_table(), **rc.layout_table())
   for cname, (build, metrics, rlabels, skipna, mode) in table.items():
     case = build()
     ctx = context(case)
     forecast, truth = to_dataset(case, 'forecast'), to_dataset(case, 'truth')
+    if 'truth_full' in case:
+      # by-init: the truth the metrics see is what evaluation.py:474 selects
+      selected = to_dataset(case, 'truth_full').sel(time=forecast.valid_time)
+      for k in truth.data_vars:
+        assert selected[k].dims == truth[k].dims
+        np.testing.assert_array_equal(selected[k].data, truth[k].data)
+      truth = selected
     for mlabel, mfac in metrics.items():
       metric = mfac(ref_metrics, ctx)
       for rlabel in rlabels:

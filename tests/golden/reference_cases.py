@@ -494,3 +494,63 @@ LOOP_METRICS = {
     'bias': DET_METRICS['bias'],
 }
 LOOP_REGIONS = ('global', 'tropics', 'extra_tropical', 'europe')
+
+
+# --------------------------------------------------------------------------
+# by-init layout (evaluation.py:474-477): forecast (init_time, lead_time, ...)
+# with a 2-D valid_time coordinate, truth selected at the valid times
+# --------------------------------------------------------------------------
+def by_init_case(dtype, seed=81):
+  rs = np.random.RandomState(seed)
+  n_init, n_lead, levels = 3, 3, np.array([500, 850])
+  sshape = (len(LON10), len(LAT10))
+  step = np.timedelta64(12, 'h').astype('timedelta64[ns]')
+  init = _times(n_init)
+  lead = np.arange(n_lead) * step
+  valid = init[:, None] + lead[None, :]
+  times = _times(n_init + n_lead - 1)           # every valid time, once
+  truth_full = rs.standard_normal((len(times), len(levels)) + sshape)
+  idx = np.arange(n_init)[:, None] + np.arange(n_lead)[None, :]
+  forecast = truth_full[idx] + 0.5 * rs.standard_normal(
+      (n_init, n_lead, len(levels)) + sshape)
+  hours, days = np.array([0, 12]), np.arange(57, 63)
+  clim = 0.3 * rs.standard_normal((len(hours), len(days), len(levels)) + sshape)
+  dims = ('init_time', 'lead_time', 'level', 'longitude', 'latitude')
+  return {
+      'coords': {'init_time': init, 'lead_time': lead, 'time': times,
+                 'level': levels, 'latitude': LAT10, 'longitude': LON10,
+                 'hour': hours, 'dayofyear': days},
+      'extra_coords': {'valid_time': _arr(valid, 'init_time', 'lead_time')},
+      'truth_full': {'geopotential': _arr(truth_full.astype(dtype), 'time',
+                                          'level', 'longitude', 'latitude')},
+      'truth': {'geopotential': _arr(truth_full[idx].astype(dtype), *dims)},
+      'forecast': {'geopotential': _arr(forecast.astype(dtype), *dims)},
+      'climatology': {'geopotential': _arr(clim.astype(dtype), 'hour',
+                                           'dayofyear', 'level', 'longitude',
+                                           'latitude')},
+      'lsm': _arr(rs.rand(len(LAT10), len(LON10)), 'latitude', 'longitude'),
+  }
+
+
+def f32_coordinate_case(seed=82):
+  """float32 latitude / longitude coordinates, as 0.25-degree ERA5 ships them:
+  the latitude weights inherit float32 (metrics.py:41, 57) and xarray's dot of
+  float32 data with float32 weights accumulates and returns float32."""
+  case = det_case(np.float32, seed=seed)
+  case['coords'] = dict(case['coords'],
+                        latitude=LAT10.astype(np.float32),
+                        longitude=LON10.astype(np.float32))
+  return case
+
+
+def layout_table():
+  small = ['global', 'europe', 'land_thr']
+  return {
+      'by_init_f32_chunk': (lambda: by_init_case(np.float32), DET_METRICS,
+                            small, False, 'chunk'),
+      'by_init_f64_compute': (lambda: by_init_case(np.float64, seed=83),
+                              DET_METRICS, ['global', 'tropics'], False,
+                              'compute'),
+      'det_f32_coords32': (f32_coordinate_case, DET_METRICS,
+                           small + ['extra_tropical'], False, 'chunk'),
+  }
