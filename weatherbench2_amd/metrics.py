@@ -926,6 +926,10 @@ class RMSESqrtBeforeTimeAvg(_DetMetric):
   _index = _lib.METRIC_INDEX['rmse']
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    # converted once, here: the wind-vector metrics below are then called with
+    # lite Datasets and answer with lite Datasets (xarray callers get their
+    # xarray result from the wrapper around THIS method)
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     results = self._scalar(forecast, truth, region, skipna)
     if self.wind_vector_rmse is not None:
       for wv in self.wind_vector_rmse:
@@ -934,6 +938,7 @@ class RMSESqrtBeforeTimeAvg(_DetMetric):
     return results
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     results = self._scalar(forecast, truth, None, skipna, regions)
     if self.wind_vector_rmse is not None:
       for wv in self.wind_vector_rmse:
@@ -950,6 +955,10 @@ class MSE(_DetMetric):
   _index = _lib.METRIC_INDEX['mse']
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    # converted once, here: the wind-vector metrics below are then called with
+    # lite Datasets and answer with lite Datasets (xarray callers get their
+    # xarray result from the wrapper around THIS method)
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     results = self._scalar(forecast, truth, region, skipna)
     if self.wind_vector_mse is not None:
       for wv in self.wind_vector_mse:
@@ -958,6 +967,7 @@ class MSE(_DetMetric):
     return results
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     results = self._scalar(forecast, truth, None, skipna, regions)
     if self.wind_vector_mse is not None:
       for wv in self.wind_vector_mse:
@@ -1514,6 +1524,7 @@ class EnergyScore(EnsembleMetric):
   """ES = E||X - Y|| - 0.5 E||X - X'|| (metrics.py:1402-1465)."""
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
+    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
     skill = EnergyScoreSkill(self.ensemble_dim).compute_chunk(
         forecast, truth, region=region, skipna=skipna)
     spread = EnergyScoreSpread(self.ensemble_dim).compute_chunk(

@@ -168,6 +168,8 @@ class Dataset:
   def __setitem__(self, name, value):
     if isinstance(value, tuple):
       value = DataArray(value[1], value[0])
+    if is_xarray(value):  # an xarray.DataArray (a foreign metric's result)
+      value = DataArray(value.data, tuple(value.dims))
     if not isinstance(value, DataArray):
       value = DataArray(value, ())
     for k, c in value.coords.items():
