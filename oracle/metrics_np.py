@@ -756,8 +756,10 @@ class SpatialSEEPS(Metric):
 
   @property
   def p1(self) -> NA:
+    # metrics.py:443-444: `.mean(("hour", "dayofyear"))` with xarray's default
+    # skipna=None, i.e. NaN dry fractions are skipped
     return self.climatology[f'{self.precip_name}_seeps_dry_fraction'].mean(
-        ('hour', 'dayofyear'))
+        ('hour', 'dayofyear'), skipna=True)
 
   def _valid_time(self, ds: DS) -> NA:
     vt = ds.coords['valid_time']

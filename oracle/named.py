@@ -179,9 +179,13 @@ class NA:
         warnings.simplefilter('ignore')
         return NA(fn(self.data, axis=axes, ddof=ddof), keep)
 
-  def sum(self, dim=None):
+  def sum(self, dim=None, skipna=None):
+    """xarray's `sum`: with the default skipna=None missing values are SKIPPED
+    for float dtypes (an all-NaN slice sums to 0) -- what the reference's
+    `result.sum("quantile")` does (metrics.py:1158, 1868, 1891)."""
     axes, keep = self._axes(dim)
-    return NA(np.sum(self.data, axis=axes), keep)
+    skip = self.data.dtype.kind in 'cf' if skipna is None else skipna
+    return NA((np.nansum if skip else np.sum)(self.data, axis=axes), keep)
 
 
 class DS:

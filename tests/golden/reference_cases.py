@@ -391,6 +391,8 @@ def seeps_case(dtype, seed=53):
   dry_fraction = rs.rand(len(hours), len(days), *sshape)
   dry_fraction[..., :6, :] = 0.95  # p1 > max_p1: masked out
   dry_fraction[..., 6:9, :] = 0.02  # p1 < min_p1: masked out
+  dry_fraction[0, :2, 12:15, :] = np.nan  # skipped by the mean (skipna=None)
+  dry_fraction[:, :, 15, 3] = np.nan      # NaN everywhere: p1 NaN, masked out
   tail = ('hour', 'dayofyear', 'longitude', 'latitude')
   times = _times(n_time)
   return {

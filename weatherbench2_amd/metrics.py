@@ -698,6 +698,17 @@ def _stack(arrays):
   return np.stack([np.asarray(a, dtype=np.float64) for a in arrays])
 
 
+def _nansum_leading(values):
+  """xarray's `.sum(dim)` with its default skipna=None: NaNs are skipped for
+  float data, an all-NaN slice sums to 0.  This is what the reference's
+  `result.sum("quantile")` does to the per-threshold terms of the ranked
+  probability scores (metrics.py:1158, 1868, 1891): a NaN term -- an empty
+  region, a NaN input without skipna -- drops out of the sum."""
+  if isinstance(values, torch.Tensor):
+    return torch.nansum(values, 0)
+  return np.nansum(values, 0)
+
+
 def _transpose(values, axes):
   if isinstance(values, torch.Tensor):
     return values.permute(*axes)
@@ -1547,7 +1558,8 @@ def _stack_quantiles(forecast, per_threshold: list, quantiles, method: str,
   for name, (dims, _) in first.items():
     data = _stack([p[name][1] for p in per_threshold])
     if sum_over_quantile:
-      out.data_vars[name] = xl.DataArray(data.sum(0), dims, out.coords, name)
+      out.data_vars[name] = xl.DataArray(_nansum_leading(data), dims,
+                                         out.coords, name)
     else:
       out.data_vars[name] = xl.DataArray(data, ('quantile',) + tuple(dims),
                                          out.coords, name)
@@ -1833,7 +1845,9 @@ class SEEPS(Metric):
 
   def _p1(self, climatology) -> xl.DataArray:
     frac = climatology[f'{self.precip_name}_seeps_dry_fraction']
-    return frac.mean(('hour', 'dayofyear'))
+    # metrics.py:443-444 takes xarray's default skipna=None: NaN dry fractions
+    # are skipped (a point is masked only if it is NaN at every hour and day)
+    return frac.mean(('hour', 'dayofyear'), skipna=True)
 
   def _prepare(self, forecast, truth):
     """(geo, [forecast, truth, wet threshold], slab tables, masked p1)."""
@@ -2024,7 +2038,8 @@ class _SpatialEnsembleThresholdMetric(ThresholdMetric):
       data = torch.stack([d for _, d in stacks[name]])
       out.coords.update(_spatial_coords(forecast, dims))
       if self._sum_over_quantile:
-        out.data_vars[name] = xl.DataArray(data.sum(0), dims, out.coords, name)
+        out.data_vars[name] = xl.DataArray(_nansum_leading(data), dims,
+                                           out.coords, name)
       else:
         out.coords['quantile'] = np.array(
             [th.quantile for th in self.thresholds], dtype=np.float64)
