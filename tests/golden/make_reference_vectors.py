@@ -46,7 +46,8 @@ def to_dataset(case, key):
   used = set()
   for a in arrays.values():
     used |= set(a['dims'])
-  coords = {k: v for k, v in case['coords'].items() if k in used}
+  source = case.get(f'coords_{key}', case['coords'])  # per-dataset labels
+  coords = {k: v for k, v in source.items() if k in used}
   for k, a in case.get('extra_coords', {}).items():  # e.g. valid_time(time)
     if set(a['dims']) <= used:
       coords[k] = (a['dims'], a['data'])
@@ -77,7 +78,8 @@ def store(out, key, ds):
 def main():
   out = {}
   regions = rc.region_factories()
-  table = dict(rc.case_table(), **rc.tier2_table(), **rc.layout_table())
+  table = dict(rc.case_table(), **rc.tier2_table(), **rc.layout_table(),
+               **rc.ragged_table())
   for cname, (build, metrics, rlabels, skipna, mode) in table.items():
     case = build()
     ctx = context(case)

@@ -556,3 +556,33 @@ def layout_table():
       'det_f32_coords32': (f32_coordinate_case, DET_METRICS,
                            small + ['extra_tropical'], False, 'chunk'),
   }
+
+
+def ragged_case(seed=91):
+  """Forecast and truth that only partly overlap: xarray arithmetic keeps the
+  variables present in both and inner-joins the `time` index (forecast's order);
+  truth has times and a variable the forecast lacks, and vice versa."""
+  case = det_case(np.float32, seed=seed)
+  rs = np.random.RandomState(seed + 1)
+  keep = np.array([1, 3, 4, 5])
+  f = case['forecast']['geopotential']
+  t = case['truth']['geopotential']
+  case['forecast'] = {
+      'geopotential': _arr(f['data'][:, keep], *f['dims']),
+      'temperature': _arr(rs.standard_normal(f['data'][:, keep].shape).astype(
+          np.float32), *f['dims'])}
+  case['truth'] = {
+      'geopotential': t,
+      'specific_humidity': _arr(rs.standard_normal(t['data'].shape).astype(
+          np.float32), *t['dims'])}
+  c = case['climatology']['geopotential']
+  case['climatology'] = dict(case['climatology'], specific_humidity=_arr(
+      rs.standard_normal(c['data'].shape).astype(np.float32), *c['dims']))
+  case['coords_forecast'] = dict(case['coords'],
+                                 time=case['coords']['time'][keep])
+  return case
+
+
+def ragged_table():
+  return {'ragged_f32': (ragged_case, DET_METRICS, ['global', 'europe'], False,
+                         'chunk')}

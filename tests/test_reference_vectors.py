@@ -36,7 +36,8 @@ def oracle_dataset(case, key) -> DS:
   used = set()
   for a in arrays.values():
     used |= set(a['dims'])
-  coords = {k: v for k, v in case['coords'].items() if k in used}
+  source = case.get(f'coords_{key}', case['coords'])  # per-dataset labels
+  coords = {k: v for k, v in source.items() if k in used}
   for k, a in case.get('extra_coords', {}).items():  # e.g. valid_time(time)
     if set(a['dims']) <= used:
       coords[k] = NA(a['data'], a['dims'])
@@ -62,7 +63,8 @@ def oracle_context(case):
   return ctx, regions
 
 
-TABLE = dict(rc.case_table(), **rc.tier2_table(), **rc.layout_table())
+TABLE = dict(rc.case_table(), **rc.tier2_table(), **rc.layout_table(),
+             **rc.ragged_table())
 CASES = list(TABLE)
 
 # float64 sums on both sides, identical elementwise arithmetic: only the order
