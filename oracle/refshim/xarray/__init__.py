@@ -571,7 +571,7 @@ class DataArray:
         pos[dim] = label  # no index: xarray falls back to positions
         continue
       pos[dim] = _labels_to_positions(_index(self._coords[dim]), label, method,
-                                      dim)
+                                      dim, tolerance)
     return _isel(self, pos, drop)
 
   def __getitem__(self, key):
@@ -1100,12 +1100,14 @@ def align(*objects, join='inner', copy=True, exclude=frozenset()):
   raise NotImplementedError('wb2shim: align of Datasets')
 
 
-def _labels_to_positions(index: pd.Index, label, method, dim):
+def _labels_to_positions(index: pd.Index, label, method, dim,
+                         tolerance=None):
   if isinstance(label, DataArray):
     if label.ndim == 0:
-      return _labels_to_positions(index, label._data[()], method, dim)
+      return _labels_to_positions(index, label._data[()], method, dim,
+                                  tolerance)
     flat = _as_index_values(label._data).ravel()
-    pos = _get_indexer(index, flat, method, dim)
+    pos = _get_indexer(index, flat, method, dim, tolerance)
     return DataArray(pos.reshape(label.shape),
                      {k: c for k, c in label._coords.items() if k != dim},
                      label.dims, _fast=True, name=None, attrs={})
@@ -1120,7 +1122,7 @@ def _labels_to_positions(index: pd.Index, label, method, dim):
     arr = _as_index_values(label)
     if arr.dtype == bool:
       return np.nonzero(arr)[0]
-    return _get_indexer(index, arr, method, dim)
+    return _get_indexer(index, arr, method, dim, tolerance)
   # scalar
   if isinstance(label, np.ndarray):
     label = label[()]
@@ -1141,18 +1143,18 @@ def _labels_to_positions(index: pd.Index, label, method, dim):
     if isinstance(loc, np.ndarray):
       return np.nonzero(loc)[0]
     return int(loc)
-  pos = index.get_indexer([label], method=method)
+  pos = index.get_indexer([label], method=method, tolerance=tolerance)
   if pos[0] < 0:
     raise KeyError(f'{label!r} not found in index {dim!r}')
   return int(pos[0])
 
 
-def _get_indexer(index, arr, method, dim):
+def _get_indexer(index, arr, method, dim, tolerance=None):
   if index.dtype.kind == 'M':
     arr = pd.DatetimeIndex(arr)
   elif index.dtype.kind == 'm':
     arr = pd.TimedeltaIndex(arr)
-  pos = index.get_indexer(pd.Index(arr), method=method)
+  pos = index.get_indexer(pd.Index(arr), method=method, tolerance=tolerance)
   if (pos < 0).any():
     missing = np.asarray(arr)[pos < 0]
     raise KeyError(f'not all values found in index {dim!r}: {missing[:5]}')
@@ -1929,7 +1931,7 @@ class Dataset:
           continue
         raise KeyError(f'{dim!r} is not a valid dimension or coordinate')
       pos[dim] = _labels_to_positions(_index(self._coords[dim]), label, method,
-                                      dim)
+                                      dim, tolerance)
     return self.isel(pos, drop=drop)
 
   def head(self, indexers=None, **kw):
