@@ -1417,23 +1417,47 @@ class SpatialBias(_SpatialMetric):
   _map = 'bias'
 
 
-def compute_spread_skill_ratio(results: xl.Dataset) -> xl.Dataset:
-  """ensemble_stddev / ensemble_mean_rmse along the `metric` dim
-  (weatherbench2/visualization.py:136-141); expects the two metrics under those
-  names, e.g. from EnsembleStddevSqrtBeforeTimeAvg / EnsembleMeanRMSESqrtBeforeTimeAvg."""
-  labels = list(np.atleast_1d(results.coords['metric']))
+def compute_spread_skill_ratio(results):
+  """ensemble_stddev / ensemble_mean_rmse along the `metric` dim, NaN at lead
+  time 0 (weatherbench2/visualization.py:136-141: `ratio.where(ratio.lead_time
+  > np.timedelta64(0))`).  Takes the merged result of the loop -- a Dataset
+  (every variable) or, like the reference, one DataArray of it -- with the two
+  metrics under those names (EnsembleStddevSqrtBeforeTimeAvg /
+  EnsembleMeanRMSESqrtBeforeTimeAvg); xarray in, xarray out.  Results without
+  a `lead_time` coordinate (the reference requires one) are returned unmasked."""
+  given = results
+  if xl.is_xarray(results) and not hasattr(results, 'data_vars'):
+    name = results.name if results.name is not None else '__ratio__'
+    ds = xl.as_dataset(results.to_dataset(name=name))
+    ratio = compute_spread_skill_ratio(ds)[name]
+    return xl.like_input(xl.DataArray(ratio.values, ratio.dims, ratio.coords,
+                                      results.name), given)
+  if isinstance(results, xl.DataArray):
+    name = results.name if results.name is not None else '__ratio__'
+    ds = xl.Dataset({name: results}, results.coords)
+    ratio = compute_spread_skill_ratio(ds)[name]
+    return xl.DataArray(ratio.values, ratio.dims, ratio.coords, results.name)
+  results = xl.as_dataset(results)
+  labels = [str(m) for m in np.atleast_1d(results.coords['metric'])]
   i_std, i_rmse = labels.index('ensemble_stddev'), labels.index(
       'ensemble_mean_rmse')
   out = xl.Dataset(coords={k: v for k, v in results.coords.items()
                            if k != 'metric'})
+  lead = results.coords.get('lead_time')
   for name, da in results.data_vars.items():
     ax = da.dims.index('metric')
-    a = np.take(da.values, i_std, axis=ax)
-    b = np.take(da.values, i_rmse, axis=ax)
+    a = np.take(np.asarray(da.values), i_std, axis=ax)
+    b = np.take(np.asarray(da.values), i_rmse, axis=ax)
+    dims = tuple(d for d in da.dims if d != 'metric')
     with np.errstate(all='ignore'):
-      out.data_vars[name] = xl.DataArray(
-          a / b, tuple(d for d in da.dims if d != 'metric'), out.coords, name)
-  return out
+      ratio = a / b
+    if lead is not None and 'lead_time' in dims:
+      positive = np.asarray(lead) > np.timedelta64(0)
+      shape = [1] * ratio.ndim
+      shape[dims.index('lead_time')] = len(positive)
+      ratio = np.where(positive.reshape(shape), ratio, np.nan)
+    out.data_vars[name] = xl.DataArray(ratio, dims, out.coords, name)
+  return xl.like_input(out, given)
 
 
 # ---------------------------------------------------------------------------
