@@ -14,7 +14,6 @@ Only runs where /root/reference exists (this container):
     python tests/golden/make_reference_vectors.py
 """
 import io
-import json
 import os
 import sys
 
@@ -74,19 +73,6 @@ def store(out, key, ds):
     da = ds[name]
     out[f'{key}/{name}'] = np.asarray(da.data)  # dtype kept: part of the record
     out[f'{key}/{name}/dims'] = np.array(list(da.dims), dtype='U32')
-  # what else a caller of the reference sees on the result: its attributes and
-  # the labels along the result's dimensions (stored as int64 / str)
-  meta = {'attrs': {k: (v if isinstance(v, (int, float, str)) else str(v))
-                    for k, v in ds.attrs.items()},
-          'coord_names': sorted(str(k) for k in ds.coords),
-          'index': {}}
-  for d in ds.sizes:
-    if d in ds.coords and ds.coords[d].dims == (d,):
-      v = np.asarray(ds.coords[d].data)
-      meta['index'][d] = (v.astype('int64').tolist() if v.dtype.kind in 'Mmiu'
-                          else v.astype(float).tolist() if v.dtype.kind == 'f'
-                          else [str(x) for x in v])
-  out[f'{key}//meta'] = np.array(json.dumps(meta, sort_keys=True))
 
 
 def main():
@@ -145,10 +131,8 @@ def main():
   path = os.environ.get('WB2_VECTORS_OUT') or os.path.join(
       HERE, 'reference_vectors_v1.npz')
   np.savez_compressed(path, **out)
-  n_val = sum(v.size for k, v in out.items()
-              if not k.endswith('/dims') and not k.endswith('//meta'))
-  n_arr = sum(1 for k in out if not k.endswith('/dims') and not k.endswith('//meta'))
-  print(f'wrote {path}: {n_arr} arrays, {n_val} values, '
+  n_val = sum(v.size for k, v in out.items() if not k.endswith('/dims'))
+  print(f'wrote {path}: {len(out) // 2} arrays, {n_val} values, '
         f'{os.path.getsize(path) / 1e3:.0f} kB')
 
 
