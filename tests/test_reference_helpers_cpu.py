@@ -228,3 +228,69 @@ def test_spread_skill_ratio_equals_the_reference_function():
                        capture_output=True, text=True, timeout=600)
   assert res.returncode == 0 and 'RATIO-OK' in res.stdout, (
       res.stdout[-1500:] + res.stderr[-5000:])
+
+
+THRESHOLDS_SCRIPT = textwrap.dedent('''
+    import numpy as np
+    import xarray as xr
+    from weatherbench2 import thresholds as rth
+    from weatherbench2_amd import thresholds as gth, evaluation as gev
+    rs = np.random.RandomState(0)
+    lat = np.linspace(-90, 90, 7)
+    lon = np.linspace(0, 360, 12, endpoint=False)
+    time = np.datetime64('2020-02-27T00', 'ns') + np.arange(8) * np.timedelta64(
+        12, 'h')                                   # crosses Feb 29 of a leap year
+    days, hours = np.arange(55, 66), np.array([0, 12])
+    tail = ('hour', 'dayofyear', 'latitude', 'longitude')
+    for dtype in (np.float32, np.float64):
+      truth = xr.Dataset({'t2m': (('time', 'latitude', 'longitude'),
+                                  rs.standard_normal((8, 7, 12)).astype(dtype))},
+                         {'time': time, 'latitude': lat, 'longitude': lon})
+      init = time[:3]
+      lead = (np.arange(3) * np.timedelta64(24, 'h')).astype('timedelta64[ns]')
+      forecast = xr.Dataset(
+          {'t2m': (('init_time', 'lead_time', 'latitude', 'longitude'),
+                   rs.standard_normal((3, 3, 7, 12)).astype(dtype))},
+          {'init_time': init, 'lead_time': lead, 'latitude': lat,
+           'longitude': lon,
+           'valid_time': (('init_time', 'lead_time'),
+                          init[:, None] + lead[None, :])})
+      cq = xr.Dataset({'t2m_quantile': (('quantile',) + tail, rs.standard_normal(
+          (2, 2, 11, 7, 12)).astype(dtype))},
+                      {'quantile': [0.25, 0.9], 'hour': hours, 'dayofyear': days,
+                       'latitude': lat, 'longitude': lon})
+      cg = xr.Dataset(
+          {'t2m': (tail, rs.standard_normal((2, 11, 7, 12)).astype(dtype)),
+           't2m_std': (tail, (rs.rand(2, 11, 7, 12) + 0.5).astype(dtype))},
+          {'hour': hours, 'dayofyear': days, 'latitude': lat, 'longitude': lon})
+      by_init_ref = truth.sel(time=forecast.valid_time)     # evaluation.py:474
+      by_init_got = gev.select_truth_at_valid_time(
+          truth, forecast, init_dim='init_time', lead_dim='lead_time')
+      for cls, clim, q in (('QuantileThreshold', cq, 0.9),
+                           ('QuantileThreshold', cq, 0.25),
+                           ('GaussianQuantileThreshold', cg, 0.25),
+                           ('GaussianQuantileThreshold', cg, 0.9)):
+        for t_ref, t_got in ((truth, truth), (by_init_ref, by_init_got)):
+          want = getattr(rth, cls)(climatology=clim, quantile=q).compute(t_ref)
+          got = getattr(gth, cls)(climatology=clim, quantile=q).compute(t_got)
+          assert isinstance(got, xr.Dataset)
+          w, g = want['t2m'], got['t2m']
+          assert g.dims == w.dims and g.dtype == w.dtype, (cls, q, g.dims,
+                                                           w.dims, g.dtype)
+          np.testing.assert_array_equal(g.values, w.values)   # label gather
+    print('THRESHOLDS-OK')
+''')
+
+
+def test_threshold_datasets_equal_the_reference():
+  """thresholds.py:116-187 is host work (label selection by day of year and
+  hour, a Gaussian quantile): bit-identical to the reference's own classes, in
+  the by-valid layout and for by-init truth with 2-D time coordinates."""
+  env = dict(os.environ)
+  env['PYTHONPATH'] = os.pathsep.join(
+      [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
+       env.get('PYTHONPATH', '')])
+  res = subprocess.run([sys.executable, '-c', THRESHOLDS_SCRIPT], env=env,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0 and 'THRESHOLDS-OK' in res.stdout, (
+      res.stdout[-1500:] + res.stderr[-5000:])
