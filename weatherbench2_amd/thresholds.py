@@ -108,6 +108,7 @@ class QuantileThreshold(Threshold):
   0.01 (thresholds.py:116-148, 62-87)."""
 
   def compute(self, truth) -> xl.Dataset:
+    given = truth  # xarray in, xarray out (the metrics call this with lite data)
     truth = xl.as_dataset(truth)
     climatology = xl.as_dataset(self.climatology)
     names = {str(k) + '_quantile': str(k) for k in truth.keys()}
@@ -120,7 +121,8 @@ class QuantileThreshold(Threshold):
       raise KeyError(f'Did not find quantiles {self.quantile}+-0.01 in '
                      'climatology. Consider increasing the tolerance or '
                      'recomputing the climatology.')
-    return _time_gather(climatology.isel(quantile=i), truth, names)
+    return xl.like_input(_time_gather(climatology.isel(quantile=i), truth,
+                                      names), given)
 
 
 @dataclasses.dataclass
@@ -129,6 +131,7 @@ class GaussianQuantileThreshold(Threshold):
   (thresholds.py:151-187)."""
 
   def compute(self, truth) -> xl.Dataset:
+    given = truth
     truth = xl.as_dataset(truth)
     climatology = xl.as_dataset(self.climatology)
     variables = [str(k) for k in truth.keys()]
@@ -151,7 +154,7 @@ class GaussianQuantileThreshold(Threshold):
     for v in variables:
       out.data_vars[v] = xl.DataArray(mean[v].values + z * std[v].values,
                                       mean[v].dims, mean.coords, v)
-    return out
+    return xl.like_input(out, given)
 
 
 def get_threshold_cls(threshold_method: str):
