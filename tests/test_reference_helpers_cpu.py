@@ -294,3 +294,59 @@ def test_threshold_datasets_equal_the_reference():
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0 and 'THRESHOLDS-OK' in res.stdout, (
       res.stdout[-1500:] + res.stderr[-5000:])
+
+
+REGIONS_SCRIPT = textwrap.dedent('''
+    import numpy as np
+    import xarray as xr
+    from weatherbench2 import metrics as rm, regions as rr
+    from weatherbench2_amd import regions as gr
+    from tests.golden import reference_cases as rc
+
+    rs = np.random.RandomState(1)
+    lat = np.linspace(-90, 90, 19).astype(np.float32)   # float32 labels (ERA5)
+    lon = np.linspace(0, 360, 36, endpoint=False).astype(np.float32)
+    ds = xr.Dataset({'z': (('time', 'longitude', 'latitude'),
+                           rs.standard_normal((2, 36, 19)).astype(np.float32))},
+                    {'time': np.arange(2), 'latitude': lat, 'longitude': lon})
+    lsm = xr.DataArray(rs.rand(19, 36), dims=('latitude', 'longitude'),
+                       coords={'latitude': np.linspace(-90, 90, 19),
+                               'longitude': np.linspace(0, 360, 36,
+                                                        endpoint=False)})
+    ctx = {'lsm': lsm}
+    weights = rm.get_lat_weights(ds)
+    for label, factory in rc.region_factories().items():
+      ref, got = factory(rr, ctx), factory(gr, ctx)
+      if ref is None:
+        continue
+      d_ref, w_ref = ref.apply(ds, weights)
+      d_got, w_got = got.apply(ds, weights)
+      xr.testing.assert_identical(d_got, d_ref)
+      assert w_got.dims == w_ref.dims and w_got.dtype == w_ref.dtype, label
+      np.testing.assert_array_equal(w_got.values, w_ref.values, err_msg=label)
+      for c in w_ref.coords:
+        np.testing.assert_array_equal(w_got.coords[c].values,
+                                      w_ref.coords[c].values)
+      # and through the reference's own spatial average: a foreign metric that
+      # is handed one of OUR regions gets the reference's number
+      a = rm.MSE().compute_chunk(ds, ds * 0.5, region=got)['z']
+      b = rm.MSE().compute_chunk(ds, ds * 0.5, region=ref)['z']
+      # (float32 labels -> float32 weights and a float32 einsum, whose summation
+      # order follows the memory layout of the selection: float32 tolerance)
+      np.testing.assert_allclose(a.values, b.values, rtol=2e-6, err_msg=label)
+    print('REGIONS-OK')
+''')
+
+
+def test_region_apply_equals_the_reference():
+  """Region.apply of the product's classes (used only by foreign, xarray-based
+  metrics) returns what the reference's regions.py returns, for every region
+  type of the reference cases -- labels, order of concatenated slices, dtypes."""
+  env = dict(os.environ)
+  env['PYTHONPATH'] = os.pathsep.join(
+      [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
+       env.get('PYTHONPATH', '')])
+  res = subprocess.run([sys.executable, '-c', REGIONS_SCRIPT], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0 and 'REGIONS-OK' in res.stdout, (
+      res.stdout[-1500:] + res.stderr[-5000:])

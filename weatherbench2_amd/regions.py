@@ -26,13 +26,28 @@ import typing as t
 import numpy as np
 
 
+def _xarray_of(dataset, weights):
+  """`Region.apply` exists for FOREIGN metrics -- objects written against the
+  reference's protocol, which call `region.apply(dataset, weights)` on xarray
+  objects inside their own `_spatial_average` (metrics.py:157).  The GPU metrics
+  never call it: they evaluate every region inside the fused pass
+  (`decompose_region`)."""
+  from weatherbench2_amd import xarray_lite as xl
+  if not (xl.is_xarray(dataset) and xl.is_xarray(weights)):
+    raise NotImplementedError(
+        'Region.apply serves xarray-based (foreign) metrics; GPU metrics '
+        'evaluate regions in the fused kernel, see decompose_region')
+  return xl._xr
+
+
 @dataclasses.dataclass
 class Region:
   """regions.py:24-54."""
 
   def apply(self, dataset, weights):
-    raise NotImplementedError(
-        'GPU regions are evaluated by the fused kernel; see decompose_region')
+    """(dataset, weights) restricted to the region, like the reference's
+    `Region.apply` (regions.py:40-54)."""
+    raise NotImplementedError
 
 
 @dataclasses.dataclass
@@ -44,12 +59,34 @@ class SliceRegion(Region):
   lon_slice: t.Optional[t.Union[slice, list]] = dataclasses.field(
       default_factory=lambda: slice(None, None))
 
+  def apply(self, dataset, weights):
+    """Rows / columns of every slice, in the order the slices are listed
+    (regions.py:72-95 concatenates the selected labels the same way)."""
+    _xarray_of(dataset, weights)
+    picked = {}
+    for dim, spec in (('latitude', self.lat_slice),
+                      ('longitude', self.lon_slice)):
+      labels = np.asarray(dataset[dim].values)
+      parts = spec if isinstance(spec, list) else [spec]
+      picked[dim] = np.concatenate(
+          [_slice_positions(labels, s) for s in parts]).astype(np.int64)
+    return (dataset.isel(picked),
+            weights.isel({d: i for d, i in picked.items()
+                          if d in weights.dims}))
+
 
 @dataclasses.dataclass
 class ExtraTropicalRegion(Region):
   """|lat| >= 20; `threshold_lat` is ignored like in regions.py:102-109."""
 
   threshold_lat: t.Optional[float] = 20
+
+  def apply(self, dataset, weights):
+    xr = _xarray_of(dataset, weights)
+    lat = np.asarray(dataset['latitude'].values)
+    outside = xr.DataArray((np.abs(lat) >= 20).astype(float),
+                           dims=('latitude',), coords={'latitude': lat})
+    return dataset, weights * outside
 
 
 @dataclasses.dataclass
@@ -63,12 +100,34 @@ class LandRegion(Region):
   land_sea_mask: t.Any = None
   threshold: t.Optional[float] = None
 
+  def apply(self, dataset, weights):
+    """Weights x mask; the mask's labels are cast to the dataset's coordinate
+    dtype first and xarray aligns the product by label (regions.py:125-138)."""
+    xr = _xarray_of(dataset, weights)
+    lsm = self.land_sea_mask
+    values = np.asarray(lsm.values)
+    labels = {}
+    for name in ('latitude', 'longitude'):
+      c = lsm.coords[name]
+      labels[name] = np.asarray(getattr(c, 'values', c)).astype(
+          np.asarray(dataset[name].values).dtype)
+    if self.threshold is not None:
+      values = (values > self.threshold).astype(float)
+    land = xr.DataArray(values, dims=tuple(lsm.dims),
+                        coords={d: labels[d] for d in lsm.dims})
+    return dataset, weights * land
+
 
 @dataclasses.dataclass
 class CombinedRegion(Region):
   """Sequential application (regions.py:141-158)."""
 
   regions: list = dataclasses.field(default_factory=list)
+
+  def apply(self, dataset, weights):
+    for region in self.regions:
+      dataset, weights = region.apply(dataset, weights)
+    return dataset, weights
 
 
 @dataclasses.dataclass
