@@ -25,11 +25,16 @@ class DerivedVariable:
 
   @property
   def base_variables(self) -> list:
-    raise NotImplementedError
+    return []
 
   @property
   def core_dims(self):
     raise NotImplementedError
+
+  @property
+  def all_input_core_dims(self) -> set:
+    """The set of all input core dimensions (derived_variables.py:50-52)."""
+    return set().union(*self.core_dims[0])
 
   def compute(self, dataset):
     raise NotImplementedError
