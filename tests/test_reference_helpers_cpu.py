@@ -350,3 +350,70 @@ def test_region_apply_equals_the_reference():
                        capture_output=True, text=True, timeout=600)
   assert res.returncode == 0 and 'REGIONS-OK' in res.stdout, (
       res.stdout[-1500:] + res.stderr[-5000:])
+
+
+SURFACE_SCRIPT = textwrap.dedent('''
+    import dataclasses
+    import inspect
+    from weatherbench2 import config as rcfg, derived_variables as rdv
+    from weatherbench2 import metrics as rm, regions as rr, thresholds as rth
+    from weatherbench2_amd import config as gcfg, derived_variables as gdv
+    from weatherbench2_amd import metrics as gm, regions as gr
+    from weatherbench2_amd import thresholds as gth
+
+    def fields(cls):
+      if dataclasses.is_dataclass(cls):
+        return [(f.name, f.default) for f in dataclasses.fields(cls)
+                if not f.name.startswith('_')]
+      sig = inspect.signature(cls.__init__)
+      return [(n, p.default if p.default is not inspect._empty
+               else dataclasses.MISSING)
+              for n, p in sig.parameters.items() if n != 'self']
+
+    n = 0
+    for rmod, gmod, base in ((rm, gm, rm.Metric), (rr, gr, rr.Region),
+                             (rth, gth, rth.Threshold)):
+      for name, cls in vars(rmod).items():
+        if not (inspect.isclass(cls) and issubclass(cls, base)):
+          continue
+        ours = getattr(gmod, name, None)
+        assert ours is not None, f'{rmod.__name__}.{name} has no counterpart'
+        fr, fg = fields(cls), fields(ours)
+        assert [a for a, _ in fr] == [a for a, _ in fg], (name, fr, fg)
+        for (a, dr), (_, dg) in zip(fr, fg):   # same defaults where it has one
+          if dr is not dataclasses.MISSING and not callable(dr):
+            assert dg == dr, (name, a, dr, dg)
+        for method in ('compute_chunk', 'compute', 'apply'):
+          if hasattr(cls, method):
+            pr = list(inspect.signature(getattr(cls, method)).parameters)
+            pg = list(inspect.signature(getattr(ours, method)).parameters)
+            assert pg[:len(pr)] == pr, (name, method, pr, pg)
+        n += 1
+    assert n >= 45, n
+    assert [f.name for f in dataclasses.fields(rcfg.Eval)] == [
+        f.name for f in dataclasses.fields(gcfg.Eval)]
+    r, g = rdv.ZonalEnergySpectrum('z'), gdv.ZonalEnergySpectrum('z')
+    assert (r.base_variables, r.core_dims, r.all_input_core_dims) == (
+        g.base_variables, g.core_dims, g.all_input_core_dims)
+    for fn in ('get_lat_weights', 'central_reliability'):
+      assert list(inspect.signature(getattr(rm, fn)).parameters) == list(
+          inspect.signature(getattr(gm, fn)).parameters)[:len(
+              inspect.signature(getattr(rm, fn)).parameters)]
+    assert gth.get_threshold_cls('quantile').__name__ == 'QuantileThreshold'
+    print('SURFACE-OK', n)
+''')
+
+
+def test_api_surface_equals_the_reference():
+  """Every Metric / Region / Threshold class of the reference has a product
+  class of the same name with the same public fields (order and defaults) and
+  the same compute_chunk / compute / apply parameters; config.Eval has the same
+  fields; the DerivedVariable protocol attributes agree."""
+  env = dict(os.environ)
+  env['PYTHONPATH'] = os.pathsep.join(
+      [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
+       env.get('PYTHONPATH', '')])
+  res = subprocess.run([sys.executable, '-c', SURFACE_SCRIPT], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0 and 'SURFACE-OK' in res.stdout, (
+      res.stdout[-1500:] + res.stderr[-5000:])
