@@ -269,8 +269,58 @@ SCRIPT = textwrap.dedent('''
       compare(wmap, gmap, f'SpatialSEEPS seed={seed}')
       n_checked += 2
 
+    def rank_case(seed):
+      """Seeded rank histograms on heavily tied data in random layouts: the
+      reference's perturbation stream (np.random.default_rng(seed).uniform over
+      concat([truth, forecast]), metrics.py:1955-2010) decides the bins, so the
+      oracle must consume NumPy's stream in exactly the reference's element
+      order; and Metric.compute (time mean) of the deterministic metrics."""
+      global n_checked
+      rs = np.random.RandomState(8000 + seed)
+      lat, lon = fz._grid(rs)
+      m = int(rs.choice([2, 3, 5, 8]))
+      sizes = {'realization': m, 'time': int(rs.randint(1, 4)),
+               'level': int(rs.randint(1, 3)), 'latitude': len(lat),
+               'longitude': len(lon)}
+      coords = {'realization': np.arange(m), 'time': np.arange(sizes['time']),
+                'level': np.arange(sizes['level']), 'latitude': lat,
+                'longitude': lon}
+      spatial = (['latitude', 'longitude'] if rs.rand() < 0.6
+                 else ['longitude', 'latitude'])
+      eouter = ['realization', 'time', 'level']
+      rs.shuffle(eouter)
+      edims = tuple(eouter) + tuple(spatial)
+      touter = ['time', 'level']
+      rs.shuffle(touter)
+      tdims = tuple(touter) + tuple(spatial)
+      dtype = np.float32 if rs.rand() < 0.5 else np.float64
+      ens = fz._dataset(rs, edims, sizes, coords, dtype, 0.0)
+      truth = fz._dataset(rs, tdims, sizes, coords, dtype, 0.0)
+      round1 = lambda ds: DS({'z': NA(np.round(ds['z'].data, 1).astype(dtype),
+                                      ds['z'].dims)}, ds.coords)
+      ens, truth = round1(ens), round1(truth)             # many exact ties
+      rng_seed = int(rs.randint(0, 2**31 - 1))
+      nb = None if (m + 1) % 2 or rs.rand() < 0.5 else (m + 1) // 2
+      want = rm.RankHistogram(num_bins=nb, seed=rng_seed).compute_chunk(
+          to_xr(ens), to_xr(truth))['z']
+      got = om.RankHistogram(num_bins=nb, seed=rng_seed).compute_chunk(
+          ens, truth)['z']
+      assert tuple(got.dims) == tuple(want.dims), (seed, got.dims, want.dims)
+      np.testing.assert_array_equal(np.asarray(got.data), np.asarray(want.data),
+                                    err_msg=f'rank seed={seed} M={m} {edims}')
+      n_checked += 1
+      # Metric.compute: the time mean with and without skipna
+      f = fz._dataset(rs, tdims, sizes, coords, dtype, 0.1)
+      for skipna in (False, True):
+        for name in ('MSE', 'Bias', 'RMSESqrtBeforeTimeAvg'):
+          w = getattr(rm, name)().compute(to_xr(f), to_xr(truth),
+                                          skipna=skipna)['z']
+          g = getattr(om, name)().compute(f, truth, skipna=skipna)['z']
+          compare(w, g, f'compute {name} seed={seed} skipna={skipna}')
+          n_checked += 1
+
     special = {'maps': maps_case, 'thr': thr_case, 'spectrum': spectrum_case,
-               'seeps': seeps_case}
+               'seeps': seeps_case, 'rank': rank_case}
     for seed in range(n_cases):
       if family in special:
         special[family](seed)
@@ -368,7 +418,7 @@ def _run(family, n):
 
 @pytest.mark.parametrize('family,n', [('det', 160), ('ens', 60), ('maps', 40),
                                       ('thr', 30), ('spectrum', 24),
-                                      ('seeps', 20)])
+                                      ('seeps', 20), ('rank', 30)])
 def test_oracle_equals_the_reference_on_random_cases(family, n):
   res = _run(family, n)
   assert res.returncode == 0 and f'FUZZ-OK {family}' in res.stdout, (
