@@ -14,6 +14,8 @@ import os
 import sys
 import unittest
 
+sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE = os.environ.get('WB2_REFERENCE', '/root/reference')
 

@@ -17,6 +17,8 @@ import io
 import os
 import sys
 
+sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

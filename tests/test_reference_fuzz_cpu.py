@@ -407,7 +407,7 @@ SCRIPT = textwrap.dedent('''
 
 
 def _run(family, n):
-  env = dict(os.environ)
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')  # nothing into /root/reference
   env['PYTHONPATH'] = os.pathsep.join(
       [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
        env.get('PYTHONPATH', '')])

@@ -101,7 +101,7 @@ SCRIPT = textwrap.dedent('''
 
 
 def test_host_helpers_equal_the_reference_functions():
-  env = dict(os.environ)
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')  # nothing into /root/reference
   env['PYTHONPATH'] = os.pathsep.join(
       [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
        env.get('PYTHONPATH', '')])
@@ -182,7 +182,7 @@ ERRORS_SCRIPT = textwrap.dedent('''
 def test_host_side_errors_match_the_reference():
   """Same exception type and message as the reference for the misuse the
   reference checks for -- all raised on the host, before any kernel launch."""
-  env = dict(os.environ)
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')  # nothing into /root/reference
   env['PYTHONPATH'] = os.pathsep.join(
       [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
        env.get('PYTHONPATH', '')])
@@ -220,7 +220,7 @@ RATIO_SCRIPT = textwrap.dedent('''
 
 
 def test_spread_skill_ratio_equals_the_reference_function():
-  env = dict(os.environ)
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')  # nothing into /root/reference
   env['PYTHONPATH'] = os.pathsep.join(
       [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
        env.get('PYTHONPATH', '')])
@@ -286,7 +286,7 @@ def test_threshold_datasets_equal_the_reference():
   """thresholds.py:116-187 is host work (label selection by day of year and
   hour, a Gaussian quantile): bit-identical to the reference's own classes, in
   the by-valid layout and for by-init truth with 2-D time coordinates."""
-  env = dict(os.environ)
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')  # nothing into /root/reference
   env['PYTHONPATH'] = os.pathsep.join(
       [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
        env.get('PYTHONPATH', '')])
@@ -342,7 +342,7 @@ def test_region_apply_equals_the_reference():
   """Region.apply of the product's classes (used only by foreign, xarray-based
   metrics) returns what the reference's regions.py returns, for every region
   type of the reference cases -- labels, order of concatenated slices, dtypes."""
-  env = dict(os.environ)
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')  # nothing into /root/reference
   env['PYTHONPATH'] = os.pathsep.join(
       [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
        env.get('PYTHONPATH', '')])
@@ -409,7 +409,7 @@ def test_api_surface_equals_the_reference():
   class of the same name with the same public fields (order and defaults) and
   the same compute_chunk / compute / apply parameters; config.Eval has the same
   fields; the DerivedVariable protocol attributes agree."""
-  env = dict(os.environ)
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')  # nothing into /root/reference
   env['PYTHONPATH'] = os.pathsep.join(
       [os.path.join(ROOT, 'oracle', 'refshim'), REFERENCE, ROOT,
        env.get('PYTHONPATH', '')])

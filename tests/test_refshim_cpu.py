@@ -25,7 +25,8 @@ needs_reference = pytest.mark.skipif(
 
 def _run(script, *args):
   return subprocess.run([sys.executable, os.path.join(ROOT, script), *args],
-                        capture_output=True, text=True, cwd=ROOT, timeout=900)
+                        capture_output=True, text=True, cwd=ROOT, timeout=900,
+                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
 
 
 @needs_reference
@@ -44,7 +45,8 @@ def test_reference_unit_tests_pass_on_the_mini_xarray():
 def test_committed_reference_vectors_are_what_the_reference_produces(tmp_path):
   """make_reference_vectors.py, re-run now, reproduces the committed .npz bit
   for bit (so the fixture cannot drift from the generator or the reference)."""
-  env = dict(os.environ, WB2_VECTORS_OUT=str(tmp_path / 'v.npz'))
+  env = dict(os.environ, WB2_VECTORS_OUT=str(tmp_path / 'v.npz'),
+             PYTHONDONTWRITEBYTECODE='1')
   r = subprocess.run([sys.executable, os.path.join(
       ROOT, 'tests', 'golden', 'make_reference_vectors.py')],
                      capture_output=True, text=True, cwd=ROOT, env=env,
