@@ -156,3 +156,15 @@ def test_concat_and_merge_orders(xr):
   same = xr.merge([one('mse'), one('mse').rename({'v': 'w'})])
   assert list(same.metric.values) == ['mse'] and set(same.data_vars) == {'v',
                                                                         'w'}
+
+
+@needs_reference
+def test_the_reference_checkout_is_left_untouched():
+  """Importing the reference from these tests must not leave bytecode caches
+  (or anything else) behind in the read-only checkout."""
+  leftovers = []
+  for base, dirs, files in os.walk(REFERENCE):
+    leftovers += [os.path.join(base, d) for d in dirs
+                  if d in ('__pycache__', '.pytest_cache')]
+    leftovers += [os.path.join(base, f) for f in files if f.endswith('.pyc')]
+  assert not leftovers, leftovers[:5]
