@@ -423,3 +423,18 @@ def test_oracle_equals_the_reference_on_random_cases(family, n):
   res = _run(family, n)
   assert res.returncode == 0 and f'FUZZ-OK {family}' in res.stdout, (
       res.stdout[-1500:] + res.stderr[-5000:])
+
+
+def test_oracle_equals_the_reference_at_full_size():
+  """One BASELINE-size unit (13 x 721 x 1440 float32): the oracle and the
+  reference's own metric code agree on the first (metric, region) evaluations
+  -- every metric on the global region, then MSE / RMSE on the tropics -- to the
+  printed digits of the summed results (tools/cpu_reference_vs_port.py)."""
+  env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+  res = subprocess.run([sys.executable, os.path.join(
+      ROOT, 'tools', 'cpu_reference_vs_port.py'), '7'], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+  assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+  sums = [line.split('checksum')[1].strip(' )\n')
+          for line in res.stdout.splitlines() if 'checksum' in line]
+  assert len(sums) == 2 and sums[0] == sums[1], res.stdout
