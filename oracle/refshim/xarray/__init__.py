@@ -1112,6 +1112,15 @@ def _labels_to_positions(index: pd.Index, label, method, dim,
                      {k: c for k, c in label._coords.items() if k != dim},
                      label.dims, _fast=True, name=None, attrs={})
   if isinstance(label, slice):
+    def bound(x):  # xarray's _sanitize_slice_element: 0-d arrays -> scalars
+      if isinstance(x, DataArray):
+        x = x._data
+      if isinstance(x, np.ndarray):
+        if x.ndim != 0:
+          raise ValueError('cannot use non-scalar arrays in a slice')
+        x = x[()]
+      return x
+    label = slice(bound(label.start), bound(label.stop), label.step)
     if label.step not in (None, 1):
       sl = index.slice_indexer(label.start, label.stop, label.step)
     else:
@@ -1126,10 +1135,21 @@ def _labels_to_positions(index: pd.Index, label, method, dim,
   # scalar
   if isinstance(label, np.ndarray):
     label = label[()]
+  if index.dtype.kind == 'M' and isinstance(label, str):
+    # pandas' partial-string indexing ('2020' = the whole year): a slice of a
+    # monotonic index (the dim is kept), KeyError when nothing matches
+    try:
+      loc = index.get_loc(label)
+    except KeyError:
+      raise KeyError(f'{label!r} not found in index {dim!r}') from None
+    if isinstance(loc, slice):
+      return loc
+    if isinstance(loc, np.ndarray):
+      return np.nonzero(loc)[0] if loc.dtype == bool else loc
+    return int(loc)
   if index.dtype.kind == 'M' and not isinstance(label, (np.datetime64,
                                                        pd.Timestamp)):
     label = pd.Timestamp(label)
-    # partial-string indexing is not supported here
   if index.dtype.kind == 'm' and not isinstance(label, (np.timedelta64,
                                                        pd.Timedelta)):
     label = pd.Timedelta(label)
@@ -2239,6 +2259,7 @@ def concat(objs, dim, data_vars='all', coords='different', compat='equals',
     labels = _as_index_values(dim)
   else:
     raise TypeError(f'concat dim of type {type(dim)}')
+  objs = _join_for_concat(objs, dim_name, join, fill_value)
   if _builtin_all(isinstance(o, DataArray) for o in objs):
     return _concat_arrays(objs, dim_name, labels)
   if not _builtin_all(isinstance(o, Dataset) for o in objs):
@@ -2275,6 +2296,36 @@ def concat(objs, dim, data_vars='all', coords='different', compat='equals',
       coords_out[ck] = first._coords[ck]
   out._coords = coords_out
   return out
+
+
+def _join_for_concat(objs, dim_name, join, fill_value):
+  """xarray aligns the objects along every indexed dim other than the concat
+  dim before concatenating (core/concat.py: `align(*datasets, join=join,
+  exclude=[dim])`): with the default join='outer' differing indexes become
+  their union -- pandas' Index.union, i.e. SORTED unless the indexes are equal
+  -- and the holes are filled with `fill_value`."""
+  if join in ('override', 'exact'):
+    return objs
+  dims = _union_dims([tuple(o.indexes) for o in objs])
+  for d in dims:
+    if d == dim_name:
+      continue
+    idxs = [o.indexes[d] for o in objs if d in o.indexes]
+    if len(idxs) < 2 or _builtin_all(idxs[0].equals(i) for i in idxs[1:]):
+      continue
+    joined = idxs[0]
+    for i in idxs[1:]:
+      if join == 'outer':
+        joined = joined.union(i)
+      elif join == 'inner':
+        joined = joined.intersection(i)
+      elif join == 'left':
+        break
+      else:
+        raise NotImplementedError(f'wb2shim: concat(join={join!r})')
+    objs = [o.reindex({d: joined}, fill_value=fill_value)
+            if d in o.indexes else o for o in objs]
+  return objs
 
 
 def _concat_arrays(arrays, dim_name, labels):

@@ -30,6 +30,7 @@ sys.path.insert(0, REFERENCE)
 sys.path.insert(0, SHIM)  # `import xarray` -> the mini-xarray
 
 import xarray as xr  # noqa: E402  (the stand-in)
+import xarray_beam as xbeam  # noqa: E402  (import-only stand-in)
 from weatherbench2 import config as ref_config  # noqa: E402
 from weatherbench2 import derived_variables as ref_dv  # noqa: E402
 from weatherbench2 import evaluation as ref_evaluation  # noqa: E402  (beam stubs)
@@ -135,6 +136,75 @@ def main():
   np.savez_compressed(path, **out)
   n_val = sum(v.size for k, v in out.items() if not k.endswith('/dims'))
   print(f'wrote {path}: {len(out) // 2} arrays, {n_val} values, '
+        f'{os.path.getsize(path) / 1e3:.0f} kB')
+  evalall()
+
+
+def evalall_datasets(case):
+  """The opened (forecast, truth, climatology) of an evalall case."""
+  def ds(key, extra=None):
+    coords = dict(case[f'coords_{key}'])
+    for k, a in (extra or {}).items():
+      coords[k] = (a['dims'], a['data'])
+    return xr.Dataset({k: (a['dims'], a['data'])
+                       for k, a in case[key].items()}, coords)
+  return (ds('forecast', case['forecast_extra_coords']), ds('truth'),
+          ds('climatology'), ds('acc_climatology'))
+
+
+def evalall():
+  """The reference's own _evaluate_all_metrics (evaluation.py:441-483) and the
+  per-chunk functions of its Beam driver (:601-675), with the baseline
+  switches of config.Eval, on in-memory datasets: only dataset OPENING and
+  NetCDF WRITING are replaced (module attributes patched at run time; the
+  reference's files are untouched)."""
+  out = {}
+  regions = rc.region_factories()
+  captured = {}
+  ref_evaluation._to_netcdf = lambda ds, fn: captured.__setitem__('result', ds)
+  ref_evaluation._get_output_path = lambda *a, **k: 'unused'
+  for cname, (build, switches, metrics, rlabels, skipna) in (
+      rc.evalall_table().items()):
+    case = build()
+    forecast, truth, climatology, acc_clim = evalall_datasets(case)
+    ctx = {'acc_climatology': acc_clim}
+    cfg = ref_config.Eval(
+        metrics={k: f(ref_metrics, ctx) for k, f in metrics.items()},
+        regions={r: regions[r](ref_regions, ctx) for r in rlabels}, **switches)
+    data_config = ref_config.Data(
+        selection=None, paths=None, by_init=case['by_init'])
+    if case['kind'].endswith('_chunk') or 'chunk' in case['kind']:
+      # Beam driver, one chunk = the whole forecast: the forecast's variables
+      # are dropped (:684-690), truth is selected per chunk (:601-616), the
+      # baseline replaces the forecast chunk, then _evaluate_chunk (:583-599)
+      t = ref_evaluation._EvaluateAllMetrics(
+          'e', cfg, data_config, input_chunks={'init_time': 1}, skipna=skipna)
+      variables = list(forecast.keys())
+      key = xbeam.Key({'init_time': 0})
+      bare = forecast.drop_vars(variables)
+      key, chunks = t._sel_corresponding_truth_chunk(key, bare, truth=truth)
+      if cfg.evaluate_climatology:
+        key, chunks = t._climatology_like_forecast_chunk(
+            key, chunks, climatology=climatology, variables=variables)
+      if cfg.evaluate_persistence:
+        key, chunks = t._persistence_like_forecast_chunk(
+            key, chunks, truth=truth, variables=variables)
+      key.with_offsets = lambda **kw: key
+      _, res = t._evaluate_chunk(key, list(chunks))
+    else:
+      ref_evaluation.open_forecast_and_truth_datasets = (
+          lambda dc, ec, use_dask=False: (forecast, truth, climatology))
+      ref_evaluation._evaluate_all_metrics('e', cfg, data_config, skipna=skipna)
+      res = captured.pop('result')
+    store(out, cname, res)
+    for c in ('metric', 'region'):
+      out[f'{cname}/coord/{c}'] = np.array(list(res.coords[c].data),
+                                           dtype='U32')
+      out[f'{cname}/coord/{c}/dims'] = np.array([c], dtype='U32')
+  path = os.environ.get('WB2_EVALALL_OUT') or os.path.join(
+      HERE, 'reference_evalall_v1.npz')
+  np.savez_compressed(path, **out)
+  print(f'wrote {path}: {len(out) // 2} arrays, '
         f'{os.path.getsize(path) / 1e3:.0f} kB')
 
 

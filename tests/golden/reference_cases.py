@@ -586,3 +586,131 @@ def ragged_case(seed=91):
 def ragged_table():
   return {'ragged_f32': (ragged_case, DET_METRICS, ['global', 'europe'], False,
                          'chunk')}
+
+
+# --------------------------------------------------------------------------
+# _evaluate_all_metrics with its baseline substitutions (evaluation.py:441-483):
+# forecast := climatology / probabilistic climatology / persistence.
+# A case carries the OPENED datasets the reference's driver would have read
+# (`forecast`, `truth`, `climatology`, each with its own coordinates) and the
+# Eval / Data switches.
+# --------------------------------------------------------------------------
+LAT30 = np.linspace(-75.0, 75.0, 6)
+LON45 = np.linspace(0.0, 360.0, 8, endpoint=False)
+EVALALL_REGIONS = ('global', 'tropics', 'extra_tropical')
+EVALALL_DET = {k: DET_METRICS[k] for k in ('mse', 'rmse', 'mae', 'bias')}
+
+
+def evalall_case(kind: str, dtype=np.float32, seed=71):
+  """kind: 'clim_byinit' | 'clim_byvalid' | 'persist_byvalid' |
+  'persist_byinit_chunk' | 'probclim_byinit' | 'clim_chunk_mean_names'."""
+  rs = np.random.RandomState(seed + sum(map(ord, kind)))
+  levels = np.array([500, 850])
+  sshape = (len(LAT30), len(LON45))
+  spatial = ('latitude', 'longitude')
+  h = np.timedelta64(1, 'h').astype('timedelta64[ns]')
+  by_init = 'byinit' in kind or kind == 'clim_chunk_mean_names'
+  if kind == 'probclim_byinit':
+    # two years and a bit of 12-hourly truth: 2019 has no day 366, 2020 has
+    t0, t1 = np.datetime64('2018-12-20T00', 'ns'), np.datetime64(
+        '2021-01-12T00', 'ns')
+  else:
+    # crosses the end of a leap year: dayofyear 364, 365, 366, 1, 2, ...
+    t0, t1 = np.datetime64('2020-12-26T00', 'ns'), np.datetime64(
+        '2021-01-08T00', 'ns')
+  times = np.arange(t0, t1, 12 * h)
+  truth = rs.standard_normal((len(times), len(levels)) + sshape).astype(dtype)
+  lead = np.arange(3) * 12 * h
+  n_init = 6
+  first = int(np.nonzero(times == np.datetime64('2020-12-28T00', 'ns'))[0][0])
+  init = times[first:first + n_init]
+  case = {
+      'kind': kind, 'by_init': by_init,
+      'coords_truth': {'time': times, 'level': levels, 'latitude': LAT30,
+                       'longitude': LON45},
+      'truth': {'geopotential': _arr(truth, 'time', 'level', *spatial)},
+  }
+  if by_init:
+    f = rs.standard_normal((n_init, len(lead), len(levels)) + sshape)
+    case['coords_forecast'] = {'init_time': init, 'lead_time': lead,
+                               'level': levels, 'latitude': LAT30,
+                               'longitude': LON45}
+    case['forecast'] = {'geopotential': _arr(
+        f.astype(dtype), 'init_time', 'lead_time', 'level', *spatial)}
+    case['forecast_extra_coords'] = {
+        'valid_time': _arr(init[:, None] + lead[None, :], 'init_time',
+                           'lead_time')}
+  else:
+    ftime = times[first:first + n_init + 2]
+    f = rs.standard_normal((len(ftime), len(lead), len(levels)) + sshape)
+    case['coords_forecast'] = {'time': ftime, 'lead_time': lead,
+                               'level': levels, 'latitude': LAT30,
+                               'longitude': LON45}
+    case['forecast'] = {'geopotential': _arr(
+        f.astype(dtype), 'time', 'lead_time', 'level', *spatial)}
+    case['forecast_extra_coords'] = {
+        'init_time': _arr(ftime[:, None] - lead[None, :], 'time', 'lead_time')}
+  hours = np.array([0, 12])
+  days = np.arange(1, 367)
+  cname = 'geopotential_mean' if kind == 'clim_chunk_mean_names' else (
+      'geopotential')
+  clim = 0.4 * rs.standard_normal((len(hours), len(days), len(levels)) + sshape)
+  case['coords_climatology'] = {'hour': hours, 'dayofyear': days,
+                                'level': levels, 'latitude': LAT30,
+                                'longitude': LON45}
+  case['climatology'] = {cname: _arr(clim.astype(dtype), 'hour', 'dayofyear',
+                                     'level', *spatial)}
+  # the ACC of the case reads a climatology under the plain name
+  case['coords_acc_climatology'] = case['coords_climatology']
+  case['acc_climatology'] = {'geopotential': _arr(
+      clim.astype(dtype), 'hour', 'dayofyear', 'level', *spatial)}
+  return case
+
+
+def evalall_table():
+  """name -> (case builder, eval switches, metric table, region labels,
+  skipna).  The `_chunk` kinds go through the Beam driver's per-chunk
+  functions (evaluation.py:618-675) followed by _evaluate_chunk."""
+  det_acc = dict(EVALALL_DET,
+                 acc=lambda m, c: m.ACC(climatology=c['acc_climatology']))
+  ens = {k: ENS_METRICS[k] for k in ('crps', 'crps_spread', 'crps_skill',
+                                     'ensemble_mean_mse', 'ensemble_variance')}
+  number = lambda table: {
+      k: (lambda m, c, f=f: _with_ensemble_dim(f(m, c), 'number'))
+      for k, f in table.items()}
+  return {
+      'evalall_clim_byinit': (
+          lambda: evalall_case('clim_byinit'),
+          {'evaluate_climatology': True}, det_acc, EVALALL_REGIONS, False),
+      'evalall_clim_byvalid': (
+          lambda: evalall_case('clim_byvalid'),
+          {'evaluate_climatology': True}, EVALALL_DET, EVALALL_REGIONS, False),
+      'evalall_persist_byvalid': (
+          lambda: evalall_case('persist_byvalid', np.float64),
+          {'evaluate_persistence': True}, det_acc, EVALALL_REGIONS, False),
+      'evalall_probclim_byinit': (
+          lambda: evalall_case('probclim_byinit'),
+          {'evaluate_probabilistic_climatology': True,
+           'probabilistic_climatology_start_year': 2019,
+           'probabilistic_climatology_end_year': 2020,
+           'probabilistic_climatology_hour_interval': 12},
+          number(ens), ('global', 'tropics'), False),
+      'evalall_probclim_byinit_skipna': (
+          lambda: evalall_case('probclim_byinit', seed=72),
+          {'evaluate_probabilistic_climatology': True,
+           'probabilistic_climatology_start_year': 2019,
+           'probabilistic_climatology_end_year': 2020,
+           'probabilistic_climatology_hour_interval': 12},
+          number(ens), ('global',), True),
+      'evalall_persist_byinit_chunk': (
+          lambda: evalall_case('persist_byinit_chunk'),
+          {'evaluate_persistence': True}, det_acc, EVALALL_REGIONS, False),
+      'evalall_clim_chunk_mean_names': (
+          lambda: evalall_case('clim_chunk_mean_names'),
+          {'evaluate_climatology': True}, EVALALL_DET, EVALALL_REGIONS, False),
+  }
+
+
+def _with_ensemble_dim(metric, dim):
+  metric.ensemble_dim = dim
+  return metric

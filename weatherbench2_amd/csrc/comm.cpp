@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace wb2 {
@@ -74,10 +75,17 @@ struct Rccl {
   group_fn group_start = nullptr, group_end = nullptr;
   error_string_fn error_string = nullptr;
   bool ok = false;
+  // why `ok` is false, captured ONCE here: dlerror() returns NULL when the
+  // library opened but a symbol is missing, and after any earlier dlerror()
+  std::string why;
   Rccl() {
     static const char* const libs[] = {"librccl.so.1", "librccl.so", nullptr};
     void* h = open_first(libs);
-    if (!h) return;
+    if (!h) {
+      const char* msg = dlerror();
+      why = msg ? msg : "librccl.so.1 / librccl.so not found";
+      return;
+    }
     get_unique_id =
         reinterpret_cast<get_unique_id_fn>(dlsym(h, "ncclGetUniqueId"));
     comm_init_rank =
@@ -90,6 +98,7 @@ struct Rccl {
         reinterpret_cast<error_string_fn>(dlsym(h, "ncclGetErrorString"));
     ok = get_unique_id && comm_init_rank && comm_destroy && all_reduce &&
          group_start && group_end;
+    if (!ok) why = "librccl opened but an ncclXxx entry point is missing";
   }
 };
 const Rccl& rccl() {
@@ -173,7 +182,7 @@ int wb2_comm_unique_id(void* id128) {
   WB2_TRACE();
   WB2_REQUIRE(id128, "null pointer argument");
   const Rccl& r = rccl();
-  WB2_REQUIRE(r.ok, "librccl.so.1 could not be loaded: %s", dlerror());
+  WB2_REQUIRE(r.ok, "RCCL is unavailable: %s", r.why.c_str());
   NcclUniqueId id;
   const int rc = r.get_unique_id(&id);
   if (rc != 0) return rccl_fail("ncclGetUniqueId", rc);
@@ -189,7 +198,7 @@ int wb2_comm_init_rank(const void* id128, int32_t n_ranks, int32_t rank,
   WB2_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "rank %d of %d", rank,
               n_ranks);
   const Rccl& r = rccl();
-  WB2_REQUIRE(r.ok, "librccl.so.1 could not be loaded: %s", dlerror());
+  WB2_REQUIRE(r.ok, "RCCL is unavailable: %s", r.why.c_str());
   NcclUniqueId id;
   std::memcpy(id.internal, id128, sizeof(id.internal));
   void* comm = nullptr;
@@ -204,7 +213,7 @@ int wb2_comm_destroy(void* comm) {
   WB2_TRACE();
   if (!comm) return 0;
   const Rccl& r = rccl();
-  WB2_REQUIRE(r.ok, "librccl.so.1 could not be loaded");
+  WB2_REQUIRE(r.ok, "RCCL is unavailable: %s", r.why.c_str());
   const int rc = r.comm_destroy(comm);
   if (rc != 0) return rccl_fail("ncclCommDestroy", rc);
   return 0;
@@ -218,7 +227,7 @@ int wb2_time_mean_allreduce(double* sum, double* count, int64_t n, void* comm,
   WB2_REQUIRE(n >= 0, "n=%lld", (long long)n);
   if (n == 0) return 0;
   const Rccl& r = rccl();
-  WB2_REQUIRE(r.ok, "librccl.so.1 could not be loaded");
+  WB2_REQUIRE(r.ok, "RCCL is unavailable: %s", r.why.c_str());
   hipStream_t s = static_cast<hipStream_t>(stream);
   // one fused exchange: both buffers inside a group, in place
   int rc = r.group_start();

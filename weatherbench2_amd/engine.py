@@ -39,9 +39,21 @@ class _ThreadStreams(threading.local):
 
   def __init__(self):
     self.streams: dict = {}
+    self.disabled = False
 
 
 _THREAD_STREAMS = _ThreadStreams()
+
+
+def disable_thread_stream() -> None:
+  """The calling thread keeps the default / caller's stream for good (IO helper
+  threads -- evaluation._prefetched -- whose uploads the main thread consumes:
+  a private stream there would order nothing with the consumer)."""
+  _THREAD_STREAMS.disabled = True
+
+
+def _own_stream(device: torch.device):
+  return _THREAD_STREAMS.streams.get((device.type, device.index))
 
 
 def _adopt_thread_stream(device: torch.device) -> None:
@@ -50,22 +62,52 @@ def _adopt_thread_stream(device: torch.device) -> None:
   as their torch *current* stream the first time they reach the GPU path:
   everything such a thread launches, allocates and reads back is then ordered
   on its stream, and the passes of different threads overlap on the device
-  instead of queueing on the shared default stream.  The new stream starts
-  after whatever the default stream had queued at that moment (inputs made
-  resident by the main thread).  The main thread keeps the caller's stream.
-  WB2HIP_THREAD_STREAMS=0 disables."""
+  instead of queueing on the shared default stream.
+
+  Hand-offs between threads are ordered through the default stream:
+    * every ENTRY to the GPU path (`require_gpu`) makes the own stream wait for
+      what the default stream has queued -- inputs the main thread produced or
+      made resident at any time before, and whatever other workers published;
+    * `publish_thread_stream` (the exit of the outermost chunk scope, i.e. the
+      moment results leave the pass) makes the default stream wait for the own
+      stream, so a result read on the main thread, or on another worker (whose
+      reads wait for the default stream, `order_read`), sees finished kernels.
+  The main thread keeps the caller's stream.  WB2HIP_THREAD_STREAMS=0 disables."""
   if threading.current_thread() is threading.main_thread():
     return
+  st = _THREAD_STREAMS
   key = (device.type, device.index)
-  if key in _THREAD_STREAMS.streams:
+  if key not in st.streams:
+    if st.disabled or os.environ.get('WB2HIP_THREAD_STREAMS', '1') == '0':
+      st.streams[key] = None
+    else:
+      own = torch.cuda.Stream(device=device)
+      torch.cuda.set_stream(own)
+      st.streams[key] = own
+  own = st.streams[key]
+  if own is not None:
+    own.wait_stream(torch.cuda.default_stream(device))
+
+
+def publish_thread_stream() -> None:
+  """Results of this (worker) thread's stream become visible to the default
+  stream: called when the outermost chunk scope of a pass exits."""
+  for (kind, index), own in _THREAD_STREAMS.streams.items():
+    if own is not None:
+      torch.cuda.default_stream(torch.device(kind, index)).wait_stream(own)
+
+
+def order_read(tensor: torch.Tensor) -> None:
+  """Before a device result is read (`.values`, RunningMean.add) on a thread
+  whose current stream is not the default stream: wait for what has been
+  published there.  No-op on the main thread's default stream."""
+  if not tensor.is_cuda:
     return
-  if os.environ.get('WB2HIP_THREAD_STREAMS', '1') == '0':
-    _THREAD_STREAMS.streams[key] = None
-    return
-  own = torch.cuda.Stream(device=device)
-  own.wait_stream(torch.cuda.default_stream(device))
-  torch.cuda.set_stream(own)
-  _THREAD_STREAMS.streams[key] = own
+  dev = tensor.device
+  cur = torch.cuda.current_stream(dev)
+  default = torch.cuda.default_stream(dev)
+  if cur != default:
+    cur.wait_stream(default)
 
 
 def require_gpu() -> torch.device:
@@ -103,12 +145,24 @@ def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
   return ten.contiguous()
 
 
+def digest(buf: np.ndarray) -> bytes:
+  """Content digest of a contiguous numeric array (xxh3 when importable --
+  GB/s --, blake2b otherwise)."""
+  raw = memoryview(np.ascontiguousarray(buf)).cast('B')
+  try:
+    import xxhash
+    return xxhash.xxh3_128_digest(raw)
+  except ImportError:
+    import hashlib
+    return hashlib.blake2b(raw, digest_size=16).digest()
+
+
 class _TableUploads(threading.local):
   """Per-thread, per-device: content cache of uploaded int64 tables + a small
   pinned ring for the misses."""
 
   def __init__(self):
-    self.cache: dict = {}   # (device, bytes) -> device tensor
+    self.cache: dict = {}   # (device, shape, digest) -> (device tensor, event)
     self.ring: dict = {}    # device -> [pinned slots, events, next]
 
 
@@ -122,17 +176,24 @@ def upload_table(table: np.ndarray, device) -> torch.Tensor:
   `torch.from_numpy(t).to(device)` is a synchronous pageable copy: with kernels
   queued ahead the host blocks until the GPU has drained, once per table and
   call.  Tables recur (same chunk geometry, same valid times), so they are
-  cached by content; a miss goes through a pinned slot with an asynchronous
-  copy on the current stream."""
+  cached by a digest of their content; a miss goes through a pinned slot with
+  an asynchronous copy on the current stream of `device`, and the event of that
+  copy stays with the cache entry: a hit under a different current stream
+  (`torch.cuda.stream(...)`) waits for it before the table is read."""
   table = np.ascontiguousarray(table, dtype=np.int64)
+  device = torch.device(device)
   st = _TABLES
-  key = (str(device), table.shape, table.tobytes())
+  key = (str(device), table.shape, digest(table))
   hit = st.cache.get(key)
   if hit is not None:
-    return hit
+    dev, ev = hit
+    if ev is not None:
+      torch.cuda.current_stream(device).wait_event(ev)
+    return dev
   nbytes = table.nbytes
-  if nbytes > _TABLE_SLOT_BYTES or nbytes == 0:
-    dev = torch.from_numpy(table).to(device)
+  ev = None
+  if nbytes > _TABLE_SLOT_BYTES or nbytes == 0 or device.type != 'cuda':
+    dev = torch.from_numpy(table).to(device)  # synchronous: complete on return
   else:
     ring = st.ring.get(str(device))
     if ring is None:
@@ -145,14 +206,16 @@ def upload_table(table: np.ndarray, device) -> torch.Tensor:
       events[nxt].synchronize()
     slot = slots[nxt][:table.size]
     slot.numpy()[...] = table.reshape(-1)
-    dev = torch.empty(table.shape, dtype=torch.int64, device=device)
-    dev.view(-1).copy_(slot, non_blocking=True)
+    stream = torch.cuda.current_stream(device)
+    with torch.cuda.stream(stream):
+      dev = torch.empty(table.shape, dtype=torch.int64, device=device)
+      dev.view(-1).copy_(slot, non_blocking=True)
     ev = torch.cuda.Event()
-    ev.record()
+    ev.record(stream)
     events[nxt] = ev
   if len(st.cache) >= 512:
     st.cache.clear()
-  st.cache[key] = dev
+  st.cache[key] = (dev, ev)
   return dev
 
 

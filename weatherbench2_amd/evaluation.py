@@ -23,10 +23,25 @@ Mirrors (reference = /root/reference/weatherbench2/evaluation.py):
   evaluate_in_memory's per-config driver      :441-517
       `evaluate_chunks`: init-time chunks sharded contiguously over ranks
       (SURVEY.md 8e), one fused pass per chunk, one all-reduce at the end.
+
+  _evaluate_all_metrics                       :441-483
+      same name and leading arguments, but the datasets arrive already opened
+      (dataset opening / NetCDF writing are the IO layer, out of scope) and the
+      result is returned.  Its baseline substitutions are GATHERS and cost no
+      copy: forecast := climatology.sel(dayofyear, hour) of the valid time
+      (:452-460), the probabilistic climatology (:461-471 + utils.py:47-70),
+      the persistence forecast (:165-193) come back as `xarray_lite.SlabGather`
+      arrays -- an index table over the resident source -- which the fused
+      deterministic passes read through their slab tables.
+
+  _climatology_like_forecast_chunk / _persistence_like_forecast_chunk
+                                              :618-675
+      the per-chunk versions of the Beam pipeline, same gathers.
 """
 from __future__ import annotations
 
 import contextlib
+import logging
 import typing as t
 
 import numpy as np
@@ -247,6 +262,7 @@ class RunningMean:
         # on the device: accumulate there, no host round trip
         if self.device is None and raw.is_cuda:
           self.device = raw.device
+        engine.order_read(raw)  # produced on another thread's stream?
         values = raw.to(torch.float64)
       else:
         values = torch.as_tensor(np.ascontiguousarray(da.values),
@@ -267,6 +283,15 @@ class RunningMean:
     import torch.distributed as dist
     out = xl.Dataset(coords=self._coords)
     names = sorted(self._acc)
+    in_group = self.comm is not None or (
+        dist.is_available() and dist.is_initialized()
+        and dist.get_world_size() > 1)
+    if in_group and not names:
+      # every rank must enter the collective with the same layout: a rank
+      # without a single chunk would leave the others waiting in the all-reduce
+      raise ValueError('RunningMean.result() on a rank that accumulated '
+                       'nothing: give every rank at least one chunk '
+                       '(evaluate_chunks checks this up front)')
     if self.comm is not None and names:
       from weatherbench2_amd import engine
       flat_t = torch.cat([self._acc[n][0].reshape(-1) for n in names])
@@ -337,8 +362,12 @@ def _prefetched(chunks, lo: int, hi: int, depth: int):
     return
   import collections
   from concurrent import futures
+  from weatherbench2_amd import engine
+  # the fetch thread may upload (a lazy chunks[i] calling make_resident): it
+  # must not get a private stream -- its uploads are consumed by THIS thread
   with futures.ThreadPoolExecutor(
-      max_workers=1, thread_name_prefix='wb2hip-prefetch') as pool:
+      max_workers=1, thread_name_prefix='wb2hip-prefetch',
+      initializer=engine.disable_thread_stream) as pool:
     pending: collections.deque = collections.deque()
     nxt = lo
     try:
@@ -352,14 +381,70 @@ def _prefetched(chunks, lo: int, hi: int, depth: int):
         fut.cancel()
 
 
+def _chunk_substitution(eval_config, truth, climatology, by_init: bool):
+  """The forecast replacement of `_EvaluateAllMetrics._evaluate`
+  (evaluation.py:677-733) as one function of a chunk, or None."""
+  steps = []
+  if getattr(eval_config, 'evaluate_climatology', False):
+    if climatology is None:
+      raise ValueError('eval_config.evaluate_climatology is set: pass the '
+                       'climatology dataset (climatology=...)')
+    steps.append(lambda f, tc: _climatology_like_forecast_chunk(
+        f, tc, climatology, list(f.keys()), by_init)[0])
+  if getattr(eval_config, 'evaluate_probabilistic_climatology', False):
+    if truth is None:
+      raise ValueError('eval_config.evaluate_probabilistic_climatology is set: '
+                       'pass the full ground-truth dataset (truth=...)')
+    made: list = []
+
+    def prob(f, tc):
+      if not made:  # once: label work over truth.time
+        made.append(make_probabilistic_climatology(
+            truth, eval_config.probabilistic_climatology_start_year,
+            eval_config.probabilistic_climatology_end_year,
+            eval_config.probabilistic_climatology_hour_interval,
+            variables=list(f.keys())))
+      return _climatology_like_forecast_chunk(f, tc, made[0], list(f.keys()),
+                                              by_init)[0]
+    steps.append(prob)
+  elif getattr(eval_config, 'evaluate_persistence', False):
+    if truth is None:
+      raise ValueError('eval_config.evaluate_persistence is set: pass the full '
+                       'ground-truth dataset (truth=...)')
+    steps.append(lambda f, tc: _persistence_like_forecast_chunk(
+        f, tc, truth, list(f.keys()), by_init)[0])
+  if not steps:
+    return None
+
+  def substitute(forecast, truth_chunk):
+    # like the pipeline, every step sees the ORIGINAL chunk's labels
+    out = forecast
+    for step in steps:
+      out = step(forecast, truth_chunk)
+    return out
+  return substitute
+
+
 def evaluate_chunks(
     chunks: t.Sequence[tuple],
     eval_config: config.Eval,
     skipna: bool = False,
     device=None,
     prefetch: int = 2,
+    *,
+    truth=None,
+    climatology=None,
+    by_init: bool = True,
 ) -> xl.Dataset:
   """Evaluates (forecast, truth) chunks and returns the temporal mean.
+
+  The baseline switches of `eval_config` are honoured the way the Beam pipeline
+  does (evaluation.py:677-733): with `evaluate_climatology` /
+  `evaluate_probabilistic_climatology` / `evaluate_persistence` the forecast of
+  every chunk is replaced by a gather from `climatology` / from the years of
+  `truth` / from `truth` at the init time (the full datasets, passed here; made
+  resident they are read in place) -- a switch that is set without its dataset
+  raises instead of silently evaluating the forecast.
 
   `chunks` is the full, ordered list (or any indexable) of per-init-time chunk
   pairs; each rank of the current torch.distributed group (if any) evaluates a
@@ -382,10 +467,13 @@ def evaluate_chunks(
     raise ValueError(f'{len(chunks)} chunks cannot be sharded over {world} '
                      'ranks (every rank must take part in the all-reduce)')
   lo, hi = shard_bounds(len(chunks), world, rank)
+  substitute = _chunk_substitution(eval_config, truth, climatology, by_init)
   mean: t.Optional[RunningMean] = None
-  for forecast, truth in _prefetched(chunks, lo, hi, prefetch):
+  for forecast, truth_chunk in _prefetched(chunks, lo, hi, prefetch):
     forecast = xl.as_dataset(forecast)
-    result = _metric_and_region_loop(forecast, truth, eval_config, skipna,
+    if substitute is not None:
+      forecast = xl.as_dataset(substitute(forecast, truth_chunk))
+    result = _metric_and_region_loop(forecast, truth_chunk, eval_config, skipna,
                                      compute_chunk=True)
     if mean is None:
       dim = 'time' if 'time' in forecast.dims else 'init_time'
@@ -393,3 +481,338 @@ def evaluate_chunks(
     mean.add(result)
   assert mean is not None
   return mean.result()
+
+
+# ---------------------------------------------------------------------------
+# Baseline substitutions (evaluation.py:165-193, 452-472, 618-675;
+# utils.py:47-70): label work on the host, the data stays where it is
+# ---------------------------------------------------------------------------
+def _index_values(ds: xl.Dataset, name: str) -> np.ndarray:
+  c = ds.coords[name]
+  return np.asarray(c.values if isinstance(c, xl.DataArray) else c)
+
+
+def _positions(have: np.ndarray, want: np.ndarray, what: str) -> np.ndarray:
+  """Positions of the labels `want` in the index `have` (KeyError like .sel)."""
+  pos = {v: i for i, v in enumerate(np.asarray(have).tolist())}
+  try:
+    flat = [pos[v] for v in np.asarray(want).ravel().tolist()]
+  except KeyError as e:
+    raise KeyError(f'not all values found in index {what!r}: {e}') from e
+  return np.array(flat, dtype=np.int64).reshape(np.shape(want))
+
+
+def _slab_source(da: xl.DataArray):
+  """(base with the two spatial dims last and C-contiguous, its outer dims,
+  index of an existing gather or None, slab dims) of a variable."""
+  import torch
+  spatial = tuple(d for d in da.dims if d in ('latitude', 'longitude'))
+  if len(spatial) != 2:
+    raise ValueError(f'{da.name}: needs latitude and longitude, has {da.dims}')
+  data, dims = da.data, tuple(da.dims)
+  if dims[-2:] != spatial:
+    moved = da.transpose(*[d for d in dims if d not in spatial], *spatial)
+    data, dims = moved.data, tuple(moved.dims)
+  if isinstance(data, xl.SlabGather):
+    return data.base, dims[:-2], data.index, spatial
+  if isinstance(data, torch.Tensor):
+    data = data if data.is_contiguous() else data.contiguous()
+  else:
+    data = np.ascontiguousarray(data)
+  return data, dims[:-2], None, spatial
+
+
+def _gather_dataset(source: xl.Dataset, names, selectors: dict, new_dims: tuple,
+                    new_shape: tuple, coords: dict) -> xl.Dataset:
+  """xarray's vectorised `source[names].sel/isel({dim: indexer})` where every
+  indexer has the dims `new_dims`: `selectors[dim]` holds POSITIONS along `dim`
+  (-1 = no such label: the hole of an outer join, NaN).  The result's dims
+  follow xarray's rule (Variable._broadcast_indexes_vectorized): walk the
+  variable's dims in order, an indexed dim contributes `new_dims` (once), any
+  other dim itself.  No data moves: every variable comes back as a SlabGather
+  over the source array."""
+  out_coords = {k: v for k, v in source.coords.items()
+                if k not in selectors and not (
+                    isinstance(v, xl.DataArray)
+                    and any(d in selectors for d in v.dims))}
+  out_coords.update(coords)
+  out = xl.Dataset(coords=out_coords, attrs=dict(source.attrs))
+  for name in names:
+    da = source[name]
+    base, outer, prior, spatial = _slab_source(da)
+    missing = [d for d in selectors if d not in outer]
+    if missing:
+      raise ValueError(f'{name}: dims {missing} to select are not in {da.dims}')
+    sizes = dict(zip(outer, (prior.shape if prior is not None
+                             else base.shape[:-2])))
+    out_dims: list = []
+    for d in outer:
+      for nd in (new_dims if d in selectors else (d,)):
+        if nd not in out_dims:
+          out_dims.append(nd)
+    out_shape = tuple(new_shape[new_dims.index(d)] if d in new_dims
+                      else sizes[d] for d in out_dims)
+    index = np.zeros(out_shape, dtype=np.int64)
+    hole = np.zeros(out_shape, dtype=bool)
+    stride = 1
+    for d in reversed(outer):
+      if d in selectors:
+        pos = np.asarray(selectors[d], dtype=np.int64)
+        shape = [1] * len(out_dims)
+        for nd, n in zip(new_dims, new_shape):
+          shape[out_dims.index(nd)] = n
+        order = [nd for nd in out_dims if nd in new_dims]
+        pos = np.transpose(pos, [new_dims.index(nd) for nd in order]
+                           ).reshape(shape)
+        hole = hole | (pos < 0)
+        index = index + np.maximum(pos, 0) * stride
+      else:
+        shape = [1] * len(out_dims)
+        shape[out_dims.index(d)] = sizes[d]
+        index = index + (np.arange(sizes[d], dtype=np.int64) * stride
+                         ).reshape(shape)
+      stride *= sizes[d]
+    if prior is not None:  # a gather of a gather: compose the tables
+      index = prior.ravel()[index]
+    index = np.where(hole, -1, index)
+    out.data_vars[name] = xl.DataArray(
+        xl.SlabGather(base, index), tuple(out_dims) + spatial, out_coords, name)
+  return out
+
+
+def _when(forecast: xl.Dataset, time_dim: str):
+  """(datetime64 values, dims, coords that travel with the indexer) of
+  `forecast[time_dim]`."""
+  c = forecast.coords[time_dim]
+  if isinstance(c, xl.DataArray):
+    values, dims = np.asarray(c.values), tuple(c.dims)
+  else:
+    values, dims = np.asarray(c), (time_dim,)
+  carried = {}
+  for k, v in forecast.coords.items():
+    vdims = tuple(v.dims) if isinstance(v, xl.DataArray) else (k,)
+    if all(d in dims for d in vdims) and (isinstance(v, xl.DataArray)
+                                          or k in dims):
+      carried[k] = v
+  return values, dims, carried
+
+
+def _dayofyear_hour(values: np.ndarray):
+  import pandas as pd
+  idx = pd.DatetimeIndex(np.asarray(values).ravel())
+  shape = np.shape(values)
+  return (np.asarray(idx.dayofyear).reshape(shape),
+          np.asarray(idx.hour).reshape(shape))
+
+
+def _climatology_variables(climatology: xl.Dataset, variables) -> dict:
+  """{forecast variable: climatology variable}: by name, else `<name>_mean`
+  (evaluation.py:633-639)."""
+  variables = list(variables)
+  if all(v in climatology for v in variables):
+    return {v: v for v in variables}
+  renamed = {v: f'{v}_mean' for v in variables}
+  absent = [k for k in renamed.values() if k not in climatology]
+  if absent:
+    raise KeyError(f'{absent} not found in the climatology')
+  return renamed
+
+
+def climatology_like_forecast(forecast, climatology, time_dim: str,
+                              variables=None, hour_if_present: bool = False):
+  """`climatology[variables].sel(dayofyear=forecast[time_dim].dt.dayofyear,
+  hour=forecast[time_dim].dt.hour)` (evaluation.py:452-460; with
+  `hour_if_present` the Beam version, :629-646, which selects `hour` only when
+  the climatology has one and falls back to `<var>_mean` names).
+
+  Zero-copy: every variable of the result is a SlabGather over the climatology
+  array (resident in HBM after `make_resident`; a host climatology crosses
+  PCIe as the distinct slabs one chunk touches)."""
+  given = (forecast, climatology)
+  forecast, climatology = xl.as_dataset(forecast), xl.as_dataset(climatology)
+  if variables is None:
+    variables = list(forecast.keys())
+  values, dims, carried = _when(forecast, time_dim)
+  doy, hour = _dayofyear_hour(values)
+  selectors = {'dayofyear': _positions(_index_values(climatology, 'dayofyear'),
+                                       doy, 'dayofyear')}
+  coords = dict(carried)
+  coords['dayofyear'] = xl.DataArray(doy, dims)
+  if not hour_if_present or 'hour' in climatology.coords:
+    selectors['hour'] = _positions(_index_values(climatology, 'hour'), hour,
+                                   'hour')
+    coords['hour'] = xl.DataArray(hour, dims)
+  if hour_if_present:
+    names = _climatology_variables(climatology, variables)
+  else:
+    for v in variables:
+      if v not in climatology:
+        raise KeyError(v)
+    names = {v: v for v in variables}
+  picked = _gather_dataset(climatology, list(names.values()), selectors, dims,
+                           np.shape(values), coords)
+  out = xl.Dataset(coords=picked.coords, attrs=picked.attrs)
+  for v, cname in names.items():
+    da = picked.data_vars[cname]
+    out.data_vars[v] = xl.DataArray(da.data, da.dims, out.coords, v)
+  return xl.like_input(out, *given)
+
+
+def make_probabilistic_climatology(ds, start_year: int, end_year: int,
+                                   hour_interval: int, variables=None):
+  """utils.py:47-70: the years of `ds` stacked as ensemble members -- dims
+  (hour, number, dayofyear, ...), day 366 (and any other missing time stamp)
+  NaN.  Nothing is copied: member `number` of (hour, dayofyear) is the time
+  step of `ds` with that (year, dayofyear, hour), kept as a SlabGather index
+  over `ds`'s own array, -1 where the year has no such step."""
+  import pandas as pd
+  given = ds
+  ds = xl.as_dataset(ds)
+  hours = np.arange(0, 24, hour_interval)
+  years = np.arange(start_year, end_year + 1)
+  times = pd.DatetimeIndex(_index_values(ds, 'time'))
+  t_year, t_doy, t_hour = (np.asarray(times.year), np.asarray(times.dayofyear),
+                           np.asarray(times.hour))
+  for year in years:  # `.sel(time=str(year))` of a year without data: KeyError
+    if not (t_year == year).any():
+      raise KeyError(str(year))
+  used = np.isin(t_hour, hours) & np.isin(t_year, years)
+  doys = np.unique(t_doy[used])  # concat's outer join: the sorted union
+  where = np.full((len(hours), len(years), len(doys)), -1, dtype=np.int64)
+  hi = np.searchsorted(hours, t_hour[used])
+  yi = t_year[used] - start_year
+  di = np.searchsorted(doys, t_doy[used])
+  if len(np.unique(np.stack([hi, yi, di]), axis=1)[0]) != used.sum():
+    raise ValueError('several time steps share one (year, dayofyear, hour): '
+                     'the probabilistic climatology needs at most hourly data')
+  where[hi, yi, di] = np.nonzero(used)[0]
+  names = [k for k in (variables or ds.keys())]
+  for k in names:
+    if 'time' not in ds[k].dims:
+      raise ValueError(f'{k} has no time dim: {ds[k].dims}')
+  coords = {'hour': hours, 'number': np.arange(len(years)), 'dayofyear': doys}
+  out = _gather_dataset(ds, names, {'time': where},
+                        ('hour', 'number', 'dayofyear'), where.shape, coords)
+  return xl.like_input(out, given)
+
+
+def create_persistence_forecast(forecast, obs):
+  """evaluation.py:165-193 (by-valid layout: `forecast.init_time` is a
+  coordinate over (time, lead_time)): the observation at the initialisation
+  time of every (time, lead_time), for the times at least the longest lead time
+  after the first one.  A gather from `obs` by time label."""
+  given = (forecast, obs)
+  forecast, obs = xl.as_dataset(forecast), xl.as_dataset(obs)
+  logging.warning('by-valid with evaluate_persistence is not 100% correct.')
+  init = forecast.coords['init_time']
+  if not isinstance(init, xl.DataArray) or 'time' not in init.dims:
+    raise AttributeError(
+        "forecast.init_time has no 'time' dim: create_persistence_forecast is "
+        'for the by-valid layout (evaluation.py:184-187); by-init chunks use '
+        '_persistence_like_forecast_chunk')
+  init = init.transpose('time', *[d for d in init.dims if d != 'time'])
+  time = _index_values(forecast, 'time')
+  lead_dims = tuple(d for d in init.dims if d != 'time')
+  lead_max = max(np.max(_index_values(forecast, d)) for d in lead_dims)
+  keep = time >= time[0] + lead_max  # label slice(start, None), ascending time
+  init_values = np.asarray(init.values)[keep]
+  where = _positions(_index_values(obs, 'time'), init_values, 'time')
+  coords = {'time': time[keep]}
+  for d in lead_dims:
+    coords[d] = _index_values(forecast, d)
+  coords['init_time'] = xl.DataArray(init_values, init.dims)
+  names = [k for k in obs.keys() if 'time' in obs[k].dims]
+  out = _gather_dataset(obs, names, {'time': where}, tuple(init.dims),
+                        init_values.shape, coords)
+  for k in obs.keys():  # variables without a time dim pass through (.sel)
+    if k not in names:
+      out.data_vars[k] = obs[k]
+  return xl.like_input(out, *given)
+
+
+def _lead_dim(forecast: xl.Dataset) -> str:
+  return 'lead_time' if 'lead_time' in forecast.dims or (
+      'lead_time' in forecast.coords) else 'prediction_timedelta'
+
+
+def _persistence_like_forecast_chunk(forecast_chunk, truth_chunk, truth,
+                                     variables=None, by_init: bool = True):
+  """evaluation.py:651-675: `truth.sel(time=init_time)` with the chunk's
+  lead_time dim and valid_time coordinate -- every lead of an init time reads
+  the SAME truth slab (a slab table with repeats, no expand / copy)."""
+  if truth is None:
+    raise ValueError('`truth` must not be `None`')
+  if not by_init:
+    raise NotImplementedError('Persistence not compatible with by-valid format.')
+  given = (forecast_chunk, truth)
+  forecast_chunk, truth = xl.as_dataset(forecast_chunk), xl.as_dataset(truth)
+  lead_dim = _lead_dim(forecast_chunk)
+  init = _index_values(forecast_chunk, 'init_time')
+  lead = _index_values(forecast_chunk, lead_dim)
+  pos = _positions(_index_values(truth, 'time'), init, 'time')
+  where = np.broadcast_to(pos[None, :], (len(lead), len(init)))
+  coords = {lead_dim: lead, 'init_time': init}
+  if 'valid_time' in forecast_chunk.coords:
+    coords['valid_time'] = forecast_chunk.coords['valid_time']
+  names = [k for k in (variables or truth.keys()) if 'time' in truth[k].dims]
+  # expand_dims puts the new dim first: (lead_time, init_time, ...)
+  out = _gather_dataset(truth, names, {'time': where}, (lead_dim, 'init_time'),
+                        where.shape, coords)
+  return xl.like_input(out, *given), truth_chunk
+
+
+def _climatology_like_forecast_chunk(forecast_chunk, truth_chunk, climatology,
+                                     variables=None, by_init: bool = True):
+  """evaluation.py:618-649."""
+  time_dim = 'valid_time' if by_init else 'time'
+  if variables is None:
+    variables = list(xl.as_dataset(truth_chunk).keys())
+  return (climatology_like_forecast(forecast_chunk, climatology, time_dim,
+                                    variables, hour_if_present=True),
+          truth_chunk)
+
+
+def _evaluate_all_metrics(eval_name: str, eval_config: config.Eval,
+                          data_config, skipna: bool, *, forecast, truth,
+                          climatology=None) -> xl.Dataset:
+  """Evaluate a set of eval metrics in memory (evaluation.py:441-483).
+
+  The reference opens `forecast, truth, climatology` from `data_config.paths`
+  and writes a NetCDF file; here they are arguments (already opened, with the
+  reference's time conventions applied: init_time / lead_time / valid_time for
+  by-init data) and the merged result is returned -- IO is out of scope.
+  Everything between is the reference's sequence: the baseline substitutions
+  selected by `eval_config` (as zero-copy gathers), `truth.sel(time=
+  forecast.valid_time)` for by-init data, then the metric x region loop."""
+  del eval_name  # names the output file in the reference
+  given = (forecast, truth)
+  forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
+  by_init = bool(getattr(data_config, 'by_init', True))
+  time_dim = 'valid_time' if by_init else 'time'
+  if eval_config.evaluate_climatology:
+    if climatology is None:
+      raise ValueError('evaluate_climatology needs a climatology dataset')
+    forecast = climatology_like_forecast(forecast, climatology, time_dim)
+  if eval_config.evaluate_probabilistic_climatology:
+    probabilistic_climatology = make_probabilistic_climatology(
+        truth, eval_config.probabilistic_climatology_start_year,
+        eval_config.probabilistic_climatology_end_year,
+        eval_config.probabilistic_climatology_hour_interval,
+        variables=list(forecast.keys()))
+    forecast = climatology_like_forecast(forecast, probabilistic_climatology,
+                                         time_dim)
+  if eval_config.evaluate_persistence:
+    if by_init:
+      # the reference's in-memory driver raises AttributeError here (:184-187
+      # expect the by-valid init_time coordinate); its Beam driver defines
+      # by-init persistence (:651-675) and that is what runs
+      forecast, _ = _persistence_like_forecast_chunk(
+          forecast, truth, truth, list(forecast.keys()), by_init=True)
+    else:
+      forecast = create_persistence_forecast(forecast, truth)
+  forecast = xl.as_dataset(forecast)
+  if by_init:
+    truth = select_truth_at_valid_time(truth, forecast,
+                                       lead_dim=_lead_dim(forecast))
+  results = _metric_and_region_loop(forecast, truth, eval_config, skipna=skipna)
+  return xl.like_input(xl.as_dataset(results), *given)

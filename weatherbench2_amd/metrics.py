@@ -86,6 +86,9 @@ def chunk_scope():
     if st.depth == 0:
       st.scoped.clear()
       st.memo.clear()
+      # results leave the pass here: a worker thread's private stream is made
+      # visible to the default stream (engine._adopt_thread_stream)
+      engine.publish_thread_stream()
 
 
 def _field_key(region):
@@ -304,14 +307,24 @@ def _stamp(a) -> tuple:
   dataset_safe_lru_cache compares whole arrays too, utils.py:322-350)."""
   if isinstance(a, torch.Tensor):
     return (id(a), a._version, a.data_ptr())
+  if isinstance(a, xl.SlabGather):
+    # a gather is what it reads: the index and the base (a host base is hashed
+    # over the slabs the gather touches only -- _to_device compacts it first)
+    base = a.base
+    if isinstance(base, np.ndarray) and _ANNOUNCED.depth == 0:
+      small, _ = a.compact_host()
+      base_stamp = ('gathered', _stamp(small)[-1])
+    else:
+      base_stamp = _stamp(base)
+    return ('gather', base_stamp, a.index.shape, engine.digest(a.index))
   if isinstance(a, np.ndarray):
     ident = (id(a), a.__array_interface__['data'][0], a.shape, a.strides,
              a.dtype.str)
     if _ANNOUNCED.depth > 0 or a.size == 0:
       return ident
-    import xxhash
-    buf = a if a.flags.c_contiguous else np.ascontiguousarray(a)
-    return ident + (xxhash.xxh3_64_intdigest(buf.reshape(-1).view(np.uint8)),)
+    if a.dtype.kind not in 'biufc':  # object / string arrays: never cached
+      return ident + (object(),)
+    return ident + (engine.digest(a),)
   return (id(a),)
 
 
@@ -343,9 +356,31 @@ def _coord_sig(*datasets) -> tuple:
   return tuple(out)
 
 
-def _to_device(data, device) -> torch.Tensor:
+_BIG_UPLOAD_BYTES = 2 << 30
+
+
+def _to_device(data, device, allow_gather: bool = False):
+  """`data` on `device`.  A SlabGather stays a gather (over a device base)
+  when the caller can read through slab tables (`allow_gather`), otherwise it is
+  materialised on the device; a host base crosses PCIe as the DISTINCT slabs
+  the gather touches, never as the whole array."""
   if isinstance(data, torch.Tensor) and data.device == device:
     return data
+  if isinstance(data, xl.SlabGather):
+    base, index = data.base, data.index
+    if isinstance(base, np.ndarray):
+      base, index = data.compact_host()
+    dev_base = _to_device(base, device)
+    gathered = xl.SlabGather(dev_base, index)
+    if allow_gather and not gathered.has_missing:
+      return gathered
+    return gathered.materialize()
+  if isinstance(data, np.ndarray) and data.nbytes >= _BIG_UPLOAD_BYTES:
+    import warnings
+    warnings.warn(
+        f'uploading a {data.nbytes / 2**30:.1f} GiB host array for one chunk; '
+        'inputs that recur across chunks (climatology, truth) are better made '
+        'resident once (evaluation.make_resident)', stacklevel=3)
   key = _stamp(data)
   hit = _DEVICE.get(key)
   if hit is not None:
@@ -385,6 +420,8 @@ def _spatial_last(da: xl.DataArray, layout: t.Optional[str]):
     return da.data, rest, layout
   moved = da.transpose(*rest, *want)
   data = moved.data
+  if isinstance(data, xl.SlabGather):
+    data = data.materialize_host()
   data = data.contiguous() if isinstance(data, torch.Tensor) else (
       np.ascontiguousarray(data))
   return data, rest, layout
@@ -565,6 +602,10 @@ def _physical_slabs(x: torch.Tensor, table, n_row: int, n_col: int):
   select_truth_at_valid_time --, `expand`ed broadcasts, slices with a step) is
   handed over as it is: the table is rewritten to physical slab offsets from
   the view's strides, so the selection costs no copy at all."""
+  if isinstance(x, xl.SlabGather):
+    index = x.index.ravel()
+    return (x.base.reshape(-1, n_row, n_col),
+            index if table is None else index[table])
   if x.is_contiguous():
     return x.reshape(-1, n_row, n_col), table
   se = n_row * n_col
@@ -593,13 +634,29 @@ def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
   pl = plan_lib.cached_plan(
       geo.latitude, geo.longitude, geo.layout, regions, device,
       plan_lib.auto_rows_per_chunk(n_row, geo.n_outer))
-  tensors = [_to_device(a, device) for a in arrays]
-  dtype = torch.result_type(tensors[0], tensors[1])
-  for x in tensors[2:]:
+  arrays, tables = list(arrays), list(tables)
+  for i, (a, tb) in enumerate(zip(arrays, tables)):
+    # a host array read through a table that touches only some of its slabs (a
+    # climatology gathered by dayofyear / hour): only those cross PCIe
+    if isinstance(a, np.ndarray) and tb is not None and a.ndim >= 2 and (
+        a.flags.c_contiguous):
+      n_slab = a.size // max(a.shape[-1] * a.shape[-2], 1)
+      if len(np.unique(tb)) < n_slab:
+        arrays[i], tables[i] = xl.SlabGather(a, tb), None
+  tensors = [_to_device(a, device, allow_gather=True) for a in arrays]
+  dtype = tensors[0].dtype
+  for x in tensors[1:]:
     dtype = torch.promote_types(dtype, x.dtype)
   if dtype not in (torch.float32, torch.float64):
     dtype = torch.float64
-  tensors = [x if x.dtype == dtype else x.to(dtype) for x in tensors]
+
+  def cast(x):
+    if x.dtype == dtype:
+      return x
+    if isinstance(x, xl.SlabGather):  # never convert a whole resident base
+      x = x.materialize()
+    return x.to(dtype)
+  tensors = [cast(x) for x in tensors]
   for x in tensors:
     _check_grid(geo, x)
   flat, tables = zip(*[_physical_slabs(x, tb, pl.n_row, pl.n_col)
@@ -743,14 +800,78 @@ def _assemble(forecast, per_var: dict,
   out = xl.Dataset()
   if regions is not None:
     out.coords['region'] = np.array(list(regions), dtype=object)
-  for name, (dims, arr) in per_var.items():
-    out.coords.update(_result_coords(forecast, dims))
-  for name, (dims, arr) in per_var.items():
+  for name, entry in per_var.items():
+    out.coords.update(_result_coords(forecast, entry[0]))
+  for name, entry in per_var.items():
+    dims, arr = entry[0], entry[1]
+    # third entry: the dtype the reference's weighted mean returns for this
+    # variable (_reference_result_dtype); float64 when not given
+    dtype = np.dtype(entry[2]) if len(entry) > 2 else np.dtype(np.float64)
     if isinstance(arr, torch.Tensor):
-      data = arr.to(torch.float64)
+      data = arr.to(torch.float32 if dtype == np.float32 else torch.float64)
     else:
-      data = np.array(arr, dtype=np.float64)
+      data = np.array(arr, dtype=dtype)
     out.data_vars[name] = xl.DataArray(data, dims, out.coords, name)
+  return out
+
+
+def _np_dtype(x) -> np.dtype:
+  """NumPy dtype of a numpy / torch / SlabGather array."""
+  dt = x.dtype
+  if isinstance(dt, torch.dtype):
+    return np.dtype(str(dt).replace('torch.', ''))
+  return np.dtype(dt)
+
+
+def _region_weight_dtype(w: np.dtype, region) -> np.dtype:
+  """dtype of the weights after `region.apply` (regions.py:56-158): slices keep
+  it, the extra-tropical mask and a thresholded land-sea mask are
+  `.astype(float)` fields (float64), an unthresholded land-sea mask brings its
+  own dtype, a combined region applies its parts in turn."""
+  if region is None:
+    return w
+  kind = type(region).__name__
+  if kind == 'SliceRegion':
+    return w
+  if kind == 'LandRegion':
+    if getattr(region, 'threshold', None) is not None:
+      return np.promote_types(w, np.float64)
+    mask = getattr(region.land_sea_mask, 'data', region.land_sea_mask)
+    return np.promote_types(w, _np_dtype(mask))
+  if kind == 'CombinedRegion':
+    for r in region.regions:
+      w = _region_weight_dtype(w, r)
+    return w
+  return np.promote_types(w, np.float64)  # ExtraTropicalRegion, foreign regions
+
+
+def _reference_result_dtype(forecast: xl.Dataset, data_dtypes, region,
+                            regions: t.Optional[dict]) -> np.dtype:
+  """The dtype `_spatial_average` returns in the reference (metrics.py:141-163):
+  xarray's weighted mean is `dot(data, weights) / dot(notnull, weights)`, both
+  in promote(data dtype, weights dtype), and the weights inherit the dtype of
+  the LATITUDE COORDINATE (metrics.py:41, 57) unless a mask region multiplies a
+  float64 field in.  So float32 data on a grid with float32 coordinates (0.25
+  degree ERA5) comes back float32 for slice regions and float64 for mask
+  regions; with float64 coordinates everything is float64.  A loop over several
+  regions concatenates along `region` (evaluation.py:430): NumPy promotion over
+  the regions' dtypes.  The VALUES here are the float64 sums of the fused pass
+  rounded once to that dtype (the reference's float32 einsum carries ~1e-5 of
+  summation noise at 10^6 points)."""
+  w = np.sin(np.deg2rad(_coord_values(forecast, 'latitude')[:1])).dtype
+  data = np.dtype(np.float32)
+  first = True
+  for dt in data_dtypes:
+    data = dt if first else np.promote_types(data, dt)
+    first = False
+  if data.kind not in 'f':
+    data = np.promote_types(data, np.float32)
+  out = None
+  for r in (regions.values() if regions is not None else [region]):
+    dt = np.promote_types(data, _region_weight_dtype(w, r))
+    out = dt if out is None else np.promote_types(out, dt)
+  if out not in (np.dtype(np.float32), np.dtype(np.float64)):
+    out = np.dtype(np.float64)
   return out
 
 
@@ -778,8 +899,10 @@ def _returns_like_input(fn):
   calls between metrics pass lite Datasets and skip the conversion."""
   @functools.wraps(fn)
   def wrapper(self, forecast, truth, *args, **kwargs):
-    return xl.like_input(fn(self, forecast, truth, *args, **kwargs), forecast,
-                         truth)
+    result = fn(self, forecast, truth, *args, **kwargs)
+    if _ANNOUNCED.depth == 0:  # a bare call outside any chunk scope
+      engine.publish_thread_stream()
+    return xl.like_input(result, forecast, truth)
   wrapper._wb2_like_input = True
   return wrapper
 
@@ -866,7 +989,9 @@ class _DetMetric(Metric):
             lambda r, name=name: _det_pass(forecast, truth, name, r, skipna),
             region, regions)
         lead, values = _pick(by_region, region, self._index, regions)
-        per_var[name] = (lead + geo.out_dims, values)
+        per_var[name] = (lead + geo.out_dims, values, _reference_result_dtype(
+            forecast, [_np_dtype(forecast[name].data),
+                       _np_dtype(truth[name].data)], region, regions))
     return _assemble(forecast, per_var, regions)
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
@@ -912,8 +1037,11 @@ class WindVectorMSE(Metric):
           lambda r: _wind_pass(forecast, truth, self.u_name, self.v_name, r,
                                skipna), region, regions)
       lead, values = _pick(by_region, region, self._index, regions)
+    dtype = _reference_result_dtype(
+        forecast, [_np_dtype(ds[k].data) for ds in (forecast, truth)
+                   for k in (self.u_name, self.v_name)], region, regions)
     return _assemble(forecast, {self.vector_name: (lead + geo.out_dims,
-                                                   values)}, regions)
+                                                   values, dtype)}, regions)
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
     return self.compute_chunk(forecast, truth, None, skipna, regions)
@@ -1031,7 +1159,11 @@ class ACC(Metric):
                                            climatology), region, regions)
         lead, values = _pick(by_region, region, _lib.METRIC_INDEX['acc'],
                              regions)
-        per_var[name] = (lead + geo.out_dims, values)
+        cvar = _get_climatology_chunk(climatology, truth)[name]
+        per_var[name] = (lead + geo.out_dims, values, _reference_result_dtype(
+            forecast, [_np_dtype(forecast[name].data),
+                       _np_dtype(truth[name].data), _np_dtype(cvar.data)],
+            region, regions))
     return _assemble(forecast, per_var, regions)
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):

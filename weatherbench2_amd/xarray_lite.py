@@ -28,11 +28,126 @@ def _is_torch(x) -> bool:
   return type(x).__module__.startswith('torch')
 
 
+class SlabGather:
+  """A gather that has not happened: element [o..., r, c] of the array is
+  `base[index[o...], r, c]`.
+
+  `base` is a C-contiguous numpy array or torch tensor whose last two dims are
+  one 2-D slab (n_row, n_col) and whose leading dims, flattened, number the
+  slabs; `index` is an int64 numpy array over the OUTER dims of the gathered
+  array, -1 marking a slab that does not exist (NaN-filled, like the holes of
+  an xarray outer join).  This is how `forecast := climatology.sel(dayofyear,
+  hour)` (evaluation.py:452-460), the persistence forecast (:165-193, 651-675)
+  and the probabilistic climatology (utils.py:47-70) are handed to the fused
+  passes without copying anything: the deterministic passes read the base
+  through `index` as their slab table (metrics._physical_slabs); every other
+  consumer materialises (`materialize` on the device, `__array__` on the
+  host) and is merely correct."""
+
+  def __init__(self, base, index):
+    index = np.asarray(index, dtype=np.int64)
+    if base.ndim < 2:
+      raise ValueError('base needs (n_row, n_col) as its last two dims')
+    self.base = base
+    self.index = index
+    self.slab_shape = tuple(int(n) for n in base.shape[-2:])
+    n_slab = 1
+    for n in base.shape[:-2]:
+      n_slab *= int(n)
+    self.n_slab = n_slab
+    if index.size and (index.max() >= n_slab or index.min() < -1):
+      raise IndexError(f'slab index out of range [-1, {n_slab})')
+
+  @property
+  def shape(self):
+    return tuple(self.index.shape) + self.slab_shape
+
+  @property
+  def ndim(self):
+    return self.index.ndim + 2
+
+  @property
+  def dtype(self):
+    return self.base.dtype
+
+  @property
+  def has_missing(self) -> bool:
+    return bool(self.index.size) and bool((self.index < 0).any())
+
+  def __repr__(self):
+    return (f'<wb2hip.SlabGather shape={self.shape} dtype={self.dtype} of '
+            f'{self.n_slab} slabs>')
+
+  def _flat_base(self):
+    return self.base.reshape((self.n_slab,) + self.slab_shape)
+
+  def __getitem__(self, key):
+    """Indexing of the outer dims (the two slab dims must be kept whole)."""
+    if not isinstance(key, tuple):
+      key = (key,)
+    outer = key[:self.index.ndim]
+    rest = key[self.index.ndim:]
+    if any(not (isinstance(k, slice) and k == slice(None)) for k in rest):
+      return np.asarray(self)[key]
+    return SlabGather(self.base, self.index[outer])
+
+  def permute_outer(self, perm):
+    return SlabGather(self.base, np.transpose(self.index, perm))
+
+  def materialize_host(self) -> np.ndarray:
+    flat = self._flat_base()
+    if _is_torch(flat):
+      return self.materialize().cpu().numpy()
+    idx = self.index.ravel()
+    out = np.take(flat, np.maximum(idx, 0), axis=0)
+    if (idx < 0).any():
+      if out.dtype.kind != 'f':
+        out = out.astype(np.float64)
+      out[idx < 0] = np.nan
+    return out.reshape(self.shape)
+
+  def __array__(self, dtype=None, copy=None):
+    out = self.materialize_host()
+    return out if dtype is None else out.astype(dtype, copy=False)
+
+  def materialize(self, device=None):
+    """The gathered array as a torch tensor (one index_select where the base
+    lives; host bases gather on the host first, so only the needed slabs cross
+    PCIe)."""
+    import torch
+    flat = self._flat_base()
+    if not _is_torch(flat):
+      host = self.materialize_host()
+      if device is None:
+        return torch.from_numpy(host)
+      from weatherbench2_amd import engine
+      return engine.as_device_tensor(host, torch.device(device))
+    idx = torch.as_tensor(np.maximum(self.index.ravel(), 0), device=flat.device)
+    out = torch.index_select(flat, 0, idx)
+    missing = self.index.ravel() < 0
+    if missing.any():
+      if not out.dtype.is_floating_point:
+        out = out.to(torch.float64)
+      out[torch.as_tensor(missing, device=flat.device)] = float('nan')
+    out = out.reshape(self.shape)
+    return out if device is None else out.to(device)
+
+  def compact_host(self):
+    """(array of the DISTINCT slabs referenced, index into it) for a host
+    base: what has to cross PCIe."""
+    idx = self.index.ravel()
+    uniq, inv = np.unique(idx[idx >= 0], return_inverse=True)
+    new_index = np.full(idx.shape, -1, dtype=np.int64)
+    new_index[idx >= 0] = inv
+    small = np.take(self._flat_base(), uniq, axis=0)
+    return small, new_index.reshape(self.index.shape)
+
+
 class DataArray:
   """N-d array with named dims and (1-D, per-dim) coordinates."""
 
   def __init__(self, data, dims: t.Sequence[str] = (), coords=None, name=None):
-    if not _is_torch(data):
+    if not _is_torch(data) and not isinstance(data, SlabGather):
       data = np.asarray(data)
     self.data = data
     self.dims = tuple(dims)
@@ -60,7 +175,13 @@ class DataArray:
   @property
   def values(self) -> np.ndarray:
     if _is_torch(self.data):
+      # a result produced on another thread's stream has been published to the
+      # default stream; a reader on a private stream waits for that first
+      from weatherbench2_amd import engine
+      engine.order_read(self.data)
       return self.data.detach().cpu().numpy()
+    if isinstance(self.data, SlabGather):
+      return self.data.materialize_host()
     return self.data
 
   def copy(self, data=None):
@@ -76,7 +197,13 @@ class DataArray:
 
   def transpose(self, *dims):
     perm = [self.dims.index(d) for d in dims]
-    if _is_torch(self.data):
+    if isinstance(self.data, SlabGather):
+      n = self.data.index.ndim
+      if perm[n:] == [n, n + 1]:  # the slab dims stay where they are
+        data = self.data.permute_outer(perm[:n])
+      else:
+        data = np.transpose(self.data.materialize_host(), perm)
+    elif _is_torch(self.data):
       data = self.data.permute(*perm)
     else:
       data = np.transpose(self.data, perm)
@@ -335,12 +462,18 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
     shape[ax] = len(labels)
     holders = [d.data_vars[name] for d in datasets if name in d.data_vars]
     on_device = all(_is_torch(v.data) for v in holders)
+    # NumPy promotion over the operands (float32 results stay float32 when
+    # every metric returned float32, like xarray's merge)
+    as_np = lambda dt: np.dtype(str(dt).replace('torch.', ''))
+    dtype = np.result_type(*[as_np(v.dtype) for v in holders])
+    if dtype.kind != 'f':
+      dtype = np.dtype(np.float64)  # the NaN fill needs a float
     if on_device:  # map-valued results: merge where they live
       import torch
-      data = torch.full(shape, float('nan'), dtype=torch.float64,
+      data = torch.full(shape, float('nan'), dtype=getattr(torch, dtype.name),
                         device=ref.data.device)
     else:
-      data = np.full(shape, np.nan, dtype=np.float64)
+      data = np.full(shape, np.nan, dtype=dtype)
     for d in datasets:
       if name not in d.data_vars:
         continue
