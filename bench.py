@@ -23,11 +23,27 @@ scaling curve); the same JSON line carries, measured in the same process:
                   K3) suites over the same number of units per step, sharded
                   the same way, both [sum, count] sets all-reduced;
   map_allreduce   N > 1: the bandwidth-relevant all-reduce of Spatial* maps;
-  api             N = 1: the same 16-unit chunk through the drop-in API
+and on one GPU (N = 1), each with its own `roofline`:
+  ensemble        BASELINE configs[2]: the standalone 50-member K3 launch;
+  spectrum        BASELINE configs[3]: zonal spectrum + latitude mean fused
+                  (LATSEG + combine), with the sub-legs `materialized`
+                  (ZonalEnergySpectrum.compute) and `time_mean` (the script's
+                  pipeline);
+  variants        K1's production instantiations: the official 16 regions
+                  incl. three land-sea-mask regions, skipna, float64 inputs,
+                  wind vectors, the lon-lat layout, no ACC;
+  api             the same 16-unit chunk through the drop-in API
                   (_metric_and_region_loop, 5 metrics x 13 regions);
-  pcie_inclusive  N = 1, --pcie: inputs arriving from pinned host memory
-                  through the pipelined feeder (never `value`);
-  cpu_baseline    N = 1: the NumPy oracle on this box's host cores.
+  pcie_inclusive  inputs arriving from pinned host memory through the
+                  pipelined feeder (never `value`);
+  cpu_baseline    the NumPy oracle on this box's host cores;
+and `roofline.traffic` is collected LIVE: rocprofv3 --pmc FETCH_SIZE /
+WRITE_SIZE around the benched K1 launch (tools/live_traffic.py; --no-pmc
+skips it and quotes profiles/ instead).
+
+`--total-units N` switches to STRONG scaling (BASELINE configs[4] literally:
+2920 units, contiguous shards over the ranks, K = the steps of the largest
+shard).
 
 Prints ONE JSON line (rank 0).
 """
@@ -224,9 +240,27 @@ def parse_args():
   ap.add_argument('--no-api', action='store_true',
                   help='skip the drop-in API leg (N = 1 only)')
   ap.add_argument('--pcie', action='store_true',
-                  help='also time the step with its inputs arriving from '
-                       'pinned host memory (reported as pcie_inclusive, never '
-                       'as value)')
+                  help='(kept for compatibility: the pcie_inclusive leg is part '
+                       'of the default N = 1 line now)')
+  ap.add_argument('--no-pcie', action='store_true',
+                  help='skip the pcie_inclusive leg (N = 1 only)')
+  ap.add_argument('--no-secondary', action='store_true',
+                  help='skip the ensemble / spectrum / variants legs (N = 1)')
+  ap.add_argument('--no-pmc', action='store_true',
+                  help='do not collect roofline.traffic live with rocprofv3 '
+                       '(N = 1 only; the profiles/ figure is quoted instead)')
+  ap.add_argument('--total-units', type=int, default=0,
+                  help='STRONG scaling: this many (init, lead) units in total '
+                       '(BASELINE configs[4]: 2920), sharded contiguously over '
+                       'the ranks (evaluation.shard_bounds); --steps is then '
+                       'derived (the steps of the largest shard)')
+  ap.add_argument('--launch-timeout', type=float, default=900.0,
+                  help='seconds after which a self-launched job (and the '
+                       'rendezvous / collectives of every rank) gives up '
+                       'instead of hanging')
+  ap.add_argument('--traffic-probe', action='store_true',
+                  help='(tools/live_traffic.py) only run a few launches of the '
+                       'benched K1 configuration, for the PMC passes')
   ap.add_argument('--workload', default='deterministic',
                   choices=['deterministic', 'ensemble', 'spectrum',
                            'spectrum_materialized', 'spectrum_mean'],
@@ -266,11 +300,17 @@ def self_launch(args) -> int:
       target=lambda: out_box.append(procs[0].stdout.read()), daemon=True)
   reader.start()
   rc = 0
+  deadline = time.monotonic() + args.launch_timeout
   while True:
     codes = [pr.poll() for pr in procs]
     failed = [c for c in codes if c not in (None, 0)]
-    if failed:
-      rc = failed[0]
+    if failed or time.monotonic() > deadline:
+      # a dead rank (or a rendezvous / collective that never completes) must
+      # not hang the caller: take the whole job down
+      rc = failed[0] if failed else 124
+      if not failed:
+        print(f'bench.py: ranks still running after {args.launch_timeout:.0f} s '
+              '(--launch-timeout): killing the job', file=sys.stderr)
       for pr in procs:
         if pr.poll() is None:
           pr.kill()
@@ -289,7 +329,10 @@ def self_launch(args) -> int:
 def main():
   args = parse_args()
   if args.workload != 'deterministic':
-    return secondary(args)
+    print(json.dumps(secondary(args.workload, args.steps, args.warmup,
+                               args.ramp_ms, args.members,
+                               args.rows_per_chunk)))
+    return
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     sys.exit(self_launch(args))
 
@@ -314,11 +357,18 @@ def main():
   # calls of the N > 1 path then run on a 1-GPU box too
   ddp = world > 1 or ('WORLD_SIZE' in os.environ and 'MASTER_PORT' in os.environ)
   if ddp:
+    import datetime
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    # rendezvous and every collective give up after --launch-timeout instead of
+    # waiting forever for a rank that died
+    limit = datetime.timedelta(seconds=args.launch_timeout)
     if backend == 'nccl':
-      dist.init_process_group('nccl', device_id=dev)
+      dist.init_process_group('nccl', device_id=dev, timeout=limit)
     else:
-      dist.init_process_group(backend)
+      dist.init_process_group(backend, timeout=limit)
+    if dist.get_world_size() != args.gpus:
+      raise SystemExit(f'--gpus {args.gpus} but the process group has '
+                       f'{dist.get_world_size()} ranks')
 
   def all_reduce(tensor, op=None):
     op = op or dist.ReduceOp.SUM
@@ -342,6 +392,24 @@ def main():
   units, pool = args.units, max(args.pool, args.units)
   if not args.rows_per_chunk:
     args.rows_per_chunk = plan_lib.auto_rows_per_chunk(N_LAT, units * N_LEV)
+  # STRONG scaling (--total-units): this rank's contiguous shard of the units,
+  # `units` per step, the last step partial; K = the steps of the largest shard
+  strong = args.total_units > 0
+  unit_lo, n_mine = 0, None
+  if strong:
+    from weatherbench2_amd.evaluation import shard_bounds
+    if args.total_units < world:
+      raise SystemExit(f'--total-units {args.total_units} < {world} ranks')
+    unit_lo, unit_hi = shard_bounds(args.total_units, world, rank)
+    n_mine = unit_hi - unit_lo
+    largest = shard_bounds(args.total_units, world, 0)
+    args.steps = -(-(largest[1] - largest[0]) // units)
+
+  def units_of_step(i):
+    """Units the timed step i handles on this rank."""
+    if not strong:
+      return units
+    return max(0, min(units, n_mine - i * units))
   regions = predefined_regions()
   pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev,
                            rows_per_chunk=args.rows_per_chunk)
@@ -355,26 +423,31 @@ def main():
   count = torch.zeros_like(total)
   lev = torch.arange(N_LEV, device=dev, dtype=torch.int64)
 
-  def tables(step):
-    """Slab tables of this step: forecast units are consecutive pool entries,
+  def tables(first_unit, n_units):
+    """Slab tables of one step: forecast units are consecutive pool entries,
     truth / climatology are gathered through (different) offsets."""
-    u = (step * units + torch.arange(units, device=dev)) % pool
+    u = (first_unit + torch.arange(n_units, device=dev)) % pool
     fu = (u[:, None] * N_LEV + lev[None]).reshape(-1)
     tu = (((u + 7) % pool)[:, None] * N_LEV + lev[None]).reshape(-1)
     cu = (((u * 5 + 3) % pool)[:, None] * N_LEV + lev[None]).reshape(-1)
     return fu.contiguous(), tu.contiguous(), cu.contiguous()
 
-  all_tables = [tables(s) for s in range(args.warmup + args.steps)]
+  # warmup steps are always full; timed step i covers units_of_step(i)
+  all_tables = [(tables(s * units, units), units) for s in range(args.warmup)]
+  all_tables += [(tables(unit_lo + (args.warmup + s) * units, units_of_step(s)),
+                  units_of_step(s)) for s in range(args.steps)]
   k1_timer = KernelTimer()
 
   def step(i, timed):
-    fu, tu, cu = all_tables[i]
-    engine.set_launch_hook(k1_timer if timed else None)
+    (fu, tu, cu), n_u = all_tables[i]
+    if n_u == 0:  # strong scaling: this rank's shard is already done
+      return
+    engine.set_launch_hook(k1_timer if timed and n_u == units else None)
     metrics, _ = engine.stream_reduce(
-        pl, _lib.MODE_DET_ACC, [fpool, tpool, cpool], [fu, tu, cu], n_outer,
+        pl, _lib.MODE_DET_ACC, [fpool, tpool, cpool], [fu, tu, cu], n_u * N_LEV,
         skipna=False)
     # running init-time mean: (metric*region, unit, level)
-    engine.time_accumulate(metrics.view(_lib.NMETRIC * nr, units, N_LEV), 1,
+    engine.time_accumulate(metrics.view(_lib.NMETRIC * nr, n_u, N_LEV), 1,
                            False, total, count)
 
   # Touch every op of the timed region once: on a cold box the first use of a
@@ -384,6 +457,13 @@ def main():
   _ = (total / count).sum().item()
   if ddp:
     all_reduce(torch.cat([total.reshape(-1), count.reshape(-1)]))
+  if args.traffic_probe:
+    # tools/live_traffic.py: a few launches of exactly the benched K1
+    # configuration under rocprofv3 --pmc, nothing else
+    for i in range(6):
+      step(args.warmup + i % max(args.steps, 1), False)
+    torch.cuda.synchronize()
+    return
 
   def timed_region(step_fn, n_steps, accumulators):
     """The contract's bracket: barrier + synchronize on both sides, exactly
@@ -441,20 +521,24 @@ def main():
   k1_avg_s = float(np.mean(k1_ms)) / 1e3
   pts_step = units * PTS_PER_UNIT
   achieved = pts_step * BYTES_PER_PT / k1_avg_s / 1e9
+  job_pts = (args.total_units * PTS_PER_UNIT if strong
+             else world * pts_step * args.steps)
   out = {
       'metric': 'grid-point-evals/sec (721x1440x13)',
-      'value': world * pts_step * args.steps / dt,
+      'value': job_pts / dt,
       'unit': 'grid-point-evals/s',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': dt / args.steps * 1e3,
       'gpu_ms_per_step': gpu_ms / args.steps,
-      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+      'vs_baseline': None,
       'dtype': 'f32 (elementwise) + f64 (sums)', 'data': 'synthetic',
       'config': {
           'workload': ('BASELINE configs[1]: 721x1440x13 f32, deterministic '
                        'MSE+RMSE+MAE+Bias+ACC, 13 predefined slice regions, '
                        'running init-time mean'),
           'units_per_step_per_gpu': units, 'pool_units': pool,
+          'total_units': args.total_units if strong else None,
           'regions': nr, 'rows_per_chunk': args.rows_per_chunk,
           'parallelism': f'init-time shards x{world}, 1 all-reduce of [sum,count]',
           'launcher': ('self-spawned ranks' if os.environ.get(
@@ -466,6 +550,14 @@ def main():
           'backend': ('rccl (torch "nccl")' if backend == 'nccl' else backend)
                      if ddp else None,
           'ms_per_step_per_rank': rank_ms,
+          # which exchange steps of this line ran on RCCL over the GPUs' links
+          'collectives': ({
+              'time_mean_allreduce ([sum,count], in every timed region)':
+                  'rccl' if backend == 'nccl' else f'{backend} via host copies',
+              'map_allreduce': 'rccl' if backend == 'nccl' else
+                               f'{backend} via host copies',
+              'timing max-over-ranks / barriers':
+                  'rccl' if backend == 'nccl' else backend} if ddp else None),
       },
       'roofline': {
           'bound': 'hbm', 'kernel': 'stream_partials_kernel<float,4,DET_ACC>',
@@ -487,7 +579,7 @@ def main():
   dt_cold, _, _ = timed_region(lambda i: step(args.warmup + i, False),
                                args.steps, [total, count])
   out['unramped'] = {
-      'value': world * pts_step * args.steps / dt_cold,
+      'value': job_pts / dt_cold,
       'ms_per_step': dt_cold / args.steps * 1e3,
       'note': 'same K steps started from an idle queue (no ramp, no warmup)'}
 
@@ -502,8 +594,50 @@ def main():
       out['api'] = api_leg(dev, regions, units)
     except Exception as e:  # never lose the GPU line to a secondary leg
       out['api'] = {'error': f'{type(e).__name__}: {e}'}
-  if rank == 0 and world == 1 and args.pcie:
-    out['pcie_inclusive'] = pcie_leg(dev, pl, units, nr, total, count)
+  if rank == 0 and world == 1 and not args.no_secondary:
+    # ---- BASELINE configs[2] / configs[3] and K1's production variants, each
+    # with its own roofline; bounded step counts keep the whole line in minutes
+    legs = (('ensemble', 'ensemble', 40), ('spectrum', 'spectrum', 100),
+            ('spectrum/materialized', 'spectrum_materialized', 60),
+            ('spectrum/time_mean', 'spectrum_mean', 60))
+    for key, workload, n in legs:
+      try:
+        leg = secondary(workload, n, 5, 20.0, args.members, 0)
+      except Exception as e:  # never lose the GPU line to a secondary leg
+        leg = {'error': f'{type(e).__name__}: {e}'}
+      leg = {k: leg[k] for k in ('value', 'unit', 'steps', 'ms_per_step',
+                                 'config', 'roofline', 'error') if k in leg}
+      if '/' in key:
+        out.setdefault('spectrum', {})[key.split('/')[1]] = leg
+      else:
+        out[key] = leg
+      torch.cuda.empty_cache()
+    try:
+      out['variants'] = k1_variants(dev, fpool, tpool, cpool, units, pool)
+    except Exception as e:
+      out['variants'] = {'error': f'{type(e).__name__}: {e}'}
+    torch.cuda.empty_cache()
+  if rank == 0 and world == 1 and not args.no_pcie:
+    try:
+      out['pcie_inclusive'] = pcie_leg(dev, pl, units, nr, total, count)
+    except Exception as e:
+      out['pcie_inclusive'] = {'error': f'{type(e).__name__}: {e}'}
+  if rank == 0 and world == 1 and not args.no_pmc and not strong:
+    # ---- roofline.traffic, live: the PMC passes run in child processes under
+    # rocprofv3 (their own 7.8 GB pools; 288 GB of HBM hold both)
+    live = live_traffic(units, pool, args.rows_per_chunk)
+    if live.get('traffic_bytes'):
+      out['roofline'].update(
+          traffic=live['traffic_bytes'],
+          traffic_over_algorithmic=live['traffic_bytes'] / (
+              pts_step * BYTES_PER_PT),
+          traffic_source=('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate '
+                          'passes, --kernel-trace only) around this launch '
+                          'configuration, collected by this run: '
+                          'tools/live_traffic.py'),
+          traffic_detail=live)
+    else:
+      out['roofline']['traffic_live_error'] = live.get('error', 'unavailable')
   if rank == 0:
     if world == 1 and not args.no_cpu_baseline:
       try:
@@ -550,22 +684,31 @@ def full_suite(args, dev, pl_det, det_step, det_acc, timed_region, per_rank,
   etotal = torch.zeros((_lib.NMETRIC_ENS * nr, N_LEV), dtype=torch.float64,
                        device=dev)
   ecount = torch.zeros_like(etotal)
-  n_steps = min(args.steps, 20)
+  strong = args.total_units > 0
+  n_steps = args.steps if strong else min(args.steps, 20)
+  if strong:  # the same contiguous shard of units as the deterministic suite
+    from weatherbench2_amd.evaluation import shard_bounds
+    lo, hi = shard_bounds(args.total_units, world, rank)
   etabs = []
   for s in range(n_steps + 2):
-    u = (s * units + torch.arange(units, device=dev)) % ens_pool
+    n_u = units
+    if strong and s < n_steps:
+      n_u = max(0, min(units, hi - lo - s * units))
+    u = (s * units + torch.arange(n_u, device=dev)) % ens_pool
     etabs.append(((u[:, None] * N_LEV + lev[None]).reshape(-1).contiguous(),
                   (((u + 1) % ens_pool)[:, None] * N_LEV + lev[None]
-                   ).reshape(-1).contiguous()))
+                   ).reshape(-1).contiguous(), n_u))
   k3_timer = KernelTimer()
 
   def ens_step(i, timed=True):
-    et, tt = etabs[i]
-    engine.set_launch_hook(k3_timer if timed else None)
+    et, tt, n_u = etabs[i]
+    if n_u == 0:
+      return
+    engine.set_launch_hook(k3_timer if timed and n_u == units else None)
     metrics, _ = engine.ensemble_reduce(pl_ens, ens, stride, m, et, etruth, tt,
-                                        units * N_LEV, False)
+                                        n_u * N_LEV, False)
     engine.set_launch_hook(None)
-    engine.time_accumulate(metrics.view(_lib.NMETRIC_ENS * nr, units, N_LEV), 1,
+    engine.time_accumulate(metrics.view(_lib.NMETRIC_ENS * nr, n_u, N_LEV), 1,
                            False, etotal, ecount)
 
   def both(i):
@@ -585,7 +728,10 @@ def full_suite(args, dev, pl_det, det_step, det_acc, timed_region, per_rank,
                    f'{m}-member units through the probabilistic suite (K3), 13 '
                    'regions, init-time shards, one all-reduce of both '
                    '[sum,count] pairs'),
-      'value': world * pts_step * n_steps / dt, 'unit': 'grid-point-evals/s',
+      'value': (args.total_units * PTS_PER_UNIT if strong
+                else world * pts_step * n_steps) / dt,
+      'unit': 'grid-point-evals/s',
+      'scaling': 'strong' if strong else 'weak',
       'steps': n_steps, 'ms_per_step': dt / n_steps * 1e3,
       'ms_per_step_per_rank': per_rank(own / n_steps * 1e3),
       'ensemble_kernel': {
@@ -738,13 +884,18 @@ def pcie_leg(dev, pl, units, nr, total, count) -> dict:
   return result
 
 
-def secondary(args):
+def secondary(workload_name, steps, warmup, ramp_ms, members=50,
+              rows_per_chunk=0) -> dict:
   """BASELINE configs[2] (50-member ensemble) and configs[3] (zonal spectrum)
-  on one GPU: same timing discipline, their own roofline."""
+  on one GPU: same timing discipline, their own roofline.  Returns the JSON
+  line of `--workload NAME`; the default run embeds the same dicts."""
+  import types
   import torch
   from weatherbench2_amd import _lib, engine, plan as plan_lib
-  dev = torch.device('cuda', 0)
-  torch.cuda.set_device(dev)
+  args = types.SimpleNamespace(workload=workload_name, steps=steps,
+                               warmup=warmup, ramp_ms=ramp_ms, members=members,
+                               rows_per_chunk=rows_per_chunk)
+  dev = torch.device('cuda', torch.cuda.current_device())
   lat = np.linspace(-90, 90, N_LAT)
   lon = np.linspace(0, 360, N_LON, endpoint=False)
   gen = torch.Generator(device=dev).manual_seed(99)
@@ -870,7 +1021,7 @@ def secondary(args):
   pairs = events or timer.pairs
   k_s = float(np.mean([a.elapsed_time(b) for a, b in pairs])) / 1e3
   achieved = pts * bytes_per_pt / k_s / 1e9
-  print(json.dumps({
+  return {
       'metric': 'grid-point-evals/sec (721x1440x13)',
       'value': pts * args.steps / dt, 'unit': 'grid-point-evals/s',
       'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -888,7 +1039,148 @@ def secondary(args):
                                    {'spectrum_materialized': 'spectrum',
                                     'spectrum': 'spectrum_latmean'}.get(
                                         args.workload, args.workload),
-                                   units_per_launch=8))}}))
+                                   units_per_launch=8)),
+                   'traffic_source': 'rocprofv3 PMC of an earlier run of this '
+                                     'launch size (profiles/)'}}
+
+
+def land_sea_mask(rs, lat, lon):
+  """A synthetic land-sea mask in [0, 1] (smooth blobs, ~30 % land, fractional
+  coast cells like ERA5's `land_sea_mask`)."""
+  yy, xx = np.meshgrid(np.deg2rad(lat), np.deg2rad(lon), indexing='ij')
+  field = np.zeros_like(yy)
+  for _ in range(24):
+    a, b, c, d = rs.uniform(-1, 1), rs.randint(1, 5), rs.randint(1, 4), (
+        rs.uniform(0, 2 * np.pi))
+    field += a * np.cos(b * xx + d) * np.cos(c * yy + d)
+  return np.clip((field - np.quantile(field, 0.6)) * 2.0, 0.0, 1.0)
+
+
+def official_regions():
+  """The 16 regions of the reference's `deterministic` config with a land-sea
+  mask present (scripts/evaluate.py:345-395): the 13 slice regions +
+  global_land, extra-tropics_land, tropics_land."""
+  from weatherbench2_amd import regions as R
+  from weatherbench2_amd import xarray_lite as xl
+  lat = np.linspace(-90, 90, N_LAT)
+  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  lsm = xl.DataArray(land_sea_mask(np.random.RandomState(7), lat, lon),
+                     ('latitude', 'longitude'),
+                     {'latitude': lat, 'longitude': lon})
+  regions = predefined_regions()
+  regions['global_land'] = R.LandRegion(land_sea_mask=lsm)
+  regions['extra-tropics_land'] = R.CombinedRegion(regions=[
+      R.SliceRegion(lat_slice=[slice(None, -20), slice(20, None)]),
+      R.LandRegion(land_sea_mask=lsm)])
+  regions['tropics_land'] = R.CombinedRegion(regions=[
+      R.SliceRegion(lat_slice=slice(-20, 20)), R.LandRegion(land_sea_mask=lsm)])
+  return regions
+
+
+def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30) -> dict:
+  """Kernel time + fraction of the HBM peak of K1's OTHER production
+  instantiations (the headline is MODE_DET_ACC / float32 / 13 slice regions /
+  no skipna), same launch size (16 units of 13 x 721 x 1440), same pools:
+    official16_landmask  the 16 regions of the official `deterministic` config
+                         (scripts/evaluate.py:345-395): three of them carry the
+                         2-D land-sea mask -> the WF = true instantiation (a
+                         second set of fp64 accumulators + the mask field)
+    skipna               notnull-weighted extra slots (K 6 -> 10)
+    f64_inputs           float64 forecast / truth / climatology (24 B/pt)
+    wind                 MODE_WIND: u, v of forecast and truth (16 B/pt)
+    det_no_acc           MODE_DET: no climatology (8 B/pt)
+    lonlat               (..., longitude, latitude) slabs: rows = longitude,
+                         the latitude weights applied per column
+  Algorithmic bytes exclude the mask / weight tables (cache-resident)."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  lat = np.linspace(-90, 90, N_LAT)
+  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  lev = torch.arange(N_LEV, device=dev, dtype=torch.int64)
+  n_outer = units * N_LEV
+  rows = plan_lib.auto_rows_per_chunk(N_LAT, n_outer)
+
+  def tabs(step, pool_units, k):
+    u = (step * units + torch.arange(units, device=dev)) % pool_units
+    return [(((u * (2 * j + 1) + 3 * j) % pool_units)[:, None] * N_LEV
+             + lev[None]).reshape(-1).contiguous() for j in range(k)]
+
+  def run(name, pl, mode, inputs, pool_units, skipna, bytes_per_pt, what):
+    timer = KernelTimer()
+    k = len(inputs)
+    tables = [tabs(s_, pool_units, k) for s_ in range(steps + 3)]
+    for i in range(3):
+      engine.stream_reduce(pl, mode, inputs, tables[i], n_outer, skipna)
+    engine.set_launch_hook(timer)
+    for i in range(steps):
+      engine.stream_reduce(pl, mode, inputs, tables[3 + i], n_outer, skipna)
+    engine.set_launch_hook(None)
+    torch.cuda.synchronize()
+    ms = timer.mean_ms()
+    nbytes = units * PTS_PER_UNIT * bytes_per_pt
+    return {'what': what, 'kernel_ms': ms,
+            'algorithmic_bytes_per_launch': nbytes,
+            'achieved': nbytes / ms / 1e6, 'unit': 'GB/s',
+            'frac': nbytes / ms / 1e6 / HBM_PEAK_GBPS,
+            'regions': pl.n_region, 'rows_per_chunk': rows,
+            'weight_field': pl.wfield is not None}
+
+  out = {}
+  pl13 = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(),
+                             dev, rows_per_chunk=rows)
+  pl16 = plan_lib.build_plan(lat, lon, plan_lib.LATLON, official_regions(), dev,
+                             rows_per_chunk=rows)
+  f32 = [fpool, tpool, cpool]
+  out['official16_landmask'] = run(
+      'official16', pl16, _lib.MODE_DET_ACC, f32, pool, False, 12.0,
+      'MODE_DET_ACC f32, the 16 regions of scripts/evaluate.py:345-395 incl. '
+      'global_land / extra-tropics_land / tropics_land (2-D mask: WF = true)')
+  out['skipna'] = run(
+      'skipna', pl13, _lib.MODE_DET_ACC, f32, pool, True, 12.0,
+      'MODE_DET_ACC f32, 13 regions, skipna = True (K = 10 slots)')
+  out['det_no_acc'] = run(
+      'det', pl13, _lib.MODE_DET, f32[:2], pool, False, 8.0,
+      'MODE_DET f32 (MSE / RMSE / MAE / Bias without a climatology), 13 regions')
+  out['wind'] = run(
+      'wind', pl13, _lib.MODE_WIND, [fpool, tpool, cpool, fpool], pool, False,
+      16.0, 'MODE_WIND f32: u, v of forecast and truth (4 inputs), 13 regions')
+  # lon-lat layout: the same bytes viewed as (slab, longitude, latitude)
+  pl_ll = plan_lib.build_plan(lat, lon, plan_lib.LONLAT, predefined_regions(),
+                              dev, rows_per_chunk=plan_lib.auto_rows_per_chunk(
+                                  N_LON, n_outer))
+  ll = [x.view(-1, N_LON, N_LAT) for x in f32]
+  out['lonlat'] = run(
+      'lonlat', pl_ll, _lib.MODE_DET_ACC, ll, pool, False, 12.0,
+      'MODE_DET_ACC f32 on (..., longitude, latitude) slabs (721 columns: '
+      'rows are not 16-byte aligned), 13 regions')
+  out['lonlat']['rows_per_chunk'] = plan_lib.auto_rows_per_chunk(N_LON, n_outer)
+  pool64 = units + 8
+  gen = torch.Generator(device=dev).manual_seed(77)
+  f64 = [torch.randn((pool64 * N_LEV, N_LAT, N_LON), generator=gen, device=dev,
+                     dtype=torch.float64) for _ in range(3)]
+  out['f64_inputs'] = run(
+      'f64', pl13, _lib.MODE_DET_ACC, f64, pool64, False, 24.0,
+      'MODE_DET_ACC float64 inputs (24 B/pt), 13 regions')
+  del f64
+  return out
+
+
+def live_traffic(units, pool, rows_per_chunk) -> dict:
+  """HBM bytes per launch of the benched K1 configuration from PMC counters,
+  collected NOW (tools/live_traffic.py: two rocprofv3 passes around
+  `bench.py --traffic-probe`)."""
+  tool = os.path.join(ROOT, 'tools', 'live_traffic.py')
+  try:
+    res = subprocess.run(
+        [sys.executable, tool, '--units', str(units), '--pool', str(pool),
+         '--rows-per-chunk', str(rows_per_chunk)],
+        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+        timeout=240)
+    if res.returncode != 0:
+      return {'error': (res.stderr or res.stdout).strip()[-300:]}
+    return json.loads(res.stdout.strip().splitlines()[-1])
+  except Exception as e:  # rocprofv3 missing, timeout, ...
+    return {'error': f'{type(e).__name__}: {e}'}
 
 
 if __name__ == '__main__':

@@ -545,6 +545,39 @@ def f32_coordinate_case(seed=82):
   return case
 
 
+LAT025 = np.linspace(-90.0, 90.0, 721)
+LON025 = np.linspace(0.0, 360.0, 1440, endpoint=False)
+
+
+def f32_coordinate_case_era5(seed=84):
+  """The same at the real size: one 0.25-degree grid (721 x 1440) with float32
+  coordinates, (time, level, latitude, longitude) float32 data -- a million
+  points per spatial sum, where the reference's float32 einsum shows its
+  summation noise (DESIGN.md 4 records the measured deviation)."""
+  rs = np.random.RandomState(seed)
+  n_time, levels = 2, np.array([500])
+  sshape = (len(LAT025), len(LON025))
+  spatial = ('latitude', 'longitude')
+  truth = rs.standard_normal((n_time, 1) + sshape).astype(np.float32)
+  forecast = (truth + 0.5 * rs.standard_normal(truth.shape)).astype(np.float32)
+  days, hours = np.arange(57, 61), np.array([0, 12])
+  clim = (0.3 * rs.standard_normal((len(hours), len(days), 1) + sshape)
+          ).astype(np.float32)
+  lsm = rs.rand(*sshape)
+  lsm[lsm < 0.25] = 0.0
+  return {
+      'coords': {'time': _times(n_time), 'level': levels,
+                 'latitude': LAT025.astype(np.float32),
+                 'longitude': LON025.astype(np.float32),
+                 'hour': hours, 'dayofyear': days},
+      'truth': {'geopotential': _arr(truth, 'time', 'level', *spatial)},
+      'forecast': {'geopotential': _arr(forecast, 'time', 'level', *spatial)},
+      'climatology': {'geopotential': _arr(clim, 'hour', 'dayofyear', 'level',
+                                           *spatial)},
+      'lsm': _arr(lsm, 'latitude', 'longitude'),
+  }
+
+
 def layout_table():
   small = ['global', 'europe', 'land_thr']
   return {
@@ -555,6 +588,8 @@ def layout_table():
                               'compute'),
       'det_f32_coords32': (f32_coordinate_case, DET_METRICS,
                            small + ['extra_tropical'], False, 'chunk'),
+      'det_f32_era5_coords32': (f32_coordinate_case_era5, DET_METRICS,
+                                small + ['extra_tropical'], False, 'chunk'),
   }
 
 

@@ -148,9 +148,10 @@ def test_float32_latitude_era5_style(torch_dev, n_lat, n_lon):
   evaluation-time flip (evaluation.py:41-47) the weights are computed in
   float32 (metrics.py:41, 57).  The reference's einsum then accumulates in
   float32 (noise ~1e-5 at a million points, result float32); the product
-  applies the SAME float32-valued weights but sums in float64 and returns
-  float64.  Checked (a) tightly against a float64 evaluation with those weights
-  and (b) against the oracle's float32 path at the float32-summation noise."""
+  applies the SAME float32-valued weights, sums in float64 and returns the
+  reference's dtype (float32 here: the float64 sum rounded once).  Checked (a)
+  against a float64 evaluation with those weights to one float32 ulp and (b)
+  against the oracle's float32 path at the float32-summation noise."""
   from weatherbench2_amd import evaluation, metrics as gm
   from weatherbench2_amd import plan as plan_lib
   rs = np.random.RandomState(5)
@@ -196,9 +197,12 @@ def test_float32_latitude_era5_style(torch_dev, n_lat, n_lon):
   for rname in oregions:
     for mname, (gmet, omet) in pairs.items():
       got = gmet.compute_chunk(gf, gt, region=gregions[rname])['z'].values
-      assert got.dtype == np.float64
-      helpers.assert_close(got, exact[mname](lat_sel[rname]), rtol=1e-11,
-                           atol=1e-14, err_msg=f'{mname}/{rname} (fp64 sums)')
+      # the reference's dtype for float32 data on float32 coordinates and a
+      # slice region (metrics._reference_result_dtype); the VALUE is the
+      # float64 sum rounded once: within one float32 ulp of the exact one
+      assert got.dtype == np.float32
+      helpers.assert_close(got, exact[mname](lat_sel[rname]), rtol=1.2e-7,
+                           atol=1e-9, err_msg=f'{mname}/{rname} (fp64 sums)')
       want = omet.compute_chunk(of, ot, region=oregions[rname])['z'].data
       assert want.dtype == np.float32  # the reference's result dtype
       # float32 einsum noise of the reference path; Bias cancels to ~1e-3, so

@@ -190,6 +190,10 @@ def test_hip_path_reproduces_the_reference(vectors, cname):
             use = dict(rtol=1e-9, atol=1e-12)  # float64 sums in the reference
           helpers.assert_close(np.asarray(got.values), vectors[key],
                                err_msg=key, **use)
+          if mlabel in rc.DET_METRICS or mlabel in rc.WIND_METRICS:
+            # the public API returns the dtype the reference returns: float32
+            # for slice regions on float32 coordinates, float64 otherwise
+            assert np.asarray(got.values).dtype == vectors[key].dtype, key
           n += 1
   assert n > 0
 

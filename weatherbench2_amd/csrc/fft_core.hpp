@@ -20,6 +20,13 @@ namespace fftcore {
 
 #define WB2_HD __host__ __device__ __forceinline__
 
+// How a pass stores one complex point into the slab; spectrum_fused.hip
+// overrides it for device code (single ds_write_b64 instead of the compiler's
+// ds_write2_b64 pairs), the host check keeps the plain assignment.
+#ifndef WB2_FFT_SLAB_STORE
+#define WB2_FFT_SLAB_STORE(ptr, value) (*(ptr) = (value))
+#endif
+
 typedef float cf __attribute__((ext_vector_type(2)));   // (re, im)
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -348,7 +355,7 @@ struct Pass {
           const int k = j % NS;
           const int j0 = (j / NS) * (NS * R + OUT_PAD) + k;
 #pragma unroll
-          for (int t = 0; t < R; ++t) z[j0 + t * NS] = v[rd][t];
+          for (int t = 0; t < R; ++t) WB2_FFT_SLAB_STORE(z + j0 + t * NS, v[rd][t]);
         }
       }
     }

@@ -29,6 +29,18 @@
 // that the plan owns.
 
 #include "common.hpp"
+
+#ifndef WB2_FFT_SINGLE_WRITES
+// 1: 8-byte LDS stores stay single ds_write_b64 (17 cycles per instruction and
+// SIMD, tools/valu_rate.hip) instead of the ds_write2_b64 pairs hipcc's
+// load/store optimiser makes of them (44): volatile stores in address space 3
+#define WB2_FFT_SINGLE_WRITES 1
+#endif
+#if WB2_FFT_SINGLE_WRITES && defined(__HIP_DEVICE_COMPILE__)
+#define WB2_FFT_SLAB_STORE(ptr, value)                                         \
+  (*(__attribute__((address_space(3))) volatile ::wb2::fftcore::cf*)(ptr) = \
+       (value))
+#endif
 #include "fft_core.hpp"
 #include "wb2hip.h"
 
@@ -43,6 +55,29 @@
 #endif
 #ifndef WB2_FFT_WIDE_STORE
 #define WB2_FFT_WIDE_STORE 1  // materialising kernel: 16-byte stores of adjacent bins
+#endif
+#ifndef WB2_FFT_SINGLE_READS
+// 1: every 8-byte LDS read of the transform is its own ds_read_b64.  hipcc's
+// load/store optimiser otherwise pairs them into ds_read2_b64 /
+// ds_read2st64_b64, which gfx950 services at 128 B/clk (8 LDS cycles per
+// wave-instruction) where two ds_read_b64 take 2 + 2 (256 B/clk,
+// MI355X_MICROARCH.md "LDS"): 152 -> 90 LDS-pipe cycles of reads per row
+// (profiles/r03_k4_stalls.md).  The reads are marked volatile in address
+// space 3 -- the one thing the optimiser does not merge.
+#define WB2_FFT_SINGLE_READS 1
+#endif
+#ifndef WB2_FFT_STAGE
+// 1: the reducing kernels (TIME_MEAN, LATSEG) fetch the NEXT row HBM -> LDS by
+// DMA (global_load_lds_dwordx4: 6 instructions per 5760-byte row, no VGPRs)
+// while the current row is transformed; pass 0 then reads its inputs from the
+// wave's staging buffer (12 more ds_read_b64).  Hides the HBM latency of a row
+// (~1.5 k of the ~6.8 k cycles a wave spends per row) at no register cost.
+// Measured twice with NO gain (round 2 with ds_read2_b64 pairs, round 3 with
+// single ds_read_b64: 0.1065-0.1093 ms against 0.1075-0.1078 ms for LATSEG,
+// profiles/r03_k4_stalls.md), so it stays off: the staged instantiations are
+// only compiled with -DWB2_FFT_STAGE=1 (tools/ab_round3b.sh; the spectrum
+// parity tests pass through them).
+#define WB2_FFT_STAGE 0
 #endif
 #ifndef WB2_FFT_DIAG
 // timing diagnostics only (wrong results): 1 / 2 skip LDS pass 1 / 2, 4 replace
@@ -112,6 +147,16 @@ __device__ __forceinline__ void twiddle_block(cf* v, const cf* tw) {
   }
 }
 
+// One 8-byte read from the wave's LDS slab (or the shared twiddle table).
+__device__ __forceinline__ cf lds_read(const cf* p) {
+#if WB2_FFT_SINGLE_READS
+  typedef __attribute__((address_space(3))) const volatile cf* lds_ptr;
+  return *(lds_ptr)p;
+#else
+  return *p;
+#endif
+}
+
 struct FusedParams {
   const float* x;
   const cf* twz;   // [N2]      exp(-2 pi i j / N2)
@@ -133,7 +178,7 @@ template <typename P, int R>
 __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
                                          const cf (&tw)[P::ROUNDS][P::NTW]) {
   cf v[P::ROUNDS][R];
-  P::load([&](int i) { return z[i]; }, lane, v);
+  P::load([&](int i) { return lds_read(z + i); }, lane, v);
 #if WB2_FFT_ASM_CMUL
 #pragma unroll
   for (int rd = 0; rd < P::ROUNDS; ++rd) twiddle_block<R - 1>(&v[rd][1], &tw[rd][0]);
@@ -163,7 +208,7 @@ __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
 //                field are added in segment order by latseg_combine_kernel).
 enum { MATERIALISE = 0, TIME_MEAN = 1, LATSEG = 2 };
 
-template <int N2, int MODE>
+template <int N2, int MODE, bool STAGED = false>
 __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
     fused_spectrum_kernel(const FusedParams p) {
   using PL = Plan<N2>;
@@ -177,6 +222,9 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   constexpr bool REDUCE = MODE != MATERIALISE;
   __shared__ __attribute__((aligned(16))) cf s_twq[NH + 1];
   __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][slab_slots<N2>()];
+  constexpr bool STAGE = REDUCE && STAGED;
+  __shared__ __attribute__((aligned(16))) float
+      s_stage[STAGE ? NWAVE : 1][STAGE ? N : 4];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   for (int i = threadIdx.x; i <= NH; i += blockDim.x)
@@ -195,8 +243,50 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
   else if constexpr (MODE == LATSEG) rows_out = p.n_rows / p.n_lat * p.n_seg;
   else rows_out = p.n_rows;
   const long long stride = (long long)gridDim.x * NWAVE;
-  for (long long orow_i = (long long)blockIdx.x * NWAVE + wave;
-       orow_i < rows_out; orow_i += stride) {
+  // the input rows of output row o: row0 + t * row_step, t = 0 .. nt - 1
+  struct Task {
+    long long row0, nt, row_step;
+    int lat0;
+  };
+  auto task_of = [&](long long o) {
+    Task k{o, 1, 0, 0};
+    if constexpr (MODE == TIME_MEAN) {
+      k.nt = p.n_time;
+      k.row_step = rows_out;
+    } else if constexpr (MODE == LATSEG) {
+      const long long field = o / p.n_seg;
+      const int seg = (int)(o - field * p.n_seg);
+      k.lat0 = (int)((long long)seg * p.n_lat / p.n_seg);  // balanced split
+      k.nt = (long long)(seg + 1) * p.n_lat / p.n_seg - k.lat0;
+      k.row0 = field * p.n_lat + k.lat0;
+      k.row_step = 1;
+    }
+    return k;
+  };
+  // HBM -> LDS DMA of one input row into this wave's staging buffer: 16 bytes
+  // per lane and instruction, lane l of instruction i lands at byte
+  // i * 1024 + 16 l (M0 carries the wave-uniform LDS base)
+  auto stage_row = [&](long long row) {
+    if constexpr (STAGE) {
+      const char* g = reinterpret_cast<const char*>(p.x + row * N);
+      char* dst = reinterpret_cast<char*>(s_stage[wave]);
+#pragma unroll
+      for (int i = 0; i < (N * 4 + 1023) / 1024; ++i) {
+        const int off = i * 1024 + lane * 16;
+        if ((i + 1) * 1024 <= N * 4 || off < N * 4)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(g + off),
+              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0,
+              /*aux: nt*/ 2);
+      }
+    }
+  };
+  const long long orow_first = (long long)blockIdx.x * NWAVE + wave;
+  Task next_task = task_of(orow_first < rows_out ? orow_first : 0);
+  if constexpr (STAGE) {
+    if (orow_first < rows_out) stage_row(next_task.row0);
+  }
+  for (long long orow_i = orow_first; orow_i < rows_out; orow_i += stride) {
     double sum1[NIT], sum2[NIT];
     int cnt[NIT];  // TIME + skipna: valid spectra, bin k (low half) / N2 - k
 #pragma unroll
@@ -204,19 +294,11 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
       sum1[i] = sum2[i] = 0.0;
       cnt[i] = 0;
     }
-    long long nt = 1, row0 = orow_i, row_step = 0;
-    int lat0 = 0;
-    if constexpr (MODE == TIME_MEAN) {
-      nt = p.n_time;
-      row_step = rows_out;
-    } else if constexpr (MODE == LATSEG) {
-      const long long field = orow_i / p.n_seg;
-      const int seg = (int)(orow_i - field * p.n_seg);
-      lat0 = (int)((long long)seg * p.n_lat / p.n_seg);  // balanced split
-      nt = (long long)(seg + 1) * p.n_lat / p.n_seg - lat0;
-      row0 = field * p.n_lat + lat0;
-      row_step = 1;
-    }
+    const Task task = next_task;
+    const bool has_next = orow_i + stride < rows_out;
+    if (has_next) next_task = task_of(orow_i + stride);  // once per task
+    const long long nt = task.nt, row0 = task.row0, row_step = task.row_step;
+    const int lat0 = task.lat0;
     double c = 0.0;
     if constexpr (MODE != LATSEG) c = p.circ[(unsigned)(orow_i % p.n_lat)];
     double* orow = p.out + orow_i * NB;
@@ -224,11 +306,25 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
       if constexpr (MODE == LATSEG) c = p.circ[lat0 + t];
       const double c2 = 2.0 * c;
       {  // ---- pass 0: HBM -> butterflies -> contiguous runs in the slab
-        const cf* src =
-            reinterpret_cast<const cf*>(p.x + (row0 + t * row_step) * N);
         cf v[P0::ROUNDS][R0];
-        P0::load([&](int i) { return __builtin_nontemporal_load(src + i); },
-                 lane, v);
+        if constexpr (STAGE) {
+          // this row was staged one row-time ago: wait for the DMA, copy it
+          // out, and only when every read has RETURNED (the DMA of the next
+          // row overwrites the buffer) start the next fetch
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+          const cf* src = reinterpret_cast<const cf*>(s_stage[wave]);
+          P0::load([&](int i) { return lds_read(src + i); }, lane, v);
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          const bool more = t + 1 < nt;
+          if (more || has_next)
+            stage_row(more ? row0 + (t + 1) * row_step : next_task.row0);
+        } else {
+          const cf* src =
+              reinterpret_cast<const cf*>(p.x + (row0 + t * row_step) * N);
+          P0::load([&](int i) { return __builtin_nontemporal_load(src + i); },
+                   lane, v);
+        }
 #if WB2_FFT_DIAG & 8
         sum1[0] += (double)(v[0][0].x + v[0][R0 - 1].y);
 #else
@@ -263,8 +359,8 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
           if (k0 <= N2 / 2) {
             const f4 a01 = *reinterpret_cast<const f4*>(z + k0);
             const cf a0 = {a01.x, a01.y}, a1 = {a01.z, a01.w};
-            const cf b0 = z[(i == 0 && k0 == 0) ? 0 : N2 - k0];
-            const cf b1 = z[N2 - k0 - 1];
+            const cf b0 = lds_read(z + ((i == 0 && k0 == 0) ? 0 : N2 - k0));
+            const cf b1 = lds_read(z + (N2 - k0 - 1));
             const f4 w01 = *reinterpret_cast<const f4*>(s_twq + k0);
             float p1a, p2a, p1b, p2b;
             recombine_pair(a0, b0, cf{w01.x, w01.y}, half_inv_n, p1a, p2a);
@@ -293,10 +389,10 @@ __global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
         for (int i = 0; i < NIT; ++i) {
           const int k = lane + i * kWave;
           if ((i + 1) * kWave <= NH || k < NH) {
-            const cf a = z[k];
-            const cf b = z[(i == 0 && k == 0) ? 0 : N2 - k];
+            const cf a = lds_read(z + k);
+            const cf b = lds_read(z + ((i == 0 && k == 0) ? 0 : N2 - k));
             float p1, p2;
-            recombine_pair(a, b, s_twq[k], half_inv_n, p1, p2);
+            recombine_pair(a, b, lds_read(s_twq + k), half_inv_n, p1, p2);
             // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
             const double v1 = (double)p1 * ((i == 0 && k == 0) ? c : c2);
             const double v2 = (double)p2 * c2;
@@ -406,6 +502,25 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
   WB2_REQUIRE(p.n_time < 65536, "fused time mean: n_time=%lld exceeds 65535",
               p.n_time);
   if (blocks > WB2_FFT_MAX_BLOCKS) blocks = WB2_FFT_MAX_BLOCKS;  // row-strided waves beyond that
+  // the LDS DMA moves 16 bytes per lane: rows must start 16-byte aligned
+  const bool staged = WB2_FFT_STAGE && mode != MATERIALISE &&
+                      reinterpret_cast<uintptr_t>(p.x) % 16 == 0 &&
+                      (2 * N2 * sizeof(float)) % 16 == 0;
+#if WB2_FFT_STAGE
+  if (mode == TIME_MEAN && staged) {
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN, true>),
+                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+    WB2_HIP_OK(hipGetLastError());
+    return 0;
+  }
+  if (mode == LATSEG && staged) {
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, LATSEG, true>),
+                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+    WB2_HIP_OK(hipGetLastError());
+    return 0;
+  }
+#endif
+  (void)staged;
   if (mode == TIME_MEAN)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN>),
                        dim3((unsigned)blocks), dim3(256), 0, s, p);
@@ -423,8 +538,10 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
 // at once (one task per wave, no second round).
 template <int N2>
 int latseg_segments(long long n_field, int n_lat) {
+  // (sized for the staged instantiation: its LDS footprint is the larger one,
+  // so the task count also fits the unstaged fallback)
   const long long waves =
-      4LL * resident_blocks(fused_spectrum_kernel<N2, LATSEG>);
+      4LL * resident_blocks(fused_spectrum_kernel<N2, LATSEG, WB2_FFT_STAGE != 0>);
   long long n_seg = waves / (n_field > 0 ? n_field : 1);
   if (n_seg < 1) n_seg = 1;
   if (n_seg > n_lat) n_seg = n_lat;
