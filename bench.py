@@ -258,9 +258,12 @@ def parse_args():
                   help='seconds after which a self-launched job (and the '
                        'rendezvous / collectives of every rank) gives up '
                        'instead of hanging')
-  ap.add_argument('--traffic-probe', action='store_true',
+  ap.add_argument('--traffic-probe', nargs='?', const='deterministic',
+                  default=None,
+                  choices=['deterministic', 'official16_landmask', 'skipna'],
                   help='(tools/live_traffic.py) only run a few launches of the '
-                       'benched K1 configuration, for the PMC passes')
+                       'benched K1 configuration -- or of one of its variants '
+                       '-- for the PMC passes')
   ap.add_argument('--workload', default='deterministic',
                   choices=['deterministic', 'ensemble', 'spectrum',
                            'spectrum_materialized', 'spectrum_mean'],
@@ -459,9 +462,13 @@ def main():
     all_reduce(torch.cat([total.reshape(-1), count.reshape(-1)]))
   if args.traffic_probe:
     # tools/live_traffic.py: a few launches of exactly the benched K1
-    # configuration under rocprofv3 --pmc, nothing else
-    for i in range(6):
-      step(args.warmup + i % max(args.steps, 1), False)
+    # configuration (or one variant of it) under rocprofv3 --pmc, nothing else
+    if args.traffic_probe == 'deterministic':
+      for i in range(6):
+        step(args.warmup + i % max(args.steps, 1), False)
+    else:
+      k1_variants(dev, fpool, tpool, cpool, units, pool, steps=6,
+                  only=args.traffic_probe)
     torch.cuda.synchronize()
     return
 
@@ -1077,7 +1084,8 @@ def official_regions():
   return regions
 
 
-def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30) -> dict:
+def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
+                only=None) -> dict:
   """Kernel time + fraction of the HBM peak of K1's OTHER production
   instantiations (the headline is MODE_DET_ACC / float32 / 13 slice regions /
   no skipna), same launch size (16 units of 13 x 721 x 1440), same pools:
@@ -1106,6 +1114,8 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30) -> dict:
              + lev[None]).reshape(-1).contiguous() for j in range(k)]
 
   def run(name, pl, mode, inputs, pool_units, skipna, bytes_per_pt, what):
+    if only is not None and only != name:
+      return None
     timer = KernelTimer()
     k = len(inputs)
     tables = [tabs(s_, pool_units, k) for s_ in range(steps + 3)]
@@ -1132,14 +1142,14 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30) -> dict:
                              rows_per_chunk=rows)
   f32 = [fpool, tpool, cpool]
   out['official16_landmask'] = run(
-      'official16', pl16, _lib.MODE_DET_ACC, f32, pool, False, 12.0,
+      'official16_landmask', pl16, _lib.MODE_DET_ACC, f32, pool, False, 12.0,
       'MODE_DET_ACC f32, the 16 regions of scripts/evaluate.py:345-395 incl. '
       'global_land / extra-tropics_land / tropics_land (2-D mask: WF = true)')
   out['skipna'] = run(
       'skipna', pl13, _lib.MODE_DET_ACC, f32, pool, True, 12.0,
       'MODE_DET_ACC f32, 13 regions, skipna = True (K = 10 slots)')
   out['det_no_acc'] = run(
-      'det', pl13, _lib.MODE_DET, f32[:2], pool, False, 8.0,
+      'det_no_acc', pl13, _lib.MODE_DET, f32[:2], pool, False, 8.0,
       'MODE_DET f32 (MSE / RMSE / MAE / Bias without a climatology), 13 regions')
   out['wind'] = run(
       'wind', pl13, _lib.MODE_WIND, [fpool, tpool, cpool, fpool], pool, False,
@@ -1153,16 +1163,19 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30) -> dict:
       'lonlat', pl_ll, _lib.MODE_DET_ACC, ll, pool, False, 12.0,
       'MODE_DET_ACC f32 on (..., longitude, latitude) slabs (721 columns: '
       'rows are not 16-byte aligned), 13 regions')
-  out['lonlat']['rows_per_chunk'] = plan_lib.auto_rows_per_chunk(N_LON, n_outer)
-  pool64 = units + 8
-  gen = torch.Generator(device=dev).manual_seed(77)
-  f64 = [torch.randn((pool64 * N_LEV, N_LAT, N_LON), generator=gen, device=dev,
-                     dtype=torch.float64) for _ in range(3)]
-  out['f64_inputs'] = run(
-      'f64', pl13, _lib.MODE_DET_ACC, f64, pool64, False, 24.0,
-      'MODE_DET_ACC float64 inputs (24 B/pt), 13 regions')
-  del f64
-  return out
+  if out['lonlat'] is not None:
+    out['lonlat']['rows_per_chunk'] = plan_lib.auto_rows_per_chunk(N_LON,
+                                                                   n_outer)
+  if only in (None, 'f64_inputs'):
+    pool64 = units + 8
+    gen = torch.Generator(device=dev).manual_seed(77)
+    f64 = [torch.randn((pool64 * N_LEV, N_LAT, N_LON), generator=gen,
+                       device=dev, dtype=torch.float64) for _ in range(3)]
+    out['f64_inputs'] = run(
+        'f64_inputs', pl13, _lib.MODE_DET_ACC, f64, pool64, False, 24.0,
+        'MODE_DET_ACC float64 inputs (24 B/pt), 13 regions')
+    del f64
+  return {k: v for k, v in out.items() if v is not None}
 
 
 def live_traffic(units, pool, rows_per_chunk) -> dict:

@@ -112,6 +112,13 @@ int wb2_num_slots(int mode, int skipna);
 /* Columns one wavefront covers (64 lanes x 16-byte vectors when n_col and the
  * base pointers allow it); n_ctile = ceil(n_col / wb2_tile_cols(...)). */
 int wb2_tile_cols(int dtype, int n_col, int aligned16);
+/* The same for a given instantiation: the register-heavy ones (WB2_MODE_DET_ACC
+ * with skipna or a 2-D weight field) cover half as many columns per wavefront
+ * (8-byte vectors).  wb2_tile_cols(d, n, a) == wb2_tile_cols_ex(WB2_MODE_DET,
+ * d, 0, 0, n, a).  Callers of wb2_stream_partials[_ex] size n_ctile / seg_eoff
+ * with THIS function. */
+int wb2_tile_cols_ex(int mode, int dtype, int skipna, int has_wfield, int n_col,
+                     int aligned16);
 
 /*
  * K1: fused weighted streaming reduction.  Replaces the elementwise temporaries
@@ -140,7 +147,8 @@ int wb2_tile_cols(int dtype, int n_col, int aligned16);
  *  partials    DEV  double[n_outer][n_chunk][nwf][n_ts][K] (out),
  *                   nwf = wfield ? 2 : 1, K = wb2_num_slots(mode, skipna).
  *                   Entries of padding chunks are not written.
- *  n_ctile          must equal ceil(n_col / wb2_tile_cols(dtype, n_col, a16))
+ *  n_ctile          must equal ceil(n_col / wb2_tile_cols_ex(mode, dtype, skipna,
+ *                   wfield != NULL, n_col, a16))
  *                   with a16 = all of in[] (and wfield) are 16-byte aligned; it
  *                   is passed explicitly so that the caller's allocation of
  *                   `partials` and the launch can never disagree.

@@ -76,9 +76,18 @@ ORACLE_TOL = dict(rtol=1e-12, atol=1e-13)
 # uses the same float32-valued weights but sums and returns float64
 # -- both agree with the reference to float32 summation noise.
 F32_COORD_TOL = dict(rtol=5e-5, atol=5e-6)
+# The same at 721 x 1440 (a million points per sum): two float32 evaluations of
+# the reference's expression that differ only in summation order -- the
+# stand-in's dot (what the vectors hold) and the oracle's einsum -- are 1e-4
+# apart (ACC / MSE, global region; measured: DESIGN.md 4), while the float64
+# sums of the product sit within 1e-6 of the stand-in's.  The reference's
+# float32 number is only defined to that noise.
+F32_COORD_TOL_ERA5 = dict(rtol=3e-4, atol=5e-6)
 
 
 def _tolerance_gpu(cname):
+  if cname.endswith('era5_coords32'):
+    return F32_COORD_TOL_ERA5
   if cname.endswith('coords32'):
     return F32_COORD_TOL
   if cname.startswith('ens') or cname.startswith('spatial_ens'):
@@ -117,7 +126,8 @@ def test_oracle_reproduces_the_reference(vectors, cname):
           # region multiplies them by a float64 field (float64 result)
           f32 = rlabel in ('global', 'europe')
           assert vectors[key].dtype == (np.float32 if f32 else np.float64)
-          tol = F32_COORD_TOL if f32 else ORACLE_TOL
+          tol = ((F32_COORD_TOL_ERA5 if 'era5' in cname else F32_COORD_TOL)
+                 if f32 else ORACLE_TOL)
         helpers.assert_close(got.data, vectors[key], err_msg=key, **tol)
         n += 1
   assert n > 0

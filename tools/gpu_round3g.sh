@@ -1,0 +1,39 @@
+# Round 3: workgroup width of K1 (waves per workgroup; every wave is independent)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r3g
+mkdir -p $O
+V=$GRAFT_REPO_ROOT/build/variants
+for n in default wg4 wg3 wg2 wg1 default wg3 wg2; do
+  lib=""; [ "$n" != default ] && lib=$V/libwb2hip_$n.so
+  WB2HIP_LIB=$lib timeout 300 python - <<PY | tee -a $O/variants.txt
+import json, sys, torch
+sys.path.insert(0, '.')
+import bench
+dev = torch.device('cuda', 0)
+gen = torch.Generator(device=dev).manual_seed(1)
+pool = 48
+mk = lambda: torch.randn((pool * 13, 721, 1440), generator=gen, device=dev)
+f, t, c = mk(), mk(), mk()
+res = []
+from weatherbench2_amd import _lib, engine, plan as plan_lib
+import numpy as np
+lat = np.linspace(-90, 90, 721); lon = np.linspace(0, 360, 1440, endpoint=False)
+pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, bench.predefined_regions(), dev, rows_per_chunk=32)
+lev = torch.arange(13, device=dev)
+timer = bench.KernelTimer()
+def tabs(s):
+  u = (s * 16 + torch.arange(16, device=dev)) % pool
+  return [(((u * (2 * j + 1) + 3 * j) % pool)[:, None] * 13 + lev[None]).reshape(-1).contiguous() for j in range(3)]
+T = [tabs(s) for s in range(64)]
+for i in range(10): engine.stream_reduce(pl, _lib.MODE_DET_ACC, [f, t, c], T[i], 208, False)
+engine.set_launch_hook(timer)
+for i in range(50): engine.stream_reduce(pl, _lib.MODE_DET_ACC, [f, t, c], T[10 + i], 208, False)
+engine.set_launch_hook(None); torch.cuda.synchronize()
+ms = timer.mean_ms()
+res.append('headline=%.4f(%.3f)' % (ms, 16 * 13 * 721 * 1440 * 12 / ms / 1e6 / 8000))
+for only in ('official16_landmask', 'skipna', 'det_no_acc', 'f64_inputs'):
+  out = bench.k1_variants(dev, f, t, c, 16, pool, only=only)
+  res += ['%s=%.4f(%.3f)' % (k, v['kernel_ms'], v['frac']) for k, v in out.items()]
+print('$n', ' '.join(res))
+PY
+done

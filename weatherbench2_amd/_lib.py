@@ -37,6 +37,7 @@ _SIGNATURES = {
     'wb2_last_error': (_c.c_char_p, []),
     'wb2_num_slots': (_int, [_int, _int]),
     'wb2_tile_cols': (_int, [_int, _int, _int]),
+    'wb2_tile_cols_ex': (_int, [_int, _int, _int, _int, _int, _int]),
     'wb2_stream_partials': (_int, [
         _int, _int, _int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i32, _i32,
         _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),

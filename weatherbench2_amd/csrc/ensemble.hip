@@ -494,6 +494,10 @@ __device__ __forceinline__ void ens_point_large(
   }
 }
 
+#ifndef WB2_ENS_WG_WAVES
+#define WB2_ENS_WG_WAVES 4   // waves per workgroup (independent waves)
+#endif
+
 template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
 __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
     ens_partials_kernel(const EnsParams p) {
@@ -788,7 +792,7 @@ template <typename T>
 int launch_ens_threshold(const EnsThrParams& q, bool skipna, bool wf,
                          hipStream_t stream) {
   const EnsParams& p = q.e;
-  int nwave = p.n_ctile < 4 ? p.n_ctile : 4;
+  int nwave = p.n_ctile < WB2_ENS_WG_WAVES ? p.n_ctile : WB2_ENS_WG_WAVES;
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
   const long long gz = (p.n_outer + gy - 1) / gy;
@@ -808,7 +812,7 @@ int launch_ens_threshold(const EnsThrParams& q, bool skipna, bool wf,
 
 template <typename T, int NPAD, int MS>
 int launch_ens(const EnsParams& p, bool skipna, bool wf, hipStream_t stream) {
-  int nwave = p.n_ctile < 4 ? p.n_ctile : 4;
+  int nwave = p.n_ctile < WB2_ENS_WG_WAVES ? p.n_ctile : WB2_ENS_WG_WAVES;
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
   const long long gz = (p.n_outer + gy - 1) / gy;

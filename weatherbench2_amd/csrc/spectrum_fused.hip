@@ -50,6 +50,9 @@
 #ifndef WB2_FFT_MIN_WAVES
 #define WB2_FFT_MIN_WAVES 1
 #endif
+#ifndef WB2_FFT_NWAVE
+#define WB2_FFT_NWAVE 4   // waves (= rows in flight) per workgroup
+#endif
 #ifndef WB2_FFT_ASM_CMUL
 #define WB2_FFT_ASM_CMUL 1   // 0: let hipcc build (-w.y, w.x) per twiddle (2 extra VALU)
 #endif
@@ -209,14 +212,14 @@ __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
 enum { MATERIALISE = 0, TIME_MEAN = 1, LATSEG = 2 };
 
 template <int N2, int MODE, bool STAGED = false>
-__global__ void __launch_bounds__(256, WB2_FFT_MIN_WAVES)
+__global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
     fused_spectrum_kernel(const FusedParams p) {
   using PL = Plan<N2>;
   constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2;
   using P0 = Pass<N2, R0, 1, 1, 0, PL::PAD0>;
   using P1 = Pass<N2, R1, R0, R0, PL::PAD0, PL::PAD1>;
   using P2 = Pass<N2, R2, R0 * R1, R0 * R1, PL::PAD1, 0>;
-  constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = 4;
+  constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = WB2_FFT_NWAVE;
   constexpr int NH = N2 / 2 + 1;  // bin pairs (k, N2 - k), k = 0..N2/2
   constexpr int NIT = (NH + kWave - 1) / kWave;
   constexpr bool REDUCE = MODE != MATERIALISE;
@@ -485,7 +488,8 @@ int resident_blocks(K kernel) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) !=
           hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) !=
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel,
+                                                   64 * WB2_FFT_NWAVE, 0) !=
           hipSuccess ||
       per_cu <= 0 || cus <= 0)
     return 768;
@@ -498,10 +502,12 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
   long long rows_out = p.n_rows;
   if (mode == TIME_MEAN) rows_out = p.n_rows / p.n_time;
   if (mode == LATSEG) rows_out = p.n_rows / p.n_lat * p.n_seg;
-  long long blocks = (rows_out + 3) / 4;
+  long long blocks = (rows_out + WB2_FFT_NWAVE - 1) / WB2_FFT_NWAVE;
   WB2_REQUIRE(p.n_time < 65536, "fused time mean: n_time=%lld exceeds 65535",
               p.n_time);
-  if (blocks > WB2_FFT_MAX_BLOCKS) blocks = WB2_FFT_MAX_BLOCKS;  // row-strided waves beyond that
+  // row-strided waves beyond that (the cap counts 4-wave workgroups)
+  if (blocks > WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE)
+    blocks = WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE;
   // the LDS DMA moves 16 bytes per lane: rows must start 16-byte aligned
   const bool staged = WB2_FFT_STAGE && mode != MATERIALISE &&
                       reinterpret_cast<uintptr_t>(p.x) % 16 == 0 &&
@@ -509,13 +515,13 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
 #if WB2_FFT_STAGE
   if (mode == TIME_MEAN && staged) {
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN, true>),
-                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+                       dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
     WB2_HIP_OK(hipGetLastError());
     return 0;
   }
   if (mode == LATSEG && staged) {
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, LATSEG, true>),
-                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+                       dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
     WB2_HIP_OK(hipGetLastError());
     return 0;
   }
@@ -523,13 +529,13 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
   (void)staged;
   if (mode == TIME_MEAN)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN>),
-                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+                       dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
   else if (mode == LATSEG)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, LATSEG>),
-                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+                       dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
   else
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, MATERIALISE>),
-                       dim3((unsigned)blocks), dim3(256), 0, s, p);
+                       dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -541,7 +547,7 @@ int latseg_segments(long long n_field, int n_lat) {
   // (sized for the staged instantiation: its LDS footprint is the larger one,
   // so the task count also fits the unstaged fallback)
   const long long waves =
-      4LL * resident_blocks(fused_spectrum_kernel<N2, LATSEG, WB2_FFT_STAGE != 0>);
+      (long long)WB2_FFT_NWAVE * resident_blocks(fused_spectrum_kernel<N2, LATSEG, WB2_FFT_STAGE != 0>);
   long long n_seg = waves / (n_field > 0 ? n_field : 1);
   if (n_seg < 1) n_seg = 1;
   if (n_seg > n_lat) n_seg = n_lat;

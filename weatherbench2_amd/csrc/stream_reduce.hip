@@ -81,6 +81,19 @@ struct ModeTraits<WB2_MODE_SEEPS, S> {
 // One grid point: inputs -> the K values whose weighted sums we need.  With
 // SKIPNA, NaN numerators become 0 and the trailing slots carry notnull() as
 // 1.0/0.0 so that the same weighted accumulation yields xarray's sum_of_weights.
+// skipna: `ok ? v : 0` for a float32 value as ONE v_mul_legacy_f32 with the
+// flag as a 1.0f / 0.0f multiplier (DX9 rule: 0 * anything, NaN and Inf
+// included, is 0; times 1.0 is exact) -- hipcc turns the select into a 64-bit
+// one after the conversion otherwise (two v_cndmask per slot).
+__device__ __forceinline__ float keep_if(float v, float flag) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(flag));
+  return r;
+}
+__device__ __forceinline__ double keep_if(double v, double flag) {
+  return flag != 0.0 ? v : 0.0;
+}
+
 template <int MODE, bool SKIPNA, typename T>
 __device__ __forceinline__ void eval_slots(
     const T (&in)[ModeTraits<MODE, SKIPNA>::NIN],
@@ -166,7 +179,7 @@ __device__ __forceinline__ void eval_slots(
     const T q = du * du + dv * dv;  // metrics.py:195-197
     if constexpr (SKIPNA) {
       const bool ok = !is_nan(q);
-      x[0] = ok ? (double)q : 0.0;
+      x[0] = (double)(ok ? q : (T)0);
       x[1] = ok ? 1.0 : 0.0;
     } else {
       x[0] = (double)q;
@@ -177,10 +190,12 @@ __device__ __forceinline__ void eval_slots(
     const T ad = abs_of(d);  // MAE
     const T d2 = d * d;      // MSE / RMSE
     if constexpr (SKIPNA) {
-      const bool ok = !is_nan(d);
-      x[0] = ok ? (double)d : 0.0;
-      x[1] = ok ? (double)ad : 0.0;
-      x[2] = ok ? (double)d2 : 0.0;
+      // the selects act on the input dtype (one v_cndmask for float32, not
+      // the two of a float64 select); the conversion of 0 is exact
+      const T okd = !is_nan(d) ? (T)1 : (T)0;
+      x[0] = (double)keep_if(d, okd);
+      x[1] = (double)keep_if(ad, okd);
+      x[2] = (double)keep_if(d2, okd);
     } else {
       x[0] = (double)d;
       x[1] = (double)ad;
@@ -192,15 +207,16 @@ __device__ __forceinline__ void eval_slots(
       const T ta = t - c;  // metrics.py:406
       const T p = fa * ta, fa2 = fa * fa, ta2 = ta * ta;
       if constexpr (SKIPNA) {
-        const bool okd = !is_nan(d), okp = !is_nan(p), okf = !is_nan(fa2),
-                   okt = !is_nan(ta2);
-        x[3] = okp ? (double)p : 0.0;
-        x[4] = okf ? (double)fa2 : 0.0;
-        x[5] = okt ? (double)ta2 : 0.0;
-        x[6] = okd ? 1.0 : 0.0;
-        x[7] = okp ? 1.0 : 0.0;
-        x[8] = okf ? 1.0 : 0.0;
-        x[9] = okt ? 1.0 : 0.0;
+        const T okd = !is_nan(d) ? (T)1 : (T)0, okp = !is_nan(p) ? (T)1 : (T)0,
+                okf = !is_nan(fa2) ? (T)1 : (T)0,
+                okt = !is_nan(ta2) ? (T)1 : (T)0;
+        x[3] = (double)keep_if(p, okp);
+        x[4] = (double)keep_if(fa2, okf);
+        x[5] = (double)keep_if(ta2, okt);
+        x[6] = (double)okd;
+        x[7] = (double)okp;
+        x[8] = (double)okf;
+        x[9] = (double)okt;
       } else {
         x[3] = (double)p;
         x[4] = (double)fa2;
@@ -222,8 +238,25 @@ __device__ __forceinline__ void eval_slots(
 #ifndef WB2_F32_VEC
 #define WB2_F32_VEC 4         // float32 columns per lane (16-byte loads)
 #endif
+#ifndef WB2_F32_VEC_HEAVY
+// float32 columns per lane of the register-heavy DET_ACC instantiations (a 2-D
+// weight field: two accumulator sets; skipna: 10 slots): with 4 columns they
+// need 150-252 VGPRs = 2-3 waves per SIMD and ran at 0.43-0.46 of the HBM peak
+// (profiles/r03_k1_variants.md); 2 columns (8-byte loads) halve the
+// accumulators.
+#define WB2_F32_VEC_HEAVY 2
+#endif
 #ifndef WB2_NT_LOADS
 #define WB2_NT_LOADS 1
+#endif
+#ifndef WB2_WF_OUTER_FASTEST
+// Workgroup order of the weight-field instantiations: 1 = the outer slab is the
+// fastest-varying grid dim, so the workgroups resident at any moment work on
+// the SAME few row chunks of different slabs and re-read the same ~1 MB of the
+// 2-D weight field from L2 (with the chunk fastest, as the field-free kernels
+// run, the field is re-fetched through the fabric for every slab: measured
+// 1.6 x the algorithmic bytes, profiles/r03_k1_variants.md).
+#define WB2_WF_OUTER_FASTEST 1
 #endif
 #ifndef WB2_DIAG
 #define WB2_DIAG 0  // 1: skip the fold/store epilogue, 2: trivial arithmetic
@@ -273,23 +306,31 @@ __device__ __forceinline__ void load_wf(const double* __restrict__ p,
 // branch-free on purpose: every scalar (table / slab-index) load is issued
 // before the first wait, instead of one dependent round trip per table.
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
-__global__ void __launch_bounds__(512, WB2_MIN_WAVES)
+__global__ void __launch_bounds__(
+    512, (WF && !SKIPNA && sizeof(T) * VEC == 8 && MODE == WB2_MODE_DET_ACC)
+             ? 4 : WB2_MIN_WAVES)  // the 2-column weight-field kernel needs 130
+                                   // VGPRs unprompted: 128 = 4 waves per SIMD
     stream_partials_kernel(const StreamParams p) {
   using M = ModeTraits<MODE, SKIPNA>;
   constexpr int NIN = M::NIN, K = M::K, NWF = WF ? 2 : 1;
+  // rows per batch: the same bytes in flight per lane for 16- and 8-byte loads
   constexpr int U = (sizeof(T) * VEC >= 16)
                         ? (NIN >= 4 ? WB2_U_ROWS / 2 : WB2_U_ROWS)
-                        : WB2_U_ROWS_NARROW;
+                        : (sizeof(T) * VEC == 8 ? 2 * WB2_U_ROWS
+                                                : WB2_U_ROWS_NARROW);
   constexpr int TILE = kWave * VEC;
 
   const int lane = threadIdx.x & (kWave - 1);
   // readfirstlane: tell the compiler the wave index is wave-uniform (SGPR).
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int nwave = blockDim.x / kWave;
-  const unsigned bx = blockIdx.x;
+  constexpr bool OUTER_FASTEST = WF && WB2_WF_OUTER_FASTEST;
+  const unsigned bx = OUTER_FASTEST ? blockIdx.y : blockIdx.x;
   const unsigned tblk = bx / (unsigned)p.n_chunk;
   const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
-  const long long o = (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  const long long o =
+      OUTER_FASTEST ? (long long)blockIdx.z * gridDim.x + blockIdx.x
+                    : (long long)blockIdx.z * gridDim.y + blockIdx.y;
   const int tile = (int)tblk * nwave + wave;
 
   // ---- branch-free prologue: issue every scalar load before any wait ----
@@ -353,12 +394,21 @@ __global__ void __launch_bounds__(512, WB2_MIN_WAVES)
 #endif
         if constexpr (WF) {
           // metrics.py:159-160: values where the weight is not > 0 become 0.
+          // The field is >= 0 and finite (plan.py rejects anything else), so
+          // outside w2 = wr * 0 = 0 and the slot only has to be FINITE to drop
+          // out of the sum: clearing the high dword (sign, exponent, top of the
+          // mantissa) of the float64 slot does that in ONE 32-bit AND instead
+          // of the two v_cndmask of a 64-bit select.
           const bool inside = wf[e] > 0.0;
-          const double w2 = inside ? wr * wf[e] : 0.0;
+          const unsigned long long keep =
+              inside ? ~0ull : 0x00000000ffffffffull;
+          const double w2 = wr * wf[e];
 #pragma unroll
-          for (int k = 0; k < K; ++k)
-            acc[1][e][k] =
-                __builtin_fma(w2, inside ? x[k] : 0.0, acc[1][e][k]);
+          for (int k = 0; k < K; ++k) {
+            const double xs = __builtin_bit_cast(
+                double, __builtin_bit_cast(unsigned long long, x[k]) & keep);
+            acc[1][e][k] = __builtin_fma(w2, xs, acc[1][e][k]);
+          }
         }
       }
     };
@@ -695,7 +745,10 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
   const long long gz = (p.n_outer + gy - 1) / gy;  // kernel guards o < n_outer
-  const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
+  const dim3 grid =
+      (WF && WB2_WF_OUTER_FASTEST)
+          ? dim3((unsigned)gy, (unsigned)(p.n_chunk * n_tblk), (unsigned)gz)
+          : dim3((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
   hipLaunchKernelGGL((stream_partials_kernel<T, VEC, MODE, SKIPNA, WF>), grid,
                      dim3(threads), 0, stream, p);
   WB2_HIP_OK(hipGetLastError());
@@ -714,13 +767,19 @@ int launch_stream_flags(const StreamParams& p, bool skipna, bool wf,
 }
 
 template <typename T, int VECW>
-int launch_stream_mode(const StreamParams& p, int mode, bool vec, bool skipna,
+int launch_stream_mode(const StreamParams& p, int mode, int vec, bool skipna,
                        bool wf, int threads, hipStream_t stream) {
+  // the narrower vector of the register-heavy instantiations (vec_width)
+  if (std::is_same<T, float>::value && mode == WB2_MODE_DET_ACC &&
+      vec == WB2_F32_VEC_HEAVY && WB2_F32_VEC_HEAVY != VECW && vec > 1)
+    return launch_stream_flags<T, WB2_F32_VEC_HEAVY, WB2_MODE_DET_ACC>(
+        p, skipna, wf, threads, stream);
 #define WB2_MODE_CASE(M)                                                     \
   case M:                                                                    \
-    return vec ? launch_stream_flags<T, VECW, M>(p, skipna, wf, threads,     \
-                                                 stream)                     \
-               : launch_stream_flags<T, 1, M>(p, skipna, wf, threads, stream);
+    return vec > 1 ? launch_stream_flags<T, VECW, M>(p, skipna, wf, threads, \
+                                                     stream)                 \
+                   : launch_stream_flags<T, 1, M>(p, skipna, wf, threads,    \
+                                                  stream);
   switch (mode) {
     WB2_MODE_CASE(WB2_MODE_DET)
     WB2_MODE_CASE(WB2_MODE_DET_ACC)
@@ -733,8 +792,11 @@ int launch_stream_mode(const StreamParams& p, int mode, bool vec, bool skipna,
   return fail("unknown mode %d", mode);
 }
 
-int vec_width(int dtype, int n_col, bool aligned16) {
-  const int w = dtype == WB2_F32 ? WB2_F32_VEC : 2;
+int vec_width(int mode, int dtype, bool skipna, bool wf, int n_col,
+              bool aligned16) {
+  int w = dtype == WB2_F32 ? WB2_F32_VEC : 2;
+  if (dtype == WB2_F32 && mode == WB2_MODE_DET_ACC && (skipna || wf))
+    w = WB2_F32_VEC_HEAVY;
   return (aligned16 && n_col % w == 0) ? w : 1;
 }
 
@@ -767,10 +829,25 @@ __global__ void __launch_bounds__(256) seeps_map_kernel(const SeepsMapParams p) 
 }
 
 // One wave per column tile; up to 8 tiles share a workgroup.
+#ifndef WB2_MAX_WG_WAVES
+// Waves per workgroup.  Every wave is independent (no LDS, no barrier), so the
+// workgroup is only a scheduling unit: with 2 waves instead of 6-8 the headline
+// kernel gains 4 % (0.435 -> 0.418 ms), the weight-field and skipna
+// instantiations 8-11 % (same box, interleaved: profiles/r03_k1_variants.md) --
+// a wave that finishes its chunk frees its slot without waiting for five others.
+#define WB2_MAX_WG_WAVES 2
+#endif
+
 int threads_for(int n_col, int vec) {
   const int lanes = (n_col + vec - 1) / vec;
-  int threads = ((lanes + kWave - 1) / kWave) * kWave;
-  return threads > 512 ? 512 : threads;
+  const int tiles = (lanes + kWave - 1) / kWave;
+  if (tiles <= WB2_MAX_WG_WAVES) return tiles * kWave;
+  // more tiles than the waves of a workgroup: the widest workgroup that
+  // divides them leaves no idle wave (1440 columns, 2 per lane: 12 tiles =
+  // 2 x 6 waves)
+  for (int w = WB2_MAX_WG_WAVES; w >= 3; --w)
+    if (tiles % w == 0) return w * kWave;
+  return WB2_MAX_WG_WAVES * kWave;
 }
 
 int mode_nin(int mode) {
@@ -797,8 +874,14 @@ int wb2_num_slots(int mode, int skipna) {
 }
 
 int wb2_tile_cols(int dtype, int n_col, int aligned16) {
+  return wb2_tile_cols_ex(WB2_MODE_DET, dtype, 0, 0, n_col, aligned16);
+}
+
+int wb2_tile_cols_ex(int mode, int dtype, int skipna, int has_wfield, int n_col,
+                     int aligned16) {
   if (dtype != WB2_F32 && dtype != WB2_F64) return wb2::fail("bad dtype");
-  return wb2::kWave * wb2::vec_width(dtype, n_col, aligned16 != 0);
+  return wb2::kWave * wb2::vec_width(mode, dtype, skipna != 0, has_wfield != 0,
+                                     n_col, aligned16 != 0);
 }
 
 int wb2_stream_partials(int mode, int dtype, int skipna,
@@ -859,7 +942,8 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
     aligned = aligned && (reinterpret_cast<uintptr_t>(in[i]) % 16 == 0);
   }
   if (wfield) aligned = aligned && reinterpret_cast<uintptr_t>(wfield) % 16 == 0;
-  const int vec = vec_width(dtype, n_col, aligned);
+  const int vec = vec_width(mode, dtype, skipna != 0, wfield != nullptr, n_col,
+                            aligned);
   const int threads = threads_for(n_col, vec);
   p.w_row = w_row;
   p.w_col = w_col;
@@ -879,14 +963,14 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
   p.n_ctile = (n_col + kWave * vec - 1) / (kWave * vec);
   WB2_REQUIRE(p.n_ctile == n_ctile,
               "n_ctile=%d does not match the launch geometry (%d): inputs "
-              "must be 16-byte aligned iff wb2_tile_cols() was asked so",
+              "must be 16-byte aligned iff wb2_tile_cols_ex() was asked so",
               n_ctile, p.n_ctile);
   p.n_seg = n_seg;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == WB2_F32)
-    return launch_stream_mode<float, WB2_F32_VEC>(p, mode, vec > 1, skipna != 0,
+    return launch_stream_mode<float, WB2_F32_VEC>(p, mode, vec, skipna != 0,
                                         wfield != nullptr, threads, s);
-  return launch_stream_mode<double, 2>(p, mode, vec > 1, skipna != 0,
+  return launch_stream_mode<double, 2>(p, mode, vec, skipna != 0,
                                        wfield != nullptr, threads, s);
 }
 

@@ -266,7 +266,9 @@ def stream_reduce(plan: ReductionPlan, mode: int,
   k = lib.wb2_num_slots(mode, int(skipna))
   aligned = all(x.data_ptr() % 16 == 0 for x in inputs) and (
       plan.wfield is None or plan.wfield.data_ptr() % 16 == 0)
-  tile = lib.wb2_tile_cols(code, plan.n_col, int(aligned))
+  tile = lib.wb2_tile_cols_ex(mode, code, int(skipna),
+                              int(plan.wfield is not None), plan.n_col,
+                              int(aligned))
   n_ctile = -(-plan.n_col // tile)
   stream = current_stream_ptr(dev)
   seg_eoff, n_ts = plan.seg_entries(tile)

@@ -164,8 +164,8 @@ def build_plan(latitude: np.ndarray, longitude: np.ndarray, layout: str,
         raise NotImplementedError(
             'more than one distinct 2-D weight field per pass; evaluate the '
             'regions in separate groups')
-    if (field < 0).any():
-      raise NotImplementedError('negative 2-D region weights')
+    if (field < 0).any() or not np.isfinite(field).all():
+      raise NotImplementedError('negative or non-finite 2-D region weights')
 
   lat_mult = np.stack([s.lat_mult for s in specs], axis=1)  # [n_lat, R]
   lon_mult = np.stack([s.lon_mult for s in specs], axis=1)  # [n_lon, R]
