@@ -375,3 +375,49 @@ def test_large_ensembles_take_the_streaming_path(gm, ensemble_size, dtype,
   da = got['geopotential']
   v = da.data.cpu().numpy() if hasattr(da.data, 'cpu') else np.asarray(da.data)
   helpers.assert_close(v, want['geopotential'].transpose(*da.dims).data, **tol)
+
+
+def test_exact_50_members_reference_fp64_chain_is_selectable():
+  """WB2HIP_ENS_REFERENCE_SPREAD=1 (read once per process, hence the child
+  process): the 50-member float32 launch takes the padded network with the
+  reference's fp64 rank-weighted sum (int64 x float32 -> float64,
+  metrics.py:806-812) -- pointwise within fp64 summation-order noise of the
+  oracle, where the default float32-paired form is within one float32
+  rounding (test above).  Both paths stay selectable and tested."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from oracle import metrics_np as om
+from oracle.named import DS
+from tests import helpers
+from weatherbench2_amd import metrics as gm
+rng = np.random.default_rng(11)
+M, T, NLAT, NLON = 50, 2, 19, 36
+f = (55000 + 300 * rng.standard_normal((T, NLAT, NLON))[None]
+     + 100 * rng.standard_normal((M, T, NLAT, NLON))).astype(np.float32)
+t = (f.mean(0) + f.std(0) * rng.standard_normal((T, NLAT, NLON))).astype(np.float32)
+coords = {'time': np.arange(T), 'latitude': np.linspace(-85, 85, NLAT),
+          'longitude': np.linspace(0, 350, NLON)}
+forecast = DS({'z': (('realization', 'time', 'latitude', 'longitude'), f)},
+              coords={'realization': np.arange(M), **coords})
+truth = DS({'z': (('time', 'latitude', 'longitude'), t)}, coords=coords)
+g = helpers.to_gpu_dataset
+want = om.SpatialCRPSSpread().compute_chunk(forecast, truth)['z'].data
+got = gm.SpatialCRPSSpread().compute_chunk(g(forecast), g(truth))['z'].values
+print('MAXREL', float(np.max(np.abs(got - want) / np.abs(want))))
+''' % root
+  rel = {}
+  for flag in ('0', '1'):
+    env = dict(os.environ, WB2HIP_ENS_REFERENCE_SPREAD=flag)
+    out = subprocess.run([sys.executable, '-c', code], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rel[flag] = float([l for l in out.stdout.splitlines()
+                       if l.startswith('MAXREL')][-1].split()[1])
+  assert rel['1'] < 1e-13, rel      # the reference's fp64 chain
+  assert rel['0'] < 3e-7, rel       # the default: one float32 rounding
+  assert rel['0'] > rel['1']        # ... and they are different code paths

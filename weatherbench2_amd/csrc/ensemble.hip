@@ -21,6 +21,8 @@
 // Slots: 0 skill, 1 spread, 2 (t-mean)^2, 3 var, 4 std^2, 5 debiased
 //        [skipna: 6 n(skill,mse), 7 n(spread), 8 n(var,std^2), 9 n(debiased)]
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "trace.hpp"
 #include "reduce_common.hpp"
@@ -835,8 +837,19 @@ template <typename T>
 int launch_ens_npad(const EnsParams& p, bool skipna, bool wf,
                     hipStream_t stream) {
   const int m = p.n_member;
-  // exact-size kernel for the operational ensemble size (IFS ENS: 50 members)
-  if (m == 50) return launch_ens<T, 64, 50>(p, skipna, wf, stream);
+  // exact-size kernel for the operational ensemble size (IFS ENS: 50 members).
+  // Its float32 / no-skipna instantiation is the ONE place where K3 is not
+  // operation for operation the reference's arithmetic (rank-weighted sum over
+  // (hi, lo) pairs in float32, ens_point): WB2HIP_ENS_REFERENCE_SPREAD=1 takes
+  // the padded 64-network with the reference's fp64 chain (int64 x float32 ->
+  // float64, metrics.py:806-812) instead -- slower, selectable, tested beside
+  // the default (tests/test_ens_gpu.py).
+  static const bool reference_spread = [] {
+    const char* v = getenv("WB2HIP_ENS_REFERENCE_SPREAD");
+    return v && v[0] && v[0] != '0';
+  }();
+  if (m == 50 && !reference_spread)
+    return launch_ens<T, 64, 50>(p, skipna, wf, stream);
   if (m <= 4) return launch_ens<T, 4, 0>(p, skipna, wf, stream);
   if (m <= 16) return launch_ens<T, 16, 0>(p, skipna, wf, stream);
   if (m <= 32) return launch_ens<T, 32, 0>(p, skipna, wf, stream);
