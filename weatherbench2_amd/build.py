@@ -38,12 +38,34 @@ def needs_rebuild() -> bool:
   return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_fold_check(verbose: bool = True) -> None:
+  """build/fold_check: the standalone device check of the fold primitives
+  (tools/fold_check.hip, run by tests/test_fold_gpu.py)."""
+  src = os.path.join(ROOT, 'tools', 'fold_check.hip')
+  exe = os.path.join(ROOT, 'build', 'fold_check')
+  deps = [src, os.path.join(CSRC, 'reduce_common.hpp'),
+          os.path.join(CSRC, 'common.hpp')]
+  if not os.path.exists(src):
+    return
+  if os.path.exists(exe) and all(
+      os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
+    return
+  os.makedirs(os.path.dirname(exe), exist_ok=True)
+  cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
+         '-Wno-unused-result', '-I' + CSRC, '-I' + os.path.join(ROOT, 'include'),
+         '-o', exe, src]
+  if verbose:
+    print('[wb2hip build]', ' '.join(cmd), file=sys.stderr)
+  subprocess.run(cmd, check=True)
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
   """Compiles every HIP source for gfx950 into weatherbench2_amd/libwb2hip.so.
 
   One hipcc process per translation unit (in parallel), then one link step.
   """
   if not force and not needs_rebuild():
+    build_fold_check(verbose)
     return LIB_PATH
   import concurrent.futures
   obj_dir = os.path.join(ROOT, 'build', 'obj')
@@ -70,6 +92,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
   if verbose:
     print('[wb2hip build]', ' '.join(link), file=sys.stderr)
   subprocess.run(link, check=True)
+  build_fold_check(verbose)
   return LIB_PATH
 
 
