@@ -72,19 +72,19 @@ int run_fold(const std::vector<double>& host) {
   std::vector<int> eoff = {0, 1, 2, 3, 4};
   double *in, *o3, *o6;
   int *c, *e;
-  hipMalloc(&in, host.size() * 8);
-  hipMalloc(&o3, 4 * 3 * 8);
-  hipMalloc(&o6, 4 * 6 * 8);
-  hipMalloc(&c, 5 * 4);
-  hipMalloc(&e, 5 * 4);
-  hipMemcpy(in, host.data(), host.size() * 8, hipMemcpyHostToDevice);
-  hipMemcpy(c, col0.data(), 5 * 4, hipMemcpyHostToDevice);
-  hipMemcpy(e, eoff.data(), 5 * 4, hipMemcpyHostToDevice);
+  (void)hipMalloc(&in, host.size() * 8);
+  (void)hipMalloc(&o3, 4 * 3 * 8);
+  (void)hipMalloc(&o6, 4 * 6 * 8);
+  (void)hipMalloc(&c, 5 * 4);
+  (void)hipMalloc(&e, 5 * 4);
+  (void)hipMemcpy(in, host.data(), host.size() * 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(c, col0.data(), 5 * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(e, eoff.data(), 5 * 4, hipMemcpyHostToDevice);
   hipLaunchKernelGGL((fold_kernel<VEC, 3>), dim3(1), dim3(64), 0, 0, in, c, e, n_seg, 4, n_col, o3);
   hipLaunchKernelGGL((fold_kernel<VEC, 6>), dim3(1), dim3(64), 0, 0, in, c, e, n_seg, 4, n_col, o6);
   std::vector<double> h3(12), h6(24);
-  hipMemcpy(h3.data(), o3, 12 * 8, hipMemcpyDeviceToHost);
-  hipMemcpy(h6.data(), o6, 24 * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(h3.data(), o3, 12 * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(h6.data(), o6, 24 * 8, hipMemcpyDeviceToHost);
   int bad = 0;
   for (int s = 0; s < 4; ++s)
     for (int k = 0; k < 3; ++k)
@@ -100,17 +100,17 @@ template <int N>
 int run(const std::vector<double>& host) {
   double *in, *tree, *ref;
   int* slots;
-  hipMalloc(&in, N * 64 * 8);
-  hipMalloc(&tree, 64 * 8);
-  hipMalloc(&ref, N * 8);
-  hipMalloc(&slots, 64 * 4);
-  hipMemcpy(in, host.data(), N * 64 * 8, hipMemcpyHostToDevice);
+  (void)hipMalloc(&in, N * 64 * 8);
+  (void)hipMalloc(&tree, 64 * 8);
+  (void)hipMalloc(&ref, N * 8);
+  (void)hipMalloc(&slots, 64 * 4);
+  (void)hipMemcpy(in, host.data(), N * 64 * 8, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(check<N>, dim3(1), dim3(64), 0, 0, in, tree, slots, ref);
   std::vector<double> t(64), r(N);
   std::vector<int> s(64);
-  hipMemcpy(t.data(), tree, 64 * 8, hipMemcpyDeviceToHost);
-  hipMemcpy(r.data(), ref, N * 8, hipMemcpyDeviceToHost);
-  hipMemcpy(s.data(), slots, 64 * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(t.data(), tree, 64 * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(r.data(), ref, N * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(s.data(), slots, 64 * 4, hipMemcpyDeviceToHost);
   int bad = 0, seen = 0;
   std::vector<int> have(N, 0);
   for (int l = 0; l < 64; ++l) {
@@ -136,12 +136,12 @@ int main() {
   std::vector<double> ids(128);
   for (int l = 0; l < 64; ++l) { ids[l] = l; ids[64 + l] = 100 + l; }
   double *pin, *pout;
-  hipMalloc(&pin, 128 * 8);
-  hipMalloc(&pout, 512 * 8);
-  hipMemcpy(pin, ids.data(), 128 * 8, hipMemcpyHostToDevice);
+  (void)hipMalloc(&pin, 128 * 8);
+  (void)hipMalloc(&pout, 512 * 8);
+  (void)hipMemcpy(pin, ids.data(), 128 * 8, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(prims, dim3(1), dim3(64), 0, 0, pin, pout);
   std::vector<double> po(512);
-  hipMemcpy(po.data(), pout, 512 * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(po.data(), pout, 512 * 8, hipMemcpyDeviceToHost);
   const char* names[8] = {"swap32 a", "swap32 b", "swap16 a", "swap16 b", "row_ror:8", "quad 0x4E", "quad 0xB1", "swizzle xor4"};
   for (int k = 0; k < 8; ++k) {
     printf("%-13s", names[k]);
