@@ -52,4 +52,4 @@ PY
   done
 done 2>&1 | tee $O/r03_pmc_raw.txt
 ls $O
-timeout 900 python -m pytest -x -q -m gpu tests/test_threads_gpu.py tests/test_bench_gpu.py tests/test_live_traffic_gpu.py tests/test_det_gpu.py tests/test_eval_gpu.py 2>&1 | tail -5 | tee $O/pytest.txt
+timeout 1500 python -m pytest -x -q -m gpu tests > $O/pytest_full.txt 2>&1; grep -E "passed|failed" $O/pytest_full.txt | tail -3 | tee $O/pytest.txt

@@ -50,6 +50,21 @@
 #ifndef WB2_FFT_MIN_WAVES
 #define WB2_FFT_MIN_WAVES 1
 #endif
+#ifndef WB2_FFT_TW_POWERS
+// 1: only the first powers of every butterfly's inter-pass twiddle stay in
+// VGPRs (w^1..w^4 of a radix-12 butterfly, w^1 of a radix-5 one) and the others
+// are derived per row (w^5 = w^4 w, ... : 7 + 3 x 3 complex multiplies, depth
+// <= 3) -- 32 VGPRs less, which buys a fourth wave per SIMD without spills.
+#define WB2_FFT_TW_POWERS 0
+#endif
+#ifndef WB2_FFT_LATSEG_INTERLEAVE
+// LATSEG: 1 = segment `seg` of a field takes the latitudes seg, seg + n_seg,
+// seg + 2 n_seg, ... instead of a contiguous run, so that at any moment the
+// waves of a field read ADJACENT rows (one contiguous window per field instead
+// of n_seg separate streams).  Any partition works: the partials are added up by
+// latseg_combine_kernel.
+#define WB2_FFT_LATSEG_INTERLEAVE 0
+#endif
 #ifndef WB2_FFT_NWAVE
 #define WB2_FFT_NWAVE 4   // waves (= rows in flight) per workgroup
 #endif
@@ -137,6 +152,47 @@ __device__ __forceinline__ void cmul3_asm(cf& a0, cf w0, cf& a1, cf w1, cf& a2,
 #undef WB2_PK_MUL
 #undef WB2_PK_FMA
 
+// a * w (returned), same instruction pair as the in-place forms above
+__device__ __forceinline__ cf cprod_asm(cf a, cf w) {
+  cf t;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\ts_nop 0\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] "
+      "neg_lo:[0,1,0]\n\ts_nop 0"
+      : "=&v"(t)
+      : "v"(a), "v"(w));
+  return t;
+}
+
+// Number of twiddle powers kept resident for a radix-R butterfly.
+template <int R>
+constexpr int resident_powers() {
+#if WB2_FFT_TW_POWERS
+  return R - 1 <= 4 ? 1 : 4;
+#else
+  return R - 1;
+#endif
+}
+
+// w^1 .. w^(R-1) from the resident powers b[0..NB): w^(q+1) for q >= NB is the
+// product of the largest resident-or-derived power of two and the rest.
+template <int R, int NB>
+__device__ __forceinline__ void expand_powers(const cf (&b)[NB], cf (&w)[R - 1]) {
+#pragma unroll
+  for (int q = 0; q < R - 1; ++q) {
+    if (q < NB) {
+      w[q] = b[q];
+    } else {
+      const int e = q + 1;               // the exponent wanted
+      int p2 = 1;
+      while (2 * p2 <= e) p2 *= 2;       // largest power of two <= e
+      const int rest = e - p2;
+      // w^e = w^p2 * w^rest (rest == 0: e is a power of two = (w^(e/2))^2)
+      w[q] = rest == 0 ? cprod_asm(w[e / 2 - 1], w[e / 2 - 1])
+                       : cprod_asm(w[p2 - 1], w[rest - 1]);
+    }
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void twiddle_block(cf* v, const cf* tw) {
   // v[0..N) *= tw[0..N)
@@ -177,15 +233,28 @@ struct FusedParams {
 // A later pass (NS > 1) over the wave's slab: strided reads, twiddle multiplies
 // (the twiddles of a lane depend on the lane only: VGPR-resident for the whole
 // kernel), butterflies, in-place writes.
-template <typename P, int R>
+template <typename P, int R, int NB>
 __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
-                                         const cf (&tw)[P::ROUNDS][P::NTW]) {
+                                         cf (&tw)[P::ROUNDS][NB]) {
   cf v[P::ROUNDS][R];
   P::load([&](int i) { return lds_read(z + i); }, lane, v);
 #if WB2_FFT_ASM_CMUL
 #pragma unroll
-  for (int rd = 0; rd < P::ROUNDS; ++rd) twiddle_block<R - 1>(&v[rd][1], &tw[rd][0]);
+  for (int rd = 0; rd < P::ROUNDS; ++rd) {
+    if constexpr (NB == R - 1) {
+      twiddle_block<R - 1>(&v[rd][1], &tw[rd][0]);
+    } else {
+      // derived per row: the asm keeps hipcc from hoisting the products out of
+      // the row loop (which would bring the registers back)
+#pragma unroll
+      for (int q = 0; q < NB; ++q) asm volatile("" : "+v"(tw[rd][q]));
+      cf w[R - 1];
+      expand_powers<R, NB>(tw[rd], w);
+      twiddle_block<R - 1>(&v[rd][1], &w[0]);
+    }
+  }
 #else
+  static_assert(NB == R - 1, "derived twiddles need the asm multiply");
   P::twiddle(v, tw);
 #endif
   P::butterflies(v);
@@ -233,9 +302,24 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
   for (int i = threadIdx.x; i <= NH; i += blockDim.x)
     s_twq[i] = p.twq[i < NH ? i : NH - 1];
   // inter-pass twiddles: functions of the lane only, resident in VGPRs
-  cf tw1[P1::ROUNDS][P1::NTW], tw2[P2::ROUNDS][P2::NTW];
-  P1::load_twiddles(p.twz, lane, tw1);
-  if constexpr (R2 > 1) P2::load_twiddles(p.twz, lane, tw2);
+  constexpr int NB1 = resident_powers<R1>();
+  constexpr int NB2 = resident_powers<(R2 > 1 ? R2 : 2)>();
+  cf tw1[P1::ROUNDS][NB1], tw2[P2::ROUNDS][NB2];
+  {
+    cf full1[P1::ROUNDS][P1::NTW], full2[P2::ROUNDS][P2::NTW];
+    P1::load_twiddles(p.twz, lane, full1);
+    if constexpr (R2 > 1) P2::load_twiddles(p.twz, lane, full2);
+#pragma unroll
+    for (int rd = 0; rd < P1::ROUNDS; ++rd)
+#pragma unroll
+      for (int q = 0; q < NB1; ++q) tw1[rd][q] = full1[rd][q];
+    if constexpr (R2 > 1) {
+#pragma unroll
+      for (int rd = 0; rd < P2::ROUNDS; ++rd)
+#pragma unroll
+        for (int q = 0; q < NB2; ++q) tw2[rd][q] = full2[rd][q];
+    }
+  }
   __syncthreads();
   cf* z = s_z[wave];
   const float half_inv_n = 0.5f / (float)N;
@@ -259,10 +343,17 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
     } else if constexpr (MODE == LATSEG) {
       const long long field = o / p.n_seg;
       const int seg = (int)(o - field * p.n_seg);
+#if WB2_FFT_LATSEG_INTERLEAVE
+      k.lat0 = seg;
+      k.nt = (p.n_lat - seg + p.n_seg - 1) / p.n_seg;
+      k.row0 = field * p.n_lat + seg;
+      k.row_step = p.n_seg;
+#else
       k.lat0 = (int)((long long)seg * p.n_lat / p.n_seg);  // balanced split
       k.nt = (long long)(seg + 1) * p.n_lat / p.n_seg - k.lat0;
       k.row0 = field * p.n_lat + k.lat0;
       k.row_step = 1;
+#endif
     }
     return k;
   };
@@ -306,7 +397,7 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
     if constexpr (MODE != LATSEG) c = p.circ[(unsigned)(orow_i % p.n_lat)];
     double* orow = p.out + orow_i * NB;
     for (long long t = 0; t < nt; ++t) {
-      if constexpr (MODE == LATSEG) c = p.circ[lat0 + t];
+      if constexpr (MODE == LATSEG) c = p.circ[lat0 + t * row_step];
       const double c2 = 2.0 * c;
       {  // ---- pass 0: HBM -> butterflies -> contiguous runs in the slab
         cf v[P0::ROUNDS][R0];
@@ -337,10 +428,10 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
 #if !(WB2_FFT_DIAG & 1)
-      lds_pass<P1, R1>(z, lane, tw1);
+      lds_pass<P1, R1, NB1>(z, lane, tw1);
 #endif
 #if !(WB2_FFT_DIAG & 2)
-      if constexpr (R2 > 1) lds_pass<P2, R2>(z, lane, tw2);
+      if constexpr (R2 > 1) lds_pass<P2, R2, NB2>(z, lane, tw2);
 #endif
 #if WB2_FFT_DIAG & 4
       {
