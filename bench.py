@@ -265,6 +265,10 @@ def parse_args():
                   help='(tools/live_traffic.py) only run a few launches of the '
                        'benched K1 configuration -- or of one of its variants '
                        '-- for the PMC passes')
+  ap.add_argument('--variants-only', action='store_true',
+                  help="only K1's production instantiations (the `variants` "
+                       'object of the default line), printed as one JSON line: '
+                       'for A/B runs of kernel changes')
   ap.add_argument('--workload', default='deterministic',
                   choices=['deterministic', 'ensemble', 'spectrum',
                            'spectrum_materialized', 'spectrum_mean'],
@@ -467,6 +471,11 @@ def main():
   _ = (total / count).sum().item()
   if ddp:
     all_reduce(torch.cat([total.reshape(-1), count.reshape(-1)]))
+  if args.variants_only:
+    print(json.dumps(k1_variants(dev, fpool, tpool, cpool, units, pool,
+                                 with_headline=True,
+                                 rows=args.rows_per_chunk)))
+    return
   if args.traffic_probe:
     # tools/live_traffic.py: a few launches of exactly the benched K1
     # configuration (or one variant of it) under rocprofv3 --pmc, nothing else
@@ -1093,7 +1102,7 @@ def official_regions():
 
 
 def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
-                only=None) -> dict:
+                only=None, with_headline=False, rows=0) -> dict:
   """Kernel time + fraction of the HBM peak of K1's OTHER production
   instantiations (the headline is MODE_DET_ACC / float32 / 13 slice regions /
   no skipna), same launch size (16 units of 13 x 721 x 1440), same pools:
@@ -1114,7 +1123,7 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
   lon = np.linspace(0, 360, N_LON, endpoint=False)
   lev = torch.arange(N_LEV, device=dev, dtype=torch.int64)
   n_outer = units * N_LEV
-  rows = plan_lib.auto_rows_per_chunk(N_LAT, n_outer)
+  rows = rows or plan_lib.auto_rows_per_chunk(N_LAT, n_outer)
 
   def tabs(step, pool_units, k):
     u = (step * units + torch.arange(units, device=dev)) % pool_units
@@ -1149,6 +1158,9 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
   pl16 = plan_lib.build_plan(lat, lon, plan_lib.LATLON, official_regions(), dev,
                              rows_per_chunk=rows)
   f32 = [fpool, tpool, cpool]
+  if with_headline:  # the benched instantiation beside its variants (A/B runs)
+    out['headline'] = run('headline', pl13, _lib.MODE_DET_ACC, f32, pool, False,
+                          12.0, 'MODE_DET_ACC f32, 13 regions (the benched one)')
   out['official16_landmask'] = run(
       'official16_landmask', pl16, _lib.MODE_DET_ACC, f32, pool, False, 12.0,
       'MODE_DET_ACC f32, the 16 regions of scripts/evaluate.py:345-395 incl. '

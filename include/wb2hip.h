@@ -109,8 +109,11 @@ const char* wb2_last_error(void);
  * them always, but without NaNs they are data independent: metrics.py:161-163). */
 int wb2_num_slots(int mode, int skipna);
 
-/* Columns one wavefront covers (64 lanes x 16-byte vectors when n_col and the
- * base pointers allow it); n_ctile = ceil(n_col / wb2_tile_cols(...)). */
+/* Columns one wavefront covers (64 lanes x 16-byte vectors whenever n_col holds
+ * one vector: rows of any length and element-aligned base pointers take the wide
+ * loads -- `aligned16` only matters with WB2HIP_UNALIGNED_VEC=0, the rule of
+ * rounds 1-3: one column per lane unless everything is 16-byte aligned);
+ * n_ctile = ceil(n_col / wb2_tile_cols(...)). */
 int wb2_tile_cols(int dtype, int n_col, int aligned16);
 /* The same for a given instantiation: the register-heavy ones (WB2_MODE_DET_ACC
  * with skipna or a 2-D weight field) cover half as many columns per wavefront

@@ -60,8 +60,8 @@ __global__ void fold_kernel(const double* in, const int* seg_col0,
   for (int e = 0; e < VEC; ++e)
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[0][e][k] = in[(k * 8 + e) * 64 + lane];
-  fold_tile_to_segs<1, VEC, K>(acc, lane, 0, lane * VEC, n_col, seg_col0,
-                               seg_eoff, n_seg, n_ts, out);
+  fold_tile_to_segs<1, VEC, K>(acc, lane, 0, lane * VEC, lane * VEC, n_col,
+                               seg_col0, seg_eoff, n_seg, n_ts, out);
 }
 
 template <int VEC>

@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
     }
   }
   fold_tile_to_segs<NWF, 1, K>(
-      acc, lane, tile, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg, p.n_ts,
+      acc, lane, tile, col0, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg,
+      p.n_ts,
       p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
 }
 
@@ -749,7 +750,8 @@ __global__ void __launch_bounds__(256)
     }
   }
   fold_tile_to_segs<NWF, 1, K>(
-      acc, lane, tile, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg, p.n_ts,
+      acc, lane, tile, col0, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg,
+      p.n_ts,
       p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
 }
 

@@ -127,10 +127,12 @@ __device__ __forceinline__ void wave_sum_many(double (&v)[N], int lane,
 // butterfly (no LDS, no barrier, fixed order => bit-reproducible) and store the
 // K sums of each (seg, tile) entry.  `out` points at this (outer, chunk)'s
 // [NWF][n_ts][K] block; see seg_eoff in include/wb2hip.h for the entry index.
+// The lane holds the columns col0 .. col0 + VEC - 1 and owns those >= own0
+// (own0 > col0 only for a row-end lane that loaded shifted back).
 template <int NWF, int VEC, int K>
 __device__ __forceinline__ void fold_tile_to_segs(
-    const double (&acc)[NWF][VEC][K], int lane, int tile, int col0, int n_col,
-    const int* __restrict__ seg_col0, const int* __restrict__ seg_eoff,
+    const double (&acc)[NWF][VEC][K], int lane, int tile, int col0, int own0,
+    int n_col, const int* __restrict__ seg_col0, const int* __restrict__ seg_eoff,
     int n_seg, int n_ts, double* __restrict__ out) {
   constexpr int TILE = kWave * VEC;
   const int tile_c0 = tile * TILE;
@@ -149,7 +151,7 @@ __device__ __forceinline__ void fold_tile_to_segs(
       for (int k = 0; k < K; ++k) v[w * K + k] = 0.0;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const bool in_seg = (col0 + e >= c0) && (col0 + e < c1);
+        const bool in_seg = (col0 + e >= max(c0, own0)) && (col0 + e < c1);
 #pragma unroll
         for (int k = 0; k < K; ++k)
           v[w * K + k] += in_seg ? acc[w][e][k] : 0.0;

@@ -27,6 +27,7 @@
 #include "reduce_common.hpp"
 #include "wb2hip.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace wb2 {
@@ -93,6 +94,111 @@ __device__ __forceinline__ float keep_if(float v, float flag) {
 __device__ __forceinline__ double keep_if(double v, double flag) {
   return flag != 0.0 ? v : 0.0;
 }
+
+// The deterministic modes in two stages.  elementwise(): the arithmetic the
+// reference does in the input dtype (metrics.py:195-197, 264, 284, 329, 358,
+// 405-410), written on a value type V that is either T or a 2-vector of T --
+// two adjacent columns of a lane's load go through v_pk_add_f32 / v_pk_mul_f32
+// as ONE instruction each (same IEEE results per component).  slots(): one
+// point's quantities -> the K float64 values whose weighted sums are needed.
+template <int MODE>
+struct PointOps;
+
+template <>
+struct PointOps<WB2_MODE_WIND> {
+  static constexpr int NIN = 4, NQ = 1;
+  template <typename V>
+  static __device__ __forceinline__ void elementwise(const V (&in)[NIN],
+                                                     V (&q)[NQ]) {
+    const V du = in[0] - in[1];
+    const V dv = in[2] - in[3];
+    q[0] = du * du + dv * dv;  // metrics.py:195-197
+  }
+  template <bool SKIPNA, typename T>
+  static __device__ __forceinline__ void slots(
+      const T (&q)[NQ], double (&x)[ModeTraits<WB2_MODE_WIND, SKIPNA>::K]) {
+    if constexpr (SKIPNA) {
+      const bool ok = !is_nan(q[0]);
+      x[0] = (double)(ok ? q[0] : (T)0);
+      x[1] = ok ? 1.0 : 0.0;
+    } else {
+      x[0] = (double)q[0];
+    }
+  }
+};
+
+template <>
+struct PointOps<WB2_MODE_DET> {
+  static constexpr int NIN = 2, NQ = 2;
+  template <typename V>
+  static __device__ __forceinline__ void elementwise(const V (&in)[NIN],
+                                                     V (&q)[NQ]) {
+    const V d = in[0] - in[1];  // metrics.py:264, 284, 329, 358
+    q[0] = d;
+    q[1] = d * d;  // MSE / RMSE
+  }
+  // MAE: |d| converted == the converted d with its sign cleared, which the
+  // float64 FMA takes as a source modifier (no instruction of its own).
+  template <bool SKIPNA, typename T>
+  static __device__ __forceinline__ void slots(
+      const T (&q)[NQ], double (&x)[ModeTraits<WB2_MODE_DET, SKIPNA>::K]) {
+    if constexpr (SKIPNA) {
+      // the selects act on the input dtype (one v_cndmask for float32, not
+      // the two of a float64 select); the conversion of 0 is exact
+      const T okd = !is_nan(q[0]) ? (T)1 : (T)0;
+      x[0] = (double)keep_if(q[0], okd);
+      x[1] = __builtin_fabs(x[0]);
+      x[2] = (double)keep_if(q[1], okd);
+      x[3] = (double)okd;
+    } else {
+      x[0] = (double)q[0];
+      x[1] = __builtin_fabs(x[0]);
+      x[2] = (double)q[1];
+    }
+  }
+};
+
+template <>
+struct PointOps<WB2_MODE_DET_ACC> {
+  static constexpr int NIN = 3, NQ = 5;
+  template <typename V>
+  static __device__ __forceinline__ void elementwise(const V (&in)[NIN],
+                                                     V (&q)[NQ]) {
+    const V d = in[0] - in[1];
+    const V fa = in[0] - in[2];  // metrics.py:405
+    const V ta = in[1] - in[2];  // metrics.py:406
+    q[0] = d;
+    q[1] = d * d;
+    q[2] = fa * ta;
+    q[3] = fa * fa;
+    q[4] = ta * ta;
+  }
+  template <bool SKIPNA, typename T>
+  static __device__ __forceinline__ void slots(
+      const T (&q)[NQ], double (&x)[ModeTraits<WB2_MODE_DET_ACC, SKIPNA>::K]) {
+    if constexpr (SKIPNA) {
+      const T okd = !is_nan(q[0]) ? (T)1 : (T)0,
+              okp = !is_nan(q[2]) ? (T)1 : (T)0,
+              okf = !is_nan(q[3]) ? (T)1 : (T)0,
+              okt = !is_nan(q[4]) ? (T)1 : (T)0;
+      x[0] = (double)keep_if(q[0], okd);
+      x[1] = __builtin_fabs(x[0]);
+      x[2] = (double)keep_if(q[1], okd);
+      x[3] = (double)keep_if(q[2], okp);
+      x[4] = (double)keep_if(q[3], okf);
+      x[5] = (double)keep_if(q[4], okt);
+      x[6] = (double)okd;
+      x[7] = (double)okp;
+      x[8] = (double)okf;
+      x[9] = (double)okt;
+    } else {
+      x[0] = (double)q[0];
+      x[1] = __builtin_fabs(x[0]);
+#pragma unroll
+      for (int j = 1; j < NQ; ++j) x[1 + j] = (double)q[j];
+    }
+  }
+};
 
 template <int MODE, bool SKIPNA, typename T>
 __device__ __forceinline__ void eval_slots(
@@ -173,58 +279,11 @@ __device__ __forceinline__ void eval_slots(
       x[0] = crps;
       x[1] = (double)var;
     }
-  } else if constexpr (MODE == WB2_MODE_WIND) {
-    const T du = in[0] - in[1];
-    const T dv = in[2] - in[3];
-    const T q = du * du + dv * dv;  // metrics.py:195-197
-    if constexpr (SKIPNA) {
-      const bool ok = !is_nan(q);
-      x[0] = (double)(ok ? q : (T)0);
-      x[1] = ok ? 1.0 : 0.0;
-    } else {
-      x[0] = (double)q;
-    }
   } else {
-    const T f = in[0], t = in[1];
-    const T d = f - t;       // metrics.py:264, 284, 329, 358
-    const T ad = abs_of(d);  // MAE
-    const T d2 = d * d;      // MSE / RMSE
-    if constexpr (SKIPNA) {
-      // the selects act on the input dtype (one v_cndmask for float32, not
-      // the two of a float64 select); the conversion of 0 is exact
-      const T okd = !is_nan(d) ? (T)1 : (T)0;
-      x[0] = (double)keep_if(d, okd);
-      x[1] = (double)keep_if(ad, okd);
-      x[2] = (double)keep_if(d2, okd);
-    } else {
-      x[0] = (double)d;
-      x[1] = (double)ad;
-      x[2] = (double)d2;
-    }
-    if constexpr (MODE == WB2_MODE_DET_ACC) {
-      const T c = in[2];
-      const T fa = f - c;  // metrics.py:405
-      const T ta = t - c;  // metrics.py:406
-      const T p = fa * ta, fa2 = fa * fa, ta2 = ta * ta;
-      if constexpr (SKIPNA) {
-        const T okd = !is_nan(d) ? (T)1 : (T)0, okp = !is_nan(p) ? (T)1 : (T)0,
-                okf = !is_nan(fa2) ? (T)1 : (T)0,
-                okt = !is_nan(ta2) ? (T)1 : (T)0;
-        x[3] = (double)keep_if(p, okp);
-        x[4] = (double)keep_if(fa2, okf);
-        x[5] = (double)keep_if(ta2, okt);
-        x[6] = (double)okd;
-        x[7] = (double)okp;
-        x[8] = (double)okf;
-        x[9] = (double)okt;
-      } else {
-        x[3] = (double)p;
-        x[4] = (double)fa2;
-        x[5] = (double)ta2;
-      }
-    } else if constexpr (SKIPNA) {
-      x[3] = !is_nan(d) ? 1.0 : 0.0;
-    }
+    // DET / DET_ACC / WIND: the elementwise stage, then the slots
+    T q[PointOps<MODE>::NQ];
+    PointOps<MODE>::template elementwise<T>(in, q);
+    PointOps<MODE>::template slots<SKIPNA, T>(q, x);
   }
 }
 
@@ -240,11 +299,14 @@ __device__ __forceinline__ void eval_slots(
 #endif
 #ifndef WB2_F32_VEC_HEAVY
 // float32 columns per lane of the register-heavy DET_ACC instantiations (a 2-D
-// weight field: two accumulator sets; skipna: 10 slots): with 4 columns they
-// need 150-252 VGPRs = 2-3 waves per SIMD and ran at 0.43-0.46 of the HBM peak
-// (profiles/r03_k1_variants.md); 2 columns (8-byte loads) halve the
-// accumulators.
-#define WB2_F32_VEC_HEAVY 2
+// weight field: two accumulator sets; skipna: 10 slots).  Round 3 first halved
+// it (4 columns: 150-252 VGPRs = 2-3 waves per SIMD, 0.43-0.46 of the HBM peak;
+// 2 columns: 0.51-0.57); with the elementwise stage packed, the fold a halving
+// tree and |d| a source modifier the 4-column kernels need 122 / 157 VGPRs and
+// are the faster ones again (same box, interleaved: weight field 0.455-0.462 ms
+// against 0.463-0.500, skipna 0.445-0.447 against 0.449-0.461;
+// profiles/r03_k1_ab7_summary.txt) -- 1 KB instead of 512 B per wave and row.
+#define WB2_F32_VEC_HEAVY 4
 #endif
 #ifndef WB2_NT_LOADS
 #define WB2_NT_LOADS 1
@@ -258,6 +320,20 @@ __device__ __forceinline__ void eval_slots(
 // 1.6 x the algorithmic bytes, profiles/r03_k1_variants.md).
 #define WB2_WF_OUTER_FASTEST 1
 #endif
+#ifndef WB2_SGPR_ROWS
+// 1: row pointers pinned to SGPR pairs + one 32-bit lane offset (the
+// `global_load v_off, s[base:base+1]` form); 0: plain pointer arithmetic (hipcc
+// adds a 64-bit lane offset to every load's base with a v_lshl_add_u64).
+// Measured (profiles/r03_k1_ab5_summary.txt): the SGPR form is SLOWER -- every
+// load then waits for the scalar add that makes its base (headline 0.418 ->
+// 0.427 ms, weight field 0.500 -> 0.556, skipna 0.463 -> 0.560); only the
+// unaligned lon-lat rows gain (0.493 -> 0.473).
+#define WB2_SGPR_ROWS 0
+#endif
+#ifndef WB2_PACK_PAIRS
+// 1: float32 columns through the elementwise stage in pairs (v_pk_*_f32).
+#define WB2_PACK_PAIRS 1
+#endif
 #ifndef WB2_DIAG
 #define WB2_DIAG 0  // 1: skip the fold/store epilogue, 2: trivial arithmetic
 #endif
@@ -267,6 +343,12 @@ __device__ __forceinline__ void eval_slots(
 #ifndef WB2_MIN_WAVES
 #define WB2_MIN_WAVES 1
 #endif
+#ifndef WB2_WF_MIN_WAVES
+#define WB2_WF_MIN_WAVES 1
+#endif
+#ifndef WB2_SKIPNA_MIN_WAVES
+#define WB2_SKIPNA_MIN_WAVES 1
+#endif
 
 #if WB2_NT_LOADS
 #define WB2_LOAD(ptr) __builtin_nontemporal_load(ptr)
@@ -274,21 +356,25 @@ __device__ __forceinline__ void eval_slots(
 #define WB2_LOAD(ptr) (*(ptr))
 #endif
 
+#define WB2_GLOBAL __attribute__((address_space(1)))
+
 template <typename T, int VEC>
-__device__ __forceinline__ void load_vec(const T* __restrict__ p,
-                                         T (&v)[VEC]) {
+__device__ __forceinline__ void load_vec(const WB2_GLOBAL T* p, T (&v)[VEC]) {
   if constexpr (VEC == 1) {
     v[0] = WB2_LOAD(p);
   } else {
-    typedef T V __attribute__((ext_vector_type(VEC)));
-    const V x = WB2_LOAD(reinterpret_cast<const V*>(p));
+    // Element alignment only: rows of an odd length (721 latitudes last) start
+    // anywhere; gfx950 takes the same global_load_dwordx4 either way.
+    typedef T V0 __attribute__((ext_vector_type(VEC)));
+    typedef V0 V __attribute__((aligned(sizeof(T))));
+    const V0 x = WB2_LOAD(reinterpret_cast<const WB2_GLOBAL V*>(p));
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = x[e];
   }
 }
 
 template <int VEC>
-__device__ __forceinline__ void load_wf(const double* __restrict__ p,
+__device__ __forceinline__ void load_wf(const WB2_GLOBAL double* p,
                                         double (&v)[VEC]) {
   // The weight field is re-read by every outer slab: keep it cacheable.
 #pragma unroll
@@ -308,8 +394,10 @@ __device__ __forceinline__ void load_wf(const double* __restrict__ p,
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
 __global__ void __launch_bounds__(
     512, (WF && !SKIPNA && sizeof(T) * VEC == 8 && MODE == WB2_MODE_DET_ACC)
-             ? 4 : WB2_MIN_WAVES)  // the 2-column weight-field kernel needs 130
-                                   // VGPRs unprompted: 128 = 4 waves per SIMD
+             ? WB2_WF_MIN_WAVES
+             : ((SKIPNA && sizeof(T) * VEC == 8 && MODE == WB2_MODE_DET_ACC)
+                    ? WB2_SKIPNA_MIN_WAVES : WB2_MIN_WAVES))
+    // (occupancy knobs of the 2-column heavy instantiations, A/B only)
     stream_partials_kernel(const StreamParams p) {
   using M = ModeTraits<MODE, SKIPNA>;
   constexpr int NIN = M::NIN, K = M::K, NWF = WF ? 2 : 1;
@@ -346,8 +434,12 @@ __global__ void __launch_bounds__(
     const long long v = tab[(p.slab[i] && o < p.n_outer) ? o : 0];
     slab_idx[i] = p.slab[i] ? v : o;
   }
-  const int col0 = tile * TILE + lane * VEC;
+  const int col0 = tile * TILE + lane * VEC;  // first column the lane OWNS
   const bool active = tile < p.n_ctile && col0 < p.n_col;
+  // A lane whose VEC columns would run past the end of the row (n_col % VEC
+  // != 0) loads the row's LAST VEC columns instead; the columns below col0,
+  // which its neighbour owns, are dropped when the sums are folded.
+  const int colb = (VEC > 1 && col0 + VEC > p.n_col) ? p.n_col - VEC : col0;
   if (nrow <= 0 || tile >= p.n_ctile || o >= p.n_outer) return;  // wave-uniform
 
   double acc[NWF][VEC][K];
@@ -359,58 +451,140 @@ __global__ void __launch_bounds__(
       for (int k = 0; k < K; ++k) acc[w][e][k] = 0.0;
 
   if (active) {
+    // Row pointers stay wave-uniform (SGPR pairs advanced by scalar adds); the
+    // lane's columns enter as ONE unsigned 32-bit byte offset, which is the
+    // `global_load ... v_off, s[base:base+1]` addressing form: no 64-bit vector
+    // add per load.
     const long long slab_elems = (long long)p.n_row * p.n_col;
     const T* base[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
       base[i] = static_cast<const T*>(p.in[i]) + slab_idx[i] * slab_elems +
-                (long long)row0 * p.n_col + col0;
-    const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + col0
-                           : nullptr;
+                (long long)row0 * p.n_col;
+    const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col : nullptr;
     const double* wrp = p.w_row + row0;
+    unsigned lane_off = (unsigned)colb * (unsigned)sizeof(T);
+    unsigned lane_off_wf = (unsigned)colb * (unsigned)sizeof(double);
+    // (the row pointer pinned to an SGPR pair: otherwise the row offset, common
+    // to every input, is added to the lane offset first and each load pays one
+    // 64-bit vector add for its base.)
+#if WB2_SGPR_ROWS
+    auto at = [&](const T* row) {
+      unsigned long long rp = reinterpret_cast<unsigned long long>(row);
+      asm volatile("" : "+s"(rp));
+      return reinterpret_cast<const WB2_GLOBAL T*>(
+          reinterpret_cast<const WB2_GLOBAL char*>(rp) + lane_off);
+    };
+    auto at_wf = [&](const double* row) {
+      unsigned long long rp = reinterpret_cast<unsigned long long>(row);
+      asm volatile("" : "+s"(rp));
+      return reinterpret_cast<const WB2_GLOBAL double*>(
+          reinterpret_cast<const WB2_GLOBAL char*>(rp) + lane_off_wf);
+    };
+#else
+    auto at = [&](const T* row) {
+      return reinterpret_cast<const WB2_GLOBAL T*>(
+          reinterpret_cast<unsigned long long>(row + colb));
+    };
+    auto at_wf = [&](const double* row) {
+      return reinterpret_cast<const WB2_GLOBAL double*>(
+          reinterpret_cast<unsigned long long>(row + colb));
+    };
+#endif
+    // Opaque to the optimiser inside the loop: hoisted, the zero-extension
+    // becomes a loop-invariant 64-bit VGPR pair and instruction selection (per
+    // block) no longer sees a 32-bit offset -- back to one v_lshl_add_u64 per
+    // load.
+    auto pin_offsets = [&]() {
+#if WB2_SGPR_ROWS
+      asm volatile("" : "+v"(lane_off));
+      if constexpr (WF) asm volatile("" : "+v"(lane_off_wf));
+#endif
+    };
+
+    // One point's K values into the accumulators (both weight sets).
+    auto accumulate = [&](int e, const double (&x)[K], double wfe, double wr) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        acc[0][e][k] = __builtin_fma(wr, x[k], acc[0][e][k]);
+      if constexpr (WF) {
+        // metrics.py:159-160: values where the weight is not > 0 become 0.
+        // The field is >= 0 and finite (plan.py rejects anything else), so
+        // outside w2 = wr * 0 = 0 and the slot only has to be FINITE to drop
+        // out of the sum: clearing the high dword (sign, exponent, top of the
+        // mantissa) of the float64 slot does that in ONE 32-bit AND instead
+        // of the two v_cndmask of a 64-bit select.
+        const bool inside = wfe > 0.0;
+        const unsigned long long keep = inside ? ~0ull : 0x00000000ffffffffull;
+        const double w2 = wr * wfe;
+        double xs[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if ((MODE == WB2_MODE_DET || MODE == WB2_MODE_DET_ACC) && k == 1) {
+            xs[1] = __builtin_fabs(xs[0]);  // slot 1 is |slot 0| (PointOps)
+          } else {
+            xs[k] = __builtin_bit_cast(
+                double, __builtin_bit_cast(unsigned long long, x[k]) & keep);
+          }
+          acc[1][e][k] = __builtin_fma(w2, xs[k], acc[1][e][k]);
+        }
+      }
+    };
+    constexpr bool POINT_OPS = MODE == WB2_MODE_DET ||
+                               MODE == WB2_MODE_DET_ACC ||
+                               MODE == WB2_MODE_WIND;
+    // float32 columns in pairs: the elementwise stage as packed instructions
+    constexpr bool PAIRS =
+        WB2_PACK_PAIRS && POINT_OPS && sizeof(T) == 4 && VEC % 2 == 0;
 
     auto consume = [&](const T (&v)[NIN][VEC], const double (&wf)[VEC],
                        double wr, const double* auxrow) {
+#if WB2_DIAG == 2
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        T in[NIN];
-#pragma unroll
-        for (int i = 0; i < NIN; ++i) in[i] = v[i][e];
-        double x[K];
-#if WB2_DIAG == 2
-        for (int k = 0; k < K; ++k) x[k] = 0.0;
         T sdiag = 0;
-        for (int i = 0; i < NIN; ++i) sdiag += in[i];
+        for (int i = 0; i < NIN; ++i) sdiag += v[i][e];
         acc[0][e][0] += (double)sdiag;
+      }
 #else
-        if constexpr (MODE == WB2_MODE_SEEPS) {
-          eval_slots<MODE, SKIPNA, T>(in, x, auxrow[e], p.scalar);
-        } else {
-          eval_slots<MODE, SKIPNA, T>(in, x);
-        }
+      if constexpr (PAIRS) {
+        typedef T V2 __attribute__((ext_vector_type(2)));
+        using Ops = PointOps<POINT_OPS ? MODE : WB2_MODE_DET>;
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-          acc[0][e][k] = __builtin_fma(wr, x[k], acc[0][e][k]);
-#endif
-        if constexpr (WF) {
-          // metrics.py:159-160: values where the weight is not > 0 become 0.
-          // The field is >= 0 and finite (plan.py rejects anything else), so
-          // outside w2 = wr * 0 = 0 and the slot only has to be FINITE to drop
-          // out of the sum: clearing the high dword (sign, exponent, top of the
-          // mantissa) of the float64 slot does that in ONE 32-bit AND instead
-          // of the two v_cndmask of a 64-bit select.
-          const bool inside = wf[e] > 0.0;
-          const unsigned long long keep =
-              inside ? ~0ull : 0x00000000ffffffffull;
-          const double w2 = wr * wf[e];
+        for (int e = 0; e < VEC; e += 2) {
+          V2 in2[NIN], q2[Ops::NQ];
 #pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const double xs = __builtin_bit_cast(
-                double, __builtin_bit_cast(unsigned long long, x[k]) & keep);
-            acc[1][e][k] = __builtin_fma(w2, xs, acc[1][e][k]);
+          for (int i = 0; i < NIN; ++i) {
+            in2[i][0] = v[i][e];
+            in2[i][1] = v[i][e + 1];
+          }
+          Ops::template elementwise<V2>(in2, q2);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            T q[Ops::NQ];
+#pragma unroll
+            for (int j = 0; j < Ops::NQ; ++j) q[j] = q2[j][h];
+            double x[K];
+            Ops::template slots<SKIPNA, T>(q, x);
+            accumulate(e + h, x, wf[e + h], wr);
           }
         }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          T in[NIN];
+#pragma unroll
+          for (int i = 0; i < NIN; ++i) in[i] = v[i][e];
+          double x[K];
+          if constexpr (MODE == WB2_MODE_SEEPS) {
+            eval_slots<MODE, SKIPNA, T>(in, x, auxrow[e], p.scalar);
+          } else {
+            eval_slots<MODE, SKIPNA, T>(in, x);
+          }
+          accumulate(e, x, wf[e], wr);
+        }
       }
+#endif
     };
 
     // A batch = U rows.  issue() puts the batch's loads in flight, eat() folds
@@ -421,13 +595,15 @@ __global__ void __launch_bounds__(
       double wr[U];
     };
     auto issue = [&](Batch& bt, int r) {
+      pin_offsets();
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int i = 0; i < NIN; ++i)
-          load_vec<T, VEC>(base[i] + (long long)(r + u) * p.n_col, bt.v[u][i]);
+          load_vec<T, VEC>(at(base[i] + (long long)(r + u) * p.n_col),
+                           bt.v[u][i]);
         if constexpr (WF) {
-          load_wf<VEC>(wfp + (long long)(r + u) * p.n_col, bt.wf[u]);
+          load_wf<VEC>(at_wf(wfp + (long long)(r + u) * p.n_col), bt.wf[u]);
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) bt.wf[u][e] = 1.0;
@@ -440,7 +616,7 @@ __global__ void __launch_bounds__(
       for (int u = 0; u < U; ++u)
         consume(bt.v[u], bt.wf[u], bt.wr[u],
                 MODE == WB2_MODE_SEEPS
-                    ? p.aux + (long long)(row0 + r + u) * p.n_col + col0
+                    ? p.aux + (long long)(row0 + r + u) * p.n_col + colb
                     : nullptr);
     };
     int r = 0;
@@ -484,24 +660,25 @@ __global__ void __launch_bounds__(
     for (; r < nrow; ++r) {
       T v[NIN][VEC];
       double wf[VEC];
+      pin_offsets();
 #pragma unroll
       for (int i = 0; i < NIN; ++i)
-        load_vec<T, VEC>(base[i] + (long long)r * p.n_col, v[i]);
+        load_vec<T, VEC>(at(base[i] + (long long)r * p.n_col), v[i]);
       if constexpr (WF) {
-        load_wf<VEC>(wfp + (long long)r * p.n_col, wf);
+        load_wf<VEC>(at_wf(wfp + (long long)r * p.n_col), wf);
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) wf[e] = 1.0;
       }
       consume(v, wf, wrp[r],
               MODE == WB2_MODE_SEEPS
-                  ? p.aux + (long long)(row0 + r) * p.n_col + col0
+                  ? p.aux + (long long)(row0 + r) * p.n_col + colb
                   : nullptr);
     }
     if (p.w_col) {  // only when columns are latitudes (lon-lat layout)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const double wc = p.w_col[col0 + e];
+        const double wc = p.w_col[colb + e];
 #pragma unroll
         for (int w = 0; w < NWF; ++w)
 #pragma unroll
@@ -516,7 +693,8 @@ __global__ void __launch_bounds__(
   return;
 #endif
   fold_tile_to_segs<NWF, VEC, K>(
-      acc, lane, tile, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg, p.n_ts,
+      acc, lane, tile, colb, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg,
+      p.n_ts,
       p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
 }
 
@@ -792,11 +970,22 @@ int launch_stream_mode(const StreamParams& p, int mode, int vec, bool skipna,
   return fail("unknown mode %d", mode);
 }
 
+// Columns per lane.  Wide loads need neither 16-byte alignment nor n_col % w ==
+// 0 (the kernel's loads are element-aligned, its last lane shifts back): rows of
+// 721 latitudes -- the lon-lat layout of the WeatherBench 2 Zarr stores -- run
+// at the same width as rows of 1440 longitudes.  WB2HIP_UNALIGNED_VEC=0 brings
+// back the round-1..3 rule (one column per lane unless everything is aligned),
+// for A/B measurements.
 int vec_width(int mode, int dtype, bool skipna, bool wf, int n_col,
               bool aligned16) {
+  static const bool unaligned_ok = [] {
+    const char* e = getenv("WB2HIP_UNALIGNED_VEC");
+    return !(e && e[0] == '0');
+  }();
   int w = dtype == WB2_F32 ? WB2_F32_VEC : 2;
   if (dtype == WB2_F32 && mode == WB2_MODE_DET_ACC && (skipna || wf))
     w = WB2_F32_VEC_HEAVY;
+  if (unaligned_ok) return n_col >= w ? w : 1;
   return (aligned16 && n_col % w == 0) ? w : 1;
 }
 
