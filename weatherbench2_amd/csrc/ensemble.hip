@@ -59,6 +59,9 @@ struct EnsParams {
 #ifndef WB2_ENS_ASM_MINMAX
 #define WB2_ENS_ASM_MINMAX 1  // 0: __builtin_fmin/fmax (adds one canonicalize per member)
 #endif
+#ifndef WB2_ENS_NT
+#define WB2_ENS_NT 1  // 1: non-temporal member loads where members are read once
+#endif
 #ifndef WB2_ENS_BUFFER_LOADS
 #define WB2_ENS_BUFFER_LOADS 1  // 0: global loads with a 64-bit VALU address per member
 #endif
@@ -109,17 +112,24 @@ __device__ __forceinline__ double abs_or_zero(double d) {
 // stride, so a raw buffer load (SGPR base per member, one constant per-lane byte
 // offset) needs no vector address arithmetic at all, where a global load costs
 // a 64-bit VALU add per member.
-template <typename T>
+// ONCE: the caller reads every member exactly once (the register-sort kernel):
+// non-temporal loads, +3.5 % on BASELINE configs[2] (0.488 -> 0.471 ms,
+// profiles/r03_k3_ab8_summary.txt); the multi-pass streaming form re-reads its
+// members from the caches and keeps them cacheable.
+template <typename T, bool ONCE = false>
 __device__ __forceinline__ T member_load(const T* uniform_base, int lane_bytes) {
 #if WB2_ENS_BUFFER_LOADS
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(uniform_base), 0, 0x7fffffff, 0x00020000);
+  // cache policy (gfx940+): bit 1 = nt -- the members are read once
   if constexpr (sizeof(T) == 4) {
     return __builtin_bit_cast(
-        T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, 0, 0));
+        T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, 0,
+                                                WB2_ENS_NT && ONCE ? 2 : 0));
   } else {
     return __builtin_bit_cast(
-        T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, 0, 0));
+        T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, 0,
+                                                WB2_ENS_NT && ONCE ? 2 : 0));
   }
 #else
   return __builtin_nontemporal_load(
@@ -156,6 +166,14 @@ __device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
 #ifndef WB2_ENS_PAIRED_SPREAD
 #define WB2_ENS_PAIRED_SPREAD 1  // 50 float32 members: rank-weighted sum over (hi, lo) pairs
 #endif
+#ifndef WB2_ENS_PACKED
+// 50 float32 members: t - x, (x - mean)^2 and the rank-weighted sum on member
+// pairs (v_pk_add / mul / fma_f32: 1 007 instead of 1 096 VALU per row).  OFF:
+// measured 1.5 % SLOWER (0.495 against 0.488 ms, profiles/r03_k3_ab8_summary.txt)
+// -- the pairs cost 114 instead of 87 VGPRs (4 instead of 5 waves per SIMD) and
+// the kernel is as close to its HBM limit (256-byte bursts) as to the VALU's.
+#define WB2_ENS_PACKED 0
+#endif
 #ifndef WB2_ENS_SORT3
 #define WB2_ENS_SORT3 1  // 50 float32 members: the 2-/3-sorter program (677 instead of 806 VALU)
 #endif
@@ -179,18 +197,42 @@ __device__ __forceinline__ void sort3_asm(float& a, float& b, float& c) {
 // tools/gen_sort3_network.py.  The values are never moved: rank r ends up in
 // register kSort3Order50[r].
 constexpr int kSort3Order50[50] = {WB2_SORT3_ORDER_50};
-__device__ __forceinline__ void sort3_network_50(float (&x)[64]) {
-#define WB2_S2(i, j)                      \
-  {                                       \
-    const float lo_ = vmin(x[i], x[j]);   \
-    const float hi_ = vmax(x[i], x[j]);   \
-    x[i] = lo_;                           \
-    x[j] = hi_;                           \
+// Which register a wire of the program lives in is free (the inputs are a set):
+// choose it so that the ranks the paired rank-weighted sum combines sit in
+// (even, odd) register pairs -- ranks (1,2), (3,4), ..., (47,48) in registers
+// (0,1), (2,3), ..., (46,47), ranks 0 and 49 in (48,49) -- and that sum runs on
+// v_pk_add_f32 / v_pk_fma_f32.  of_rank[r]: register of rank r after the sort;
+// reg[w]: register of wire w.
+struct Sort3Layout50 {
+  int reg[50];
+  int of_rank[50];
+  constexpr Sort3Layout50() : reg{}, of_rank{} {
+    for (int r = 0; r < 50; ++r) {
+#if WB2_ENS_PACKED
+      const int q = r == 0 ? 48 : (r == 49 ? 49 : r - 1);
+#else
+      const int q = kSort3Order50[r];
+#endif
+      of_rank[r] = q;
+      reg[kSort3Order50[r]] = q;
+    }
   }
-#define WB2_S3(i, j, k) sort3_asm(x[i], x[j], x[k]);
+};
+constexpr Sort3Layout50 kSort3Layout50{};
+__device__ __forceinline__ void sort3_network_50(float (&x)[64]) {
+#define WB2_R(i) x[kSort3Layout50.reg[i]]
+#define WB2_S2(i, j)                            \
+  {                                             \
+    const float lo_ = vmin(WB2_R(i), WB2_R(j)); \
+    const float hi_ = vmax(WB2_R(i), WB2_R(j)); \
+    WB2_R(i) = lo_;                             \
+    WB2_R(j) = hi_;                             \
+  }
+#define WB2_S3(i, j, k) sort3_asm(WB2_R(i), WB2_R(j), WB2_R(k));
   WB2_SORT3_NETWORK_50
 #undef WB2_S2
 #undef WB2_S3
+#undef WB2_R
 }
 
 template <typename T>
@@ -245,10 +287,22 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
     // PAIR finds the NaNs
 #pragma unroll
     for (int m = 0; m < NM; m += 2) {
+      T d0, d1;
+      if constexpr (WB2_ENS_PACKED && sizeof(T) == 4) {
+        // t - x for a member PAIR as one v_pk_add_f32 (same IEEE results)
+        typedef float F2 __attribute__((ext_vector_type(2)));
+        const F2 xp = {x[m], x[m + 1]}, tt = {t, t};
+        const F2 d = tt - xp;
+        d0 = d[0];
+        d1 = d[1];
+      } else {
+        d0 = t - x[m];
+        d1 = t - x[m + 1];
+      }
       sum += x[m];
-      sk += abs_of(t - x[m]);
+      sk += abs_of(d0);
       sum += x[m + 1];
-      sk += abs_of(t - x[m + 1]);
+      sk += abs_of(d1);
       bad = bad || __builtin_isunordered(x[m], x[m + 1]);
     }
     // the flag is first needed after the sort: without this pin hipcc sinks the
@@ -275,11 +329,27 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   {
     if constexpr (MS > 0 && !SKIPNA) mean = div_const<MS>(sum);
     else mean = sum / (T)cnt;
+    if constexpr (WB2_ENS_PACKED && MS > 0 && !SKIPNA && MS % 2 == 0 &&
+                  sizeof(T) == 4) {
+      // (x - mean)^2 for a member pair: v_pk_add_f32 + v_pk_mul_f32, summed in
+      // member order as before
+      typedef float F2 __attribute__((ext_vector_type(2)));
+      const F2 mm = {mean, mean};
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
-      const T d = x[m] - mean;
-      sq += use ? d * d : (T)0;
+      for (int m = 0; m < NM; m += 2) {
+        const F2 xp = {x[m], x[m + 1]};
+        const F2 d = xp - mm;
+        const F2 q = d * d;
+        sq += q[0];
+        sq += q[1];
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
+        const T d = x[m] - mean;
+        sq += use ? d * d : (T)0;
+      }
     }
   }
   T var;
@@ -326,12 +396,34 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
         // inf - finite = inf, and inf - inf = NaN exactly when an infinity
         // receives a non-positive weight.
         constexpr int H = MS / 2;
+        constexpr auto& R = kSort3Layout50.of_rank;
         float s0 = 0.0f, s1 = 0.0f;
+        if constexpr (WB2_ENS_PACKED) {
+          // the two chains side by side: j = 2k - 1 in element 0 (s1), j = 2k
+          // in element 1 (s0); the register pairs are the layout's
+          typedef float F2 __attribute__((ext_vector_type(2)));
+          F2 s10 = {0.0f, 0.0f};
 #pragma unroll
-        for (int j = 1; j <= H; ++j) {
-          const float g = x[kSort3Order50[H + j - 1]] - x[kSort3Order50[H - j]];
-          if (j & 1) s1 = __builtin_fmaf((float)(2 * j - 1), g, s1);
-          else s0 = __builtin_fmaf((float)(2 * j - 1), g, s0);
+          for (int k = 1; 2 * k <= H; ++k) {
+            const int j = 2 * k - 1;
+            const F2 hi = {x[R[H + j - 1]], x[R[H + j]]};
+            const F2 lo = {x[R[H - j]], x[R[H - j - 1]]};
+            const F2 c = {(float)(2 * j - 1), (float)(2 * j + 1)};
+            s10 = __builtin_elementwise_fma(c, hi - lo, s10);
+          }
+          s1 = s10[0];
+          s0 = s10[1];
+          if constexpr (H & 1) {
+            const float g = x[R[2 * H - 1]] - x[R[0]];
+            s1 = __builtin_fmaf((float)(2 * H - 1), g, s1);
+          }
+        } else {
+#pragma unroll
+          for (int j = 1; j <= H; ++j) {
+            const float g = x[R[H + j - 1]] - x[R[H - j]];
+            if (j & 1) s1 = __builtin_fmaf((float)(2 * j - 1), g, s1);
+            else s0 = __builtin_fmaf((float)(2 * j - 1), g, s0);
+          }
         }
         s = (double)s0 + (double)s1;
       } else {
@@ -339,7 +431,8 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
         for (int m = 0; m < NM; ++m) {
           const bool use = SKIPNA ? m < n : true;
           s = __builtin_fma((double)(2 * (m + 1) - M - 1),
-                            use ? (double)x[kSort3Order50[m]] : 0.0, s);
+                            use ? (double)x[kSort3Layout50.of_rank[m]] : 0.0,
+                            s);
         }
       }
     } else {
@@ -562,7 +655,8 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
           if (m < NM) {
             // runtime M: slots >= M re-read the last member (cache hit, ignored)
             const int mm = MS > 0 ? m : (m < M ? m : M - 1);
-            x[m] = member_load<T>(xrow + mm * p.member_stride, lane_bytes);
+            x[m] = member_load<T, true>(xrow + mm * p.member_stride,
+                                        lane_bytes);
           } else {
             x[m] = (T)0;
           }
