@@ -62,6 +62,9 @@ struct EnsParams {
 #ifndef WB2_ENS_NT
 #define WB2_ENS_NT 1  // 1: non-temporal member loads where members are read once
 #endif
+#ifndef WB2_ENS_NT_AUX
+#define WB2_ENS_NT_AUX 2  // buffer-load cache policy bits: 1 sc0, 2 nt, 16 sc1
+#endif
 #ifndef WB2_ENS_BUFFER_LOADS
 #define WB2_ENS_BUFFER_LOADS 1  // 0: global loads with a 64-bit VALU address per member
 #endif
@@ -125,11 +128,11 @@ __device__ __forceinline__ T member_load(const T* uniform_base, int lane_bytes) 
   if constexpr (sizeof(T) == 4) {
     return __builtin_bit_cast(
         T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, 0,
-                                                WB2_ENS_NT && ONCE ? 2 : 0));
+                                                WB2_ENS_NT && ONCE ? WB2_ENS_NT_AUX : 0));
   } else {
     return __builtin_bit_cast(
         T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, 0,
-                                                WB2_ENS_NT && ONCE ? 2 : 0));
+                                                WB2_ENS_NT && ONCE ? WB2_ENS_NT_AUX : 0));
   }
 #else
   return __builtin_nontemporal_load(
@@ -590,7 +593,9 @@ __device__ __forceinline__ void ens_point_large(
 }
 
 #ifndef WB2_ENS_WG_WAVES
-#define WB2_ENS_WG_WAVES 4   // waves per workgroup (independent waves)
+// waves per workgroup (independent waves: the workgroup is only a scheduling
+// unit).  2 instead of 4: +1 % with non-temporal loads (r03_k3_ab10_summary.txt)
+#define WB2_ENS_WG_WAVES 2
 #endif
 
 template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>

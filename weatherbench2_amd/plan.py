@@ -34,8 +34,11 @@ LONLAT = 'lonlat'  # slabs are (longitude, latitude): rows = longitude
 DEFAULT_ROWS_PER_CHUNK = 16
 
 
-ENSEMBLE_ROWS_PER_CHUNK = 8  # K3 (VALU-bound, 64 columns per wave): measured
-                             # 4.96 TB/s at 4-8 rows, 4.59 at 16, 4.07 at 32
+# K3 (64 columns per wave, ~1 100 VALU per row): 5 rows per chunk with
+# non-temporal member loads and 2-wave workgroups (0.445 ms per 13-slab launch
+# against 0.452 / 0.456 / 0.457 at 6 / 7 / 8 rows and 0.469 at 4, same box:
+# profiles/r03_k3_ab10_summary.txt; 12 and 16 rows are 4-6 % slower).
+ENSEMBLE_ROWS_PER_CHUNK = 5
 
 
 def auto_rows_per_chunk(n_row: int, n_outer: int) -> int:
