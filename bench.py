@@ -67,6 +67,7 @@ N_LEV, N_LAT, N_LON = 13, 721, 1440
 PTS_PER_UNIT = N_LEV * N_LAT * N_LON
 BYTES_PER_PT = 12.0  # forecast 4 + truth 4 + climatology 4
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+SPECTRUM_UNITS = 16      # units per launch of the spectrum workloads (as the headline)
 
 
 def predefined_regions():
@@ -281,6 +282,9 @@ def parse_args():
                        'the spectrum script with the mean fused; used for '
                        'profiles/ and DESIGN.md')
   ap.add_argument('--members', type=int, default=50)
+  ap.add_argument('--spectrum-units', type=int, default=SPECTRUM_UNITS,
+                  help='units of 13 x 721 x 1440 per launch of the spectrum '
+                       'workloads')
   return ap.parse_args()
 
 
@@ -339,7 +343,7 @@ def main():
   if args.workload != 'deterministic':
     print(json.dumps(secondary(args.workload, args.steps, args.warmup,
                                args.ramp_ms, args.members,
-                               args.rows_per_chunk)))
+                               args.rows_per_chunk, args.spectrum_units)))
     return
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     sys.exit(self_launch(args))
@@ -909,7 +913,7 @@ def pcie_leg(dev, pl, units, nr, total, count) -> dict:
 
 
 def secondary(workload_name, steps, warmup, ramp_ms, members=50,
-              rows_per_chunk=0) -> dict:
+              rows_per_chunk=0, spectrum_units=SPECTRUM_UNITS) -> dict:
   """BASELINE configs[2] (50-member ensemble) and configs[3] (zonal spectrum)
   on one GPU: same timing discipline, their own roofline.  Returns the JSON
   line of `--workload NAME`; the default run embeds the same dicts."""
@@ -918,7 +922,8 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
   from weatherbench2_amd import _lib, engine, plan as plan_lib
   args = types.SimpleNamespace(workload=workload_name, steps=steps,
                                warmup=warmup, ramp_ms=ramp_ms, members=members,
-                               rows_per_chunk=rows_per_chunk)
+                               rows_per_chunk=rows_per_chunk,
+                               spectrum_units=spectrum_units)
   dev = torch.device('cuda', torch.cuda.current_device())
   lat = np.linspace(-90, 90, N_LAT)
   lon = np.linspace(0, 360, N_LON, endpoint=False)
@@ -951,8 +956,8 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
                 'spread/skill + ensemble-mean MSE + variance + debiased MSE, '
                 '13 regions')
   else:
-    units = 8
-    pool = 6
+    units = args.spectrum_units
+    pool = max(2, 48 // units)   # 2.6 GB of distinct input >> Infinity Cache
     x = torch.randn((pool * units, N_LEV, N_LAT, N_LON), generator=gen,
                     device=dev)
     from weatherbench2_amd.derived_variables import ZonalEnergySpectrum
@@ -983,7 +988,7 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
         ev[0].record()
       if args.workload == 'spectrum_mean':
         # the script's pipeline (compute_zonal_energy_spectrum.py:234): the
-        # time mean of the spectrum, fused -- the 8 units act as 8 times
+        # time mean of the spectrum, fused -- the units act as times
         engine.zonal_spectrum(xs, circ, N_LAT, n_time=units)
         if timed:
           ev[1].record()
@@ -1020,14 +1025,14 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
                                  'C2C + power_kernel'}[args.workload]
     workload = {
         'spectrum_mean': 'the time-mean pipeline of scripts/compute_zonal_energy_'
-                         'spectrum.py:234 on 8 units of 13x721x1440 f32 per '
-                         'step: spectrum and its mean over the 8 units in ONE '
+                         f'spectrum.py:234 on {units} units of 13x721x1440 f32 per '
+                         'step: spectrum and its mean over the units in ONE '
                          'kernel (4 B/pt read, one 721-bin spectrum per row '
                          'written)',
-        'spectrum': 'BASELINE configs[3]: zonal energy spectrum of 8 units of '
+        'spectrum': f'BASELINE configs[3]: zonal energy spectrum of {units} units of '
                     '13x721x1440 f32 per step + its area-weighted latitude '
                     'mean, fused (per-latitude spectra never written)',
-        'spectrum_materialized': 'ZonalEnergySpectrum.compute on 8 units of '
+        'spectrum_materialized': f'ZonalEnergySpectrum.compute on {units} units of '
                                  '13x721x1440 f32 per step (per-latitude spectra '
                                  'materialised, 8 B/pt), then their area-weighted '
                                  'latitude mean (K7; the roofline entry is the '
@@ -1063,7 +1068,7 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
                                    {'spectrum_materialized': 'spectrum',
                                     'spectrum': 'spectrum_latmean'}.get(
                                         args.workload, args.workload),
-                                   units_per_launch=8)),
+                                   units_per_launch=args.spectrum_units)),
                    'traffic_source': 'rocprofv3 PMC of an earlier run of this '
                                      'launch size (profiles/)'}}
 
