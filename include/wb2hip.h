@@ -350,6 +350,26 @@ int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
                           int32_t n_seg, int32_t n_ts, double* partials,
                           double* maps, void* stream);
 
+/* As wb2_ens_partials_maps for a GATHERED ensemble: member m of outer index o
+ * is the [n_row][n_col] slab at device address member_ptr[o * n_member + m]
+ * (DEV int64[n_outer][n_member]) -- no stride, no common base: the forecast of
+ * a probabilistic-climatology baseline (evaluation.py:458-470, 714-726: one
+ * member per climatological year, gathered by (dayofyear, hour) of the valid
+ * time) is read in place from the resident observations; a hole of the gather
+ * (29 February in a common year) points at a slab of NaNs.  Register-sort
+ * kernels only: n_member <= 128 (float32) / 64 (float64). */
+int wb2_ens_partials_gather(int dtype, int skipna, const int64_t* member_ptr,
+                            const void* truth, const int64_t* truth_slab,
+                            int32_t n_member, int64_t n_outer, int32_t n_row,
+                            int32_t n_col, const double* w_row,
+                            const double* w_col, const double* wfield,
+                            const int32_t* chunk_row0,
+                            const int32_t* chunk_nrow, int32_t n_chunk,
+                            int32_t n_ctile, const int32_t* seg_col0,
+                            const int32_t* seg_eoff, int32_t n_seg,
+                            int32_t n_ts, double* partials, double* maps,
+                            void* stream);
+
 /* Region fold + finalisation for the ensemble pass (same tables as
  * wb2_det_combine); metrics is double[WB2_NMETRIC_ENS][n_region][n_outer]. */
 int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,

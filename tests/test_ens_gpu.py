@@ -296,6 +296,55 @@ def test_member_pool_beyond_4_gib():
   assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+@pytest.mark.parametrize('skipna', [False, True])
+@pytest.mark.parametrize('n_member', [3, 13, 50])
+def test_gathered_ensemble_equals_its_copy(dtype, skipna, n_member):
+  """wb2_ens_partials_gather: member m of outer index o read at its own slab
+  address (a pool in arbitrary order, holes -> the NaN slab) == the same
+  ensemble copied member-major, bit for bit, maps included."""
+  import torch
+  from weatherbench2_amd import engine, plan as plan_lib
+  dev = torch.device('cuda')
+  td = getattr(torch, dtype)
+  n_lat, n_lon, n_outer, n_pool = 33, 130, 6, 40
+  pl = plan_lib.build_plan(
+      np.linspace(-90, 90, n_lat), np.linspace(0, 360, n_lon, endpoint=False),
+      plan_lib.LATLON, {'global': None}, dev,
+      rows_per_chunk=plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+  gen = torch.Generator(device=dev).manual_seed(11)
+  pool = torch.randn((n_pool, n_lat, n_lon), generator=gen, device=dev, dtype=td)
+  truth = torch.randn((n_outer, n_lat, n_lon), generator=gen, device=dev,
+                      dtype=td)
+  rs = np.random.RandomState(3)
+  index = rs.randint(0, n_pool, size=(n_outer, n_member)).astype(np.int64)
+  if skipna or n_member == 3:
+    index[1, 0] = -1  # a hole: NaN member
+    index[4, n_member - 1] = -1
+  ptrs = torch.from_numpy(np.ascontiguousarray(engine.gather_pointers(
+      pool, index, n_lat * n_lon))).to(dev)
+  slab = n_lat * n_lon
+  maps_a = torch.empty((6, n_outer, slab), dtype=torch.float64, device=dev)
+  maps_b = torch.empty_like(maps_a)
+  a, _ = engine.ensemble_reduce(pl, pool, 0, n_member, None, truth, None,
+                                n_outer, skipna, maps=maps_a, member_ptrs=ptrs)
+  copy = pool[torch.from_numpy(np.maximum(index, 0)).to(dev)]  # [o, m, ...]
+  copy[torch.from_numpy(index < 0).to(dev)] = float('nan')
+  copy = copy.permute(1, 0, 2, 3).contiguous()  # member-major
+  b, _ = engine.ensemble_reduce(pl, copy, n_outer * slab, n_member, None,
+                                truth, None, n_outer, skipna, maps=maps_b)
+  torch.cuda.synchronize()
+  if n_member == 50:  # the copy takes the exact-50 kernel (paired float32
+    # rank sum), the gather the runtime-M one (fp64 chain): one rounding apart
+    helpers.assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=3e-7,
+                         atol=1e-12)
+  else:
+    assert torch.equal(torch.nan_to_num(a, nan=-7.0),
+                       torch.nan_to_num(b, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(maps_a, nan=-7.0),
+                       torch.nan_to_num(maps_b, nan=-7.0))
+
+
 def test_perfect_prediction_zero_ensemble_mean_rmse(gm):
   # metrics_test.py:842-851
   truth, _ = fixtures.get_random_truth_and_forecast(ensemble_size=10)

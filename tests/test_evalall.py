@@ -13,7 +13,8 @@ run on the stand-in xarray of oracle/refshim (make_reference_vectors.py).
         slabs the oracle's eager np.take copies;
   GPU   the product's `_evaluate_all_metrics` / chunk functions reproduce them
         through the HIP path, with host AND device-resident datasets, and the
-        deterministic passes read the gathers in place (no materialisation).
+        deterministic AND ensemble passes read the gathers in place (no
+        materialisation).
 """
 import os
 import types
@@ -263,6 +264,11 @@ def test_deterministic_passes_read_the_gather_in_place(monkeypatch):
                           self, device))
   _product_run('evalall_clim_byinit', resident=True)
   _product_run('evalall_persist_byvalid', resident=True)
+  assert not calls
+  # forecast := probabilistic climatology: K3 reads every member slab where it
+  # lives (one address per (outer, member); holes -> a resident NaN slab)
+  _product_run('evalall_probclim_byinit', resident=True)
+  _product_run('evalall_probclim_byinit_skipna', resident=True)
   assert not calls
   torch.cuda.synchronize()
 

@@ -40,6 +40,10 @@ struct EnsParams {
   const void* truth;
   const long long* ens_slab;
   const long long* truth_slab;
+  // gathered ensembles (wb2_ens_partials_gather): device ADDRESS of the slab of
+  // member m at outer index o in member_ptr[o * n_member + m]; NULL = members
+  // at a constant stride from `ens`.  Runtime-M register-sort kernels only.
+  const long long* member_ptr;
   const double* w_row;
   const double* w_col;
   const double* wfield;
@@ -632,6 +636,31 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[w][0][k] = 0.0;
 
+  // gathered members: lane l keeps the slab address of member j * 64 + l in
+  // a VGPR pair (ONE vector load per wave; indices >= M repeat the last
+  // member, like the strided form); the row loop takes member m's address
+  // out of lane m with two v_readlane -- scalar loads inside the loop would
+  // each be a dependent round trip (measured: 6 x slower).  Loaded by EVERY
+  // lane, before the `active` branch: v_readlane ignores EXEC, and in a row-end
+  // tile lane m may own no column.
+  constexpr int NMP = (MS == 0 && NPAD > 0) ? (NPAD + kWave - 1) / kWave : 1;
+  unsigned mp_lo[NMP], mp_hi[NMP];
+  const bool gathered = MS == 0 && NPAD > 0 && p.member_ptr != nullptr;
+  if constexpr (MS == 0 && NPAD > 0) {
+#pragma unroll
+    for (int j = 0; j < NMP; ++j) {
+      mp_lo[j] = mp_hi[j] = 0;
+      if (gathered) {
+        const int mi = j * kWave + lane;
+        const unsigned long long a = (unsigned long long)
+            p.member_ptr[o * (long long)M + (mi < M ? mi : M - 1)];
+        mp_lo[j] = (unsigned)a;
+        mp_hi[j] = (unsigned)(a >> 32);
+      }
+      // (side-effecting: keeps the load from being sunk into the branch below)
+      asm volatile("" : "+v"(mp_lo[j]), "+v"(mp_hi[j]));
+    }
+  }
   if (active) {
     const long long slab_elems = (long long)p.n_row * p.n_col;
     // wave-uniform row base (SGPRs) + this lane's byte offset inside the row
@@ -655,19 +684,50 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
         ens_point_large<T, SKIPNA>(xrow, p.member_stride, lane_bytes, M, t, v);
       } else {
         T x[NPAD];
+        // Runtime M: everything about the member bases is row-invariant, and
+        // hipcc hoists all NPAD of them out of the row loop (64-bit pairs in
+        // SGPRs: 192-468 dwords of SGPR spills).  The stride / the address
+        // lanes are made opaque once per row instead, and the base advances
+        // member by member (slots >= M re-read the last member: cache hit,
+        // ignored).
+        long long stride_r = p.member_stride;
+        int Mr = M;  // runtime M, opaque per row: the per-member `m < M` lane
+                     // masks are recomputed (scalar compares) instead of being
+                     // kept in SGPR pairs across the whole row loop
+        if constexpr (MS == 0) {
+          asm volatile("" : "+s"(Mr));
+          asm volatile("" : "+s"(stride_r));
+#pragma unroll
+          for (int j = 0; j < NMP; ++j)
+            asm volatile("" : "+v"(mp_lo[j]), "+v"(mp_hi[j]));
+        }
+        const T* mb = xrow;
 #pragma unroll
         for (int m = 0; m < NPAD; ++m) {
           if (m < NM) {
-            // runtime M: slots >= M re-read the last member (cache hit, ignored)
-            const int mm = MS > 0 ? m : (m < M ? m : M - 1);
-            x[m] = member_load<T, true>(xrow + mm * p.member_stride,
-                                        lane_bytes);
+            const T* mrow;
+            if constexpr (MS > 0) {
+              mrow = xrow + m * p.member_stride;
+            } else {
+              mrow = mb;
+              if (gathered) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(
+                    (int)mp_lo[m / kWave], m % kWave);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane(
+                    (int)mp_hi[m / kWave], m % kWave);
+                mrow = reinterpret_cast<const T*>(
+                           ((unsigned long long)hi << 32) | lo) +
+                       (long long)(row0 + r) * p.n_col;
+              }
+              mb += (m + 1 < Mr) ? stride_r : 0;
+            }
+            x[m] = member_load<T, true>(mrow, lane_bytes);
           } else {
             x[m] = (T)0;
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        ens_point<T, NPAD, MS, SKIPNA>(x, t, M, v);
+        ens_point<T, NPAD, MS, SKIPNA>(x, t, Mr, v);
       }
       if (p.maps) {
         // Spatial* metrics (metrics.py:718-772, 1244-1266, 1366-1399): the
@@ -949,7 +1009,7 @@ int launch_ens_npad(const EnsParams& p, bool skipna, bool wf,
     const char* v = getenv("WB2HIP_ENS_REFERENCE_SPREAD");
     return v && v[0] && v[0] != '0';
   }();
-  if (m == 50 && !reference_spread)
+  if (m == 50 && !reference_spread && !p.member_ptr)  // gathers: runtime-M forms
     return launch_ens<T, 64, 50>(p, skipna, wf, stream);
   if (m <= 4) return launch_ens<T, 4, 0>(p, skipna, wf, stream);
   if (m <= 16) return launch_ens<T, 16, 0>(p, skipna, wf, stream);
@@ -1034,6 +1094,65 @@ int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
   p.partials = partials;
   p.maps = maps;
   p.member_stride = member_stride;
+  p.n_outer = n_outer;
+  p.n_member = n_member;
+  p.n_row = n_row;
+  p.n_col = n_col;
+  p.n_chunk = n_chunk;
+  p.n_ctile = n_ctile;
+  p.n_seg = n_seg;
+  p.n_ts = n_ts;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    return launch_ens_npad<float>(p, skipna != 0, wfield != nullptr, s);
+  return launch_ens_npad<double>(p, skipna != 0, wfield != nullptr, s);
+}
+
+int wb2_ens_partials_gather(int dtype, int skipna, const int64_t* member_ptr,
+                            const void* truth, const int64_t* truth_slab,
+                            int32_t n_member, int64_t n_outer, int32_t n_row,
+                            int32_t n_col, const double* w_row,
+                            const double* w_col, const double* wfield,
+                            const int32_t* chunk_row0,
+                            const int32_t* chunk_nrow, int32_t n_chunk,
+                            int32_t n_ctile, const int32_t* seg_col0,
+                            const int32_t* seg_eoff, int32_t n_seg,
+                            int32_t n_ts, double* partials, double* maps,
+                            void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_REQUIRE(member_ptr && truth && w_row && chunk_row0 && chunk_nrow &&
+                  seg_col0 && seg_eoff && partials,
+              "null pointer argument");
+  const int max_member = dtype == WB2_F32 ? 128 : 64;
+  WB2_REQUIRE(n_member >= 1 && n_member <= max_member,
+              "n_member=%d: gathered ensembles go through the register sort "
+              "(<= %d members of this dtype)", n_member, max_member);
+  WB2_REQUIRE(n_outer >= 0 && n_row > 0 && n_col > 0 && n_chunk > 0 &&
+                  n_seg > 0 && n_ts >= n_seg,
+              "bad sizes");
+  WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
+  WB2_REQUIRE(n_outer < (1ll << 31), "n_outer=%lld too large",
+              (long long)n_outer);
+  WB2_REQUIRE(n_ctile == (n_col + kWave - 1) / kWave,
+              "n_ctile=%d does not match ceil(n_col / 64)", n_ctile);
+  if (n_outer == 0) return 0;
+  EnsParams p{};
+  p.ens = truth;  // unused with member_ptr; any valid address
+  p.truth = truth;
+  p.truth_slab = reinterpret_cast<const long long*>(truth_slab);
+  p.member_ptr = reinterpret_cast<const long long*>(member_ptr);
+  p.w_row = w_row;
+  p.w_col = w_col;
+  p.wfield = wfield;
+  p.chunk_row0 = chunk_row0;
+  p.chunk_nrow = chunk_nrow;
+  p.seg_col0 = seg_col0;
+  p.seg_eoff = seg_eoff;
+  p.partials = partials;
+  p.maps = maps;
   p.n_outer = n_outer;
   p.n_member = n_member;
   p.n_row = n_row;

@@ -713,6 +713,7 @@ struct CombineParams {
   double* metrics;
   long long n_outer;
   int n_chunk, nwf, n_seg, n_ts, n_band, n_region, K, mode, skipna;
+  int group;  // lanes per (band, weight field, seg, slot) cell: 1, 2, ..., 64
 };
 
 __device__ __forceinline__ double nan_if_zero(double d) {
@@ -738,6 +739,50 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
   const long long chunk_stride = (long long)p.nwf * p.n_ts * K;
   const double* part = p.partials + o * p.n_chunk * chunk_stride;
 
+  // Few cells (one global region: ONE band, ONE seg -- K cells of n_chunk x
+  // n_tile terms each): `group` lanes share a cell, lane g sums the terms g, g +
+  // group, ... in order, a fixed xor-tree adds the lanes.  With one thread per
+  // cell the 6 sums of a 50-member slab (152 chunks x 23 tiles) took 135 us --
+  // a third of the K3 launch they follow.  `group` depends on the region
+  // decomposition only (not on the mode's K): sums common to two modes (MSE of
+  // DET and of DET_ACC) stay bit-identical.
+  if (p.group > 1) {
+    const int G = p.group;
+    for (int idx = tid; idx < p.n_band * cell * G; idx += blockDim.x) {
+      const int ci = idx / G, g = idx - ci * G;
+      const int b = ci / cell, j = ci - b * cell;
+      const int w = j / (p.n_seg * K), sk = j - w * (p.n_seg * K);
+      const int s = sk / K, k = sk - s * K;
+      const int e0 = p.seg_eoff[s], ne = p.seg_eoff[s + 1] - e0;
+      const int c0 = p.band_chunk0[b], n = (p.band_chunk0[b + 1] - c0) * ne;
+      const double* base = part + ((long long)w * p.n_ts) * K + k +
+                           c0 * chunk_stride + (long long)e0 * K;
+      int c = g / ne, e = g - c * ne;
+      const int dq = G / ne, dr = G - dq * ne;
+      auto next = [&]() {
+        const double* r = base + c * chunk_stride + (long long)e * K;
+        c += dq;
+        e += dr;
+        if (e >= ne) {
+          e -= ne;
+          ++c;
+        }
+        return r;
+      };
+      double v = 0.0;
+      int i = g;
+      for (; i + 7 * G < n; i += 8 * G) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *next();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+      }
+      for (; i < n; i += G) v += *next();
+      for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+      if (g == 0) bandsum[ci] = v;
+    }
+  } else
   // One thread per (band, weight field, seg, slot).  Its (chunk, entry) terms
   // are independent loads; the sum order is fixed (deterministic).
   for (int idx = tid; idx < p.n_band * cell; idx += blockDim.x) {
@@ -1204,6 +1249,11 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
                              : wb2_num_slots(mode, skipna);
   p.mode = mode;
   p.skipna = skipna != 0;
+  // lanes per cell: as many as keep the 1024 threads busy at a nominal K of 8
+  p.group = 1;
+  while (p.group < kWave &&
+         (long long)n_band * nwf * n_seg * 8 * (2 * p.group) <= 1024)
+    p.group *= 2;
   const size_t lds = ((size_t)n_band * nwf * n_seg * p.K +
                       (size_t)n_region * p.K * (1 + (size_t)n_band) +
                       (size_t)n_region * ((size_t)n_seg + n_band)) *

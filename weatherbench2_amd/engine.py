@@ -302,14 +302,46 @@ def stream_reduce(plan: ReductionPlan, mode: int,
   return metrics, sums
 
 
+GATHER_MAX_MEMBERS = {torch.float32: 128, torch.float64: 64}  # register sort
+_NAN_SLABS: dict = {}
+
+
+def nan_slab(device: torch.device, dtype: torch.dtype, n_elems: int):
+  """One resident slab of NaNs per (device, dtype, size): what the holes of a
+  gathered ensemble point at."""
+  key = (str(device), dtype, int(n_elems))
+  slab = _NAN_SLABS.get(key)
+  if slab is None:
+    slab = torch.full((int(n_elems),), float('nan'), dtype=dtype, device=device)
+    _NAN_SLABS[key] = slab
+  return slab
+
+
+def gather_pointers(base: torch.Tensor, index: np.ndarray, slab_elems: int):
+  """Device addresses of the slabs `index` (any shape, -1 = hole) of the
+  contiguous device tensor `base` ([..., slab]): int64 array of index.shape
+  (host).  Holes point at the resident NaN slab."""
+  index = np.asarray(index, dtype=np.int64)
+  ptrs = base.data_ptr() + index * (slab_elems * base.element_size())
+  if (index < 0).any():
+    hole = nan_slab(base.device, base.dtype, slab_elems).data_ptr()
+    ptrs = np.where(index < 0, np.int64(hole), ptrs)
+  return ptrs
+
+
 def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
                     member_stride: int, n_member: int,
                     ens_slab: t.Optional[torch.Tensor], truth: torch.Tensor,
                     truth_slab: t.Optional[torch.Tensor], n_outer: int,
                     skipna: bool, want_sums: bool = False,
-                    maps: t.Optional[torch.Tensor] = None):
+                    maps: t.Optional[torch.Tensor] = None,
+                    member_ptrs: t.Optional[torch.Tensor] = None):
   """Runs K3 + the region fold.  `ens` holds the members member-major with
   `member_stride` elements between members; `truth` is [n_slab, n_row, n_col].
+  With `member_ptrs` (int64[n_outer, n_member] device ADDRESSES of the member
+  slabs, `gather_pointers`) the ensemble is read in place from wherever its
+  slabs live: `ens` is then only the tensor those addresses point into (kept
+  alive, dtype), `member_stride` and `ens_slab` are ignored.
 
   Returns (metrics[NMETRIC_ENS, n_region, n_outer], sums or None).
   """
@@ -324,6 +356,12 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
   for s in (ens_slab, truth_slab):
     if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
       raise ValueError('slab tables are int64[n_outer]')
+  if member_ptrs is not None and (
+      member_ptrs.dtype != torch.int64 or member_ptrs.device != dev or
+      not member_ptrs.is_contiguous() or
+      member_ptrs.numel() != n_outer * n_member):
+    raise ValueError('member_ptrs is a contiguous int64[n_outer, n_member] '
+                     'on the plan device')
   k = lib.wb2_ens_num_slots(int(skipna))
   tile = lib.wb2_ens_tile_cols(plan.n_col)
   n_ctile = -(-plan.n_col // tile)
@@ -336,14 +374,23 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
   if maps is not None and (maps.dtype != torch.float64 or maps.numel() !=
                            6 * n_outer * plan.n_row * plan.n_col):
     raise ValueError('maps must be float64[6, n_outer, n_row * n_col]')
-  _lib.check(lib.wb2_ens_partials_maps(
-      _DTYPES[dtype], int(skipna), _lib.ptr(ens), _lib.ptr(ens_slab),
-      _lib.ptr(truth), _lib.ptr(truth_slab), n_member, member_stride, n_outer,
-      plan.n_row, plan.n_col, _lib.ptr(plan.w_row), _lib.ptr(plan.w_col),
-      _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
-      _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
-      _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
-      _lib.ptr(partials), _lib.ptr(maps), stream), 'wb2_ens_partials_maps')
+  if member_ptrs is not None:
+    _lib.check(lib.wb2_ens_partials_gather(
+        _DTYPES[dtype], int(skipna), _lib.ptr(member_ptrs), _lib.ptr(truth),
+        _lib.ptr(truth_slab), n_member, n_outer, plan.n_row, plan.n_col,
+        _lib.ptr(plan.w_row), _lib.ptr(plan.w_col), _lib.ptr(plan.wfield),
+        _lib.ptr(plan.chunk_row0), _lib.ptr(plan.chunk_nrow), plan.n_chunk,
+        n_ctile, _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
+        _lib.ptr(partials), _lib.ptr(maps), stream), 'wb2_ens_partials_gather')
+  else:
+    _lib.check(lib.wb2_ens_partials_maps(
+        _DTYPES[dtype], int(skipna), _lib.ptr(ens), _lib.ptr(ens_slab),
+        _lib.ptr(truth), _lib.ptr(truth_slab), n_member, member_stride,
+        n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
+        _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
+        _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
+        _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
+        _lib.ptr(partials), _lib.ptr(maps), stream), 'wb2_ens_partials_maps')
   if _LAUNCH_HOOK is not None:
     _LAUNCH_HOOK('end', 'ens_partials')
   metrics = torch.empty((_lib.NMETRIC_ENS, plan.n_region, n_outer),

@@ -1188,9 +1188,11 @@ def _get_n_ensemble(ds: xl.Dataset, ensemble_dim: str,
   return n_ensemble
 
 
-def _ens_layout(forecast, fvar, tvar, ensemble_dim):
+def _ens_layout(forecast, fvar, tvar, ensemble_dim, allow_gather=False):
   """Device tensors + slab tables of one ensemble variable: member m of outer
-  index o is slab  m * stride_member + ens_table[o]  of the forecast array."""
+  index o is slab  m * stride_member + ens_table[o]  of the forecast array --
+  or, for a gathered forecast when the caller can take it (`allow_gather`: K3),
+  the slab at address member_ptrs[o, m] (last entry of the result, else None)."""
   if ensemble_dim not in fvar.dims:
     raise ValueError(f'{ensemble_dim=} not found in {fvar.dims=}')
   fdata, frest, layout = _spatial_last(fvar, None)
@@ -1228,7 +1230,39 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim):
   truth_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
 
   device = engine.require_gpu()
-  ften, tten = _to_device(fdata, device), _to_device(tdata, device)
+  tten = _to_device(tdata, device)
+  to_dev = lambda tb: None if tb is None else engine.upload_table(tb, device)
+  member_ptrs = None
+  if isinstance(fdata, xl.SlabGather) and not allow_gather:
+    ften = _to_device(fdata, device)
+  elif isinstance(fdata, xl.SlabGather):
+    # forecast := probabilistic climatology (evaluation.py:458-470): every
+    # member slab is read where it lives; K3 gets one address per (outer,
+    # member), holes point at a resident NaN slab.  Anything the gather kernels
+    # do not cover (dtype conversion, more members than the register sort
+    # takes) is materialised below, as before.
+    base, index = fdata.base, fdata.index
+    if isinstance(base, np.ndarray):
+      base, index = fdata.compact_host()
+    dev_base = _to_device(base, device)
+    if (dev_base.dtype == tten.dtype and dev_base.is_contiguous() and
+        n_member <= engine.GATHER_MAX_MEMBERS.get(dev_base.dtype, 0)):
+      ax = frest.index(ensemble_dim)
+      moved = np.moveaxis(index, ax, -1)  # [frest without the ensemble dim, M]
+      n_extra = len(out_dims) - (len(frest) - 1)
+      moved = moved.reshape(moved.shape[:-1] + (1,) * n_extra + (n_member,))
+      table = np.broadcast_to(moved, out_shape + (n_member,))
+      slab_elems = int(dev_base.shape[-2]) * int(dev_base.shape[-1])
+      ptrs = engine.gather_pointers(dev_base, table, slab_elems)
+      member_ptrs = to_dev(np.ascontiguousarray(ptrs).ravel())
+      ften = dev_base
+      _check_grid(geo, ften)
+      _check_grid(geo, tten)
+      return (geo, ften, tten, None, to_dev(truth_table), 0, n_member, device,
+              member_ptrs)
+    ften = xl.SlabGather(dev_base, index).materialize()
+  else:
+    ften = _to_device(fdata, device)
   dtype = torch.promote_types(ften.dtype, tten.dtype)
   if dtype not in (torch.float32, torch.float64):
     dtype = torch.float64
@@ -1236,9 +1270,8 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim):
   tten = tten if tten.dtype == dtype else tten.to(dtype)
   _check_grid(geo, ften)
   _check_grid(geo, tten)
-  to_dev = lambda tb: None if tb is None else engine.upload_table(tb, device)
   return (geo, ften, tten, None if identity else to_dev(ens_table),
-          to_dev(truth_table), strides[ensemble_dim], n_member, device)
+          to_dev(truth_table), strides[ensemble_dim], n_member, device, None)
 
 
 @_serialized
@@ -1253,8 +1286,9 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   hit = _RESULTS.get(key)
   if hit is not None:
     return hit
-  geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device = (
-      _ens_layout(forecast, fvar, tvar, ensemble_dim))
+  (geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device,
+   member_ptrs) = _ens_layout(forecast, fvar, tvar, ensemble_dim,
+                              allow_gather=True)
   out_shape = geo.out_shape
   regions, _ = _region_set_for(region)
   pl = plan_lib.cached_plan(
@@ -1266,7 +1300,9 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   metrics, _ = engine.ensemble_reduce(
       pl, ften, member_slabs * slab_elems, n_member, ens_table,
       tten.reshape(-1, pl.n_row, pl.n_col), truth_table,
-      geo.n_outer, skipna, maps=maps)
+      geo.n_outer, skipna, maps=maps,
+      member_ptrs=(None if member_ptrs is None
+                   else member_ptrs.reshape(geo.n_outer, n_member)))
   dev = metrics.reshape((_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
   # total weight of each region: a spatial average of zeros is 0/0 = NaN over
   # an empty region (CRPSSpread with one member, metrics.py:689-693, 783-784)
@@ -2350,8 +2386,8 @@ class RankHistogram(EnsembleMetric):
   @_serialized
   def _histogram(self, forecast, truth, name, avg_dim=None):
     fvar, tvar = forecast[name], truth[name]
-    geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device = (
-        _ens_layout(forecast, fvar, tvar, self.ensemble_dim))
+    (geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device,
+     _) = _ens_layout(forecast, fvar, tvar, self.ensemble_dim)
     n_bins = self._num_bins_actual(n_member)
     n_point = ften.shape[-2] * ften.shape[-1]
     seed = self._seed
