@@ -104,6 +104,29 @@
 #define WB2_FFT_DIAG 0
 #endif
 
+#ifndef WB2_FFT_NT_LOADS
+#define WB2_FFT_NT_LOADS 1   // input rows are read once: non-temporal
+#endif
+#ifndef WB2_FFT_NT_STORES
+// spectra are written once, but plain stores (write-back through L2) are the
+// faster ones: MATERIALISE 0.279 / 0.304 ms per 16 units against 0.303 / 0.331
+// with non-temporal stores (profiles/r03_k4_ab11_summary.txt); the reducing
+// modes write too little to care.
+#define WB2_FFT_NT_STORES 0
+#endif
+#if WB2_FFT_NT_LOADS
+#define WB2_FFT_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define WB2_FFT_LOAD(p) (*(p))
+#endif
+#if WB2_FFT_NT_STORES
+#define WB2_FFT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define WB2_FFT_STORE(v, p) (*(p) = (v))
+#endif
+
+#include <cstdlib>
+
 namespace wb2 {
 namespace fused {
 
@@ -416,7 +439,7 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
         } else {
           const cf* src =
               reinterpret_cast<const cf*>(p.x + (row0 + t * row_step) * N);
-          P0::load([&](int i) { return __builtin_nontemporal_load(src + i); },
+          P0::load([&](int i) { return WB2_FFT_LOAD(src + i); },
                    lane, v);
         }
 #if WB2_FFT_DIAG & 8
@@ -467,12 +490,12 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
             if (p1a == 1.2345f) orow[k0] = v1a + v1b + v2a + v2b;
 #else
             if (k0 < N2 / 2) {
-              __builtin_nontemporal_store(d2{v1a, v1b},
+              WB2_FFT_STORE((d2{v1a, v1b}),
                                           reinterpret_cast<d2*>(orow + k0));
-              __builtin_nontemporal_store(
-                  d2{v2b, v2a}, reinterpret_cast<d2*>(orow + N2 - k0 - 1));
+              WB2_FFT_STORE(
+                  (d2{v2b, v2a}), reinterpret_cast<d2*>(orow + N2 - k0 - 1));
             } else {  // k0 == N2 / 2: its own mirror; bin k0 + 1 belongs to k0 - 2
-              __builtin_nontemporal_store(v1a, orow + k0);
+              WB2_FFT_STORE(v1a, orow + k0);
             }
 #endif
           }
@@ -503,8 +526,8 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
 #if WB2_FFT_DIAG & 16
               if (p1 == 1.2345f) orow[k] = v1 + v2;
 #else
-              __builtin_nontemporal_store(v1, orow + k);
-              if (2 * k != N2) __builtin_nontemporal_store(v2, orow + N2 - k);
+              WB2_FFT_STORE(v1, orow + k);
+              if (2 * k != N2) WB2_FFT_STORE(v2, orow + N2 - k);
 #endif
             }
           }
@@ -523,8 +546,8 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
             o1 /= (double)(cnt[i] & 0xffff);
             o2 /= (double)(cnt[i] >> 16);
           }
-          __builtin_nontemporal_store(o1, orow + k);
-          if (2 * k != N2) __builtin_nontemporal_store(o2, orow + N2 - k);
+          WB2_FFT_STORE(o1, orow + k);
+          if (2 * k != N2) WB2_FFT_STORE(o2, orow + N2 - k);
         }
       }
     }
@@ -549,7 +572,7 @@ __global__ void latseg_combine_kernel(const double* __restrict__ partial,
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      v[u] = __builtin_nontemporal_load(src + (long long)(g + u) * n_bins);
+      v[u] = WB2_FFT_LOAD(src + (long long)(g + u) * n_bins);
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];
   }
@@ -639,7 +662,14 @@ int latseg_segments(long long n_field, int n_lat) {
   // so the task count also fits the unstaged fallback)
   const long long waves =
       (long long)WB2_FFT_NWAVE * resident_blocks(fused_spectrum_kernel<N2, LATSEG, WB2_FFT_STAGE != 0>);
-  long long n_seg = waves / (n_field > 0 ? n_field : 1);
+  // WB2HIP_LATSEG_ROUNDS (A/B runs): tasks = that many times the resident waves
+  static const double rounds = [] {
+    const char* e = getenv("WB2HIP_LATSEG_ROUNDS");
+    const double v = e ? atof(e) : 1.0;
+    return v > 0.0 ? v : 1.0;
+  }();
+  long long n_seg =
+      (long long)((double)waves * rounds) / (n_field > 0 ? n_field : 1);
   if (n_seg < 1) n_seg = 1;
   if (n_seg > n_lat) n_seg = n_lat;
   return (int)n_seg;
