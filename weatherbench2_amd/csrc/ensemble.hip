@@ -66,6 +66,9 @@ struct EnsParams {
 #ifndef WB2_ENS_NT
 #define WB2_ENS_NT 1  // 1: non-temporal member loads where members are read once
 #endif
+#ifndef WB2_ENS_MAPS_NT_STORES
+#define WB2_ENS_MAPS_NT_STORES 1
+#endif
 #ifndef WB2_ENS_NT_AUX
 #define WB2_ENS_NT_AUX 2  // buffer-load cache policy bits: 1 sc0, 2 nt, 16 sc1
 #endif
@@ -743,7 +746,10 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
             constexpr int flag[6] = {6, 7, 6, 8, 8, 9};
             out_v = v[flag[k]] != 0.0 ? v[k] : qnan;
           }
-          __builtin_nontemporal_store(out_v, p.maps + k * plane + at);
+          if (WB2_ENS_MAPS_NT_STORES)
+            __builtin_nontemporal_store(out_v, p.maps + k * plane + at);
+          else
+            p.maps[k * plane + at] = out_v;
         }
       }
 #pragma unroll

@@ -35,6 +35,15 @@ struct SpatialParams {
   long long n_time, n_rest, n_point;
 };
 
+#ifndef WB2_MAPS_NT_STORES
+#define WB2_MAPS_NT_STORES 1
+#endif
+#if WB2_MAPS_NT_STORES
+#define WB2_MAPS_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define WB2_MAPS_STORE(v, p) (*(p) = (v))
+#endif
+
 template <typename T, int VEC>
 __device__ __forceinline__ void load_v(const T* p, T (&v)[VEC]) {
   if constexpr (VEC == 1) {
@@ -50,13 +59,13 @@ __device__ __forceinline__ void load_v(const T* p, T (&v)[VEC]) {
 template <typename T, int VEC>
 __device__ __forceinline__ void store_v(T* p, const T (&v)[VEC]) {
   if constexpr (VEC == 1) {
-    __builtin_nontemporal_store(v[0], p);
+    WB2_MAPS_STORE(v[0], p);
   } else {
     typedef T V __attribute__((ext_vector_type(VEC)));
     V x;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) x[e] = v[e];
-    __builtin_nontemporal_store(x, reinterpret_cast<V*>(p));
+    WB2_MAPS_STORE(x, reinterpret_cast<V*>(p));
   }
 }
 
