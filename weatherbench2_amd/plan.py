@@ -23,6 +23,8 @@ import dataclasses
 import threading
 import typing as t
 
+import os
+
 import numpy as np
 import torch
 
@@ -38,7 +40,7 @@ DEFAULT_ROWS_PER_CHUNK = 16
 # non-temporal member loads and 2-wave workgroups (0.445 ms per 13-slab launch
 # against 0.452 / 0.456 / 0.457 at 6 / 7 / 8 rows and 0.469 at 4, same box:
 # profiles/r03_k3_ab10_summary.txt; 12 and 16 rows are 4-6 % slower).
-ENSEMBLE_ROWS_PER_CHUNK = 5
+ENSEMBLE_ROWS_PER_CHUNK = int(os.environ.get('WB2HIP_ENS_ROWS_PER_CHUNK', 5))
 
 
 def auto_rows_per_chunk(n_row: int, n_outer: int) -> int:
