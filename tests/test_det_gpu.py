@@ -229,6 +229,54 @@ def test_quarter_degree_all_predefined_regions(gm):
                              atol=1e-12, err_msg=f'{mname}/{rname}')
 
 
+def test_quarter_degree_lonlat_layout_wide_loads(gm):
+  """The (..., longitude, latitude) layout of the WeatherBench 2 Zarr stores at
+  0.25 degrees: rows of 721 latitudes (no row 16-byte aligned, 721 % 4 == 1:
+  three column tiles, the row-end lane loads shifted back) vs the oracle -- the
+  slice regions, a land-mask region (weight field) and skipna with NaNs, the
+  last column included."""
+  n_lat, n_lon, n_lev = 721, 1440, 2
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  rs = np.random.RandomState(12)
+  dims = ('time', 'level', 'longitude', 'latitude')
+  f = rs.normal(size=(1, n_lev, n_lon, n_lat)).astype(np.float32)
+  t = rs.normal(size=(1, n_lev, n_lon, n_lat)).astype(np.float32)
+  c = rs.normal(size=(1, 2, n_lev, n_lon, n_lat)).astype(np.float32)
+  coords = {'time': np.array(['2020-01-02T00'], dtype='datetime64[ns]'),
+            'level': np.array([500, 850]), 'latitude': lat, 'longitude': lon}
+  ccoords = {'hour': np.array([0]), 'dayofyear': np.array([1, 2]),
+             'level': coords['level'], 'latitude': lat, 'longitude': lon}
+  ods_c = DS({'z': NA(c, ('hour', 'dayofyear') + dims[1:])}, ccoords)
+  lsm = np.clip(rs.rand(n_lat, n_lon) * 1.6 - 0.3, 0, 1)
+  lsm[-1, :] = 1.0  # the last latitude = the last column of every row
+  oregions = dict(list(helpers.predefined_regions(oracle=True).items())[:5])
+  gregions = dict(list(helpers.predefined_regions(oracle=False).items())[:5])
+  oregions['land'] = oreg.LandRegion(NA(lsm, ('latitude', 'longitude')), lat, lon)
+  gregions['land'] = helpers.to_gpu_region(oregions['land'])
+  g = helpers.to_gpu_dataset
+  osuite, gsuite = _oracle_suite(ods_c), _gpu_suite(gm, g(ods_c))
+  for skipna in (False, True):
+    ff, tt = f.copy(), t.copy()
+    if skipna:
+      ff[rs.rand(*ff.shape) < 0.01] = np.nan
+      ff[..., -1][rs.rand(*ff[..., -1].shape) < 0.3] = np.nan  # last column
+      tt[..., 0, -3:] = np.nan
+    ods_f, ods_t = DS({'z': NA(ff, dims)}, coords), DS({'z': NA(tt, dims)}, coords)
+    gf, gt = g(ods_f), g(ods_t)
+    with gm.fused_regions(gregions):
+      for rname in oregions:
+        for mname in osuite:
+          want = osuite[mname].compute_chunk(ods_f, ods_t,
+                                             region=oregions[rname],
+                                             skipna=skipna)
+          got = gsuite[mname].compute_chunk(gf, gt, region=gregions[rname],
+                                            skipna=skipna)
+          helpers.assert_close(got['z'].values, want['z'].data, rtol=1e-9,
+                               atol=1e-12,
+                               err_msg=f'{mname}/{rname}/skipna={skipna}')
+
+
 def test_full_size_properties():
   """721x1440x13 unit: determinism, torch-fp64 agreement, scale/shift laws."""
   import torch
