@@ -115,9 +115,11 @@ int wb2_num_slots(int mode, int skipna);
  * rounds 1-3: one column per lane unless everything is 16-byte aligned);
  * n_ctile = ceil(n_col / wb2_tile_cols(...)). */
 int wb2_tile_cols(int dtype, int n_col, int aligned16);
-/* The same for a given instantiation: the register-heavy ones (WB2_MODE_DET_ACC
- * with skipna or a 2-D weight field) cover half as many columns per wavefront
- * (8-byte vectors).  wb2_tile_cols(d, n, a) == wb2_tile_cols_ex(WB2_MODE_DET,
+/* The same for a given instantiation: an instantiation may cover fewer columns
+ * per wavefront than the dtype's default (the build-time knob
+ * WB2_F32_VEC_HEAVY cuts WB2_MODE_DET_ACC with skipna or a 2-D weight field to
+ * 8-byte vectors; the shipped value keeps 16-byte vectors for all of them).
+ * wb2_tile_cols(d, n, a) == wb2_tile_cols_ex(WB2_MODE_DET,
  * d, 0, 0, n, a).  Callers of wb2_stream_partials[_ex] size n_ctile / seg_eoff
  * with THIS function. */
 int wb2_tile_cols_ex(int mode, int dtype, int skipna, int has_wfield, int n_col,
