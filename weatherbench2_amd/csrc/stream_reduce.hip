@@ -50,6 +50,10 @@ struct StreamParams {
   double* partials;
   long long n_outer;
   int n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
+  // host only: rows (n_col * sizeof(T)) or input bases are not 16-byte aligned
+  // -- the lon-lat layout's 721-column rows: selects the SGPR-addressed
+  // instantiation where there is one
+  int unaligned;
 };
 
 template <int MODE, bool SKIPNA>
@@ -327,7 +331,9 @@ __device__ __forceinline__ void eval_slots(
 // Measured (profiles/r03_k1_ab5_summary.txt): the SGPR form is SLOWER -- every
 // load then waits for the scalar add that makes its base (headline 0.418 ->
 // 0.427 ms, weight field 0.500 -> 0.556, skipna 0.463 -> 0.560); only the
-// unaligned lon-lat rows gain (0.493 -> 0.473).
+// unaligned lon-lat rows gain (0.493 -> 0.473): those -- float32, 4 columns
+// per lane, no skipna, no weight field, rows or bases not 16-byte aligned --
+// get an SGPR instantiation of their own (StreamParams::unaligned).
 #define WB2_SGPR_ROWS 0
 #endif
 #ifndef WB2_PACK_PAIRS
@@ -391,7 +397,8 @@ __device__ __forceinline__ void load_wf(const WB2_GLOBAL double* p,
 // lane are in flight before the first one is consumed.  The prologue is written
 // branch-free on purpose: every scalar (table / slab-index) load is issued
 // before the first wait, instead of one dependent round trip per table.
-template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
+template <typename T, int VEC, int MODE, bool SKIPNA, bool WF,
+          bool SG = (WB2_SGPR_ROWS != 0)>
 __global__ void __launch_bounds__(
     512, (WF && !SKIPNA && sizeof(T) * VEC == 8 && MODE == WB2_MODE_DET_ACC)
              ? WB2_WF_MIN_WAVES
@@ -468,38 +475,37 @@ __global__ void __launch_bounds__(
     // (the row pointer pinned to an SGPR pair: otherwise the row offset, common
     // to every input, is added to the lane offset first and each load pays one
     // 64-bit vector add for its base.)
-#if WB2_SGPR_ROWS
     auto at = [&](const T* row) {
-      unsigned long long rp = reinterpret_cast<unsigned long long>(row);
-      asm volatile("" : "+s"(rp));
-      return reinterpret_cast<const WB2_GLOBAL T*>(
-          reinterpret_cast<const WB2_GLOBAL char*>(rp) + lane_off);
+      if constexpr (SG) {
+        unsigned long long rp = reinterpret_cast<unsigned long long>(row);
+        asm volatile("" : "+s"(rp));
+        return reinterpret_cast<const WB2_GLOBAL T*>(
+            reinterpret_cast<const WB2_GLOBAL char*>(rp) + lane_off);
+      } else {
+        return reinterpret_cast<const WB2_GLOBAL T*>(
+            reinterpret_cast<unsigned long long>(row + colb));
+      }
     };
     auto at_wf = [&](const double* row) {
-      unsigned long long rp = reinterpret_cast<unsigned long long>(row);
-      asm volatile("" : "+s"(rp));
-      return reinterpret_cast<const WB2_GLOBAL double*>(
-          reinterpret_cast<const WB2_GLOBAL char*>(rp) + lane_off_wf);
+      if constexpr (SG) {
+        unsigned long long rp = reinterpret_cast<unsigned long long>(row);
+        asm volatile("" : "+s"(rp));
+        return reinterpret_cast<const WB2_GLOBAL double*>(
+            reinterpret_cast<const WB2_GLOBAL char*>(rp) + lane_off_wf);
+      } else {
+        return reinterpret_cast<const WB2_GLOBAL double*>(
+            reinterpret_cast<unsigned long long>(row + colb));
+      }
     };
-#else
-    auto at = [&](const T* row) {
-      return reinterpret_cast<const WB2_GLOBAL T*>(
-          reinterpret_cast<unsigned long long>(row + colb));
-    };
-    auto at_wf = [&](const double* row) {
-      return reinterpret_cast<const WB2_GLOBAL double*>(
-          reinterpret_cast<unsigned long long>(row + colb));
-    };
-#endif
     // Opaque to the optimiser inside the loop: hoisted, the zero-extension
     // becomes a loop-invariant 64-bit VGPR pair and instruction selection (per
     // block) no longer sees a 32-bit offset -- back to one v_lshl_add_u64 per
     // load.
     auto pin_offsets = [&]() {
-#if WB2_SGPR_ROWS
-      asm volatile("" : "+v"(lane_off));
-      if constexpr (WF) asm volatile("" : "+v"(lane_off_wf));
-#endif
+      if constexpr (SG) {
+        asm volatile("" : "+v"(lane_off));
+        if constexpr (WF) asm volatile("" : "+v"(lane_off_wf));
+      }
     };
 
     // One point's K values into the accumulators (both weight sets).
@@ -972,6 +978,25 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
       (WF && WB2_WF_OUTER_FASTEST)
           ? dim3((unsigned)gy, (unsigned)(p.n_chunk * n_tblk), (unsigned)gz)
           : dim3((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
+  // unaligned float32 rows at 4 columns per lane: SGPR row bases are worth 4 %
+  // there (profiles/r03_k1_ab5_summary.txt), and cost 2-20 % everywhere else
+  constexpr bool HAS_SG = std::is_same<T, float>::value && VEC == 4 &&
+                          !SKIPNA && !WF &&
+                          (MODE == WB2_MODE_DET || MODE == WB2_MODE_DET_ACC ||
+                           MODE == WB2_MODE_WIND);
+  if constexpr (HAS_SG) {
+    static const bool sg_on = [] {  // WB2HIP_SGPR_UNALIGNED=0: A/B runs
+      const char* e = getenv("WB2HIP_SGPR_UNALIGNED");
+      return !(e && e[0] == '0');
+    }();
+    if (p.unaligned && sg_on) {
+      hipLaunchKernelGGL(
+          (stream_partials_kernel<T, VEC, MODE, SKIPNA, WF, true>), grid,
+          dim3(threads), 0, stream, p);
+      WB2_HIP_OK(hipGetLastError());
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((stream_partials_kernel<T, VEC, MODE, SKIPNA, WF>), grid,
                      dim3(threads), 0, stream, p);
   WB2_HIP_OK(hipGetLastError());
@@ -1179,6 +1204,8 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
   const int vec = vec_width(mode, dtype, skipna != 0, wfield != nullptr, n_col,
                             aligned);
   const int threads = threads_for(n_col, vec);
+  p.unaligned =
+      !aligned || ((long long)n_col * (dtype == WB2_F32 ? 4 : 8)) % 16 != 0;
   p.w_row = w_row;
   p.w_col = w_col;
   p.wfield = wfield;
