@@ -304,6 +304,7 @@ def stream_reduce(plan: ReductionPlan, mode: int,
 
 GATHER_MAX_MEMBERS = {torch.float32: 128, torch.float64: 64}  # register sort
 _NAN_SLABS: dict = {}
+_NAN_SLABS_LOCK = threading.Lock()
 
 
 def nan_slab(device: torch.device, dtype: torch.dtype, n_elems: int):
@@ -312,8 +313,14 @@ def nan_slab(device: torch.device, dtype: torch.dtype, n_elems: int):
   key = (str(device), dtype, int(n_elems))
   slab = _NAN_SLABS.get(key)
   if slab is None:
-    slab = torch.full((int(n_elems),), float('nan'), dtype=dtype, device=device)
-    _NAN_SLABS[key] = slab
+    with _NAN_SLABS_LOCK:
+      slab = _NAN_SLABS.get(key)
+      if slab is None:
+        slab = torch.full((int(n_elems),), float('nan'), dtype=dtype,
+                          device=device)
+        # filled before any other thread's stream can read it (once per size)
+        torch.cuda.current_stream(device).synchronize()
+        _NAN_SLABS[key] = slab
   return slab
 
 
