@@ -319,7 +319,8 @@ def nan_slab(device: torch.device, dtype: torch.dtype, n_elems: int):
         slab = torch.full((int(n_elems),), float('nan'), dtype=dtype,
                           device=device)
         # filled before any other thread's stream can read it (once per size)
-        torch.cuda.current_stream(device).synchronize()
+        if torch.device(device).type == 'cuda':
+          torch.cuda.current_stream(device).synchronize()
         _NAN_SLABS[key] = slab
   return slab
 
