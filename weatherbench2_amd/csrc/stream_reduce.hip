@@ -325,9 +325,9 @@ __device__ __forceinline__ void eval_slots(
 #define WB2_WF_OUTER_FASTEST 1
 #endif
 #ifndef WB2_SGPR_ROWS
-// 1: row pointers pinned to SGPR pairs + one 32-bit lane offset (the
-// `global_load v_off, s[base:base+1]` form); 0: plain pointer arithmetic (hipcc
-// adds a 64-bit lane offset to every load's base with a v_lshl_add_u64).
+// Default of the kernel's SG parameter (see `at` in the kernel): 1 = SGPR row
+// bases for EVERY instantiation (A/B builds), 0 = only where launch_stream
+// selects the SG instantiation (unaligned float32 rows).
 // Measured (profiles/r03_k1_ab5_summary.txt): the SGPR form is SLOWER -- every
 // load then waits for the scalar add that makes its base (headline 0.418 ->
 // 0.427 ms, weight field 0.500 -> 0.556, skipna 0.463 -> 0.560); only the
@@ -458,10 +458,16 @@ __global__ void __launch_bounds__(
       for (int k = 0; k < K; ++k) acc[w][e][k] = 0.0;
 
   if (active) {
-    // Row pointers stay wave-uniform (SGPR pairs advanced by scalar adds); the
-    // lane's columns enter as ONE unsigned 32-bit byte offset, which is the
-    // `global_load ... v_off, s[base:base+1]` addressing form: no 64-bit vector
-    // add per load.
+    // base[i] / wfp: wave-uniform row pointers (scalar adds advance them).  Two
+    // ways to add the lane's columns (template parameter SG):
+    //   SG = false  plain pointer arithmetic -- hipcc adds the row offset to a
+    //               64-bit lane offset once and pays one v_lshl_add_u64 per
+    //               load for its base: the faster form on 16-byte aligned rows;
+    //   SG = true   the row pointer pinned to an SGPR pair and the lane's
+    //               columns as ONE unsigned 32-bit byte offset, i.e. `global_load
+    //               v_off, s[base:base+1]`: 4.5 % faster on the unaligned rows
+    //               of the lon-lat layout, 2-20 % slower on aligned ones (each
+    //               load waits for the scalar add that makes its base).
     const long long slab_elems = (long long)p.n_row * p.n_col;
     const T* base[NIN];
 #pragma unroll
@@ -472,9 +478,6 @@ __global__ void __launch_bounds__(
     const double* wrp = p.w_row + row0;
     unsigned lane_off = (unsigned)colb * (unsigned)sizeof(T);
     unsigned lane_off_wf = (unsigned)colb * (unsigned)sizeof(double);
-    // (the row pointer pinned to an SGPR pair: otherwise the row offset, common
-    // to every input, is added to the lane offset first and each load pays one
-    // 64-bit vector add for its base.)
     auto at = [&](const T* row) {
       if constexpr (SG) {
         unsigned long long rp = reinterpret_cast<unsigned long long>(row);
@@ -497,10 +500,10 @@ __global__ void __launch_bounds__(
             reinterpret_cast<unsigned long long>(row + colb));
       }
     };
-    // Opaque to the optimiser inside the loop: hoisted, the zero-extension
-    // becomes a loop-invariant 64-bit VGPR pair and instruction selection (per
-    // block) no longer sees a 32-bit offset -- back to one v_lshl_add_u64 per
-    // load.
+    // SG: the lane offset opaque to the optimiser inside the loop -- hoisted,
+    // its zero-extension becomes a loop-invariant 64-bit VGPR pair and
+    // instruction selection (per block) no longer sees a 32-bit offset: back
+    // to one v_lshl_add_u64 per load.
     auto pin_offsets = [&]() {
       if constexpr (SG) {
         asm volatile("" : "+v"(lane_off));
