@@ -487,6 +487,116 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   }
 }
 
+#ifndef WB2_ENS_LEAN_RUNTIME
+#define WB2_ENS_LEAN_RUNTIME 1  // 0: the select-per-member runtime-M path for every case
+#endif
+
+// Runtime member count WITHOUT NaN skipping, lean form.  The caller has set the
+// slots >= M to +inf; the dead slots are a wave-uniform SUFFIX, so the
+// statistics walk the members in groups of four behind wave-uniform branches
+// -- a group inside [0, M) runs without a single select, the group that
+// straddles M takes per-member branches, groups beyond M are skipped -- and
+// the padded network sorts the +inf to the end, where the rank-weighted sum
+// stops.  Same operations in the same order as ens_point's generic path for
+// the M live members (the select-per-member form cost six v_cndmask per member
+// and kept a lane mask per member and phase in SGPRs: 0.26-0.50 of the HBM
+// peak against 0.76 for the exact-50 kernel).
+template <typename T, int NPAD>
+__device__ __forceinline__ void ens_point_runtime(T (&x)[NPAD], const T t,
+                                                  const int M,
+                                                  double (&out)[6]) {
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  T sum = 0, sk = 0, sq = 0;
+  bool bad = false;
+  constexpr int G = 4;
+  static_assert(NPAD % G == 0, "padded sizes are multiples of 4");
+#pragma unroll
+  for (int g = 0; g < NPAD; g += G) {
+    if (g < M) {  // wave-uniform
+      if (g + G <= M) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          sum += x[g + u];
+          sk += abs_of(t - x[g + u]);
+        }
+        bad = bad || __builtin_isunordered(x[g], x[g + 1]) ||
+              __builtin_isunordered(x[g + 2], x[g + 3]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (g + u < M) {
+            sum += x[g + u];
+            sk += abs_of(t - x[g + u]);
+            bad = bad || is_nan(x[g + u]);
+          }
+        }
+      }
+    }
+  }
+  // metrics.py:562-565 / :824 -- numpy mean / var(ddof=1) / mean(abs) over the
+  // leading (member) axis: sequential, in the input dtype
+  const T mean = sum / (T)M;
+#pragma unroll
+  for (int g = 0; g < NPAD; g += G) {
+    if (g < M) {
+      if (g + G <= M) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const T d = x[g + u] - mean;
+          sq += d * d;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (g + u < M) {
+            const T d = x[g + u] - mean;
+            sq += d * d;
+          }
+        }
+      }
+    }
+  }
+  const T var = sq / (T)(M - 1);
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  const T deb = mse - var / (T)M;
+  const T skill = sk / (T)M;
+  // metrics.py:804-813: ranks from the full ensemble; the +inf padding sorts
+  // behind every live member (a NaN member poisons the result: `bad`)
+  double spread = 0.0;
+  if (M >= 2) {
+    sort_network<NPAD, NPAD>(x);
+    double s = 0.0;
+    const int c0 = -M - 1;  // weight of rank r (0-based): 2 (r + 1) - M - 1
+#pragma unroll
+    for (int g = 0; g < NPAD; g += G) {
+      if (g < M) {
+        if (g + G <= M) {
+#pragma unroll
+          for (int u = 0; u < G; ++u)
+            s = __builtin_fma((double)(2 * (g + u + 1) + c0), (double)x[g + u],
+                              s);
+        } else {
+#pragma unroll
+          for (int u = 0; u < G; ++u)
+            if (g + u < M)
+              s = __builtin_fma((double)(2 * (g + u + 1) + c0),
+                                (double)x[g + u], s);
+        }
+      }
+    }
+    spread = 2.0 * (s / (double)M) / (double)(M - 1);
+    if (bad) spread = (double)nan;  // a NaN member poisons the mean
+  }
+  out[0] = (double)skill;
+  out[1] = spread;
+  out[2] = (double)mse;
+  out[3] = (double)var;
+  out[4] = (double)(sd * sd);
+  out[5] = (double)deb;
+}
+
 #ifndef WB2_ENS_MIN_WAVES
 #define WB2_ENS_MIN_WAVES 1
 #endif
@@ -691,8 +801,7 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
         // hipcc hoists all NPAD of them out of the row loop (64-bit pairs in
         // SGPRs: 192-468 dwords of SGPR spills).  The stride / the address
         // lanes are made opaque once per row instead, and the base advances
-        // member by member (slots >= M re-read the last member: cache hit,
-        // ignored).
+        // member by member.
         long long stride_r = p.member_stride;
         int Mr = M;  // runtime M, opaque per row: the per-member `m < M` lane
                      // masks are recomputed (scalar compares) instead of being
@@ -712,7 +821,11 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
             if constexpr (MS > 0) {
               mrow = xrow + m * p.member_stride;
             } else {
-              mrow = mb;
+              // slots >= M read member 0 again (cache hit; replaced by +inf or
+              // ignored); the base itself advances unconditionally -- a select
+              // inside the chain made every load wait for 5 dependent scalar
+              // instructions per member before it
+              mrow = m < Mr ? mb : xrow;
               if (gathered) {
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane(
                     (int)mp_lo[m / kWave], m % kWave);
@@ -722,7 +835,7 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
                            ((unsigned long long)hi << 32) | lo) +
                        (long long)(row0 + r) * p.n_col;
               }
-              mb += (m + 1 < Mr) ? stride_r : 0;
+              mb += stride_r;
             }
             x[m] = member_load<T, true>(mrow, lane_bytes);
           } else {
@@ -730,7 +843,15 @@ __global__ void __launch_bounds__(256, WB2_ENS_MIN_WAVES)
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        ens_point<T, NPAD, MS, SKIPNA>(x, t, Mr, v);
+        if constexpr (WB2_ENS_LEAN_RUNTIME && MS == 0 && !SKIPNA) {
+          // dead slots (a wave-uniform suffix) become +inf ONCE, here
+#pragma unroll
+          for (int m = 0; m < NPAD; ++m)
+            x[m] = m < Mr ? x[m] : std::numeric_limits<T>::infinity();
+          ens_point_runtime<T, NPAD>(x, t, Mr, v);
+        } else {
+          ens_point<T, NPAD, MS, SKIPNA>(x, t, Mr, v);
+        }
       }
       if (p.maps) {
         // Spatial* metrics (metrics.py:718-772, 1244-1266, 1366-1399): the
