@@ -170,6 +170,9 @@ __device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
 #undef WB2_CE
 }
 
+#ifndef WB2_ENS_SKIPNA_LEAN
+#define WB2_ENS_SKIPNA_LEAN 1  // exact M with skipna: mask-free variance / sort preparation
+#endif
 #ifndef WB2_ENS_DIV_CONST
 #define WB2_ENS_DIV_CONST 1  // compile-time member count: x / M as mul + 2 FMA (exact)
 #endif
@@ -290,6 +293,17 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   T sum = 0, sk = 0;
   int n = 0;          // valid members (SKIPNA)
   bool bad = false;   // any NaN member (!SKIPNA)
+  // Exact member count WITH NaN skipping: the per-member NaN masks are used
+  // where they are made (sum, |t - x|, count) and nowhere else -- kept for the
+  // variance and the sort they cost an SGPR pair per member and phase (spilled
+  // and reloaded through VGPR lanes: 264 v_readlane / v_writelane per row).  The
+  // later phases get mask-free forms with the same values: max(d * d, 0) is d * d
+  // for a valid member and 0 for a NaN one (v_max returns the non-NaN
+  // operand), min(x, +inf) turns a NaN member into the +inf the sort wants.
+  // The one case where d * d is NaN for a VALID member is an infinite member
+  // (inf - inf): then, as before, the sum of squares is NaN.
+  constexpr bool SKIPNA_LEAN = WB2_ENS_SKIPNA_LEAN && SKIPNA && MS > 0;
+  bool inf_member = false;
   T sq = 0;
   T mean;
   if constexpr (MS > 0 && !SKIPNA && MS % 2 == 0) {
@@ -330,6 +344,15 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
       sk += use ? abs_of(t - x[m]) : (T)0;
       n += use ? 1 : 0;
       bad = bad || (live(m) && isn);
+      if constexpr (SKIPNA_LEAN) inf_member = inf_member || abs_of(x[m]) == inf;
+    }
+    if constexpr (SKIPNA_LEAN) {
+      // as for `bad` above: everything the sort does not need is finished (and
+      // pinned) before it, or hipcc sinks it below the sort and keeps the
+      // unsorted ensemble alive beside the sorted one
+      int pinned = inf_member ? 1 : 0;
+      asm volatile("" : "+v"(sum), "+v"(sk), "+v"(n), "+v"(pinned));
+      inf_member = pinned != 0;
     }
   }
   const int cnt = SKIPNA ? n : M;
@@ -356,10 +379,16 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
     } else {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
         const T d = x[m] - mean;
-        sq += use ? d * d : (T)0;
+        if constexpr (SKIPNA_LEAN) {
+          sq += abs_or_zero(d * d);
+        } else {
+          const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
+          sq += use ? d * d : (T)0;
+        }
       }
+      if (SKIPNA_LEAN && inf_member) sq = nan;
+      if constexpr (SKIPNA_LEAN) asm volatile("" : "+v"(sq));
     }
   }
   T var;
@@ -384,6 +413,8 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
     for (int m = 0; m < NPAD; ++m) {
       if (m >= NM) {
         x[m] = inf;
+      } else if constexpr (SKIPNA_LEAN) {
+        x[m] = vmin(x[m], inf);  // NaN -> +inf, everything else unchanged
       } else {
         x[m] = (!live(m) || (SKIPNA && is_nan(x[m]))) ? inf : x[m];
       }
