@@ -184,6 +184,33 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
                            const int32_t* seg_eoff, int32_t n_seg,
                            int32_t n_ts, double* partials, void* stream);
 
+/* As wb2_stream_partials_ex for slabs that do not share an allocation: input i
+ * of outer slab o is the n_row x n_col slab at BYTE ADDRESS slab_addr[i][o].
+ * This is how ONE launch serves every variable of a chunk (a Dataset's
+ * variables are separate arrays; the reference walks them one after the other,
+ * metrics.py:264, 284, 329, 358, 405-410 under xarray's Dataset arithmetic) and
+ * several consecutive chunks of the Beam pipeline
+ * (evaluation.py:583-599, 693-705: `input_chunks=init_time=1,lead_time=1`,
+ * `split_vars=False`).  The fold is per slab, so results are bit-identical to
+ * those of separate launches with the same chunk tables.
+ *
+ *  slab_addr[i] DEV int64[n_outer]: addresses of device memory, each a multiple
+ *                   of the element size; required for every input of `mode`
+ *  aligned16        nonzero iff every address (and wfield) is 16-byte aligned:
+ *                   the caller built the tables and knows; selects the same
+ *                   instantiation as aligned in[] would (n_ctile as above)
+ */
+int wb2_stream_partials_addr(int mode, int dtype, int skipna,
+                             const int64_t* const* slab_addr, int aligned16,
+                             int64_t n_outer, int32_t n_row, int32_t n_col,
+                             const double* w_row, const double* w_col,
+                             const double* wfield, const double* aux,
+                             double scalar, const int32_t* chunk_row0,
+                             const int32_t* chunk_nrow, int32_t n_chunk,
+                             int32_t n_ctile, const int32_t* seg_col0,
+                             const int32_t* seg_eoff, int32_t n_seg,
+                             int32_t n_ts, double* partials, void* stream);
+
 /*
  * K2: fold the partials into per-region sums and finalise the metrics.
  * Replaces the region loop + concat of evaluation.py:416-430 and the ratio /

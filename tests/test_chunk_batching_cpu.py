@@ -1,0 +1,117 @@
+"""Host logic of the chunk batching (no GPU): the zero-copy concatenation of
+(init_time=1, lead_time=1) chunks (evaluation.py:693-705 chunking), the
+windows `evaluate_chunks` forms from them, and the temporal mean keyed by lead
+labels (xbeam.Mean combines per chunk key, evaluation.py:735-744)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers, official_chunks as oc
+from weatherbench2_amd import evaluation
+from weatherbench2_amd import xarray_lite as xl
+
+
+def _product(n_init=4, n_lead=3):
+  forecast, truth, _ = oc.make(n_init=n_init, n_lead=n_lead, n_lat=7, n_lon=8)
+  return helpers.to_gpu_dataset(forecast), helpers.to_gpu_dataset(truth)
+
+
+def test_slab_concat_indexes_its_bases():
+  rs = np.random.RandomState(0)
+  bases = [rs.normal(size=(2, 3, 4, 5)), rs.normal(size=(1, 4, 5)),
+           rs.normal(size=(3, 4, 5))]
+  flat = np.concatenate([b.reshape(-1, 4, 5) for b in bases])
+  index = rs.permutation(flat.shape[0]).reshape(2, 5)
+  sc = xl.SlabConcat(bases, index)
+  assert sc.shape == (2, 5, 4, 5) and sc.ndim == 4 and sc.dtype == flat.dtype
+  np.testing.assert_array_equal(np.asarray(sc), flat[index])
+  np.testing.assert_array_equal(np.asarray(sc[1]), flat[index[1]])
+  np.testing.assert_array_equal(np.asarray(sc.permute_outer((1, 0))),
+                                flat[index.T])
+  tens = xl.SlabConcat([torch.from_numpy(b) for b in bases], index)
+  np.testing.assert_array_equal(tens.materialize().numpy(), flat[index])
+  # addresses: base pointer of the owning array + slab offset inside it
+  addr = tens.addresses()
+  step = 4 * 5 * 8
+  for pos, g in np.ndenumerate(index):
+    b = int(np.searchsorted(tens.offsets, g, side='right') - 1)
+    assert addr[pos] == tens.bases[b].data_ptr() + (g - tens.offsets[b]) * step
+  with pytest.raises(IndexError):
+    xl.SlabConcat(bases, [[flat.shape[0]]])
+  with pytest.raises(ValueError):
+    xl.SlabConcat([bases[0], rs.normal(size=(2, 4, 6))], [0])
+
+
+@pytest.mark.parametrize('order', ['init', 'lead'])
+def test_concat_chunks_is_the_concatenation(order):
+  forecast, truth = _product()
+  pairs = oc.chunk_pairs(forecast, truth, order)
+  joined = evaluation.concat_chunks([p[0] for p in pairs], 'init_time',
+                                    'lead_time')
+  assert joined is not None
+  # labels come back in chunk order (blocks by first appearance)
+  np.testing.assert_array_equal(np.sort(joined.coords['init_time']),
+                                forecast.coords['init_time'])
+  i_of = [list(forecast.coords['init_time']).index(v)
+          for v in joined.coords['init_time']]
+  l_of = [list(forecast.coords['lead_time']).index(v)
+          for v in joined.coords['lead_time']]
+  for name, da in joined.items():
+    assert isinstance(da.data, xl.SlabConcat)
+    assert da.dims == forecast[name].dims
+    want = np.asarray(forecast[name].data)[i_of][:, l_of]
+    np.testing.assert_array_equal(np.asarray(da.data), want)
+  vt = joined.coords['valid_time']
+  np.testing.assert_array_equal(
+      vt.values, np.asarray(forecast.coords['valid_time'].values)[i_of][:, l_of])
+
+
+def test_concat_chunks_refuses_what_is_not_a_rectangle():
+  forecast, truth = _product()
+  pairs = oc.chunk_pairs(forecast, truth)
+  fs = [p[0] for p in pairs]
+  assert evaluation.concat_chunks(fs[:5], 'init_time', 'lead_time') is None
+  assert evaluation.concat_chunks([fs[0], fs[0]], 'init_time',
+                                  'lead_time') is None
+  # a lazily gathered variable cannot be addressed in place
+  lazy = xl.Dataset(coords=fs[1].coords)
+  for k, v in fs[1].items():
+    lazy[k] = xl.DataArray(
+        xl.SlabGather(np.asarray(v.data), np.arange(
+            int(np.prod(v.shape[:-2]))).reshape(v.shape[:-2])), v.dims)
+  assert evaluation.concat_chunks([fs[0], lazy], 'init_time',
+                                  'lead_time') is None
+  # one lead per piece when the window is ragged
+  pieces = evaluation._batches(pairs[:5], 'init_time', 'lead_time')
+  assert sorted(p[0].sizes['init_time'] for p in pieces) == [1, 2, 2]
+
+
+def test_running_mean_keeps_lead_blocks_apart():
+  rs = np.random.RandomState(1)
+  leads = (np.arange(3) * np.timedelta64(6, 'h')).astype('timedelta64[ns]')
+  values = rs.normal(size=(5, 3, 2))  # (init, lead, level)
+  values[1, 2, 0] = np.nan
+  for skipna in (False, True):
+    mean = evaluation.RunningMean('init_time', skipna, split_dim='lead_time')
+    for i in range(5):
+      for l in (2, 0, 1):  # any order
+        mean.add(xl.Dataset(
+            {'z': xl.DataArray(values[i:i + 1, l:l + 1],
+                               ('init_time', 'lead_time', 'level'))},
+            {'init_time': np.arange(i, i + 1), 'lead_time': leads[l:l + 1],
+             'level': np.array([500, 850])}))
+    got = mean.result()
+    np.testing.assert_array_equal(got.coords['lead_time'], leads)
+    want = (np.nanmean if skipna else np.mean)(values, axis=0)
+    np.testing.assert_allclose(got['z'].values, want, rtol=1e-15,
+                               equal_nan=True)
+  # whole-lead chunks behave as before (one block, labels kept as given)
+  mean = evaluation.RunningMean('init_time', False, split_dim='lead_time')
+  for i in range(5):
+    mean.add(xl.Dataset(
+        {'z': xl.DataArray(values[i:i + 1], ('init_time', 'lead_time',
+                                             'level'))},
+        {'init_time': np.arange(i, i + 1), 'lead_time': leads,
+         'level': np.array([500, 850])}))
+  np.testing.assert_allclose(mean.result()['z'].values, values.mean(0),
+                             rtol=1e-15, equal_nan=True)

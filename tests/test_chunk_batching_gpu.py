@@ -1,0 +1,180 @@
+"""GPU parity of the production chunking (-m gpu): every variable of a chunk
+in ONE fused launch (wb2_stream_partials_addr), k consecutive
+(init_time=1, lead_time=1) chunks in one pass of the metric x region loop.
+Reference: evaluation.py:583-599 (_evaluate_chunk), 693-705 (chunk source,
+split_vars=False), 735-744 (TemporalMean); docs/source/official-evaluation.md:
+537-556 (the official 0.25-degree configuration)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers, official_chunks as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(device_resident, **kw):
+  import torch
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  forecast, truth, clim = oc.make(**kw)
+  lat, lon = forecast.coords['latitude'], forecast.coords['longitude']
+  lsm = oc.land_sea_mask(len(lat), len(lon))
+  oregions = oc.oracle_regions(lat, lon, lsm)
+  gregions = {k: helpers.to_gpu_region(v) for k, v in oregions.items()}
+  gf, gt, gc = (helpers.to_gpu_dataset(x) for x in (forecast, truth, clim))
+  if device_resident:
+    gf, gt, gc = (evaluation.make_resident(x) for x in (gf, gt, gc))
+  cfg = config.Eval(metrics=oc.product_metrics(gm, gc), regions=gregions)
+  return forecast, truth, clim, oregions, gf, gt, cfg
+
+
+def _launch_counter():
+  from weatherbench2_amd import engine
+  seen = []
+
+  def hook(when, kernel):
+    if when == 'begin':
+      seen.append(kernel)
+  old = engine.set_launch_hook(hook)
+  return seen, old
+
+
+def _check_against_oracle(res, want, rtol=1e-9):
+  metric_labels = list(res.coords['metric'])
+  region_labels = list(res.coords['region'])
+  checked = 0
+  for (mname, rname), per_var in want.items():
+    mi, ri = metric_labels.index(mname), region_labels.index(rname)
+    for var, (dims, values) in per_var.items():
+      got = res[var]
+      order = [d for d in got.dims if d not in ('metric', 'region')]
+      vals = got.values[mi, ri]
+      vals = np.transpose(vals, [order.index(d) for d in dims])
+      helpers.assert_close(vals, values, rtol=rtol, atol=1e-12,
+                           err_msg=f'{mname}/{rname}/{var}')
+      checked += 1
+  assert checked >= len(want)
+
+
+@pytest.mark.parametrize('device_resident', [True, False])
+def test_every_variable_of_a_chunk_in_one_launch(device_resident, monkeypatch):
+  """The loop over one chunk: <= 2 K1 launches (deterministic suite + wind
+  vectors) for 6 variables, results bit-identical to one launch per variable
+  under the same chunking, and equal to the oracle's."""
+  from weatherbench2_amd import engine, evaluation, metrics as gm
+  forecast, truth, clim, oregions, gf, gt, cfg = _setup(
+      device_resident, n_init=2, n_lead=2)
+  want = oc.expected_time_mean(forecast, truth, clim, oregions, False)
+  del want  # (the per-chunk values are checked below, not their mean)
+  with gm.pinned_rows_per_chunk(8):
+    seen, old = _launch_counter()
+    try:
+      fused = evaluation._metric_and_region_loop(gf, gt, cfg, False,
+                                                 compute_chunk=True)
+      n_fused = seen.count('stream_partials')
+      seen.clear()
+      monkeypatch.setenv('WB2HIP_FUSE_VARIABLES', '0')
+      gm.clear_caches()
+      single = evaluation._metric_and_region_loop(gf, gt, cfg, False,
+                                                  compute_chunk=True)
+      n_single = seen.count('stream_partials')
+    finally:
+      engine.set_launch_hook(old)
+  assert n_fused == 2, n_fused
+  assert n_single == len(oc.VARS_3D) + len(oc.VARS_2D) + len(oc.WIND)
+  for name in fused.keys():
+    a, b = fused[name].values, single[name].values
+    assert a.dtype == b.dtype and a.shape == b.shape
+    assert np.array_equal(a, b, equal_nan=True), name
+  # against the oracle, chunk values
+  from oracle import evaluation_np as oe
+  per_chunk = oe.metric_and_region_loop(
+      forecast, truth, oc.oracle_metrics(clim), oregions, False,
+      compute_chunk=True)
+  labels_m, labels_r = list(fused.coords['metric']), list(
+      fused.coords['region'])
+  for (mname, rname), ds in per_chunk.items():
+    for var, v in ds.items():
+      got = fused[var]
+      order = [d for d in got.dims if d not in ('metric', 'region')]
+      vals = got.values[labels_m.index(mname), labels_r.index(rname)]
+      vals = np.transpose(vals, [order.index(d) for d in v.dims])
+      helpers.assert_close(vals, v.data, rtol=1e-9, atol=1e-12,
+                           err_msg=f'{mname}/{rname}/{var}')
+
+
+@pytest.mark.parametrize('order', ['init', 'lead'])
+@pytest.mark.parametrize('skipna', [False, True])
+def test_batched_chunks_equal_unbatched_bit_for_bit(order, skipna):
+  """evaluate_chunks over (init_time=1, lead_time=1) chunks: every
+  batch_chunks gives the SAME bits (one fused pass per window, the fold is per
+  slab and the chunking is pinned), and the result is the oracle's."""
+  from weatherbench2_amd import engine, evaluation
+  forecast, truth, clim, oregions, gf, gt, cfg = _setup(
+      True, n_init=6, n_lead=3, nan_frac=0.002 if skipna else 0.0)
+  pairs = oc.chunk_pairs(gf, gt, order)
+  base = evaluation.evaluate_chunks(pairs, cfg, skipna, batch_chunks=1)
+  want = oc.expected_time_mean(forecast, truth, clim, oregions, skipna)
+  _check_against_oracle(base, want)
+  np.testing.assert_array_equal(base.coords['lead_time'],
+                                forecast.coords['lead_time'])
+  for k in (3, 4, 6, 18, 64):
+    seen, old = _launch_counter()
+    try:
+      got = evaluation.evaluate_chunks(pairs, cfg, skipna, batch_chunks=k)
+    finally:
+      engine.set_launch_hook(old)
+    for name in base.keys():
+      a, b = got[name].values, base[name].values
+      assert got[name].dims == base[name].dims
+      assert np.array_equal(a, b, equal_nan=True), (k, name)
+    if k == 18 or k == 64:  # the whole job is one rectangle: 2 launches
+      assert seen.count('stream_partials') == 2, seen
+
+
+def test_batching_host_chunks_and_ragged_windows():
+  """Host (NumPy) chunks are uploaded array by array and read in place; a
+  window that is no rectangle falls back to per-lead pieces."""
+  from weatherbench2_amd import evaluation
+  forecast, truth, clim, oregions, gf, gt, cfg = _setup(
+      False, n_init=5, n_lead=2)
+  pairs = oc.chunk_pairs(gf, gt, 'init')
+  want = oc.expected_time_mean(forecast, truth, clim, oregions, False)
+  base = evaluation.evaluate_chunks(pairs, cfg, False, batch_chunks=1)
+  _check_against_oracle(base, want)
+  for k in (3, 7):  # windows cut rectangles apart
+    got = evaluation.evaluate_chunks(pairs, cfg, False, batch_chunks=k)
+    for name in base.keys():
+      assert np.array_equal(got[name].values, base[name].values,
+                            equal_nan=True), (k, name)
+
+
+def test_addr_entry_point_equals_the_slab_table_one():
+  """wb2_stream_partials_addr == wb2_stream_partials_ex bit for bit on the
+  same slabs (engine level, BASELINE grid, slabs scattered over allocations)."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  dev = torch.device('cuda', 0)
+  lat = np.linspace(-90, 90, 721)
+  lon = np.linspace(0, 360, 1440, endpoint=False)
+  regions = helpers.predefined_regions(oracle=False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev, 32)
+  g = torch.Generator(device=dev).manual_seed(5)
+  n = 6
+  f, t, c = (torch.randn((n, 721, 1440), device=dev, generator=g)
+             for _ in range(3))
+  tab = [None, torch.tensor([3, 0, 5, 1, 1, 4], device=dev),
+         torch.tensor([0, 0, 2, 2, 4, 5], device=dev)]
+  want, _ = engine.stream_reduce(pl, _lib.MODE_DET_ACC, [f, t, c], tab, n,
+                                 False)
+  # the same slabs, each copied into an allocation of its own
+  step = 721 * 1440 * 4
+  parts = [[x[i].clone() for i in range(n)] for x in (f, t, c)]
+  idx = [list(range(n)), [3, 0, 5, 1, 1, 4], [0, 0, 2, 2, 4, 5]]
+  addr = torch.tensor([[parts[j][i].data_ptr() for i in idx[j]]
+                       for j in range(3)], dtype=torch.int64, device=dev)
+  got, _ = engine.stream_reduce_addr(pl, _lib.MODE_DET_ACC, torch.float32,
+                                     list(addr), True, n, False)
+  assert torch.equal(got, want)
+  del step

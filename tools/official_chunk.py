@@ -1,0 +1,261 @@
+"""The drop-in boundary at the reference's PRODUCTION chunking, measured.
+
+  python tools/official_chunk.py [--chunks 96] [--batch 1,16,32] [--profile]
+
+The official 0.25-degree deterministic run (docs/source/official-evaluation.md:
+537-556) feeds `_evaluate_chunk` (evaluation.py:583-599) one chunk per
+`--input_chunks=init_time=1,lead_time=1` with all 13 variables in it
+(`split_vars=False`, evaluation.py:693-705): six 13-level fields (geopotential,
+temperature, u / v wind, specific humidity, wind speed) and seven surface
+fields = 85 slabs of 721 x 1440 per chunk, against the 16 regions of
+scripts/evaluate.py:345-395 (13 slices + 3 land-sea-mask regions) with the
+metrics of its `deterministic` config (:420-425): mse (+ the two wind-vector
+pairs, :279-311), acc, bias, mae.
+
+This leg streams such chunks -- device-resident, float32, synthetic N(0, 1) --
+through `evaluation.evaluate_chunks(..., batch_chunks=k)` and reports, per k:
+grid-point-evals/s (one eval = one point of one variable through the whole
+metric set), wall / host time per chunk, K1 launches per chunk and the K1
+roofline fraction at that launch size (HIP events on the launch stream).
+`bench.py` puts the result into its default line as `api_official_chunk`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+N_LEV, N_LAT, N_LON = 13, 721, 1440
+VARS_3D = ('geopotential', 'temperature', 'u_component_of_wind',
+           'v_component_of_wind', 'specific_humidity', 'wind_speed')
+VARS_2D = ('2m_temperature', '10m_u_component_of_wind',
+           '10m_v_component_of_wind', 'mean_sea_level_pressure',
+           'total_precipitation_6hr', 'total_precipitation_24hr',
+           '10m_wind_speed')
+WIND = (('u_component_of_wind', 'v_component_of_wind', 'wind_vector'),
+        ('10m_u_component_of_wind', '10m_v_component_of_wind',
+         '10m_wind_vector'))
+SLABS_PER_CHUNK = len(VARS_3D) * N_LEV + len(VARS_2D)           # 85
+WIND_SLABS_PER_CHUNK = N_LEV + 1                                # 14 (u, v) pairs
+PTS_PER_CHUNK = SLABS_PER_CHUNK * N_LAT * N_LON
+# algorithmic bytes: 12 B per point of every variable (forecast +
+# truth + climatology) + 16 B per point of every wind-vector pair (u, v of
+# forecast and truth, read again by the wind-vector pass)
+DET_BYTES_PER_CHUNK = PTS_PER_CHUNK * 12.0
+WIND_BYTES_PER_CHUNK = WIND_SLABS_PER_CHUNK * N_LAT * N_LON * 16.0
+HBM_PEAK_GBPS = 8000.0
+
+
+class _Events:
+  """HIP events around every K1 launch (engine's launch hook) + a count."""
+
+  def __init__(self, timed: bool):
+    self.timed = timed
+    self.pairs: list = []
+    self.launches = 0
+    self.cur = None
+
+  def __call__(self, when, kernel):
+    import torch
+    if kernel != 'stream_partials':
+      return
+    if when == 'begin':
+      self.launches += 1
+      if self.timed:
+        self.cur = (torch.cuda.Event(enable_timing=True),
+                    torch.cuda.Event(enable_timing=True))
+        self.cur[0].record()
+    elif self.timed:
+      self.cur[1].record()
+      self.pairs.append(self.cur)
+
+
+def build(dev, n_chunks: int, pool: int, n_lead: int = 4):
+  """(chunks, eval config): `n_chunks` (init_time=1, lead_time=1) chunk pairs
+  in init-major order over a pool of `pool` distinct device-resident chunks."""
+  import torch
+  import bench
+  from weatherbench2_amd import config, metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  lat = np.linspace(-90, 90, N_LAT)
+  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  level = np.array([50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925,
+                    1000])
+  n_init = -(-n_chunks // n_lead)
+  init = (np.datetime64('2020-01-01T00', 'ns') +
+          np.arange(n_init) * np.timedelta64(12, 'h'))
+  lead = (np.arange(n_lead) * np.timedelta64(6, 'h')).astype('timedelta64[ns]')
+  n_day = int(np.ceil((n_init * 12 + n_lead * 6) / 24.0)) + 1
+  g = torch.Generator(device=dev).manual_seed(11)
+
+  def randn(*shape):
+    return torch.randn(shape, device=dev, generator=g)
+  d3 = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+  d2 = ('init_time', 'lead_time', 'latitude', 'longitude')
+  pooled = []
+  for _ in range(pool):
+    f = {k: randn(1, 1, N_LEV, N_LAT, N_LON) for k in VARS_3D}
+    f.update({k: randn(1, 1, N_LAT, N_LON) for k in VARS_2D})
+    t = {k: randn(1, 1, N_LEV, N_LAT, N_LON) for k in VARS_3D}
+    t.update({k: randn(1, 1, N_LAT, N_LON) for k in VARS_2D})
+    pooled.append((f, t))
+  ccoords = {'hour': np.array([0, 6, 12, 18]),
+             'dayofyear': 1 + np.arange(n_day), 'level': level,
+             'latitude': lat, 'longitude': lon}
+  clim = xl.Dataset(coords=ccoords)
+  for k in VARS_3D:
+    clim[k] = xl.DataArray(randn(4, n_day, N_LEV, N_LAT, N_LON),
+                           ('hour', 'dayofyear', 'level', 'latitude',
+                            'longitude'))
+  for k in VARS_2D:
+    clim[k] = xl.DataArray(randn(4, n_day, N_LAT, N_LON),
+                           ('hour', 'dayofyear', 'latitude', 'longitude'))
+  chunks = []
+  for j in range(n_chunks):
+    i, l = divmod(j, n_lead)
+    valid = init[i:i + 1, None] + lead[None, l:l + 1]
+    coords = {'init_time': init[i:i + 1], 'lead_time': lead[l:l + 1],
+              'level': level, 'latitude': lat, 'longitude': lon,
+              'valid_time': xl.DataArray(valid, ('init_time', 'lead_time'))}
+    f, t = pooled[j % pool]
+    fd = xl.Dataset({k: xl.DataArray(v, d3 if v.dim() == 5 else d2)
+                     for k, v in f.items()}, coords)
+    td = xl.Dataset({k: xl.DataArray(v, d3 if v.dim() == 5 else d2)
+                     for k, v in t.items()}, dict(coords))
+    chunks.append((fd, td))
+  wv = [gm.WindVectorMSE(u_name=u, v_name=v, vector_name=n)
+        for u, v, n in WIND]
+  cfg = config.Eval(
+      metrics={'mse': gm.MSE(wind_vector_mse=wv),
+               'acc': gm.ACC(climatology=clim), 'bias': gm.Bias(),
+               'mae': gm.MAE()},
+      regions=bench.official_regions())
+  return chunks, cfg
+
+
+def measure(chunks, cfg, batch: int, timed_events: bool = True) -> dict:
+  import torch
+  from weatherbench2_amd import engine, evaluation
+  marks = {}
+  real_result = evaluation.RunningMean.result
+
+  def result(self):
+    marks['enqueued'] = time.perf_counter()  # the host is done with the chunks
+    return real_result(self)
+  ev = _Events(timed_events)
+  old = engine.set_launch_hook(ev)
+  evaluation.RunningMean.result = result
+  try:
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = evaluation.evaluate_chunks(chunks, cfg, False, batch_chunks=batch,
+                                     prefetch=0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+  finally:
+    evaluation.RunningMean.result = real_result
+    engine.set_launch_hook(old)
+  n = len(chunks)
+  leg = {
+      'batch_chunks': batch, 'chunks': n,
+      'value': n * PTS_PER_CHUNK / (t1 - t0), 'unit': 'grid-point-evals/s',
+      'wall_ms_per_chunk': (t1 - t0) / n * 1e3,
+      'host_ms_per_chunk': (marks['enqueued'] - t0) / n * 1e3,
+      'k1_launches_per_chunk': ev.launches / n,
+  }
+  if timed_events and ev.pairs:
+    ms = [a.elapsed_time(b) for a, b in ev.pairs]
+    # launches alternate (deterministic suite, wind vectors) per window
+    det, wind = sum(ms[0::2]), sum(ms[1::2])
+    if ev.launches == 2 * (len(ms) // 2) and len(ms) % 2 == 0:
+      leg['roofline'] = {
+          'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
+          'kernel': 'stream_partials_kernel<float,4,DET_ACC,WF> over '
+                    f'{SLABS_PER_CHUNK * batch} slabs + <float,4,WIND,WF> over '
+                    f'{WIND_SLABS_PER_CHUNK * batch} slabs per window',
+          'k1_ms_per_chunk': (det + wind) / n,
+          'det_acc': {'ms_per_launch': det / (len(ms) // 2),
+                      'achieved': n * DET_BYTES_PER_CHUNK / det / 1e6,
+                      'frac': n * DET_BYTES_PER_CHUNK / det / 1e6 /
+                              HBM_PEAK_GBPS},
+          'wind': {'ms_per_launch': wind / (len(ms) // 2),
+                   'achieved': n * WIND_BYTES_PER_CHUNK / wind / 1e6,
+                   'frac': n * WIND_BYTES_PER_CHUNK / wind / 1e6 /
+                           HBM_PEAK_GBPS},
+          'algorithmic_bytes_per_chunk': DET_BYTES_PER_CHUNK +
+                                         WIND_BYTES_PER_CHUNK,
+          'achieved': n * (DET_BYTES_PER_CHUNK + WIND_BYTES_PER_CHUNK) /
+                      (det + wind) / 1e6,
+      }
+      leg['roofline']['frac'] = leg['roofline']['achieved'] / HBM_PEAK_GBPS
+    else:
+      leg['k1_ms_per_chunk'] = sum(ms) / n
+  del out
+  return leg
+
+
+def run(dev, n_chunks: int = 96, pool: int = 24, batches=(1, 16, 32),
+        headline_batch: int = 32) -> dict:
+  """The `api_official_chunk` object of the bench line."""
+  import torch
+  from weatherbench2_amd import metrics as gm
+  chunks, cfg = build(dev, n_chunks, pool)
+  measure(chunks[:8], cfg, 4, timed_events=False)  # plans, tables, allocator
+  legs = {}
+  for b in batches:
+    gm.clear_caches()
+    measure(chunks[:max(2 * b, 8)], cfg, b, timed_events=False)  # warm
+    legs[str(b)] = measure(chunks, cfg, b)
+  head = legs[str(headline_batch)] if str(headline_batch) in legs else (
+      legs[str(batches[-1])])
+  out = dict(head)
+  out['by_batch_chunks'] = legs
+  out['config'] = {
+      'workload': ('official 0.25-degree deterministic chunking: '
+                   'init_time=1,lead_time=1 chunks of 13 variables (6 x 13 '
+                   f'levels + 7 surface = {SLABS_PER_CHUNK} slabs of '
+                   f'{N_LAT}x{N_LON} f32), 16 regions incl. 3 land-sea-mask '
+                   'regions, mse (+ 2 wind vectors) + acc + bias + mae, '
+                   'evaluation.evaluate_chunks from device-resident chunks'),
+      'pool_chunks': pool, 'points_per_chunk': PTS_PER_CHUNK}
+  del chunks, cfg
+  torch.cuda.empty_cache()
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--chunks', type=int, default=96)
+  ap.add_argument('--pool', type=int, default=24)
+  ap.add_argument('--batch', default='1,16,32')
+  ap.add_argument('--profile', action='store_true',
+                  help='cProfile of the host path at the first batch size')
+  args = ap.parse_args()
+  import torch
+  dev = torch.device('cuda', 0)
+  batches = tuple(int(b) for b in args.batch.split(','))
+  if args.profile:
+    import cProfile
+    import pstats
+    chunks, cfg = build(dev, args.chunks, args.pool)
+    measure(chunks[:8], cfg, batches[0], timed_events=False)
+    pr = cProfile.Profile()
+    pr.enable()
+    measure(chunks, cfg, batches[0], timed_events=False)
+    pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+    return
+  print(json.dumps(run(dev, args.chunks, args.pool, batches,
+                       headline_batch=batches[-1])))
+
+
+if __name__ == '__main__':
+  main()

@@ -49,6 +49,12 @@ struct StreamParams {
   const int* seg_eoff;
   double* partials;
   long long n_outer;
+  // bytes between consecutive slab numbers of an input: n_row * n_col *
+  // sizeof(T) when `slab` holds slab numbers (or is NULL), 1 when it holds the
+  // byte ADDRESS of every slab and in[] is NULL (wb2_stream_partials_addr: the
+  // slabs of one launch live in different allocations -- the variables of a
+  // chunk, consecutive chunks)
+  long long slab_step_bytes;
   int n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
   // host only: rows (n_col * sizeof(T)) or input bases are not 16-byte aligned
   // -- the lon-lat layout's 721-column rows: selects the SGPR-addressed
@@ -468,11 +474,12 @@ __global__ void __launch_bounds__(
     //               v_off, s[base:base+1]`: 4.5 % faster on the unaligned rows
     //               of the lon-lat layout, 2-20 % slower on aligned ones (each
     //               load waits for the scalar add that makes its base).
-    const long long slab_elems = (long long)p.n_row * p.n_col;
     const T* base[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
-      base[i] = static_cast<const T*>(p.in[i]) + slab_idx[i] * slab_elems +
+      base[i] = reinterpret_cast<const T*>(
+                    static_cast<const char*>(p.in[i]) +
+                    slab_idx[i] * p.slab_step_bytes) +
                 (long long)row0 * p.n_col;
     const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col : nullptr;
     const double* wrp = p.w_row + row0;
@@ -1120,6 +1127,95 @@ int mode_nin(int mode) {
 }  // namespace
 }  // namespace wb2
 
+namespace wb2 {
+namespace {
+
+// The one body behind wb2_stream_partials[_ex] (in[] + slab NUMBERS) and
+// wb2_stream_partials_addr (slab ADDRESSES, in == nullptr).
+int stream_partials_impl(int mode, int dtype, int skipna, const void* const* in,
+                         const int64_t* const* slab, int addr_aligned16,
+                         int64_t n_outer, int32_t n_row, int32_t n_col,
+                         const double* w_row, const double* w_col,
+                         const double* wfield, const double* aux, double scalar,
+                         const int32_t* chunk_row0, const int32_t* chunk_nrow,
+                         int32_t n_chunk, int32_t n_ctile,
+                         const int32_t* seg_col0, const int32_t* seg_eoff,
+                         int32_t n_seg, int32_t n_ts, double* partials,
+                         void* stream) {
+  const bool by_addr = in == nullptr;
+  WB2_REQUIRE(mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC ||
+                  mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS ||
+                  mode == WB2_MODE_GAUSS_THR || mode == WB2_MODE_SEEPS,
+              "unknown mode %d", mode);
+  WB2_REQUIRE(mode != WB2_MODE_SEEPS || aux != nullptr,
+              "WB2_MODE_SEEPS needs the p1 field in `aux`");
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_REQUIRE((in || slab) && w_row && chunk_row0 && chunk_nrow && seg_col0 &&
+                  seg_eoff && partials,
+              "null pointer argument");
+  WB2_REQUIRE(n_outer >= 0 && n_row > 0 && n_col > 0 && n_chunk > 0 &&
+                  n_seg > 0,
+              "bad sizes: n_outer=%lld n_row=%d n_col=%d n_chunk=%d n_seg=%d",
+              (long long)n_outer, n_row, n_col, n_chunk, n_seg);
+  if (n_outer == 0) return 0;
+  WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
+  WB2_REQUIRE(n_outer < (1ll << 31), "n_outer=%lld too large",
+              (long long)n_outer);
+  StreamParams p{};
+  const int nin = mode_nin(mode);
+  const long long elem = dtype == WB2_F32 ? 4 : 8;
+  bool aligned = by_addr ? addr_aligned16 != 0 : true;
+  for (int i = 0; i < nin; ++i) {
+    if (by_addr) {
+      WB2_REQUIRE(slab[i] != nullptr, "address table %d is null", i);
+      p.in[i] = nullptr;
+      p.slab[i] = reinterpret_cast<const long long*>(slab[i]);
+      continue;
+    }
+    WB2_REQUIRE(in[i] != nullptr, "input %d is null", i);
+    p.in[i] = in[i];
+    p.slab[i] = slab ? reinterpret_cast<const long long*>(slab[i]) : nullptr;
+    aligned = aligned && (reinterpret_cast<uintptr_t>(in[i]) % 16 == 0);
+  }
+  p.slab_step_bytes = by_addr ? 1 : (long long)n_row * n_col * elem;
+  if (wfield) aligned = aligned && reinterpret_cast<uintptr_t>(wfield) % 16 == 0;
+  const int vec = vec_width(mode, dtype, skipna != 0, wfield != nullptr, n_col,
+                            aligned);
+  const int threads = threads_for(n_col, vec);
+  p.unaligned = !aligned || ((long long)n_col * elem) % 16 != 0;
+  p.w_row = w_row;
+  p.w_col = w_col;
+  p.wfield = wfield;
+  p.aux = aux;
+  p.scalar = scalar;
+  p.chunk_row0 = chunk_row0;
+  p.chunk_nrow = chunk_nrow;
+  p.seg_col0 = seg_col0;
+  p.seg_eoff = seg_eoff;
+  p.n_ts = n_ts;
+  p.partials = partials;
+  p.n_outer = n_outer;
+  p.n_row = n_row;
+  p.n_col = n_col;
+  p.n_chunk = n_chunk;
+  p.n_ctile = (n_col + kWave * vec - 1) / (kWave * vec);
+  WB2_REQUIRE(p.n_ctile == n_ctile,
+              "n_ctile=%d does not match the launch geometry (%d): inputs "
+              "must be 16-byte aligned iff wb2_tile_cols_ex() was asked so",
+              n_ctile, p.n_ctile);
+  p.n_seg = n_seg;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    return launch_stream_mode<float, WB2_F32_VEC>(p, mode, vec, skipna != 0,
+                                        wfield != nullptr, threads, s);
+  return launch_stream_mode<double, 2>(p, mode, vec, skipna != 0,
+                                       wfield != nullptr, threads, s);
+}
+
+}  // namespace
+}  // namespace wb2
+
 extern "C" {
 
 int wb2_num_slots(int mode, int skipna) {
@@ -1163,6 +1259,7 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                                 stream);
 }
 
+
 int wb2_stream_partials_ex(int mode, int dtype, int skipna,
                            const void* const* in, const int64_t* const* slab,
                            int64_t n_outer, int32_t n_row, int32_t n_col,
@@ -1175,67 +1272,31 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
                            int32_t n_ts, double* partials, void* stream) {
   WB2_TRACE();
   using namespace wb2;
-  WB2_REQUIRE(mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC ||
-                  mode == WB2_MODE_WIND || mode == WB2_MODE_GAUSS ||
-                  mode == WB2_MODE_GAUSS_THR || mode == WB2_MODE_SEEPS,
-              "unknown mode %d", mode);
-  WB2_REQUIRE(mode != WB2_MODE_SEEPS || aux != nullptr,
-              "WB2_MODE_SEEPS needs the p1 field in `aux`");
-  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
-  WB2_EMPTY_OK(n_outer);
-  WB2_REQUIRE(in && w_row && chunk_row0 && chunk_nrow && seg_col0 && seg_eoff &&
-                  partials,
-              "null pointer argument");
-  WB2_REQUIRE(n_outer >= 0 && n_row > 0 && n_col > 0 && n_chunk > 0 &&
-                  n_seg > 0,
-              "bad sizes: n_outer=%lld n_row=%d n_col=%d n_chunk=%d n_seg=%d",
-              (long long)n_outer, n_row, n_col, n_chunk, n_seg);
-  if (n_outer == 0) return 0;
-  WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
-  WB2_REQUIRE(n_outer < (1ll << 31), "n_outer=%lld too large",
-              (long long)n_outer);
-  StreamParams p{};
-  const int nin = mode_nin(mode);
-  bool aligned = true;
-  for (int i = 0; i < nin; ++i) {
-    WB2_REQUIRE(in[i] != nullptr, "input %d is null", i);
-    p.in[i] = in[i];
-    p.slab[i] = slab ? reinterpret_cast<const long long*>(slab[i]) : nullptr;
-    aligned = aligned && (reinterpret_cast<uintptr_t>(in[i]) % 16 == 0);
-  }
-  if (wfield) aligned = aligned && reinterpret_cast<uintptr_t>(wfield) % 16 == 0;
-  const int vec = vec_width(mode, dtype, skipna != 0, wfield != nullptr, n_col,
-                            aligned);
-  const int threads = threads_for(n_col, vec);
-  p.unaligned =
-      !aligned || ((long long)n_col * (dtype == WB2_F32 ? 4 : 8)) % 16 != 0;
-  p.w_row = w_row;
-  p.w_col = w_col;
-  p.wfield = wfield;
-  p.aux = aux;
-  p.scalar = scalar;
-  p.chunk_row0 = chunk_row0;
-  p.chunk_nrow = chunk_nrow;
-  p.seg_col0 = seg_col0;
-  p.seg_eoff = seg_eoff;
-  p.n_ts = n_ts;
-  p.partials = partials;
-  p.n_outer = n_outer;
-  p.n_row = n_row;
-  p.n_col = n_col;
-  p.n_chunk = n_chunk;
-  p.n_ctile = (n_col + kWave * vec - 1) / (kWave * vec);
-  WB2_REQUIRE(p.n_ctile == n_ctile,
-              "n_ctile=%d does not match the launch geometry (%d): inputs "
-              "must be 16-byte aligned iff wb2_tile_cols_ex() was asked so",
-              n_ctile, p.n_ctile);
-  p.n_seg = n_seg;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == WB2_F32)
-    return launch_stream_mode<float, WB2_F32_VEC>(p, mode, vec, skipna != 0,
-                                        wfield != nullptr, threads, s);
-  return launch_stream_mode<double, 2>(p, mode, vec, skipna != 0,
-                                       wfield != nullptr, threads, s);
+  WB2_REQUIRE(in != nullptr, "null pointer argument");
+  return stream_partials_impl(mode, dtype, skipna, in, slab, 0, n_outer, n_row,
+                              n_col, w_row, w_col, wfield, aux, scalar,
+                              chunk_row0, chunk_nrow, n_chunk, n_ctile,
+                              seg_col0, seg_eoff, n_seg, n_ts, partials, stream);
+}
+
+int wb2_stream_partials_addr(int mode, int dtype, int skipna,
+                             const int64_t* const* slab_addr, int aligned16,
+                             int64_t n_outer, int32_t n_row, int32_t n_col,
+                             const double* w_row, const double* w_col,
+                             const double* wfield, const double* aux,
+                             double scalar, const int32_t* chunk_row0,
+                             const int32_t* chunk_nrow, int32_t n_chunk,
+                             int32_t n_ctile, const int32_t* seg_col0,
+                             const int32_t* seg_eoff, int32_t n_seg,
+                             int32_t n_ts, double* partials, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(slab_addr != nullptr, "null pointer argument");
+  return stream_partials_impl(mode, dtype, skipna, nullptr, slab_addr,
+                              aligned16, n_outer, n_row, n_col, w_row, w_col,
+                              wfield, aux, scalar, chunk_row0, chunk_nrow,
+                              n_chunk, n_ctile, seg_col0, seg_eoff, n_seg, n_ts,
+                              partials, stream);
 }
 
 int wb2_det_combine(int mode, int skipna, const double* partials,

@@ -243,7 +243,6 @@ def stream_reduce(plan: ReductionPlan, mode: int,
   None) as float64 device tensors; the call is asynchronous on the current
   stream.
   """
-  lib = _lib.load()
   dev = plan.device
   dtype = inputs[0].dtype
   if dtype not in _DTYPES:
@@ -262,9 +261,40 @@ def stream_reduce(plan: ReductionPlan, mode: int,
                        'contiguous slabs')
     if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
       raise ValueError('slab tables are int64[n_outer]')
+  aligned = all(x.data_ptr() % 16 == 0 for x in inputs)
+  return _stream_launch(plan, mode, dtype, n_outer, skipna, want_sums, aux,
+                        scalar, aligned, inputs=inputs, slabs=slabs)
+
+
+def stream_reduce_addr(plan: ReductionPlan, mode: int, dtype: torch.dtype,
+                       addr: t.Sequence[torch.Tensor], aligned16: bool,
+                       n_outer: int, skipna: bool, want_sums: bool = False,
+                       aux: t.Optional[torch.Tensor] = None,
+                       scalar: float = 0.0):
+  """K1 + K2 over slabs that live in different allocations (the variables of
+  a chunk, several consecutive chunks): `addr[i]` is an int64[n_outer] device
+  tensor holding the byte address of input i's slab for every outer slab
+  (wb2_stream_partials_addr).  The caller keeps the memory behind the
+  addresses alive until the launch has been enqueued on the current stream
+  (torch's allocator is stream-ordered).  Same return value as stream_reduce."""
+  if dtype not in _DTYPES:
+    raise TypeError(f'unsupported dtype {dtype}')
+  for a in addr:
+    if (a.dtype != torch.int64 or a.device != plan.device or
+        a.numel() != n_outer or not a.is_contiguous()):
+      raise ValueError('address tables are contiguous int64[n_outer] on the '
+                       'plan device')
+  return _stream_launch(plan, mode, dtype, n_outer, skipna, want_sums, aux,
+                        scalar, bool(aligned16), addr=addr)
+
+
+def _stream_launch(plan, mode, dtype, n_outer, skipna, want_sums, aux, scalar,
+                   aligned, inputs=None, slabs=None, addr=None):
+  lib = _lib.load()
+  dev = plan.device
   code = _DTYPES[dtype]
   k = lib.wb2_num_slots(mode, int(skipna))
-  aligned = all(x.data_ptr() % 16 == 0 for x in inputs) and (
+  aligned = aligned and (
       plan.wfield is None or plan.wfield.data_ptr() % 16 == 0)
   tile = lib.wb2_tile_cols_ex(mode, code, int(skipna),
                               int(plan.wfield is not None), plan.n_col,
@@ -276,15 +306,20 @@ def stream_reduce(plan: ReductionPlan, mode: int,
                          dtype=torch.float64, device=dev)
   if _LAUNCH_HOOK is not None:
     _LAUNCH_HOOK('begin', 'stream_partials')
-  _lib.check(lib.wb2_stream_partials_ex(
-      mode, code, int(skipna), _lib.ptr_array(inputs), _lib.ptr_array(slabs),
-      n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
-      _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(aux),
-      float(scalar), _lib.ptr(plan.chunk_row0),
-      _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
-      _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
-      _lib.ptr(partials), stream),
-              'wb2_stream_partials')
+  tail = (n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
+          _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(aux),
+          float(scalar), _lib.ptr(plan.chunk_row0),
+          _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
+          _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
+          _lib.ptr(partials), stream)
+  if addr is not None:
+    _lib.check(lib.wb2_stream_partials_addr(
+        mode, code, int(skipna), _lib.ptr_array(addr), int(aligned), *tail),
+               'wb2_stream_partials_addr')
+  else:
+    _lib.check(lib.wb2_stream_partials_ex(
+        mode, code, int(skipna), _lib.ptr_array(inputs), _lib.ptr_array(slabs),
+        *tail), 'wb2_stream_partials')
   if _LAUNCH_HOOK is not None:
     _LAUNCH_HOOK('end', 'stream_partials')
   metrics = torch.empty((_lib.GENERIC_KQ.get(mode, _lib.NMETRIC),

@@ -78,6 +78,7 @@ def _metric_and_region_loop(
     stack.enter_context(metrics_lib.fused_regions(regions))
     if acc is not None:
       stack.enter_context(metrics_lib.fused_climatology(acc.climatology))
+    stack.enter_context(metrics_lib.fused_wind_vectors(_wind_pairs(eval_config)))
     for name, metric in eval_config.metrics.items():
       if compute_chunk or not eval_config.temporal_mean:
         eval_fn = metric.compute_chunk
@@ -104,6 +105,21 @@ def _metric_and_region_loop(
                 {'metric': [name]})
       results.append(result)
   return xl.like_input(xl.merge(results), given_forecast, given_truth)
+
+
+def _wind_pairs(eval_config) -> list:
+  """(u_name, v_name) of every wind-vector metric the loop will evaluate, on
+  its own or inside an MSE / RMSE (scripts/evaluate.py:279-311, 420-430)."""
+  pairs: list = []
+  for metric in eval_config.metrics.values():
+    nested = (list(getattr(metric, 'wind_vector_mse', None) or []) +
+              list(getattr(metric, 'wind_vector_rmse', None) or []))
+    for m in [metric] + nested:
+      if isinstance(m, metrics_lib.WindVectorMSE):
+        pair = (m.u_name, m.v_name)
+        if pair not in pairs:
+          pairs.append(pair)
+  return pairs
 
 
 def make_latitude_increasing(dataset):
@@ -219,24 +235,43 @@ class RunningMean:
   add(chunk_result) accumulates `sum` and `count` over `dim` (NaNs add to
   neither when skipna); result() all-reduces both across the process group (if
   one is initialised) and divides.
+
+  Chunks may split another dim as well -- the official 0.25-degree runs use
+  `input_chunks=init_time=1,lead_time=1` (docs/source/official-evaluation.md:
+  537-549) --: xbeam.Mean combines per key of the remaining chunk offsets, so
+  results with different `split_dim` labels accumulate separately and are
+  laid side by side, in label order, by result() (`split_dim`: the forecast's
+  lead dim when the results have one).
   """
 
-  def __init__(self, dim: str, skipna: bool = False, device=None, comm=None):
+  def __init__(self, dim: str, skipna: bool = False, device=None, comm=None,
+               split_dim: t.Optional[str] = None):
     self.dim = dim
     self.skipna = skipna
     self.device = device
+    self.split_dim = split_dim
     # an RCCL communicator from engine.comm_init_rank: the exchange then goes
     # through the C ABI (wb2_time_mean_allreduce) instead of torch.distributed
     self.comm = comm
-    self._acc: dict = {}     # var -> (sum, count, dims, shape)
+    self._acc: dict = {}     # (var, split labels) -> (sum, count, dims, shape)
     self._coords: dict = {}
+    self._labels: dict = {}  # split labels key -> label array
 
-  def _tensors(self, name, dims, shape):
+  def _split_key(self, chunk: xl.Dataset, da: xl.DataArray):
+    d = self.split_dim
+    if d is None or d not in da.dims or d not in chunk.coords:
+      return None
+    labels = np.asarray(chunk.coords[d])
+    key = (labels.dtype.str, labels.tobytes())
+    self._labels.setdefault(key, labels)
+    return key
+
+  def _tensors(self, name, key, dims, shape):
     import torch
-    if name not in self._acc:
+    if (name, key) not in self._acc:
       total = torch.zeros(shape, dtype=torch.float64, device=self.device)
-      self._acc[name] = (total, torch.zeros_like(total), dims, shape)
-    total, count, d, s = self._acc[name]
+      self._acc[(name, key)] = (total, torch.zeros_like(total), dims, shape)
+    total, count, d, s = self._acc[(name, key)]
     if d != dims or s != shape:
       raise ValueError(f'{name}: chunk layout changed {d}{s} -> {dims}{shape}')
     return total, count
@@ -246,9 +281,10 @@ class RunningMean:
     from weatherbench2_amd import engine
     for k, c in chunk.coords.items():
       # coordinates that vary along the averaged dim go with it (valid_time of
-      # a by-init chunk), like xarray's mean
-      if k != self.dim and not (isinstance(c, xl.DataArray)
-                                and self.dim in c.dims):
+      # a by-init chunk), like xarray's mean; the split dim's labels are put
+      # back together by result()
+      if k != self.dim and k != self.split_dim and not (
+          isinstance(c, xl.DataArray) and self.dim in c.dims):
         self._coords.setdefault(k, c)
     for name, da in chunk.data_vars.items():
       if self.dim not in da.dims:
@@ -267,7 +303,8 @@ class RunningMean:
       else:
         values = torch.as_tensor(np.ascontiguousarray(da.values),
                                  dtype=torch.float64)
-      total, count = self._tensors(name, dims, shape)
+      total, count = self._tensors(name, self._split_key(chunk, da), dims,
+                                   shape)
       if self.device is not None and torch.device(self.device).type == 'cuda':
         engine.time_accumulate(values.to(self.device).contiguous(), axis,
                                self.skipna, total, count)
@@ -278,20 +315,54 @@ class RunningMean:
         total += torch.where(ok, values, torch.zeros_like(values)).sum(axis)
         count += ok.to(torch.float64).sum(axis)
 
+  def _agree_on_layout(self):
+    """Every rank enters the all-reduce with the same accumulators in the same
+    order: ranks whose shard never met some split label (lead-major chunk
+    lists) get zero accumulators for it."""
+    import torch
+    import torch.distributed as dist
+    mine = [(n, k, self._acc[(n, k)][2], self._acc[(n, k)][3],
+             None if k is None else self._labels[k]) for n, k in self._acc]
+    everyone: list = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    for layout in everyone:
+      for n, k, dims, shape, labels in layout:
+        if k is not None:
+          self._labels.setdefault(k, labels)
+        if (n, k) not in self._acc:
+          total = torch.zeros(shape, dtype=torch.float64, device=self.device)
+          self._acc[(n, k)] = (total, torch.zeros_like(total), dims, shape)
+
+  def _ordered(self) -> list:
+    """Accumulators by variable, the blocks of a split dim by their first
+    label (chunk offsets of a sorted lead coordinate)."""
+    def order(item):
+      name, key = item
+      if key is None:
+        return (name, 0, 0, b'')
+      first = self._labels[key].ravel()[:1]
+      if first.size and first.dtype.kind in 'mMiu':
+        return (name, 1, int(first.astype('int64')[0]), key[1])
+      if first.size and first.dtype.kind == 'f':
+        return (name, 1, float(first[0]), key[1])
+      return (name, 1, 0, key[1])
+    return sorted(self._acc, key=order)
+
   def result(self) -> xl.Dataset:
     import torch
     import torch.distributed as dist
-    out = xl.Dataset(coords=self._coords)
-    names = sorted(self._acc)
-    in_group = self.comm is not None or (
-        dist.is_available() and dist.is_initialized()
-        and dist.get_world_size() > 1)
-    if in_group and not names:
+    in_torch_group = (dist.is_available() and dist.is_initialized()
+                      and dist.get_world_size() > 1)
+    in_group = self.comm is not None or in_torch_group
+    if in_group and not self._acc:
       # every rank must enter the collective with the same layout: a rank
       # without a single chunk would leave the others waiting in the all-reduce
       raise ValueError('RunningMean.result() on a rank that accumulated '
                        'nothing: give every rank at least one chunk '
                        '(evaluate_chunks checks this up front)')
+    if in_torch_group and self.comm is None:
+      self._agree_on_layout()
+    names = self._ordered()
     if self.comm is not None and names:
       from weatherbench2_amd import engine
       flat_t = torch.cat([self._acc[n][0].reshape(-1) for n in names])
@@ -304,8 +375,7 @@ class RunningMean:
         self._acc[n] = (flat_t[offset:offset + size].reshape(shape),
                         flat_c[offset:offset + size].reshape(shape), dims, shape)
         offset += size
-    elif dist.is_available() and dist.is_initialized() and (
-        dist.get_world_size() > 1) and names:
+    elif in_torch_group and names:
       flat = torch.cat([torch.stack([self._acc[n][0], self._acc[n][1]]
                                     ).reshape(-1) for n in names])
       dist.all_reduce(flat)  # the path's only exchange step
@@ -317,10 +387,32 @@ class RunningMean:
                         flat[offset + size:offset + 2 * size].reshape(shape),
                         dims, shape)
         offset += 2 * size
-    for n in names:
-      total, count, dims, shape = self._acc[n]
+    coords = dict(self._coords)
+    pieces: dict = {}
+    for name, key in names:
+      total, count, dims, shape = self._acc[(name, key)]
       mean = (total / count).cpu().numpy()  # 0/0 -> NaN like an empty mean
-      out.data_vars[n] = xl.DataArray(mean, dims, self._coords, n)
+      pieces.setdefault(name, []).append((key, dims, mean))
+    split_labels = None
+    out_vars = {}
+    for name, parts in pieces.items():
+      dims = parts[0][1]
+      if len(parts) == 1 and parts[0][0] is None:
+        out_vars[name] = (dims, parts[0][2])
+        continue
+      ax = dims.index(self.split_dim)
+      labels = np.concatenate([self._labels[k] for k, _, _ in parts])
+      out_vars[name] = (dims, np.concatenate([m for _, _, m in parts],
+                                             axis=ax))
+      if split_labels is not None and not np.array_equal(split_labels, labels):
+        raise ValueError(f'{name}: {self.split_dim} labels differ between '
+                         'variables')
+      split_labels = labels
+    if split_labels is not None:
+      coords[self.split_dim] = split_labels
+    out = xl.Dataset(coords=coords)
+    for name, (dims, mean) in out_vars.items():
+      out.data_vars[name] = xl.DataArray(mean, dims, coords, name)
     return out
 
 
@@ -425,6 +517,185 @@ def _chunk_substitution(eval_config, truth, climatology, by_init: bool):
   return substitute
 
 
+def _plain_slabs(da: xl.DataArray) -> bool:
+  """Data a concatenation can address slab by slab: a C-contiguous numpy array
+  or torch tensor with the two spatial dims last."""
+  data = da.data
+  if isinstance(data, (xl.SlabGather, xl.SlabConcat)) or da.ndim < 2:
+    return False
+  if set(da.dims[-2:]) != {'latitude', 'longitude'}:
+    return False
+  if isinstance(data, np.ndarray):
+    return bool(data.flags.c_contiguous)
+  return bool(data.is_contiguous())
+
+
+def _block_matrix(cells: dict, n_i: int, n_l: int, ax_i, ax_l):
+  """np.block over a (time block, lead block) grid of arrays."""
+  rows = []
+  for bi in range(n_i):
+    row = [cells[(bi, bl)] for bl in range(n_l)]
+    rows.append(row[0] if ax_l is None or n_l == 1
+                else np.concatenate(row, axis=ax_l))
+  return rows[0] if ax_i is None or n_i == 1 else np.concatenate(rows,
+                                                                  axis=ax_i)
+
+
+def concat_chunks(datasets: t.Sequence, time_dim: str,
+                  lead_dim: t.Optional[str] = None):
+  """The chunks of a (time block x lead block) rectangle as ONE Dataset over
+  the concatenated `time_dim` (and `lead_dim`) labels -- without moving data:
+  every variable becomes an `xarray_lite.SlabConcat`, an index over the
+  chunks' own arrays, which the fused deterministic passes read slab by slab
+  through device addresses.  Coordinates that follow the two dims (valid_time,
+  the 2-D `time` of a by-init truth chunk) are put together the same way.
+
+  Returns None when the chunks do not form such a rectangle or hold data that
+  cannot be addressed in place (lazy gathers, transposed or strided arrays):
+  the caller then evaluates them one by one."""
+  datasets = [xl.as_dataset(d) for d in datasets]
+  first = datasets[0]
+  if len(datasets) == 1:
+    return first
+  if time_dim not in first.dims:
+    return None
+  split = (time_dim,) + ((lead_dim,) if lead_dim and lead_dim in first.dims
+                         else ())
+  names = list(first.keys())
+  # position of every chunk in the rectangle, by its labels
+  blocks: list = [[] for _ in split]
+  where = []
+  for ds in datasets:
+    if list(ds.keys()) != names:
+      return None
+    pos = []
+    for j, d in enumerate(split):
+      if d not in ds.coords or isinstance(ds.coords[d], xl.DataArray):
+        return None
+      labels = np.asarray(ds.coords[d])
+      key = (labels.dtype.str, labels.tobytes())
+      known = [k for k, _ in blocks[j]]
+      if key not in known:
+        blocks[j].append((key, labels))
+        known.append(key)
+      pos.append(known.index(key))
+    where.append(tuple(pos) if len(pos) == 2 else (pos[0], 0))
+  n_i = len(blocks[0])
+  n_l = len(blocks[1]) if len(split) == 2 else 1
+  if len(set(where)) != len(where) or len(where) != n_i * n_l:
+    return None
+  for j in range(len(split)):  # blocks must not share labels
+    labels = np.concatenate([lab for _, lab in blocks[j]])
+    if len(set(labels.tolist())) != len(labels):
+      return None
+  # everything else must be common to the chunks
+  for ds in datasets[1:]:
+    for k, c in first.coords.items():
+      cdims = tuple(c.dims) if isinstance(c, xl.DataArray) else (k,)
+      if any(d in split for d in cdims):
+        continue
+      other = ds.coords.get(k)
+      if other is None or not np.array_equal(
+          np.asarray(c.values if isinstance(c, xl.DataArray) else c),
+          np.asarray(other.values if isinstance(other, xl.DataArray)
+                     else other)):
+        return None
+  coords = {}
+  for k, c in first.coords.items():
+    cdims = tuple(c.dims) if isinstance(c, xl.DataArray) else (k,)
+    if not any(d in split for d in cdims):
+      coords[k] = c
+      continue
+    if not isinstance(c, xl.DataArray):  # the split dims' own labels
+      j = split.index(k)
+      coords[k] = np.concatenate([lab for _, lab in blocks[j]])
+      continue
+    cells = {}
+    for ds, at in zip(datasets, where):
+      other = ds.coords.get(k)
+      if not isinstance(other, xl.DataArray) or tuple(other.dims) != cdims:
+        return None
+      cells[at] = np.asarray(other.values)
+    ax_i = cdims.index(time_dim) if time_dim in cdims else None
+    ax_l = cdims.index(split[1]) if len(split) == 2 and split[1] in cdims else (
+        None)
+    if ax_i is None:  # follows the lead dim only: the first time block's
+      cells = {(0, bl): cells[(0, bl)] for bl in range(n_l)}
+    if ax_l is None:
+      cells = {(bi, 0): cells[(bi, 0)] for bi in range(n_i if ax_i is not None
+                                                       else 1)}
+    coords[k] = xl.DataArray(
+        _block_matrix(cells, n_i if ax_i is not None else 1,
+                      n_l if ax_l is not None else 1, ax_i, ax_l), cdims)
+  out = xl.Dataset(coords=coords, attrs=dict(first.attrs))
+  for name in names:
+    ref = first[name]
+    if not any(d in ref.dims for d in split):
+      out.data_vars[name] = xl.DataArray(ref.data, ref.dims, coords, name)
+      continue
+    if any(d in ref.dims[-2:] for d in split):
+      return None
+    ax_i = ref.dims.index(time_dim) if time_dim in ref.dims else None
+    ax_l = (ref.dims.index(split[1])
+            if len(split) == 2 and split[1] in ref.dims else None)
+    bases, cells, offset = [], {}, 0
+    kind = type(ref.data)
+    for ds, at in zip(datasets, where):
+      da = ds[name]
+      if (da.dims != ref.dims or not _plain_slabs(da)
+          or type(da.data) is not kind or da.dtype != ref.dtype
+          or tuple(da.shape[-2:]) != tuple(ref.shape[-2:])):
+        return None
+      at = (at[0] if ax_i is not None else 0, at[1] if ax_l is not None else 0)
+      if at in cells:  # the variable does not follow one of the split dims
+        continue
+      outer = tuple(da.shape[:-2])
+      n = int(np.prod(outer, dtype=np.int64))
+      cells[at] = offset + np.arange(n, dtype=np.int64).reshape(outer)
+      bases.append(da.data)
+      offset += n
+    index = _block_matrix(cells, n_i if ax_i is not None else 1,
+                          n_l if ax_l is not None else 1, ax_i, ax_l)
+    out.data_vars[name] = xl.DataArray(xl.SlabConcat(bases, index), ref.dims,
+                                       coords, name)
+  return out
+
+
+def _batches(pairs: list, time_dim: str, lead_dim: t.Optional[str]):
+  """Splits a window of (forecast, truth) chunks into the largest pieces that
+  `concat_chunks` accepts: the whole window if it is a rectangle, else one
+  piece per lead block, else the chunks themselves."""
+  def joined(group):
+    f = concat_chunks([p[0] for p in group], time_dim, lead_dim)
+    t_ = concat_chunks([p[1] for p in group], time_dim, lead_dim)
+    return None if f is None or t_ is None else (f, t_)
+
+  whole = joined(pairs) if len(pairs) > 1 else None
+  if whole is not None:
+    return [whole]
+  if len(pairs) > 1 and lead_dim is not None:
+    by_lead: dict = {}
+    for p in pairs:
+      c = p[0].coords.get(lead_dim)
+      if c is None or isinstance(c, xl.DataArray):
+        return [(p[0], p[1]) for p in pairs]
+      labels = np.asarray(c)
+      by_lead.setdefault((labels.dtype.str, labels.tobytes()), []).append(p)
+    if len(by_lead) > 1:
+      out = []
+      for group in by_lead.values():
+        one = joined(group) if len(group) > 1 else None
+        out += [one] if one is not None else [(p[0], p[1]) for p in group]
+      return out
+  return [(p[0], p[1]) for p in pairs]
+
+
+# K1 chunking of evaluate_chunks (pinned: the result must not depend on how
+# many chunks share a launch); 32 rows is the measured optimum of launches of
+# 100+ slabs (profiles/r01_rows_per_chunk.md)
+EVALUATE_ROWS_PER_CHUNK = 32
+
+
 def evaluate_chunks(
     chunks: t.Sequence[tuple],
     eval_config: config.Eval,
@@ -435,6 +706,7 @@ def evaluate_chunks(
     truth=None,
     climatology=None,
     by_init: bool = True,
+    batch_chunks: int = 1,
 ) -> xl.Dataset:
   """Evaluates (forecast, truth) chunks and returns the temporal mean.
 
@@ -446,11 +718,21 @@ def evaluate_chunks(
   resident they are read in place) -- a switch that is set without its dataset
   raises instead of silently evaluating the forecast.
 
-  `chunks` is the full, ordered list (or any indexable) of per-init-time chunk
-  pairs; each rank of the current torch.distributed group (if any) evaluates a
-  contiguous shard, like Beam's workers do for
-  `input_chunks=init_time=1,lead_time=1` (docs/source/official-evaluation.md),
-  and the shards meet in one all-reduce.
+  `chunks` is the full, ordered list (or any indexable) of chunk pairs; each
+  rank of the current torch.distributed group (if any) evaluates a contiguous
+  shard, like Beam's workers do for `input_chunks=init_time=1,lead_time=1`
+  (docs/source/official-evaluation.md:537-549), and the shards meet in one
+  all-reduce.  Chunks may split the lead dim as well as the time dim (that
+  configuration does): results accumulate per lead label (`RunningMean`).
+
+  `batch_chunks` = k evaluates k consecutive chunks in ONE pass of the metric x
+  region loop: they are concatenated without copying (`concat_chunks`: a
+  (time x lead) rectangle of chunks becomes one Dataset whose variables index
+  the chunks' own arrays), so one fused launch reads every variable of all k
+  chunks and the host work of the loop is paid once per k chunks.  The K1
+  chunking is pinned for the whole call: the result is bit-identical for every
+  `batch_chunks` (windows that do not form a rectangle fall back to smaller
+  pieces, down to single chunks).
 
   `chunks[i]` is where a lazy sequence does its IO (the reference reads its
   chunks on a thread pool around the same workers, evaluation.py:696-697):
@@ -468,17 +750,35 @@ def evaluate_chunks(
                      'ranks (every rank must take part in the all-reduce)')
   lo, hi = shard_bounds(len(chunks), world, rank)
   substitute = _chunk_substitution(eval_config, truth, climatology, by_init)
+  batch_chunks = max(1, int(batch_chunks))
   mean: t.Optional[RunningMean] = None
-  for forecast, truth_chunk in _prefetched(chunks, lo, hi, prefetch):
-    forecast = xl.as_dataset(forecast)
-    if substitute is not None:
-      forecast = xl.as_dataset(substitute(forecast, truth_chunk))
-    result = _metric_and_region_loop(forecast, truth_chunk, eval_config, skipna,
-                                     compute_chunk=True)
+  window: list = []
+
+  def flush():
+    nonlocal mean
+    if not window:
+      return
+    first = window[0][0]
+    time_dim = 'time' if 'time' in first.dims else 'init_time'
+    lead_dim = _lead_dim(first)
+    lead_dim = lead_dim if lead_dim in first.dims else None
     if mean is None:
-      dim = 'time' if 'time' in forecast.dims else 'init_time'
-      mean = RunningMean(dim, skipna, device)
-    mean.add(result)
+      mean = RunningMean(time_dim, skipna, device, split_dim=lead_dim)
+    for forecast, truth_chunk in _batches(window, time_dim, lead_dim):
+      mean.add(_metric_and_region_loop(forecast, truth_chunk, eval_config,
+                                       skipna, compute_chunk=True))
+    window.clear()
+
+  with metrics_lib.pinned_rows_per_chunk(EVALUATE_ROWS_PER_CHUNK):
+    for forecast, truth_chunk in _prefetched(
+        chunks, lo, hi, max(prefetch, batch_chunks - 1 if prefetch else 0)):
+      forecast = xl.as_dataset(forecast)
+      if substitute is not None:
+        forecast = xl.as_dataset(substitute(forecast, truth_chunk))
+      window.append((forecast, xl.as_dataset(truth_chunk)))
+      if len(window) >= batch_chunks:
+        flush()
+    flush()
   assert mean is not None
   return mean.result()
 

@@ -61,6 +61,8 @@ class _Announced(threading.local):
     self.scoped: dict = {}        # cache name -> {key: (pins, value)}
     self.memo: dict = {}          # per-scope memo (stamps, coordinate signatures)
     self.groupings: list = []     # memo of fused_regions' grouping (identity)
+    self.wind: list = []          # (u_name, v_name) pairs the loop will ask for
+    self.rows_per_chunk: list = []  # pinned K1 chunking (evaluate_chunks)
     self.lru: dict = {}           # cache name -> _LRU (calls outside any scope)
 
 
@@ -164,6 +166,37 @@ def fused_climatology(climatology):
     _ANNOUNCED.climatology.pop()
 
 
+@contextlib.contextmanager
+def fused_wind_vectors(pairs):
+  """Announce the (u_name, v_name) pairs of every wind-vector metric of a loop
+  (scripts/evaluate.py:279-311: the pressure-level and the 10 m wind): the
+  first one asked for reads them all in ONE launch."""
+  _ANNOUNCED.wind.append(tuple(pairs))
+  try:
+    yield
+  finally:
+    _ANNOUNCED.wind.pop()
+
+
+@contextlib.contextmanager
+def pinned_rows_per_chunk(rows: t.Optional[int]):
+  """Fixes the row-chunking of the streaming kernel for every pass inside:
+  chunk partials are summed in chunk order, so results are bit-identical
+  between launches of different sizes only when the chunking does not follow
+  the launch size (`plan.auto_rows_per_chunk`).  `evaluation.evaluate_chunks`
+  pins it, which makes its result independent of `batch_chunks`."""
+  _ANNOUNCED.rows_per_chunk.append(rows)
+  try:
+    yield
+  finally:
+    _ANNOUNCED.rows_per_chunk.pop()
+
+
+def _rows_per_chunk(n_row: int, n_outer: int) -> int:
+  pinned = _ANNOUNCED.rows_per_chunk[-1] if _ANNOUNCED.rows_per_chunk else None
+  return int(pinned) if pinned else plan_lib.auto_rows_per_chunk(n_row, n_outer)
+
+
 def _region_set_for(region) -> tuple[dict, str]:
   """Returns (ordered region dict to evaluate, key of the requested one)."""
   return _region_set_sig(region)[:2]
@@ -199,13 +232,6 @@ def _fused(pass_fn, region, regions: t.Optional[dict]):
     out = out or res
   merged.pop(_ALL, None)  # the stacked tensor of ONE pass is not all regions
   return (out[0], merged) + tuple(out[2:])
-
-
-def _serialized(fn):
-  """Historical name: passes used to run under one process-wide lock.  Every
-  cache is per thread now and the kernels are stream-ordered, so this is the
-  identity (kept as a marker of the pass entry points)."""
-  return fn
 
 
 class _LRU:
@@ -317,6 +343,11 @@ def _stamp(a) -> tuple:
     else:
       base_stamp = _stamp(base)
     return ('gather', base_stamp, a.index.shape, engine.digest(a.index))
+  if isinstance(a, xl.SlabConcat):
+    if _ANNOUNCED.depth > 0:  # inputs do not change inside a chunk scope
+      return ('concat', id(a))
+    return ('concat', tuple(_stamp(b) for b in a.bases), a.index.shape,
+            engine.digest(a.index))
   if isinstance(a, np.ndarray):
     ident = (id(a), a.__array_interface__['data'][0], a.shape, a.strides,
              a.dtype.str)
@@ -375,6 +406,11 @@ def _to_device(data, device, allow_gather: bool = False):
     if allow_gather and not gathered.has_missing:
       return gathered
     return gathered.materialize()
+  if isinstance(data, xl.SlabConcat):
+    if not data.on_device:
+      data = xl.SlabConcat([_to_device(b, device) for b in data.bases],
+                           data.index)
+    return data if allow_gather else data.materialize(device)
   if isinstance(data, np.ndarray) and data.nbytes >= _BIG_UPLOAD_BYTES:
     import warnings
     warnings.warn(
@@ -420,8 +456,9 @@ def _spatial_last(da: xl.DataArray, layout: t.Optional[str]):
     return da.data, rest, layout
   moved = da.transpose(*rest, *want)
   data = moved.data
-  if isinstance(data, xl.SlabGather):
-    data = data.materialize_host()
+  if isinstance(data, (xl.SlabGather, xl.SlabConcat)):
+    data = data.materialize() if getattr(
+        data, 'on_device', False) else data.materialize_host()
   data = data.contiguous() if isinstance(data, torch.Tensor) else (
       np.ascontiguousarray(data))
   return data, rest, layout
@@ -626,14 +663,9 @@ def _physical_slabs(x: torch.Tensor, table, n_row: int, n_col: int):
 # ---------------------------------------------------------------------------
 # the fused passes
 # ---------------------------------------------------------------------------
-def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
-  """Uploads (if needed), launches, returns {region_key: metrics[NMETRIC, ...]}."""
-  device = engine.require_gpu()
-  regions, rkey = _region_set_for(region)
-  n_row = len(geo.latitude if geo.layout == plan_lib.LATLON else geo.longitude)
-  pl = plan_lib.cached_plan(
-      geo.latitude, geo.longitude, geo.layout, regions, device,
-      plan_lib.auto_rows_per_chunk(n_row, geo.n_outer))
+def _prepare_inputs(geo, arrays, tables, device):
+  """The inputs of one variable's pass on the device, in one dtype:
+  (tensors or lazy slab arrays, slab tables, dtype)."""
   arrays, tables = list(arrays), list(tables)
   for i, (a, tb) in enumerate(zip(arrays, tables)):
     # a host array read through a table that touches only some of its slabs (a
@@ -653,26 +685,110 @@ def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
   def cast(x):
     if x.dtype == dtype:
       return x
-    if isinstance(x, xl.SlabGather):  # never convert a whole resident base
-      x = x.materialize()
+    if isinstance(x, (xl.SlabGather, xl.SlabConcat)):
+      x = x.materialize()  # never convert a whole resident base
     return x.to(dtype)
   tensors = [cast(x) for x in tensors]
   for x in tensors:
     _check_grid(geo, x)
-  flat, tables = zip(*[_physical_slabs(x, tb, pl.n_row, pl.n_col)
-                       for x, tb in zip(tensors, tables)])
-  slabs = [None if tb is None else engine.upload_table(tb, device)
-           for tb in tables]
-  if aux is not None:
-    aux = torch.as_tensor(np.ascontiguousarray(aux, dtype=np.float64)).to(device)
-  metrics, _ = engine.stream_reduce(pl, mode, flat, slabs, geo.n_outer, skipna,
-                                    aux=aux, scalar=scalar)
-  # results stay on the device (tiny fp64 tensors): nothing here waits for the
-  # GPU, so a caller streaming chunks keeps the queue full; `.values` of the
-  # returned DataArrays is where the copy (and the sync) happens
-  dev = metrics.reshape((metrics.shape[0], pl.n_region) + geo.out_shape)
+  return tensors, tables, dtype
+
+
+def _slab_addresses(x, table, n_row: int, n_col: int, n_outer: int):
+  """(int64[n_outer] device byte addresses of the slabs of input `x` read
+  through `table`, what must stay alive until the launch is enqueued)."""
+  if isinstance(x, xl.SlabConcat):
+    flat = x.addresses().ravel()
+    return (flat if table is None else flat[table]), x.bases
+  flat, tb = _physical_slabs(x, table, n_row, n_col)
+  step = n_row * n_col * flat.element_size()
+  if tb is None:
+    tb = np.arange(n_outer, dtype=np.int64)
+  return flat.data_ptr() + np.asarray(tb, dtype=np.int64) * step, flat
+
+
+def _by_region(pl, dev, out_shape) -> dict:
   by_region = {name: dev[:, i] for i, name in enumerate(pl.region_names)}
   by_region[_ALL] = (dev, list(pl.region_names))
+  return by_region
+
+
+def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
+  """One fused pass (K1 + K2) per launch signature over the variables in
+  `entries` = [(geo, arrays, tables)]: variables that share grid, layout and
+  dtype -- every variable of an ERA5-style chunk -- are read by ONE launch
+  whose slabs are addressed one by one (wb2_stream_partials_addr); the fold is
+  per slab, so every variable's numbers are those of a launch of its own.
+  Returns the list of {region_key: metrics[NMETRIC, ...]} dicts, in order.
+
+  Nothing here waits for the GPU: results stay on the device (tiny fp64
+  tensors), `.values` of the returned DataArrays is where the copy (and the
+  sync) happens, so a caller streaming chunks keeps the queue full."""
+  device = engine.require_gpu()
+  regions, _ = _region_set_for(region)
+  prepped = [_prepare_inputs(geo, arrays, tables, device)
+             for geo, arrays, tables in entries]
+  groups: dict = {}
+  for i, ((geo, _, _), (_, _, dtype)) in enumerate(zip(entries, prepped)):
+    sig = (geo.layout, geo.latitude.tobytes(), str(geo.latitude.dtype),
+           geo.longitude.tobytes(), str(geo.longitude.dtype), dtype)
+    groups.setdefault(sig, []).append(i)
+  if aux is not None:
+    aux = torch.as_tensor(np.ascontiguousarray(aux, dtype=np.float64)).to(device)
+  out: list = [None] * len(entries)
+  for members in groups.values():
+    geo0 = entries[members[0]][0]
+    n_row = len(geo0.latitude if geo0.layout == plan_lib.LATLON
+                else geo0.longitude)
+    n_total = sum(entries[i][0].n_outer for i in members)
+    pl = plan_lib.cached_plan(geo0.latitude, geo0.longitude, geo0.layout,
+                              regions, device, _rows_per_chunk(n_row, n_total))
+    lazy = any(isinstance(x, xl.SlabConcat)
+               for i in members for x in prepped[i][0])
+    if len(members) == 1 and not lazy:
+      # one variable in one allocation: slab NUMBERS (wb2_stream_partials_ex)
+      i = members[0]
+      tensors, tables, _ = prepped[i]
+      flat, tables = zip(*[_physical_slabs(x, tb, pl.n_row, pl.n_col)
+                           for x, tb in zip(tensors, tables)])
+      slabs = [None if tb is None else engine.upload_table(tb, device)
+               for tb in tables]
+      metrics, _ = engine.stream_reduce(pl, mode, flat, slabs, n_total, skipna,
+                                        aux=aux, scalar=scalar)
+    else:
+      n_in = len(prepped[members[0]][0])
+      addr = np.empty((n_in, n_total), dtype=np.int64)
+      keep, off = [], 0
+      for i in members:
+        tensors, tables, _ = prepped[i]
+        n = entries[i][0].n_outer
+        for j, (x, tb) in enumerate(zip(tensors, tables)):
+          addr[j, off:off + n], alive = _slab_addresses(x, tb, pl.n_row,
+                                                        pl.n_col, n)
+          keep.append(alive)
+        off += n
+      aligned = not (addr % 16).any()
+      dev_addr = engine.upload_table(addr, device)
+      metrics, _ = engine.stream_reduce_addr(
+          pl, mode, prepped[members[0]][2], list(dev_addr), aligned, n_total,
+          skipna, aux=aux, scalar=scalar)
+      del keep  # the launch is enqueued: the allocator orders any reuse after it
+    off = 0
+    for i in members:
+      geo = entries[i][0]
+      n = geo.n_outer
+      dev = metrics[:, :, off:off + n].reshape(
+          (metrics.shape[0], pl.n_region) + geo.out_shape)
+      out[i] = _by_region(pl, dev, geo.out_shape)
+      off += n
+  return out
+
+
+def _run_pass(mode, geo, arrays, tables, region, skipna, aux=None, scalar=0.0):
+  """Uploads (if needed), launches, returns {region_key: metrics[NMETRIC, ...]}."""
+  _, rkey = _region_set_for(region)
+  by_region, = _run_group(mode, [(geo, arrays, tables)], region, skipna, aux,
+                          scalar)
   return by_region, rkey
 
 
@@ -685,21 +801,22 @@ def _result_key(kind, arrays, region_key_obj, skipna, datasets=()):
           bool(skipna))
 
 
-@_serialized
-def _det_pass(forecast, truth, name, region, skipna, climatology=None):
-  """All five deterministic metrics of one variable, for the active regions."""
+def _fuse_variables() -> bool:
+  """Inside a chunk scope the first variable asked for brings every variable
+  of the chunk along (WB2HIP_FUSE_VARIABLES=0: one launch per variable, the
+  behaviour of rounds 1-3, for A/B runs)."""
+  return _ANNOUNCED.depth > 0 and os.environ.get(
+      'WB2HIP_FUSE_VARIABLES', '1') != '0'
+
+
+def _det_plan(forecast, truth, name, climatology):
+  """Host part of one variable's deterministic pass (label work only):
+  (geo, arrays, tables, mode, pins, climatology stamp)."""
   fvar, tvar = forecast[name], truth[name]
-  cvar = None
+  cvar, announced = None, False
   if climatology is not None:
     cvar = _get_climatology_chunk(climatology, truth)[name]
-  pins = [fvar.data, tvar.data] + ([cvar.data] if cvar is not None else [])
-  key = _result_key('det', pins[:2], region, skipna, (forecast, truth))
-  hit = _RESULTS.get(key)
-  # A cached ACC pass also answers MSE/RMSE/MAE/Bias queries.
-  if hit is not None and (cvar is None or hit['clim'] == _stamp(cvar.data)):
-    return hit['geo'], hit['by_region']
-  announced = False
-  if cvar is None and _ANNOUNCED.climatology:
+  elif _ANNOUNCED.climatology:
     # an ACC over this chunk is coming (fused_climatology): read its
     # climatology now, the ACC call then becomes a cache hit
     try:
@@ -708,6 +825,7 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
       announced = True
     except (KeyError, ValueError):
       climatology, cvar = None, None
+  pins = [fvar.data, tvar.data]
   geo, prepared = _geometry(forecast, fvar, [tvar])
   tables = [_slab_table(geo.out_dims, geo.out_shape, p[1], p[0].shape[:-2])
             for p in prepared]
@@ -722,17 +840,64 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
         raise
       cvar = None  # the ACC call itself will report what is wrong
   if cvar is not None:
-    if announced:
-      pins.append(cvar.data)
+    pins.append(cvar.data)
     prepared.append((cdata, crest))
     tables.append(ctable)
     mode = _lib.MODE_DET_ACC
-  by_region, _ = _run_pass(mode, geo, [p[0] for p in prepared], tables, region,
-                           skipna)
-  _RESULTS.put(key, tuple(pins), {
-      'geo': geo, 'by_region': by_region,
-      'clim': None if cvar is None else _stamp(cvar.data)})
-  return geo, by_region
+  return (geo, [p[0] for p in prepared], tables, mode, tuple(pins),
+          None if cvar is None else _stamp(cvar.data))
+
+
+def _det_key(forecast, truth, name, region, skipna):
+  return _result_key('det', [forecast[name].data, truth[name].data], region,
+                     skipna, (forecast, truth))
+
+
+def _det_pass(forecast, truth, name, region, skipna, climatology=None):
+  """All five deterministic metrics of one variable, for the active regions.
+
+  Inside a chunk scope a miss runs the pass for EVERY variable the two
+  datasets share (the reference's Dataset arithmetic does the same, one
+  variable after the other): one launch per (grid, dtype, mode) instead of one
+  per variable, the other variables' calls are cache hits."""
+  key = _det_key(forecast, truth, name, region, skipna)
+  hit = _RESULTS.get(key)
+  # A cached ACC pass also answers MSE/RMSE/MAE/Bias queries.
+  if hit is not None and (climatology is None or hit['clim'] == _stamp(
+      _get_climatology_chunk(climatology, truth)[name].data)):
+    return hit['geo'], hit['by_region']
+  plans = {name: _det_plan(forecast, truth, name, climatology)}
+  if _fuse_variables():
+    for other in _common_vars(forecast, truth):
+      if other in plans:
+        continue
+      try:
+        if _RESULTS.get(_det_key(forecast, truth, other, region, skipna)):
+          continue  # an earlier (narrower) pass already answered it
+        plans[other] = _det_plan(forecast, truth, other, climatology)
+      except Exception:  # reported when that variable is asked for
+        continue
+  by_mode: dict = {}
+  for n, pl in plans.items():
+    by_mode.setdefault(pl[3], []).append(n)
+  for mode, names in by_mode.items():
+    try:
+      results = _run_group(mode, [plans[n][:3] for n in names], region, skipna)
+    except Exception:
+      if len(names) == 1 and names[0] == name:
+        raise
+      # a companion variable cannot be read (foreign dtype, bad grid): the
+      # requested one goes alone, the others report when they are asked for
+      names = [n for n in names if n == name]
+      if not names:
+        continue
+      results = _run_group(mode, [plans[name][:3]], region, skipna)
+    for n, by_region in zip(names, results):
+      geo, _, _, _, pins, clim = plans[n]
+      _RESULTS.put(_det_key(forecast, truth, n, region, skipna), pins,
+                   {'geo': geo, 'by_region': by_region, 'clim': clim})
+  hit = _RESULTS.get(key)
+  return hit['geo'], hit['by_region']
 
 
 def _result_coords(forecast: xl.Dataset, out_dims) -> dict:
@@ -1001,23 +1166,56 @@ class _DetMetric(Metric):
     return self._mean_regions(forecast, truth, regions, skipna)
 
 
-@_serialized
-def _wind_pass(forecast, truth, u_name, v_name, region, skipna):
+def _wind_plan(forecast, truth, u_name, v_name):
   fu, fv, tu, tv = (forecast[u_name], forecast[v_name], truth[u_name],
                     truth[v_name])
-  pins = [fu.data, tu.data, fv.data, tv.data]
-  key = _result_key('wind', pins, region, skipna, (forecast, truth))
-  hit = _RESULTS.get(key)
-  if hit is not None:
-    return hit
+  pins = (fu.data, tu.data, fv.data, tv.data)
   geo, prepared = _geometry(forecast, fu, [tu, fv, tv])
   tables = [_slab_table(geo.out_dims, geo.out_shape, p[1], p[0].shape[:-2])
             for p in prepared]
-  by_region, _ = _run_pass(_lib.MODE_WIND, geo, [p[0] for p in prepared],
-                           tables, region, skipna)
-  value = (geo, by_region)
-  _RESULTS.put(key, tuple(pins), value)
-  return value
+  return geo, [p[0] for p in prepared], tables, pins
+
+
+def _wind_key(forecast, truth, u_name, v_name, region, skipna):
+  pins = [forecast[u_name].data, truth[u_name].data, forecast[v_name].data,
+          truth[v_name].data]
+  return _result_key('wind', pins, region, skipna, (forecast, truth))
+
+
+def _wind_pass(forecast, truth, u_name, v_name, region, skipna):
+  """Wind-vector MSE / RMSE of one (u, v) pair; inside a chunk scope every
+  announced pair (`fused_wind_vectors`) is read by the same launch."""
+  key = _wind_key(forecast, truth, u_name, v_name, region, skipna)
+  hit = _RESULTS.get(key)
+  if hit is not None:
+    return hit
+  pairs = [(u_name, v_name)]
+  if _fuse_variables() and _ANNOUNCED.wind:
+    pairs += [p for p in _ANNOUNCED.wind[-1] if p not in pairs
+              and all(k in forecast and k in truth for k in p)]
+  plans = {}
+  for pair in pairs:
+    try:
+      if pair != pairs[0] and _RESULTS.get(
+          _wind_key(forecast, truth, *pair, region, skipna)):
+        continue
+      plans[pair] = _wind_plan(forecast, truth, *pair)
+    except Exception:
+      if pair == pairs[0]:
+        raise
+  names = list(plans)
+  try:
+    results = _run_group(_lib.MODE_WIND, [plans[p][:3] for p in names], region,
+                         skipna)
+  except Exception:
+    if len(names) == 1:
+      raise
+    names = names[:1]
+    results = _run_group(_lib.MODE_WIND, [plans[names[0]][:3]], region, skipna)
+  for pair, by_region in zip(names, results):
+    _RESULTS.put(_wind_key(forecast, truth, *pair, region, skipna),
+                 plans[pair][3], (plans[pair][0], by_region))
+  return _RESULTS.get(key)
 
 
 @dataclasses.dataclass
@@ -1274,7 +1472,6 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim, allow_gather=False):
           to_dev(truth_table), strides[ensemble_dim], n_member, device, None)
 
 
-@_serialized
 def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
               want_maps: bool = False):
   """All ensemble metrics of one variable for the active regions (and, with
@@ -1632,7 +1829,6 @@ def compute_spread_skill_ratio(results):
 # Tier 2: Gaussian forecasts (metrics.py:849-937) and the energy score
 # (metrics.py:1402-1517)
 # ---------------------------------------------------------------------------
-@_serialized
 def _gauss_pass(forecast, truth, name, region, skipna):
   mvar, svar, tvar = forecast[name], forecast[f'{name}_std'], truth[name]
   pins = [mvar.data, svar.data, tvar.data]
@@ -1758,7 +1954,6 @@ def _stack_quantiles(forecast, per_threshold: list, quantiles, method: str,
   return out.assign_attrs(threshold_method=method)
 
 
-@_serialized
 def _gauss_threshold_pass(forecast, truth, threshold_ds, name, region, skipna):
   mvar, svar = forecast[name], forecast[f'{name}_std']
   tvar, hvar = truth[name], threshold_ds[name]
@@ -1914,7 +2109,6 @@ def _ens_threshold_layout(forecast, truth, threshold_ds, name, ensemble_dim):
   return geo, tens, tables, strides[ensemble_dim], n_member, device
 
 
-@_serialized
 def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
                         region, skipna):
   geo, tens, tables, member_slabs, n_member, device = _ens_threshold_layout(
@@ -1931,7 +2125,6 @@ def _ens_threshold_pass(forecast, truth, threshold_ds, name, ensemble_dim,
   return geo, {nm: dev[:, i] for i, nm in enumerate(pl.region_names)}
 
 
-@_serialized
 def _ens_threshold_maps(forecast, truth, threshold_ds, name, ensemble_dim,
                         skipna):
   """The four pointwise score maps [4, *out_shape, n_row, n_col] (device)."""
@@ -2383,7 +2576,6 @@ class RankHistogram(EnsembleMetric):
             engine.upload_table(np.ascontiguousarray(off).ravel(), device),
             (stride[row_dim], stride[col_dim], stride[self.ensemble_dim]), n_col)
 
-  @_serialized
   def _histogram(self, forecast, truth, name, avg_dim=None):
     fvar, tvar = forecast[name], truth[name]
     (geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device,

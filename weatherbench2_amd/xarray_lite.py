@@ -143,11 +143,120 @@ class SlabGather:
     return small, new_index.reshape(self.index.shape)
 
 
+class SlabConcat:
+  """A concatenation that has not happened: element [o..., r, c] of the array
+  is slab `index[o...]` of the VIRTUAL concatenation of `bases` along their
+  flattened leading dims.
+
+  `bases` are C-contiguous arrays (all numpy or all torch tensors on one
+  device, one dtype) whose last two dims are one 2-D slab (n_row, n_col);
+  `index` is an int64 numpy array over the outer dims of the result.  This is
+  how `evaluation.concat_chunks` hands k consecutive (init_time=1, lead_time=1)
+  chunks of the Beam pipeline (evaluation.py:693-705) to ONE fused pass without
+  moving a byte: the deterministic passes turn the index into one device
+  ADDRESS per slab (`addresses`, wb2_stream_partials_addr); every other
+  consumer materialises (one `cat` + `index_select`) and is merely correct."""
+
+  def __init__(self, bases, index):
+    bases = list(bases)
+    if not bases:
+      raise ValueError('SlabConcat needs at least one base')
+    index = np.asarray(index, dtype=np.int64)
+    self.slab_shape = tuple(int(n) for n in bases[0].shape[-2:])
+    counts = []
+    for b in bases:
+      if b.ndim < 2 or tuple(int(n) for n in b.shape[-2:]) != self.slab_shape:
+        raise ValueError('every base needs the same (n_row, n_col) last dims')
+      if b.dtype != bases[0].dtype:
+        raise ValueError('bases differ in dtype')
+      n = 1
+      for m in b.shape[:-2]:
+        n *= int(m)
+      counts.append(n)
+    self.bases = bases
+    self.index = index
+    self.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    self.n_slab = int(self.offsets[-1])
+    if index.size and (index.max() >= self.n_slab or index.min() < 0):
+      raise IndexError(f'slab index out of range [0, {self.n_slab})')
+
+  @property
+  def shape(self):
+    return tuple(self.index.shape) + self.slab_shape
+
+  @property
+  def ndim(self):
+    return self.index.ndim + 2
+
+  @property
+  def dtype(self):
+    return self.bases[0].dtype
+
+  has_missing = False
+
+  @property
+  def on_device(self) -> bool:
+    return _is_torch(self.bases[0])
+
+  def __repr__(self):
+    return (f'<wb2hip.SlabConcat shape={self.shape} dtype={self.dtype} of '
+            f'{len(self.bases)} arrays>')
+
+  def __getitem__(self, key):
+    """Indexing of the outer dims (the two slab dims must be kept whole)."""
+    if not isinstance(key, tuple):
+      key = (key,)
+    outer = key[:self.index.ndim]
+    rest = key[self.index.ndim:]
+    if any(not (isinstance(k, slice) and k == slice(None)) for k in rest):
+      return np.asarray(self)[key]
+    return SlabConcat(self.bases, self.index[outer])
+
+  def permute_outer(self, perm):
+    return SlabConcat(self.bases, np.transpose(self.index, perm))
+
+  def addresses(self) -> np.ndarray:
+    """int64 array of index.shape: the device address of every slab (bases
+    must be torch tensors)."""
+    item = self.bases[0].element_size()
+    step = self.slab_shape[0] * self.slab_shape[1] * item
+    first = np.array([b.data_ptr() for b in self.bases], dtype=np.int64)
+    which = np.searchsorted(self.offsets, self.index, side='right') - 1
+    return first[which] + (self.index - self.offsets[which]) * step
+
+  def materialize(self, device=None):
+    import torch
+    if not self.on_device:
+      host = self.materialize_host()
+      if device is None:
+        return torch.from_numpy(host)
+      from weatherbench2_amd import engine
+      return engine.as_device_tensor(host, torch.device(device))
+    flat = torch.cat([b.reshape((-1,) + self.slab_shape) for b in self.bases])
+    idx = torch.as_tensor(self.index.ravel(), device=flat.device)
+    out = torch.index_select(flat, 0, idx).reshape(self.shape)
+    return out if device is None else out.to(device)
+
+  def materialize_host(self) -> np.ndarray:
+    if self.on_device:
+      return self.materialize().cpu().numpy()
+    flat = np.concatenate([np.asarray(b).reshape((-1,) + self.slab_shape)
+                           for b in self.bases])
+    return np.take(flat, self.index.ravel(), axis=0).reshape(self.shape)
+
+  def __array__(self, dtype=None, copy=None):
+    out = self.materialize_host()
+    return out if dtype is None else out.astype(dtype, copy=False)
+
+
+_LAZY = (SlabGather, SlabConcat)
+
+
 class DataArray:
   """N-d array with named dims and (1-D, per-dim) coordinates."""
 
   def __init__(self, data, dims: t.Sequence[str] = (), coords=None, name=None):
-    if not _is_torch(data) and not isinstance(data, SlabGather):
+    if not _is_torch(data) and not isinstance(data, _LAZY):
       data = np.asarray(data)
     self.data = data
     self.dims = tuple(dims)
@@ -180,7 +289,7 @@ class DataArray:
       from weatherbench2_amd import engine
       engine.order_read(self.data)
       return self.data.detach().cpu().numpy()
-    if isinstance(self.data, SlabGather):
+    if isinstance(self.data, _LAZY):
       return self.data.materialize_host()
     return self.data
 
@@ -197,7 +306,7 @@ class DataArray:
 
   def transpose(self, *dims):
     perm = [self.dims.index(d) for d in dims]
-    if isinstance(self.data, SlabGather):
+    if isinstance(self.data, _LAZY):
       n = self.data.index.ndim
       if perm[n:] == [n, n + 1]:  # the slab dims stay where they are
         data = self.data.permute_outer(perm[:n])
