@@ -34,6 +34,11 @@ and on one GPU (N = 1), each with its own `roofline`:
                   wind vectors, the lon-lat layout, no ACC;
   api             the same 16-unit chunk through the drop-in API
                   (_metric_and_region_loop, 5 metrics x 13 regions);
+  api_official_chunk  the drop-in API at the reference's production chunking
+                  (init_time=1,lead_time=1 chunks of 13 variables, the 16
+                  official regions, mse + wind vectors + acc + bias + mae)
+                  through evaluation.evaluate_chunks(batch_chunks=1 / 16 / 32):
+                  tools/official_chunk.py;
   pcie_inclusive  inputs arriving from pinned host memory through the
                   pipelined feeder (never `value`);
   cpu_baseline    the NumPy oracle on this box's host cores;
@@ -622,6 +627,17 @@ def main():
       out['api'] = api_leg(dev, regions, units)
     except Exception as e:  # never lose the GPU line to a secondary leg
       out['api'] = {'error': f'{type(e).__name__}: {e}'}
+  if rank == 0 and world == 1 and not args.no_api:
+    # ---- the boundary at the reference's PRODUCTION chunking: init_time=1,
+    # lead_time=1 chunks of 13 variables, 16 regions, through evaluate_chunks
+    try:
+      torch.cuda.empty_cache()
+      sys.path.insert(0, os.path.join(ROOT, 'tools'))
+      import official_chunk
+      out['api_official_chunk'] = official_chunk.run(dev)
+    except Exception as e:
+      out['api_official_chunk'] = {'error': f'{type(e).__name__}: {e}'}
+    torch.cuda.empty_cache()
   if rank == 0 and world == 1 and not args.no_secondary:
     # ---- BASELINE configs[2] / configs[3] and K1's production variants, each
     # with its own roofline; bounded step counts keep the whole line in minutes

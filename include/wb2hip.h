@@ -416,10 +416,24 @@ int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,
  *   values DEV double[n_lead][n_time][n_tail] viewed as (lead.., time, tail..)
  *   sum, count DEV double[n_lead][n_tail]  (in/out, caller zero-initialises)
  * skipna != 0: NaN values add nothing to sum nor count.
+ * The sum continues FROM the accumulator, value by value in time order
+ * (sum = ((sum + v_0) + v_1) + ...): feeding the time steps one call at a time
+ * or several per call gives the same bits.
  */
 int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         int64_t n_tail, int skipna, double* sum, double* count,
                         void* stream);
+
+/* The same with a destination table: result element idx of [n_lead][n_tail]
+ * goes to accumulator element dst[idx] (DEV int64[n_lead * n_tail], entries
+ * distinct).  Chunks that split the lead dim as well
+ * (`input_chunks=init_time=1,lead_time=1`, docs/source/official-evaluation.md:
+ * 537-549) accumulate into the rows of their lead labels: xbeam.Mean combines
+ * per chunk key (evaluation.py:740-744).  dst == NULL: identity. */
+int wb2_time_accumulate_scatter(const double* values, int64_t n_lead,
+                                int64_t n_time, int64_t n_tail, int skipna,
+                                const int64_t* dst, double* sum, double* count,
+                                void* stream);
 
 /*
  * K5: the Spatial* metrics (no spatial reduction): SpatialBias / SpatialMSE /

@@ -115,3 +115,29 @@ def test_running_mean_keeps_lead_blocks_apart():
          'level': np.array([500, 850])}))
   np.testing.assert_allclose(mean.result()['z'].values, values.mean(0),
                              rtol=1e-15, equal_nan=True)
+
+
+def test_running_mean_rows_are_per_label_whatever_the_chunks_carry():
+  """A window of two leads, then single leads, then all three: every label
+  keeps ONE accumulator row."""
+  rs = np.random.RandomState(2)
+  leads = (np.arange(3) * np.timedelta64(6, 'h')).astype('timedelta64[ns]')
+  values = rs.normal(size=(4, 3, 2))
+
+  def piece(i, sel):
+    return xl.Dataset(
+        {'z': xl.DataArray(values[i:i + 1][:, sel],
+                           ('init_time', 'lead_time', 'level'))},
+        {'init_time': np.arange(i, i + 1), 'lead_time': leads[sel],
+         'level': np.array([500, 850])})
+  mean = evaluation.RunningMean('init_time', False, split_dim='lead_time')
+  mean.add(piece(0, [1, 2]))
+  mean.add(piece(0, [0]))
+  for sel in ([2], [0], [1]):
+    mean.add(piece(1, sel))
+  mean.add(piece(2, [0, 1, 2]))
+  mean.add(piece(3, [2, 0]))
+  mean.add(piece(3, [1]))
+  got = mean.result()
+  np.testing.assert_array_equal(got.coords['lead_time'], leads)
+  np.testing.assert_allclose(got['z'].values, values.mean(0), rtol=1e-15)

@@ -946,15 +946,23 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
   }
 }
 
+// The running temporal mean (xbeam.Mean's (sum, count) combiner,
+// evaluation.py:735-744).  The sum continues from the accumulator, value by
+// value in time order: how many time steps one call brings (one chunk, or k
+// chunks evaluated as one batch) does not change a bit of the result.  `dst`
+// (optional) sends element idx of the [n_lead][n_tail] result to accumulator
+// element dst[idx] (lead-time blocks of chunks that split the lead dim).
 __global__ void __launch_bounds__(256)
     time_accumulate_kernel(const double* __restrict__ values, long long n_lead,
                            long long n_time, long long n_tail, int skipna,
+                           const long long* __restrict__ dst,
                            double* __restrict__ sum,
                            double* __restrict__ count) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_lead * n_tail) return;
   const long long l = idx / n_tail, j = idx - l * n_tail;
-  double s = 0.0, c = 0.0;
+  const long long out = dst ? dst[idx] : idx;
+  double s = sum[out], c = count[out];
   const double* base = values + l * n_time * n_tail + j;
   auto add = [&](double v) {
     const bool keep = !(skipna && is_nan(v));
@@ -971,8 +979,8 @@ __global__ void __launch_bounds__(256)
     add(v3);
   }
   for (; t < n_time; ++t) add(base[t * n_tail]);
-  sum[idx] += s;
-  count[idx] += c;
+  sum[out] = s;
+  count[out] = c;
 }
 
 // ---------------------------------------------------------------------------
@@ -1378,6 +1386,15 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         int64_t n_tail, int skipna, double* sum, double* count,
                         void* stream) {
   WB2_TRACE();
+  return wb2_time_accumulate_scatter(values, n_lead, n_time, n_tail, skipna,
+                                     nullptr, sum, count, stream);
+}
+
+int wb2_time_accumulate_scatter(const double* values, int64_t n_lead,
+                                int64_t n_time, int64_t n_tail, int skipna,
+                                const int64_t* dst, double* sum, double* count,
+                                void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_EMPTY_OK(n_lead);
   WB2_EMPTY_OK(n_time);
@@ -1388,7 +1405,8 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
   hipLaunchKernelGGL(time_accumulate_kernel, dim3((unsigned)((n + 255) / 256)),
                      dim3(256), 0, static_cast<hipStream_t>(stream), values,
                      (long long)n_lead, (long long)n_time, (long long)n_tail,
-                     skipna, sum, count);
+                     skipna, reinterpret_cast<const long long*>(dst), sum,
+                     count);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }

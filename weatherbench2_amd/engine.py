@@ -450,19 +450,27 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
 
 
 def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
-                    total: torch.Tensor, count: torch.Tensor):
-  """total/count += sum/notnull-count of `values` over `time_axis` (device)."""
+                    total: torch.Tensor, count: torch.Tensor,
+                    dst: t.Optional[torch.Tensor] = None):
+  """total/count += sum/notnull-count of `values` over `time_axis` (device);
+  the sums continue from the accumulators value by value.  `dst` (int64 device
+  tensor, one entry per element of `values` without its time axis): where in
+  `total` / `count` each result element goes (identity without it)."""
   lib = _lib.load()
   values = values.contiguous()
   shape = tuple(values.shape)
   n_lead = int(np.prod(shape[:time_axis], dtype=np.int64))
   n_time = shape[time_axis]
   n_tail = int(np.prod(shape[time_axis + 1:], dtype=np.int64))
-  if total.numel() != n_lead * n_tail or count.numel() != n_lead * n_tail:
-    raise ValueError('accumulator shape mismatch')
-  _lib.check(lib.wb2_time_accumulate(
-      _lib.ptr(values), n_lead, n_time, n_tail, int(skipna), _lib.ptr(total),
-      _lib.ptr(count), current_stream_ptr(values.device)),
+  if dst is None:
+    if total.numel() != n_lead * n_tail or count.numel() != n_lead * n_tail:
+      raise ValueError('accumulator shape mismatch')
+  elif (dst.dtype != torch.int64 or dst.numel() != n_lead * n_tail
+        or total.numel() != count.numel()):
+    raise ValueError('dst is int64 with one entry per result element')
+  _lib.check(lib.wb2_time_accumulate_scatter(
+      _lib.ptr(values), n_lead, n_time, n_tail, int(skipna), _lib.ptr(dst),
+      _lib.ptr(total), _lib.ptr(count), current_stream_ptr(values.device)),
              'wb2_time_accumulate')
 
 

@@ -229,19 +229,66 @@ def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
   return xl.like_input(out, *given)
 
 
+class _Accumulator:
+  """(sum, count) of one result variable.  Without a split dim: tensors of the
+  result's shape (minus the averaged dim).  With one: [row, *rest], one row per
+  label of the split dim in order of first appearance, the rest dims in order."""
+
+  def __init__(self, dims, shape, split, device):
+    import torch
+    self.dims, self.shape, self.split = dims, shape, split
+    self.labels: list = []     # label arrays (0-d), row order
+    self.row_of: dict = {}     # label value -> row
+    self.dst: dict = {}        # label-vector key -> device int64 table
+    if split is None:
+      self.rest_shape = shape
+      alloc = shape
+    else:
+      self.pos = dims.index(split)
+      self.rest_shape = shape[:self.pos] + shape[self.pos + 1:]
+      alloc = (8,) + self.rest_shape
+    self.total = torch.zeros(alloc, dtype=torch.float64, device=device)
+    self.count = torch.zeros_like(self.total)
+
+  def rows(self, labels: np.ndarray) -> np.ndarray:
+    import torch
+    out = np.empty(len(labels), dtype=np.int64)
+    for j, (value, label) in enumerate(zip(labels.tolist(), labels)):
+      row = self.row_of.get(value)
+      if row is None:
+        row = self.row_of[value] = len(self.labels)
+        self.labels.append(label)
+      out[j] = row
+    while len(self.labels) > self.total.shape[0]:
+      grow = torch.zeros_like(self.total)
+      self.total = torch.cat([self.total, grow])
+      self.count = torch.cat([self.count, torch.zeros_like(grow)])
+    return out
+
+  def destinations(self, rows: np.ndarray) -> np.ndarray:
+    """Accumulator element of every element of a result of `self.shape`."""
+    block = int(np.prod(self.rest_shape, dtype=np.int64))
+    rest = np.arange(block, dtype=np.int64).reshape(self.rest_shape)
+    where = [1] * len(self.shape)
+    where[self.pos] = len(rows)
+    return (rows.reshape(where) * block + np.expand_dims(rest, self.pos)).ravel()
+
+
 class RunningMean:
   """xbeam.Mean's (sum, count) combiner, kept on the device.
 
   add(chunk_result) accumulates `sum` and `count` over `dim` (NaNs add to
   neither when skipna); result() all-reduces both across the process group (if
-  one is initialised) and divides.
+  one is initialised) and divides.  Sums continue value by value in the order
+  the time steps arrive (wb2_time_accumulate): the result does not depend on
+  how many of them one add() brings.
 
   Chunks may split another dim as well -- the official 0.25-degree runs use
   `input_chunks=init_time=1,lead_time=1` (docs/source/official-evaluation.md:
   537-549) --: xbeam.Mean combines per key of the remaining chunk offsets, so
-  results with different `split_dim` labels accumulate separately and are
-  laid side by side, in label order, by result() (`split_dim`: the forecast's
-  lead dim when the results have one).
+  with `split_dim` (the forecast's lead dim) every label of that dim has its
+  own accumulator row, whatever mix of labels a chunk result carries, and
+  result() lays the rows out in label order.
   """
 
   def __init__(self, dim: str, skipna: bool = False, device=None, comm=None,
@@ -253,28 +300,12 @@ class RunningMean:
     # an RCCL communicator from engine.comm_init_rank: the exchange then goes
     # through the C ABI (wb2_time_mean_allreduce) instead of torch.distributed
     self.comm = comm
-    self._acc: dict = {}     # (var, split labels) -> (sum, count, dims, shape)
+    self._acc: dict = {}     # var -> _Accumulator
     self._coords: dict = {}
-    self._labels: dict = {}  # split labels key -> label array
 
-  def _split_key(self, chunk: xl.Dataset, da: xl.DataArray):
-    d = self.split_dim
-    if d is None or d not in da.dims or d not in chunk.coords:
-      return None
-    labels = np.asarray(chunk.coords[d])
-    key = (labels.dtype.str, labels.tobytes())
-    self._labels.setdefault(key, labels)
-    return key
-
-  def _tensors(self, name, key, dims, shape):
+  def _on_gpu(self) -> bool:
     import torch
-    if (name, key) not in self._acc:
-      total = torch.zeros(shape, dtype=torch.float64, device=self.device)
-      self._acc[(name, key)] = (total, torch.zeros_like(total), dims, shape)
-    total, count, d, s = self._acc[(name, key)]
-    if d != dims or s != shape:
-      raise ValueError(f'{name}: chunk layout changed {d}{s} -> {dims}{shape}')
-    return total, count
+    return self.device is not None and torch.device(self.device).type == 'cuda'
 
   def add(self, chunk: xl.Dataset):
     import torch
@@ -292,6 +323,10 @@ class RunningMean:
       axis = da.dims.index(self.dim)
       dims = tuple(d for d in da.dims if d != self.dim)
       shape = tuple(n for d, n in zip(da.dims, da.shape) if d != self.dim)
+      labels = chunk.coords.get(self.split_dim) if self.split_dim else None
+      split = self.split_dim if (
+          labels is not None and not isinstance(labels, xl.DataArray)
+          and self.split_dim in dims) else None
       raw = da.data
       if isinstance(raw, torch.Tensor):
         # map-valued results (Spatial* metrics, rank histograms) already live
@@ -303,50 +338,59 @@ class RunningMean:
       else:
         values = torch.as_tensor(np.ascontiguousarray(da.values),
                                  dtype=torch.float64)
-      total, count = self._tensors(name, self._split_key(chunk, da), dims,
-                                   shape)
-      if self.device is not None and torch.device(self.device).type == 'cuda':
+      acc = self._acc.get(name)
+      if acc is None:
+        acc = self._acc[name] = _Accumulator(dims, shape if split is None
+                                             else shape, split, self.device)
+      if acc.dims != dims or acc.split != split or (
+          acc.rest_shape != (shape if split is None else
+                             shape[:acc.pos] + shape[acc.pos + 1:])):
+        raise ValueError(f'{name}: chunk layout changed {acc.dims}'
+                         f'{acc.shape} -> {dims}{shape}')
+      rows = None
+      if split is not None:
+        labels = np.asarray(labels)
+        rows = acc.rows(labels)
+      if self._on_gpu():
+        dst = None
+        if rows is not None:
+          key = (shape, rows.tobytes())
+          dst = acc.dst.get(key)
+          if dst is None:
+            acc.shape = shape
+            dst = acc.dst[key] = engine.upload_table(acc.destinations(rows),
+                                                     self.device)
         engine.time_accumulate(values.to(self.device).contiguous(), axis,
-                               self.skipna, total, count)
+                               self.skipna, acc.total, acc.count, dst)
       else:  # host accumulators (CPU tests of the sharding logic)
         values = values.cpu()
         ok = ~torch.isnan(values) if self.skipna else torch.ones_like(
             values, dtype=torch.bool)
-        total += torch.where(ok, values, torch.zeros_like(values)).sum(axis)
-        count += ok.to(torch.float64).sum(axis)
+        s = torch.where(ok, values, torch.zeros_like(values)).sum(axis)
+        c = ok.to(torch.float64).sum(axis)
+        if rows is None:
+          acc.total += s
+          acc.count += c
+        else:
+          idx = torch.as_tensor(rows)
+          acc.total.index_add_(0, idx, s.movedim(acc.pos, 0))
+          acc.count.index_add_(0, idx, c.movedim(acc.pos, 0))
 
-  def _agree_on_layout(self):
-    """Every rank enters the all-reduce with the same accumulators in the same
-    order: ranks whose shard never met some split label (lead-major chunk
-    lists) get zero accumulators for it."""
-    import torch
+  def _split_labels(self, names) -> dict:
+    """{var: labels in output order}: the union over the ranks, sorted."""
     import torch.distributed as dist
-    mine = [(n, k, self._acc[(n, k)][2], self._acc[(n, k)][3],
-             None if k is None else self._labels[k]) for n, k in self._acc]
-    everyone: list = [None] * dist.get_world_size()
-    dist.all_gather_object(everyone, mine)
-    for layout in everyone:
-      for n, k, dims, shape, labels in layout:
-        if k is not None:
-          self._labels.setdefault(k, labels)
-        if (n, k) not in self._acc:
-          total = torch.zeros(shape, dtype=torch.float64, device=self.device)
-          self._acc[(n, k)] = (total, torch.zeros_like(total), dims, shape)
-
-  def _ordered(self) -> list:
-    """Accumulators by variable, the blocks of a split dim by their first
-    label (chunk offsets of a sorted lead coordinate)."""
-    def order(item):
-      name, key = item
-      if key is None:
-        return (name, 0, 0, b'')
-      first = self._labels[key].ravel()[:1]
-      if first.size and first.dtype.kind in 'mMiu':
-        return (name, 1, int(first.astype('int64')[0]), key[1])
-      if first.size and first.dtype.kind == 'f':
-        return (name, 1, float(first[0]), key[1])
-      return (name, 1, 0, key[1])
-    return sorted(self._acc, key=order)
+    mine = {n: np.array(self._acc[n].labels) for n in names
+            if self._acc[n].split is not None}
+    out = {}
+    if self.comm is None and dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size() > 1):
+      everyone: list = [None] * dist.get_world_size()
+      dist.all_gather_object(everyone, mine)
+      for n in mine:
+        out[n] = np.unique(np.concatenate([e[n] for e in everyone if n in e]))
+    else:
+      out = {n: np.unique(v) for n, v in mine.items()}
+    return out
 
   def result(self) -> xl.Dataset:
     import torch
@@ -360,59 +404,64 @@ class RunningMean:
       raise ValueError('RunningMean.result() on a rank that accumulated '
                        'nothing: give every rank at least one chunk '
                        '(evaluate_chunks checks this up front)')
-    if in_torch_group and self.comm is None:
-      self._agree_on_layout()
-    names = self._ordered()
+    names = sorted(self._acc)
+    labels = self._split_labels(names)
+    # (sum, count) in output layout: rows in label order, labels a rank never
+    # met (lead-major chunk lists) as zeros
+    sums = {}
+    for n in names:
+      acc = self._acc[n]
+      if acc.split is None:
+        sums[n] = (acc.total, acc.count)
+        continue
+      rows = [acc.row_of.get(v) for v in labels[n].tolist()]
+      pad = acc.total.shape[0]
+      idx = torch.as_tensor([pad if r is None else r for r in rows],
+                            device=acc.total.device)
+      zero = torch.zeros((1,) + acc.rest_shape, dtype=torch.float64,
+                         device=acc.total.device)
+      sums[n] = tuple(torch.cat([x, zero]).index_select(0, idx)
+                      for x in (acc.total, acc.count))
     if self.comm is not None and names:
       from weatherbench2_amd import engine
-      flat_t = torch.cat([self._acc[n][0].reshape(-1) for n in names])
-      flat_c = torch.cat([self._acc[n][1].reshape(-1) for n in names])
+      flat_t = torch.cat([sums[n][0].reshape(-1) for n in names])
+      flat_c = torch.cat([sums[n][1].reshape(-1) for n in names])
       engine.time_mean_allreduce(flat_t, flat_c, self.comm)
       offset = 0
       for n in names:
-        total, count, dims, shape = self._acc[n]
-        size = total.numel()
-        self._acc[n] = (flat_t[offset:offset + size].reshape(shape),
-                        flat_c[offset:offset + size].reshape(shape), dims, shape)
+        shape, size = sums[n][0].shape, sums[n][0].numel()
+        sums[n] = (flat_t[offset:offset + size].reshape(shape),
+                   flat_c[offset:offset + size].reshape(shape))
         offset += size
     elif in_torch_group and names:
-      flat = torch.cat([torch.stack([self._acc[n][0], self._acc[n][1]]
-                                    ).reshape(-1) for n in names])
+      flat = torch.cat([torch.stack(sums[n]).reshape(-1) for n in names])
       dist.all_reduce(flat)  # the path's only exchange step
       offset = 0
       for n in names:
-        total, count, dims, shape = self._acc[n]
-        size = total.numel()
-        self._acc[n] = (flat[offset:offset + size].reshape(shape),
-                        flat[offset + size:offset + 2 * size].reshape(shape),
-                        dims, shape)
+        shape, size = sums[n][0].shape, sums[n][0].numel()
+        sums[n] = (flat[offset:offset + size].reshape(shape),
+                   flat[offset + size:offset + 2 * size].reshape(shape))
         offset += 2 * size
     coords = dict(self._coords)
-    pieces: dict = {}
-    for name, key in names:
-      total, count, dims, shape = self._acc[(name, key)]
-      mean = (total / count).cpu().numpy()  # 0/0 -> NaN like an empty mean
-      pieces.setdefault(name, []).append((key, dims, mean))
     split_labels = None
     out_vars = {}
-    for name, parts in pieces.items():
-      dims = parts[0][1]
-      if len(parts) == 1 and parts[0][0] is None:
-        out_vars[name] = (dims, parts[0][2])
-        continue
-      ax = dims.index(self.split_dim)
-      labels = np.concatenate([self._labels[k] for k, _, _ in parts])
-      out_vars[name] = (dims, np.concatenate([m for _, _, m in parts],
-                                             axis=ax))
-      if split_labels is not None and not np.array_equal(split_labels, labels):
-        raise ValueError(f'{name}: {self.split_dim} labels differ between '
-                         'variables')
-      split_labels = labels
+    for n in names:
+      acc = self._acc[n]
+      total, count = sums[n]
+      mean = (total / count).cpu().numpy()  # 0/0 -> NaN like an empty mean
+      if acc.split is not None:
+        mean = np.moveaxis(mean, 0, acc.pos)
+        if split_labels is not None and not np.array_equal(split_labels,
+                                                           labels[n]):
+          raise ValueError(f'{n}: {self.split_dim} labels differ between '
+                           'variables')
+        split_labels = labels[n]
+      out_vars[n] = (acc.dims, mean)
     if split_labels is not None:
       coords[self.split_dim] = split_labels
     out = xl.Dataset(coords=coords)
-    for name, (dims, mean) in out_vars.items():
-      out.data_vars[name] = xl.DataArray(mean, dims, coords, name)
+    for n, (dims, mean) in out_vars.items():
+      out.data_vars[n] = xl.DataArray(mean, dims, coords, n)
     return out
 
 
@@ -517,28 +566,19 @@ def _chunk_substitution(eval_config, truth, climatology, by_init: bool):
   return substitute
 
 
-def _plain_slabs(da: xl.DataArray) -> bool:
-  """Data a concatenation can address slab by slab: a C-contiguous numpy array
-  or torch tensor with the two spatial dims last."""
-  data = da.data
-  if isinstance(data, (xl.SlabGather, xl.SlabConcat)) or da.ndim < 2:
-    return False
-  if set(da.dims[-2:]) != {'latitude', 'longitude'}:
-    return False
+def _contiguous(data) -> bool:
   if isinstance(data, np.ndarray):
     return bool(data.flags.c_contiguous)
-  return bool(data.is_contiguous())
+  return not isinstance(data, (xl.SlabGather, xl.SlabConcat)) and bool(
+      data.is_contiguous())
 
 
-def _block_matrix(cells: dict, n_i: int, n_l: int, ax_i, ax_l):
-  """np.block over a (time block, lead block) grid of arrays."""
-  rows = []
-  for bi in range(n_i):
-    row = [cells[(bi, bl)] for bl in range(n_l)]
-    rows.append(row[0] if ax_l is None or n_l == 1
-                else np.concatenate(row, axis=ax_l))
-  return rows[0] if ax_i is None or n_i == 1 else np.concatenate(rows,
-                                                                  axis=ax_i)
+def _same_values(a, b) -> bool:
+  if a is b:
+    return True
+  a = a.values if isinstance(a, xl.DataArray) else a
+  b = b.values if isinstance(b, xl.DataArray) else b
+  return a is b or np.array_equal(np.asarray(a), np.asarray(b))
 
 
 def concat_chunks(datasets: t.Sequence, time_dim: str,
@@ -550,9 +590,9 @@ def concat_chunks(datasets: t.Sequence, time_dim: str,
   through device addresses.  Coordinates that follow the two dims (valid_time,
   the 2-D `time` of a by-init truth chunk) are put together the same way.
 
-  Returns None when the chunks do not form such a rectangle or hold data that
-  cannot be addressed in place (lazy gathers, transposed or strided arrays):
-  the caller then evaluates them one by one."""
+  Returns None when the chunks are not equally shaped pieces of such a
+  rectangle or hold data that cannot be addressed in place (lazy gathers,
+  transposed or strided arrays): the caller then evaluates them one by one."""
   datasets = [xl.as_dataset(d) for d in datasets]
   first = datasets[0]
   if len(datasets) == 1:
@@ -561,103 +601,120 @@ def concat_chunks(datasets: t.Sequence, time_dim: str,
     return None
   split = (time_dim,) + ((lead_dim,) if lead_dim and lead_dim in first.dims
                          else ())
-  names = list(first.keys())
+  names = list(first.data_vars)
   # position of every chunk in the rectangle, by its labels
-  blocks: list = [[] for _ in split]
+  blocks: list = [{} for _ in split]   # label bytes -> (position, labels)
   where = []
   for ds in datasets:
-    if list(ds.keys()) != names:
-      return None
     pos = []
     for j, d in enumerate(split):
-      if d not in ds.coords or isinstance(ds.coords[d], xl.DataArray):
+      labels = ds.coords.get(d)
+      if labels is None or isinstance(labels, xl.DataArray):
         return None
-      labels = np.asarray(ds.coords[d])
+      labels = np.asarray(labels)
       key = (labels.dtype.str, labels.tobytes())
-      known = [k for k, _ in blocks[j]]
-      if key not in known:
-        blocks[j].append((key, labels))
-        known.append(key)
-      pos.append(known.index(key))
-    where.append(tuple(pos) if len(pos) == 2 else (pos[0], 0))
+      hit = blocks[j].get(key)
+      if hit is None:
+        hit = blocks[j][key] = (len(blocks[j]), labels)
+      pos.append(hit[0])
+    where.append((pos[0], pos[1] if len(pos) == 2 else 0))
   n_i = len(blocks[0])
   n_l = len(blocks[1]) if len(split) == 2 else 1
   if len(set(where)) != len(where) or len(where) != n_i * n_l:
     return None
-  for j in range(len(split)):  # blocks must not share labels
-    labels = np.concatenate([lab for _, lab in blocks[j]])
-    if len(set(labels.tolist())) != len(labels):
+  labels_of = []
+  for j in range(len(split)):  # blocks neither share labels nor differ in size
+    parts = [lab for _, lab in blocks[j].values()]
+    if len({len(p) for p in parts}) != 1:
       return None
-  # everything else must be common to the chunks
-  for ds in datasets[1:]:
-    for k, c in first.coords.items():
-      cdims = tuple(c.dims) if isinstance(c, xl.DataArray) else (k,)
-      if any(d in split for d in cdims):
-        continue
-      other = ds.coords.get(k)
-      if other is None or not np.array_equal(
-          np.asarray(c.values if isinstance(c, xl.DataArray) else c),
-          np.asarray(other.values if isinstance(other, xl.DataArray)
-                     else other)):
-        return None
+    joined = np.concatenate(parts)
+    if len(set(joined.tolist())) != len(joined):
+      return None
+    labels_of.append(joined)
+  size = {d: len(labels_of[j]) // (n_i, n_l)[j] for j, d in enumerate(split)}
+  count = {time_dim: n_i}
+  if len(split) == 2:
+    count[split[1]] = n_l
+
+  def assemble(dims, shape, cells, dtype):
+    """Block matrix of equally shaped cells {(bi, bl): array} over `dims`."""
+    out_shape = tuple(n * count.get(d, 1) for d, n in zip(dims, shape))
+    out = np.empty(out_shape, dtype=dtype)
+    ax = [dims.index(d) if d in dims else None for d in split] + [None]
+    for (bi, bl), cell in cells.items():
+      sl = [slice(None)] * len(dims)
+      if ax[0] is not None:
+        sl[ax[0]] = slice(bi * shape[ax[0]], (bi + 1) * shape[ax[0]])
+      if ax[1] is not None:
+        sl[ax[1]] = slice(bl * shape[ax[1]], (bl + 1) * shape[ax[1]])
+      out[tuple(sl)] = cell
+    return out
+
+  def cell_of(at, dims):
+    return (at[0] if time_dim in dims else 0,
+            at[1] if len(split) == 2 and split[1] in dims else 0)
+
+  # coordinates: common ones must agree, those along the split dims are joined
   coords = {}
   for k, c in first.coords.items():
     cdims = tuple(c.dims) if isinstance(c, xl.DataArray) else (k,)
     if not any(d in split for d in cdims):
+      for ds in datasets[1:]:
+        other = ds.coords.get(k)
+        if other is None or not _same_values(c, other):
+          return None
       coords[k] = c
       continue
     if not isinstance(c, xl.DataArray):  # the split dims' own labels
-      j = split.index(k)
-      coords[k] = np.concatenate([lab for _, lab in blocks[j]])
+      coords[k] = labels_of[split.index(k)]
       continue
     cells = {}
+    ref = np.asarray(c.values)
     for ds, at in zip(datasets, where):
       other = ds.coords.get(k)
       if not isinstance(other, xl.DataArray) or tuple(other.dims) != cdims:
         return None
-      cells[at] = np.asarray(other.values)
-    ax_i = cdims.index(time_dim) if time_dim in cdims else None
-    ax_l = cdims.index(split[1]) if len(split) == 2 and split[1] in cdims else (
-        None)
-    if ax_i is None:  # follows the lead dim only: the first time block's
-      cells = {(0, bl): cells[(0, bl)] for bl in range(n_l)}
-    if ax_l is None:
-      cells = {(bi, 0): cells[(bi, 0)] for bi in range(n_i if ax_i is not None
-                                                       else 1)}
-    coords[k] = xl.DataArray(
-        _block_matrix(cells, n_i if ax_i is not None else 1,
-                      n_l if ax_l is not None else 1, ax_i, ax_l), cdims)
-  out = xl.Dataset(coords=coords, attrs=dict(first.attrs))
-  for name in names:
-    ref = first[name]
-    if not any(d in ref.dims for d in split):
-      out.data_vars[name] = xl.DataArray(ref.data, ref.dims, coords, name)
-      continue
-    if any(d in ref.dims[-2:] for d in split):
-      return None
-    ax_i = ref.dims.index(time_dim) if time_dim in ref.dims else None
-    ax_l = (ref.dims.index(split[1])
-            if len(split) == 2 and split[1] in ref.dims else None)
-    bases, cells, offset = [], {}, 0
-    kind = type(ref.data)
-    for ds, at in zip(datasets, where):
-      da = ds[name]
-      if (da.dims != ref.dims or not _plain_slabs(da)
-          or type(da.data) is not kind or da.dtype != ref.dtype
-          or tuple(da.shape[-2:]) != tuple(ref.shape[-2:])):
+      value = np.asarray(other.values)
+      if value.shape != ref.shape:
         return None
-      at = (at[0] if ax_i is not None else 0, at[1] if ax_l is not None else 0)
+      cells.setdefault(cell_of(at, cdims), value)
+    coords[k] = xl.DataArray(assemble(cdims, ref.shape, cells, ref.dtype),
+                             cdims)
+  out = xl.Dataset(coords=coords, attrs=dict(first.attrs))
+  for ds in datasets[1:]:
+    if len(ds.data_vars) != len(names):
+      return None
+  for name in names:
+    ref = first.data_vars[name]
+    rdims, rshape, rdtype, kind = ref.dims, ref.shape, ref.dtype, type(ref.data)
+    if not any(d in rdims for d in split):
+      out.data_vars[name] = xl.DataArray(ref.data, rdims, coords, name)
+      continue
+    if (len(rdims) < 2 or set(rdims[-2:]) != {'latitude', 'longitude'}
+        or any(size[d] != rshape[rdims.index(d)] for d in split
+               if d in rdims)):
+      return None
+    outer = rshape[:-2]
+    n = int(np.prod(outer, dtype=np.int64))
+    template = np.arange(n, dtype=np.int64).reshape(outer)
+    bases, cells = [], {}
+    for ds, at in zip(datasets, where):
+      da = ds.data_vars.get(name)
+      if da is None:
+        return None
+      data = da.data
+      if (da.dims != rdims or type(data) is not kind
+          or tuple(data.shape) != rshape or data.dtype != rdtype
+          or not _contiguous(data)):
+        return None
+      at = cell_of(at, rdims)
       if at in cells:  # the variable does not follow one of the split dims
         continue
-      outer = tuple(da.shape[:-2])
-      n = int(np.prod(outer, dtype=np.int64))
-      cells[at] = offset + np.arange(n, dtype=np.int64).reshape(outer)
-      bases.append(da.data)
-      offset += n
-    index = _block_matrix(cells, n_i if ax_i is not None else 1,
-                          n_l if ax_l is not None else 1, ax_i, ax_l)
-    out.data_vars[name] = xl.DataArray(xl.SlabConcat(bases, index), ref.dims,
-                                       coords, name)
+      cells[at] = len(bases) * n + template
+      bases.append(data)
+    index = assemble(rdims[:-2], outer, cells, np.int64)
+    out.data_vars[name] = xl.DataArray(
+        xl.SlabConcat(bases, index, uniform=True), rdims, coords, name)
   return out
 
 

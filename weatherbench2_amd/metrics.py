@@ -106,9 +106,12 @@ def _field_key(region):
       ident = id(mask)
     return (ident, getattr(region, 'threshold', None))
   if kind == 'CombinedRegion':
-    keys = tuple(k for k in (_field_key(r) for r in region.regions)
-                 if k is not None)
-    return keys or None
+    keys = [k for k in (_field_key(r) for r in region.regions)
+            if k is not None]
+    # a slice combined with ONE land-sea mask carries that mask's field and
+    # shares its pass (scripts/evaluate.py:378-395: global_land,
+    # extra-tropics_land and tropics_land are one group)
+    return None if not keys else keys[0] if len(keys) == 1 else tuple(keys)
   return None
 
 
@@ -228,7 +231,8 @@ def _fused(pass_fn, region, regions: t.Optional[dict]):
   out, merged = None, {}
   for group, _ in groups:
     res = pass_fn(next(iter(group.values())))
-    merged.update(res[1])
+    merged.update(res[1].materialized() if isinstance(res[1], _ByRegion)
+                  else res[1])
     out = out or res
   merged.pop(_ALL, None)  # the stacked tensor of ONE pass is not all regions
   return (out[0], merged) + tuple(out[2:])
@@ -558,6 +562,23 @@ def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
   times, levels, the climatology's dayofyear / hour / level labels, the output
   layout), so a stream of chunks with recurring time stamps -- or the five
   metrics of one loop -- builds each table once."""
+  st = _ANNOUNCED
+  memo_key = None
+  if st.depth > 0:  # the variables of one chunk share their tables
+    memo_key = ('clim_slabs', id(climatology), id(forecast), crest,
+                geo.out_dims, geo.out_shape,
+                tuple(cvar.sizes[d] for d in crest))
+    hit = st.memo.get(memo_key)
+    if hit is not None and hit[0] is climatology and hit[1] is forecast:
+      return hit[2]
+    table = _climatology_slabs_by_content(climatology, cvar, forecast, geo,
+                                          crest)
+    st.memo[memo_key] = (climatology, forecast, table)
+    return table
+  return _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest)
+
+
+def _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest):
   if 'init_time' in forecast.dims:
     vt = forecast.coords['valid_time']
     if not isinstance(vt, xl.DataArray):
@@ -707,10 +728,35 @@ def _slab_addresses(x, table, n_row: int, n_col: int, n_outer: int):
   return flat.data_ptr() + np.asarray(tb, dtype=np.int64) * step, flat
 
 
+class _ByRegion(dict):
+  """{region key: metrics[NMETRIC, ...]} over the stacked result of a pass,
+  sliced on first use (a loop over all regions only ever takes `_ALL`)."""
+
+  def __init__(self, dev, names):
+    super().__init__()
+    self._dev, self._names = dev, list(names)
+    dict.__setitem__(self, _ALL, (dev, self._names))
+
+  def __missing__(self, key):
+    value = self._dev[:, self._names.index(key)]  # ValueError -> KeyError below
+    self[key] = value
+    return value
+
+  def __contains__(self, key):
+    return dict.__contains__(self, key) or key in self._names
+
+  def get(self, key, default=None):
+    try:
+      return self[key]
+    except (KeyError, ValueError):
+      return default
+
+  def materialized(self) -> dict:
+    return {k: self[k] for k in self._names}
+
+
 def _by_region(pl, dev, out_shape) -> dict:
-  by_region = {name: dev[:, i] for i, name in enumerate(pl.region_names)}
-  by_region[_ALL] = (dev, list(pl.region_names))
-  return by_region
+  return _ByRegion(dev, pl.region_names)
 
 
 def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
@@ -1023,6 +1069,23 @@ def _reference_result_dtype(forecast: xl.Dataset, data_dtypes, region,
   the regions' dtypes.  The VALUES here are the float64 sums of the fused pass
   rounded once to that dtype (the reference's float32 einsum carries ~1e-5 of
   summation noise at 10^6 points)."""
+  st = _ANNOUNCED
+  data_dtypes = tuple(data_dtypes)
+  memo_key = None
+  if st.depth > 0:
+    memo_key = ('result_dtype', id(forecast), data_dtypes, id(region),
+                id(regions))
+    hit = st.memo.get(memo_key)
+    if hit is not None and hit[0] is forecast and hit[1] is region and (
+        hit[2] is regions):
+      return hit[3]
+  out = _reference_result_dtype_uncached(forecast, data_dtypes, region, regions)
+  if memo_key is not None:
+    st.memo[memo_key] = (forecast, region, regions, out)
+  return out
+
+
+def _reference_result_dtype_uncached(forecast, data_dtypes, region, regions):
   w = np.sin(np.deg2rad(_coord_values(forecast, 'latitude')[:1])).dtype
   data = np.dtype(np.float32)
   first = True

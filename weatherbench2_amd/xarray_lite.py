@@ -157,22 +157,29 @@ class SlabConcat:
   ADDRESS per slab (`addresses`, wb2_stream_partials_addr); every other
   consumer materialises (one `cat` + `index_select`) and is merely correct."""
 
-  def __init__(self, bases, index):
+  def __init__(self, bases, index, uniform: bool = False):
     bases = list(bases)
     if not bases:
       raise ValueError('SlabConcat needs at least one base')
     index = np.asarray(index, dtype=np.int64)
     self.slab_shape = tuple(int(n) for n in bases[0].shape[-2:])
-    counts = []
-    for b in bases:
-      if b.ndim < 2 or tuple(int(n) for n in b.shape[-2:]) != self.slab_shape:
-        raise ValueError('every base needs the same (n_row, n_col) last dims')
-      if b.dtype != bases[0].dtype:
-        raise ValueError('bases differ in dtype')
+    if uniform:  # the caller vouches: equally shaped bases of one dtype
       n = 1
-      for m in b.shape[:-2]:
+      for m in bases[0].shape[:-2]:
         n *= int(m)
-      counts.append(n)
+      counts = [n] * len(bases)
+    else:
+      counts = []
+      for b in bases:
+        if b.ndim < 2 or tuple(int(n) for n in b.shape[-2:]) != self.slab_shape:
+          raise ValueError('every base needs the same (n_row, n_col) last '
+                           'dims')
+        if b.dtype != bases[0].dtype:
+          raise ValueError('bases differ in dtype')
+        n = 1
+        for m in b.shape[:-2]:
+          n *= int(m)
+        counts.append(n)
     self.bases = bases
     self.index = index
     self.offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -577,12 +584,32 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
     dtype = np.result_type(*[as_np(v.dtype) for v in holders])
     if dtype.kind != 'f':
       dtype = np.dtype(np.float64)  # the NaN fill needs a float
-    if on_device:  # map-valued results: merge where they live
+    if on_device:
+      # results that live on the device are merged there, with ONE stack per
+      # variable: the per-metric slices are views into the fused passes' output
       import torch
-      data = torch.full(shape, float('nan'), dtype=getattr(torch, dtype.name),
-                        device=ref.data.device)
-    else:
-      data = np.full(shape, np.nan, dtype=dtype)
+      tdtype = getattr(torch, dtype.name)
+      rows: list = [None] * len(labels)
+      for d in datasets:
+        if name not in d.data_vars:
+          continue
+        v = d.data_vars[name]
+        if v.dims != ref.dims:  # xarray aligns by name: same dims, other order
+          if sorted(v.dims) != sorted(ref.dims):
+            raise ValueError(
+                f'{name}: cannot merge dims {v.dims} with {ref.dims}')
+          v = v.transpose(*ref.dims)
+        for i, m in enumerate(np.atleast_1d(d.coords['metric'])):
+          rows[labels.index(m)] = v.data.select(ax, i).to(tdtype)
+      if any(r is None for r in rows):
+        shape.pop(ax)
+        hole = torch.full(shape, float('nan'), dtype=tdtype,
+                          device=ref.data.device)
+        rows = [hole if r is None else r for r in rows]
+      out.data_vars[name] = DataArray(torch.stack(rows, dim=ax), ref.dims,
+                                      coords, name)
+      continue
+    data = np.full(shape, np.nan, dtype=dtype)
     for d in datasets:
       if name not in d.data_vars:
         continue
@@ -591,7 +618,7 @@ def merge(datasets: t.Sequence[Dataset]) -> Dataset:
         if sorted(v.dims) != sorted(ref.dims):
           raise ValueError(f'{name}: cannot merge dims {v.dims} with {ref.dims}')
         v = v.transpose(*ref.dims)
-      values = v.data if on_device else v.values
+      values = v.values
       for i, m in enumerate(np.atleast_1d(d.coords['metric'])):
         sl = [slice(None)] * len(shape)
         sl[ax] = labels.index(m)
