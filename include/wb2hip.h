@@ -139,8 +139,13 @@ int wb2_tile_cols_ex(int mode, int dtype, int skipna, int has_wfield, int n_col,
  *  w_col       DEV  double[n_col]  > 0   (latitude weights when cols = lat) or NULL
  *                   when every column weight is 1 (rows = lat)
  *  wfield      DEV  double[n_row*n_col] or NULL: a 2-D weight factor such as the
- *                   land-sea mask (regions.py:112-138); points with wfield <= 0
- *                   are excluded (metrics.py:159-160).
+ *                   land-sea mask (regions.py:112-138); points with wfield == 0
+ *                   are excluded (metrics.py:159-160).  PRECONDITION: every
+ *                   value is finite and >= 0 -- the kernel multiplies the
+ *                   weight through unconditionally and only clears the DATA of
+ *                   excluded points, so a NaN cell would make every sum of its
+ *                   tile NaN and a negative cell would be counted.  The Python
+ *                   host checks this (plan.build_plan); other callers must.
  *  chunk_row0/chunk_nrow  DEV int32[n_chunk]: row range of each chunk (a chunk
  *                   never straddles a band boundary; nrow == 0 chunks are padding)
  *  seg_col0    DEV  int32[n_seg+1]: column range of each seg

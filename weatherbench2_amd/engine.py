@@ -98,9 +98,9 @@ def publish_thread_stream() -> None:
 
 
 def order_read(tensor: torch.Tensor) -> None:
-  """Before a device result is read (`.values`, RunningMean.add) on a thread
-  whose current stream is not the default stream: wait for what has been
-  published there.  No-op on the main thread's default stream."""
+  """Before a device result is read (`.values`, RunningMean.add): a reader on a
+  private stream waits for what has been published on the default stream, and
+  the read is recorded with the allocator (cross-stream block reuse)."""
   if not tensor.is_cuda:
     return
   dev = tensor.device
@@ -108,6 +108,14 @@ def order_read(tensor: torch.Tensor) -> None:
   default = torch.cuda.default_stream(dev)
   if cur != default:
     cur.wait_stream(default)
+  # The reader's stream is (in general) not the stream the result was
+  # allocated on -- a worker's private stream -- and `wait_stream` orders
+  # visibility only: the caching allocator hands a freed block back to its
+  # OWN stream at once, where the worker's next pass could overwrite it while
+  # this read is still queued here.  Recording the use makes the allocator
+  # wait for this stream before it reuses the block (a no-op when the streams
+  # are the same).
+  tensor.record_stream(cur)
 
 
 def require_gpu() -> torch.device:
@@ -148,7 +156,10 @@ def as_device_tensor(x, device, dtype=None) -> torch.Tensor:
 def digest(buf: np.ndarray) -> bytes:
   """Content digest of a contiguous numeric array (xxh3 when importable --
   GB/s --, blake2b otherwise)."""
-  raw = memoryview(np.ascontiguousarray(buf)).cast('B')
+  buf = np.ascontiguousarray(buf)
+  if buf.size == 0:  # memoryview cannot cast shapes with zeros
+    return b'empty:' + repr((buf.shape, buf.dtype.str)).encode()
+  raw = memoryview(buf.reshape(-1)).cast('B')
   try:
     import xxhash
     return xxhash.xxh3_128_digest(raw)

@@ -194,9 +194,9 @@ def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
   else:
     valid = init[:, None] + lead[None, :]
   have = np.asarray(truth.coords[time_dim])
-  pos = {v: i for i, v in enumerate(have.tolist())}
+  pos = {v: i for i, v in enumerate(xl.label_list(have))}
   try:
-    index = np.array([pos[v] for v in valid.ravel().tolist()], dtype=np.int64)
+    index = np.array([pos[v] for v in xl.label_list(valid)], dtype=np.int64)
   except KeyError as e:
     raise KeyError(f'not all valid times found in truth.{time_dim}: {e}') from e
   coords = {k: v for k, v in truth.coords.items()
@@ -851,9 +851,9 @@ def _index_values(ds: xl.Dataset, name: str) -> np.ndarray:
 
 def _positions(have: np.ndarray, want: np.ndarray, what: str) -> np.ndarray:
   """Positions of the labels `want` in the index `have` (KeyError like .sel)."""
-  pos = {v: i for i, v in enumerate(np.asarray(have).tolist())}
+  pos = {v: i for i, v in enumerate(xl.label_list(have))}
   try:
-    flat = [pos[v] for v in np.asarray(want).ravel().tolist()]
+    flat = [pos[v] for v in xl.label_list(want)]
   except KeyError as e:
     raise KeyError(f'not all values found in index {what!r}: {e}') from e
   return np.array(flat, dtype=np.int64).reshape(np.shape(want))
@@ -1111,10 +1111,18 @@ def _persistence_like_forecast_chunk(forecast_chunk, truth_chunk, truth,
   coords = {lead_dim: lead, 'init_time': init}
   if 'valid_time' in forecast_chunk.coords:
     coords['valid_time'] = forecast_chunk.coords['valid_time']
-  names = [k for k in (variables or truth.keys()) if 'time' in truth[k].dims]
+  # `truth.sel(time=init_time)` keeps EVERY variable of the truth dataset
+  # (`variables` only sizes the reference's thread pool, :661-667); variables
+  # without a time dim pass through and get the lead dim like the others
+  del variables
+  names = [k for k in truth.keys() if 'time' in truth[k].dims]
   # expand_dims puts the new dim first: (lead_time, init_time, ...)
   out = _gather_dataset(truth, names, {'time': where}, (lead_dim, 'init_time'),
                         where.shape, coords)
+  for k in truth.keys():
+    if k not in names:
+      wide = truth[k].expand_dims({lead_dim: lead})
+      out.data_vars[k] = xl.DataArray(wide.data, wide.dims, out.coords, k)
   return xl.like_input(out, *given), truth_chunk
 
 

@@ -543,9 +543,9 @@ def _get_climatology_chunk(climatology: xl.Dataset, truth: xl.Dataset) -> dict:
 
 
 def _label_positions(have: np.ndarray, want: np.ndarray, what: str):
-  pos = {v: i for i, v in enumerate(np.asarray(have).tolist())}
+  pos = {v: i for i, v in enumerate(xl.label_list(have))}
   try:
-    return np.array([pos[v] for v in np.asarray(want).ravel().tolist()],
+    return np.array([pos[v] for v in xl.label_list(want)],
                     dtype=np.int64).reshape(np.shape(want))
   except KeyError as e:
     raise KeyError(f'{what} label {e} not found in climatology') from e

@@ -28,6 +28,20 @@ def _is_torch(x) -> bool:
   return type(x).__module__.startswith('torch')
 
 
+def label_list(values) -> list:
+  """Labels as hashable Python values for exact matching (`.sel` semantics).
+  datetime64 / timedelta64 of any unit are brought to nanoseconds first:
+  `tolist()` gives ints for [ns] but datetime objects for [s] / [h], so the
+  same instant in two units would not match (pandas indexes compare them
+  equal)."""
+  a = np.asarray(values)
+  if a.dtype.kind == 'M':
+    a = a.astype('datetime64[ns]')
+  elif a.dtype.kind == 'm':
+    a = a.astype('timedelta64[ns]')
+  return a.ravel().tolist()
+
+
 class SlabGather:
   """A gather that has not happened: element [o..., r, c] of the array is
   `base[index[o...], r, c]`.
@@ -651,8 +665,8 @@ def align_inner(a: Dataset, b: Dataset, exclude=()) -> tuple:
       continue
     if ca.shape == cb.shape and np.array_equal(ca, cb):
       continue
-    pos_b = {v: i for i, v in enumerate(cb.tolist())}
-    keep = [(i, pos_b[v]) for i, v in enumerate(ca.tolist()) if v in pos_b]
+    pos_b = {v: i for i, v in enumerate(label_list(cb))}
+    keep = [(i, pos_b[v]) for i, v in enumerate(label_list(ca)) if v in pos_b]
     sel_a[d] = _index_or_slice(np.array([i for i, _ in keep], dtype=np.int64))
     sel_b[d] = _index_or_slice(np.array([j for _, j in keep], dtype=np.int64))
   if not sel_a:
