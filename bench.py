@@ -32,6 +32,9 @@ and on one GPU (N = 1), each with its own `roofline`:
   variants        K1's production instantiations: the official 16 regions
                   incl. three land-sea-mask regions, skipna, float64 inputs,
                   wind vectors, the lon-lat layout, no ACC;
+  k3_variants     K3's: the member counts with kernels of their own (10 ... 56),
+                  skipna with and without NaN patches, land masks, float64
+                  (tools/k3_variants.py; medians of 3 interleaved repetitions);
   api             the same 16-unit chunk through the drop-in API
                   (_metric_and_region_loop, 5 metrics x 13 regions);
   api_official_chunk  the drop-in API at the reference's production chunking
@@ -660,6 +663,13 @@ def main():
       out['variants'] = k1_variants(dev, fpool, tpool, cpool, units, pool)
     except Exception as e:
       out['variants'] = {'error': f'{type(e).__name__}: {e}'}
+    torch.cuda.empty_cache()
+    try:  # K3's other instantiations (member counts, skipna, land masks)
+      sys.path.insert(0, os.path.join(ROOT, 'tools'))
+      import k3_variants
+      out['k3_variants'] = k3_variants.variants(dev)
+    except Exception as e:
+      out['k3_variants'] = {'error': f'{type(e).__name__}: {e}'}
     torch.cuda.empty_cache()
   if rank == 0 and world == 1 and not args.no_pcie:
     try:

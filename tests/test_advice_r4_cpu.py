@@ -1,0 +1,64 @@
+"""Regressions for the round-3 review findings that need no GPU."""
+import numpy as np
+import pytest
+
+from weatherbench2_amd import engine, evaluation
+from weatherbench2_amd import xarray_lite as xl
+
+
+def test_digest_of_empty_arrays():
+  a = engine.digest(np.zeros((0, 3), dtype=np.int64))
+  b = engine.digest(np.zeros((0, 4), dtype=np.int64))
+  assert isinstance(a, bytes) and a != b
+  assert engine.digest(np.zeros((0,), dtype=np.float32)) != a
+
+
+def test_datetime_labels_match_across_units():
+  """truth.time in [ns] against valid times in [h]: `.sel` matches them
+  (pandas compares instants), so does the label lookup."""
+  have = (np.datetime64('2020-01-01T00', 'ns') +
+          np.arange(8) * np.timedelta64(6, 'h'))
+  want = (np.datetime64('2020-01-01T00', 'h') +
+          np.array([[0, 6], [12, 42]]).astype('timedelta64[h]'))
+  pos = evaluation._positions(have, want, 'time')
+  np.testing.assert_array_equal(pos, [[0, 1], [2, 7]])
+  with pytest.raises(KeyError):
+    evaluation._positions(have, want + np.timedelta64(1, 'h'), 'time')
+  lead_s = np.array([0, 21600], dtype='timedelta64[s]')
+  lead_ns = lead_s.astype('timedelta64[ns]')
+  assert xl.label_list(lead_s) == xl.label_list(lead_ns)
+
+
+def test_by_init_persistence_keeps_every_truth_variable():
+  """evaluation.py:651-675: truth.sel(time=init_time) keeps all variables,
+  also those without a time dim (expanded along lead_time like the rest)."""
+  rs = np.random.RandomState(0)
+  time = (np.datetime64('2020-01-01T00', 'ns') +
+          np.arange(6) * np.timedelta64(12, 'h'))
+  lat, lon = np.linspace(-90, 90, 5), np.arange(0, 360, 60.0)
+  truth = xl.Dataset(
+      {'z': xl.DataArray(rs.normal(size=(6, 5, 6)),
+                         ('time', 'latitude', 'longitude')),
+       't2m': xl.DataArray(rs.normal(size=(6, 5, 6)),
+                           ('time', 'latitude', 'longitude')),
+       'orography': xl.DataArray(rs.normal(size=(5, 6)),
+                                 ('latitude', 'longitude'))},
+      {'time': time, 'latitude': lat, 'longitude': lon})
+  lead = (np.arange(2) * np.timedelta64(12, 'h')).astype('timedelta64[ns]')
+  init = time[1:3]
+  fc = xl.Dataset(
+      {'z': xl.DataArray(rs.normal(size=(2, 2, 5, 6)),
+                         ('init_time', 'lead_time', 'latitude', 'longitude'))},
+      {'init_time': init, 'lead_time': lead, 'latitude': lat, 'longitude': lon,
+       'valid_time': xl.DataArray(init[:, None] + lead[None, :],
+                                  ('init_time', 'lead_time'))})
+  out, _ = evaluation._persistence_like_forecast_chunk(fc, None, truth, ['z'])
+  assert set(out.keys()) == {'z', 't2m', 'orography'}
+  assert out['z'].dims == ('lead_time', 'init_time', 'latitude', 'longitude')
+  for name in ('z', 't2m'):
+    want = np.broadcast_to(np.asarray(truth[name].data)[1:3][None],
+                           (2, 2, 5, 6))
+    np.testing.assert_array_equal(np.asarray(out[name].values), want)
+  assert out['orography'].dims[0] == 'lead_time'
+  np.testing.assert_array_equal(np.asarray(out['orography'].values)[1],
+                                np.asarray(truth['orography'].data))

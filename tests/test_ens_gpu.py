@@ -470,3 +470,42 @@ print('MAXREL', float(np.max(np.abs(got - want) / np.abs(want))))
   assert rel['1'] < 1e-13, rel      # the reference's fp64 chain
   assert rel['0'] < 3e-7, rel       # the default: one float32 rounding
   assert rel['0'] > rel['1']        # ... and they are different code paths
+
+
+@pytest.mark.parametrize('skipna', [False, True])
+@pytest.mark.parametrize('n_member', [70, 100, 128])
+def test_gathered_ensemble_with_two_address_lanes(skipna, n_member):
+  """65..128 float32 members: the gathered kernel keeps TWO address registers
+  per lane (member j * 64 + lane) and reads them with v_readlane in row-end
+  tiles too (130 columns: the third tile has 2 live lanes)."""
+  import torch
+  from weatherbench2_amd import engine, plan as plan_lib
+  dev = torch.device('cuda')
+  n_lat, n_lon, n_outer, n_pool = 9, 130, 3, 150
+  pl = plan_lib.build_plan(
+      np.linspace(-90, 90, n_lat), np.linspace(0, 360, n_lon, endpoint=False),
+      plan_lib.LATLON, {'global': None}, dev,
+      rows_per_chunk=plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+  gen = torch.Generator(device=dev).manual_seed(n_member)
+  pool = torch.randn((n_pool, n_lat, n_lon), generator=gen, device=dev)
+  truth = torch.randn((n_outer, n_lat, n_lon), generator=gen, device=dev)
+  rs = np.random.RandomState(n_member)
+  index = rs.randint(0, n_pool, size=(n_outer, n_member)).astype(np.int64)
+  if skipna:
+    index[1, 66] = -1
+  ptrs = torch.from_numpy(np.ascontiguousarray(engine.gather_pointers(
+      pool, index, n_lat * n_lon))).to(dev)
+  slab = n_lat * n_lon
+  maps_a = torch.empty((6, n_outer, slab), dtype=torch.float64, device=dev)
+  maps_b = torch.empty_like(maps_a)
+  a, _ = engine.ensemble_reduce(pl, pool, 0, n_member, None, truth, None,
+                                n_outer, skipna, maps=maps_a, member_ptrs=ptrs)
+  copy = pool[torch.from_numpy(np.maximum(index, 0)).to(dev)]
+  copy[torch.from_numpy(index < 0).to(dev)] = float('nan')
+  copy = copy.permute(1, 0, 2, 3).contiguous()
+  b, _ = engine.ensemble_reduce(pl, copy, n_outer * slab, n_member, None,
+                                truth, None, n_outer, skipna, maps=maps_b)
+  assert torch.equal(torch.nan_to_num(a, nan=-7.0),
+                     torch.nan_to_num(b, nan=-7.0))
+  assert torch.equal(torch.nan_to_num(maps_a, nan=-7.0),
+                     torch.nan_to_num(maps_b, nan=-7.0))

@@ -303,3 +303,137 @@ def _batcher(n):
 
 if __name__ == '__main__':
   main()
+
+
+# ---------------------------------------------------------------------------
+# Round 4: programs for the other ensemble sizes K3 instantiates exactly
+# (csrc/sort3_networks.inc): the cheapest of a few constructions per size.
+# ---------------------------------------------------------------------------
+EXACT_SIZES = (10, 16, 20, 30, 32, 51, 56)
+
+
+def _sorted_by(builder, n_wires, n_real):
+  net = Net()
+  order = builder(net, list(range(n_wires)))
+  return prune(net.ops, order, n_wires, n_real)
+
+
+def _blocks_of_27(net, wires):
+  """27-sorters on consecutive blocks, merged pairwise (2-way odd-even)."""
+  parts = [sort3k(net, wires[i:i + 27]) for i in range(0, len(wires), 27)]
+  while len(parts) > 1:
+    nxt = [merge2(net, parts[i], parts[i + 1]) if i + 1 < len(parts)
+           else parts[i] for i in range(0, len(parts), 2)]
+    parts = nxt
+  return parts[0]
+
+
+_BEST: dict = {}
+
+
+def best_program(n):
+  """(ops, order) sorting n registers: the cheapest of
+    * the 3-way merge sort on 3^k blocks + 2-way merges (`sort_general`),
+    * k 27-sorters merged pairwise, pruned to n,
+    * Batcher's network on the next power of two, pruned to n,
+    * the best programs of two parts merged (every split, recursively)."""
+  if n in _BEST:
+    return _BEST[n]
+  cands = []
+  if n <= 2:
+    cands.append(_sorted_by(sort_general, n, n))
+  else:
+    cands.append(_sorted_by(sort_general, n, n))
+    p = 1
+    while p < n:
+      p *= 2
+    cands.append(prune(*_batcher(p), p, n))
+    for blocks in (1, 2, 3):
+      if 27 * (blocks - 1) < n <= 27 * blocks:
+        cands.append(_sorted_by(_blocks_of_27, 27 * blocks, n))
+    p3 = 3
+    while p3 < n:
+      p3 *= 3
+    if p3 <= 81:
+      cands.append(_sorted_by(sort3k, p3, n))
+    for a in range(max(1, n // 2 - 6), n // 2 + 1):  # near-even splits
+      oa, ra = best_program(a)
+      ob, rb = best_program(n - a)
+      net = Net()
+      net.ops = list(oa) + [tuple(w + a for w in op) for op in ob]
+      order = merge2(net, list(ra), [w + a for w in rb])
+      # two sorted parts + a merge that is correct on every pair of sorted 0/1
+      # lists of these lengths (0-1 principle) = a sorter
+      assert check_merge_sorted_01(merge2, (a, n - a))
+      cands.append((net.ops, order))
+  _BEST[n] = min(cands, key=lambda c: cost(c[0]))
+  return _BEST[n]
+
+
+def check_program(ops, order, n, rs):
+  x = rs.standard_normal((n, 20000)).astype(np.float32)
+  x[:, :4000] = np.round(x[:, :4000] * 2) / 2        # many ties
+  x[:, 4000:4100] = np.float32(np.inf) * (rs.rand(n, 100) < 0.2)
+  x[np.isnan(x)] = 0
+  assert sorted(order) == list(range(n)), 'order is not a permutation'
+  assert np.array_equal(run(ops, x)[order], np.sort(x, axis=0))
+  if n <= 24:
+    assert check_exhaustive_01(ops, order, n), f'0-1 principle fails, n={n}'
+    return 'all 2^%d 0/1 inputs' % n
+  # larger: 2^22 random 0/1 inputs, bit-sliced, + every sorted-halves input
+  words = rs.randint(0, 2**63, size=(n, 1 << 16), dtype=np.int64).astype(
+      np.uint64)
+  w = [words[i].copy() for i in range(n)]
+  for op in ops:
+    if len(op) == 2:
+      a, b = op
+      w[a], w[b] = w[a] & w[b], w[a] | w[b]
+    else:
+      a, b, c = op
+      x0, y0, z0 = w[a], w[b], w[c]
+      w[a], w[b], w[c] = (x0 & y0 & z0, (x0 & y0) | (x0 & z0) | (y0 & z0),
+                          x0 | y0 | z0)
+  for lo, hi in zip(order, order[1:]):
+    assert not np.any(w[lo] & ~w[hi]), f'0-1 sample fails, n={n}'
+  return '2^22 sampled 0/1 inputs (blocks and merges verified exhaustively)'
+
+
+def emit_exact(path):
+  rs = np.random.RandomState(1)
+  lines = ['// GENERATED by tools/gen_sort3_network.py --emit-exact -- do not edit.',
+           '// Sorting programs from 2-sorters (WB2_S2(a, b): x[a] <= x[b]) and',
+           '// 3-sorters (WB2_S3(a, b, c): v_min3 / v_med3 / v_max3) for the ensemble',
+           '// sizes K3 instantiates with a compile-time member count; rank r ends up',
+           '// in register WB2_SORT3_ORDER_<M>[r], no data is moved.', '']
+  for n in EXACT_SIZES:
+    ops, order = best_program(n)
+    how = check_program(ops, order, n, rs)
+    p = 1
+    while p < n:
+      p *= 2
+    bops, _ = prune(*_batcher(p), p, n)
+    print(f'{n} members: {cost(ops)} instructions '
+          f'({sum(len(o) == 3 for o in ops)} 3-sorters, '
+          f'{sum(len(o) == 2 for o in ops)} 2-sorters); pruned Batcher '
+          f'{cost(bops)}; verified on {how}')
+    lines.append(f'// {n}: {sum(len(o) == 2 for o in ops)} 2-sorters + '
+                 f'{sum(len(o) == 3 for o in ops)} 3-sorters = {cost(ops)} '
+                 f'instructions (pruned Batcher: {cost(bops)})')
+    lines.append(f'#define WB2_SORT3_NETWORK_{n} \\')
+    body = []
+    for i in range(0, len(ops), 6):
+      body.append('  ' + ' '.join(
+          (f'WB2_S2({o[0]},{o[1]})' if len(o) == 2
+           else f'WB2_S3({o[0]},{o[1]},{o[2]})') for o in ops[i:i + 6]))
+    lines.append(' \\\n'.join(body))
+    lines.append(f'#define WB2_SORT3_ORDER_{n} \\')
+    lines.append('  ' + ', '.join(str(r) for r in order))
+    lines.append('')
+  open(path, 'w').write('\n'.join(lines))
+  print('wrote', path)
+
+
+if __name__ == '__main__' and '--emit-exact' in sys.argv:
+  emit_exact(os.path.join(
+      os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+      'weatherbench2_amd', 'csrc', 'sort3_networks.inc'))

@@ -9,7 +9,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
-SOURCES = ('common.cpp', 'comm.cpp', 'stream_reduce.hip', 'ensemble.hip', 'spectrum.hip',
+SOURCES = ('common.cpp', 'comm.cpp', 'stream_reduce.hip', 'ensemble.hip',
+           'ensemble_m10.hip', 'ensemble_m16.hip', 'ensemble_m20.hip',
+           'ensemble_m30.hip', 'ensemble_m32.hip', 'ensemble_m51.hip',
+           'ensemble_m56.hip', 'spectrum.hip',
            'spectrum_fused.hip', 'spatial_maps.hip', 'rank_histogram.hip',
            'axis_reduce.hip')
 
@@ -32,8 +35,9 @@ def needs_rebuild() -> bool:
     return True
   t = os.path.getmtime(LIB_PATH)
   deps = sources() + [os.path.join(CSRC, h) for h in
-                      ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc', 'sort3_network_50.inc',
-                       'fft_core.hpp', 'trace.hpp')
+                      ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc',
+                       'sort3_network_50.inc', 'sort3_networks.inc',
+                       'ensemble_kernels.hpp', 'fft_core.hpp', 'trace.hpp')
                       ] + [os.path.join(ROOT, 'include', 'wb2hip.h')]
   return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -82,7 +86,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     subprocess.run(cmd, check=True)
     return obj
 
-  with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
+  with concurrent.futures.ThreadPoolExecutor(
+      max_workers=min(8, os.cpu_count() or 4)) as pool:
     objs = list(pool.map(compile_one, sources()))
   link = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH
           ] + objs

@@ -1,0 +1,1112 @@
+// K3's device code (templates): included by ensemble.hip (the runtime-M and
+// exact-50 instantiations + the host entry points) and by the per-size
+// translation units ensemble_m<M>.hip (compile-time member counts).
+#pragma once
+
+#include <cstdlib>
+
+#include "common.hpp"
+#include "trace.hpp"
+#include "reduce_common.hpp"
+#include "sort_networks.inc"
+#include "sort3_network_50.inc"
+#include "sort3_networks.inc"
+#include "wb2hip.h"
+
+#include <limits>
+#include <type_traits>
+
+namespace wb2 {
+
+struct EnsParams {
+  const void* ens;
+  const void* truth;
+  const long long* ens_slab;
+  const long long* truth_slab;
+  // gathered ensembles (wb2_ens_partials_gather): device ADDRESS of the slab of
+  // member m at outer index o in member_ptr[o * n_member + m]; NULL = members
+  // at a constant stride from `ens`.  Runtime-M register-sort kernels only.
+  const long long* member_ptr;
+  const double* w_row;
+  const double* w_col;
+  const double* wfield;
+  const int* chunk_row0;
+  const int* chunk_nrow;
+  const int* seg_col0;
+  const int* seg_eoff;
+  double* partials;
+  double* maps;  // optional [6][n_outer][n_row*n_col]: the pointwise values
+  long long member_stride;
+  long long n_outer;
+  int n_member, n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
+};
+
+// Exact float32 instantiations that live in translation units of their own
+// (ensemble_m<M>.hip; the member counts of tools/gen_sort3_network.py's
+// EXACT_SIZES): X(member count, padded register count).
+#define WB2_ENS_EXACT_SIZES(X) \
+  X(10, 16) X(16, 16) X(20, 32) X(30, 32) X(32, 32) X(51, 64) X(56, 64)
+#define WB2_ENS_DECLARE(M, NPAD)                                       \
+  int launch_ens_exact_f32_##M(const EnsParams& p, bool skipna, bool wf, \
+                               hipStream_t stream);
+WB2_ENS_EXACT_SIZES(WB2_ENS_DECLARE)
+#undef WB2_ENS_DECLARE
+
+namespace {
+
+// v_min_f32 / v_max_f32 (NaNs never reach the network: they are replaced first
+// or the result is overridden).
+#ifndef WB2_ENS_ASM_MINMAX
+#define WB2_ENS_ASM_MINMAX 1  // 0: __builtin_fmin/fmax (adds one canonicalize per member)
+#endif
+#ifndef WB2_ENS_NT
+#define WB2_ENS_NT 1  // 1: non-temporal member loads where members are read once
+#endif
+#ifndef WB2_ENS_MAPS_NT_STORES
+#define WB2_ENS_MAPS_NT_STORES 1
+#endif
+#ifndef WB2_ENS_NT_AUX
+#define WB2_ENS_NT_AUX 2  // buffer-load cache policy bits: 1 sc0, 2 nt, 16 sc1
+#endif
+#ifndef WB2_ENS_BUFFER_LOADS
+#define WB2_ENS_BUFFER_LOADS 1  // 0: global loads with a 64-bit VALU address per member
+#endif
+#if WB2_ENS_ASM_MINMAX
+// The instructions themselves: fminf/fmaxf make hipcc canonicalise every loaded
+// value first (a v_max_f32 x, x, x per member) because of signalling NaNs,
+// which this kernel never looks at.
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#else
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
+#endif
+
+// max(|d|, 0): |d|, or 0 when d is NaN (v_max returns the non-NaN operand).
+__device__ __forceinline__ float abs_or_zero(float d) {
+  float r;
+  asm("v_max_f32 %0, |%1|, 0" : "=v"(r) : "v"(d));
+  return r;
+}
+__device__ __forceinline__ double abs_or_zero(double d) {
+  double r;
+  asm("v_max_f64 %0, |%1|, 0" : "=v"(r) : "v"(d));
+  return r;
+}
+
+// Member loads: the M addresses of a grid point differ by a wave-uniform
+// stride, so a raw buffer load (SGPR base per member, one constant per-lane byte
+// offset) needs no vector address arithmetic at all, where a global load costs
+// a 64-bit VALU add per member.
+// ONCE: the caller reads every member exactly once (the register-sort kernel):
+// non-temporal loads, +3.5 % on BASELINE configs[2] (0.488 -> 0.471 ms,
+// profiles/r03_k3_ab8_summary.txt); the multi-pass streaming form re-reads its
+// members from the caches and keeps them cacheable.
+template <typename T, bool ONCE = false>
+__device__ __forceinline__ T member_load(const T* uniform_base, int lane_bytes) {
+#if WB2_ENS_BUFFER_LOADS
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(uniform_base), 0, 0x7fffffff, 0x00020000);
+  // cache policy (gfx940+): bit 1 = nt -- the members are read once
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(
+        T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, 0,
+                                                WB2_ENS_NT && ONCE ? WB2_ENS_NT_AUX : 0));
+  } else {
+    return __builtin_bit_cast(
+        T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, 0,
+                                                WB2_ENS_NT && ONCE ? WB2_ENS_NT_AUX : 0));
+  }
+#else
+  return __builtin_nontemporal_load(
+      reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) +
+                                 lane_bytes));
+#endif
+}
+
+// Sorts x[0..LIMIT) (slots >= LIMIT hold +inf padding and never move: every
+// comparator that touches one of them is a no-op and is pruned at compile time,
+// e.g. 403 instead of 543 comparators for 50 members in the 64-network).
+template <int NPAD, int LIMIT, typename T>
+__device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
+#define WB2_CE(i, j)                    \
+  if constexpr ((j) < LIMIT) {          \
+    const T lo_ = vmin(x[i], x[j]);     \
+    const T hi_ = vmax(x[i], x[j]);     \
+    x[i] = lo_;                         \
+    x[j] = hi_;                         \
+  }
+  if constexpr (NPAD == 2) { WB2_SORT_NETWORK_2 }
+  if constexpr (NPAD == 4) { WB2_SORT_NETWORK_4 }
+  if constexpr (NPAD == 8) { WB2_SORT_NETWORK_8 }
+  if constexpr (NPAD == 16) { WB2_SORT_NETWORK_16 }
+  if constexpr (NPAD == 32) { WB2_SORT_NETWORK_32 }
+  if constexpr (NPAD == 64) { WB2_SORT_NETWORK_64 }
+  if constexpr (NPAD == 128) { WB2_SORT_NETWORK_128 }
+#undef WB2_CE
+}
+
+#ifndef WB2_ENS_SKIPNA_LEAN
+#define WB2_ENS_SKIPNA_LEAN 1  // exact M with skipna: mask-free variance / sort preparation
+#endif
+#ifndef WB2_ENS_DIV_CONST
+#define WB2_ENS_DIV_CONST 1  // compile-time member count: x / M as mul + 2 FMA (exact)
+#endif
+#ifndef WB2_ENS_PAIRED_SPREAD
+#define WB2_ENS_PAIRED_SPREAD 1  // 50 float32 members: rank-weighted sum over (hi, lo) pairs
+#endif
+#ifndef WB2_ENS_PACKED
+// 50 float32 members: t - x, (x - mean)^2 and the rank-weighted sum on member
+// pairs (v_pk_add / mul / fma_f32: 1 007 instead of 1 096 VALU per row).  OFF:
+// measured 1.5 % SLOWER (0.495 against 0.488 ms, profiles/r03_k3_ab8_summary.txt)
+// -- the pairs cost 114 instead of 87 VGPRs (4 instead of 5 waves per SIMD) and
+// the kernel is as close to its HBM limit (256-byte bursts) as to the VALU's.
+#define WB2_ENS_PACKED 0
+#endif
+#ifndef WB2_ENS_SORT3
+#define WB2_ENS_SORT3 1  // 50 float32 members: the 2-/3-sorter program (677 instead of 806 VALU)
+#endif
+__device__ __forceinline__ void sort3_asm(float& a, float& b, float& c) {
+  float lo, mid, hi;
+  asm("v_min3_f32 %0, %3, %4, %5\n\t"
+      "v_med3_f32 %1, %3, %4, %5\n\t"
+      "v_max3_f32 %2, %3, %4, %5"
+      : "=&v"(lo), "=&v"(mid), "=&v"(hi)
+      : "v"(a), "v"(b), "v"(c));
+  a = lo;
+  b = mid;
+  c = hi;
+}
+// Sorting program for exactly 50 float32 values from 2-sorters and 3-sorters
+// (v_min3 / v_med3 / v_max3: three instructions order three values, where three
+// compare-exchanges cost six): two 27-sorters by 3-way odd-even merge sort + one
+// 2-way odd-even merge, pruned for the +inf padding -- 677 instructions instead
+// of the 806 of the pruned Batcher network.  Generated and verified (0-1
+// principle, exhaustively for the 27-sorter and every merge) by
+// tools/gen_sort3_network.py.  The values are never moved: rank r ends up in
+// register kSort3Order50[r].
+constexpr int kSort3Order50[50] = {WB2_SORT3_ORDER_50};
+// Which register a wire of the program lives in is free (the inputs are a set):
+// choose it so that the ranks the paired rank-weighted sum combines sit in
+// (even, odd) register pairs -- ranks (1,2), (3,4), ..., (47,48) in registers
+// (0,1), (2,3), ..., (46,47), ranks 0 and 49 in (48,49) -- and that sum runs on
+// v_pk_add_f32 / v_pk_fma_f32.  of_rank[r]: register of rank r after the sort;
+// reg[w]: register of wire w.
+struct Sort3Layout50 {
+  int reg[50];
+  int of_rank[50];
+  constexpr Sort3Layout50() : reg{}, of_rank{} {
+    for (int r = 0; r < 50; ++r) {
+#if WB2_ENS_PACKED
+      const int q = r == 0 ? 48 : (r == 49 ? 49 : r - 1);
+#else
+      const int q = kSort3Order50[r];
+#endif
+      of_rank[r] = q;
+      reg[kSort3Order50[r]] = q;
+    }
+  }
+};
+constexpr Sort3Layout50 kSort3Layout50{};
+__device__ __forceinline__ void sort3_network_50(float (&x)[64]) {
+#define WB2_R(i) x[kSort3Layout50.reg[i]]
+#define WB2_S2(i, j)                            \
+  {                                             \
+    const float lo_ = vmin(WB2_R(i), WB2_R(j)); \
+    const float hi_ = vmax(WB2_R(i), WB2_R(j)); \
+    WB2_R(i) = lo_;                             \
+    WB2_R(j) = hi_;                             \
+  }
+#define WB2_S3(i, j, k) sort3_asm(WB2_R(i), WB2_R(j), WB2_R(k));
+  WB2_SORT3_NETWORK_50
+#undef WB2_S2
+#undef WB2_S3
+#undef WB2_R
+}
+
+// The same kind of program for the other member counts K3 instantiates exactly
+// (sort3_networks.inc, tools/gen_sort3_network.py --emit-exact): float32 only
+// (there is no v_min3_f64); rank r ends up in register Sort3<M>::order[r].
+template <int M>
+struct Sort3 {
+  static constexpr bool has = false;
+};
+#define WB2_SORT3_DEFINE(M)                                                  \
+  template <>                                                                \
+  struct Sort3<M> {                                                          \
+    static constexpr bool has = true;                                        \
+    static constexpr int order[M] = {WB2_SORT3_ORDER_##M};                   \
+    template <int NPAD>                                                      \
+    static __device__ __forceinline__ void run(float (&x)[NPAD]) {           \
+      WB2_SORT3_NETWORK_##M                                                  \
+    }                                                                        \
+  };
+#define WB2_S2(i, j)                      \
+  {                                       \
+    const float lo_ = vmin(x[i], x[j]);   \
+    const float hi_ = vmax(x[i], x[j]);   \
+    x[i] = lo_;                           \
+    x[j] = hi_;                           \
+  }
+#define WB2_S3(i, j, k) sort3_asm(x[i], x[j], x[k]);
+WB2_SORT3_DEFINE(10)
+WB2_SORT3_DEFINE(16)
+WB2_SORT3_DEFINE(20)
+WB2_SORT3_DEFINE(30)
+WB2_SORT3_DEFINE(32)
+WB2_SORT3_DEFINE(51)
+WB2_SORT3_DEFINE(56)
+#undef WB2_S2
+#undef WB2_S3
+#undef WB2_SORT3_DEFINE
+
+// v * flag for flag in {0, 1} with 0 * inf = 0 * NaN = 0 (v_mul_legacy_f32's
+// DX9 rule) -- a select without a lane mask; float64: a plain select.
+__device__ __forceinline__ float times_flag(float v, float flag) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(flag));
+  return r;
+}
+__device__ __forceinline__ double times_flag(double v, double flag) {
+  return flag != 0.0 ? v : 0.0;
+}
+// min(max(a, 0), 1) as one v_med3
+__device__ __forceinline__ float clamp01(float a) {
+  float r;
+  asm("v_med3_f32 %0, %1, 0, 1.0" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ double clamp01(double a) {
+  return a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
+}
+
+template <typename T>
+__device__ __forceinline__ T sqrt_of(T x);
+template <>
+__device__ __forceinline__ float sqrt_of(float x) { return __builtin_sqrtf(x); }
+template <>
+__device__ __forceinline__ double sqrt_of(double x) { return __builtin_sqrt(x); }
+
+// x / C for a compile-time integer C in float32: Markstein's sequence, one
+// multiply and two FMAs instead of the ten instructions of the IEEE division,
+// with the IDENTICAL (correctly rounded) result: tools/check_div_const.py checks
+// all 2^23 mantissas in integer arithmetic (C = 49, 50 and others).  The proof
+// needs e = x - C q0 exact, i.e. not underflowed; whenever e is not a normal
+// number or zero (tiny x, inf, NaN) the IEEE division runs instead -- behind a
+// real branch (the empty asm keeps hipcc from speculating it).
+template <int C, typename T>
+__device__ __forceinline__ T div_const(T x) {
+  if constexpr (WB2_ENS_DIV_CONST && sizeof(T) == 4) {
+    constexpr float r = 1.0f / (float)C;
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-(float)C, q0, x);
+    // classes: -normal (8), -0 (32), +0 (64), +normal (256)
+    if (__builtin_expect(__builtin_amdgcn_classf(e, 8 | 32 | 64 | 256), 1))
+      return __builtin_fmaf(e, r, q0);
+    asm volatile("" ::: "memory");
+    return x / (float)C;
+  } else {
+    return x / (T)C;
+  }
+}
+
+// One grid point -> the K slot values (see header comment).  MS > 0: the member
+// count is the compile-time constant MS (exact network, no selects); MS == 0:
+// runtime M <= NPAD, slots >= M are neutralised with selects (straight-line code
+// on purpose: per-member branches wreck hipcc's register allocation).
+// REFCHAIN (MS > 0, !SKIPNA): the NaN-free fast path of a SKIPNA kernel -- the
+// rank-weighted sum as the reference's fp64 chain and the final divisions as
+// the skipna form writes them, so that a point's value does not depend on
+// whether its wave took the fast path.
+template <typename T, int NPAD, int MS, bool SKIPNA, bool REFCHAIN = false>
+__device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt,
+                                          double (&out)[SKIPNA ? 10 : 6]) {
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  const T inf = std::numeric_limits<T>::infinity();
+  constexpr int NM = MS > 0 ? MS : NPAD;  // slots visited
+  const int M = MS > 0 ? MS : Mrt;
+  auto live = [&](int m) { return MS > 0 ? true : m < M; };
+  T sum = 0, sk = 0;
+  int n = 0;          // valid members (SKIPNA)
+  bool bad = false;   // any NaN member (!SKIPNA)
+  // Exact member count WITH NaN skipping: the per-member NaN masks are used
+  // where they are made (sum, |t - x|, count) and nowhere else -- kept for the
+  // variance and the sort they cost an SGPR pair per member and phase (spilled
+  // and reloaded through VGPR lanes: 264 v_readlane / v_writelane per row).  The
+  // later phases get mask-free forms with the same values: max(d * d, 0) is d * d
+  // for a valid member and 0 for a NaN one (v_max returns the non-NaN
+  // operand), min(x, +inf) turns a NaN member into the +inf the sort wants.
+  // The one case where d * d is NaN for a VALID member is an infinite member
+  // (inf - inf): then, as before, the sum of squares is NaN.
+  constexpr bool SKIPNA_LEAN = WB2_ENS_SKIPNA_LEAN && SKIPNA && MS > 0;
+  bool inf_member = false;
+  T sq = 0;
+  T mean;
+  if constexpr (MS > 0 && !SKIPNA) {
+    // exact member count without NaN skipping: one unordered compare per member
+    // PAIR finds the NaNs (an odd count's last member alone)
+#pragma unroll
+    for (int m = 0; m + 1 < NM; m += 2) {
+      T d0, d1;
+      if constexpr (WB2_ENS_PACKED && sizeof(T) == 4) {
+        // t - x for a member PAIR as one v_pk_add_f32 (same IEEE results)
+        typedef float F2 __attribute__((ext_vector_type(2)));
+        const F2 xp = {x[m], x[m + 1]}, tt = {t, t};
+        const F2 d = tt - xp;
+        d0 = d[0];
+        d1 = d[1];
+      } else {
+        d0 = t - x[m];
+        d1 = t - x[m + 1];
+      }
+      sum += x[m];
+      sk += abs_of(d0);
+      sum += x[m + 1];
+      sk += abs_of(d1);
+      // (REFCHAIN: the caller has found the whole wave free of NaNs)
+      if constexpr (!REFCHAIN)
+        bad = bad || __builtin_isunordered(x[m], x[m + 1]);
+    }
+    if constexpr (NM % 2 == 1) {
+      sum += x[NM - 1];
+      sk += abs_of(t - x[NM - 1]);
+      if constexpr (!REFCHAIN) bad = bad || is_nan(x[NM - 1]);
+    }
+    // the flag is first needed after the sort: without this pin hipcc sinks the
+    // compares down there and keeps the unsorted ensemble alive next to the
+    // sorted one (131 instead of 87 VGPRs)
+    int pinned = bad ? 1 : 0;
+    asm volatile("" : "+v"(pinned));
+    bad = pinned != 0;
+  } else {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const bool isn = is_nan(x[m]);
+      const bool use = live(m) && (SKIPNA ? !isn : true);
+      sum += use ? x[m] : (T)0;
+      sk += use ? abs_of(t - x[m]) : (T)0;
+      n += use ? 1 : 0;
+      bad = bad || (live(m) && isn);
+      if constexpr (SKIPNA_LEAN) inf_member = inf_member || abs_of(x[m]) == inf;
+    }
+    if constexpr (SKIPNA_LEAN) {
+      // as for `bad` above: everything the sort does not need is finished (and
+      // pinned) before it, or hipcc sinks it below the sort and keeps the
+      // unsorted ensemble alive beside the sorted one
+      int pinned = inf_member ? 1 : 0;
+      asm volatile("" : "+v"(sum), "+v"(sk), "+v"(n), "+v"(pinned));
+      inf_member = pinned != 0;
+    }
+  }
+  const int cnt = SKIPNA ? n : M;
+  // metrics.py:562-565 / :824 -- numpy mean / var(ddof=1) / mean(abs) over the
+  // leading (member) axis: sequential, in the input dtype (nan* variants reduce
+  // over the valid members only).
+  {
+    if constexpr (MS > 0 && !SKIPNA) mean = div_const<MS>(sum);
+    else mean = sum / (T)cnt;
+    if constexpr (WB2_ENS_PACKED && MS > 0 && !SKIPNA && MS % 2 == 0 &&
+                  sizeof(T) == 4) {
+      // (x - mean)^2 for a member pair: v_pk_add_f32 + v_pk_mul_f32, summed in
+      // member order as before
+      typedef float F2 __attribute__((ext_vector_type(2)));
+      const F2 mm = {mean, mean};
+#pragma unroll
+      for (int m = 0; m < NM; m += 2) {
+        const F2 xp = {x[m], x[m + 1]};
+        const F2 d = xp - mm;
+        const F2 q = d * d;
+        sq += q[0];
+        sq += q[1];
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const T d = x[m] - mean;
+        if constexpr (SKIPNA_LEAN) {
+          sq += abs_or_zero(d * d);
+        } else {
+          const bool use = live(m) && (SKIPNA ? !is_nan(x[m]) : true);
+          sq += use ? d * d : (T)0;
+        }
+      }
+      if (SKIPNA_LEAN && inf_member) sq = nan;
+      if constexpr (SKIPNA_LEAN) asm volatile("" : "+v"(sq));
+    }
+    // everything that reads the members in MEMBER order is finished before the
+    // sort starts (or the unsorted ensemble stays alive beside the sorted one)
+    if constexpr (REFCHAIN) asm volatile("" : "+v"(sq), "+v"(sum), "+v"(sk));
+  }
+  T var;
+  if constexpr (MS > 1 && !SKIPNA) var = div_const<MS - 1>(sq);
+  else var = sq / (T)(cnt - 1);
+  if (SKIPNA && cnt <= 1) var = nan;
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  T deb, skill;
+  if constexpr (MS > 0) deb = mse - div_const<MS>(var);
+  else deb = mse - var / (T)M;
+  if constexpr (MS > 0 && !SKIPNA) skill = div_const<MS>(sk);
+  else skill = sk / (T)cnt;
+  if (SKIPNA && is_nan(t)) skill = nan;
+  // metrics.py:804-813: 2 * mean_m((2 r_m - M - 1) x_m) / (M - 1) in fp64; ranks
+  // come from the FULL ensemble with NaN last (np.argsort), so sort with
+  // NaN -> +inf and weight the i-th smallest by 2(i+1) - M - 1.
+  double spread = 0.0;
+  if (M >= 2) {
+#pragma unroll
+    for (int m = 0; m < NPAD; ++m) {
+      if (m >= NM) {
+        x[m] = inf;
+      } else if constexpr (SKIPNA_LEAN) {
+        x[m] = vmin(x[m], inf);  // NaN -> +inf, everything else unchanged
+      } else {
+        x[m] = (!live(m) || (SKIPNA && is_nan(x[m]))) ? inf : x[m];
+      }
+    }
+    double s = 0.0;
+    // NaN skipping: rank m counts while m < n -- as the flag min(max(n - m, 0), 1) and a legacy multiply
+    // (0 * inf = 0) instead of a compare + select per member (51 lane masks
+    // at once do not fit the SGPRs and spill through VGPR lanes)
+    const T nf = (T)n;
+    auto ranked = [&](int m, T xm) {
+      if constexpr (SKIPNA) return times_flag(xm, clamp01(nf - (T)m));
+      else return xm;
+    };
+    if constexpr (WB2_ENS_SORT3 && MS == 50 && NPAD == 64 && sizeof(T) == 4) {
+      sort3_network_50(x);  // rank m lives in register kSort3Order50[m]
+      if constexpr (WB2_ENS_PAIRED_SPREAD && !SKIPNA && !REFCHAIN) {
+        // Ranks H + j and H + 1 - j (H = M / 2) carry the weights +-(2 j - 1):
+        //   sum_r (2 r - M - 1) x_(r) = sum_j (2 j - 1) (x_(H+j) - x_(H+1-j)),
+        // a sum of NON-NEGATIVE terms.  The differences are taken in float32
+        // (exact whenever the two members are within a factor of two, Sterbenz)
+        // and accumulated innermost pair first -- ascending magnitudes -- in two
+        // float32 FMA chains that meet in fp64: 53 instructions instead of the
+        // 100 of the fp64 form below, at most 1.1e-7 (rms 2.5e-8) away from it
+        // on ERA5-like, normal and log-normal ensembles -- the accuracy of one
+        // float32 rounding; the reference evaluates this sum in fp64
+        // (int64 x float32, metrics.py:806-812) and the parity tolerance for
+        // float32 ensembles is 1e-6.  inf / NaN members behave as there:
+        // inf - finite = inf, and inf - inf = NaN exactly when an infinity
+        // receives a non-positive weight.
+        constexpr int H = MS / 2;
+        constexpr auto& R = kSort3Layout50.of_rank;
+        float s0 = 0.0f, s1 = 0.0f;
+        if constexpr (WB2_ENS_PACKED) {
+          // the two chains side by side: j = 2k - 1 in element 0 (s1), j = 2k
+          // in element 1 (s0); the register pairs are the layout's
+          typedef float F2 __attribute__((ext_vector_type(2)));
+          F2 s10 = {0.0f, 0.0f};
+#pragma unroll
+          for (int k = 1; 2 * k <= H; ++k) {
+            const int j = 2 * k - 1;
+            const F2 hi = {x[R[H + j - 1]], x[R[H + j]]};
+            const F2 lo = {x[R[H - j]], x[R[H - j - 1]]};
+            const F2 c = {(float)(2 * j - 1), (float)(2 * j + 1)};
+            s10 = __builtin_elementwise_fma(c, hi - lo, s10);
+          }
+          s1 = s10[0];
+          s0 = s10[1];
+          if constexpr (H & 1) {
+            const float g = x[R[2 * H - 1]] - x[R[0]];
+            s1 = __builtin_fmaf((float)(2 * H - 1), g, s1);
+          }
+        } else {
+#pragma unroll
+          for (int j = 1; j <= H; ++j) {
+            const float g = x[R[H + j - 1]] - x[R[H - j]];
+            if (j & 1) s1 = __builtin_fmaf((float)(2 * j - 1), g, s1);
+            else s0 = __builtin_fmaf((float)(2 * j - 1), g, s0);
+          }
+        }
+        s = (double)s0 + (double)s1;
+      } else {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                            (double)ranked(m, x[kSort3Layout50.of_rank[m]]), s);
+        }
+      }
+    } else if constexpr (WB2_ENS_SORT3 && Sort3<MS>::has && sizeof(T) == 4) {
+      Sort3<MS>::template run<NPAD>(x);  // rank m: register Sort3<MS>::order[m]
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                          (double)ranked(m, x[Sort3<MS>::order[m]]), s);
+      }
+    } else {
+      sort_network<NPAD, NM>(x);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        if constexpr (SKIPNA) {  // n <= M: dead slots are beyond rank n too
+          s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                            (double)ranked(m, x[m]), s);
+        } else {
+          s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                            live(m) ? (double)x[m] : 0.0, s);
+        }
+      }
+    }
+    if constexpr (MS > 0 && !SKIPNA && !REFCHAIN) {
+      // compile-time member count: 2 / (M (M - 1)) is one constant (<= 2 ulp of
+      // fp64 away from the two divisions, far inside the summation noise)
+      spread = s * (2.0 / ((double)MS * (double)(MS - 1)));
+    } else {
+      spread = 2.0 * (s / (double)cnt) / (double)(M - 1);
+    }
+    if (!SKIPNA && bad) spread = (double)nan;  // a NaN member poisons the mean
+  }
+  if constexpr (!SKIPNA) {
+    out[0] = (double)skill;
+    out[1] = spread;
+    out[2] = (double)mse;
+    out[3] = (double)var;
+    out[4] = (double)(sd * sd);
+    out[5] = (double)deb;
+  } else {
+    const bool ok_skill = !is_nan(skill), ok_spread = !is_nan(spread),
+               ok_mse = !is_nan(mse), ok_var = !is_nan(var),
+               ok_deb = !is_nan(deb);
+    out[0] = ok_skill ? (double)skill : 0.0;
+    out[1] = ok_spread ? spread : 0.0;
+    out[2] = ok_mse ? (double)mse : 0.0;
+    out[3] = ok_var ? (double)var : 0.0;
+    out[4] = ok_var ? (double)(sd * sd) : 0.0;
+    out[5] = ok_deb ? (double)deb : 0.0;
+    out[6] = ok_skill ? 1.0 : 0.0;  // == ok_mse (same NaN pattern)
+    out[7] = ok_spread ? 1.0 : 0.0;
+    out[8] = ok_var ? 1.0 : 0.0;
+    out[9] = ok_deb ? 1.0 : 0.0;
+  }
+}
+
+#ifndef WB2_ENS_LEAN_RUNTIME
+#define WB2_ENS_LEAN_RUNTIME 1  // 0: the select-per-member runtime-M path for every case
+#endif
+
+// Runtime member count WITHOUT NaN skipping, lean form.  The caller has set the
+// slots >= M to +inf; the dead slots are a wave-uniform SUFFIX, so the
+// statistics walk the members in groups of four behind wave-uniform branches
+// -- a group inside [0, M) runs without a single select, the group that
+// straddles M takes per-member branches, groups beyond M are skipped -- and
+// the padded network sorts the +inf to the end, where the rank-weighted sum
+// stops.  Same operations in the same order as ens_point's generic path for
+// the M live members (the select-per-member form cost six v_cndmask per member
+// and kept a lane mask per member and phase in SGPRs: 0.26-0.50 of the HBM
+// peak against 0.76 for the exact-50 kernel).
+template <typename T, int NPAD>
+__device__ __forceinline__ void ens_point_runtime(T (&x)[NPAD], const T t,
+                                                  const int M,
+                                                  double (&out)[6]) {
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  T sum = 0, sk = 0, sq = 0;
+  bool bad = false;
+  constexpr int G = 4;
+  static_assert(NPAD % G == 0, "padded sizes are multiples of 4");
+#pragma unroll
+  for (int g = 0; g < NPAD; g += G) {
+    if (g < M) {  // wave-uniform
+      if (g + G <= M) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          sum += x[g + u];
+          sk += abs_of(t - x[g + u]);
+        }
+        bad = bad || __builtin_isunordered(x[g], x[g + 1]) ||
+              __builtin_isunordered(x[g + 2], x[g + 3]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (g + u < M) {
+            sum += x[g + u];
+            sk += abs_of(t - x[g + u]);
+            bad = bad || is_nan(x[g + u]);
+          }
+        }
+      }
+    }
+  }
+  // metrics.py:562-565 / :824 -- numpy mean / var(ddof=1) / mean(abs) over the
+  // leading (member) axis: sequential, in the input dtype
+  const T mean = sum / (T)M;
+#pragma unroll
+  for (int g = 0; g < NPAD; g += G) {
+    if (g < M) {
+      if (g + G <= M) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const T d = x[g + u] - mean;
+          sq += d * d;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (g + u < M) {
+            const T d = x[g + u] - mean;
+            sq += d * d;
+          }
+        }
+      }
+    }
+  }
+  const T var = sq / (T)(M - 1);
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  const T deb = mse - var / (T)M;
+  const T skill = sk / (T)M;
+  // metrics.py:804-813: ranks from the full ensemble; the +inf padding sorts
+  // behind every live member (a NaN member poisons the result: `bad`)
+  double spread = 0.0;
+  if (M >= 2) {
+    sort_network<NPAD, NPAD>(x);
+    double s = 0.0;
+    const int c0 = -M - 1;  // weight of rank r (0-based): 2 (r + 1) - M - 1
+#pragma unroll
+    for (int g = 0; g < NPAD; g += G) {
+      if (g < M) {
+        if (g + G <= M) {
+#pragma unroll
+          for (int u = 0; u < G; ++u)
+            s = __builtin_fma((double)(2 * (g + u + 1) + c0), (double)x[g + u],
+                              s);
+        } else {
+#pragma unroll
+          for (int u = 0; u < G; ++u)
+            if (g + u < M)
+              s = __builtin_fma((double)(2 * (g + u + 1) + c0),
+                                (double)x[g + u], s);
+        }
+      }
+    }
+    spread = 2.0 * (s / (double)M) / (double)(M - 1);
+    if (bad) spread = (double)nan;  // a NaN member poisons the mean
+  }
+  out[0] = (double)skill;
+  out[1] = spread;
+  out[2] = (double)mse;
+  out[3] = (double)var;
+  out[4] = (double)(sd * sd);
+  out[5] = (double)deb;
+}
+
+#ifndef WB2_ENS_MIN_WAVES
+#define WB2_ENS_MIN_WAVES 1
+#endif
+
+// Ensembles too large for the register sort (M > 128 float32 / 64 float64):
+// the same six values from three streaming passes over the members (cache
+// resident after the first) -- no sort at all.  The rank-weighted sum is
+//   sum_i (2 r_i - M - 1) x_i = P - (M - n) * sum_valid x_i,
+//   P = sum_{i<j valid} |x_i - x_j|     (r: ranks in the full ensemble, NaN last)
+// and P is accumulated blockwise: 32 members in VGPRs against every later
+// member.  max(|d|, 0) drops the pairs that involve a NaN member (v_max returns
+// the non-NaN operand) and the padding of the last block alike; without skipna
+// a NaN member makes the result NaN, as in ens_point.
+template <typename T, bool SKIPNA>
+__device__ __forceinline__ void ens_point_large(
+    const T* xrow, long long member_stride, int lane_bytes, const int M,
+    const T t, double (&out)[SKIPNA ? 10 : 6]) {
+  constexpr int B = 32;
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  T sum = 0, sk = 0;
+  double sx = 0.0;  // fp64 sum of the valid members (rank correction term)
+  int n = 0;
+  bool bad = false;
+#pragma unroll 4
+  for (int m = 0; m < M; ++m) {
+    const T x = member_load<T>(xrow + m * member_stride, lane_bytes);
+    const bool isn = is_nan(x);
+    const bool use = SKIPNA ? !isn : true;
+    sum += use ? x : (T)0;
+    sk += use ? abs_of(t - x) : (T)0;
+    if constexpr (SKIPNA) sx += use ? (double)x : 0.0;
+    n += use ? 1 : 0;
+    bad = bad || isn;
+  }
+  const int cnt = SKIPNA ? n : M;
+  const T mean = sum / (T)cnt;
+  T sq = 0;
+#pragma unroll 4
+  for (int m = 0; m < M; ++m) {
+    const T x = member_load<T>(xrow + m * member_stride, lane_bytes);
+    const bool use = SKIPNA ? !is_nan(x) : true;
+    const T d = x - mean;
+    sq += use ? d * d : (T)0;
+  }
+  T var = sq / (T)(cnt - 1);
+  if (SKIPNA && cnt <= 1) var = nan;
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  const T deb = mse - var / (T)M;
+  T skill = sk / (T)cnt;
+  if (SKIPNA && is_nan(t)) skill = nan;
+
+  double pairs = 0.0;  // P
+  for (int a0 = 0; a0 < M; a0 += B) {
+    T xa[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int m = a0 + i < M ? a0 + i : M - 1;  // wave-uniform clamp
+      const T x = member_load<T>(xrow + m * member_stride, lane_bytes);
+      xa[i] = a0 + i < M ? x : nan;
+    }
+    // pairs inside the block: the full B x B table counts each one twice
+    double own = 0.0;
+    const int a1 = a0 + B < M ? a0 + B : M;
+    for (int b = a0; b < a1; ++b) {
+      const T xb = member_load<T>(xrow + b * member_stride, lane_bytes);
+      T acc = 0;
+#pragma unroll
+      for (int i = 0; i < B; ++i) acc += abs_or_zero(xa[i] - xb);
+      own += (double)acc;
+    }
+    double cross = 0.0;
+    for (int b = a1; b < M; ++b) {
+      const T xb = member_load<T>(xrow + b * member_stride, lane_bytes);
+      T acc = 0;
+#pragma unroll
+      for (int i = 0; i < B; ++i) acc += abs_or_zero(xa[i] - xb);
+      cross += (double)acc;
+    }
+    pairs += 0.5 * own + cross;
+  }
+  double spread = 0.0;
+  if (M >= 2) {
+    const double s = pairs - (SKIPNA ? (double)(M - n) * sx : 0.0);
+    spread = 2.0 * (s / (double)cnt) / (double)(M - 1);
+    if (!SKIPNA && bad) spread = (double)nan;
+  }
+  if constexpr (!SKIPNA) {
+    out[0] = (double)skill;
+    out[1] = spread;
+    out[2] = (double)mse;
+    out[3] = (double)var;
+    out[4] = (double)(sd * sd);
+    out[5] = (double)deb;
+  } else {
+    const bool ok_skill = !is_nan(skill), ok_spread = !is_nan(spread),
+               ok_mse = !is_nan(mse), ok_var = !is_nan(var),
+               ok_deb = !is_nan(deb);
+    out[0] = ok_skill ? (double)skill : 0.0;
+    out[1] = ok_spread ? spread : 0.0;
+    out[2] = ok_mse ? (double)mse : 0.0;
+    out[3] = ok_var ? (double)var : 0.0;
+    out[4] = ok_var ? (double)(sd * sd) : 0.0;
+    out[5] = ok_deb ? (double)deb : 0.0;
+    out[6] = ok_skill ? 1.0 : 0.0;
+    out[7] = ok_spread ? 1.0 : 0.0;
+    out[8] = ok_var ? 1.0 : 0.0;
+    out[9] = ok_deb ? 1.0 : 0.0;
+  }
+}
+
+#ifndef WB2_ENS_SKIPNA_FAST
+#define WB2_ENS_SKIPNA_FAST 1  // exact M with skipna: NaN-free waves skip the selects
+#endif
+#ifndef WB2_ENS_WG_WAVES
+// waves per workgroup (independent waves: the workgroup is only a scheduling
+// unit).  2 instead of 4: +1 % with non-temporal loads (r03_k3_ab10_summary.txt)
+#define WB2_ENS_WG_WAVES 2
+#endif
+
+#ifndef WB2_ENS_SKIPNA_MIN_WAVES
+#define WB2_ENS_SKIPNA_MIN_WAVES 1
+#endif
+
+template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
+__global__ void __launch_bounds__(
+    256, (SKIPNA && MS > 1 && sizeof(T) == 4) ? WB2_ENS_SKIPNA_MIN_WAVES
+                                               : WB2_ENS_MIN_WAVES)
+    ens_partials_kernel(const EnsParams p) {
+  constexpr int K = SKIPNA ? 10 : 6, NWF = WF ? 2 : 1;
+  constexpr int NM = MS > 0 ? MS : NPAD;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int nwave = blockDim.x / kWave;
+  const unsigned bx = blockIdx.x;
+  const unsigned tblk = bx / (unsigned)p.n_chunk;
+  const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
+  const long long o = (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  const int tile = (int)tblk * nwave + wave;
+
+  const int row0 = p.chunk_row0[chunk];
+  const int nrow = p.chunk_nrow[chunk];
+  const long long* dummy = reinterpret_cast<const long long*>(p.chunk_row0);
+  const bool o_ok = o < p.n_outer;  // the (y, z) grid may overshoot n_outer
+  const long long es_v =
+      (p.ens_slab ? p.ens_slab : dummy)[(p.ens_slab && o_ok) ? o : 0];
+  const long long ts_v =
+      (p.truth_slab ? p.truth_slab : dummy)[(p.truth_slab && o_ok) ? o : 0];
+  const long long es = p.ens_slab ? es_v : o, ts = p.truth_slab ? ts_v : o;
+  const int col0 = tile * kWave + lane;
+  const bool active = tile < p.n_ctile && col0 < p.n_col;
+  if (nrow <= 0 || tile >= p.n_ctile || !o_ok) return;
+  const int M = MS > 0 ? MS : p.n_member;
+
+  double acc[NWF][1][K];
+#pragma unroll
+  for (int w = 0; w < NWF; ++w)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[w][0][k] = 0.0;
+
+  // gathered members: lane l keeps the slab address of member j * 64 + l in
+  // a VGPR pair (ONE vector load per wave; indices >= M repeat the last
+  // member, like the strided form); the row loop takes member m's address
+  // out of lane m with two v_readlane -- scalar loads inside the loop would
+  // each be a dependent round trip (measured: 6 x slower).  Loaded by EVERY
+  // lane (in a row-end tile lane m may own no column; the row loop below runs
+  // in wave-uniform control flow for the same reason).
+  constexpr int NMP = (MS == 0 && NPAD > 0) ? (NPAD + kWave - 1) / kWave : 1;
+  unsigned mp_lo[NMP], mp_hi[NMP];
+  const bool gathered = MS == 0 && NPAD > 0 && p.member_ptr != nullptr;
+  if constexpr (MS == 0 && NPAD > 0) {
+#pragma unroll
+    for (int j = 0; j < NMP; ++j) {
+      mp_lo[j] = mp_hi[j] = 0;
+      if (gathered) {
+        const int mi = j * kWave + lane;
+        const unsigned long long a = (unsigned long long)
+            p.member_ptr[o * (long long)M + (mi < M ? mi : M - 1)];
+        mp_lo[j] = (unsigned)a;
+        mp_hi[j] = (unsigned)(a >> 32);
+      }
+      // (side-effecting: keeps the load from being sunk into the branch below)
+      asm volatile("" : "+v"(mp_lo[j]), "+v"(mp_hi[j]));
+    }
+  }
+  // EVERY lane of the wave walks the rows: a lane past the end of the row (the
+  // last column tile of a row whose length is no multiple of 64) reads the
+  // row's last column again and its sums are dropped afterwards.  Control flow
+  // stays wave-uniform, so the v_readlane of the gathered member addresses
+  // (which ignore EXEC) can never meet a register copy made under a partial
+  // EXEC mask.
+  const int colc = active ? col0 : p.n_col - 1;
+  {
+    const long long slab_elems = (long long)p.n_row * p.n_col;
+    // wave-uniform row base (SGPRs) + this lane's byte offset inside the row
+    const T* xrow0 = static_cast<const T*>(p.ens) + es * slab_elems +
+                     (long long)row0 * p.n_col;
+    const int lane_bytes = colc * (int)sizeof(T);
+    const T* tb = static_cast<const T*>(p.truth) + ts * slab_elems +
+                  (long long)row0 * p.n_col + colc;
+    const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + colc
+                           : nullptr;
+    // One row of the chunk.  PASS 0: the whole job (every kernel but the exact
+    // skipna ones).  Exact member count WITH NaN skipping: PASS 1 does the row
+    // when the wave holds no NaN at all -- the select-free code of the
+    // no-skipna kernel (fp64 rank chain, the skipna form's divisions: the same
+    // bits as the general code gives for NaN-free points) -- and returns true
+    // otherwise; PASS 2 does such a row with the general code.  NaNs come in
+    // patches (a masked variable, a missing field): most waves hold none.
+    auto row = [&](const int r, auto pass_tag) -> bool {
+      constexpr int PASS = decltype(pass_tag)::value;
+      const long long off = (long long)r * p.n_col;
+      const T* xrow = xrow0 + off;
+      const T t = __builtin_nontemporal_load(tb + off);
+      const double wr = p.w_row[row0 + r];
+      double wf = 1.0;
+      if constexpr (WF) wf = wfp[off];
+      double v[K];
+      if constexpr (NPAD == 0) {  // any M: streaming passes, no sort
+        ens_point_large<T, SKIPNA>(xrow, p.member_stride, lane_bytes, M, t, v);
+      } else {
+        T x[NPAD];
+        // Runtime M: everything about the member bases is row-invariant, and
+        // hipcc hoists all NPAD of them out of the row loop (64-bit pairs in
+        // SGPRs: 192-468 dwords of SGPR spills).  The stride / the address
+        // lanes are made opaque once per row instead, and the base advances
+        // member by member.
+        long long stride_r = p.member_stride;
+        int Mr = M;  // runtime M, opaque per row: the per-member `m < M` lane
+                     // masks are recomputed (scalar compares) instead of being
+                     // kept in SGPR pairs across the whole row loop
+        if constexpr (MS == 0) {
+          asm volatile("" : "+s"(Mr));
+          asm volatile("" : "+s"(stride_r));
+#pragma unroll
+          for (int j = 0; j < NMP; ++j)
+            asm volatile("" : "+v"(mp_lo[j]), "+v"(mp_hi[j]));
+        }
+        const T* mb = xrow;
+#pragma unroll
+        for (int m = 0; m < NPAD; ++m) {
+          if (m < NM) {
+            const T* mrow;
+            if constexpr (MS > 0) {
+              mrow = xrow + m * p.member_stride;
+            } else {
+              // slots >= M read member 0 again (cache hit; replaced by +inf or
+              // ignored); the base itself advances unconditionally -- a select
+              // inside the chain made every load wait for 5 dependent scalar
+              // instructions per member before it
+              mrow = m < Mr ? mb : xrow;
+              if (gathered) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(
+                    (int)mp_lo[m / kWave], m % kWave);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane(
+                    (int)mp_hi[m / kWave], m % kWave);
+                mrow = reinterpret_cast<const T*>(
+                           ((unsigned long long)hi << 32) | lo) +
+                       (long long)(row0 + r) * p.n_col;
+              }
+              mb += stride_r;
+            }
+            x[m] = member_load<T, true>(mrow, lane_bytes);
+          } else {
+            x[m] = (T)0;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WB2_ENS_LEAN_RUNTIME && MS == 0 && !SKIPNA) {
+          // dead slots (a wave-uniform suffix) become +inf ONCE, here
+#pragma unroll
+          for (int m = 0; m < NPAD; ++m)
+            x[m] = m < Mr ? x[m] : std::numeric_limits<T>::infinity();
+          ens_point_runtime<T, NPAD>(x, t, Mr, v);
+        } else if constexpr (PASS == 1) {
+          bool dirty = is_nan(t);
+#pragma unroll
+          for (int m = 0; m + 1 < NM; m += 2)
+            dirty = dirty || __builtin_isunordered(x[m], x[m + 1]);
+          if constexpr (NM % 2 == 1) dirty = dirty || is_nan(x[NM - 1]);
+          if (__builtin_amdgcn_ballot_w64(dirty) != 0) return true;
+          double q[6];
+          ens_point<T, NPAD, MS, false, true>(x, t, Mr, q);
+          const bool ok_skill = !is_nan(q[0]), ok_spread = !is_nan(q[1]),
+                     ok_mse = !is_nan(q[2]), ok_var = !is_nan(q[3]),
+                     ok_deb = !is_nan(q[5]);
+          v[0] = ok_skill ? q[0] : 0.0;
+          v[1] = ok_spread ? q[1] : 0.0;
+          v[2] = ok_mse ? q[2] : 0.0;
+          v[3] = ok_var ? q[3] : 0.0;
+          v[4] = ok_var ? q[4] : 0.0;
+          v[5] = ok_deb ? q[5] : 0.0;
+          v[K - 4] = ok_skill ? 1.0 : 0.0;
+          v[K - 3] = ok_spread ? 1.0 : 0.0;
+          v[K - 2] = ok_var ? 1.0 : 0.0;
+          v[K - 1] = ok_deb ? 1.0 : 0.0;
+        } else {
+          ens_point<T, NPAD, MS, SKIPNA>(x, t, Mr, v);
+        }
+      }
+      if (p.maps && active) {
+        // Spatial* metrics (metrics.py:718-772, 1244-1266, 1366-1399): the
+        // pointwise values themselves; with SKIPNA slots 6.. flag the NaNs.
+        const long long at = o * slab_elems + (long long)(row0 + r) * p.n_col +
+                             col0;
+        const long long plane = p.n_outer * slab_elems;
+        const double qnan = __builtin_nan("");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double out_v = v[k];
+          if constexpr (SKIPNA) {
+            constexpr int flag[6] = {6, 7, 6, 8, 8, 9};
+            out_v = v[flag[k]] != 0.0 ? v[k] : qnan;
+          }
+          if (WB2_ENS_MAPS_NT_STORES)
+            __builtin_nontemporal_store(out_v, p.maps + k * plane + at);
+          else
+            p.maps[k * plane + at] = out_v;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        acc[0][0][k] = __builtin_fma(wr, v[k], acc[0][0][k]);
+      if constexpr (WF) {
+        const bool inside = wf > 0.0;
+        const double w2 = inside ? wr * wf : 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          acc[1][0][k] = __builtin_fma(w2, inside ? v[k] : 0.0, acc[1][0][k]);
+      }
+      return false;
+    };
+    constexpr bool TWO_PASS =
+        WB2_ENS_SKIPNA_FAST && SKIPNA && MS > 1 && NPAD > 0;
+    if constexpr (TWO_PASS) {
+      // rows with a NaN somewhere in the wave wait for a loop of their own:
+      // two loops, two register allocations -- the NaN-free rows are not held
+      // to the general code's register needs inside one loop body (and the
+      // general code of PASS 0 is not instantiated at all: it would set the
+      // kernel's register count).  64 rows at a time: one bit per row.
+      for (int r0 = 0; r0 < nrow; r0 += 64) {
+        const int r1 = r0 + 64 < nrow ? r0 + 64 : nrow;
+        unsigned long long todo = 0;
+#pragma clang loop unroll(disable)
+        for (int r = r0; r < r1; ++r)
+          if (row(r, std::integral_constant<int, 1>{}))
+            todo |= 1ull << (r - r0);
+#pragma clang loop unroll(disable)
+        for (int r = r0; r < r1; ++r)
+          if ((todo >> (r - r0)) & 1) row(r, std::integral_constant<int, 2>{});
+      }
+    } else {
+#pragma clang loop unroll(disable)
+      for (int r = 0; r < nrow; ++r) row(r, std::integral_constant<int, 0>{});
+    }
+    if (p.w_col) {
+      const double wc = p.w_col[colc];
+#pragma unroll
+      for (int w = 0; w < NWF; ++w)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[w][0][k] *= wc;
+    }
+    if (!active) {
+#pragma unroll
+      for (int w = 0; w < NWF; ++w)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[w][0][k] = 0.0;
+    }
+  }
+  fold_tile_to_segs<NWF, 1, K>(
+      acc, lane, tile, col0, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg,
+      p.n_ts,
+      p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * K));
+}
+
+template <typename T, int NPAD, int MS>
+int launch_ens(const EnsParams& p, bool skipna, bool wf, hipStream_t stream) {
+  int nwave = p.n_ctile < WB2_ENS_WG_WAVES ? p.n_ctile : WB2_ENS_WG_WAVES;
+  const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
+  const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
+  const long long gz = (p.n_outer + gy - 1) / gy;
+  const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
+  const dim3 block(nwave * kWave);
+#define WB2_L(S, W)                                                            \
+  hipLaunchKernelGGL((ens_partials_kernel<T, NPAD, MS, S, W>), grid, block, 0, \
+                     stream, p)
+  if (skipna) {
+    if (wf) WB2_L(true, true); else WB2_L(true, false);
+  } else {
+    if (wf) WB2_L(false, true); else WB2_L(false, false);
+  }
+#undef WB2_L
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+}  // namespace wb2
