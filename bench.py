@@ -101,23 +101,6 @@ def predefined_regions():
   }
 
 
-def measured_traffic(workload: str, **match):
-  """HBM bytes per launch of the dominant kernel as measured EARLIER with
-  rocprofv3 PMC counters for exactly this launch size (profiles/*pmc_traffic*,
-  not collected in this run), or None when the run uses a different
-  configuration."""
-  for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json',
-               'r01_pmc_traffic.json'):
-    try:
-      table = json.load(open(os.path.join(ROOT, 'profiles', name)))
-      entry = table[workload]
-      if all(entry.get(k) == v for k, v in match.items()):
-        return entry['traffic_bytes']
-    except (OSError, KeyError, ValueError):
-      pass
-  return None
-
-
 def ramp(step_fn, ms: float) -> None:
   """Untimed clock ramp: the same step, enqueued back to back for `ms` of wall
   time before the W warmup steps, WITHOUT draining the queue (the host only
@@ -270,7 +253,8 @@ def parse_args():
                        'instead of hanging')
   ap.add_argument('--traffic-probe', nargs='?', const='deterministic',
                   default=None,
-                  choices=['deterministic', 'official16_landmask', 'skipna'],
+                  choices=['deterministic', 'official16_landmask', 'skipna',
+                           'all'],
                   help='(tools/live_traffic.py) only run a few launches of the '
                        'benched K1 configuration -- or of one of its variants '
                        '-- for the PMC passes')
@@ -491,12 +475,18 @@ def main():
   if args.traffic_probe:
     # tools/live_traffic.py: a few launches of exactly the benched K1
     # configuration (or one variant of it) under rocprofv3 --pmc, nothing else
-    if args.traffic_probe == 'deterministic':
+    if args.traffic_probe in ('deterministic', 'all'):
       for i in range(6):
         step(args.warmup + i % max(args.steps, 1), False)
+      if args.traffic_probe == 'all':
+        # the dominant kernels of the other legs, same process, same passes
+        for workload in ('ensemble', 'spectrum', 'spectrum_materialized',
+                         'spectrum_mean'):
+          secondary(workload, 5, 1, 0.0, args.members, 0)
+          torch.cuda.empty_cache()
     else:
       k1_variants(dev, fpool, tpool, cpool, units, pool, steps=6,
-                  only=args.traffic_probe)
+                  only=args.traffic_probe, reps=1)
     torch.cuda.synchronize()
     return
 
@@ -602,10 +592,8 @@ def main():
           'kernel_ms': k1_avg_s * 1e3,
           'kernel_ms_samples': len(k1_ms),
           'algorithmic_bytes_per_launch': pts_step * BYTES_PER_PT,
-          'traffic': measured_traffic('deterministic', units_per_launch=units,
-                                      regions=nr),
-          'traffic_source': ('rocprofv3 FETCH_SIZE of an earlier run of this '
-                             'launch size (profiles/), not collected now'),
+          # HBM bytes per launch from PMC counters: collected below, live
+          'traffic': None,
       },
   }
 
@@ -644,21 +632,34 @@ def main():
   if rank == 0 and world == 1 and not args.no_secondary:
     # ---- BASELINE configs[2] / configs[3] and K1's production variants, each
     # with its own roofline; bounded step counts keep the whole line in minutes
-    legs = (('ensemble', 'ensemble', 40), ('spectrum', 'spectrum', 100),
-            ('spectrum/materialized', 'spectrum_materialized', 60),
-            ('spectrum/time_mean', 'spectrum_mean', 60))
-    for key, workload, n in legs:
-      try:
-        leg = secondary(workload, n, 5, 20.0, args.members, 0)
-      except Exception as e:  # never lose the GPU line to a secondary leg
-        leg = {'error': f'{type(e).__name__}: {e}'}
+    legs = (('ensemble', 'ensemble', 20), ('spectrum', 'spectrum', 40),
+            ('spectrum/materialized', 'spectrum_materialized', 30),
+            ('spectrum/time_mean', 'spectrum_mean', 30))
+    # three repetitions, the legs interleaved; the line carries the repetition
+    # with the median kernel time and the min / max fraction over all three
+    runs = {key: [] for key, _, _ in legs}
+    for _ in range(3):
+      for key, workload, n in legs:
+        try:
+          leg = secondary(workload, n, 5, 20.0, args.members, 0)
+        except Exception as e:  # never lose the GPU line to a secondary leg
+          leg = {'error': f'{type(e).__name__}: {e}'}
+        runs[key].append(leg)
+        torch.cuda.empty_cache()
+    for key, _, _ in legs:
+      good = sorted((r for r in runs[key] if 'roofline' in r),
+                    key=lambda r: r['roofline']['kernel_ms'])
+      leg = good[len(good) // 2] if good else runs[key][-1]
       leg = {k: leg[k] for k in ('value', 'unit', 'steps', 'ms_per_step',
                                  'config', 'roofline', 'error') if k in leg}
+      if good:
+        leg['roofline'].update(
+            frac_min=good[-1]['roofline']['frac'],
+            frac_max=good[0]['roofline']['frac'], repetitions=len(good))
       if '/' in key:
         out.setdefault('spectrum', {})[key.split('/')[1]] = leg
       else:
         out[key] = leg
-      torch.cuda.empty_cache()
     try:
       out['variants'] = k1_variants(dev, fpool, tpool, cpool, units, pool)
     except Exception as e:
@@ -680,18 +681,27 @@ def main():
     # ---- roofline.traffic, live: the PMC passes run in child processes under
     # rocprofv3 (their own 7.8 GB pools; 288 GB of HBM hold both)
     live = live_traffic(units, pool, args.rows_per_chunk)
-    if live.get('traffic_bytes'):
-      out['roofline'].update(
-          traffic=live['traffic_bytes'],
-          traffic_over_algorithmic=live['traffic_bytes'] / (
-              pts_step * BYTES_PER_PT),
-          traffic_source=('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate '
-                          'passes, --kernel-trace only) around this launch '
-                          'configuration, collected by this run: '
-                          'tools/live_traffic.py'),
-          traffic_detail=live)
-    else:
-      out['roofline']['traffic_live_error'] = live.get('error', 'unavailable')
+    source = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, '
+              '--kernel-trace only) around this launch configuration, '
+              'collected by this run: tools/live_traffic.py')
+    legs = {'deterministic': out.get('roofline'),
+            'ensemble': (out.get('ensemble') or {}).get('roofline'),
+            'spectrum': (out.get('spectrum') or {}).get('roofline'),
+            'spectrum_materialized': ((out.get('spectrum') or {}).get(
+                'materialized') or {}).get('roofline'),
+            'spectrum_mean': ((out.get('spectrum') or {}).get(
+                'time_mean') or {}).get('roofline')}
+    for name, roof in legs.items():
+      if roof is None:
+        continue
+      got = live.get(name) if 'error' not in live else None
+      if got and got.get('traffic_bytes'):
+        roof.update(traffic=got['traffic_bytes'],
+                    traffic_over_algorithmic=got['traffic_bytes'] /
+                    roof['algorithmic_bytes_per_launch'],
+                    traffic_source=source, traffic_detail=got)
+      else:
+        roof['traffic_live_error'] = live.get('error', 'unavailable')
   if rank == 0:
     if world == 1 and not args.no_cpu_baseline:
       try:
@@ -998,13 +1008,11 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
     if args.workload == 'spectrum_mean':
       bytes_per_pt = 4.0 + n_bins * 8.0 / N_LON / units
     if args.workload == 'spectrum':
-      # fused latitude mean: 4 B/pt read + one partial spectrum per (field,
-      # latitude segment) written and re-read by the combine step
-      from weatherbench2_amd import _lib as _l
-      handle, _ = engine._SPECTRUM_PLANS.get(_l.WB2_F32, N_LON,
-                                             units * N_LEV * N_LAT)
-      n_seg = _l.load().wb2_zonal_spectrum_latmean_segments(handle, N_LAT)
-      bytes_per_pt = 4.0 + 2.0 * n_seg * n_bins * 8.0 / (N_LAT * N_LON)
+      # fused latitude mean, SURVEY 8d strictly: 4 B/pt read + the ONE reduced
+      # 721-bin float64 spectrum per field.  The per-segment partial spectra
+      # the two-step reduction writes and re-reads are scratch: they show up
+      # in `traffic` (1.04 x), not here
+      bytes_per_pt = 4.0 + n_bins * 8.0 / (N_LAT * N_LON)
 
     def step(i, timed):
       xs = x[(i % pool) * units:(i % pool + 1) * units]
@@ -1087,16 +1095,9 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
                    'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBPS, 'kernel_ms': k_s * 1e3,
                    'algorithmic_bytes_per_launch': pts * bytes_per_pt,
-                   'traffic': (measured_traffic('ensemble', slabs_per_launch=13,
-                                                members=args.members)
-                               if args.workload == 'ensemble' else
-                               measured_traffic(
-                                   {'spectrum_materialized': 'spectrum',
-                                    'spectrum': 'spectrum_latmean'}.get(
-                                        args.workload, args.workload),
-                                   units_per_launch=args.spectrum_units)),
-                   'traffic_source': 'rocprofv3 PMC of an earlier run of this '
-                                     'launch size (profiles/)'}}
+                   # filled in by the default line from PMC counters
+                   # collected in the same run (tools/live_traffic.py)
+                   'traffic': None}}
 
 
 def land_sea_mask(rs, lat, lon):
@@ -1133,7 +1134,7 @@ def official_regions():
 
 
 def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
-                only=None, with_headline=False, rows=0) -> dict:
+                only=None, with_headline=False, rows=0, reps=3) -> dict:
   """Kernel time + fraction of the HBM peak of K1's OTHER production
   instantiations (the headline is MODE_DET_ACC / float32 / 13 slice regions /
   no skipna), same launch size (16 units of 13 x 721 x 1440), same pools:
@@ -1161,9 +1162,7 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
     return [(((u * (2 * j + 1) + 3 * j) % pool_units)[:, None] * N_LEV
              + lev[None]).reshape(-1).contiguous() for j in range(k)]
 
-  def run(name, pl, mode, inputs, pool_units, skipna, bytes_per_pt, what):
-    if only is not None and only != name:
-      return None
+  def run(pl, mode, inputs, pool_units, skipna):
     timer = KernelTimer()
     k = len(inputs)
     tables = [tabs(s_, pool_units, k) for s_ in range(steps + 3)]
@@ -1178,72 +1177,84 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
       engine.stream_reduce(pl, mode, inputs, tables[3 + i], n_outer, skipna)
     engine.set_launch_hook(None)
     torch.cuda.synchronize()
-    ms = timer.mean_ms()
-    nbytes = units * PTS_PER_UNIT * bytes_per_pt
-    return {'what': what, 'kernel_ms': ms,
-            'algorithmic_bytes_per_launch': nbytes,
-            'achieved': nbytes / ms / 1e6, 'unit': 'GB/s',
-            'frac': nbytes / ms / 1e6 / HBM_PEAK_GBPS,
-            'regions': pl.n_region, 'rows_per_chunk': rows,
-            'weight_field': pl.wfield is not None}
+    return timer.mean_ms()
 
-  out = {}
   pl13 = plan_lib.build_plan(lat, lon, plan_lib.LATLON, predefined_regions(),
                              dev, rows_per_chunk=rows)
   pl16 = plan_lib.build_plan(lat, lon, plan_lib.LATLON, official_regions(), dev,
                              rows_per_chunk=rows)
-  f32 = [fpool, tpool, cpool]
-  if with_headline:  # the benched instantiation beside its variants (A/B runs)
-    out['headline'] = run('headline', pl13, _lib.MODE_DET_ACC, f32, pool, False,
-                          12.0, 'MODE_DET_ACC f32, 13 regions (the benched one)')
-  out['official16_landmask'] = run(
-      'official16_landmask', pl16, _lib.MODE_DET_ACC, f32, pool, False, 12.0,
-      'MODE_DET_ACC f32, the 16 regions of scripts/evaluate.py:345-395 incl. '
-      'global_land / extra-tropics_land / tropics_land (2-D mask: WF = true)')
-  out['skipna'] = run(
-      'skipna', pl13, _lib.MODE_DET_ACC, f32, pool, True, 12.0,
-      'MODE_DET_ACC f32, 13 regions, skipna = True (K = 10 slots)')
-  out['det_no_acc'] = run(
-      'det_no_acc', pl13, _lib.MODE_DET, f32[:2], pool, False, 8.0,
-      'MODE_DET f32 (MSE / RMSE / MAE / Bias without a climatology), 13 regions')
-  out['wind'] = run(
-      'wind', pl13, _lib.MODE_WIND, [fpool, tpool, cpool, fpool], pool, False,
-      16.0, 'MODE_WIND f32: u, v of forecast and truth (4 inputs), 13 regions')
-  # lon-lat layout: the same bytes viewed as (slab, longitude, latitude)
+  rows_ll = plan_lib.auto_rows_per_chunk(N_LON, n_outer)
   pl_ll = plan_lib.build_plan(lat, lon, plan_lib.LONLAT, predefined_regions(),
-                              dev, rows_per_chunk=plan_lib.auto_rows_per_chunk(
-                                  N_LON, n_outer))
+                              dev, rows_per_chunk=rows_ll)
+  f32 = [fpool, tpool, cpool]
+  # lon-lat layout: the same bytes viewed as (slab, longitude, latitude)
   ll = [x.view(-1, N_LON, N_LAT) for x in f32]
-  out['lonlat'] = run(
-      'lonlat', pl_ll, _lib.MODE_DET_ACC, ll, pool, False, 12.0,
-      'MODE_DET_ACC f32 on (..., longitude, latitude) slabs (721 columns: '
-      'rows are not 16-byte aligned), 13 regions')
-  if out['lonlat'] is not None:
-    out['lonlat']['rows_per_chunk'] = plan_lib.auto_rows_per_chunk(N_LON,
-                                                                   n_outer)
+  f64 = None
+  pool64 = units + 8
   if only in (None, 'f64_inputs'):
-    pool64 = units + 8
     gen = torch.Generator(device=dev).manual_seed(77)
     f64 = [torch.randn((pool64 * N_LEV, N_LAT, N_LON), generator=gen,
                        device=dev, dtype=torch.float64) for _ in range(3)]
-    out['f64_inputs'] = run(
-        'f64_inputs', pl13, _lib.MODE_DET_ACC, f64, pool64, False, 24.0,
-        'MODE_DET_ACC float64 inputs (24 B/pt), 13 regions')
-    del f64
-  return {k: v for k, v in out.items() if v is not None}
+  # (name, plan, mode, inputs, pool units, skipna, B/pt, what)
+  specs = [
+      ('headline', pl13, _lib.MODE_DET_ACC, f32, pool, False, 12.0,
+       'MODE_DET_ACC f32, 13 regions (the benched one)'),
+      ('official16_landmask', pl16, _lib.MODE_DET_ACC, f32, pool, False, 12.0,
+       'MODE_DET_ACC f32, the 16 regions of scripts/evaluate.py:345-395 incl. '
+       'global_land / extra-tropics_land / tropics_land (2-D mask: WF = true)'),
+      ('skipna', pl13, _lib.MODE_DET_ACC, f32, pool, True, 12.0,
+       'MODE_DET_ACC f32, 13 regions, skipna = True (K = 10 slots)'),
+      ('det_no_acc', pl13, _lib.MODE_DET, f32[:2], pool, False, 8.0,
+       'MODE_DET f32 (MSE / RMSE / MAE / Bias without a climatology), 13 '
+       'regions'),
+      ('wind', pl13, _lib.MODE_WIND, [fpool, tpool, cpool, fpool], pool, False,
+       16.0, 'MODE_WIND f32: u, v of forecast and truth (4 inputs), 13 regions'),
+      ('lonlat', pl_ll, _lib.MODE_DET_ACC, ll, pool, False, 12.0,
+       'MODE_DET_ACC f32 on (..., longitude, latitude) slabs (721 columns: '
+       'rows are not 16-byte aligned), 13 regions'),
+      ('f64_inputs', pl13, _lib.MODE_DET_ACC, f64, pool64, False, 24.0,
+       'MODE_DET_ACC float64 inputs (24 B/pt), 13 regions'),
+  ]
+  specs = [sp for sp in specs if sp[3] is not None and (
+      sp[0] == only if only is not None
+      else (sp[0] != 'headline' or with_headline))]
+  # `reps` repetitions, the variants interleaved: one sample per run is not a
+  # measurement (the register-heavy instantiations spread by 10 % between
+  # boxes and moments); the line carries the median with min / max
+  samples = {sp[0]: [] for sp in specs}
+  for _ in range(reps):
+    for name, pl, mode, inputs, pool_units, skipna, _, _ in specs:
+      samples[name].append(run(pl, mode, inputs, pool_units, skipna))
+  out = {}
+  for name, pl, mode, inputs, pool_units, skipna, bytes_per_pt, what in specs:
+    ms = sorted(samples[name])
+    med = ms[len(ms) // 2]
+    nbytes = units * PTS_PER_UNIT * bytes_per_pt
+    frac = lambda t: nbytes / t / 1e6 / HBM_PEAK_GBPS
+    out[name] = {'what': what, 'kernel_ms': med,
+                 'algorithmic_bytes_per_launch': nbytes,
+                 'achieved': nbytes / med / 1e6, 'unit': 'GB/s',
+                 'frac': frac(med), 'frac_min': frac(ms[-1]),
+                 'frac_max': frac(ms[0]), 'repetitions': len(ms),
+                 'regions': pl.n_region,
+                 'rows_per_chunk': rows_ll if name == 'lonlat' else rows,
+                 'weight_field': pl.wfield is not None}
+  del f64
+  return out
 
 
-def live_traffic(units, pool, rows_per_chunk) -> dict:
-  """HBM bytes per launch of the benched K1 configuration from PMC counters,
-  collected NOW (tools/live_traffic.py: two rocprofv3 passes around
-  `bench.py --traffic-probe`)."""
+def live_traffic(units, pool, rows_per_chunk, workload='all') -> dict:
+  """HBM bytes per launch of the benched kernels (K1, K3, the three modes of the
+  fused spectrum kernel) from PMC counters, collected NOW (tools/
+  live_traffic.py: two rocprofv3 passes around `bench.py --traffic-probe all`):
+  {workload: {traffic_bytes, algorithmic_bytes, ratio, ...}}."""
   tool = os.path.join(ROOT, 'tools', 'live_traffic.py')
   try:
     res = subprocess.run(
-        [sys.executable, tool, '--units', str(units), '--pool', str(pool),
-         '--rows-per-chunk', str(rows_per_chunk)],
+        [sys.executable, tool, '--workload', workload, '--units', str(units),
+         '--pool', str(pool), '--rows-per-chunk', str(rows_per_chunk)],
         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-        timeout=240)
+        timeout=500)
     if res.returncode != 0:
       return {'error': (res.stderr or res.stdout).strip()[-300:]}
     return json.loads(res.stdout.strip().splitlines()[-1])
