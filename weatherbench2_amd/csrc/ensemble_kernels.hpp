@@ -56,22 +56,6 @@ namespace {
 
 // v_min_f32 / v_max_f32 (NaNs never reach the network: they are replaced first
 // or the result is overridden).
-#ifndef WB2_ENS_ASM_MINMAX
-#define WB2_ENS_ASM_MINMAX 1  // 0: __builtin_fmin/fmax (adds one canonicalize per member)
-#endif
-#ifndef WB2_ENS_NT
-#define WB2_ENS_NT 1  // 1: non-temporal member loads where members are read once
-#endif
-#ifndef WB2_ENS_MAPS_NT_STORES
-#define WB2_ENS_MAPS_NT_STORES 1
-#endif
-#ifndef WB2_ENS_NT_AUX
-#define WB2_ENS_NT_AUX 2  // buffer-load cache policy bits: 1 sc0, 2 nt, 16 sc1
-#endif
-#ifndef WB2_ENS_BUFFER_LOADS
-#define WB2_ENS_BUFFER_LOADS 1  // 0: global loads with a 64-bit VALU address per member
-#endif
-#if WB2_ENS_ASM_MINMAX
 // The instructions themselves: fminf/fmaxf make hipcc canonicalise every loaded
 // value first (a v_max_f32 x, x, x per member) because of signalling NaNs,
 // which this kernel never looks at.
@@ -95,12 +79,6 @@ __device__ __forceinline__ double vmax(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-#else
-__device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
-__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
-__device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
-__device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
-#endif
 
 // max(|d|, 0): |d|, or 0 when d is NaN (v_max returns the non-NaN operand).
 __device__ __forceinline__ float abs_or_zero(float d) {
@@ -122,26 +100,24 @@ __device__ __forceinline__ double abs_or_zero(double d) {
 // non-temporal loads, +3.5 % on BASELINE configs[2] (0.488 -> 0.471 ms,
 // profiles/r03_k3_ab8_summary.txt); the multi-pass streaming form re-reads its
 // members from the caches and keeps them cacheable.
+// buffer-load cache policy of the read-once loads (gfx940+ aux bits: 1 sc0,
+// 2 nt, 16 sc1)
+constexpr int kNtPolicy = 2;
+
 template <typename T, bool ONCE = false>
 __device__ __forceinline__ T member_load(const T* uniform_base, int lane_bytes) {
-#if WB2_ENS_BUFFER_LOADS
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(uniform_base), 0, 0x7fffffff, 0x00020000);
   // cache policy (gfx940+): bit 1 = nt -- the members are read once
   if constexpr (sizeof(T) == 4) {
     return __builtin_bit_cast(
         T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, 0,
-                                                WB2_ENS_NT && ONCE ? WB2_ENS_NT_AUX : 0));
+                                                ONCE ? kNtPolicy : 0));
   } else {
     return __builtin_bit_cast(
         T, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, 0,
-                                                WB2_ENS_NT && ONCE ? WB2_ENS_NT_AUX : 0));
+                                                ONCE ? kNtPolicy : 0));
   }
-#else
-  return __builtin_nontemporal_load(
-      reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) +
-                                 lane_bytes));
-#endif
 }
 
 // Sorts x[0..LIMIT) (slots >= LIMIT hold +inf padding and never move: every
@@ -166,25 +142,8 @@ __device__ __forceinline__ void sort_network(T (&x)[NPAD]) {
 #undef WB2_CE
 }
 
-#ifndef WB2_ENS_SKIPNA_LEAN
-#define WB2_ENS_SKIPNA_LEAN 1  // exact M with skipna: mask-free variance / sort preparation
-#endif
-#ifndef WB2_ENS_DIV_CONST
-#define WB2_ENS_DIV_CONST 1  // compile-time member count: x / M as mul + 2 FMA (exact)
-#endif
 #ifndef WB2_ENS_PAIRED_SPREAD
 #define WB2_ENS_PAIRED_SPREAD 1  // 50 float32 members: rank-weighted sum over (hi, lo) pairs
-#endif
-#ifndef WB2_ENS_PACKED
-// 50 float32 members: t - x, (x - mean)^2 and the rank-weighted sum on member
-// pairs (v_pk_add / mul / fma_f32: 1 007 instead of 1 096 VALU per row).  OFF:
-// measured 1.5 % SLOWER (0.495 against 0.488 ms, profiles/r03_k3_ab8_summary.txt)
-// -- the pairs cost 114 instead of 87 VGPRs (4 instead of 5 waves per SIMD) and
-// the kernel is as close to its HBM limit (256-byte bursts) as to the VALU's.
-#define WB2_ENS_PACKED 0
-#endif
-#ifndef WB2_ENS_SORT3
-#define WB2_ENS_SORT3 1  // 50 float32 members: the 2-/3-sorter program (677 instead of 806 VALU)
 #endif
 __device__ __forceinline__ void sort3_asm(float& a, float& b, float& c) {
   float lo, mid, hi;
@@ -217,11 +176,7 @@ struct Sort3Layout50 {
   int of_rank[50];
   constexpr Sort3Layout50() : reg{}, of_rank{} {
     for (int r = 0; r < 50; ++r) {
-#if WB2_ENS_PACKED
-      const int q = r == 0 ? 48 : (r == 49 ? 49 : r - 1);
-#else
       const int q = kSort3Order50[r];
-#endif
       of_rank[r] = q;
       reg[kSort3Order50[r]] = q;
     }
@@ -316,7 +271,7 @@ __device__ __forceinline__ double sqrt_of(double x) { return __builtin_sqrt(x); 
 // real branch (the empty asm keeps hipcc from speculating it).
 template <int C, typename T>
 __device__ __forceinline__ T div_const(T x) {
-  if constexpr (WB2_ENS_DIV_CONST && sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4) {
     constexpr float r = 1.0f / (float)C;
     const float q0 = x * r;
     const float e = __builtin_fmaf(-(float)C, q0, x);
@@ -358,7 +313,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   // operand), min(x, +inf) turns a NaN member into the +inf the sort wants.
   // The one case where d * d is NaN for a VALID member is an infinite member
   // (inf - inf): then, as before, the sum of squares is NaN.
-  constexpr bool SKIPNA_LEAN = WB2_ENS_SKIPNA_LEAN && SKIPNA && MS > 0;
+  constexpr bool SKIPNA_LEAN = SKIPNA && MS > 0;
   bool inf_member = false;
   T sq = 0;
   T mean;
@@ -367,18 +322,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
     // PAIR finds the NaNs (an odd count's last member alone)
 #pragma unroll
     for (int m = 0; m + 1 < NM; m += 2) {
-      T d0, d1;
-      if constexpr (WB2_ENS_PACKED && sizeof(T) == 4) {
-        // t - x for a member PAIR as one v_pk_add_f32 (same IEEE results)
-        typedef float F2 __attribute__((ext_vector_type(2)));
-        const F2 xp = {x[m], x[m + 1]}, tt = {t, t};
-        const F2 d = tt - xp;
-        d0 = d[0];
-        d1 = d[1];
-      } else {
-        d0 = t - x[m];
-        d1 = t - x[m + 1];
-      }
+      const T d0 = t - x[m], d1 = t - x[m + 1];
       sum += x[m];
       sk += abs_of(d0);
       sum += x[m + 1];
@@ -425,21 +369,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   {
     if constexpr (MS > 0 && !SKIPNA) mean = div_const<MS>(sum);
     else mean = sum / (T)cnt;
-    if constexpr (WB2_ENS_PACKED && MS > 0 && !SKIPNA && MS % 2 == 0 &&
-                  sizeof(T) == 4) {
-      // (x - mean)^2 for a member pair: v_pk_add_f32 + v_pk_mul_f32, summed in
-      // member order as before
-      typedef float F2 __attribute__((ext_vector_type(2)));
-      const F2 mm = {mean, mean};
-#pragma unroll
-      for (int m = 0; m < NM; m += 2) {
-        const F2 xp = {x[m], x[m + 1]};
-        const F2 d = xp - mm;
-        const F2 q = d * d;
-        sq += q[0];
-        sq += q[1];
-      }
-    } else {
+    {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const T d = x[m] - mean;
@@ -494,7 +424,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
       if constexpr (SKIPNA) return times_flag(xm, clamp01(nf - (T)m));
       else return xm;
     };
-    if constexpr (WB2_ENS_SORT3 && MS == 50 && NPAD == 64 && sizeof(T) == 4) {
+    if constexpr (MS == 50 && NPAD == 64 && sizeof(T) == 4) {
       sort3_network_50(x);  // rank m lives in register kSort3Order50[m]
       if constexpr (WB2_ENS_PAIRED_SPREAD && !SKIPNA && !REFCHAIN) {
         // Ranks H + j and H + 1 - j (H = M / 2) carry the weights +-(2 j - 1):
@@ -513,32 +443,11 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
         constexpr int H = MS / 2;
         constexpr auto& R = kSort3Layout50.of_rank;
         float s0 = 0.0f, s1 = 0.0f;
-        if constexpr (WB2_ENS_PACKED) {
-          // the two chains side by side: j = 2k - 1 in element 0 (s1), j = 2k
-          // in element 1 (s0); the register pairs are the layout's
-          typedef float F2 __attribute__((ext_vector_type(2)));
-          F2 s10 = {0.0f, 0.0f};
 #pragma unroll
-          for (int k = 1; 2 * k <= H; ++k) {
-            const int j = 2 * k - 1;
-            const F2 hi = {x[R[H + j - 1]], x[R[H + j]]};
-            const F2 lo = {x[R[H - j]], x[R[H - j - 1]]};
-            const F2 c = {(float)(2 * j - 1), (float)(2 * j + 1)};
-            s10 = __builtin_elementwise_fma(c, hi - lo, s10);
-          }
-          s1 = s10[0];
-          s0 = s10[1];
-          if constexpr (H & 1) {
-            const float g = x[R[2 * H - 1]] - x[R[0]];
-            s1 = __builtin_fmaf((float)(2 * H - 1), g, s1);
-          }
-        } else {
-#pragma unroll
-          for (int j = 1; j <= H; ++j) {
-            const float g = x[R[H + j - 1]] - x[R[H - j]];
-            if (j & 1) s1 = __builtin_fmaf((float)(2 * j - 1), g, s1);
-            else s0 = __builtin_fmaf((float)(2 * j - 1), g, s0);
-          }
+        for (int j = 1; j <= H; ++j) {
+          const float g = x[R[H + j - 1]] - x[R[H - j]];
+          if (j & 1) s1 = __builtin_fmaf((float)(2 * j - 1), g, s1);
+          else s0 = __builtin_fmaf((float)(2 * j - 1), g, s0);
         }
         s = (double)s0 + (double)s1;
       } else {
@@ -548,7 +457,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
                             (double)ranked(m, x[kSort3Layout50.of_rank[m]]), s);
         }
       }
-    } else if constexpr (WB2_ENS_SORT3 && Sort3<MS>::has && sizeof(T) == 4) {
+    } else if constexpr (Sort3<MS>::has && sizeof(T) == 4) {
       Sort3<MS>::template run<NPAD>(x);  // rank m: register Sort3<MS>::order[m]
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
@@ -601,9 +510,6 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   }
 }
 
-#ifndef WB2_ENS_LEAN_RUNTIME
-#define WB2_ENS_LEAN_RUNTIME 1  // 0: the select-per-member runtime-M path for every case
-#endif
 
 // Runtime member count WITHOUT NaN skipping, lean form.  The caller has set the
 // slots >= M to +inf; the dead slots are a wave-uniform SUFFIX, so the
@@ -711,9 +617,6 @@ __device__ __forceinline__ void ens_point_runtime(T (&x)[NPAD], const T t,
   out[5] = (double)deb;
 }
 
-#ifndef WB2_ENS_MIN_WAVES
-#define WB2_ENS_MIN_WAVES 1
-#endif
 
 // Ensembles too large for the register sort (M > 128 float32 / 64 float64):
 // the same six values from three streaming passes over the members (cache
@@ -823,23 +726,15 @@ __device__ __forceinline__ void ens_point_large(
   }
 }
 
-#ifndef WB2_ENS_SKIPNA_FAST
-#define WB2_ENS_SKIPNA_FAST 1  // exact M with skipna: NaN-free waves skip the selects
-#endif
 #ifndef WB2_ENS_WG_WAVES
 // waves per workgroup (independent waves: the workgroup is only a scheduling
 // unit).  2 instead of 4: +1 % with non-temporal loads (r03_k3_ab10_summary.txt)
 #define WB2_ENS_WG_WAVES 2
 #endif
 
-#ifndef WB2_ENS_SKIPNA_MIN_WAVES
-#define WB2_ENS_SKIPNA_MIN_WAVES 1
-#endif
 
 template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
-__global__ void __launch_bounds__(
-    256, (SKIPNA && MS > 1 && sizeof(T) == 4) ? WB2_ENS_SKIPNA_MIN_WAVES
-                                               : WB2_ENS_MIN_WAVES)
+__global__ void __launch_bounds__(256)
     ens_partials_kernel(const EnsParams p) {
   constexpr int K = SKIPNA ? 10 : 6, NWF = WF ? 2 : 1;
   constexpr int NM = MS > 0 ? MS : NPAD;
@@ -980,7 +875,7 @@ __global__ void __launch_bounds__(
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (WB2_ENS_LEAN_RUNTIME && MS == 0 && !SKIPNA) {
+        if constexpr (MS == 0 && !SKIPNA) {
           // dead slots (a wave-uniform suffix) become +inf ONCE, here
 #pragma unroll
           for (int m = 0; m < NPAD; ++m)
@@ -1026,10 +921,7 @@ __global__ void __launch_bounds__(
             constexpr int flag[6] = {6, 7, 6, 8, 8, 9};
             out_v = v[flag[k]] != 0.0 ? v[k] : qnan;
           }
-          if (WB2_ENS_MAPS_NT_STORES)
-            __builtin_nontemporal_store(out_v, p.maps + k * plane + at);
-          else
-            p.maps[k * plane + at] = out_v;
+          __builtin_nontemporal_store(out_v, p.maps + k * plane + at);
         }
       }
 #pragma unroll
@@ -1045,7 +937,7 @@ __global__ void __launch_bounds__(
       return false;
     };
     constexpr bool TWO_PASS =
-        WB2_ENS_SKIPNA_FAST && SKIPNA && MS > 1 && NPAD > 0;
+        SKIPNA && MS > 1 && NPAD > 0;
     if constexpr (TWO_PASS) {
       // rows with a NaN somewhere in the wave wait for a loop of their own:
       // two loops, two register allocations -- the NaN-free rows are not held

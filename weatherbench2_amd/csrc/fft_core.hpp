@@ -232,14 +232,7 @@ WB2_FFT_PLAN(180, 5, 6, 6, 0, 0)
 WB2_FFT_PLAN(256, 4, 8, 8, 0, 0)
 WB2_FFT_PLAN(360, 6, 6, 10, 0, 0)
 WB2_FFT_PLAN(512, 8, 8, 8, 0, 0)
-#ifndef WB2_FFT_PAD720
-#define WB2_FFT_PAD720 1
-#endif
-#if WB2_FFT_PAD720
 WB2_FFT_PLAN(720, 12, 12, 5, 2, 12)
-#else
-WB2_FFT_PLAN(720, 12, 12, 5, 0, 0)
-#endif
 #undef WB2_FFT_PLAN
 
 // ---- one Stockham pass of radix R; NS = product of the radices already done ---

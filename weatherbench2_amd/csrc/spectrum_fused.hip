@@ -30,13 +30,10 @@
 
 #include "common.hpp"
 
-#ifndef WB2_FFT_SINGLE_WRITES
-// 1: 8-byte LDS stores stay single ds_write_b64 (17 cycles per instruction and
+// 8-byte LDS stores stay single ds_write_b64 (17 cycles per instruction and
 // SIMD, tools/valu_rate.hip) instead of the ds_write2_b64 pairs hipcc's
 // load/store optimiser makes of them (44): volatile stores in address space 3
-#define WB2_FFT_SINGLE_WRITES 1
-#endif
-#if WB2_FFT_SINGLE_WRITES && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define WB2_FFT_SLAB_STORE(ptr, value)                                         \
   (*(__attribute__((address_space(3))) volatile ::wb2::fftcore::cf*)(ptr) = \
        (value))
@@ -47,83 +44,16 @@
 #ifndef WB2_FFT_MAX_BLOCKS
 #define WB2_FFT_MAX_BLOCKS 2048   // persistent workgroups (4 waves each)
 #endif
-#ifndef WB2_FFT_MIN_WAVES
-#define WB2_FFT_MIN_WAVES 1
-#endif
-#ifndef WB2_FFT_TW_POWERS
-// 1: only the first powers of every butterfly's inter-pass twiddle stay in
-// VGPRs (w^1..w^4 of a radix-12 butterfly, w^1 of a radix-5 one) and the others
-// are derived per row (w^5 = w^4 w, ... : 7 + 3 x 3 complex multiplies, depth
-// <= 3) -- 32 VGPRs less, which buys a fourth wave per SIMD without spills.
-#define WB2_FFT_TW_POWERS 0
-#endif
-#ifndef WB2_FFT_LATSEG_INTERLEAVE
-// LATSEG: 1 = segment `seg` of a field takes the latitudes seg, seg + n_seg,
-// seg + 2 n_seg, ... instead of a contiguous run, so that at any moment the
-// waves of a field read ADJACENT rows (one contiguous window per field instead
-// of n_seg separate streams).  Any partition works: the partials are added up by
-// latseg_combine_kernel.
-#define WB2_FFT_LATSEG_INTERLEAVE 0
-#endif
 #ifndef WB2_FFT_NWAVE
 #define WB2_FFT_NWAVE 4   // waves (= rows in flight) per workgroup
 #endif
-#ifndef WB2_FFT_ASM_CMUL
-#define WB2_FFT_ASM_CMUL 1   // 0: let hipcc build (-w.y, w.x) per twiddle (2 extra VALU)
-#endif
-#ifndef WB2_FFT_WIDE_STORE
-#define WB2_FFT_WIDE_STORE 1  // materialising kernel: 16-byte stores of adjacent bins
-#endif
-#ifndef WB2_FFT_SINGLE_READS
-// 1: every 8-byte LDS read of the transform is its own ds_read_b64.  hipcc's
-// load/store optimiser otherwise pairs them into ds_read2_b64 /
-// ds_read2st64_b64, which gfx950 services at 128 B/clk (8 LDS cycles per
-// wave-instruction) where two ds_read_b64 take 2 + 2 (256 B/clk,
-// MI355X_MICROARCH.md "LDS"): 152 -> 90 LDS-pipe cycles of reads per row
-// (profiles/r03_k4_stalls.md).  The reads are marked volatile in address
-// space 3 -- the one thing the optimiser does not merge.
-#define WB2_FFT_SINGLE_READS 1
-#endif
-#ifndef WB2_FFT_STAGE
-// 1: the reducing kernels (TIME_MEAN, LATSEG) fetch the NEXT row HBM -> LDS by
-// DMA (global_load_lds_dwordx4: 6 instructions per 5760-byte row, no VGPRs)
-// while the current row is transformed; pass 0 then reads its inputs from the
-// wave's staging buffer (12 more ds_read_b64).  Hides the HBM latency of a row
-// (~1.5 k of the ~6.8 k cycles a wave spends per row) at no register cost.
-// Measured twice with NO gain (round 2 with ds_read2_b64 pairs, round 3 with
-// single ds_read_b64: 0.1065-0.1093 ms against 0.1075-0.1078 ms for LATSEG,
-// profiles/r03_k4_stalls.md), so it stays off: the staged instantiations are
-// only compiled with -DWB2_FFT_STAGE=1 (tools/ab_round3b.sh; the spectrum
-// parity tests pass through them).
-#define WB2_FFT_STAGE 0
-#endif
-#ifndef WB2_FFT_DIAG
-// timing diagnostics only (wrong results): 1 / 2 skip LDS pass 1 / 2, 4 replace
-// the recombination epilogue by a token read, 8 skip pass 0's butterflies and
-// stores, 16 no global stores in the materialising kernel
-#define WB2_FFT_DIAG 0
-#endif
 
-#ifndef WB2_FFT_NT_LOADS
-#define WB2_FFT_NT_LOADS 1   // input rows are read once: non-temporal
-#endif
-#ifndef WB2_FFT_NT_STORES
-// spectra are written once, but plain stores (write-back through L2) are the
-// faster ones: MATERIALISE 0.279 / 0.304 ms per 16 units against 0.303 / 0.331
-// with non-temporal stores (profiles/r03_k4_ab11_summary.txt); the reducing
-// modes write too little to care.
-#define WB2_FFT_NT_STORES 0
-#endif
-#if WB2_FFT_NT_LOADS
+// input rows are read once: non-temporal loads.  The spectra are written once
+// too, but plain stores (write-back through L2) are the faster ones:
+// MATERIALISE 0.279 / 0.304 ms per 16 units against 0.303 / 0.331 with
+// non-temporal stores (profiles/r03_k4_ab11_summary.txt).
 #define WB2_FFT_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define WB2_FFT_LOAD(p) (*(p))
-#endif
-#if WB2_FFT_NT_STORES
-#define WB2_FFT_STORE(v, p) __builtin_nontemporal_store(v, p)
-#else
 #define WB2_FFT_STORE(v, p) (*(p) = (v))
-#endif
 
 #include <cstdlib>
 
@@ -175,47 +105,6 @@ __device__ __forceinline__ void cmul3_asm(cf& a0, cf w0, cf& a1, cf w1, cf& a2,
 #undef WB2_PK_MUL
 #undef WB2_PK_FMA
 
-// a * w (returned), same instruction pair as the in-place forms above
-__device__ __forceinline__ cf cprod_asm(cf a, cf w) {
-  cf t;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\ts_nop 0\n\t"
-      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] "
-      "neg_lo:[0,1,0]\n\ts_nop 0"
-      : "=&v"(t)
-      : "v"(a), "v"(w));
-  return t;
-}
-
-// Number of twiddle powers kept resident for a radix-R butterfly.
-template <int R>
-constexpr int resident_powers() {
-#if WB2_FFT_TW_POWERS
-  return R - 1 <= 4 ? 1 : 4;
-#else
-  return R - 1;
-#endif
-}
-
-// w^1 .. w^(R-1) from the resident powers b[0..NB): w^(q+1) for q >= NB is the
-// product of the largest resident-or-derived power of two and the rest.
-template <int R, int NB>
-__device__ __forceinline__ void expand_powers(const cf (&b)[NB], cf (&w)[R - 1]) {
-#pragma unroll
-  for (int q = 0; q < R - 1; ++q) {
-    if (q < NB) {
-      w[q] = b[q];
-    } else {
-      const int e = q + 1;               // the exponent wanted
-      int p2 = 1;
-      while (2 * p2 <= e) p2 *= 2;       // largest power of two <= e
-      const int rest = e - p2;
-      // w^e = w^p2 * w^rest (rest == 0: e is a power of two = (w^(e/2))^2)
-      w[q] = rest == 0 ? cprod_asm(w[e / 2 - 1], w[e / 2 - 1])
-                       : cprod_asm(w[p2 - 1], w[rest - 1]);
-    }
-  }
-}
-
 template <int N>
 __device__ __forceinline__ void twiddle_block(cf* v, const cf* tw) {
   // v[0..N) *= tw[0..N)
@@ -231,12 +120,13 @@ __device__ __forceinline__ void twiddle_block(cf* v, const cf* tw) {
 
 // One 8-byte read from the wave's LDS slab (or the shared twiddle table).
 __device__ __forceinline__ cf lds_read(const cf* p) {
-#if WB2_FFT_SINGLE_READS
+  // its own ds_read_b64: hipcc's load/store optimiser otherwise pairs the
+  // 8-byte slab reads into ds_read2_b64 / ds_read2st64_b64, which gfx950
+  // services at 44 cycles per wave-instruction against 6.4 for a ds_read_b64
+  // (tools/valu_rate.hip); volatile in address space 3 is the one thing the
+  // optimiser does not merge
   typedef __attribute__((address_space(3))) const volatile cf* lds_ptr;
   return *(lds_ptr)p;
-#else
-  return *p;
-#endif
 }
 
 struct FusedParams {
@@ -256,30 +146,14 @@ struct FusedParams {
 // A later pass (NS > 1) over the wave's slab: strided reads, twiddle multiplies
 // (the twiddles of a lane depend on the lane only: VGPR-resident for the whole
 // kernel), butterflies, in-place writes.
-template <typename P, int R, int NB>
+template <typename P, int R>
 __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
-                                         cf (&tw)[P::ROUNDS][NB]) {
+                                         cf (&tw)[P::ROUNDS][R - 1]) {
   cf v[P::ROUNDS][R];
   P::load([&](int i) { return lds_read(z + i); }, lane, v);
-#if WB2_FFT_ASM_CMUL
 #pragma unroll
-  for (int rd = 0; rd < P::ROUNDS; ++rd) {
-    if constexpr (NB == R - 1) {
-      twiddle_block<R - 1>(&v[rd][1], &tw[rd][0]);
-    } else {
-      // derived per row: the asm keeps hipcc from hoisting the products out of
-      // the row loop (which would bring the registers back)
-#pragma unroll
-      for (int q = 0; q < NB; ++q) asm volatile("" : "+v"(tw[rd][q]));
-      cf w[R - 1];
-      expand_powers<R, NB>(tw[rd], w);
-      twiddle_block<R - 1>(&v[rd][1], &w[0]);
-    }
-  }
-#else
-  static_assert(NB == R - 1, "derived twiddles need the asm multiply");
-  P::twiddle(v, tw);
-#endif
+  for (int rd = 0; rd < P::ROUNDS; ++rd)
+    twiddle_block<R - 1>(&v[rd][1], &tw[rd][0]);
   P::butterflies(v);
   // every read of this pass precedes every write (program order; the DS
   // operations of one wave execute in order) -- the fence only restrains the
@@ -303,8 +177,8 @@ __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
 //                field are added in segment order by latseg_combine_kernel).
 enum { MATERIALISE = 0, TIME_MEAN = 1, LATSEG = 2 };
 
-template <int N2, int MODE, bool STAGED = false>
-__global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
+template <int N2, int MODE>
+__global__ void __launch_bounds__(64 * WB2_FFT_NWAVE)
     fused_spectrum_kernel(const FusedParams p) {
   using PL = Plan<N2>;
   constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2;
@@ -317,32 +191,14 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
   constexpr bool REDUCE = MODE != MATERIALISE;
   __shared__ __attribute__((aligned(16))) cf s_twq[NH + 1];
   __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][slab_slots<N2>()];
-  constexpr bool STAGE = REDUCE && STAGED;
-  __shared__ __attribute__((aligned(16))) float
-      s_stage[STAGE ? NWAVE : 1][STAGE ? N : 4];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   for (int i = threadIdx.x; i <= NH; i += blockDim.x)
     s_twq[i] = p.twq[i < NH ? i : NH - 1];
   // inter-pass twiddles: functions of the lane only, resident in VGPRs
-  constexpr int NB1 = resident_powers<R1>();
-  constexpr int NB2 = resident_powers<(R2 > 1 ? R2 : 2)>();
-  cf tw1[P1::ROUNDS][NB1], tw2[P2::ROUNDS][NB2];
-  {
-    cf full1[P1::ROUNDS][P1::NTW], full2[P2::ROUNDS][P2::NTW];
-    P1::load_twiddles(p.twz, lane, full1);
-    if constexpr (R2 > 1) P2::load_twiddles(p.twz, lane, full2);
-#pragma unroll
-    for (int rd = 0; rd < P1::ROUNDS; ++rd)
-#pragma unroll
-      for (int q = 0; q < NB1; ++q) tw1[rd][q] = full1[rd][q];
-    if constexpr (R2 > 1) {
-#pragma unroll
-      for (int rd = 0; rd < P2::ROUNDS; ++rd)
-#pragma unroll
-        for (int q = 0; q < NB2; ++q) tw2[rd][q] = full2[rd][q];
-    }
-  }
+  cf tw1[P1::ROUNDS][P1::NTW], tw2[P2::ROUNDS][P2::NTW];
+  P1::load_twiddles(p.twz, lane, tw1);
+  if constexpr (R2 > 1) P2::load_twiddles(p.twz, lane, tw2);
   __syncthreads();
   cf* z = s_z[wave];
   const float half_inv_n = 0.5f / (float)N;
@@ -366,43 +222,15 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
     } else if constexpr (MODE == LATSEG) {
       const long long field = o / p.n_seg;
       const int seg = (int)(o - field * p.n_seg);
-#if WB2_FFT_LATSEG_INTERLEAVE
-      k.lat0 = seg;
-      k.nt = (p.n_lat - seg + p.n_seg - 1) / p.n_seg;
-      k.row0 = field * p.n_lat + seg;
-      k.row_step = p.n_seg;
-#else
       k.lat0 = (int)((long long)seg * p.n_lat / p.n_seg);  // balanced split
       k.nt = (long long)(seg + 1) * p.n_lat / p.n_seg - k.lat0;
       k.row0 = field * p.n_lat + k.lat0;
       k.row_step = 1;
-#endif
     }
     return k;
   };
-  // HBM -> LDS DMA of one input row into this wave's staging buffer: 16 bytes
-  // per lane and instruction, lane l of instruction i lands at byte
-  // i * 1024 + 16 l (M0 carries the wave-uniform LDS base)
-  auto stage_row = [&](long long row) {
-    if constexpr (STAGE) {
-      const char* g = reinterpret_cast<const char*>(p.x + row * N);
-      char* dst = reinterpret_cast<char*>(s_stage[wave]);
-#pragma unroll
-      for (int i = 0; i < (N * 4 + 1023) / 1024; ++i) {
-        const int off = i * 1024 + lane * 16;
-        if ((i + 1) * 1024 <= N * 4 || off < N * 4)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(g + off),
-              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0,
-              /*aux: nt*/ 2);
-      }
-    }
-  };
   const long long orow_first = (long long)blockIdx.x * NWAVE + wave;
   Task next_task = task_of(orow_first < rows_out ? orow_first : 0);
-  if constexpr (STAGE) {
-    if (orow_first < rows_out) stage_row(next_task.row0);
-  }
   for (long long orow_i = orow_first; orow_i < rows_out; orow_i += stride) {
     double sum1[NIT], sum2[NIT];
     int cnt[NIT];  // TIME + skipna: valid spectra, bin k (low half) / N2 - k
@@ -412,8 +240,8 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
       cnt[i] = 0;
     }
     const Task task = next_task;
-    const bool has_next = orow_i + stride < rows_out;
-    if (has_next) next_task = task_of(orow_i + stride);  // once per task
+    if (orow_i + stride < rows_out)
+      next_task = task_of(orow_i + stride);  // once per task
     const long long nt = task.nt, row0 = task.row0, row_step = task.row_step;
     const int lat0 = task.lat0;
     double c = 0.0;
@@ -424,46 +252,17 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
       const double c2 = 2.0 * c;
       {  // ---- pass 0: HBM -> butterflies -> contiguous runs in the slab
         cf v[P0::ROUNDS][R0];
-        if constexpr (STAGE) {
-          // this row was staged one row-time ago: wait for the DMA, copy it
-          // out, and only when every read has RETURNED (the DMA of the next
-          // row overwrites the buffer) start the next fetch
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-          const cf* src = reinterpret_cast<const cf*>(s_stage[wave]);
-          P0::load([&](int i) { return lds_read(src + i); }, lane, v);
-          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          const bool more = t + 1 < nt;
-          if (more || has_next)
-            stage_row(more ? row0 + (t + 1) * row_step : next_task.row0);
-        } else {
-          const cf* src =
-              reinterpret_cast<const cf*>(p.x + (row0 + t * row_step) * N);
-          P0::load([&](int i) { return WB2_FFT_LOAD(src + i); },
-                   lane, v);
-        }
-#if WB2_FFT_DIAG & 8
-        sum1[0] += (double)(v[0][0].x + v[0][R0 - 1].y);
-#else
+        const cf* src =
+            reinterpret_cast<const cf*>(p.x + (row0 + t * row_step) * N);
+        P0::load([&](int i) { return WB2_FFT_LOAD(src + i); },
+                 lane, v);
         P0::butterflies(v);
         P0::store(z, lane, v);
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-#if !(WB2_FFT_DIAG & 1)
-      lds_pass<P1, R1, NB1>(z, lane, tw1);
-#endif
-#if !(WB2_FFT_DIAG & 2)
-      if constexpr (R2 > 1) lds_pass<P2, R2, NB2>(z, lane, tw2);
-#endif
-#if WB2_FFT_DIAG & 4
-      {
-        const cf a = z[lane];
-        sum1[0] += (double)a.x * c2;
-        if (!REDUCE && a.x == 1.2345f) orow[lane] = sum1[0];
-      }
-#else
-      if constexpr (!REDUCE && WB2_FFT_WIDE_STORE) {
+      lds_pass<P1, R1>(z, lane, tw1);
+      if constexpr (R2 > 1) lds_pass<P2, R2>(z, lane, tw2);
+      if constexpr (!REDUCE) {
         // ---- materialising kernel: a lane owns the ADJACENT bins k0, k0 + 1
         // (and their mirrors N2 - k0, N2 - k0 - 1), so the fp64 spectrum leaves
         // in 16-byte stores (1 KiB per wave instruction instead of 512 B)
@@ -486,9 +285,6 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
             const double v1a = (double)p1a * ((i == 0 && k0 == 0) ? c : c2);
             const double v1b = (double)p1b * c2;
             const double v2a = (double)p2a * c2, v2b = (double)p2b * c2;
-#if WB2_FFT_DIAG & 16
-            if (p1a == 1.2345f) orow[k0] = v1a + v1b + v2a + v2b;
-#else
             if (k0 < N2 / 2) {
               WB2_FFT_STORE((d2{v1a, v1b}),
                                           reinterpret_cast<d2*>(orow + k0));
@@ -497,7 +293,6 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
             } else {  // k0 == N2 / 2: its own mirror; bin k0 + 1 belongs to k0 - 2
               WB2_FFT_STORE(v1a, orow + k0);
             }
-#endif
           }
         }
       } else {
@@ -523,17 +318,12 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE, WB2_FFT_MIN_WAVES)
               sum1[i] += v1;
               sum2[i] += v2;
             } else {
-#if WB2_FFT_DIAG & 16
-              if (p1 == 1.2345f) orow[k] = v1 + v2;
-#else
               WB2_FFT_STORE(v1, orow + k);
               if (2 * k != N2) WB2_FFT_STORE(v2, orow + N2 - k);
-#endif
             }
           }
         }
       }
-#endif
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // reduced rows
     if constexpr (REDUCE) {
@@ -622,25 +412,6 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
   // row-strided waves beyond that (the cap counts 4-wave workgroups)
   if (blocks > WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE)
     blocks = WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE;
-  // the LDS DMA moves 16 bytes per lane: rows must start 16-byte aligned
-  const bool staged = WB2_FFT_STAGE && mode != MATERIALISE &&
-                      reinterpret_cast<uintptr_t>(p.x) % 16 == 0 &&
-                      (2 * N2 * sizeof(float)) % 16 == 0;
-#if WB2_FFT_STAGE
-  if (mode == TIME_MEAN && staged) {
-    hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN, true>),
-                       dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
-    WB2_HIP_OK(hipGetLastError());
-    return 0;
-  }
-  if (mode == LATSEG && staged) {
-    hipLaunchKernelGGL((fused_spectrum_kernel<N2, LATSEG, true>),
-                       dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
-    WB2_HIP_OK(hipGetLastError());
-    return 0;
-  }
-#endif
-  (void)staged;
   if (mode == TIME_MEAN)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN>),
                        dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
@@ -658,10 +429,8 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
 // at once (one task per wave, no second round).
 template <int N2>
 int latseg_segments(long long n_field, int n_lat) {
-  // (sized for the staged instantiation: its LDS footprint is the larger one,
-  // so the task count also fits the unstaged fallback)
-  const long long waves =
-      (long long)WB2_FFT_NWAVE * resident_blocks(fused_spectrum_kernel<N2, LATSEG, WB2_FFT_STAGE != 0>);
+  const long long waves = (long long)WB2_FFT_NWAVE *
+                          resident_blocks(fused_spectrum_kernel<N2, LATSEG>);
   // WB2HIP_LATSEG_ROUNDS (A/B runs): tasks = that many times the resident waves
   static const double rounds = [] {
     const char* e = getenv("WB2HIP_LATSEG_ROUNDS");

@@ -330,36 +330,9 @@ __device__ __forceinline__ void eval_slots(
 // 1.6 x the algorithmic bytes, profiles/r03_k1_variants.md).
 #define WB2_WF_OUTER_FASTEST 1
 #endif
-#ifndef WB2_SGPR_ROWS
-// Default of the kernel's SG parameter (see `at` in the kernel): 1 = SGPR row
-// bases for EVERY instantiation (A/B builds), 0 = only where launch_stream
-// selects the SG instantiation (unaligned float32 rows).
-// Measured (profiles/r03_k1_ab5_summary.txt): the SGPR form is SLOWER -- every
-// load then waits for the scalar add that makes its base (headline 0.418 ->
-// 0.427 ms, weight field 0.500 -> 0.556, skipna 0.463 -> 0.560); only the
-// unaligned lon-lat rows gain (0.493 -> 0.473): those -- float32, 4 columns
-// per lane, no skipna, no weight field, rows or bases not 16-byte aligned --
-// get an SGPR instantiation of their own (StreamParams::unaligned).
-#define WB2_SGPR_ROWS 0
-#endif
 #ifndef WB2_PACK_PAIRS
 // 1: float32 columns through the elementwise stage in pairs (v_pk_*_f32).
 #define WB2_PACK_PAIRS 1
-#endif
-#ifndef WB2_DIAG
-#define WB2_DIAG 0  // 1: skip the fold/store epilogue, 2: trivial arithmetic
-#endif
-#ifndef WB2_PIPELINE
-#define WB2_PIPELINE 0  // 1: double-buffered batches (next loads before this fold)
-#endif
-#ifndef WB2_MIN_WAVES
-#define WB2_MIN_WAVES 1
-#endif
-#ifndef WB2_WF_MIN_WAVES
-#define WB2_WF_MIN_WAVES 1
-#endif
-#ifndef WB2_SKIPNA_MIN_WAVES
-#define WB2_SKIPNA_MIN_WAVES 1
 #endif
 
 #if WB2_NT_LOADS
@@ -404,13 +377,8 @@ __device__ __forceinline__ void load_wf(const WB2_GLOBAL double* p,
 // branch-free on purpose: every scalar (table / slab-index) load is issued
 // before the first wait, instead of one dependent round trip per table.
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF,
-          bool SG = (WB2_SGPR_ROWS != 0)>
-__global__ void __launch_bounds__(
-    512, (WF && !SKIPNA && sizeof(T) * VEC == 8 && MODE == WB2_MODE_DET_ACC)
-             ? WB2_WF_MIN_WAVES
-             : ((SKIPNA && sizeof(T) * VEC == 8 && MODE == WB2_MODE_DET_ACC)
-                    ? WB2_SKIPNA_MIN_WAVES : WB2_MIN_WAVES))
-    // (occupancy knobs of the 2-column heavy instantiations, A/B only)
+          bool SG = false>
+__global__ void __launch_bounds__(512)
     stream_partials_kernel(const StreamParams p) {
   using M = ModeTraits<MODE, SKIPNA>;
   constexpr int NIN = M::NIN, K = M::K, NWF = WF ? 2 : 1;
@@ -555,14 +523,6 @@ __global__ void __launch_bounds__(
 
     auto consume = [&](const T (&v)[NIN][VEC], const double (&wf)[VEC],
                        double wr, const double* auxrow) {
-#if WB2_DIAG == 2
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        T sdiag = 0;
-        for (int i = 0; i < NIN; ++i) sdiag += v[i][e];
-        acc[0][e][0] += (double)sdiag;
-      }
-#else
       if constexpr (PAIRS) {
         typedef T V2 __attribute__((ext_vector_type(2)));
         using Ops = PointOps<POINT_OPS ? MODE : WB2_MODE_DET>;
@@ -600,7 +560,6 @@ __global__ void __launch_bounds__(
           accumulate(e, x, wf[e], wr);
         }
       }
-#endif
     };
 
     // A batch = U rows.  issue() puts the batch's loads in flight, eat() folds
@@ -636,32 +595,6 @@ __global__ void __launch_bounds__(
                     : nullptr);
     };
     int r = 0;
-#if WB2_PIPELINE
-    // Software pipeline: the next batch is already in flight while the current
-    // one is being folded, so a wave never sits between batches with nothing
-    // outstanding.  Invariant at the loop head: `a` holds batch bi (in flight).
-    // The sched_barriers keep hipcc from sinking loads below the arithmetic.
-    {
-      const int nb = nrow / U;
-      Batch a, b;
-      if (nb > 0) issue(a, 0);
-      int bi = 0;
-#pragma clang loop unroll(disable)
-      for (; bi + 1 < nb; bi += 2) {
-        issue(b, (bi + 1) * U);
-        __builtin_amdgcn_sched_barrier(0);
-        eat(a, bi * U);
-        if (bi + 2 < nb) issue(a, (bi + 2) * U);
-        __builtin_amdgcn_sched_barrier(0);
-        eat(b, (bi + 1) * U);
-      }
-      if (bi < nb) {
-        __builtin_amdgcn_sched_barrier(0);
-        eat(a, bi * U);
-      }
-      r = nb * U;
-    }
-#else
 #pragma clang loop unroll(disable)
     for (; r + U <= nrow; r += U) {
       Batch bt;
@@ -671,7 +604,6 @@ __global__ void __launch_bounds__(
       __builtin_amdgcn_sched_barrier(0);
       eat(bt, r);
     }
-#endif
 #pragma clang loop unroll(disable)
     for (; r < nrow; ++r) {
       T v[NIN][VEC];
@@ -704,10 +636,6 @@ __global__ void __launch_bounds__(
   }
 
   // ---- fold owned columns into the segs intersecting this wave's tile ----
-#if WB2_DIAG == 1
-  if (acc[0][0][0] == 1.2345) p.partials[0] = acc[0][0][0] + acc[0][VEC - 1][K - 1];
-  return;
-#endif
   fold_tile_to_segs<NWF, VEC, K>(
       acc, lane, tile, colb, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg,
       p.n_ts,
