@@ -448,7 +448,7 @@ def test_fused_latitude_mean_matches_oracle(n_lat, n_lon, n_field):
   assert torch.equal(got, again)
 
 
-def test_latitude_mean_falls_back_for_float64_and_odd_lengths():
+def test_latitude_mean_of_other_lengths_and_float64():
   import torch
   from weatherbench2_amd import engine, plan as plan_lib
   dev = torch.device('cuda')
@@ -487,3 +487,68 @@ def test_area_mean_dataset_api(dv):
           * w[None, None, :, None]).sum(2) / w.sum()
   np.testing.assert_allclose(got.values, want, rtol=1e-9,
                              atol=1e-9 * np.abs(want).max())
+
+
+# ---- float64 rows through the fused kernel (complex128 LDS FFT) -------------
+@pytest.mark.parametrize('n_lon', [64, 128, 240, 256, 360, 512, 720, 1024, 1440])
+def test_fused_float64_matches_numpy(n_lon):
+  """float64 rows of every instantiated length: the single-kernel path against
+  np.fft.rfft (complex128, what the reference computes for float64 data:
+  derived_variables.py:592-626) to 1e-12 of each row's total power -- all
+  three modes (materialised, time mean fused, latitude mean fused)."""
+  import torch
+  from weatherbench2_amd import engine, plan as plan_lib
+  dev = torch.device('cuda')
+  rs = np.random.RandomState(n_lon)
+  n_time, n_lev, n_lat = 3, 2, 11
+  lat = np.linspace(-85, 85, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  x = rs.standard_normal((n_time, n_lev, n_lat, n_lon))
+  want, _, _ = spectrum_np.zonal_energy_spectrum(x, lat, lon, 2, 3)
+  circ = torch.as_tensor(spectrum_np.circumference(lat)).to(dev)
+  xd = torch.as_tensor(x, device=dev)
+  got = engine.zonal_spectrum(xd, circ, n_lat)
+  assert got.dtype == torch.float64 and got.shape == want.shape
+  assert _row_rel_err(got.cpu().numpy(), want) < 1e-12
+  mean = engine.zonal_spectrum(xd, circ, n_lat, n_time=n_time, skipna=False)
+  assert _row_rel_err(mean.cpu().numpy(), want.mean(0)) < 1e-12
+  w = plan_lib.get_lat_weights(lat)
+  lat_mean = engine.zonal_spectrum_lat_mean(xd, circ, torch.as_tensor(
+      w, device=dev), n_lat)
+  want_lm = (want * w[None, None, :, None]).sum(2) / w.sum()
+  scale = np.abs(want_lm).max(axis=-1, keepdims=True)
+  np.testing.assert_allclose(lat_mean.cpu().numpy() / scale, want_lm / scale,
+                             atol=1e-12)
+
+
+def test_fused_float64_full_size_and_nan_handling():
+  """A 13 x 721 x 1440 float64 unit (16 B per point in, fp64 spectra out):
+  Parseval per row, NaN rows with and without skipna, determinism."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda')
+  gen = torch.Generator(device=dev).manual_seed(3)
+  n_time, n_lat, n_lon = 2, 721, 1440
+  x = torch.randn((n_time, 4, n_lat, n_lon), generator=gen, device=dev,
+                  dtype=torch.float64)
+  x[1, 2, 100, 7] = float('nan')
+  lat = np.linspace(-90, 90, n_lat)
+  circ = torch.ones(n_lat, dtype=torch.float64, device=dev)
+  spec = engine.zonal_spectrum(x, circ, n_lat)
+  again = engine.zonal_spectrum(x, circ, n_lat)
+  assert torch.equal(torch.nan_to_num(spec, nan=-1.0),
+                     torch.nan_to_num(again, nan=-1.0))
+  # Parseval: sum of the (doubled) bins = mean square of the row (+ the Nyquist
+  # bin counted twice, derived_variables.py:600)
+  row = x[0, 0, 300]
+  f = np.fft.rfft(row.cpu().numpy(), norm='forward')
+  want = (np.abs(f) ** 2) * np.r_[1.0, np.full(n_lon // 2, 2.0)]
+  np.testing.assert_allclose(spec[0, 0, 300].cpu().numpy(), want, rtol=1e-10,
+                             atol=1e-15)
+  assert torch.isnan(spec[1, 2, 100]).all()
+  assert torch.isfinite(spec[1, 2, 99]).all()
+  for skipna in (False, True):
+    mean = engine.zonal_spectrum(x, circ, n_lat, n_time=n_time, skipna=skipna)
+    ref = torch.nanmean(spec, 0) if skipna else spec.mean(0)
+    torch.testing.assert_close(mean, ref, rtol=1e-12, atol=0, equal_nan=True)
+  del lat

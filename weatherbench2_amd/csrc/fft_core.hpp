@@ -27,8 +27,32 @@ namespace fftcore {
 #define WB2_FFT_SLAB_STORE(ptr, value) (*(ptr) = (value))
 #endif
 
-typedef float cf __attribute__((ext_vector_type(2)));   // (re, im)
-typedef float f4 __attribute__((ext_vector_type(4)));
+// complex (re, im) of float (the float32 transform: complex64 like NumPy's
+// rfft of float32 data) or double (float64 rows: complex128)
+template <typename S>
+using cx = S __attribute__((ext_vector_type(2)));
+template <typename S>
+using cx2 = S __attribute__((ext_vector_type(4)));  // two adjacent points
+typedef cx<float> cf;
+typedef cx<double> cd;
+template <typename C>
+struct ScalarOf;
+template <>
+struct ScalarOf<cf> {
+  typedef float type;
+};
+template <>
+struct ScalarOf<cd> {
+  typedef double type;
+};
+template <typename C>
+using scalar_t = typename ScalarOf<C>::type;
+// a literal in the transform's precision: the float32 code keeps its float
+// literals (no double rounding), the float64 code gets the double ones
+template <typename S>
+constexpr S lit(float f, double d) {
+  return sizeof(S) == 4 ? (S)f : (S)d;
+}
 
 constexpr int kLanes = 64;  // a wavefront on gfx950
 
@@ -76,31 +100,41 @@ WB2_HD void static_for(F&& f) {
 }
 
 // ---- complex helpers ---------------------------------------------------------
-WB2_HD cf dup_x(cf a) { return __builtin_shufflevector(a, a, 0, 0); }
-WB2_HD cf dup_y(cf a) { return __builtin_shufflevector(a, a, 1, 1); }
-WB2_HD cf vfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
-WB2_HD cf splat(float s) { return cf{s, s}; }
+template <typename C>
+WB2_HD C dup_x(C a) { return __builtin_shufflevector(a, a, 0, 0); }
+template <typename C>
+WB2_HD C dup_y(C a) { return __builtin_shufflevector(a, a, 1, 1); }
+template <typename C>
+WB2_HD C vfma(C a, C b, C c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename C>
+WB2_HD C splat(scalar_t<C> s) { return C{s, s}; }
 // Multiplications by -i / +i as ONE packed multiply of the swapped operand with a
 // literal sign pair: a half-negated vector (a.y, -a.x) costs hipcc a v_xor and
 // a v_mov, while swaps (op_sel) and literal operands are free.
-WB2_HD cf swap_xy(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
-WB2_HD cf mul_neg_i(cf a) { return swap_xy(a) * cf{1.0f, -1.0f}; }  // a * (-i)
-WB2_HD cf mul_pos_i(cf a) { return swap_xy(a) * cf{-1.0f, 1.0f}; }  // a * (+i)
+template <typename C>
+WB2_HD C swap_xy(C a) { return __builtin_shufflevector(a, a, 1, 0); }
+template <typename C>
+WB2_HD C mul_neg_i(C a) { return swap_xy(a) * C{1, -1}; }  // a * (-i)
+template <typename C>
+WB2_HD C mul_pos_i(C a) { return swap_xy(a) * C{-1, 1}; }  // a * (+i)
 // m + s * (-i) * d  for a real scalar s: one packed FMA
-WB2_HD cf add_neg_i(cf m, cf d, float s) {
-  return vfma(swap_xy(d), cf{s, -s}, m);
+template <typename C>
+WB2_HD C add_neg_i(C m, C d, scalar_t<C> s) {
+  return vfma(swap_xy(d), C{s, -s}, m);
 }
 
 // a * w: one packed multiply + one packed FMA (w and its rotation i*w are
 // separate operands; for compile-time w both are literals)
-WB2_HD cf cmul(cf a, cf w) {
-  const cf wr = {-w.y, w.x};
+template <typename C>
+WB2_HD C cmul(C a, C w) {
+  const C wr = {-w.y, w.x};
   return vfma(dup_y(a), wr, dup_x(a) * w);
 }
 
 // a * exp(-2 pi i M / R) for compile-time M, R
-template <int M, int R>
-WB2_HD cf mul_w(cf a) {
+template <int M, int R, typename C>
+WB2_HD C mul_w(C a) {
+  typedef scalar_t<C> S;
   constexpr int m = ((M % R) + R) % R;
   if constexpr (m == 0) {
     return a;
@@ -111,8 +145,8 @@ WB2_HD cf mul_w(cf a) {
   } else if constexpr (4 * m == 3 * R) {
     return mul_pos_i(a);
   } else {
-    constexpr float c = (float)unit_cos(m, R), s = (float)(-unit_sin(m, R));
-    const cf w = {c, s}, wr = {-s, c};
+    constexpr S c = (S)unit_cos(m, R), s = (S)(-unit_sin(m, R));
+    const C w = {c, s}, wr = {-s, c};
     return vfma(dup_y(a), wr, dup_x(a) * w);
   }
 }
@@ -123,18 +157,22 @@ struct Radix;
 
 template <>
 struct Radix<2> {
-  static WB2_HD void run(cf (&a)[2]) {
-    const cf t = a[0] - a[1];
+  template <typename C>
+  static WB2_HD void run(C (&a)[2]) {
+    const C t = a[0] - a[1];
     a[0] = a[0] + a[1];
     a[1] = t;
   }
 };
 template <>
 struct Radix<3> {
-  static WB2_HD void run(cf (&a)[3]) {
-    constexpr float c = 0.86602540378443864676f;  // sin(pi/3)
-    const cf s = a[1] + a[2], d = a[1] - a[2];
-    const cf m = vfma(splat(-0.5f), s, a[0]);
+  template <typename C>
+  static WB2_HD void run(C (&a)[3]) {
+    typedef scalar_t<C> S;
+    constexpr S c = lit<S>(0.86602540378443864676f,
+                           0.86602540378443864676);  // sin(pi/3)
+    const C s = a[1] + a[2], d = a[1] - a[2];
+    const C m = vfma(splat<C>((S)-0.5), s, a[0]);
     a[0] = a[0] + s;
     a[1] = add_neg_i(m, d, c);
     a[2] = add_neg_i(m, d, -c);
@@ -142,31 +180,37 @@ struct Radix<3> {
 };
 template <>
 struct Radix<4> {
-  static WB2_HD void run(cf (&a)[4]) {
-    const cf t0 = a[0] + a[2], t1 = a[0] - a[2], t2 = a[1] + a[3];
-    const cf d = a[1] - a[3];
+  template <typename C>
+  static WB2_HD void run(C (&a)[4]) {
+    typedef scalar_t<C> S;
+    const C t0 = a[0] + a[2], t1 = a[0] - a[2], t2 = a[1] + a[3];
+    const C d = a[1] - a[3];
     a[0] = t0 + t2;
-    a[1] = add_neg_i(t1, d, 1.0f);
+    a[1] = add_neg_i(t1, d, (S)1);
     a[2] = t0 - t2;
-    a[3] = add_neg_i(t1, d, -1.0f);
+    a[3] = add_neg_i(t1, d, (S)-1);
   }
 };
 template <>
 struct Radix<5> {
-  static WB2_HD void run(cf (&a)[5]) {
-    constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
-    constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-    const cf s14 = a[1] + a[4], d14 = a[1] - a[4];
-    const cf s23 = a[2] + a[3], d23 = a[2] - a[3];
-    const cf m1 = vfma(splat(c2), s23, vfma(splat(c1), s14, a[0]));
-    const cf m2 = vfma(splat(c1), s23, vfma(splat(c2), s14, a[0]));
-    const cf q1 = vfma(splat(s2), d23, splat(s1) * d14);
-    const cf q2 = vfma(splat(-s1), d23, splat(s2) * d14);
+  template <typename C>
+  static WB2_HD void run(C (&a)[5]) {
+    typedef scalar_t<C> S;
+    constexpr S c1 = lit<S>(0.30901699437494742410f, 0.30901699437494742410);
+    constexpr S c2 = lit<S>(-0.80901699437494742410f, -0.80901699437494742410);
+    constexpr S s1 = lit<S>(0.95105651629515357212f, 0.95105651629515357212);
+    constexpr S s2 = lit<S>(0.58778525229247312917f, 0.58778525229247312917);
+    const C s14 = a[1] + a[4], d14 = a[1] - a[4];
+    const C s23 = a[2] + a[3], d23 = a[2] - a[3];
+    const C m1 = vfma(splat<C>(c2), s23, vfma(splat<C>(c1), s14, a[0]));
+    const C m2 = vfma(splat<C>(c1), s23, vfma(splat<C>(c2), s14, a[0]));
+    const C q1 = vfma(splat<C>(s2), d23, splat<C>(s1) * d14);
+    const C q2 = vfma(splat<C>(-s1), d23, splat<C>(s2) * d14);
     a[0] = a[0] + s14 + s23;
-    a[1] = add_neg_i(m1, q1, 1.0f);
-    a[4] = add_neg_i(m1, q1, -1.0f);
-    a[2] = add_neg_i(m2, q2, 1.0f);
-    a[3] = add_neg_i(m2, q2, -1.0f);
+    a[1] = add_neg_i(m1, q1, (S)1);
+    a[4] = add_neg_i(m1, q1, (S)-1);
+    a[2] = add_neg_i(m2, q2, (S)1);
+    a[3] = add_neg_i(m2, q2, (S)-1);
   }
 };
 
@@ -175,11 +219,12 @@ struct Radix<5> {
 //   X[k1 + A k2] = sum_n2 W_B^(n2 k2) W_R^(n2 k1) sum_n1 a[B n1 + n2] W_A^(n1 k1)
 template <int A, int B>
 struct Composite {
-  static WB2_HD void run(cf (&a)[A * B]) {
-    cf y[B][A];
+  template <typename C>
+  static WB2_HD void run(C (&a)[A * B]) {
+    C y[B][A];
     static_for<0, B>([&](auto n2c) {
       constexpr int n2 = decltype(n2c)::value;
-      cf t[A];
+      C t[A];
 #pragma unroll
       for (int n1 = 0; n1 < A; ++n1) t[n1] = a[B * n1 + n2];
       Radix<A>::run(t);
@@ -190,7 +235,7 @@ struct Composite {
     });
 #pragma unroll
     for (int k1 = 0; k1 < A; ++k1) {
-      cf u[B];
+      C u[B];
 #pragma unroll
       for (int n2 = 0; n2 < B; ++n2) u[n2] = y[n2][k1];
       Radix<B>::run(u);
@@ -263,8 +308,9 @@ struct Pass {
   }
 
   // the R - 1 non-trivial twiddles of each of this lane's butterflies
-  static WB2_HD void load_twiddles(const cf* __restrict__ twz, int lane,
-                                   cf (&tw)[ROUNDS][NTW]) {
+  template <typename C>
+  static WB2_HD void load_twiddles(const C* __restrict__ twz, int lane,
+                                   C (&tw)[ROUNDS][NTW]) {
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
       const int j = lane + rd * kLanes;
@@ -276,7 +322,8 @@ struct Pass {
 
   // Compact table of this pass: tbl[(r - 1) KP + k] = exp(-2 pi i k r / (NS R)),
   // filled cooperatively (`tid` of `nthread`), read back per lane and round.
-  static WB2_HD void fill_table(const cf* __restrict__ twz, cf* __restrict__ tbl,
+  template <typename C>
+  static WB2_HD void fill_table(const C* __restrict__ twz, C* __restrict__ tbl,
                                 int tid, int nthread) {
     for (int i = tid; i < (R - 1) * KP; i += nthread) {
       const int r = i / KP + 1, k = i % KP;
@@ -287,9 +334,10 @@ struct Pass {
     const int j = lane + rd * kLanes;
     return (j < T ? j : 0) % NS;
   }
-  static WB2_HD void load_twiddles_table(const cf* __restrict__ tbl,
+  template <typename C>
+  static WB2_HD void load_twiddles_table(const C* __restrict__ tbl,
                                          const int (&row)[ROUNDS],
-                                         cf (&tw)[ROUNDS][NTW]) {
+                                         C (&tw)[ROUNDS][NTW]) {
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
@@ -299,8 +347,8 @@ struct Pass {
   // Lanes without a butterfly in a round re-read the last one's inputs (in
   // range, never stored): unconditional loads keep the wave free of exec
   // branches and of the zero-fills hipcc adds for half-defined registers.
-  template <typename Load>  // Load: index -> cf
-  static WB2_HD void load(const Load& src, int lane, cf (&v)[ROUNDS][R]) {
+  template <typename Load, typename C>  // Load: index -> C
+  static WB2_HD void load(const Load& src, int lane, C (&v)[ROUNDS][R]) {
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
       const int j0 = lane + rd * kLanes;
@@ -312,7 +360,8 @@ struct Pass {
     }
   }
 
-  static WB2_HD void twiddle(cf (&v)[ROUNDS][R], const cf (&tw)[ROUNDS][NTW]) {
+  template <typename C>
+  static WB2_HD void twiddle(C (&v)[ROUNDS][R], const C (&tw)[ROUNDS][NTW]) {
     if constexpr (NS > 1) {
 #pragma unroll
       for (int rd = 0; rd < ROUNDS; ++rd)
@@ -321,23 +370,26 @@ struct Pass {
     }
   }
 
-  static WB2_HD void butterflies(cf (&v)[ROUNDS][R]) {
+  template <typename C>
+  static WB2_HD void butterflies(C (&v)[ROUNDS][R]) {
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) Radix<R>::run(v[rd]);
   }
 
-  static WB2_HD void store(cf* __restrict__ z, int lane,
-                           const cf (&v)[ROUNDS][R]) {
+  template <typename C>
+  static WB2_HD void store(C* __restrict__ z, int lane,
+                           const C (&v)[ROUNDS][R]) {
+    typedef cx2<scalar_t<C>> C2;
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
       const int j = lane + rd * kLanes;
       if (live(lane, rd)) {
         if constexpr (NS == 1 && R % 2 == 0) {
           // the R outputs of a first-pass butterfly are one contiguous run
-          f4* dst = reinterpret_cast<f4*>(z + j * (R + OUT_PAD));
+          C2* dst = reinterpret_cast<C2*>(z + j * (R + OUT_PAD));
 #pragma unroll
           for (int h = 0; h < R / 2; ++h) {
-            f4 w;
+            C2 w;
             w.x = v[rd][2 * h].x;
             w.y = v[rd][2 * h].y;
             w.z = v[rd][2 * h + 1].x;
@@ -371,13 +423,14 @@ constexpr int slab_slots() {
 // `wq` = W^k * (-i) * (0.5 / N) and `half_inv_n` = 0.5 / N carry the factor 1/2
 // and the 1/N of norm='forward'; returns |X[k]|^2 and |X[N2-k]|^2 (float32,
 // like real(f_k * conj(f_k)) of a complex64 transform).
-WB2_HD void recombine_pair(cf a, cf b, cf wq, float half_inv_n, float& p1,
-                           float& p2) {
-  const cf u = vfma(b, cf{1.0f, -1.0f}, a);  // a + conj b
-  const cf v = vfma(b, cf{-1.0f, 1.0f}, a);  // a - conj b
-  const cf wv = cmul(v, wq);
-  const cf x1 = vfma(splat(half_inv_n), u, wv);
-  const cf x2 = vfma(splat(half_inv_n), u, -wv);
+template <typename C>
+WB2_HD void recombine_pair(C a, C b, C wq, scalar_t<C> half_inv_n,
+                           scalar_t<C>& p1, scalar_t<C>& p2) {
+  const C u = vfma(b, C{1, -1}, a);  // a + conj b
+  const C v = vfma(b, C{-1, 1}, a);  // a - conj b
+  const C wv = cmul(v, wq);
+  const C x1 = vfma(splat<C>(half_inv_n), u, wv);
+  const C x2 = vfma(splat<C>(half_inv_n), u, -wv);
   p1 = x1.x * x1.x + x1.y * x1.y;
   p2 = x2.x * x2.x + x2.y * x2.y;
 }
@@ -385,17 +438,19 @@ WB2_HD void recombine_pair(cf a, cf b, cf wq, float half_inv_n, float& p1,
 // The two tables a plan keeps (evaluated in fp64, rounded once):
 //   twz[j] = exp(-2 pi i j / N2)                    j = 0 .. N2-1
 //   twq[k] = exp(-2 pi i k / N) * (-i) * (0.5 / N)  k = 0 .. N2/2
-WB2_HD void table_entry_z(int j, int n2, double cs, double sn, cf& out) {
+template <typename C>
+WB2_HD void table_entry_z(int j, int n2, double cs, double sn, C& out) {
   (void)j;
   (void)n2;
-  out.x = (float)cs;
-  out.y = (float)(-sn);
+  out.x = (scalar_t<C>)cs;
+  out.y = (scalar_t<C>)(-sn);
 }
-WB2_HD void table_entry_q(int n2, double cs, double sn, cf& out) {
+template <typename C>
+WB2_HD void table_entry_q(int n2, double cs, double sn, C& out) {
   // (cs - i sn) * (-i) = -sn - i cs
   const double s = 0.5 / (2.0 * (double)n2);
-  out.x = (float)(-sn * s);
-  out.y = (float)(-cs * s);
+  out.x = (scalar_t<C>)(-sn * s);
+  out.y = (scalar_t<C>)(-cs * s);
 }
 
 }  // namespace fftcore

@@ -33,16 +33,17 @@ namespace wb2 {
 
 // spectrum_fused.hip: single-kernel path (LDS FFT + fused epilogue)
 bool fused_spectrum_supported(int dtype, int n_lon);
-size_t fused_spectrum_table_bytes(int n_lon);
-int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s);
-int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
+size_t fused_spectrum_table_bytes(int dtype, int n_lon);
+int fused_spectrum_tables(void* tables, int dtype, int n_lon, hipStream_t s);
+int fused_spectrum_run(const void* x, int dtype, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
                        int skipna, double* out, void* tables, hipStream_t s);
-int fused_spectrum_latmean_segments(long long n_rows, int n_lon, int n_lat);
-int fused_spectrum_latmean(const float* x, long long n_rows, int n_lon,
-                           const double* row_weight, int n_lat, int n_seg,
-                           double scale, double* partial, double* out,
-                           void* tables, hipStream_t s);
+int fused_spectrum_latmean_segments(int dtype, long long n_rows, int n_lon,
+                                    int n_lat);
+int fused_spectrum_latmean(const void* x, int dtype, long long n_rows,
+                           int n_lon, const double* row_weight, int n_lat,
+                           int n_seg, double scale, double* partial,
+                           double* out, void* tables, hipStream_t s);
 
 namespace {
 
@@ -228,8 +229,10 @@ int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
   if (p->fused) {
     // the twiddle tables are generated once, here (device of the calling
     // thread), instead of by an extra kernel in front of every transform
-    hipError_t e = hipMalloc(&p->tables, fused_spectrum_table_bytes(n_lon));
-    if (e == hipSuccess && fused_spectrum_tables(p->tables, n_lon, nullptr) != 0)
+    hipError_t e =
+        hipMalloc(&p->tables, fused_spectrum_table_bytes(dtype, n_lon));
+    if (e == hipSuccess &&
+        fused_spectrum_tables(p->tables, dtype, n_lon, nullptr) != 0)
       e = hipErrorUnknown;
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -257,8 +260,8 @@ int64_t wb2_spectrum_plan_workspace(void* plan) {
   auto* p = static_cast<wb2::SpectrumPlan*>(plan);
   if (!p) return wb2::fail("null plan");
   size_t tw = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
-  if (p->fused && wb2::fused_spectrum_table_bytes(p->n_lon) > tw)
-    tw = wb2::fused_spectrum_table_bytes(p->n_lon);
+  if (p->fused && wb2::fused_spectrum_table_bytes(p->dtype, p->n_lon) > tw)
+    tw = wb2::fused_spectrum_table_bytes(p->dtype, p->n_lon);
   return (int64_t)(wb2::align_up(p->complex_bytes) +
                    wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw));
 }
@@ -285,9 +288,8 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
   // (the fused time mean keeps its per-bin sample counts in 16 bits)
   if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_time < 65536)
-    return fused_spectrum_run(static_cast<const float*>(x), p->n_rows, p->n_lon,
-                              circumference, n_lat, n_time, skipna, out,
-                              p->tables, s);
+    return fused_spectrum_run(x, p->dtype, p->n_rows, p->n_lon, circumference,
+                              n_lat, n_time, skipna, out, p->tables, s);
   hipfftResult rc = hipfftSetStream(p->fft, s);
   if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
     rc = hipfftSetWorkArea(p->fft, fft_work);
@@ -341,7 +343,7 @@ int wb2_zonal_spectrum_latmean_segments(void* plan, int32_t n_lat) {
   auto* p = static_cast<SpectrumPlan*>(plan);
   WB2_REQUIRE(p && n_lat > 0 && p->n_rows % n_lat == 0, "bad plan / n_lat");
   if (!p->fused) return 0;  // 0: no fused latitude mean for this plan
-  return fused_spectrum_latmean_segments(p->n_rows, p->n_lon, n_lat);
+  return fused_spectrum_latmean_segments(p->dtype, p->n_rows, p->n_lon, n_lat);
 }
 
 int wb2_zonal_spectrum_latmean(void* plan, const void* x,
@@ -356,12 +358,11 @@ int wb2_zonal_spectrum_latmean(void* plan, const void* x,
               "n_rows=%lld is not a multiple of n_lat=%d", p->n_rows, n_lat);
   WB2_REQUIRE(n_seg >= 1 && n_seg <= n_lat, "n_seg=%d outside [1, n_lat]", n_seg);
   WB2_REQUIRE(p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0,
-              "the fused latitude mean needs float32 rows of an instantiated "
+              "the fused latitude mean needs rows of an instantiated "
               "length, 16-byte aligned (materialise with wb2_zonal_spectrum and "
               "reduce with wb2_axis_moments otherwise)");
-  return fused_spectrum_latmean(static_cast<const float*>(x), p->n_rows,
-                                p->n_lon, row_weight, n_lat, n_seg, scale,
-                                partial, out, p->tables,
+  return fused_spectrum_latmean(x, p->dtype, p->n_rows, p->n_lon, row_weight,
+                                n_lat, n_seg, scale, partial, out, p->tables,
                                 static_cast<hipStream_t>(stream));
 }
 

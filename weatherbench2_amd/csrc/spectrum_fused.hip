@@ -25,8 +25,10 @@
 //     circumference in fp64) and stored -- or, with TIME, summed in registers
 //     over the wave's n_time rows (the time mean of
 //     scripts/compute_zonal_energy_spectrum.py:234) and stored once.
-// Twiddles come from two small fp32 tables (evaluated in fp64, rounded once)
-// that the plan owns.
+// Twiddles come from two small tables in the row dtype (evaluated in fp64,
+// rounded once) that the plan owns.  float64 rows run the same code on
+// complex128 points (no packed arithmetic: twice the VALU instructions, twice
+// the LDS).
 
 #include "common.hpp"
 
@@ -34,9 +36,13 @@
 // SIMD, tools/valu_rate.hip) instead of the ds_write2_b64 pairs hipcc's
 // load/store optimiser makes of them (44): volatile stores in address space 3
 #if defined(__HIP_DEVICE_COMPILE__)
-#define WB2_FFT_SLAB_STORE(ptr, value)                                         \
-  (*(__attribute__((address_space(3))) volatile ::wb2::fftcore::cf*)(ptr) = \
-       (value))
+namespace wb2 {
+template <typename C>
+__device__ __forceinline__ void fused_slab_store(C* p, C v) {
+  *(__attribute__((address_space(3))) volatile C*)p = v;
+}
+}  // namespace wb2
+#define WB2_FFT_SLAB_STORE(ptr, value) ::wb2::fused_slab_store(ptr, value)
 #endif
 #include "fft_core.hpp"
 #include "wb2hip.h"
@@ -118,21 +124,31 @@ __device__ __forceinline__ void twiddle_block(cf* v, const cf* tw) {
   }
 }
 
-// One 8-byte read from the wave's LDS slab (or the shared twiddle table).
-__device__ __forceinline__ cf lds_read(const cf* p) {
+// float64 rows: plain complex multiplies (v_mul_f64 / v_fma_f64; there is no
+// packed float64 arithmetic to hand-schedule)
+template <int N>
+__device__ __forceinline__ void twiddle_block(cd* v, const cd* tw) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = cmul(v[i], tw[i]);
+}
+
+// One read of a complex point from the wave's LDS slab (or the shared twiddle
+// table): 8 bytes for float32 rows, 16 for float64 ones.
+template <typename C>
+__device__ __forceinline__ C lds_read(const C* p) {
   // its own ds_read_b64: hipcc's load/store optimiser otherwise pairs the
   // 8-byte slab reads into ds_read2_b64 / ds_read2st64_b64, which gfx950
   // services at 44 cycles per wave-instruction against 6.4 for a ds_read_b64
   // (tools/valu_rate.hip); volatile in address space 3 is the one thing the
   // optimiser does not merge
-  typedef __attribute__((address_space(3))) const volatile cf* lds_ptr;
+  typedef __attribute__((address_space(3))) const volatile C* lds_ptr;
   return *(lds_ptr)p;
 }
 
 struct FusedParams {
-  const float* x;
-  const cf* twz;   // [N2]      exp(-2 pi i j / N2)
-  const cf* twq;   // [N2/2+1]  exp(-2 pi i k / N) * (-i) * (0.5 / N)
+  const void* x;     // float or double rows
+  const void* twz;   // [N2]      exp(-2 pi i j / N2), complex of the row dtype
+  const void* twq;   // [N2/2+1]  exp(-2 pi i k / N) * (-i) * (0.5 / N)
   const double* circ;  // MATERIALISE / TIME: circumference[n_lat];
                        // LATSEG: row weight[n_lat] = circumference x latitude weight
   double* out;         // MATERIALISE / TIME: spectra; LATSEG: partial[n_field][n_seg][N2+1]
@@ -146,10 +162,10 @@ struct FusedParams {
 // A later pass (NS > 1) over the wave's slab: strided reads, twiddle multiplies
 // (the twiddles of a lane depend on the lane only: VGPR-resident for the whole
 // kernel), butterflies, in-place writes.
-template <typename P, int R>
-__device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
-                                         cf (&tw)[P::ROUNDS][R - 1]) {
-  cf v[P::ROUNDS][R];
+template <typename P, int R, typename C>
+__device__ __forceinline__ void lds_pass(C* __restrict__ z, int lane,
+                                         C (&tw)[P::ROUNDS][R - 1]) {
+  C v[P::ROUNDS][R];
   P::load([&](int i) { return lds_read(z + i); }, lane, v);
 #pragma unroll
   for (int rd = 0; rd < P::ROUNDS; ++rd)
@@ -177,9 +193,11 @@ __device__ __forceinline__ void lds_pass(cf* __restrict__ z, int lane,
 //                field are added in segment order by latseg_combine_kernel).
 enum { MATERIALISE = 0, TIME_MEAN = 1, LATSEG = 2 };
 
-template <int N2, int MODE>
+template <int N2, int MODE, typename S = float>
 __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE)
     fused_spectrum_kernel(const FusedParams p) {
+  typedef cx<S> C;    // one complex point
+  typedef cx2<S> C2;  // two adjacent ones
   using PL = Plan<N2>;
   constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2;
   using P0 = Pass<N2, R0, 1, 1, 0, PL::PAD0>;
@@ -189,19 +207,28 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE)
   constexpr int NH = N2 / 2 + 1;  // bin pairs (k, N2 - k), k = 0..N2/2
   constexpr int NIT = (NH + kWave - 1) / kWave;
   constexpr bool REDUCE = MODE != MATERIALISE;
-  __shared__ __attribute__((aligned(16))) cf s_twq[NH + 1];
-  __shared__ __attribute__((aligned(16))) cf s_z[NWAVE][slab_slots<N2>()];
+  __shared__ __attribute__((aligned(16))) C s_twq[NH + 1];
+  __shared__ __attribute__((aligned(16))) C s_z[NWAVE][slab_slots<N2>()];
+  const C* g_twz = static_cast<const C*>(p.twz);
+  const C* g_twq = static_cast<const C*>(p.twq);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   for (int i = threadIdx.x; i <= NH; i += blockDim.x)
-    s_twq[i] = p.twq[i < NH ? i : NH - 1];
+    s_twq[i] = g_twq[i < NH ? i : NH - 1];
   // inter-pass twiddles: functions of the lane only, resident in VGPRs
-  cf tw1[P1::ROUNDS][P1::NTW], tw2[P2::ROUNDS][P2::NTW];
-  P1::load_twiddles(p.twz, lane, tw1);
-  if constexpr (R2 > 1) P2::load_twiddles(p.twz, lane, tw2);
+  // float32: resident in VGPRs for the whole kernel.  float64: twice the
+  // registers (92 for 720 points) -- they are fetched again for every row,
+  // right before the pass that uses them (the 11.5 KB table stays in L1 / L2),
+  // so that a pass's twiddles and its butterfly inputs share the registers
+  constexpr bool RESIDENT_TW = sizeof(S) == 4;
+  C tw1[P1::ROUNDS][P1::NTW], tw2[P2::ROUNDS][P2::NTW];
+  if constexpr (RESIDENT_TW) {
+    P1::load_twiddles(g_twz, lane, tw1);
+    if constexpr (R2 > 1) P2::load_twiddles(g_twz, lane, tw2);
+  }
   __syncthreads();
-  cf* z = s_z[wave];
-  const float half_inv_n = 0.5f / (float)N;
+  C* z = s_z[wave];
+  const S half_inv_n = (S)0.5 / (S)N;
   // output rows (MATERIALISE: = input rows; TIME: n_rows / n_time; LATSEG:
   // (field, segment) pairs) and the input rows each one reduces
   long long rows_out;
@@ -251,17 +278,29 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE)
       if constexpr (MODE == LATSEG) c = p.circ[lat0 + t * row_step];
       const double c2 = 2.0 * c;
       {  // ---- pass 0: HBM -> butterflies -> contiguous runs in the slab
-        cf v[P0::ROUNDS][R0];
-        const cf* src =
-            reinterpret_cast<const cf*>(p.x + (row0 + t * row_step) * N);
+        C v[P0::ROUNDS][R0];
+        const C* src = reinterpret_cast<const C*>(
+            static_cast<const S*>(p.x) + (row0 + t * row_step) * N);
         P0::load([&](int i) { return WB2_FFT_LOAD(src + i); },
                  lane, v);
         P0::butterflies(v);
         P0::store(z, lane, v);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
+      if constexpr (!RESIDENT_TW) {
+        const C* tz = g_twz;
+        asm volatile("" : "+s"(tz));  // per row: not hoisted out of the loop
+        P1::load_twiddles(tz, lane, tw1);
+      }
       lds_pass<P1, R1>(z, lane, tw1);
-      if constexpr (R2 > 1) lds_pass<P2, R2>(z, lane, tw2);
+      if constexpr (R2 > 1) {
+        if constexpr (!RESIDENT_TW) {
+          const C* tz = g_twz;
+          asm volatile("" : "+s"(tz));
+          P2::load_twiddles(tz, lane, tw2);
+        }
+        lds_pass<P2, R2>(z, lane, tw2);
+      }
       if constexpr (!REDUCE) {
         // ---- materialising kernel: a lane owns the ADJACENT bins k0, k0 + 1
         // (and their mirrors N2 - k0, N2 - k0 - 1), so the fp64 spectrum leaves
@@ -273,14 +312,14 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE)
         for (int i = 0; i < NIT2; ++i) {
           const int k0 = 2 * lane + i * 2 * kWave;
           if (k0 <= N2 / 2) {
-            const f4 a01 = *reinterpret_cast<const f4*>(z + k0);
-            const cf a0 = {a01.x, a01.y}, a1 = {a01.z, a01.w};
-            const cf b0 = lds_read(z + ((i == 0 && k0 == 0) ? 0 : N2 - k0));
-            const cf b1 = lds_read(z + (N2 - k0 - 1));
-            const f4 w01 = *reinterpret_cast<const f4*>(s_twq + k0);
-            float p1a, p2a, p1b, p2b;
-            recombine_pair(a0, b0, cf{w01.x, w01.y}, half_inv_n, p1a, p2a);
-            recombine_pair(a1, b1, cf{w01.z, w01.w}, half_inv_n, p1b, p2b);
+            const C2 a01 = *reinterpret_cast<const C2*>(z + k0);
+            const C a0 = {a01.x, a01.y}, a1 = {a01.z, a01.w};
+            const C b0 = lds_read(z + ((i == 0 && k0 == 0) ? 0 : N2 - k0));
+            const C b1 = lds_read(z + (N2 - k0 - 1));
+            const C2 w01 = *reinterpret_cast<const C2*>(s_twq + k0);
+            S p1a, p2a, p1b, p2b;
+            recombine_pair(a0, b0, C{w01.x, w01.y}, half_inv_n, p1a, p2a);
+            recombine_pair(a1, b1, C{w01.z, w01.w}, half_inv_n, p1b, p2b);
             // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
             const double v1a = (double)p1a * ((i == 0 && k0 == 0) ? c : c2);
             const double v1b = (double)p1b * c2;
@@ -301,9 +340,9 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE)
         for (int i = 0; i < NIT; ++i) {
           const int k = lane + i * kWave;
           if ((i + 1) * kWave <= NH || k < NH) {
-            const cf a = lds_read(z + k);
-            const cf b = lds_read(z + ((i == 0 && k == 0) ? 0 : N2 - k));
-            float p1, p2;
+            const C a = lds_read(z + k);
+            const C b = lds_read(z + ((i == 0 && k == 0) ? 0 : N2 - k));
+            S p1, p2;
             recombine_pair(a, b, lds_read(s_twq + k), half_inv_n, p1, p2);
             // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
             const double v1 = (double)p1 * ((i == 0 && k == 0) ? c : c2);
@@ -370,7 +409,8 @@ __global__ void latseg_combine_kernel(const double* __restrict__ partial,
   out[i] = s * scale;
 }
 
-__global__ void fused_twiddle_kernel(cf* twz, cf* twq, int n2) {
+template <typename C>
+__global__ void fused_twiddle_kernel(C* twz, C* twq, int n2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double sn, cs;
   if (i < n2) {
@@ -401,7 +441,7 @@ int resident_blocks(K kernel) {
   return cached;
 }
 
-template <int N2>
+template <int N2, typename S>
 int launch(const FusedParams& p, int mode, hipStream_t s) {
   long long rows_out = p.n_rows;
   if (mode == TIME_MEAN) rows_out = p.n_rows / p.n_time;
@@ -413,13 +453,13 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
   if (blocks > WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE)
     blocks = WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE;
   if (mode == TIME_MEAN)
-    hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN>),
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN, S>),
                        dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
   else if (mode == LATSEG)
-    hipLaunchKernelGGL((fused_spectrum_kernel<N2, LATSEG>),
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, LATSEG, S>),
                        dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
   else
-    hipLaunchKernelGGL((fused_spectrum_kernel<N2, MATERIALISE>),
+    hipLaunchKernelGGL((fused_spectrum_kernel<N2, MATERIALISE, S>),
                        dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
@@ -427,10 +467,10 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
 
 // Latitude segments per field such that all (field, segment) tasks are resident
 // at once (one task per wave, no second round).
-template <int N2>
+template <int N2, typename S>
 int latseg_segments(long long n_field, int n_lat) {
   const long long waves = (long long)WB2_FFT_NWAVE *
-                          resident_blocks(fused_spectrum_kernel<N2, LATSEG>);
+                          resident_blocks(fused_spectrum_kernel<N2, LATSEG, S>);
   // WB2HIP_LATSEG_ROUNDS (A/B runs): tasks = that many times the resident waves
   static const double rounds = [] {
     const char* e = getenv("WB2HIP_LATSEG_ROUNDS");
@@ -447,56 +487,88 @@ int latseg_segments(long long n_field, int n_lat) {
 }  // namespace fused
 
 // Entry points used by spectrum.hip ------------------------------------------
+#define WB2_FUSED_SIZES(X) \
+  X(32) X(64) X(120) X(128) X(180) X(256) X(360) X(512) X(720)
+
 bool fused_spectrum_supported(int dtype, int n_lon) {
-  if (dtype != WB2_F32 || n_lon % 2) return false;
+  if ((dtype != WB2_F32 && dtype != WB2_F64) || n_lon % 2) return false;
   switch (n_lon / 2) {
-    case 32: case 64: case 120: case 128: case 180: case 256: case 360:
-    case 512: case 720:
+#define WB2_CASE(N2) case N2:
+    WB2_FUSED_SIZES(WB2_CASE)
+#undef WB2_CASE
       return true;
   }
   return false;
 }
 
-size_t fused_spectrum_table_bytes(int n_lon) {
-  return (size_t)(n_lon / 2 + n_lon / 4 + 1) * sizeof(fused::cf);
+size_t fused_spectrum_table_bytes(int dtype, int n_lon) {
+  return (size_t)(n_lon / 2 + n_lon / 4 + 1) *
+         (dtype == WB2_F32 ? sizeof(fused::cf) : sizeof(fused::cd));
 }
 
-// Fills the two twiddle tables (fused_spectrum_table_bytes(n_lon) bytes at
-// `tables`); the plan does this once at creation and owns the memory.
-int fused_spectrum_tables(void* tables, int n_lon, hipStream_t s) {
+// Fills the two twiddle tables (fused_spectrum_table_bytes(dtype, n_lon) bytes
+// at `tables`, complex of the row dtype, evaluated in fp64); the plan does this
+// once at creation and owns the memory.
+int fused_spectrum_tables(void* tables, int dtype, int n_lon, hipStream_t s) {
   using namespace fused;
   const int n2 = n_lon / 2;
-  cf* twz = static_cast<cf*>(tables);
-  hipLaunchKernelGGL(fused_twiddle_kernel, dim3((unsigned)((n2 + 255) / 256)),
-                     dim3(256), 0, s, twz, twz + n2, n2);
+  const dim3 grid((unsigned)((n2 + 255) / 256));
+  if (dtype == WB2_F32) {
+    cf* twz = static_cast<cf*>(tables);
+    hipLaunchKernelGGL(fused_twiddle_kernel<cf>, grid, dim3(256), 0, s, twz,
+                       twz + n2, n2);
+  } else {
+    cd* twz = static_cast<cd*>(tables);
+    hipLaunchKernelGGL(fused_twiddle_kernel<cd>, grid, dim3(256), 0, s, twz,
+                       twz + n2, n2);
+  }
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }
 
-int fused_spectrum_run(const float* x, long long n_rows, int n_lon,
+namespace fused {
+// (twz, twq) inside the plan's table block
+inline void table_pointers(void* tables, int dtype, int n2, const void** twz,
+                           const void** twq) {
+  *twz = tables;
+  *twq = static_cast<char*>(tables) +
+         (size_t)n2 * (dtype == WB2_F32 ? sizeof(cf) : sizeof(cd));
+}
+
+template <typename S>
+int launch_size(const FusedParams& p, int n2, int mode, hipStream_t s) {
+  switch (n2) {
+#define WB2_CASE(N2) case N2: return launch<N2, S>(p, mode, s);
+    WB2_FUSED_SIZES(WB2_CASE)
+#undef WB2_CASE
+  }
+  return fail("fused spectrum: n_lon=%d is not instantiated", 2 * n2);
+}
+}  // namespace fused
+
+int fused_spectrum_run(const void* x, int dtype, long long n_rows, int n_lon,
                        const double* circ, int n_lat, long long n_time,
                        int skipna, double* out, void* tables, hipStream_t s) {
   using namespace fused;
   const int n2 = n_lon / 2;
-  cf* twz = static_cast<cf*>(tables);  // filled once by fused_spectrum_tables
-  cf* twq = twz + n2;
-  FusedParams p{x, twz, twq, circ, out, n_rows, n_time, n_lat, 0, skipna};
+  FusedParams p{x, nullptr, nullptr, circ, out, n_rows, n_time, n_lat, 0,
+                skipna};
+  table_pointers(tables, dtype, n2, &p.twz, &p.twq);
   const int mode = n_time > 0 ? TIME_MEAN : MATERIALISE;
-  switch (n2) {
-#define WB2_CASE(N2) case N2: return launch<N2>(p, mode, s);
-    WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
-    WB2_CASE(256) WB2_CASE(360) WB2_CASE(512) WB2_CASE(720)
-#undef WB2_CASE
-  }
-  return fail("fused spectrum: n_lon=%d is not instantiated", n_lon);
+  return dtype == WB2_F32 ? launch_size<float>(p, n2, mode, s)
+                          : launch_size<double>(p, n2, mode, s);
 }
 
-int fused_spectrum_latmean_segments(long long n_rows, int n_lon, int n_lat) {
+int fused_spectrum_latmean_segments(int dtype, long long n_rows, int n_lon,
+                                    int n_lat) {
   using namespace fused;
   switch (n_lon / 2) {
-#define WB2_CASE(N2) case N2: return latseg_segments<N2>(n_rows / n_lat, n_lat);
-    WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
-    WB2_CASE(256) WB2_CASE(360) WB2_CASE(512) WB2_CASE(720)
+#define WB2_CASE(N2)                                                      \
+  case N2:                                                                \
+    return dtype == WB2_F32                                               \
+               ? latseg_segments<N2, float>(n_rows / n_lat, n_lat)       \
+               : latseg_segments<N2, double>(n_rows / n_lat, n_lat);
+    WB2_FUSED_SIZES(WB2_CASE)
 #undef WB2_CASE
   }
   return 1;
@@ -505,24 +577,17 @@ int fused_spectrum_latmean_segments(long long n_rows, int n_lon, int n_lat) {
 // out[field][bin] = scale * sum_lat row_weight[lat] * spectrum[field][lat][bin]
 // (row_weight = circumference x latitude weight), partial[n_field][n_seg][bins]
 // is scratch.
-int fused_spectrum_latmean(const float* x, long long n_rows, int n_lon,
-                           const double* row_weight, int n_lat, int n_seg,
-                           double scale, double* partial, double* out,
-                           void* tables, hipStream_t s) {
+int fused_spectrum_latmean(const void* x, int dtype, long long n_rows,
+                           int n_lon, const double* row_weight, int n_lat,
+                           int n_seg, double scale, double* partial,
+                           double* out, void* tables, hipStream_t s) {
   using namespace fused;
   const int n2 = n_lon / 2;
-  cf* twz = static_cast<cf*>(tables);
-  cf* twq = twz + n2;
-  FusedParams p{x, twz, twq, row_weight, partial, n_rows, 0, n_lat, n_seg, 0};
-  int rc = -1;
-  switch (n2) {
-#define WB2_CASE(N2) case N2: rc = launch<N2>(p, LATSEG, s); break;
-    WB2_CASE(32) WB2_CASE(64) WB2_CASE(120) WB2_CASE(128) WB2_CASE(180)
-    WB2_CASE(256) WB2_CASE(360) WB2_CASE(512) WB2_CASE(720)
-#undef WB2_CASE
-    default:
-      return fail("fused spectrum: n_lon=%d is not instantiated", n_lon);
-  }
+  FusedParams p{x, nullptr, nullptr, row_weight, partial, n_rows, 0, n_lat,
+                n_seg, 0};
+  table_pointers(tables, dtype, n2, &p.twz, &p.twq);
+  const int rc = dtype == WB2_F32 ? launch_size<float>(p, n2, LATSEG, s)
+                                  : launch_size<double>(p, n2, LATSEG, s);
   if (rc != 0) return rc;
   const long long n_field = n_rows / n_lat, n = n_field * (n2 + 1);
   hipLaunchKernelGGL(latseg_combine_kernel, dim3((unsigned)((n + 255) / 256)),
