@@ -1,20 +1,37 @@
-set -x
+# The evidence of a round, collected on the GPU box into gpurun_out/profiles_rNN/
+# (copy what is to be judged into profiles/):
+#   bash tools/round_profile.sh r04 [quick]
+# * the default bench line (what the driver runs), the official-chunk leg and the
+#   K3 variants as JSON;
+# * rocprofv3 --kernel-trace --stats summaries of the default command and of
+#   every --workload (the average kernel durations the bench line's rooflines
+#   must agree with);
+# * the PMC traffic of every benched kernel (tools/live_traffic.py, separate
+#   --pmc passes, --kernel-trace only).
+R=${1:-r04}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/pytest_gpu.txt; cat gpurun_out/pytest_gpu.txt
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+OUT=gpurun_out/profiles_$R
+mkdir -p $OUT
 export TMPDIR=/tmp
-for w in deterministic ensemble spectrum; do
-  extra=""; [ $w != deterministic ] && extra="--workload $w"
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$w -o run -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $extra > $GRAFT_REPO_ROOT/gpurun_out/prof_$w.log 2>&1)
-  f=$(find gpurun_out/prof_$w -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f" > gpurun_out/stats_$w.csv
-  tail -1 gpurun_out/prof_$w.log | cut -c1-300
-  rm -rf gpurun_out/prof_$w
-done
-timeout 200 python bench.py --workload ensemble --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_ens.json
-timeout 200 python bench.py --workload spectrum --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_spec.json
-timeout 200 python bench.py --workload spectrum_mean --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_spec_mean.json
-timeout 300 python bench.py --pcie 2>/dev/null | tail -1 > gpurun_out/bench_det.json
-timeout 200 python tools/api_throughput.py 2>&1 | grep -v amdgpu | head -5 > gpurun_out/api_throughput.txt
-timeout 200 python tools/axis_bench.py 2>&1 | grep -v amdgpu > gpurun_out/axis_bench.txt
-cat gpurun_out/bench_det.json | cut -c1-300; cat gpurun_out/api_throughput.txt; cat gpurun_out/bench_spec_mean.json | cut -c1-200; cat gpurun_out/bench_ens.json | cut -c1-200; cat gpurun_out/bench_spec.json | cut -c1-200; cat gpurun_out/axis_bench.txt
+( time timeout 900 python bench.py > $OUT/${R}_bench_default_line.json 2> $OUT/bench.err ) 2>&1 | grep real
+timeout 600 python tools/live_traffic.py --workload all > $OUT/${R}_live_traffic.json 2>> $OUT/bench.err
+stats() {  # name, bench args...
+  name=$1; shift
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o run -- python $GRAFT_REPO_ROOT/bench.py "$@" > $GRAFT_REPO_ROOT/$OUT/prof_$name.log 2>&1)
+  f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && head -25 "$f" > $OUT/${R}_${name}_kernel_stats.csv
+  rm -rf /tmp/prof_$name
+}
+stats default --no-pmc --no-cpu-baseline
+if [ "$2" != quick ]; then
+  stats deterministic --no-pmc --no-cpu-baseline --no-secondary --no-api --no-pcie --no-full-suite
+  for w in ensemble spectrum spectrum_materialized spectrum_mean; do
+    stats $w --workload $w --no-cpu-baseline
+    timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${R}_bench_$w.json
+  done
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_oc -o run -- python $GRAFT_REPO_ROOT/tools/official_chunk.py --chunks 256 --batch 32 > $GRAFT_REPO_ROOT/$OUT/${R}_official_chunk_batch32.json 2>/dev/null)
+  f=$(find /tmp/prof_oc -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -25 "$f" > $OUT/${R}_official_chunk_kernel_stats.csv; rm -rf /tmp/prof_oc
+  timeout 600 python tools/official_chunk.py > $OUT/${R}_official_chunk.json 2>/dev/null
+  timeout 600 python tools/k3_variants.py > $OUT/${R}_k3_variants.json 2>/dev/null
+fi
+ls -la $OUT
