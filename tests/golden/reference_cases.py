@@ -553,7 +553,7 @@ def f32_coordinate_case_era5(seed=84):
   """The same at the real size: one 0.25-degree grid (721 x 1440) with float32
   coordinates, (time, level, latitude, longitude) float32 data -- a million
   points per spatial sum, where the reference's float32 einsum shows its
-  summation noise (DESIGN.md 4 records the measured deviation)."""
+  summation noise (profiles/NOTES.md 4 records the measured deviation)."""
   rs = np.random.RandomState(seed)
   n_time, levels = 2, np.array([500])
   sshape = (len(LAT025), len(LON025))

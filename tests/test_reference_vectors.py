@@ -73,13 +73,13 @@ ORACLE_TOL = dict(rtol=1e-12, atol=1e-13)
 # float32 latitude / longitude coordinates (0.25-degree ERA5): the reference's
 # weights are float32, its spatial sums accumulate in float32 and it RETURNS
 # float32 (recorded in the vectors' dtype).  The oracle mirrors that; the product
-# uses the same float32-valued weights but sums and returns float64
+# uses the same float32-valued weights but sums and returns float64 (profiles/NOTES.md 4)
 # -- both agree with the reference to float32 summation noise.
 F32_COORD_TOL = dict(rtol=5e-5, atol=5e-6)
 # The same at 721 x 1440 (a million points per sum): two float32 evaluations of
 # the reference's expression that differ only in summation order -- the
 # stand-in's dot (what the vectors hold) and the oracle's einsum -- are 1e-4
-# apart (ACC / MSE, global region; measured: DESIGN.md 4), while the float64
+# apart (ACC / MSE, global region; measured: profiles/NOTES.md 4), while the float64
 # sums of the product sit within 1e-6 of the stand-in's.  The reference's
 # float32 number is only defined to that noise.
 F32_COORD_TOL_ERA5 = dict(rtol=3e-4, atol=5e-6)

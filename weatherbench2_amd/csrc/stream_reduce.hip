@@ -297,7 +297,7 @@ __device__ __forceinline__ void eval_slots(
   }
 }
 
-// Tuning knobs (defaults are the measured best; see DESIGN.md / profiles/).
+// Tuning knobs (defaults are the measured best; see profiles/NOTES.md).
 #ifndef WB2_U_ROWS
 #define WB2_U_ROWS 2
 #endif

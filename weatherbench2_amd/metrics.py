@@ -1068,7 +1068,7 @@ def _reference_result_dtype(forecast: xl.Dataset, data_dtypes, region,
   regions concatenates along `region` (evaluation.py:430): NumPy promotion over
   the regions' dtypes.  The VALUES here are the float64 sums of the fused pass
   rounded once to that dtype (the reference's float32 einsum carries ~1e-5 of
-  summation noise at 10^6 points)."""
+  summation noise at 10^6 points; see profiles/NOTES.md 4)."""
   st = _ANNOUNCED
   data_dtypes = tuple(data_dtypes)
   memo_key = None
