@@ -89,22 +89,20 @@ def _metric_and_region_loop(
         regions_fn = (metric.compute_chunk_regions
                       if eval_fn == metric.compute_chunk
                       else metric.compute_regions)
-        result = xl.as_dataset(regions_fn(
-            forecast, truth, regions, skipna)).expand_dims({'metric': [name]})
+        result = xl.as_dataset(regions_fn(forecast, truth, regions, skipna))
       elif regions is not None:
         tmp_results = []
         for region_name, region in regions.items():
           tmp_result = xl.as_dataset(eval_fn(
               forecast=forecast, truth=truth, region=region, skipna=skipna))
-          tmp_results.append(tmp_result.expand_dims(
-              {'metric': [name], 'region': [region_name]}))
+          tmp_results.append(tmp_result.expand_dims({'region': [region_name]}))
         result = xl.concat(tmp_results, 'region')
       else:
         result = xl.as_dataset(eval_fn(
-            forecast=forecast, truth=truth, skipna=skipna)).expand_dims(
-                {'metric': [name]})
-      results.append(result)
-  return xl.like_input(xl.merge(results), given_forecast, given_truth)
+            forecast=forecast, truth=truth, skipna=skipna))
+      results.append((name, result))
+  # expand_dims({'metric': name}) + xr.merge of :424-437, in one step
+  return xl.like_input(xl.merge_metrics(results), given_forecast, given_truth)
 
 
 def _wind_pairs(eval_config) -> list:

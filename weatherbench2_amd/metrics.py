@@ -895,8 +895,23 @@ def _det_plan(forecast, truth, name, climatology):
 
 
 def _det_key(forecast, truth, name, region, skipna):
-  return _result_key('det', [forecast[name].data, truth[name].data], region,
-                     skipna, (forecast, truth))
+  st = _ANNOUNCED
+  if st.depth == 0:
+    return _result_key('det', [forecast[name].data, truth[name].data], region,
+                       skipna, (forecast, truth))
+  # inside a chunk scope the key of (datasets, variable, region, announcement)
+  # is computed once: a loop asks for it once per metric and variable
+  announced = st.regions[-1] if st.regions else None
+  memo_key = ('det_key', id(forecast), id(truth), name, id(region),
+              id(announced), bool(skipna))
+  hit = st.memo.get(memo_key)
+  if hit is not None and hit[0] is forecast and hit[1] is truth and (
+      hit[2] is region and hit[3] is announced):
+    return hit[4]
+  key = _result_key('det', [forecast[name].data, truth[name].data], region,
+                    skipna, (forecast, truth))
+  st.memo[memo_key] = (forecast, truth, region, announced, key)
+  return key
 
 
 def _det_pass(forecast, truth, name, region, skipna, climatology=None):

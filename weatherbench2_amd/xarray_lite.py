@@ -557,6 +557,69 @@ def concat(datasets: t.Sequence[Dataset], dim: str) -> Dataset:
   return out
 
 
+def merge_metrics(named: t.Sequence[tuple]) -> Dataset:
+  """`merge([ds.expand_dims({'metric': [name]}) for name, ds in named])`
+  (evaluation.py:424-437) in one step: every variable of the result is ONE
+  stack of the per-metric arrays along a new leading `metric` dim (NaN-filled
+  where a metric lacks the variable), labels in the order xarray's outer join
+  gives them.  No per-metric unsqueeze / select views on the way."""
+  names = [n for n, _ in named]
+  if len(set(names)) != len(names):
+    return merge([d.expand_dims({'metric': [n]}) for n, d in named])
+  labels = list(names)
+  if len(labels) > 1:
+    # xarray's outer join is pandas' Index.union: sorted (see `merge`)
+    try:
+      labels = sorted(labels)
+    except TypeError:
+      pass
+  by_label = dict(named)
+  variables: list = []
+  for _, d in named:
+    variables += [k for k in d.data_vars if k not in variables]
+  coords = {}
+  for _, d in named:
+    for k, v in d.coords.items():
+      coords.setdefault(k, v)
+  coords['metric'] = np.array(labels, dtype=object)
+  out = Dataset(coords=coords)
+  as_np = lambda dt: np.dtype(str(dt).replace('torch.', ''))
+  for var in variables:
+    holders = [by_label[m].data_vars.get(var) for m in labels]
+    have = [h for h in holders if h is not None]
+    ref = have[0]
+    dtype = np.result_type(*[as_np(h.dtype) for h in have])
+    if dtype.kind != 'f':
+      dtype = np.dtype(np.float64)
+    on_device = all(_is_torch(h.data) for h in have)
+    rows = []
+    for h in holders:
+      if h is None:
+        rows.append(None)
+        continue
+      if h.dims != ref.dims:  # xarray aligns by name: same dims, other order
+        if sorted(h.dims) != sorted(ref.dims):
+          raise ValueError(f'{var}: cannot merge dims {h.dims} with {ref.dims}')
+        h = h.transpose(*ref.dims)
+      rows.append(h.data if on_device else h.values)
+    if on_device:
+      import torch
+      tdtype = getattr(torch, dtype.name)
+      if any(r is None for r in rows):
+        hole = torch.full(ref.shape, float('nan'), dtype=tdtype,
+                          device=ref.data.device)
+        rows = [hole if r is None else r for r in rows]
+      data = torch.stack([r if r.dtype == tdtype else r.to(tdtype)
+                          for r in rows])
+    else:
+      data = np.full((len(labels),) + ref.shape, np.nan, dtype=dtype)
+      for i, r in enumerate(rows):
+        if r is not None:
+          data[i] = r
+    out.data_vars[var] = DataArray(data, ('metric',) + ref.dims, coords, var)
+  return out
+
+
 def merge(datasets: t.Sequence[Dataset]) -> Dataset:
   """xr.merge of results that differ along `metric` (evaluation.py:437).
 
