@@ -178,3 +178,58 @@ def test_addr_entry_point_equals_the_slab_table_one():
                                      list(addr), True, n, False)
   assert torch.equal(got, want)
   del step
+
+
+def test_batching_with_metrics_that_materialise():
+  """Ensemble, spatial-map and Gaussian metrics do not read address tables:
+  a concatenated window is materialised for them (one cat + index_select) and
+  the result equals chunk-by-chunk evaluation."""
+  import torch
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  dev = torch.device('cuda', 0)
+  rs = np.random.RandomState(4)
+  n_init, n_lead, n_mem, n_lat, n_lon = 4, 2, 5, 19, 36
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  init = (np.datetime64('2020-01-01T00', 'ns') +
+          np.arange(n_init) * np.timedelta64(12, 'h'))
+  lead = (np.arange(n_lead) * np.timedelta64(6, 'h')).astype('timedelta64[ns]')
+  chunks = []
+  for i in range(n_init):
+    for l in range(n_lead):
+      coords = {'init_time': init[i:i + 1], 'lead_time': lead[l:l + 1],
+                'realization': np.arange(n_mem), 'latitude': lat,
+                'longitude': lon}
+      f = xl.Dataset({'z': xl.DataArray(
+          torch.as_tensor(rs.normal(size=(1, 1, n_mem, n_lat, n_lon)).astype(
+              np.float32), device=dev),
+          ('init_time', 'lead_time', 'realization', 'latitude', 'longitude'))},
+                     coords)
+      tc = {k: v for k, v in coords.items() if k != 'realization'}
+      t = xl.Dataset({'z': xl.DataArray(
+          torch.as_tensor(rs.normal(size=(1, 1, n_lat, n_lon)).astype(
+              np.float32), device=dev),
+          ('init_time', 'lead_time', 'latitude', 'longitude'))}, tc)
+      chunks.append((f, t))
+  cfg = config.Eval(metrics={'crps': gm.CRPS(), 'var': gm.EnsembleVariance(),
+                             'emse': gm.EnsembleMeanMSE()},
+                    regions={'global': None,
+                             'tropics': helpers.predefined_regions(False)[
+                                 'tropics']})
+  base = evaluation.evaluate_chunks(chunks, cfg, False, batch_chunks=1)
+  for k in (2, 4, 8):
+    got = evaluation.evaluate_chunks(chunks, cfg, False, batch_chunks=k)
+    for name in base.keys():
+      assert got[name].dims == base[name].dims
+      helpers.assert_close(got[name].values, base[name].values, rtol=1e-12,
+                           atol=0)
+  # a map-valued metric keeps its maps on the device through the batch
+  cfg_maps = config.Eval(metrics={'smse': gm.SpatialMSE()}, regions=None)
+  det = [(xl.Dataset({'z': xl.DataArray(f['z'].data[:, :, 0], (
+      'init_time', 'lead_time', 'latitude', 'longitude'))},
+                     {k: v for k, v in f.coords.items() if k != 'realization'}),
+          t) for f, t in chunks]
+  base = evaluation.evaluate_chunks(det, cfg_maps, False, batch_chunks=1)
+  got = evaluation.evaluate_chunks(det, cfg_maps, False, batch_chunks=4)
+  helpers.assert_close(got['z'].values, base['z'].values, rtol=1e-12, atol=0)

@@ -806,6 +806,10 @@ def evaluate_chunks(
   lo, hi = shard_bounds(len(chunks), world, rank)
   substitute = _chunk_substitution(eval_config, truth, climatology, by_init)
   batch_chunks = max(1, int(batch_chunks))
+  if eval_config.derived_variables:
+    # derived variables are computed on (and assigned into) each chunk as the
+    # caller handed it in (evaluation.py:402-405): no virtual concatenation
+    batch_chunks = 1
   mean: t.Optional[RunningMean] = None
   window: list = []
 
