@@ -217,19 +217,36 @@ def test_batching_with_metrics_that_materialise():
                     regions={'global': None,
                              'tropics': helpers.predefined_regions(False)[
                                  'tropics']})
+  # evaluate_chunks does not batch for these metrics (a materialised window is
+  # a copy of the data) ...
   base = evaluation.evaluate_chunks(chunks, cfg, False, batch_chunks=1)
-  for k in (2, 4, 8):
-    got = evaluation.evaluate_chunks(chunks, cfg, False, batch_chunks=k)
-    for name in base.keys():
-      assert got[name].dims == base[name].dims
-      helpers.assert_close(got[name].values, base[name].values, rtol=1e-12,
-                           atol=0)
-  # a map-valued metric keeps its maps on the device through the batch
+  got = evaluation.evaluate_chunks(chunks, cfg, False, batch_chunks=8)
+  for name in base.keys():
+    assert np.array_equal(got[name].values, base[name].values, equal_nan=True)
+  # ... but a concatenated window handed to the loop directly is still right:
+  # the metrics materialise it
+  fw = evaluation.concat_chunks([c[0] for c in chunks], 'init_time', 'lead_time')
+  tw = evaluation.concat_chunks([c[1] for c in chunks], 'init_time', 'lead_time')
+  assert isinstance(fw['z'].data, xl.SlabConcat)
+  whole = evaluation._metric_and_region_loop(fw, tw, cfg, False,
+                                             compute_chunk=True)
+  mean = evaluation.RunningMean('init_time', False, dev, split_dim='lead_time')
+  mean.add(whole)
+  res = mean.result()
+  for name in base.keys():
+    assert res[name].dims == base[name].dims
+    helpers.assert_close(res[name].values, base[name].values, rtol=1e-12,
+                         atol=0)
   cfg_maps = config.Eval(metrics={'smse': gm.SpatialMSE()}, regions=None)
   det = [(xl.Dataset({'z': xl.DataArray(f['z'].data[:, :, 0], (
       'init_time', 'lead_time', 'latitude', 'longitude'))},
                      {k: v for k, v in f.coords.items() if k != 'realization'}),
           t) for f, t in chunks]
   base = evaluation.evaluate_chunks(det, cfg_maps, False, batch_chunks=1)
-  got = evaluation.evaluate_chunks(det, cfg_maps, False, batch_chunks=4)
-  helpers.assert_close(got['z'].values, base['z'].values, rtol=1e-12, atol=0)
+  fw = evaluation.concat_chunks([c[0] for c in det], 'init_time', 'lead_time')
+  tw = evaluation.concat_chunks([c[1] for c in det], 'init_time', 'lead_time')
+  mean = evaluation.RunningMean('init_time', False, dev, split_dim='lead_time')
+  mean.add(evaluation._metric_and_region_loop(fw, tw, cfg_maps, False,
+                                              compute_chunk=True))
+  helpers.assert_close(mean.result()['z'].values, base['z'].values, rtol=1e-12,
+                       atol=0)

@@ -780,8 +780,9 @@ def evaluate_chunks(
   all-reduce.  Chunks may split the lead dim as well as the time dim (that
   configuration does): results accumulate per lead label (`RunningMean`).
 
-  `batch_chunks` = k evaluates k consecutive chunks in ONE pass of the metric x
-  region loop: they are concatenated without copying (`concat_chunks`: a
+  `batch_chunks` = k (deterministic suites: MSE / RMSE / MAE / Bias / ACC /
+  wind vectors; ignored otherwise) evaluates k consecutive chunks in ONE pass of
+  the metric x region loop: they are concatenated without copying (`concat_chunks`: a
   (time x lead) rectangle of chunks becomes one Dataset whose variables index
   the chunks' own arrays), so one fused launch reads every variable of all k
   chunks and the host work of the loop is paid once per k chunks.  The K1
@@ -806,9 +807,14 @@ def evaluate_chunks(
   lo, hi = shard_bounds(len(chunks), world, rank)
   substitute = _chunk_substitution(eval_config, truth, climatology, by_init)
   batch_chunks = max(1, int(batch_chunks))
-  if eval_config.derived_variables:
-    # derived variables are computed on (and assigned into) each chunk as the
-    # caller handed it in (evaluation.py:402-405): no virtual concatenation
+  if eval_config.derived_variables or not all(
+      getattr(m, '_reads_slabs_in_place', False)
+      for m in eval_config.metrics.values()):
+    # Chunks are batched only for metrics that read a concatenation in place
+    # (the deterministic suite: address tables); every other metric would
+    # materialise the window first -- a copy of the data, slower than going
+    # chunk by chunk.  Derived variables are computed on (and assigned into)
+    # each chunk as the caller handed it in (evaluation.py:402-405).
     batch_chunks = 1
   mean: t.Optional[RunningMean] = None
   window: list = []

@@ -1221,6 +1221,9 @@ del _name
 
 class _DetMetric(Metric):
   _index: int = -1
+  # reads concatenated chunks (xarray_lite.SlabConcat) through address tables,
+  # without materialising them: evaluate_chunks may batch chunks for it
+  _reads_slabs_in_place = True
 
   def _scalar(self, forecast, truth, region, skipna,
               regions: t.Optional[dict] = None) -> xl.Dataset:
@@ -1304,6 +1307,7 @@ class WindVectorMSE(Metric):
   v_name: str
   vector_name: str
   _index = _lib.METRIC_INDEX['mse']
+  _reads_slabs_in_place = True
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False,
                     regions: t.Optional[dict] = None):
@@ -1421,6 +1425,7 @@ class ACC(Metric):
   """
 
   climatology: t.Any = None
+  _reads_slabs_in_place = True
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False,
                     regions: t.Optional[dict] = None):
