@@ -1,5 +1,6 @@
 """GPU parity of K3's compile-time member counts (-m gpu): the kernels of
-csrc/ensemble_m<M>.hip (10, 16, 20, 30, 32, 51, 56 float32 members) and the
+csrc/ensemble_exact.hip (one object per member count of WB2_SORT3_SIZES,
+csrc/sort3_networks.inc: 4 ... 100 float32 members) and the
 NaN-free fast path of the exact skipna kernels, against the NumPy oracle
 (oracle/metrics_np.py restating /root/reference/weatherbench2/metrics.py:
 532-565, 585-607, 775-846, 1161-1363)."""
@@ -13,7 +14,10 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-EXACT = (10, 16, 20, 30, 32, 51, 56)
+from weatherbench2_amd import build as _build
+
+# every member count with a kernel of its own (WB2_SORT3_SIZES)
+EXACT = tuple(m for m, _ in _build.exact_sizes())
 N_LAT, N_LON = 721, 1440
 LAT = np.linspace(-90, 90, N_LAT)
 LON = np.linspace(0, 360, N_LON, endpoint=False)

@@ -27,9 +27,9 @@ def main():
   obj = os.path.join(var_dir, f'{name}.o')
   subprocess.run([b._hipcc()] + flags + extra +
                  ['-c', os.path.join(b.CSRC, src), '-o', obj], check=True)
-  objs = [obj if os.path.basename(s) == src else
-          os.path.join(obj_dir, os.path.basename(s) + '.o')
-          for s in b.sources()]
+  objs = [obj if (os.path.basename(s) == src and not defines) else
+          os.path.join(obj_dir, name)
+          for s, name, defines in b.translation_units()]
   out = os.path.join(var_dir, f'libwb2hip_{name}.so')
   subprocess.run([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC',
                   '-o', out] + objs + ['-L/opt/rocm/lib', '-lhipfft', '-ldl'],

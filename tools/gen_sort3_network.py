@@ -309,7 +309,12 @@ if __name__ == '__main__':
 # Round 4: programs for the other ensemble sizes K3 instantiates exactly
 # (csrc/sort3_networks.inc): the cheapest of a few constructions per size.
 # ---------------------------------------------------------------------------
-EXACT_SIZES = (10, 16, 20, 30, 32, 51, 56)
+# member counts K3 instantiates with a compile-time M (50 has its own file):
+# small test ensembles, 10 / 11 / 20 / 21 / 31 (operational centres with and
+# without the control), 25, 30 (the 1990-2019 probabilistic climatology), 32,
+# 40, 51 / 56 (IFS ENS + control, GenCast-style), 64, 100
+EXACT_SIZES = (4, 5, 8, 10, 11, 16, 20, 21, 25, 30, 31, 32, 40, 51, 56, 64,
+               100)
 
 
 def _sorted_by(builder, n_wires, n_real):
@@ -405,6 +410,15 @@ def emit_exact(path):
            '// 3-sorters (WB2_S3(a, b, c): v_min3 / v_med3 / v_max3) for the ensemble',
            '// sizes K3 instantiates with a compile-time member count; rank r ends up',
            '// in register WB2_SORT3_ORDER_<M>[r], no data is moved.', '']
+  def npad(n):
+    p = 1
+    while p < n:
+      p *= 2
+    return max(p, 4)
+  lines.append('// X(member count, padded register count) of every program below')
+  lines.append('#define WB2_SORT3_SIZES(X) \\')
+  lines.append('  ' + ' '.join(f'X({n}, {npad(n)})' for n in EXACT_SIZES))
+  lines.append('')
   for n in EXACT_SIZES:
     ops, order = best_program(n)
     how = check_program(ops, order, n, rs)

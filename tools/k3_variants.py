@@ -4,8 +4,8 @@ slabs of 721 x 1440 float32 per launch): the official `probabilistic` config's
 496-520: the WF = true instantiation), skipna (clean data: every wave takes
 the NaN-free fast path; with NaN patches: 1 in 8 column tiles takes the general
 path), a global-only region set (`regions=None`), the member counts with
-kernels of their own (10, 16, 20, 30, 32, 51, 56: csrc/ensemble_m<M>.hip), one
-runtime-M count (40) and float64.
+kernels of their own (4 ... 100: csrc/ensemble_exact.hip, one object per entry of
+WB2_SORT3_SIZES), one runtime-M count (44) and float64.
 
   python tools/k3_variants.py         -> one JSON line
 
@@ -23,13 +23,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-EXACT_SIZES = (10, 16, 20, 30, 32, 51, 56)
 
 
 def variants(dev, reps: int = 3, launches: int = 30, only=None) -> dict:
   import torch
   import bench
-  from weatherbench2_amd import engine, plan as plan_lib
+  from weatherbench2_amd import build, engine, plan as plan_lib
+  exact_sizes = [m for m, _ in build.exact_sizes()]
   n_lat, n_lon, n_slab = bench.N_LAT, bench.N_LON, 13
   lat = np.linspace(-90, 90, n_lat)
   lon = np.linspace(0, 360, n_lon, endpoint=False)
@@ -52,9 +52,9 @@ def variants(dev, reps: int = 3, launches: int = 30, only=None) -> dict:
            ('skipna', 'slice13', 50, torch.float32, True, 0.0),
            ('skipna_nan_patches', 'slice13', 50, torch.float32, True, 0.125)]
   specs += [(f'members{m}', 'slice13', m, torch.float32, False, 0.0)
-            for m in EXACT_SIZES]
+            for m in exact_sizes]
   specs += [('members51_skipna', 'slice13', 51, torch.float32, True, 0.0),
-            ('members40_runtime', 'slice13', 40, torch.float32, False, 0.0),
+            ('members44_runtime', 'slice13', 44, torch.float32, False, 0.0),
             ('f64_members50', 'slice13', 50, torch.float64, False, 0.0)]
   if only:
     specs = [s for s in specs if s[0] in only]

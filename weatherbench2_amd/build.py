@@ -10,11 +10,10 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
 SOURCES = ('common.cpp', 'comm.cpp', 'stream_reduce.hip', 'ensemble.hip',
-           'ensemble_m10.hip', 'ensemble_m16.hip', 'ensemble_m20.hip',
-           'ensemble_m30.hip', 'ensemble_m32.hip', 'ensemble_m51.hip',
-           'ensemble_m56.hip', 'spectrum.hip',
-           'spectrum_fused.hip', 'spatial_maps.hip', 'rank_histogram.hip',
-           'axis_reduce.hip')
+           'spectrum.hip', 'spectrum_fused.hip', 'spatial_maps.hip',
+           'rank_histogram.hip', 'axis_reduce.hip')
+# compiled once per member count listed in sort3_networks.inc (WB2_SORT3_SIZES)
+EXACT_SOURCE = 'ensemble_exact.hip'
 
 
 def _hipcc() -> str:
@@ -30,11 +29,32 @@ def sources() -> list[str]:
           if os.path.exists(os.path.join(CSRC, s))]
 
 
+def exact_sizes() -> list[tuple]:
+  """[(members, padded count)] of WB2_SORT3_SIZES in sort3_networks.inc."""
+  import re
+  text = open(os.path.join(CSRC, 'sort3_networks.inc')).read()
+  block = text[text.index('#define WB2_SORT3_SIZES(X)'):]
+  block = block[:block.index('\n\n')]
+  return [(int(a), int(b)) for a, b in re.findall(r'X\((\d+),\s*(\d+)\)',
+                                                  block)]
+
+
+def translation_units() -> list[tuple]:
+  """[(source path, object name, extra flags)] of the whole library."""
+  units = [(s, os.path.basename(s) + '.o', []) for s in sources()]
+  exact = os.path.join(CSRC, EXACT_SOURCE)
+  for m, npad in exact_sizes():
+    units.append((exact, f'ensemble_exact_{m}.o',
+                  [f'-DWB2_ENS_M={m}', f'-DWB2_ENS_NPAD={npad}']))
+  return units
+
+
 def needs_rebuild() -> bool:
   if not os.path.exists(LIB_PATH):
     return True
   t = os.path.getmtime(LIB_PATH)
-  deps = sources() + [os.path.join(CSRC, h) for h in
+  deps = sources() + [os.path.join(CSRC, EXACT_SOURCE)] + [
+      os.path.join(CSRC, h) for h in
                       ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc',
                        'sort3_network_50.inc', 'sort3_networks.inc',
                        'ensemble_kernels.hpp', 'fft_core.hpp', 'trace.hpp')
@@ -78,17 +98,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
            '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
   extra = os.environ.get('WB2HIP_CXXFLAGS', '').split()
 
-  def compile_one(src):
-    obj = os.path.join(obj_dir, os.path.basename(src) + '.o')
-    cmd = [_hipcc()] + flags + extra + ['-c', src, '-o', obj]
+  def compile_one(unit):
+    src, name, defines = unit
+    obj = os.path.join(obj_dir, name)
+    cmd = [_hipcc()] + flags + extra + defines + ['-c', src, '-o', obj]
     if verbose:
       print('[wb2hip build]', ' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
     return obj
 
+  # the largest units first: the longest compile bounds the wall time
+  units = sorted(translation_units(),
+                 key=lambda u: -int(u[2][0].split('=')[1]) if u[2] else -1000)
   with concurrent.futures.ThreadPoolExecutor(
       max_workers=min(8, os.cpu_count() or 4)) as pool:
-    objs = list(pool.map(compile_one, sources()))
+    objs = list(pool.map(compile_one, units))
   link = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH
           ] + objs
   if any(s.endswith('spectrum.hip') for s in sources()):

@@ -41,11 +41,11 @@ struct EnsParams {
   int n_member, n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
 };
 
-// Exact float32 instantiations that live in translation units of their own
-// (ensemble_m<M>.hip; the member counts of tools/gen_sort3_network.py's
-// EXACT_SIZES): X(member count, padded register count).
-#define WB2_ENS_EXACT_SIZES(X) \
-  X(10, 16) X(16, 16) X(20, 32) X(30, 32) X(32, 32) X(51, 64) X(56, 64)
+// Exact float32 instantiations live in translation units of their own
+// (ensemble_exact.hip compiled once per member count of WB2_SORT3_SIZES,
+// sort3_networks.inc: the list tools/gen_sort3_network.py generates programs
+// for): X(member count, padded register count).
+#define WB2_ENS_EXACT_SIZES(X) WB2_SORT3_SIZES(X)
 #define WB2_ENS_DECLARE(M, NPAD)                                       \
   int launch_ens_exact_f32_##M(const EnsParams& p, bool skipna, bool wf, \
                                hipStream_t stream);
@@ -224,13 +224,9 @@ struct Sort3 {
     x[j] = hi_;                           \
   }
 #define WB2_S3(i, j, k) sort3_asm(x[i], x[j], x[k]);
-WB2_SORT3_DEFINE(10)
-WB2_SORT3_DEFINE(16)
-WB2_SORT3_DEFINE(20)
-WB2_SORT3_DEFINE(30)
-WB2_SORT3_DEFINE(32)
-WB2_SORT3_DEFINE(51)
-WB2_SORT3_DEFINE(56)
+#define WB2_SORT3_DEFINE2(M, NPAD) WB2_SORT3_DEFINE(M)
+WB2_SORT3_SIZES(WB2_SORT3_DEFINE2)
+#undef WB2_SORT3_DEFINE2
 #undef WB2_S2
 #undef WB2_S3
 #undef WB2_SORT3_DEFINE
