@@ -1,6 +1,6 @@
 // K3's device code (templates): included by ensemble.hip (the runtime-M and
 // exact-50 instantiations + the host entry points) and by the per-size
-// translation units ensemble_m<M>.hip (compile-time member counts).
+// objects of ensemble_exact.hip (one per compile-time member count).
 #pragma once
 
 #include <cstdlib>
