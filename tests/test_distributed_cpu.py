@@ -79,6 +79,62 @@ def test_two_rank_running_mean_matches_single_process(skipna):
     np.testing.assert_allclose(values, want, rtol=1e-13, equal_nan=True)
 
 
+def _lead_chunks(n_init=4, n_lead=3, seed=3):
+  """(init_time=1, lead_time=1) chunk results in LEAD-major order."""
+  rs = np.random.RandomState(seed)
+  leads = (np.arange(n_lead) * np.timedelta64(6, 'h')).astype('timedelta64[ns]')
+  values = rs.standard_normal((n_init, n_lead, 2))
+  out = []
+  for l in range(n_lead):
+    for i in range(n_init):
+      out.append(xl.Dataset(
+          {'z': xl.DataArray(values[i:i + 1, l:l + 1],
+                             ('init_time', 'lead_time', 'level'))},
+          {'init_time': np.arange(i, i + 1), 'lead_time': leads[l:l + 1],
+           'level': np.array([500, 850])}))
+  return out, values, leads
+
+
+def _lead_worker(rank, world, port, queue):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    chunks, _, _ = _lead_chunks()
+    lo, hi = evaluation.shard_bounds(len(chunks), world, rank)
+    mean = evaluation.RunningMean('init_time', False, device='cpu',
+                                  split_dim='lead_time')
+    for i in range(lo, hi):
+      mean.add(chunks[i])
+    res = mean.result()
+    queue.put((rank, res['z'].values, np.asarray(res.coords['lead_time'])))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_different_lead_labels_agree_on_the_layout():
+  """Lead-major chunk lists (the official chunking splits the lead dim too):
+  rank 0's shard holds leads 0 and 1, rank 1's leads 1 and 2 -- the ranks
+  exchange their label sets before the all-reduce, rows they never met count
+  as zeros, and both end with the global per-lead mean."""
+  world = 2
+  ctx = mp.get_context('spawn')
+  queue = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_lead_worker, args=(r, world, port, queue))
+           for r in range(world)]
+  for p in procs:
+    p.start()
+  got = [queue.get(timeout=120) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  _, values, leads = _lead_chunks()
+  for _, z, lead_labels in got:
+    np.testing.assert_array_equal(lead_labels, leads)
+    np.testing.assert_allclose(z, values.mean(0), rtol=1e-14)
+
+
 def test_shard_bounds_cover_everything():
   for n in (1, 7, 8, 2920):
     for world in (1, 2, 3, 8):

@@ -1,10 +1,10 @@
 # One-off GPU checks of a kernel change (edit freely; not part of the product):
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ab
-timeout 1500 python -m pytest -x -q -m gpu tests/test_ens_gpu.py tests/test_ens_exact_gpu.py tests/test_evalall.py tests/test_reference_vectors.py tests/test_bench_launch_gpu.py > gpurun_out/ab/pytest.txt 2>&1; tail -4 gpurun_out/ab/pytest.txt
-timeout 900 python tools/k3_variants.py > gpurun_out/ab/k3.json 2>gpurun_out/ab/k3.err; tail -2 gpurun_out/ab/k3.err
-python - <<'PY'
-import json
-a=json.load(open('gpurun_out/ab/k3.json'))
-for k,v in a.items(): print(f"{k:24s} {v['kernel_ms']:.4f} ms  frac {v['frac']:.3f} [{v['frac_min']:.3f}, {v['frac_max']:.3f}]")
-PY
+for rep in 1 2; do
+for v in default wg3; do
+  if [ $v = default ]; then unset WB2HIP_LIB; else export WB2HIP_LIB=$GRAFT_REPO_ROOT/build/variants/libwb2hip_$v.so; fi
+  timeout 300 python bench.py --variants-only 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$v', {k:(round(x['kernel_ms'],4), round(x['frac'],3)) for k,x in d.items() if k in ('headline','official16_landmask','lonlat','skipna')})"
+done
+done
