@@ -62,3 +62,33 @@ def test_by_init_persistence_keeps_every_truth_variable():
   assert out['orography'].dims[0] == 'lead_time'
   np.testing.assert_array_equal(np.asarray(out['orography'].values)[1],
                                 np.asarray(truth['orography'].data))
+
+
+def test_merge_metrics_is_the_merge_of_expanded_datasets():
+  """`merge_metrics` (one stack per variable) against the step-by-step
+  `merge([ds.expand_dims(metric=[name])])` it replaces: metric labels sorted,
+  dim order of the first dataset IN THE LIST that holds the variable, NaN
+  where a metric lacks a variable."""
+  import numpy as np
+  from weatherbench2_amd import xarray_lite as xl
+  rng = np.random.default_rng(0)
+  coords = {'level': np.array([500, 850]),
+            'prediction_timedelta': np.arange(3)}
+  a = xl.Dataset(coords=coords)
+  a.data_vars['z'] = xl.DataArray(rng.normal(size=(3, 2)),
+                                  ('prediction_timedelta', 'level'), coords, 'z')
+  a.data_vars['t'] = xl.DataArray(rng.normal(size=(3, 2)),
+                                  ('prediction_timedelta', 'level'), coords, 't')
+  b = xl.Dataset(coords=coords)
+  b.data_vars['z'] = xl.DataArray(rng.normal(size=(2, 3)),
+                                  ('level', 'prediction_timedelta'), coords, 'z')
+  named = [('stddev', a), ('rmse', b)]  # list order != sorted label order
+  got = xl.merge_metrics(named)
+  want = xl.merge([d.expand_dims({'metric': [n]}) for n, d in named])
+  assert list(got.coords['metric']) == list(want.coords['metric']) == [
+      'rmse', 'stddev']
+  for var in ('z', 't'):
+    assert got[var].dims == want[var].dims, var
+    np.testing.assert_array_equal(got[var].values, want[var].values)
+  assert got['z'].dims == ('metric', 'prediction_timedelta', 'level')
+  assert np.isnan(got['t'].values[0]).all()

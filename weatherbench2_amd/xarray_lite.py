@@ -587,7 +587,8 @@ def merge_metrics(named: t.Sequence[tuple]) -> Dataset:
   for var in variables:
     holders = [by_label[m].data_vars.get(var) for m in labels]
     have = [h for h in holders if h is not None]
-    ref = have[0]
+    # dim order: the first dataset IN THE LIST that holds the variable (xarray)
+    ref = next(d.data_vars[var] for _, d in named if var in d.data_vars)
     dtype = np.result_type(*[as_np(h.dtype) for h in have])
     if dtype.kind != 'f':
       dtype = np.dtype(np.float64)
