@@ -429,13 +429,15 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         int64_t n_tail, int skipna, double* sum, double* count,
                         void* stream);
 
-/* The same with a destination table: result element idx of [n_lead][n_tail]
- * goes to accumulator element dst[idx] (DEV int64[n_lead * n_tail], entries
- * distinct).  Chunks that split the lead dim as well
+/* The same for float32 or float64 values (dtype WB2_F32 / WB2_F64; float32
+ * widens exactly: metric results in the reference's float32 result dtype need
+ * no conversion pass) with a destination table: result element idx of
+ * [n_lead][n_tail] goes to accumulator element dst[idx] (DEV
+ * int64[n_lead * n_tail], entries distinct).  Chunks that split the lead dim as well
  * (`input_chunks=init_time=1,lead_time=1`, docs/source/official-evaluation.md:
  * 537-549) accumulate into the rows of their lead labels: xbeam.Mean combines
  * per chunk key (evaluation.py:740-744).  dst == NULL: identity. */
-int wb2_time_accumulate_scatter(const double* values, int64_t n_lead,
+int wb2_time_accumulate_scatter(int dtype, const void* values, int64_t n_lead,
                                 int64_t n_time, int64_t n_tail, int skipna,
                                 const int64_t* dst, double* sum, double* count,
                                 void* stream);

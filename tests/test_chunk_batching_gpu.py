@@ -250,3 +250,32 @@ def test_batching_with_metrics_that_materialise():
                                               compute_chunk=True))
   helpers.assert_close(mean.result()['z'].values, base['z'].values, rtol=1e-12,
                        atol=0)
+
+
+@pytest.mark.parametrize('skipna', [False, True])
+def test_float32_results_accumulate_like_their_float64_copies(skipna):
+  """wb2_time_accumulate_scatter takes float32 values as they are (the
+  reference's float32 result dtype): the same bits as accumulating their
+  float64 copies, with and without a destination table."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda')
+  gen = torch.Generator(device=dev).manual_seed(11)
+  v32 = torch.randn((3, 7, 5, 13), generator=gen, device=dev)
+  v32[1, 2, 3, 4] = float('nan')
+  v32[0, :, 0, 0] = float('nan')
+  n_out = 3 * 5 * 13
+  dst = torch.randperm(2 * n_out, generator=gen, device=dev)[:n_out]
+  for table in (None, dst):
+    accs = []
+    for values in (v32, v32.double()):
+      total = torch.full((2 * n_out,), 0.25, dtype=torch.float64, device=dev)
+      count = torch.ones_like(total)
+      if table is None:
+        total, count = total[:n_out].clone(), count[:n_out].clone()
+      engine.time_accumulate(values, 1, skipna, total, count, table)
+      accs.append((total, count))
+    for a, b in zip(*accs):
+      assert torch.equal(torch.nan_to_num(a, nan=-7.0),
+                         torch.nan_to_num(b, nan=-7.0))
+    assert accs[0][1].max().item() == 1.0 + 7

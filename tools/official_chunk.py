@@ -241,10 +241,54 @@ def main():
   ap.add_argument('--batch', default='1,16,32')
   ap.add_argument('--profile', action='store_true',
                   help='cProfile of the host path at the first batch size')
+  ap.add_argument('--sections', action='store_true',
+                  help='wall time of the host path by section (no profiler)')
   args = ap.parse_args()
   import torch
   dev = torch.device('cuda', 0)
   batches = tuple(int(b) for b in args.batch.split(','))
+  if args.sections:
+    # wall time of the host path's sections at batch_chunks = first entry,
+    # without a profiler's per-call overhead (a few timers per chunk)
+    import collections
+    from weatherbench2_amd import engine, evaluation, metrics as gm
+    from weatherbench2_amd import xarray_lite as xl
+    spent = collections.defaultdict(float)
+    calls = collections.Counter()
+
+    def timed(owner, attr, label=None):
+      fn = getattr(owner, attr)
+      label = label or attr
+
+      def wrapper(*a, **k):
+        t0 = time.perf_counter()
+        try:
+          return fn(*a, **k)
+        finally:
+          spent[label] += time.perf_counter() - t0
+          calls[label] += 1
+      setattr(owner, attr, wrapper)
+    for owner, attr in ((evaluation, '_metric_and_region_loop'),
+                        (evaluation.RunningMean, 'add'),
+                        (evaluation, 'concat_chunks'),
+                        (xl, 'merge_metrics'), (gm, '_run_group'),
+                        (gm, '_assemble'), (gm, '_det_plan'),
+                        (gm, '_wind_plan'), (gm, '_prepare_inputs'),
+                        (gm, '_climatology_slabs'),
+                        (gm, '_reference_result_dtype'), (gm, '_det_key'),
+                        (engine, 'time_accumulate'), (engine, 'upload_table'),
+                        (engine, 'stream_reduce_addr')):
+      timed(owner, attr)
+    chunks, cfg = build(dev, args.chunks, args.pool)
+    measure(chunks[:8], cfg, batches[0], timed_events=False)
+    spent.clear()
+    calls.clear()
+    leg = measure(chunks, cfg, batches[0], timed_events=False)
+    n = len(chunks)
+    print(f"wall {leg['wall_ms_per_chunk']:.3f} ms per chunk")
+    for k, v in sorted(spent.items(), key=lambda kv: -kv[1]):
+      print(f'{k:28s} {v / n * 1e3:7.3f} ms per chunk  {calls[k] / n:6.1f} calls')
+    return
   if args.profile:
     import cProfile
     import pstats

@@ -54,8 +54,8 @@ _SIGNATURES = {
         _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     'wb2_time_accumulate': (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp,
                                    _vp]),
-    'wb2_time_accumulate_scatter': (_int, [_vp, _i64, _i64, _i64, _int, _vp,
-                                           _vp, _vp, _vp]),
+    'wb2_time_accumulate_scatter': (_int, [_int, _vp, _i64, _i64, _i64, _int,
+                                           _vp, _vp, _vp, _vp]),
     'wb2_ens_partials': (_int, [
         _int, _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp,
         _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),

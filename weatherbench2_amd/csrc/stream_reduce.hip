@@ -880,8 +880,9 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
 // chunks evaluated as one batch) does not change a bit of the result.  `dst`
 // (optional) sends element idx of the [n_lead][n_tail] result to accumulator
 // element dst[idx] (lead-time blocks of chunks that split the lead dim).
+template <typename T>
 __global__ void __launch_bounds__(256)
-    time_accumulate_kernel(const double* __restrict__ values, long long n_lead,
+    time_accumulate_kernel(const T* __restrict__ values, long long n_lead,
                            long long n_time, long long n_tail, int skipna,
                            const long long* __restrict__ dst,
                            double* __restrict__ sum,
@@ -891,16 +892,16 @@ __global__ void __launch_bounds__(256)
   const long long l = idx / n_tail, j = idx - l * n_tail;
   const long long out = dst ? dst[idx] : idx;
   double s = sum[out], c = count[out];
-  const double* base = values + l * n_time * n_tail + j;
-  auto add = [&](double v) {
+  const T* base = values + l * n_time * n_tail + j;
+  auto add = [&](double v) {  // float32 values widen exactly
     const bool keep = !(skipna && is_nan(v));
     s += keep ? v : 0.0;
     c += keep ? 1.0 : 0.0;
   };
   long long t = 0;
   for (; t + 4 <= n_time; t += 4) {  // four independent loads per wait
-    const double v0 = base[t * n_tail], v1 = base[(t + 1) * n_tail],
-                 v2 = base[(t + 2) * n_tail], v3 = base[(t + 3) * n_tail];
+    const T v0 = base[t * n_tail], v1 = base[(t + 1) * n_tail],
+            v2 = base[(t + 2) * n_tail], v3 = base[(t + 3) * n_tail];
     add(v0);
     add(v1);
     add(v2);
@@ -1314,27 +1315,36 @@ int wb2_time_accumulate(const double* values, int64_t n_lead, int64_t n_time,
                         int64_t n_tail, int skipna, double* sum, double* count,
                         void* stream) {
   WB2_TRACE();
-  return wb2_time_accumulate_scatter(values, n_lead, n_time, n_tail, skipna,
-                                     nullptr, sum, count, stream);
+  return wb2_time_accumulate_scatter(WB2_F64, values, n_lead, n_time, n_tail,
+                                     skipna, nullptr, sum, count, stream);
 }
 
-int wb2_time_accumulate_scatter(const double* values, int64_t n_lead,
+int wb2_time_accumulate_scatter(int dtype, const void* values, int64_t n_lead,
                                 int64_t n_time, int64_t n_tail, int skipna,
                                 const int64_t* dst, double* sum, double* count,
                                 void* stream) {
   WB2_TRACE();
   using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
   WB2_EMPTY_OK(n_lead);
   WB2_EMPTY_OK(n_time);
   WB2_EMPTY_OK(n_tail);
   WB2_REQUIRE(values && sum && count, "null pointer argument");
   const long long n = n_lead * n_tail;
   if (n == 0 || n_time == 0) return 0;
-  hipLaunchKernelGGL(time_accumulate_kernel, dim3((unsigned)((n + 255) / 256)),
-                     dim3(256), 0, static_cast<hipStream_t>(stream), values,
-                     (long long)n_lead, (long long)n_time, (long long)n_tail,
-                     skipna, reinterpret_cast<const long long*>(dst), sum,
-                     count);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long* d = reinterpret_cast<const long long*>(dst);
+  if (dtype == WB2_F32)
+    hipLaunchKernelGGL(time_accumulate_kernel<float>, grid, dim3(256), 0, s,
+                       static_cast<const float*>(values), (long long)n_lead,
+                       (long long)n_time, (long long)n_tail, skipna, d, sum,
+                       count);
+  else
+    hipLaunchKernelGGL(time_accumulate_kernel<double>, grid, dim3(256), 0, s,
+                       static_cast<const double*>(values), (long long)n_lead,
+                       (long long)n_time, (long long)n_tail, skipna, d, sum,
+                       count);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }

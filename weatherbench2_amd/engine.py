@@ -463,11 +463,13 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
 def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
                     total: torch.Tensor, count: torch.Tensor,
                     dst: t.Optional[torch.Tensor] = None):
-  """total/count += sum/notnull-count of `values` over `time_axis` (device);
-  the sums continue from the accumulators value by value.  `dst` (int64 device
+  """total/count += sum/notnull-count of `values` (float32 or float64) over
+  `time_axis` (device); the sums continue from the accumulators value by value.  `dst` (int64 device
   tensor, one entry per element of `values` without its time axis): where in
   `total` / `count` each result element goes (identity without it)."""
   lib = _lib.load()
+  if values.dtype not in _DTYPES:
+    values = values.to(torch.float64)
   values = values.contiguous()
   shape = tuple(values.shape)
   n_lead = int(np.prod(shape[:time_axis], dtype=np.int64))
@@ -480,7 +482,8 @@ def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
         or total.numel() != count.numel()):
     raise ValueError('dst is int64 with one entry per result element')
   _lib.check(lib.wb2_time_accumulate_scatter(
-      _lib.ptr(values), n_lead, n_time, n_tail, int(skipna), _lib.ptr(dst),
+      _DTYPES[values.dtype], _lib.ptr(values), n_lead, n_time, n_tail,
+      int(skipna), _lib.ptr(dst),
       _lib.ptr(total), _lib.ptr(count), current_stream_ptr(values.device)),
              'wb2_time_accumulate')
 

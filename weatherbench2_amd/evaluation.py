@@ -332,7 +332,10 @@ class RunningMean:
         if self.device is None and raw.is_cuda:
           self.device = raw.device
         engine.order_read(raw)  # produced on another thread's stream?
-        values = raw.to(torch.float64)
+        # float32 results go to the accumulate kernel as they are (widened
+        # there, exactly); only the host fallback below needs float64
+        values = raw if raw.dtype in (torch.float32, torch.float64) and (
+            self._on_gpu()) else raw.to(torch.float64)
       else:
         values = torch.as_tensor(np.ascontiguousarray(da.values),
                                  dtype=torch.float64)

@@ -730,11 +730,17 @@ def _slab_addresses(x, table, n_row: int, n_col: int, n_outer: int):
 
 class _ByRegion(dict):
   """{region key: metrics[NMETRIC, ...]} over the stacked result of a pass,
-  sliced on first use (a loop over all regions only ever takes `_ALL`)."""
+  sliced on first use (a loop over all regions only ever takes `_ALL`).
 
-  def __init__(self, dev, names):
+  `cast(torch dtype)` gives the same stack in another dtype out of ONE
+  conversion of the whole launch's result (shared by every variable of the
+  launch): the reference's float32 results are views of it instead of one
+  `.to()` kernel per (variable, metric)."""
+
+  def __init__(self, dev, names, cast=None):
     super().__init__()
     self._dev, self._names = dev, list(names)
+    self._cast, self._as = cast, {}
     dict.__setitem__(self, _ALL, (dev, self._names))
 
   def __missing__(self, key):
@@ -754,9 +760,13 @@ class _ByRegion(dict):
   def materialized(self) -> dict:
     return {k: self[k] for k in self._names}
 
-
-def _by_region(pl, dev, out_shape) -> dict:
-  return _ByRegion(dev, pl.region_names)
+  def as_dtype(self, dtype) -> '_ByRegion':
+    want = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+    if want == self._dev.dtype or self._cast is None:
+      return self
+    if want not in self._as:
+      self._as[want] = _ByRegion(self._cast(want), self._names)
+    return self._as[want]
 
 
 def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
@@ -819,13 +829,21 @@ def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
           pl, mode, prepped[members[0]][2], list(dev_addr), aligned, n_total,
           skipna, aux=aux, scalar=scalar)
       del keep  # the launch is enqueued: the allocator orders any reuse after it
+    casts = {metrics.dtype: metrics}
+
+    def view(dtype, off, n, shape, casts=casts, metrics=metrics):
+      if dtype not in casts:
+        casts[dtype] = metrics.to(dtype)
+      return casts[dtype][:, :, off:off + n].reshape(shape)
     off = 0
     for i in members:
       geo = entries[i][0]
       n = geo.n_outer
-      dev = metrics[:, :, off:off + n].reshape(
-          (metrics.shape[0], pl.n_region) + geo.out_shape)
-      out[i] = _by_region(pl, dev, geo.out_shape)
+      shape = (metrics.shape[0], pl.n_region) + geo.out_shape
+      out[i] = _ByRegion(
+          view(metrics.dtype, off, n, shape), pl.region_names,
+          lambda dtype, off=off, n=n, shape=shape, view=view: view(
+              dtype, off, n, shape))
       off += n
   return out
 
@@ -998,9 +1016,14 @@ def _transpose(values, axes):
   return np.transpose(values, axes)
 
 
-def _pick(by_region: dict, region, index, regions: t.Optional[dict]):
+def _pick(by_region: dict, region, index, regions: t.Optional[dict],
+          dtype=None):
   """The requested region's row of a fused result -- or, for the all-regions
-  fast path, every announced region stacked along a leading `region` dim."""
+  fast path, every announced region stacked along a leading `region` dim --
+  in the result dtype `dtype` when the pass can give it (a view of one shared
+  conversion, _ByRegion.as_dtype; `_assemble` converts whatever is left)."""
+  if dtype is not None and isinstance(by_region, _ByRegion):
+    by_region = by_region.as_dtype(dtype)
   if regions is None:
     _, rkey = _region_set_for(region)
     return (), by_region[rkey][index]
@@ -1234,10 +1257,11 @@ class _DetMetric(Metric):
         geo, by_region = _fused(
             lambda r, name=name: _det_pass(forecast, truth, name, r, skipna),
             region, regions)
-        lead, values = _pick(by_region, region, self._index, regions)
-        per_var[name] = (lead + geo.out_dims, values, _reference_result_dtype(
+        dtype = _reference_result_dtype(
             forecast, [_np_dtype(forecast[name].data),
-                       _np_dtype(truth[name].data)], region, regions))
+                       _np_dtype(truth[name].data)], region, regions)
+        lead, values = _pick(by_region, region, self._index, regions, dtype)
+        per_var[name] = (lead + geo.out_dims, values, dtype)
     return _assemble(forecast, per_var, regions)
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
@@ -1316,10 +1340,10 @@ class WindVectorMSE(Metric):
       geo, by_region = _fused(
           lambda r: _wind_pass(forecast, truth, self.u_name, self.v_name, r,
                                skipna), region, regions)
-      lead, values = _pick(by_region, region, self._index, regions)
     dtype = _reference_result_dtype(
         forecast, [_np_dtype(ds[k].data) for ds in (forecast, truth)
                    for k in (self.u_name, self.v_name)], region, regions)
+    lead, values = _pick(by_region, region, self._index, regions, dtype)
     return _assemble(forecast, {self.vector_name: (lead + geo.out_dims,
                                                    values, dtype)}, regions)
 
@@ -1438,13 +1462,14 @@ class ACC(Metric):
         geo, by_region = _fused(
             lambda r, name=name: _det_pass(forecast, truth, name, r, skipna,
                                            climatology), region, regions)
-        lead, values = _pick(by_region, region, _lib.METRIC_INDEX['acc'],
-                             regions)
         cvar = _get_climatology_chunk(climatology, truth)[name]
-        per_var[name] = (lead + geo.out_dims, values, _reference_result_dtype(
+        dtype = _reference_result_dtype(
             forecast, [_np_dtype(forecast[name].data),
                        _np_dtype(truth[name].data), _np_dtype(cvar.data)],
-            region, regions))
+            region, regions)
+        lead, values = _pick(by_region, region, _lib.METRIC_INDEX['acc'],
+                             regions, dtype)
+        per_var[name] = (lead + geo.out_dims, values, dtype)
     return _assemble(forecast, per_var, regions)
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
