@@ -35,6 +35,10 @@ and on one GPU (N = 1), each with its own `roofline`:
   k3_variants     K3's: the member counts with kernels of their own (10 ... 56),
                   skipna with and without NaN patches, land masks, float64
                   (tools/k3_variants.py; medians of 3 interleaved repetitions);
+  tier2_variants  the tier-2 kernels (Spatial* maps and their temporal sums,
+                  SEEPS, Gaussian CRPS / thresholds, ensemble thresholds, rank
+                  histogram, axis means), each against the HBM roofline of its
+                  own algorithmic bytes (tools/tier2_variants.py);
   api             the same 16-unit chunk through the drop-in API
                   (_metric_and_region_loop, 5 metrics x 13 regions);
   api_official_chunk  the drop-in API at the reference's production chunking
@@ -671,6 +675,12 @@ def main():
       out['k3_variants'] = k3_variants.variants(dev)
     except Exception as e:
       out['k3_variants'] = {'error': f'{type(e).__name__}: {e}'}
+    torch.cuda.empty_cache()
+    try:  # the tier-2 kernels, each against its own roofline
+      import tier2_variants
+      out['tier2_variants'] = tier2_variants.variants(dev)
+    except Exception as e:
+      out['tier2_variants'] = {'error': f'{type(e).__name__}: {e}'}
     torch.cuda.empty_cache()
   if rank == 0 and world == 1 and not args.no_pcie:
     try:

@@ -514,6 +514,23 @@ int wb2_rank_histogram_seeded(
     const int64_t* ref_strides, const int64_t* acc_row, double* out,
     void* stream);
 
+/* The histogram summed (mean == 0) or averaged (mean != 0: counts / n_time,
+ * the temporal mean of the one-hots, Metric.compute metrics.py:117-138) over
+ * the MIDDLE axis of the outer index o = (l * n_time + t) * n_tail + j, without
+ * the per-sample one-hots and without atomics (a wave owns 64 points of a
+ * result row, counts in LDS): out[n_lead * n_tail][n_point][n_bins] is WRITTEN,
+ * every element once.  Samples, slab tables, ranks, ties as above;
+ * pcg_state_inc != NULL selects the seeded (NumPy PCG64) ties of
+ * wb2_rank_histogram_seeded and needs ref_outer_off[n_lead * n_time * n_tail],
+ * ref_strides and n_col.  n_bins <= 256. */
+int wb2_rank_histogram_mean(
+    int dtype, const void* ens, const int64_t* ens_slab, const void* truth,
+    const int64_t* truth_slab, int32_t n_member, int64_t member_stride,
+    int64_t n_lead, int64_t n_time, int64_t n_tail, int64_t n_point,
+    int32_t n_col, int32_t n_bins, int break_ties, uint64_t seed,
+    const uint64_t* pcg_state_inc, const int64_t* ref_outer_off,
+    const int64_t* ref_strides, int mean, double* out, void* stream);
+
 /* BASELINE configs[3] in one pass: the latitude-weighted mean of the zonal energy
  * spectrum WITHOUT materialising the per-latitude spectra,
  *   out[field][k] = scale * sum_lat row_weight[lat] * S[field][lat][k],

@@ -388,3 +388,45 @@ def test_seeded_temporal_mean_matches_oracle():
   got = gm.RankHistogram(seed=9).compute(g(forecast), g(truth))['geopotential']
   assert got.dims == want.dims
   np.testing.assert_allclose(_values(got), want.data, rtol=0, atol=1e-15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype_name', ['float32', 'float64'])
+def test_mean_kernel_equals_the_atomic_counts(dtype_name):
+  """wb2_rank_histogram_mean (a wave owns 64 points of a result row, counts in
+  LDS) against the atomic-add form over the same rows, for the averaged axis
+  first, in the middle and last, ragged point counts, ties (quantised values:
+  the same counter-based draws per sample) -- the same bits."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda', 0)
+  dtype = getattr(torch, dtype_name)
+  gen = torch.Generator(device=dev).manual_seed(4)
+  for n_member, n_bins, shape, axis, n_point in [
+      (5, 6, (4, 3), 0, 130), (5, 3, (2, 5, 3), 1, 64), (9, 10, (3, 7), 1, 77),
+      (50, 51, (6, 2), 0, 257), (1, 2, (1, 1, 1), 1, 1), (255, 256, (3,), 0, 70)]:
+    n_outer = int(np.prod(shape))
+    ens = (torch.randn((n_member, n_outer, n_point), device=dev, dtype=dtype,
+                       generator=gen) * 4).round() / 4
+    truth = (torch.randn((n_outer, n_point), device=dev, dtype=dtype,
+                         generator=gen) * 4).round() / 4
+    ens[0, 0, 0] = float('nan')
+    kept = tuple(n for i, n in enumerate(shape) if i != axis)
+    n_acc = int(np.prod(kept)) if kept else 1
+    rows = np.arange(n_acc, dtype=np.int64).reshape(kept)
+    rows = np.broadcast_to(np.expand_dims(rows, axis), shape)
+    acc_row = torch.from_numpy(np.ascontiguousarray(rows).ravel()).to(dev)
+    counts = engine.rank_histogram(ens, n_outer * n_point, n_member, None,
+                                   truth, None, n_outer, n_point, n_bins, True,
+                                   77, acc_row, n_acc)
+    mean_over = (int(np.prod(shape[:axis])), shape[axis],
+                 int(np.prod(shape[axis + 1:])))
+    mean = engine.rank_histogram(ens, n_outer * n_point, n_member, None, truth,
+                                 None, n_outer, n_point, n_bins, True, 77,
+                                 mean_over=mean_over)
+    assert mean.shape == counts.shape
+    # true division (NumPy's mean): torch turns `/ python scalar` into a
+    # multiplication by the reciprocal, tensor / tensor divides
+    want = counts / torch.full_like(counts, float(shape[axis]))
+    assert torch.equal(mean, want), (n_member, shape, axis)
+    assert float(mean.sum()) == pytest.approx(n_acc * n_point, rel=1e-12)

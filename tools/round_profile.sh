@@ -33,5 +33,6 @@ if [ "$2" != quick ]; then
   f=$(find /tmp/prof_oc -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -25 "$f" > $OUT/${R}_official_chunk_kernel_stats.csv; rm -rf /tmp/prof_oc
   timeout 600 python tools/official_chunk.py > $OUT/${R}_official_chunk.json 2>/dev/null
   timeout 600 python tools/k3_variants.py > $OUT/${R}_k3_variants.json 2>/dev/null
+  timeout 600 python tools/tier2_variants.py > $OUT/${R}_tier2_variants.json 2>/dev/null
 fi
 ls -la $OUT

@@ -82,6 +82,9 @@ _SIGNATURES = {
     'wb2_rank_histogram_seeded': (_int, [
         _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32,
         _c.POINTER(_u64), _vp, _c.POINTER(_i64), _vp, _vp, _vp]),
+    'wb2_rank_histogram_mean': (_int, [
+        _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
+        _int, _u64, _c.POINTER(_u64), _vp, _c.POINTER(_i64), _int, _vp, _vp]),
     'wb2_ens_combine': (_int, [
         _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
         _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -58,6 +58,8 @@ struct RankParams {
   const long long* acc_row;
   double* out;
   long long member_stride, n_outer, n_point;
+  long long n_lead, n_time, n_tail;  // rank_histogram_mean_kernel only
+  int mean;                          // 1: counts / n_time
   unsigned long long seed;
   int n_member, n_bins, factor, break_ties;
   // PCG64 emulation of the reference's seeded perturbation (ref_outer_off ==
@@ -160,6 +162,64 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   return z ^ (z >> 31);
 }
 
+// Bin of sample (outer slab o, grid point pt): the truth's rank among the
+// members, ties broken as configured, divided by the bin factor.
+template <typename T>
+__device__ __forceinline__ int sample_bin(const RankParams& p, long long o,
+                                          long long pt) {
+  const long long es = p.ens_slab ? p.ens_slab[o] : o;
+  const long long ts = p.truth_slab ? p.truth_slab[o] : o;
+  const int M = p.n_member;
+  const T* xb = static_cast<const T*>(p.ens) + es * p.n_point + pt;
+  const T t = __builtin_nontemporal_load(
+      static_cast<const T*>(p.truth) + ts * p.n_point + pt);
+  int lo = 0, eq = 0, nn = 0, ninf = 0;
+  auto take = [&](T x) {
+    lo += x < t ? 1 : 0;
+    eq += x == t ? 1 : 0;
+    nn += is_nan(x) ? 0 : 1;
+    ninf += abs_of(x) == (T)__builtin_huge_val() ? 1 : 0;
+  };
+  int m = 0;
+  // sixteen member loads in flight per lane (4 KB per wave), then four
+  for (; m + 16 <= M; m += 16) {
+    T x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      x[u] = __builtin_nontemporal_load(xb + (m + u) * p.member_stride);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) take(x[u]);
+  }
+  for (; m + 4 <= M; m += 4) {
+    T x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      x[u] = __builtin_nontemporal_load(xb + (m + u) * p.member_stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take(x[u]);
+  }
+  for (; m < M; ++m)
+    take(__builtin_nontemporal_load(xb + m * p.member_stride));
+  int rank = is_nan(t) ? nn : lo;
+  if (p.break_ties && p.ref_outer_off) {
+    // seeded: the reference's own perturbation wherever it can matter
+    const bool special = eq > 0 || nn != M || is_nan(t) || ninf > 0 ||
+                         abs_of(t) == (T)__builtin_huge_val();
+    if (special) {
+      const long long row = pt / p.n_col, col = pt - row * p.n_col;
+      const long long elem0 = p.ref_outer_off[o] + row * p.ref_row_stride +
+                              col * p.ref_col_stride;
+      rank = perturbed_rank<T>(xb, p.member_stride, M, t, nn, p, elem0);
+    }
+  } else if (eq > 0 && p.break_ties) {
+    const unsigned long long h =
+        mix64(p.seed ^ mix64((unsigned long long)(o * p.n_point + pt)));
+    // uniform integer in [0, eq]: high bits of a 32x32 multiply
+    rank += (int)(((h >> 32) * (unsigned long long)(eq + 1)) >> 32);
+  }
+  return rank / p.factor;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -169,56 +229,7 @@ __global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p)
   const long long o = blockIdx.y + (long long)blockIdx.z * gridDim.y;
   if (o >= p.n_outer || wave_pt0 >= p.n_point) return;  // wave-uniform
   const bool active = pt < p.n_point;
-  const long long es = p.ens_slab ? p.ens_slab[o] : o;
-  const long long ts = p.truth_slab ? p.truth_slab[o] : o;
-  const int M = p.n_member;
-
-  int bin = 0;
-  if (active) {
-    const T* xb = static_cast<const T*>(p.ens) + es * p.n_point + pt;
-    const T t = __builtin_nontemporal_load(
-        static_cast<const T*>(p.truth) + ts * p.n_point + pt);
-    int lo = 0, eq = 0, nn = 0, ninf = 0;
-    int m = 0;
-    for (; m + 4 <= M; m += 4) {  // four loads in flight
-      T x[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        x[u] = __builtin_nontemporal_load(xb + (m + u) * p.member_stride);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        lo += x[u] < t ? 1 : 0;
-        eq += x[u] == t ? 1 : 0;
-        nn += is_nan(x[u]) ? 0 : 1;
-        ninf += abs_of(x[u]) == (T)__builtin_huge_val() ? 1 : 0;
-      }
-    }
-    for (; m < M; ++m) {
-      const T x = __builtin_nontemporal_load(xb + m * p.member_stride);
-      lo += x < t ? 1 : 0;
-      eq += x == t ? 1 : 0;
-      nn += is_nan(x) ? 0 : 1;
-      ninf += abs_of(x) == (T)__builtin_huge_val() ? 1 : 0;
-    }
-    int rank = is_nan(t) ? nn : lo;
-    if (p.break_ties && p.ref_outer_off) {
-      // seeded: the reference's own perturbation wherever it can matter
-      const bool special = eq > 0 || nn != M || is_nan(t) || ninf > 0 ||
-                           abs_of(t) == (T)__builtin_huge_val();
-      if (special) {
-        const long long row = pt / p.n_col, col = pt - row * p.n_col;
-        const long long elem0 = p.ref_outer_off[o] + row * p.ref_row_stride +
-                                col * p.ref_col_stride;
-        rank = perturbed_rank<T>(xb, p.member_stride, M, t, nn, p, elem0);
-      }
-    } else if (eq > 0 && p.break_ties) {
-      const unsigned long long h =
-          mix64(p.seed ^ mix64((unsigned long long)(o * p.n_point + pt)));
-      // uniform integer in [0, eq]: high bits of a 32x32 multiply
-      rank += (int)(((h >> 32) * (unsigned long long)(eq + 1)) >> 32);
-    }
-    bin = rank / p.factor;
-  }
+  const int bin = active ? sample_bin<T>(p, o, pt) : 0;
 
   if (p.acc_row) {
     if (active)
@@ -244,6 +255,47 @@ __global__ void __launch_bounds__(256) rank_histogram_kernel(const RankParams p)
   }
 }
 
+
+// The histogram summed over one axis of the outer index -- o = (l * n_time + t)
+// * n_tail + j, result row l * n_tail + j -- without atomics and without the
+// per-sample one-hots: ONE wave owns 64 points of one result row, walks the
+// n_time samples of each point with its counts in LDS ([point][bin], a lane
+// only ever touches its own row), and writes the row's 64 x n_bins float64
+// values once, as one contiguous run (counts, or counts / n_time: the mean of
+// the one-hots, Metric.compute :117-138).  HBM: the members once + the result
+// once -- the atomic form re-fetches a 128-byte line of the result per sample.
+template <typename T>
+__global__ void __launch_bounds__(kWave)
+    rank_histogram_mean_kernel(const RankParams p) {
+  extern __shared__ unsigned counts[];  // [kWave][n_bins]
+  const int lane = threadIdx.x;
+  const long long wave_pt0 = (long long)blockIdx.x * kWave;
+  const long long row = blockIdx.y + (long long)blockIdx.z * gridDim.y;
+  if (row >= p.n_lead * p.n_tail) return;  // wave-uniform
+  const long long l = row / p.n_tail, j = row - l * p.n_tail;
+  const long long pt = wave_pt0 + lane;
+  const bool active = pt < p.n_point;
+  const int nb = p.n_bins;
+  for (int i = lane; i < kWave * nb; i += kWave) counts[i] = 0;
+  __syncthreads();
+  if (active) {
+    for (long long t = 0; t < p.n_time; ++t) {
+      const long long o = (l * p.n_time + t) * p.n_tail + j;
+      counts[lane * nb + sample_bin<T>(p, o, pt)] += 1;
+    }
+  }
+  __syncthreads();
+  const long long npt = p.n_point - wave_pt0 < kWave ? p.n_point - wave_pt0
+                                                     : kWave;
+  double* dst = p.out + (row * p.n_point + wave_pt0) * nb;
+  const int total = (int)npt * nb;
+  const double n = (double)p.n_time;
+  for (int i = lane; i < total; i += kWave) {
+    const double c = (double)counts[i];
+    __builtin_nontemporal_store(p.mean ? c / n : c, dst + i);
+  }
+}
+
 }  // namespace
 }  // namespace wb2
 
@@ -255,7 +307,9 @@ static int rank_histogram_impl(int dtype, const void* ens,
                                uint64_t seed, const int64_t* acc_row,
                                double* out, const int64_t* ref_outer_off,
                                const int64_t* ref_strides, int32_t n_col,
-                               const uint64_t* pcg_state_inc, void* stream);
+                               const uint64_t* pcg_state_inc, void* stream,
+                               int64_t n_lead = 0, int64_t n_time = 0,
+                               int64_t n_tail = 0, int mean = 0);
 
 extern "C" int wb2_rank_histogram_seeded(
     int dtype, const void* ens, const int64_t* ens_slab, const void* truth,
@@ -276,6 +330,35 @@ extern "C" int wb2_rank_histogram_seeded(
                              member_stride, n_outer, n_point, n_bins, 1, 0,
                              acc_row, out, ref_outer_off, ref_strides, n_col,
                              pcg_state_inc, stream);
+}
+
+extern "C" int wb2_rank_histogram_mean(
+    int dtype, const void* ens, const int64_t* ens_slab, const void* truth,
+    const int64_t* truth_slab, int32_t n_member, int64_t member_stride,
+    int64_t n_lead, int64_t n_time, int64_t n_tail, int64_t n_point,
+    int32_t n_col, int32_t n_bins, int break_ties, uint64_t seed,
+    const uint64_t* pcg_state_inc, const int64_t* ref_outer_off,
+    const int64_t* ref_strides, int mean, double* out, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_EMPTY_OK(n_lead);
+  WB2_EMPTY_OK(n_tail);
+  WB2_EMPTY_OK(n_point);
+  WB2_REQUIRE(n_lead >= 0 && n_time >= 1 && n_tail >= 0,
+              "bad sizes: n_lead=%lld n_time=%lld n_tail=%lld",
+              (long long)n_lead, (long long)n_time, (long long)n_tail);
+  const bool seeded = pcg_state_inc != nullptr;
+  WB2_REQUIRE(!seeded || (ref_outer_off && ref_strides && n_col >= 1 &&
+                          n_point % n_col == 0),
+              "seeded ties need ref_outer_off, ref_strides and n_col");
+  if (n_lead == 0 || n_tail == 0) return 0;
+  return rank_histogram_impl(
+      dtype, ens, ens_slab, truth, truth_slab, n_member, member_stride,
+      n_lead * n_time * n_tail, n_point, n_bins, seeded ? 1 : break_ties,
+      seeded ? 0 : seed, nullptr, out, seeded ? ref_outer_off : nullptr,
+      seeded ? ref_strides : nullptr, seeded ? n_col : 1,
+      seeded ? pcg_state_inc : nullptr, stream, n_lead, n_time, n_tail,
+      mean != 0);
 }
 
 extern "C" int wb2_rank_histogram(int dtype, const void* ens,
@@ -301,7 +384,9 @@ static int rank_histogram_impl(int dtype, const void* ens,
                                uint64_t seed, const int64_t* acc_row,
                                double* out, const int64_t* ref_outer_off,
                                const int64_t* ref_strides, int32_t n_col,
-                               const uint64_t* pcg_state_inc, void* stream) {
+                               const uint64_t* pcg_state_inc, void* stream,
+                               int64_t n_lead, int64_t n_time, int64_t n_tail,
+                               int mean) {
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64,
               "dtype must be WB2_F32 or WB2_F64, got %d", dtype);
@@ -318,7 +403,7 @@ static int rank_histogram_impl(int dtype, const void* ens,
   WB2_REQUIRE((long long)n_point * n_bins < (1ll << 31) * kWave,
               "n_point * n_bins too large");
   if (n_outer == 0 || n_point == 0) return 0;
-  RankParams p;
+  RankParams p{};
   p.ens = ens;
   p.truth = truth;
   p.ens_slab = reinterpret_cast<const long long*>(ens_slab);
@@ -342,11 +427,33 @@ static int rank_histogram_impl(int dtype, const void* ens,
   p.pcg_state_lo = pcg_state_inc ? pcg_state_inc[1] : 0;
   p.pcg_inc_hi = pcg_state_inc ? pcg_state_inc[2] : 0;
   p.pcg_inc_lo = pcg_state_inc ? pcg_state_inc[3] : 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_time > 0) {  // summed over the middle axis of (n_lead, n_time, n_tail)
+    p.n_lead = n_lead;
+    p.n_time = n_time;
+    p.n_tail = n_tail;
+    p.mean = mean;
+    const long long n_row = n_lead * n_tail;
+    const long long ry = n_row < 32768 ? n_row : 32768;
+    const long long rz = (n_row + ry - 1) / ry;
+    WB2_REQUIRE(rz <= 65535, "%lld result rows: too many", n_row);
+    const size_t lds = (size_t)kWave * n_bins * sizeof(unsigned);
+    WB2_REQUIRE(lds <= 64 * 1024, "n_bins=%d: more than 256 bins", n_bins);
+    const dim3 grid((unsigned)((n_point + kWave - 1) / kWave), (unsigned)ry,
+                    (unsigned)rz);
+    if (dtype == WB2_F32)
+      hipLaunchKernelGGL(rank_histogram_mean_kernel<float>, grid, dim3(kWave),
+                         lds, s, p);
+    else
+      hipLaunchKernelGGL(rank_histogram_mean_kernel<double>, grid, dim3(kWave),
+                         lds, s, p);
+    WB2_HIP_OK(hipGetLastError());
+    return 0;
+  }
   const long long gy = n_outer < 32768 ? n_outer : 32768;
   const long long gz = (n_outer + gy - 1) / gy;
   WB2_REQUIRE(gz <= 65535, "n_outer=%lld too large", (long long)n_outer);
   const dim3 grid((unsigned)((n_point + 255) / 256), (unsigned)gy, (unsigned)gz);
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == WB2_F32)
     hipLaunchKernelGGL(rank_histogram_kernel<float>, grid, dim3(256), 0, s, p);
   else

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256)
     s[0][e] = s[1][e] = s[2][e] = 0.0;
     c[e] = 0.0;
   }
-  constexpr int U = 2;  // time steps in flight
+  constexpr int U = 4;  // time steps in flight (8 x 16 B per thread)
   long long i = 0;
   auto body = [&](const T (&f)[VEC], const T (&t)[VEC]) {
 #pragma unroll

@@ -680,13 +680,19 @@ def ensemble_threshold_reduce(plan: ReductionPlan, ens: torch.Tensor,
   return metrics
 
 
+RANK_MEAN_MAX_BINS = 256  # wb2_rank_histogram_mean: 64 x n_bins counts in LDS
+
+
 def rank_histogram(ens: torch.Tensor, member_stride: int, n_member: int,
                    ens_slab, truth: torch.Tensor, truth_slab, n_outer: int,
                    n_point: int, n_bins: int, break_ties: bool, seed: int,
-                   acc_row=None, n_acc: int = 0, numpy_stream=None
-                   ) -> torch.Tensor:
+                   acc_row=None, n_acc: int = 0, numpy_stream=None,
+                   mean_over=None) -> torch.Tensor:
   """wb2_rank_histogram: one-hot [n_outer, n_point, n_bins] (float64), or with
-  `acc_row` the per-row counts [n_acc, n_point, n_bins].
+  `acc_row` the per-row counts [n_acc, n_point, n_bins], or with `mean_over` =
+  (n_lead, n_time, n_tail), n_outer = their product: the MEAN of the one-hots
+  over the middle axis [n_lead * n_tail, n_point, n_bins]
+  (wb2_rank_histogram_mean: no one-hots, no atomics).
 
   `numpy_stream` = (pcg_state, pcg_inc, ref_outer_off[n_outer] int64 device
   tensor, (row, col, member) strides, n_col) switches to
@@ -699,6 +705,30 @@ def rank_histogram(ens: torch.Tensor, member_stride: int, n_member: int,
   for x in (ens, truth):
     if x.device != dev or not x.is_contiguous():
       raise ValueError('inputs must be contiguous on one device')
+  if mean_over is not None:
+    import ctypes
+    n_lead, n_time, n_tail = (int(v) for v in mean_over)
+    if n_lead * n_time * n_tail != n_outer or n_time < 1:
+      raise ValueError(f'mean_over={mean_over} does not factor {n_outer}')
+    out = torch.empty((n_lead * n_tail, n_point, n_bins), dtype=torch.float64,
+                      device=dev)
+    pcg = st = ref_off = None
+    n_col = 1
+    if numpy_stream is not None and break_ties:
+      state, inc, ref_off, strides, n_col = numpy_stream
+      mask = (1 << 64) - 1
+      pcg = (ctypes.c_uint64 * 4)(state >> 64, state & mask, inc >> 64,
+                                  inc & mask)
+      st = (ctypes.c_int64 * 3)(*[int(v) for v in strides])
+      if ref_off.dtype != torch.int64 or ref_off.numel() != n_outer:
+        raise ValueError('ref_outer_off must be int64[n_outer]')
+    _lib.check(lib.wb2_rank_histogram_mean(
+        _DTYPES[ens.dtype], _lib.ptr(ens), _lib.ptr(ens_slab), _lib.ptr(truth),
+        _lib.ptr(truth_slab), n_member, member_stride, n_lead, n_time, n_tail,
+        n_point, int(n_col), n_bins, int(break_ties),
+        seed & 0xFFFFFFFFFFFFFFFF, pcg, _lib.ptr(ref_off), st, 1,
+        _lib.ptr(out), current_stream_ptr(dev)), 'wb2_rank_histogram_mean')
+    return out
   if acc_row is None:
     out = torch.empty((n_outer, n_point, n_bins), dtype=torch.float64,
                       device=dev)

@@ -2699,25 +2699,34 @@ class RankHistogram(EnsembleMetric):
       numpy_stream = self._numpy_stream(fvar, tvar, geo, n_member, device)
       seed = 0
     dims, shape = geo.out_dims, geo.out_shape
-    acc_row, n_acc = None, 0
+    mean_over, acc_row, n_acc = None, None, 0
     if avg_dim is not None:
       axis = dims.index(avg_dim)
-      kept = tuple(n for i, n in enumerate(shape) if i != axis)
-      n_acc = int(np.prod(kept, dtype=np.int64))
-      rows = np.arange(n_acc, dtype=np.int64).reshape(kept)
-      rows = np.broadcast_to(np.expand_dims(rows, axis), shape)
-      acc_row = torch.from_numpy(np.ascontiguousarray(rows).ravel()).to(device)
+      out_shape = tuple(n for i, n in enumerate(shape) if i != axis)
+      if 1 <= n_bins <= engine.RANK_MEAN_MAX_BINS and shape[axis] >= 1:
+        # the mean of the one-hots over `avg_dim`, formed by the kernel itself
+        # (the outer index is C order over `shape`)
+        mean_over = (int(np.prod(shape[:axis], dtype=np.int64)), shape[axis],
+                     int(np.prod(shape[axis + 1:], dtype=np.int64)))
+      else:  # counts by atomic adds, divided below
+        n_acc = int(np.prod(out_shape, dtype=np.int64))
+        rows = np.arange(n_acc, dtype=np.int64).reshape(out_shape)
+        rows = np.broadcast_to(np.expand_dims(rows, axis), shape)
+        acc_row = torch.from_numpy(
+            np.ascontiguousarray(rows).ravel()).to(device)
       dims = tuple(d for d in dims if d != avg_dim)
-      out_shape = kept
     else:
       out_shape = shape
     hist = engine.rank_histogram(
         ften, member_slabs * n_point, n_member, ens_table,
         tten.reshape(-1, n_point), truth_table, geo.n_outer, n_point, n_bins,
         self._break_ties_randomly, seed, acc_row, n_acc,
-        numpy_stream=numpy_stream)
-    if avg_dim is not None:
-      hist /= shape[axis]
+        numpy_stream=numpy_stream, mean_over=mean_over)
+    if acc_row is not None:
+      # tensor / tensor: a true division like NumPy's mean (torch multiplies by
+      # the reciprocal when the divisor is a Python scalar)
+      hist = hist / torch.full((), float(shape[axis]), dtype=hist.dtype,
+                               device=hist.device)
     spatial = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
     hist = hist.reshape(tuple(out_shape) + tuple(ften.shape[-2:]) + (n_bins,))
     have = tuple(dims) + tuple(spatial) + ('bins',)
