@@ -87,3 +87,67 @@ def test_energy_score_matches_oracle(ensemble_size):
       helpers.assert_close(got['geopotential'].values,
                            want['geopotential'].data, rtol=1e-9, atol=1e-12,
                            err_msg=oname)
+
+
+def test_gaussian_scores_pointwise_against_scipy():
+  """The Gaussian kernels' normal cdf / pdf (csrc/gauss_math.hpp: one exp, an
+  erfcx table in LDS, the asymptotic series beyond |z| = 17) point by point:
+  every outer slab is a 2 x 2 grid holding ONE sample four times, so the
+  spatial mean is the sample's score.  z sweeps [-37, 37] (both tails, the
+  table's interval edges, the switch to the series; beyond, the tail is a
+  float64 denormal and nobody's digits mean anything) and |z| > 39 (the tail
+  underflows to 0 on both sides), plus NaN / inf / zero std; against
+  scipy.stats.norm in float64."""
+  import torch
+  from scipy import stats
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  dev = torch.device('cuda', 0)
+  rng = np.random.default_rng(5)
+  edges = np.arange(0, 26 * 16 + 1) / 16.0 * np.sqrt(2.0)
+  z = np.concatenate([rng.uniform(-37, 37, 20000), rng.normal(0, 1.5, 20000),
+                      edges, -edges, np.nextafter(edges, 0), [0.0, -0.0],
+                      rng.uniform(39, 60, 50), -rng.uniform(39, 60, 50)])
+  sd = rng.uniform(0.25, 4.0, z.size).astype(np.float32)
+  y = rng.normal(0, 3, z.size).astype(np.float32)
+  mean = (y + z.astype(np.float32) * sd).astype(np.float32)
+  special = np.array([[np.nan, 1, 0], [0, np.nan, 0], [0, 1, np.nan],
+                      [1, 0, 0], [0, 0, 0], [np.inf, 1, 0], [0, np.inf, 1]],
+                     dtype=np.float32)
+  mean = np.concatenate([mean, special[:, 0]])
+  sd = np.concatenate([sd, special[:, 1]])
+  y = np.concatenate([y, special[:, 2]])
+  n = mean.size
+  plan = plan_lib.build_plan(np.array([-30.0, 30.0]), np.array([0.0, 180.0]),
+                             plan_lib.LATLON, {'global': None}, dev)
+
+  def slabs(v):
+    return torch.from_numpy(np.repeat(v[:, None], 4, 1).reshape(n, 2, 2)).to(dev)
+  with np.errstate(all='ignore'):
+    nd = ((mean - y) / sd).astype(np.float64)  # formed in float32, promoted
+    want_crps = sd.astype(np.float64) * (
+        nd * (2 * stats.norm.cdf(nd) - 1) + 2 * stats.norm.pdf(nd)
+        - 1 / np.sqrt(np.pi))
+  got, _ = engine.stream_reduce(plan, _lib.MODE_GAUSS,
+                                [slabs(mean), slabs(sd), slabs(y)],
+                                [None] * 3, n, False)
+  got = got.cpu().numpy()[:, 0, :]
+  np.testing.assert_allclose(got[0], want_crps, rtol=1e-13, atol=1e-14,
+                             equal_nan=True)
+  np.testing.assert_allclose(got[1], (sd * sd).astype(np.float64), rtol=1e-15,
+                             equal_nan=True)
+  # thresholds: Brier, ignorance, RPS part (metrics.py:975-1121)
+  thr = rng.normal(0, 3, n).astype(np.float32)
+  with np.errstate(all='ignore'):
+    nt = ((thr - mean) / sd).astype(np.float64)
+    cdf = stats.norm.cdf(nt)
+    above, below = y > thr, y < thr
+    want = [((1 - cdf) - above) ** 2,
+            -np.where(above, np.log(1 - cdf), np.log(cdf)),
+            (cdf - below) ** 2]
+  got, _ = engine.stream_reduce(plan, _lib.MODE_GAUSS_THR,
+                                [slabs(mean), slabs(sd), slabs(y), slabs(thr)],
+                                [None] * 4, n, False)
+  got = got.cpu().numpy()[:, 0, :]
+  for k in range(3):
+    np.testing.assert_allclose(got[k], want[k], rtol=2e-13, atol=1e-15,
+                               equal_nan=True, err_msg=str(k))

@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "trace.hpp"
 #include "reduce_common.hpp"
+#include "gauss_math.hpp"
 #include "wb2hip.h"
 
 #include <cstdlib>
@@ -210,11 +211,14 @@ struct PointOps<WB2_MODE_DET_ACC> {
   }
 };
 
-template <int MODE, bool SKIPNA, typename T>
-__device__ __forceinline__ void eval_slots(
+// Returns true when a Gaussian mode met |z| beyond the erfcx table and the
+// point has to be repeated with ERFCX_FAR = true (gauss_math.hpp).
+template <int MODE, bool SKIPNA, typename T, bool ERFCX_FAR = false>
+__device__ __forceinline__ bool eval_slots(
     const T (&in)[ModeTraits<MODE, SKIPNA>::NIN],
     double (&x)[ModeTraits<MODE, SKIPNA>::K], double aux = 0.0,
-    double scalar = 0.0) {
+    double scalar = 0.0, const double* erfcx_lds = nullptr) {
+  bool far = false;
   if constexpr (MODE == WB2_MODE_SEEPS) {
     // metrics.py:444-507: in = (forecast, truth, wet threshold at valid time),
     // aux = climatological dry fraction p1 (NaN where masked out), scalar = dry
@@ -250,13 +254,13 @@ __device__ __forceinline__ void eval_slots(
     // dtype and scipy's norm.cdf promotes it to float64.
     const T mean = in[0], sd = in[1], y = in[2], thr = in[3];
     const T nt = (thr - mean) / sd;
-    const double z = (double)nt;
-    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
+    double cdf, pdf_unused;
+    far = normal_cdf_pdf<ERFCX_FAR>((double)nt, erfcx_lds, cdf, pdf_unused);
     const bool above = y > thr, below = y < thr;
     const double tp = above ? 1.0 : 0.0, te = below ? 1.0 : 0.0;
     const double db = (1.0 - cdf) - tp;
     const double dr = cdf - te;
-    const double v[3] = {db * db, -(above ? log(1.0 - cdf) : log(cdf)), dr * dr};
+        const double v[3] = {db * db, -log_unit(above ? 1.0 - cdf : cdf), dr * dr};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if constexpr (SKIPNA) {
@@ -274,8 +278,8 @@ __device__ __forceinline__ void eval_slots(
     const T mean = in[0], sd = in[1], y = in[2];
     const T nd = (mean - y) / sd;
     const double z = (double)nd;
-    const double cdf = 0.5 * erfc(-z * 0.70710678118654752440);
-    const double pdf = exp(-0.5 * z * z) * 0.39894228040143267794;
+    double cdf, pdf;
+    far = normal_cdf_pdf<ERFCX_FAR>(z, erfcx_lds, cdf, pdf);
     const double crps =
         (double)sd * (z * (2.0 * cdf - 1.0) + 2.0 * pdf - 0.56418958354775628695);
     const T var = sd * sd;
@@ -295,6 +299,7 @@ __device__ __forceinline__ void eval_slots(
     PointOps<MODE>::template elementwise<T>(in, q);
     PointOps<MODE>::template slots<SKIPNA, T>(q, x);
   }
+  return far;
 }
 
 // Tuning knobs (defaults are the measured best; see profiles/NOTES.md).
@@ -329,6 +334,11 @@ __device__ __forceinline__ void eval_slots(
 // run, the field is re-fetched through the fabric for every slab: measured
 // 1.6 x the algorithmic bytes, profiles/r03_k1_variants.md).
 #define WB2_WF_OUTER_FASTEST 1
+#endif
+#ifndef WB2_GAUSS_GROUP
+// Gaussian modes: points of a lane's load evaluated as one straight-line block
+// (2: two dependent fp64 chains interleaved at 114 VGPRs; 4 costs a wave per SIMD)
+#define WB2_GAUSS_GROUP 2
 #endif
 #ifndef WB2_PACK_PAIRS
 // 1: float32 columns through the elementwise stage in pairs (v_pk_*_f32).
@@ -421,6 +431,14 @@ __global__ void __launch_bounds__(512)
   // != 0) loads the row's LAST VEC columns instead; the columns below col0,
   // which its neighbour owns, are dropped when the sums are folded.
   const int colb = (VEC > 1 && col0 + VEC > p.n_col) ? p.n_col - VEC : col0;
+  // Gaussian modes: the erfcx table (gauss_math.hpp) into LDS, by the whole
+  // workgroup, before any wave leaves
+  [[maybe_unused]] const double* erfcx_lds = nullptr;
+  if constexpr (MODE == WB2_MODE_GAUSS || MODE == WB2_MODE_GAUSS_THR) {
+    __shared__ __attribute__((aligned(16))) double erfcx_table[kErfcxDoubles];
+    load_erfcx_table(erfcx_table);
+    erfcx_lds = erfcx_table;
+  }
   if (nrow <= 0 || tile >= p.n_ctile || o >= p.n_outer) return;  // wave-uniform
 
   double acc[NWF][VEC][K];
@@ -544,6 +562,40 @@ __global__ void __launch_bounds__(512)
             Ops::template slots<SKIPNA, T>(q, x);
             accumulate(e + h, x, wf[e + h], wr);
           }
+        }
+      } else if constexpr (MODE == WB2_MODE_GAUSS ||
+                           MODE == WB2_MODE_GAUSS_THR) {
+        // the lane's points as ONE straight-line block (their dependent fp64
+        // chains interleave); a point beyond the erfcx table is repeated with
+        // the series behind a wave-uniform branch
+        constexpr int G = VEC < WB2_GAUSS_GROUP ? VEC : WB2_GAUSS_GROUP;
+#pragma unroll
+        for (int e0 = 0; e0 < VEC; e0 += G) {
+          double x[G][K];
+          bool far[G], any = false;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            T in[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) in[i] = v[i][e0 + g];
+            far[g] = eval_slots<MODE, SKIPNA, T>(in, x[g], 0.0, 0.0, erfcx_lds);
+            any = any || far[g];
+          }
+          if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              if (far[g]) {
+                T in[NIN];
+#pragma unroll
+                for (int i = 0; i < NIN; ++i) in[i] = v[i][e0 + g];
+                eval_slots<MODE, SKIPNA, T, true>(in, x[g], 0.0, 0.0,
+                                                  erfcx_lds);
+              }
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            accumulate(e0 + g, x[g], wf[e0 + g], wr);
         }
       } else {
 #pragma unroll
