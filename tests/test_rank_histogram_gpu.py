@@ -415,7 +415,7 @@ def test_mean_kernel_equals_the_atomic_counts(dtype_name):
     n_acc = int(np.prod(kept)) if kept else 1
     rows = np.arange(n_acc, dtype=np.int64).reshape(kept)
     rows = np.broadcast_to(np.expand_dims(rows, axis), shape)
-    acc_row = torch.from_numpy(np.ascontiguousarray(rows).ravel()).to(dev)
+    acc_row = torch.from_numpy(np.array(rows).ravel()).to(dev)
     counts = engine.rank_histogram(ens, n_outer * n_point, n_member, None,
                                    truth, None, n_outer, n_point, n_bins, True,
                                    77, acc_row, n_acc)

@@ -2712,8 +2712,7 @@ class RankHistogram(EnsembleMetric):
         n_acc = int(np.prod(out_shape, dtype=np.int64))
         rows = np.arange(n_acc, dtype=np.int64).reshape(out_shape)
         rows = np.broadcast_to(np.expand_dims(rows, axis), shape)
-        acc_row = torch.from_numpy(
-            np.ascontiguousarray(rows).ravel()).to(device)
+        acc_row = torch.from_numpy(np.array(rows).ravel()).to(device)
       dims = tuple(d for d in dims if d != avg_dim)
     else:
       out_shape = shape
