@@ -230,14 +230,24 @@ __device__ __forceinline__ bool eval_slots(
     };
     const int fc = cat(f), tc = cat(y);
     const T p1 = (T)aux, one = (T)1;
-    // 0.5 * scoring matrix [forecast_cat][truth_cat], in the dtype of p1
+    // 0.5 * scoring matrix [forecast_cat][truth_cat], in the dtype of p1:
+    //   [0][1] 1 / (1 - p1)   [0][2] 4 / (1 - p1)   [1][0] 1 / p1
+    //   [1][2] 3 / (1 - p1)   [2][1] 3 / (2 + p1)   [2][0] 1 / p1 + 3 / (2 + p1)
+    // as TWO IEEE divisions per point -- numerator and denominator of the one
+    // quotient a cell needs are selected first (the quotients themselves are
+    // the reference's, bit for bit), 3 / (2 + p1) serves [2][1] and [2][0] --
+    // instead of the five a select over ready-made entries evaluates.
+    const bool to_dry = tc == 0;  // [1][0], [2][0]: 1 / p1
+    const T num = to_dry ? one
+                         : (fc == 0 ? (tc == 1 ? one : (T)4) : (T)3);
+    const T den = to_dry ? p1 : one - p1;
+    const T d1 = num / den;
+    const T d2 = (T)3 / ((T)2 + p1);
     T m = (T)0;
-    if (fc == 0 && tc == 1) m = one / (one - p1);
-    if (fc == 0 && tc == 2) m = (T)4 / (one - p1);
-    if (fc == 1 && tc == 0) m = one / p1;
-    if (fc == 1 && tc == 2) m = (T)3 / (one - p1);
-    if (fc == 2 && tc == 0) m = one / p1 + (T)3 / ((T)2 + p1);
-    if (fc == 2 && tc == 1) m = (T)3 / ((T)2 + p1);
+    if ((fc == 0 && (tc == 1 || tc == 2)) || (fc == 1 && (tc == 0 || tc == 2)))
+      m = d1;
+    if (fc == 2 && tc == 0) m = d1 + d2;
+    if (fc == 2 && tc == 1) m = d2;
     double v = (double)((T)0.5 * m);
     if (is_nan(f) || is_nan(y) || is_nan(aux)) v = __builtin_nan("");
     if constexpr (SKIPNA) {
@@ -403,7 +413,9 @@ __global__ void __launch_bounds__(512)
   // readfirstlane: tell the compiler the wave index is wave-uniform (SGPR).
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int nwave = blockDim.x / kWave;
-  constexpr bool OUTER_FASTEST = WF && WB2_WF_OUTER_FASTEST;
+  // (SEEPS: the same for its 2-D p1 field)
+  constexpr bool OUTER_FASTEST =
+      (WF || MODE == WB2_MODE_SEEPS) && WB2_WF_OUTER_FASTEST;
   const unsigned bx = OUTER_FASTEST ? blockIdx.y : blockIdx.x;
   const unsigned tblk = bx / (unsigned)p.n_chunk;
   const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
@@ -974,7 +986,7 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
   const long long gz = (p.n_outer + gy - 1) / gy;  // kernel guards o < n_outer
   const dim3 grid =
-      (WF && WB2_WF_OUTER_FASTEST)
+      ((WF || MODE == WB2_MODE_SEEPS) && WB2_WF_OUTER_FASTEST)
           ? dim3((unsigned)gy, (unsigned)(p.n_chunk * n_tblk), (unsigned)gz)
           : dim3((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
   // unaligned float32 rows at 4 columns per lane: SGPR row bases are worth 4 %
@@ -1069,21 +1081,39 @@ struct SeepsMapParams {
   long long n_outer, n_point;
 };
 
+// A thread owns one grid point of kSeepsMapSlabs consecutive outer slabs: p1
+// (8 bytes per point, the same for every slab) is read once per group instead
+// of once per slab, and the group's 3 x kSeepsMapSlabs loads are in flight
+// together.  grid: x = point blocks, (y, z) = slab groups.
+constexpr int kSeepsMapSlabs = 8;
+
 template <typename T>
 __global__ void __launch_bounds__(256) seeps_map_kernel(const SeepsMapParams p) {
   const long long pt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long o = blockIdx.y + (long long)blockIdx.z * gridDim.y;
-  if (pt >= p.n_point || o >= p.n_outer) return;
-  T in[3];
+  const long long o0 =
+      (blockIdx.y + (long long)blockIdx.z * gridDim.y) * kSeepsMapSlabs;
+  if (pt >= p.n_point || o0 >= p.n_outer) return;
+  const double p1 = p.aux[pt];
+  T in[kSeepsMapSlabs][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const long long sl = p.slab[i] ? p.slab[i][o] : o;
-    in[i] = __builtin_nontemporal_load(static_cast<const T*>(p.in[i]) +
-                                       sl * p.n_point + pt);
+  for (int s = 0; s < kSeepsMapSlabs; ++s) {
+    // slabs past the end read the group's first one again (dropped below)
+    const long long o = o0 + s < p.n_outer ? o0 + s : o0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const long long sl = p.slab[i] ? p.slab[i][o] : o;
+      in[s][i] = __builtin_nontemporal_load(static_cast<const T*>(p.in[i]) +
+                                            sl * p.n_point + pt);
+    }
   }
-  double x[1];
-  eval_slots<WB2_MODE_SEEPS, false, T>(in, x, p.aux[pt], p.scalar);
-  __builtin_nontemporal_store(x[0], p.out + o * p.n_point + pt);
+#pragma unroll
+  for (int s = 0; s < kSeepsMapSlabs; ++s) {
+    if (o0 + s < p.n_outer) {
+      double x[1];
+      eval_slots<WB2_MODE_SEEPS, false, T>(in[s], x, p1, p.scalar);
+      __builtin_nontemporal_store(x[0], p.out + (o0 + s) * p.n_point + pt);
+    }
+  }
 }
 
 // One wave per column tile; up to 8 tiles share a workgroup.
@@ -1422,8 +1452,9 @@ int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
   p.out = out;
   p.n_outer = n_outer;
   p.n_point = n_point;
-  const long long gy = n_outer < 32768 ? n_outer : 32768;
-  const long long gz = (n_outer + gy - 1) / gy;
+  const long long n_group = (n_outer + kSeepsMapSlabs - 1) / kSeepsMapSlabs;
+  const long long gy = n_group < 32768 ? n_group : 32768;
+  const long long gz = (n_group + gy - 1) / gy;
   WB2_REQUIRE(gz <= 65535, "n_outer=%lld too large", (long long)n_outer);
   const dim3 grid((unsigned)((n_point + 255) / 256), (unsigned)gy, (unsigned)gz);
   hipStream_t s = static_cast<hipStream_t>(stream);
