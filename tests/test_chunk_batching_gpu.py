@@ -279,3 +279,31 @@ def test_float32_results_accumulate_like_their_float64_copies(skipna):
       assert torch.equal(torch.nan_to_num(a, nan=-7.0),
                          torch.nan_to_num(b, nan=-7.0))
     assert accs[0][1].max().item() == 1.0 + 7
+
+
+def test_default_window_is_sized_by_the_first_chunk(monkeypatch):
+  """evaluate_chunks without `batch_chunks`: as many chunks per window as hold
+  AUTO_BATCH_BYTES of input (at most AUTO_BATCH_MAX) -- fewer fused launches
+  than chunks, the bits of chunk-by-chunk evaluation."""
+  from weatherbench2_amd import engine, evaluation
+  _, _, _, _, gf, gt, cfg = _setup(True, n_init=6, n_lead=3)
+  pairs = oc.chunk_pairs(gf, gt, 'init')
+  base = evaluation.evaluate_chunks(pairs, cfg, batch_chunks=1)
+  seen, old = _launch_counter()
+  try:
+    auto = evaluation.evaluate_chunks(pairs, cfg)
+    n_auto = seen.count('stream_partials')
+    # a byte budget of one chunk: back to one window per chunk
+    first = sum(evaluation._input_bytes(ds) for ds in pairs[0])
+    monkeypatch.setattr(evaluation, 'AUTO_BATCH_BYTES', first)
+    del seen[:]
+    single = evaluation.evaluate_chunks(pairs, cfg)
+    n_single = seen.count('stream_partials')
+  finally:
+    engine.set_launch_hook(old)
+  assert n_auto == 2, n_auto  # 18 chunks, one rectangle: det + wind
+  assert n_single == 2 * len(pairs), (n_single, len(pairs))
+  for name in base.keys():
+    for other in (auto, single):
+      assert np.array_equal(other[name].values, base[name].values,
+                            equal_nan=True), name

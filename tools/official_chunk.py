@@ -1,6 +1,6 @@
 """The drop-in boundary at the reference's PRODUCTION chunking, measured.
 
-  python tools/official_chunk.py [--chunks 96] [--batch 1,16,32] [--profile]
+  python tools/official_chunk.py [--chunks 96] [--batch 1,16,32,default] [--profile]
 
 The official 0.25-degree deterministic run (docs/source/official-evaluation.md:
 537-556) feeds `_evaluate_chunk` (evaluation.py:583-599) one chunk per
@@ -141,7 +141,9 @@ def build(dev, n_chunks: int, pool: int, n_lead: int = 4):
   return chunks, cfg
 
 
-def measure(chunks, cfg, batch: int, timed_events: bool = True) -> dict:
+def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
+  """`batch`: chunks per window, or None = evaluate_chunks' default (as many
+  as hold 16 GiB of input: 22 of these chunks)."""
   import torch
   from weatherbench2_amd import engine, evaluation
   marks = {}
@@ -156,16 +158,24 @@ def measure(chunks, cfg, batch: int, timed_events: bool = True) -> dict:
   try:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = evaluation.evaluate_chunks(chunks, cfg, False, batch_chunks=batch,
-                                     prefetch=0)
+    out = evaluation.evaluate_chunks(
+        chunks, cfg, False, prefetch=0,
+        **({} if batch is None else {'batch_chunks': batch}))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
   finally:
     evaluation.RunningMean.result = real_result
     engine.set_launch_hook(old)
   n = len(chunks)
+  if batch is None:
+    first = sum(evaluation._input_bytes(ds) for ds in chunks[0])
+    batch = int(min(evaluation.AUTO_BATCH_MAX,
+                    max(1, evaluation.AUTO_BATCH_BYTES // first)))
+    auto = True
+  else:
+    auto = False
   leg = {
-      'batch_chunks': batch, 'chunks': n,
+      'batch_chunks': batch, 'default_window': auto, 'chunks': n,
       'value': n * PTS_PER_CHUNK / (t1 - t0), 'unit': 'grid-point-evals/s',
       'wall_ms_per_chunk': (t1 - t0) / n * 1e3,
       'host_ms_per_chunk': (marks['enqueued'] - t0) / n * 1e3,
@@ -202,8 +212,8 @@ def measure(chunks, cfg, batch: int, timed_events: bool = True) -> dict:
   return leg
 
 
-def run(dev, n_chunks: int = 256, pool: int = 24, batches=(1, 16, 32),
-        headline_batch: int = 32) -> dict:
+def run(dev, n_chunks: int = 256, pool: int = 24,
+        batches=(1, 16, 32, None), headline_batch=None) -> dict:
   """The `api_official_chunk` object of the bench line."""
   import torch
   from weatherbench2_amd import metrics as gm
@@ -212,13 +222,15 @@ def run(dev, n_chunks: int = 256, pool: int = 24, batches=(1, 16, 32),
   legs = {}
   for b in batches:
     gm.clear_caches()
-    measure(chunks[:max(2 * b, 8)], cfg, b, timed_events=False)  # warm
+    measure(chunks[:max(2 * (b or 22), 8)], cfg, b, timed_events=False)  # warm
     # host-bound small batches: a 64-chunk sample (3 ms per chunk); the rest
     # run the whole list (the first window's host time is not overlapped: a
     # fill effect of 1 / windows)
-    legs[str(b)] = measure(chunks if b >= 8 else chunks[:64], cfg, b)
-  head = legs[str(headline_batch)] if str(headline_batch) in legs else (
-      legs[str(batches[-1])])
+    name = 'default' if b is None else str(b)
+    legs[name] = measure(chunks if (b is None or b >= 8) else chunks[:64],
+                         cfg, b)
+  head_name = 'default' if headline_batch is None else str(headline_batch)
+  head = legs[head_name] if head_name in legs else legs[list(legs)[-1]]
   out = dict(head)
   out['by_batch_chunks'] = legs
   out['config'] = {
@@ -238,7 +250,7 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--chunks', type=int, default=96)
   ap.add_argument('--pool', type=int, default=24)
-  ap.add_argument('--batch', default='1,16,32')
+  ap.add_argument('--batch', default='1,16,32,default')
   ap.add_argument('--profile', action='store_true',
                   help='cProfile of the host path at the first batch size')
   ap.add_argument('--sections', action='store_true',
@@ -246,7 +258,8 @@ def main():
   args = ap.parse_args()
   import torch
   dev = torch.device('cuda', 0)
-  batches = tuple(int(b) for b in args.batch.split(','))
+  batches = tuple(None if b == 'default' else int(b)
+                  for b in args.batch.split(','))
   if args.sections:
     # wall time of the host path's sections at batch_chunks = first entry,
     # without a profiler's per-call overhead (a few timers per chunk)

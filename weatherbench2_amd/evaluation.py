@@ -494,11 +494,14 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
   return lo, lo + base + (1 if rank < extra else 0)
 
 
-def _prefetched(chunks, lo: int, hi: int, depth: int):
+def _prefetched(chunks, lo: int, hi: int, depth):
   """Yields chunks[lo], ..., chunks[hi - 1] in order, fetching up to `depth`
   items ahead on ONE background thread (so the fetches themselves stay in
-  order -- sequences that read a file sequentially keep doing so)."""
-  if depth <= 0 or hi - lo <= 1:
+  order -- sequences that read a file sequentially keep doing so).  `depth` is
+  an int or a callable read before every fetch (the window size of
+  evaluate_chunks is only known after the first chunk)."""
+  depth_now = depth if callable(depth) else (lambda: depth)
+  if depth_now() <= 0 or hi - lo <= 1:
     for i in range(lo, hi):
       yield chunks[i]
     return
@@ -514,7 +517,7 @@ def _prefetched(chunks, lo: int, hi: int, depth: int):
     nxt = lo
     try:
       while nxt < hi or pending:
-        while nxt < hi and len(pending) <= depth:
+        while nxt < hi and len(pending) <= depth_now():
           pending.append(pool.submit(chunks.__getitem__, nxt))
           nxt += 1
         yield pending.popleft().result()
@@ -754,6 +757,23 @@ def _batches(pairs: list, time_dim: str, lead_dim: t.Optional[str]):
 EVALUATE_ROWS_PER_CHUNK = 32
 
 
+# evaluate_chunks(batch_chunks=None): chunks per window = what holds this many
+# bytes of (forecast + truth) input, at most AUTO_BATCH_MAX
+AUTO_BATCH_BYTES = 16 << 30
+AUTO_BATCH_MAX = 32
+
+
+def _input_bytes(ds: xl.Dataset) -> int:
+  total = 0
+  for da in ds.data_vars.values():
+    data = da.data
+    itemsize = getattr(data, 'itemsize', None)
+    if itemsize is None and hasattr(data, 'element_size'):
+      itemsize = data.element_size()
+    total += int(np.prod(da.shape, dtype=np.int64)) * int(itemsize or 4)
+  return total
+
+
 def evaluate_chunks(
     chunks: t.Sequence[tuple],
     eval_config: config.Eval,
@@ -764,7 +784,7 @@ def evaluate_chunks(
     truth=None,
     climatology=None,
     by_init: bool = True,
-    batch_chunks: int = 1,
+    batch_chunks: t.Optional[int] = None,
 ) -> xl.Dataset:
   """Evaluates (forecast, truth) chunks and returns the temporal mean.
 
@@ -784,7 +804,9 @@ def evaluate_chunks(
   configuration does): results accumulate per lead label (`RunningMean`).
 
   `batch_chunks` = k (deterministic suites: MSE / RMSE / MAE / Bias / ACC /
-  wind vectors; ignored otherwise) evaluates k consecutive chunks in ONE pass of
+  wind vectors; ignored otherwise; None = as many chunks as hold
+  AUTO_BATCH_BYTES of input, at most AUTO_BATCH_MAX -- 22 of the official
+  0.25-degree chunks) evaluates k consecutive chunks in ONE pass of
   the metric x region loop: they are concatenated without copying (`concat_chunks`: a
   (time x lead) rectangle of chunks becomes one Dataset whose variables index
   the chunks' own arrays), so one fused launch reads every variable of all k
@@ -809,7 +831,8 @@ def evaluate_chunks(
                      'ranks (every rank must take part in the all-reduce)')
   lo, hi = shard_bounds(len(chunks), world, rank)
   substitute = _chunk_substitution(eval_config, truth, climatology, by_init)
-  batch_chunks = max(1, int(batch_chunks))
+  auto_batch = batch_chunks is None
+  batch_chunks = AUTO_BATCH_MAX if auto_batch else max(1, int(batch_chunks))
   if eval_config.derived_variables or not all(
       getattr(m, '_reads_slabs_in_place', False)
       for m in eval_config.metrics.values()):
@@ -818,7 +841,7 @@ def evaluate_chunks(
     # materialise the window first -- a copy of the data, slower than going
     # chunk by chunk.  Derived variables are computed on (and assigned into)
     # each chunk as the caller handed it in (evaluation.py:402-405).
-    batch_chunks = 1
+    batch_chunks, auto_batch = 1, False
   mean: t.Optional[RunningMean] = None
   window: list = []
 
@@ -838,12 +861,20 @@ def evaluate_chunks(
     window.clear()
 
   with metrics_lib.pinned_rows_per_chunk(EVALUATE_ROWS_PER_CHUNK):
-    for forecast, truth_chunk in _prefetched(
-        chunks, lo, hi, max(prefetch, batch_chunks - 1 if prefetch else 0)):
+    # while the window size is undecided (auto) only `prefetch` items are
+    # fetched ahead; afterwards enough to fill a window
+    depth = lambda: max(prefetch, (batch_chunks - 1)
+                        if prefetch and not auto_batch else 0)
+    for forecast, truth_chunk in _prefetched(chunks, lo, hi, depth):
       forecast = xl.as_dataset(forecast)
       if substitute is not None:
         forecast = xl.as_dataset(substitute(forecast, truth_chunk))
       window.append((forecast, xl.as_dataset(truth_chunk)))
+      if auto_batch:  # sized by the first chunk: its inputs' bytes
+        nbytes = max(1, sum(_input_bytes(ds) for ds in window[0]))
+        batch_chunks = int(min(AUTO_BATCH_MAX,
+                               max(1, AUTO_BATCH_BYTES // nbytes)))
+        auto_batch = False
       if len(window) >= batch_chunks:
         flush()
     flush()
