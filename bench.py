@@ -44,7 +44,7 @@ and on one GPU (N = 1), each with its own `roofline`:
   api_official_chunk  the drop-in API at the reference's production chunking
                   (init_time=1,lead_time=1 chunks of 13 variables, the 16
                   official regions, mse + wind vectors + acc + bias + mae)
-                  through evaluation.evaluate_chunks (its default window -- 22
+                  through evaluation.evaluate_chunks (its default window -- 24
                   chunks -- and batch_chunks=1 / 16 / 32):
                   tools/official_chunk.py;
   pcie_inclusive  inputs arriving from pinned host memory through the

@@ -143,7 +143,7 @@ def build(dev, n_chunks: int, pool: int, n_lead: int = 4):
 
 def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
   """`batch`: chunks per window, or None = evaluate_chunks' default (as many
-  as hold 16 GiB of input: 22 of these chunks)."""
+  as hold 16 GiB of input: 24 of these chunks)."""
   import torch
   from weatherbench2_amd import engine, evaluation
   marks = {}
@@ -222,7 +222,7 @@ def run(dev, n_chunks: int = 256, pool: int = 24,
   legs = {}
   for b in batches:
     gm.clear_caches()
-    measure(chunks[:max(2 * (b or 22), 8)], cfg, b, timed_events=False)  # warm
+    measure(chunks[:max(2 * (b or 24), 8)], cfg, b, timed_events=False)  # warm
     # host-bound small batches: a 64-chunk sample (3 ms per chunk); the rest
     # run the whole list (the first window's host time is not overlapped: a
     # fill effect of 1 / windows)

@@ -805,7 +805,7 @@ def evaluate_chunks(
 
   `batch_chunks` = k (deterministic suites: MSE / RMSE / MAE / Bias / ACC /
   wind vectors; ignored otherwise; None = as many chunks as hold
-  AUTO_BATCH_BYTES of input, at most AUTO_BATCH_MAX -- 22 of the official
+  AUTO_BATCH_BYTES of input, at most AUTO_BATCH_MAX -- 24 of the official
   0.25-degree chunks) evaluates k consecutive chunks in ONE pass of
   the metric x region loop: they are concatenated without copying (`concat_chunks`: a
   (time x lead) rectangle of chunks becomes one Dataset whose variables index
