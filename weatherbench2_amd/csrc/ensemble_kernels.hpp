@@ -739,8 +739,11 @@ __global__ void __launch_bounds__(256)
   const int nwave = blockDim.x / kWave;
   const unsigned bx = blockIdx.x;
   const unsigned tblk = bx / (unsigned)p.n_chunk;
-  const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
   const long long o = (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  // chunks rotated by the slab number: a fixed chunk -> XCD map (workgroup x
+  // lands on XCD x % 8) would give some XCDs the short chunks of every slab
+  const int chunk = (int)(((long long)(bx - tblk * (unsigned)p.n_chunk) +
+                           (WB2_ROTATE_CHUNKS ? o : 0)) % p.n_chunk);
   const int tile = (int)tblk * nwave + wave;
 
   const int row0 = p.chunk_row0[chunk];

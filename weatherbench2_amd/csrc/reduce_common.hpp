@@ -3,6 +3,15 @@
 
 #include "common.hpp"
 
+#ifndef WB2_ROTATE_CHUNKS
+// 1: the ensemble kernels, whose workgroup index runs over the chunks of a slab
+// first (grid x = chunk, y = slab), take chunk (x + slab) % n_chunk: workgroup
+// x always lands on XCD x % 8 (n_chunk % 8 == 0), chunks differ in size, and a
+// FIXED chunk -> XCD map gives some XCDs the short chunks of every slab
+// (profiles/r04_xcd_balance.md; K1 runs slab-fastest instead).
+#define WB2_ROTATE_CHUNKS 1
+#endif
+
 namespace wb2 {
 
 // ---- many sums at once -------------------------------------------------------

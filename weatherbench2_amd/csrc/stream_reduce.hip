@@ -336,15 +336,6 @@ __device__ __forceinline__ bool eval_slots(
 #ifndef WB2_NT_LOADS
 #define WB2_NT_LOADS 1
 #endif
-#ifndef WB2_WF_OUTER_FASTEST
-// Workgroup order of the weight-field instantiations: 1 = the outer slab is the
-// fastest-varying grid dim, so the workgroups resident at any moment work on
-// the SAME few row chunks of different slabs and re-read the same ~1 MB of the
-// 2-D weight field from L2 (with the chunk fastest, as the field-free kernels
-// run, the field is re-fetched through the fabric for every slab: measured
-// 1.6 x the algorithmic bytes, profiles/r03_k1_variants.md).
-#define WB2_WF_OUTER_FASTEST 1
-#endif
 #ifndef WB2_GAUSS_GROUP
 // Gaussian modes: points of a lane's load evaluated as one straight-line block
 // (2: two dependent fp64 chains interleaved at 114 VGPRs; 4 costs a wave per SIMD)
@@ -386,8 +377,19 @@ __device__ __forceinline__ void load_wf(const WB2_GLOBAL double* p,
   for (int e = 0; e < VEC; ++e) v[e] = p[e];
 }
 
-// Geometry: blockIdx.x = tile_block * n_chunk + chunk (n_chunk % 8 == 0, so a
-// chunk always lands on XCD chunk % 8), blockIdx.y/z = outer slab.  Every WAVE
+// Geometry: the outer SLAB is the fastest-varying grid dim (blockIdx.x; z
+// continues it), blockIdx.y = tile_block * n_chunk + chunk.  Workgroups are
+// dealt to the 8 XCDs round-robin by their linear index, so (a) every XCD works
+// on slabs of its own and all of them on the SAME row chunk at any moment --
+// chunks differ in size (bands cut them at region boundaries, the last one is
+// short, the padding is empty) and a chunk-fastest grid whose x extent is a
+// multiple of 8 pins chunk c to XCD c % 8: some XCDs then get the short chunks
+// of EVERY slab (measured, profiles/r04_xcd_balance.md: the benched launch
+// 0.75 of the HBM peak chunk-fastest, 0.81 with the chunks rotated by the slab
+// number, 0.85 slab-fastest); (b) the workgroups resident at any moment re-read
+// the same ~1 MB of a 2-D weight field / SEEPS p1 field from L2 instead of
+// fetching it through the fabric for every slab (1.6 x the algorithmic bytes,
+// profiles/r03_k1_variants.md).  Every WAVE
 // of the workgroup owns one column tile of 64*VEC columns and is completely
 // independent of the others (no LDS, no barrier): waves stream, then fold their
 // own columns into the segs that intersect their tile with a wave64 butterfly.
@@ -413,15 +415,10 @@ __global__ void __launch_bounds__(512)
   // readfirstlane: tell the compiler the wave index is wave-uniform (SGPR).
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int nwave = blockDim.x / kWave;
-  // (SEEPS: the same for its 2-D p1 field)
-  constexpr bool OUTER_FASTEST =
-      (WF || MODE == WB2_MODE_SEEPS) && WB2_WF_OUTER_FASTEST;
-  const unsigned bx = OUTER_FASTEST ? blockIdx.y : blockIdx.x;
+  const unsigned bx = blockIdx.y;
   const unsigned tblk = bx / (unsigned)p.n_chunk;
+  const long long o = (long long)blockIdx.z * gridDim.x + blockIdx.x;
   const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
-  const long long o =
-      OUTER_FASTEST ? (long long)blockIdx.z * gridDim.x + blockIdx.x
-                    : (long long)blockIdx.z * gridDim.y + blockIdx.y;
   const int tile = (int)tblk * nwave + wave;
 
   // ---- branch-free prologue: issue every scalar load before any wait ----
@@ -985,10 +982,7 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
   const long long gz = (p.n_outer + gy - 1) / gy;  // kernel guards o < n_outer
-  const dim3 grid =
-      ((WF || MODE == WB2_MODE_SEEPS) && WB2_WF_OUTER_FASTEST)
-          ? dim3((unsigned)gy, (unsigned)(p.n_chunk * n_tblk), (unsigned)gz)
-          : dim3((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
+  const dim3 grid((unsigned)gy, (unsigned)(p.n_chunk * n_tblk), (unsigned)gz);
   // unaligned float32 rows at 4 columns per lane: SGPR row bases are worth 4 %
   // there (profiles/r03_k1_ab5_summary.txt), and cost 2-20 % everywhere else
   constexpr bool HAS_SG = std::is_same<T, float>::value && VEC == 4 &&
