@@ -106,6 +106,16 @@ def predefined_regions():
   }
 
 
+def coprime(k: int, n: int) -> int:
+  """The smallest integer >= k that is coprime to n: a unit stride k would map
+  consecutive units to fewer than min(units, n) distinct ones otherwise, and a
+  launch that reads a slab twice measures cache hits, not bandwidth."""
+  import math
+  while math.gcd(k, n) != 1:
+    k += 1
+  return k
+
+
 def ramp(step_fn, ms: float) -> None:
   """Untimed clock ramp: the same step, enqueued back to back for `ms` of wall
   time before the W warmup steps, WITHOUT draining the queue (the host only
@@ -438,7 +448,8 @@ def main():
     u = (first_unit + torch.arange(n_units, device=dev)) % pool
     fu = (u[:, None] * N_LEV + lev[None]).reshape(-1)
     tu = (((u + 7) % pool)[:, None] * N_LEV + lev[None]).reshape(-1)
-    cu = (((u * 5 + 3) % pool)[:, None] * N_LEV + lev[None]).reshape(-1)
+    cu = (((u * coprime(5, pool) + 3) % pool)[:, None] * N_LEV
+          + lev[None]).reshape(-1)
     return fu.contiguous(), tu.contiguous(), cu.contiguous()
 
   # warmup steps are always full; timed step i covers units_of_step(i)
@@ -1170,7 +1181,7 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
 
   def tabs(step, pool_units, k):
     u = (step * units + torch.arange(units, device=dev)) % pool_units
-    return [(((u * (2 * j + 1) + 3 * j) % pool_units)[:, None] * N_LEV
+    return [(((u * coprime(2 * j + 1, pool_units) + 3 * j) % pool_units)[:, None] * N_LEV
              + lev[None]).reshape(-1).contiguous() for j in range(k)]
 
   def run(pl, mode, inputs, pool_units, skipna):
@@ -1200,6 +1211,9 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
   f32 = [fpool, tpool, cpool]
   # lon-lat layout: the same bytes viewed as (slab, longitude, latitude)
   ll = [x.view(-1, N_LON, N_LAT) for x in f32]
+  # the fourth input of the wind mode: a pool of its own (reusing one of the
+  # three would let a launch read some slabs twice: cache hits, not bandwidth)
+  wpool = torch.randn_like(fpool) if only in (None, 'wind') else None
   f64 = None
   pool64 = units + 8
   if only in (None, 'f64_inputs'):
@@ -1218,7 +1232,7 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
       ('det_no_acc', pl13, _lib.MODE_DET, f32[:2], pool, False, 8.0,
        'MODE_DET f32 (MSE / RMSE / MAE / Bias without a climatology), 13 '
        'regions'),
-      ('wind', pl13, _lib.MODE_WIND, [fpool, tpool, cpool, fpool], pool, False,
+      ('wind', pl13, _lib.MODE_WIND, [fpool, tpool, cpool, wpool], pool, False,
        16.0, 'MODE_WIND f32: u, v of forecast and truth (4 inputs), 13 regions'),
       ('lonlat', pl_ll, _lib.MODE_DET_ACC, ll, pool, False, 12.0,
        'MODE_DET_ACC f32 on (..., longitude, latitude) slabs (721 columns: '
@@ -1250,7 +1264,7 @@ def k1_variants(dev, fpool, tpool, cpool, units, pool, steps=30,
                  'regions': pl.n_region,
                  'rows_per_chunk': rows_ll if name == 'lonlat' else rows,
                  'weight_field': pl.wfield is not None}
-  del f64
+  del f64, wpool
   return out
 
 

@@ -29,7 +29,7 @@ if [ "$2" != quick ]; then
     stats $w --workload $w --no-cpu-baseline
     timeout 300 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${R}_bench_$w.json
   done
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_oc -o run -- python $GRAFT_REPO_ROOT/tools/official_chunk.py --chunks 256 --batch 32 > $GRAFT_REPO_ROOT/$OUT/${R}_official_chunk_batch32.json 2>/dev/null)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_oc -o run -- python $GRAFT_REPO_ROOT/tools/official_chunk.py --chunks 128 --batch 32 > $GRAFT_REPO_ROOT/$OUT/${R}_official_chunk_batch32.json 2>/dev/null)
   f=$(find /tmp/prof_oc -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -25 "$f" > $OUT/${R}_official_chunk_kernel_stats.csv; rm -rf /tmp/prof_oc
   timeout 600 python tools/official_chunk.py > $OUT/${R}_official_chunk.json 2>/dev/null
   timeout 600 python tools/k3_variants.py > $OUT/${R}_k3_variants.json 2>/dev/null

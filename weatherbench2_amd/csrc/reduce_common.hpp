@@ -4,11 +4,11 @@
 #include "common.hpp"
 
 #ifndef WB2_ROTATE_CHUNKS
-// 1: the ensemble kernels, whose workgroup index runs over the chunks of a slab
-// first (grid x = chunk, y = slab), take chunk (x + slab) % n_chunk: workgroup
-// x always lands on XCD x % 8 (n_chunk % 8 == 0), chunks differ in size, and a
-// FIXED chunk -> XCD map gives some XCDs the short chunks of every slab
-// (profiles/r04_xcd_balance.md; K1 runs slab-fastest instead).
+// 1: kernels whose workgroup index runs over the chunks of a slab first (grid
+// x = chunk, y = slab: K1 without a 2-D field, the ensemble kernels) take chunk
+// (x + slab) % n_chunk: workgroup x always lands on XCD x % 8 (n_chunk % 8 ==
+// 0), chunks differ in size, and a FIXED chunk -> XCD map gives some XCDs the
+// short chunks of every slab (profiles/r04_xcd_balance.md).
 #define WB2_ROTATE_CHUNKS 1
 #endif
 

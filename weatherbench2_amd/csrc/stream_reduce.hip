@@ -377,19 +377,23 @@ __device__ __forceinline__ void load_wf(const WB2_GLOBAL double* p,
   for (int e = 0; e < VEC; ++e) v[e] = p[e];
 }
 
-// Geometry: the outer SLAB is the fastest-varying grid dim (blockIdx.x; z
-// continues it), blockIdx.y = tile_block * n_chunk + chunk.  Workgroups are
-// dealt to the 8 XCDs round-robin by their linear index, so (a) every XCD works
-// on slabs of its own and all of them on the SAME row chunk at any moment --
-// chunks differ in size (bands cut them at region boundaries, the last one is
-// short, the padding is empty) and a chunk-fastest grid whose x extent is a
-// multiple of 8 pins chunk c to XCD c % 8: some XCDs then get the short chunks
-// of EVERY slab (measured, profiles/r04_xcd_balance.md: the benched launch
-// 0.75 of the HBM peak chunk-fastest, 0.81 with the chunks rotated by the slab
-// number, 0.85 slab-fastest); (b) the workgroups resident at any moment re-read
-// the same ~1 MB of a 2-D weight field / SEEPS p1 field from L2 instead of
-// fetching it through the fabric for every slab (1.6 x the algorithmic bytes,
-// profiles/r03_k1_variants.md).  Every WAVE
+// Geometry.  Workgroups are dealt to the 8 XCDs round-robin by their linear
+// index, and the chunks of a slab differ in size (bands cut them at region
+// boundaries, the last one is short, the padding to a multiple of 8 is empty).
+//   field-free instantiations: blockIdx.x = tile_block * n_chunk + chunk',
+//     blockIdx.y/z = outer slab, chunk = (chunk' + slab) % n_chunk.  Without the
+//     rotation chunk c of EVERY slab lands on XCD c % 8 (n_chunk % 8 == 0) and
+//     some XCDs get all the short chunks: same box, bench.py --variants-only,
+//     plain / rotated / slab-fastest: the benched launch 0.781 / 0.802 / 0.789
+//     of the HBM peak, the lon-lat layout 0.678 / 0.757 / 0.711, wind 0.788 /
+//     0.826 / 0.818 (profiles/r04_xcd_balance.md).
+//   a 2-D weight field or the SEEPS p1 field: the outer SLAB is the fastest
+//     grid dim, so the workgroups resident at any moment work on the SAME few
+//     row chunks of different slabs and re-read the same ~1 MB of the field
+//     from L2 (chunk-fastest: re-fetched through the fabric for every slab,
+//     1.6 x the algorithmic bytes, profiles/r03_k1_variants.md); the XCDs each
+//     take slabs of their own, balanced whatever the chunk sizes.
+// Every WAVE
 // of the workgroup owns one column tile of 64*VEC columns and is completely
 // independent of the others (no LDS, no barrier): waves stream, then fold their
 // own columns into the segs that intersect their tile with a wave64 butterfly.
@@ -415,10 +419,15 @@ __global__ void __launch_bounds__(512)
   // readfirstlane: tell the compiler the wave index is wave-uniform (SGPR).
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int nwave = blockDim.x / kWave;
-  const unsigned bx = blockIdx.y;
+  constexpr bool SLAB_FASTEST = WF || MODE == WB2_MODE_SEEPS;
+  const unsigned bx = SLAB_FASTEST ? blockIdx.y : blockIdx.x;
   const unsigned tblk = bx / (unsigned)p.n_chunk;
-  const long long o = (long long)blockIdx.z * gridDim.x + blockIdx.x;
-  const int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
+  const long long o =
+      SLAB_FASTEST ? (long long)blockIdx.z * gridDim.x + blockIdx.x
+                   : (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  int chunk = (int)(bx - tblk * (unsigned)p.n_chunk);
+  if (!SLAB_FASTEST && WB2_ROTATE_CHUNKS)
+    chunk = (int)(((long long)chunk + o) % p.n_chunk);
   const int tile = (int)tblk * nwave + wave;
 
   // ---- branch-free prologue: issue every scalar load before any wait ----
@@ -982,7 +991,10 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
   const long long gz = (p.n_outer + gy - 1) / gy;  // kernel guards o < n_outer
-  const dim3 grid((unsigned)gy, (unsigned)(p.n_chunk * n_tblk), (unsigned)gz);
+  const dim3 grid =
+      (WF || MODE == WB2_MODE_SEEPS)
+          ? dim3((unsigned)gy, (unsigned)(p.n_chunk * n_tblk), (unsigned)gz)
+          : dim3((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
   // unaligned float32 rows at 4 columns per lane: SGPR row bases are worth 4 %
   // there (profiles/r03_k1_ab5_summary.txt), and cost 2-20 % everywhere else
   constexpr bool HAS_SG = std::is_same<T, float>::value && VEC == 4 &&
