@@ -141,3 +141,74 @@ def test_running_mean_rows_are_per_label_whatever_the_chunks_carry():
   got = mean.result()
   np.testing.assert_array_equal(got.coords['lead_time'], leads)
   np.testing.assert_allclose(got['z'].values, values.mean(0), rtol=1e-15)
+
+
+class _EchoMetric:
+  """A stand-in metric that reads concatenated chunks in place (so that
+  evaluate_chunks may form windows) -- the loop itself is replaced below."""
+  _reads_slabs_in_place = True
+
+
+def test_default_window_follows_the_bytes_of_the_first_chunk(monkeypatch):
+  """evaluate_chunks(batch_chunks=None): the window is what holds
+  AUTO_BATCH_BYTES of (forecast + truth) input, at most AUTO_BATCH_MAX chunks;
+  an explicit batch_chunks wins; the prefetch depth follows the window only
+  once it is known."""
+  from weatherbench2_amd import config
+  forecast, truth = _product(n_init=6, n_lead=3)
+  pairs = oc.chunk_pairs(forecast, truth, 'init')
+  per_chunk = sum(evaluation._input_bytes(ds) for ds in pairs[0])
+  assert per_chunk == sum(
+      int(np.prod(da.shape)) * 4 for ds in pairs[0]
+      for da in ds.data_vars.values())
+  windows = []
+
+  def loop(fc, tr, eval_config, skipna, compute_chunk=True):
+    n_time = fc.sizes.get('init_time', 1)
+    n_lead = fc.sizes.get('lead_time', 1)
+    windows.append(n_time * n_lead)
+    out = xl.Dataset(coords={'init_time': fc.coords['init_time'],
+                             'lead_time': fc.coords['lead_time']})
+    out.data_vars['x'] = xl.DataArray(
+        np.ones((n_time, n_lead)), ('init_time', 'lead_time'), out.coords, 'x')
+    return out
+  monkeypatch.setattr(evaluation, '_metric_and_region_loop', loop)
+  cfg = config.Eval(metrics={'echo': _EchoMetric()})
+
+  def run(**kw):
+    del windows[:]
+    res = evaluation.evaluate_chunks(pairs, cfg, prefetch=0, **kw)
+    np.testing.assert_array_equal(res['x'].values, np.ones(3))
+    return list(windows)
+  assert run() == [18]                        # all 18 chunks fit one window
+  monkeypatch.setattr(evaluation, 'AUTO_BATCH_MAX', 6)
+  assert run() == [6, 6, 6]
+  monkeypatch.setattr(evaluation, 'AUTO_BATCH_BYTES', 3 * per_chunk)
+  assert run() == [3] * 6
+  monkeypatch.setattr(evaluation, 'AUTO_BATCH_BYTES', per_chunk // 2)
+  assert run() == [1] * 18                    # a chunk larger than the budget
+  assert run(batch_chunks=9) == [9, 9]        # explicit: not capped by either
+  # a metric that cannot read windows in place: chunk by chunk
+  cfg_plain = config.Eval(metrics={'echo': object()})
+  del windows[:]
+  evaluation.evaluate_chunks(pairs, cfg_plain, prefetch=0)
+  assert windows == [1] * 18
+
+
+def test_prefetch_depth_may_change_while_running():
+  fetched = []
+
+  class Lazy:
+    def __len__(self):
+      return 10
+
+    def __getitem__(self, i):
+      fetched.append(i)
+      return i
+  depth = [1]
+  seen = []
+  for item in evaluation._prefetched(Lazy(), 0, 10, lambda: depth[0]):
+    seen.append(item)
+    if item == 2:
+      depth[0] = 4
+  assert seen == list(range(10)) and sorted(fetched) == list(range(10))
