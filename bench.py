@@ -1124,14 +1124,15 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
 
 def land_sea_mask(rs, lat, lon):
   """A synthetic land-sea mask in [0, 1] (smooth blobs, ~30 % land, fractional
-  coast cells like ERA5's `land_sea_mask`)."""
+  coast cells, float32 values like ERA5's `land_sea_mask`)."""
   yy, xx = np.meshgrid(np.deg2rad(lat), np.deg2rad(lon), indexing='ij')
   field = np.zeros_like(yy)
   for _ in range(24):
     a, b, c, d = rs.uniform(-1, 1), rs.randint(1, 5), rs.randint(1, 4), (
         rs.uniform(0, 2 * np.pi))
     field += a * np.cos(b * xx + d) * np.cos(c * yy + d)
-  return np.clip((field - np.quantile(field, 0.6)) * 2.0, 0.0, 1.0)
+  return np.clip((field - np.quantile(field, 0.6)) * 2.0, 0.0, 1.0).astype(
+      np.float32)
 
 
 def official_regions():

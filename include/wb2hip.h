@@ -177,12 +177,18 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
 /* As wb2_stream_partials, plus the mode-specific extras:
  *  aux     DEV double[n_row*n_col] or NULL  (WB2_MODE_SEEPS: the climatological
  *          dry fraction p1, NaN where it is masked out, metrics.py:504-506)
- *  scalar  (WB2_MODE_SEEPS: the dry threshold in data units, metrics.py:449) */
+ *  scalar  (WB2_MODE_SEEPS: the dry threshold in data units, metrics.py:449)
+ *  wfield_dtype  WB2_F64, or WB2_F32: the 2-D weight field stored as float32 --
+ *          for a field whose values ARE float32 numbers (an ERA5 land-sea mask,
+ *          a thresholded mask): the same results bit for bit, half the field
+ *          bytes per point.  float32 inputs of the modes DET / DET_ACC / WIND
+ *          only; anything else with WB2_F32 is an error. */
 int wb2_stream_partials_ex(int mode, int dtype, int skipna,
                            const void* const* in, const int64_t* const* slab,
                            int64_t n_outer, int32_t n_row, int32_t n_col,
                            const double* w_row, const double* w_col,
-                           const double* wfield, const double* aux,
+                           const void* wfield, int wfield_dtype,
+                           const double* aux,
                            double scalar, const int32_t* chunk_row0,
                            const int32_t* chunk_nrow, int32_t n_chunk,
                            int32_t n_ctile, const int32_t* seg_col0,
@@ -209,7 +215,8 @@ int wb2_stream_partials_addr(int mode, int dtype, int skipna,
                              const int64_t* const* slab_addr, int aligned16,
                              int64_t n_outer, int32_t n_row, int32_t n_col,
                              const double* w_row, const double* w_col,
-                             const double* wfield, const double* aux,
+                             const void* wfield, int wfield_dtype,
+                             const double* aux,
                              double scalar, const int32_t* chunk_row0,
                              const int32_t* chunk_nrow, int32_t n_chunk,
                              int32_t n_ctile, const int32_t* seg_col0,

@@ -424,3 +424,77 @@ def test_more_than_32767_slabs(gm):
   want = om.SpatialMAE().compute_chunk(f, t)
   got = gm.SpatialMAE().compute_chunk(g(f), g(t))
   np.testing.assert_array_equal(got['z'].values, want['z'].data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode_name', ['DET', 'DET_ACC', 'WIND'])
+@pytest.mark.parametrize('skipna', [False, True])
+def test_float32_weight_field_gives_the_same_bits(mode_name, skipna,
+                                                  monkeypatch):
+  """A 2-D weight field whose values are float32 numbers (an ERA5 land-sea
+  mask) is read as float32 by K1 (plan.wfield32, wfield_dtype = WB2_F32): the
+  conversion is exact, so the results are those of the float64 field bit for
+  bit; a field with float64-only values has no float32 copy at all."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  from weatherbench2_amd import regions as R
+  from weatherbench2_amd import xarray_lite as xl
+  dev = torch.device('cuda', 0)
+  n_lat, n_lon, n_outer = 37, 70, 5
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  rs = np.random.RandomState(3)
+
+  def regions(mask):
+    lsm = xl.DataArray(mask, ('latitude', 'longitude'),
+                       {'latitude': lat, 'longitude': lon})
+    return {'global': None, 'land': R.LandRegion(land_sea_mask=lsm),
+            'tropics_land': R.CombinedRegion(regions=[
+                R.SliceRegion(lat_slice=slice(-20, 20)),
+                R.LandRegion(land_sea_mask=lsm)])}
+  mask32 = np.clip(rs.uniform(-0.5, 1.5, (n_lat, n_lon)), 0, 1).astype(
+      np.float32)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions(mask32), dev)
+  assert pl.wfield32 is not None and pl.wfield32.dtype == torch.float32
+  torch.testing.assert_close(pl.wfield32.double(), pl.wfield, rtol=0, atol=0)
+  mask64 = np.clip(rs.uniform(-0.5, 1.5, (n_lat, n_lon)), 0, 1)
+  assert plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions(mask64),
+                             dev).wfield32 is None
+  mode = getattr(_lib, 'MODE_' + mode_name)
+  n_in = {'DET': 2, 'DET_ACC': 3, 'WIND': 4}[mode_name]
+  gen = torch.Generator(device=dev).manual_seed(8)
+  ins = [torch.randn((n_outer, n_lat, n_lon), generator=gen, device=dev)
+         for _ in range(n_in)]
+  if skipna:
+    ins[0][1, 3:9, 5:40] = float('nan')
+  def run(flag):
+    monkeypatch.setenv('WB2HIP_FIELD_F32', flag)
+    out, sums = engine.stream_reduce(pl, mode, ins, [None] * n_in, n_outer,
+                                     skipna, want_sums=True)
+    return out.cpu().numpy(), sums.cpu().numpy()
+  a, b = run('1'), run('0')
+  for x, y in zip(a, b):
+    assert x.tobytes() == y.tobytes()
+  # float64 inputs keep the float64 field (no float32-field instantiation)
+  ins64 = [x.double() for x in ins]
+  monkeypatch.setenv('WB2HIP_FIELD_F32', '1')
+  out64, _ = engine.stream_reduce(pl, mode, ins64, [None] * n_in, n_outer,
+                                  skipna)
+  assert np.isfinite(out64.cpu().numpy()[0]).any()
+  # and the C ABI refuses the combination outright
+  import ctypes
+  lib = _lib.load()
+  tile = lib.wb2_tile_cols_ex(mode, _lib.WB2_F64, int(skipna), 1, pl.n_col, 1)
+  seg_eoff, n_ts = pl.seg_entries(tile)
+  k = lib.wb2_num_slots(mode, int(skipna))
+  partials = torch.empty((n_outer, pl.n_chunk, 2, n_ts, k), dtype=torch.float64,
+                         device=dev)
+  rc = lib.wb2_stream_partials_ex(
+      mode, _lib.WB2_F64, int(skipna), _lib.ptr_array(ins64),
+      _lib.ptr_array([None] * n_in), n_outer, pl.n_row, pl.n_col,
+      _lib.ptr(pl.w_row), _lib.ptr(pl.w_col), _lib.ptr(pl.wfield32),
+      _lib.WB2_F32, None, 0.0, _lib.ptr(pl.chunk_row0), _lib.ptr(pl.chunk_nrow),
+      pl.n_chunk, -(-pl.n_col // tile), _lib.ptr(pl.seg_col0),
+      _lib.ptr(seg_eoff), pl.n_seg, n_ts, _lib.ptr(partials),
+      engine.current_stream_ptr(dev))
+  assert rc != 0 and b'float32 weight field' in lib.wb2_last_error()

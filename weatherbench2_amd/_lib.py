@@ -43,12 +43,12 @@ _SIGNATURES = {
         _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'wb2_stream_partials_ex': (_int, [
         _int, _int, _int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i32, _i32,
-        _vp, _vp, _vp, _vp, _c.c_double, _vp, _vp, _i32, _i32, _vp, _vp, _i32,
-        _i32, _vp, _vp]),
+        _vp, _vp, _vp, _int, _vp, _c.c_double, _vp, _vp, _i32, _i32, _vp, _vp,
+        _i32, _i32, _vp, _vp]),
     'wb2_stream_partials_addr': (_int, [
         _int, _int, _int, _c.POINTER(_vp), _int, _i64, _i32, _i32,
-        _vp, _vp, _vp, _vp, _c.c_double, _vp, _vp, _i32, _i32, _vp, _vp, _i32,
-        _i32, _vp, _vp]),
+        _vp, _vp, _vp, _int, _vp, _c.c_double, _vp, _vp, _i32, _i32, _vp, _vp,
+        _i32, _i32, _vp, _vp]),
     'wb2_det_combine': (_int, [
         _int, _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp,
         _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

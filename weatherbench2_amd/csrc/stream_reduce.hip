@@ -41,7 +41,7 @@ struct StreamParams {
   const long long* slab[kMaxIn];
   const double* w_row;
   const double* w_col;
-  const double* wfield;
+  const void* wfield;  // [n_row][n_col] float64, or float32 (wfield_f32)
   const double* aux;   // mode-specific 2-D field [n_row][n_col] (SEEPS: p1)
   double scalar;       // mode-specific scalar (SEEPS: dry threshold)
   const int* chunk_row0;
@@ -61,6 +61,7 @@ struct StreamParams {
   // -- the lon-lat layout's 721-column rows: selects the SGPR-addressed
   // instantiation where there is one
   int unaligned;
+  int wfield_f32;  // the weight field is stored as float32 (exactly)
 };
 
 template <int MODE, bool SKIPNA>
@@ -369,12 +370,20 @@ __device__ __forceinline__ void load_vec(const WB2_GLOBAL T* p, T (&v)[VEC]) {
   }
 }
 
-template <int VEC>
-__device__ __forceinline__ void load_wf(const WB2_GLOBAL double* p,
+// FT: element type of the 2-D weight field in memory.  A field whose values
+// are float32 numbers (an ERA5 land-sea mask, a thresholded mask) is kept as
+// float32: half the bytes through L2 and L1 per point, the same float64 value
+// after the (exact) conversion -- the 16 official regions 0.706 -> 0.739 of
+// the HBM peak on one box.
+template <int VEC, typename FT>
+__device__ __forceinline__ void load_wf(const WB2_GLOBAL FT* p,
                                         double (&v)[VEC]) {
   // The weight field is re-read by every outer slab: keep it cacheable.
+  typedef FT V0 __attribute__((ext_vector_type(VEC)));
+  typedef V0 V __attribute__((aligned(sizeof(FT))));
+  const V0 x = *reinterpret_cast<const WB2_GLOBAL V*>(p);
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) v[e] = p[e];
+  for (int e = 0; e < VEC; ++e) v[e] = (double)x[e];
 }
 
 // Geometry.  Workgroups are dealt to the 8 XCDs round-robin by their linear
@@ -403,7 +412,7 @@ __device__ __forceinline__ void load_wf(const WB2_GLOBAL double* p,
 // branch-free on purpose: every scalar (table / slab-index) load is issued
 // before the first wait, instead of one dependent round trip per table.
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF,
-          bool SG = false>
+          bool SG = false, typename FT = double>
 __global__ void __launch_bounds__(512)
     stream_partials_kernel(const StreamParams p) {
   using M = ModeTraits<MODE, SKIPNA>;
@@ -485,10 +494,12 @@ __global__ void __launch_bounds__(512)
                     static_cast<const char*>(p.in[i]) +
                     slab_idx[i] * p.slab_step_bytes) +
                 (long long)row0 * p.n_col;
-    const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col : nullptr;
+    const FT* wfp =
+        WF ? static_cast<const FT*>(p.wfield) + (long long)row0 * p.n_col
+           : nullptr;
     const double* wrp = p.w_row + row0;
     unsigned lane_off = (unsigned)colb * (unsigned)sizeof(T);
-    unsigned lane_off_wf = (unsigned)colb * (unsigned)sizeof(double);
+    unsigned lane_off_wf = (unsigned)colb * (unsigned)sizeof(FT);
     auto at = [&](const T* row) {
       if constexpr (SG) {
         unsigned long long rp = reinterpret_cast<unsigned long long>(row);
@@ -500,14 +511,14 @@ __global__ void __launch_bounds__(512)
             reinterpret_cast<unsigned long long>(row + colb));
       }
     };
-    auto at_wf = [&](const double* row) {
+    auto at_wf = [&](const FT* row) {
       if constexpr (SG) {
         unsigned long long rp = reinterpret_cast<unsigned long long>(row);
         asm volatile("" : "+s"(rp));
-        return reinterpret_cast<const WB2_GLOBAL double*>(
+        return reinterpret_cast<const WB2_GLOBAL FT*>(
             reinterpret_cast<const WB2_GLOBAL char*>(rp) + lane_off_wf);
       } else {
-        return reinterpret_cast<const WB2_GLOBAL double*>(
+        return reinterpret_cast<const WB2_GLOBAL FT*>(
             reinterpret_cast<unsigned long long>(row + colb));
       }
     };
@@ -648,7 +659,7 @@ __global__ void __launch_bounds__(512)
           load_vec<T, VEC>(at(base[i] + (long long)(r + u) * p.n_col),
                            bt.v[u][i]);
         if constexpr (WF) {
-          load_wf<VEC>(at_wf(wfp + (long long)(r + u) * p.n_col), bt.wf[u]);
+          load_wf<VEC, FT>(at_wf(wfp + (long long)(r + u) * p.n_col), bt.wf[u]);
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) bt.wf[u][e] = 1.0;
@@ -683,7 +694,7 @@ __global__ void __launch_bounds__(512)
       for (int i = 0; i < NIN; ++i)
         load_vec<T, VEC>(at(base[i] + (long long)r * p.n_col), v[i]);
       if constexpr (WF) {
-        load_wf<VEC>(at_wf(wfp + (long long)r * p.n_col), wf);
+        load_wf<VEC, FT>(at_wf(wfp + (long long)r * p.n_col), wf);
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) wf[e] = 1.0;
@@ -985,6 +996,19 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
+// float32 weight fields: instantiated for float32 inputs of the deterministic
+// modes (the production passes)
+template <typename T, int MODE>
+constexpr bool field_f32_supported() {
+  return std::is_same<T, float>::value &&
+         (MODE == WB2_MODE_DET || MODE == WB2_MODE_DET_ACC ||
+          MODE == WB2_MODE_WIND);
+}
+bool field_f32_supported(int dtype, int mode) {
+  return dtype == WB2_F32 && (mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC ||
+                              mode == WB2_MODE_WIND);
+}
+
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
 int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
   const int nwave = threads / kWave;
@@ -1010,6 +1034,15 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
       hipLaunchKernelGGL(
           (stream_partials_kernel<T, VEC, MODE, SKIPNA, WF, true>), grid,
           dim3(threads), 0, stream, p);
+      WB2_HIP_OK(hipGetLastError());
+      return 0;
+    }
+  }
+  if constexpr (field_f32_supported<T, MODE>() && WF) {
+    if (p.wfield_f32) {
+      hipLaunchKernelGGL(
+          (stream_partials_kernel<T, VEC, MODE, SKIPNA, WF, false, float>),
+          grid, dim3(threads), 0, stream, p);
       WB2_HIP_OK(hipGetLastError());
       return 0;
     }
@@ -1161,7 +1194,8 @@ int stream_partials_impl(int mode, int dtype, int skipna, const void* const* in,
                          const int64_t* const* slab, int addr_aligned16,
                          int64_t n_outer, int32_t n_row, int32_t n_col,
                          const double* w_row, const double* w_col,
-                         const double* wfield, const double* aux, double scalar,
+                         const void* wfield, int wfield_dtype,
+                         const double* aux, double scalar,
                          const int32_t* chunk_row0, const int32_t* chunk_nrow,
                          int32_t n_chunk, int32_t n_ctile,
                          const int32_t* seg_col0, const int32_t* seg_eoff,
@@ -1175,6 +1209,11 @@ int stream_partials_impl(int mode, int dtype, int skipna, const void* const* in,
   WB2_REQUIRE(mode != WB2_MODE_SEEPS || aux != nullptr,
               "WB2_MODE_SEEPS needs the p1 field in `aux`");
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE(!wfield || wfield_dtype == WB2_F64 ||
+                  (wfield_dtype == WB2_F32 && field_f32_supported(dtype, mode)),
+              "a float32 weight field goes with float32 inputs of the modes "
+              "DET / DET_ACC / WIND (wfield_dtype=%d dtype=%d mode=%d)",
+              wfield_dtype, dtype, mode);
   WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE((in || slab) && w_row && chunk_row0 && chunk_nrow && seg_col0 &&
                   seg_eoff && partials,
@@ -1212,6 +1251,7 @@ int stream_partials_impl(int mode, int dtype, int skipna, const void* const* in,
   p.w_row = w_row;
   p.w_col = w_col;
   p.wfield = wfield;
+  p.wfield_f32 = wfield && wfield_dtype == WB2_F32;
   p.aux = aux;
   p.scalar = scalar;
   p.chunk_row0 = chunk_row0;
@@ -1278,7 +1318,7 @@ int wb2_stream_partials(int mode, int dtype, int skipna,
                         double* partials, void* stream) {
   WB2_TRACE();
   return wb2_stream_partials_ex(mode, dtype, skipna, in, slab, n_outer, n_row,
-                                n_col, w_row, w_col, wfield, nullptr, 0.0,
+                                n_col, w_row, w_col, wfield, WB2_F64, nullptr, 0.0,
                                 chunk_row0, chunk_nrow, n_chunk, n_ctile,
                                 seg_col0, seg_eoff, n_seg, n_ts, partials,
                                 stream);
@@ -1289,7 +1329,8 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
                            const void* const* in, const int64_t* const* slab,
                            int64_t n_outer, int32_t n_row, int32_t n_col,
                            const double* w_row, const double* w_col,
-                           const double* wfield, const double* aux,
+                           const void* wfield, int wfield_dtype,
+                           const double* aux,
                            double scalar, const int32_t* chunk_row0,
                            const int32_t* chunk_nrow, int32_t n_chunk,
                            int32_t n_ctile, const int32_t* seg_col0,
@@ -1299,7 +1340,8 @@ int wb2_stream_partials_ex(int mode, int dtype, int skipna,
   using namespace wb2;
   WB2_REQUIRE(in != nullptr, "null pointer argument");
   return stream_partials_impl(mode, dtype, skipna, in, slab, 0, n_outer, n_row,
-                              n_col, w_row, w_col, wfield, aux, scalar,
+                              n_col, w_row, w_col, wfield, wfield_dtype, aux,
+                              scalar,
                               chunk_row0, chunk_nrow, n_chunk, n_ctile,
                               seg_col0, seg_eoff, n_seg, n_ts, partials, stream);
 }
@@ -1308,7 +1350,8 @@ int wb2_stream_partials_addr(int mode, int dtype, int skipna,
                              const int64_t* const* slab_addr, int aligned16,
                              int64_t n_outer, int32_t n_row, int32_t n_col,
                              const double* w_row, const double* w_col,
-                             const double* wfield, const double* aux,
+                             const void* wfield, int wfield_dtype,
+                             const double* aux,
                              double scalar, const int32_t* chunk_row0,
                              const int32_t* chunk_nrow, int32_t n_chunk,
                              int32_t n_ctile, const int32_t* seg_col0,
@@ -1319,7 +1362,8 @@ int wb2_stream_partials_addr(int mode, int dtype, int skipna,
   WB2_REQUIRE(slab_addr != nullptr, "null pointer argument");
   return stream_partials_impl(mode, dtype, skipna, nullptr, slab_addr,
                               aligned16, n_outer, n_row, n_col, w_row, w_col,
-                              wfield, aux, scalar, chunk_row0, chunk_nrow,
+                              wfield, wfield_dtype, aux, scalar, chunk_row0,
+                              chunk_nrow,
                               n_chunk, n_ctile, seg_col0, seg_eoff, n_seg, n_ts,
                               partials, stream);
 }

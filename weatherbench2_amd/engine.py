@@ -16,6 +16,7 @@ from weatherbench2_amd import _lib
 from weatherbench2_amd.plan import ReductionPlan
 
 _DTYPES = {torch.float32: _lib.WB2_F32, torch.float64: _lib.WB2_F64}
+_FIELD_F32_MODES = (_lib.MODE_DET, _lib.MODE_DET_ACC, _lib.MODE_WIND)
 
 _STAGED_UPLOAD_MIN_BYTES = 1 << 20
 
@@ -305,8 +306,15 @@ def _stream_launch(plan, mode, dtype, n_outer, skipna, want_sums, aux, scalar,
   dev = plan.device
   code = _DTYPES[dtype]
   k = lib.wb2_num_slots(mode, int(skipna))
-  aligned = aligned and (
-      plan.wfield is None or plan.wfield.data_ptr() % 16 == 0)
+  # the 2-D weight field as float32 where its values are float32 numbers and
+  # the launch has the instantiation (float32 inputs, DET / DET_ACC / WIND):
+  # the same bits, half the field bytes per point
+  field, field_code = plan.wfield, _lib.WB2_F64
+  if (dtype == torch.float32 and mode in _FIELD_F32_MODES and
+      getattr(plan, 'wfield32', None) is not None and
+      os.environ.get('WB2HIP_FIELD_F32', '1') != '0'):
+    field, field_code = plan.wfield32, _lib.WB2_F32
+  aligned = aligned and (field is None or field.data_ptr() % 16 == 0)
   tile = lib.wb2_tile_cols_ex(mode, code, int(skipna),
                               int(plan.wfield is not None), plan.n_col,
                               int(aligned))
@@ -318,7 +326,7 @@ def _stream_launch(plan, mode, dtype, n_outer, skipna, want_sums, aux, scalar,
   if _LAUNCH_HOOK is not None:
     _LAUNCH_HOOK('begin', 'stream_partials')
   tail = (n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
-          _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(aux),
+          _lib.ptr(plan.w_col), _lib.ptr(field), field_code, _lib.ptr(aux),
           float(scalar), _lib.ptr(plan.chunk_row0),
           _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
           _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
