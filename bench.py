@@ -462,12 +462,15 @@ def main():
     (fu, tu, cu), n_u = all_tables[i]
     if n_u == 0:  # strong scaling: this rank's shard is already done
       return
-    # HIP events around K1 on every 4th timed step only: an event record is a
-    # barrier packet with a timestamp, and two per step cost the step 10 % on
-    # some boxes (0.49 instead of 0.44 ms with identical kernels) -- sampled,
-    # the roofline still comes from inside the timed region and the region
-    # itself stays what the contract times
-    sample = timed and n_u == units and (i - args.warmup) % 4 == 0
+    # HIP events around K1 on ~10 of the timed steps only (at least every 4th):
+    # an event record is a barrier packet with a timestamp; two per step cost
+    # the step 10 % on some boxes (0.49 instead of 0.44 ms with identical
+    # kernels), and on one box even every 4th step cost 18 % (0.50 against 0.425
+    # ms for the same loop without events, profiles/r04_round_log.md) --
+    # sampled, the roofline still comes from inside the timed region and the
+    # region itself stays what the contract times
+    sample = timed and n_u == units and (
+        (i - args.warmup) % max(4, args.steps // 10) == 0)
     engine.set_launch_hook(k1_timer if sample else None)
     metrics, _ = engine.stream_reduce(
         pl, _lib.MODE_DET_ACC, [fpool, tpool, cpool], [fu, tu, cu], n_u * N_LEV,
