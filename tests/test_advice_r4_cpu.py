@@ -92,3 +92,37 @@ def test_merge_metrics_is_the_merge_of_expanded_datasets():
     np.testing.assert_array_equal(got[var].values, want[var].values)
   assert got['z'].dims == ('metric', 'prediction_timedelta', 'level')
   assert np.isnan(got['t'].values[0]).all()
+
+
+def test_float32_copy_of_a_weight_field_only_when_it_loses_nothing():
+  """plan._as_float32_field: K1 may read a 2-D weight field as float32 only if
+  every value IS a float32 number (ERA5's land-sea mask, a 0/1 mask)."""
+  import numpy as np
+  import torch
+  from weatherbench2_amd import plan as plan_lib
+  up = lambda a, dtype: torch.as_tensor(np.ascontiguousarray(a), dtype=dtype)
+  rs = np.random.RandomState(0)
+  exact = rs.uniform(0, 1, (5, 7)).astype(np.float32).astype(np.float64)
+  got = plan_lib._as_float32_field(exact, up)
+  assert got is not None and got.dtype == torch.float32
+  np.testing.assert_array_equal(got.numpy().astype(np.float64), exact)
+  assert plan_lib._as_float32_field((exact > 0.5).astype(np.float64),
+                                    up) is not None
+  assert plan_lib._as_float32_field(rs.uniform(0, 1, (5, 7)), up) is None
+  assert plan_lib._as_float32_field(None, up) is None
+
+
+def test_bench_tables_never_read_a_slab_twice_per_launch():
+  """bench.coprime: the unit strides of the bench's slab tables are coprime to
+  the pool, so the 16 units of a launch are distinct for every input (a launch
+  that reads a slab twice measures cache hits: profiles/r04_xcd_balance.md)."""
+  import math
+  import numpy as np
+  import bench
+  for pool in range(16, 97):
+    for k in (1, 3, 5, 7):
+      m = bench.coprime(k, pool)
+      assert m >= k and math.gcd(m, pool) == 1
+      for start in (0, 5, pool - 3):
+        u = (start + np.arange(16)) % pool
+        assert len(set(((u * m + 3) % pool).tolist())) == 16, (pool, k)
