@@ -58,7 +58,8 @@ skips it and quotes profiles/ instead).
 2920 units, contiguous shards over the ranks, K = the steps of the largest
 shard).
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0): the compact contract line (< 4 kB).  The full
+record of every leg goes to bench_detail.json beside this file.
 """
 from __future__ import annotations
 
@@ -211,6 +212,11 @@ def cpu_baseline(seconds: float = 6.0) -> dict:
       'cores': best['processes'], 'kind': 'port', 'value_1core': one['value'],
       'legs': [{'processes': l['processes'], 'value': l['value']} for l in legs],
       'logical_cores': ncpu,
+      'sample_short': (f'NumPy oracle (port of the xarray path), whole 13x721x'
+                       f'1440 f32 units, {one["metrics"]} metrics x '
+                       f'{one["regions"]} regions, ~{seconds:.0f} s per leg at '
+                       + '/'.join(str(l['processes']) for l in legs)
+                       + ' single-threaded processes; best leg quoted'),
       'sample': (f'NumPy oracle (xarray-semantics restatement; the reference '
                  f'itself needs xarray, absent here): whole units of '
                  f'{N_LEV} levels x 721 x 1440 f32, {one["metrics"]} metrics x '
@@ -262,6 +268,16 @@ def parse_args():
                        '(BASELINE configs[4]: 2920), sharded contiguously over '
                        'the ranks (evaluation.shard_bounds); --steps is then '
                        'derived (the steps of the largest shard)')
+  ap.add_argument('--detail', action='store_true',
+                  help='also run every other instantiation against its own '
+                       'roofline (K1 / K3 / tier-2 variants, all window sizes '
+                       'of the official-chunk leg, live traffic of every '
+                       'benched kernel): minutes of GPU time; the record goes '
+                       'to bench_detail.json, the last stdout line stays the '
+                       'compact contract line')
+  ap.add_argument('--print-detail', action='store_true',
+                  help='also print the full record (bench_detail.json) on a '
+                       'line BEFORE the contract line')
   ap.add_argument('--launch-timeout', type=float, default=900.0,
                   help='seconds after which a self-launched job (and the '
                        'rendezvous / collectives of every rank) gives up '
@@ -456,26 +472,37 @@ def main():
   all_tables = [(tables(s * units, units), units) for s in range(args.warmup)]
   all_tables += [(tables(unit_lo + (args.warmup + s) * units, units_of_step(s)),
                   units_of_step(s)) for s in range(args.steps)]
+  # One C-ABI call per step (wb2_det_suite_step: K1 -> K2 -> running init-time
+  # mean over (metric*region, unit, level)), its arguments marshalled once per
+  # table set: the host's share of a step is one foreign call.
+  suites = {}
+  for n_u in sorted({n for _, n in all_tables if n}):
+    st = engine.SuiteStep(pl, _lib.MODE_DET_ACC, torch.float32, False,
+                          n_u * N_LEV)
+    st.accumulate_into(total, count, (_lib.NMETRIC * nr, n_u, N_LEV))
+    suites[n_u] = st
+  calls = [suites[n_u].bind([fpool, tpool, cpool], list(tabs)) if n_u else None
+           for tabs, n_u in all_tables]
   k1_timer = KernelTimer()
 
-  def step(i, timed):
+  def step(i, timed=False):
+    call = calls[i]
+    if call is not None:  # strong scaling: None = this rank's shard is done
+      call()
+
+  def sampled_step(i):
+    """The same step through the three separate entry points with HIP events
+    around K1 alone (engine's launch hook): the kernel-time sampling loop that
+    runs AFTER the timed region -- event records are barrier packets with
+    timestamps and cost a step 10-18 % on some boxes, so none is inside it."""
     (fu, tu, cu), n_u = all_tables[i]
-    if n_u == 0:  # strong scaling: this rank's shard is already done
+    if n_u != units:
       return
-    # HIP events around K1 on ~10 of the timed steps only (at least every 4th):
-    # an event record is a barrier packet with a timestamp; two per step cost
-    # the step 10 % on some boxes (0.49 instead of 0.44 ms with identical
-    # kernels), and on one box even every 4th step cost 18 % (0.50 against 0.425
-    # ms for the same loop without events, profiles/r04_round_log.md) --
-    # sampled, the roofline still comes from inside the timed region and the
-    # region itself stays what the contract times
-    sample = timed and n_u == units and (
-        (i - args.warmup) % max(4, args.steps // 10) == 0)
-    engine.set_launch_hook(k1_timer if sample else None)
+    engine.set_launch_hook(k1_timer)
     metrics, _ = engine.stream_reduce(
         pl, _lib.MODE_DET_ACC, [fpool, tpool, cpool], [fu, tu, cu], n_u * N_LEV,
         skipna=False)
-    # running init-time mean: (metric*region, unit, level)
+    engine.set_launch_hook(None)
     engine.time_accumulate(metrics.view(_lib.NMETRIC * nr, n_u, N_LEV), 1,
                            False, total, count)
 
@@ -483,6 +510,8 @@ def main():
   # torch kernel (the final division, the all-reduce) loads its code object,
   # which costs tens of ms and is not part of the hot path.
   step(0, False)
+  sampled_step(0)
+  k1_timer.pairs.clear()
   _ = (total / count).sum().item()
   if ddp:
     all_reduce(torch.cat([total.reshape(-1), count.reshape(-1)]))
@@ -556,9 +585,17 @@ def main():
     step(i, False)
   dt, own_dt, gpu_ms = timed_region(lambda i: step(args.warmup + i, True),
                                     args.steps, [total, count])
-  engine.set_launch_hook(None)
   rank_ms = per_rank(own_dt / args.steps * 1e3)
 
+  # ---- K1's duration: HIP events around the kernel alone, on the launch
+  # stream, over the same table sets as the timed steps, in a loop of its own
+  # right behind the timed region (queue kept full by a short un-evented lead-in)
+  n_samp = min(args.steps, 24)
+  for i in range(min(8, args.steps)):
+    step(args.warmup + i)
+  for i in range(n_samp):
+    sampled_step(args.warmup + i)
+  torch.cuda.synchronize()
   k1_ms = [a.elapsed_time(b) for a, b in k1_timer.pairs]
   if os.environ.get('WB2_BENCH_TRACE'):  # per-launch durations (diagnostics)
     print('k1_ms', ' '.join(f'{x:.3f}' for x in k1_ms), file=sys.stderr)
@@ -584,6 +621,7 @@ def main():
           'units_per_step_per_gpu': units, 'pool_units': pool,
           'total_units': args.total_units if strong else None,
           'regions': nr, 'rows_per_chunk': args.rows_per_chunk,
+          'step': 'one wb2_det_suite_step call (K1 + K2 + time accumulate)',
           'parallelism': f'init-time shards x{world}, 1 all-reduce of [sum,count]',
           'launcher': ('self-spawned ranks' if os.environ.get(
               'WB2_BENCH_SELF_LAUNCHED') else
@@ -610,7 +648,14 @@ def main():
           'frac_of_measured_copy_6290': achieved / 6290.0,
           'kernel_ms': k1_avg_s * 1e3,
           'kernel_ms_samples': len(k1_ms),
+          'kernel_ms_from': ('HIP events around K1 alone on the launch stream, '
+                             f'{len(k1_ms)} launches of the timed table sets in '
+                             'a loop right behind the timed region'),
           'algorithmic_bytes_per_launch': pts_step * BYTES_PER_PT,
+          # whole-step view: algorithmic bytes / the timed ms_per_step (K1 + K2
+          # + accumulate + whatever the host adds) against the same peak
+          'step_frac': (pts_step * BYTES_PER_PT / (dt / args.steps) / 1e9 /
+                        HBM_PEAK_GBPS) if not strong else None,
           # HBM bytes per launch from PMC counters: collected below, live
           'traffic': None,
       },
@@ -626,31 +671,36 @@ def main():
       'ms_per_step': dt_cold / args.steps * 1e3,
       'note': 'same K steps started from an idle queue (no ramp, no warmup)'}
 
+  solo = rank == 0 and world == 1
+
+  def leg(name, fn, *a, **k):
+    """A secondary leg never costs the run its headline: errors are recorded
+    under the leg's key (and show in the contract line's `errors` list)."""
+    try:
+      out[name] = fn(*a, **k)
+    except Exception as e:
+      out[name] = {'error': f'{type(e).__name__}: {e}'}
+    torch.cuda.empty_cache()
+
   # ---- BASELINE configs[4]: deterministic + probabilistic suites, sharded ----
   if not args.no_full_suite:
     out['full_suite'] = full_suite(args, dev, pl, step, (total, count),
                                    timed_region, per_rank, world, rank)
   if ddp:
     out['map_allreduce'] = map_allreduce(dev, all_reduce, world, backend)
-  if rank == 0 and world == 1 and not args.no_api:
-    try:
-      out['api'] = api_leg(dev, regions, units)
-    except Exception as e:  # never lose the GPU line to a secondary leg
-      out['api'] = {'error': f'{type(e).__name__}: {e}'}
-  if rank == 0 and world == 1 and not args.no_api:
+  if solo and not args.no_api:
+    leg('api', api_leg, dev, regions, units)
     # ---- the boundary at the reference's PRODUCTION chunking: init_time=1,
-    # lead_time=1 chunks of 13 variables, 16 regions, through evaluate_chunks
-    try:
-      torch.cuda.empty_cache()
-      sys.path.insert(0, os.path.join(ROOT, 'tools'))
-      import official_chunk
-      out['api_official_chunk'] = official_chunk.run(dev)
-    except Exception as e:
-      out['api_official_chunk'] = {'error': f'{type(e).__name__}: {e}'}
-    torch.cuda.empty_cache()
-  if rank == 0 and world == 1 and not args.no_secondary:
-    # ---- BASELINE configs[2] / configs[3] and K1's production variants, each
-    # with its own roofline; bounded step counts keep the whole line in minutes
+    # lead_time=1 chunks of 13 variables, 16 regions, through evaluate_chunks;
+    # device-resident chunks and chunks handed over as pageable NumPy arrays
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import official_chunk
+    leg('api_official_chunk', official_chunk.run, dev,
+        batches=(1, 16, 32, None) if args.detail else (1, None),
+        host_fed=True)
+  if solo and not args.no_secondary:
+    # ---- BASELINE configs[2] / configs[3], each with its own roofline;
+    # bounded step counts keep the whole run in minutes
     legs = (('ensemble', 'ensemble', 20), ('spectrum', 'spectrum', 40),
             ('spectrum/materialized', 'spectrum_materialized', 30),
             ('spectrum/time_mean', 'spectrum_mean', 30))
@@ -660,52 +710,42 @@ def main():
     for _ in range(3):
       for key, workload, n in legs:
         try:
-          leg = secondary(workload, n, 5, 20.0, args.members, 0)
+          one = secondary(workload, n, 5, 20.0, args.members, 0)
         except Exception as e:  # never lose the GPU line to a secondary leg
-          leg = {'error': f'{type(e).__name__}: {e}'}
-        runs[key].append(leg)
+          one = {'error': f'{type(e).__name__}: {e}'}
+        runs[key].append(one)
         torch.cuda.empty_cache()
     for key, _, _ in legs:
       good = sorted((r for r in runs[key] if 'roofline' in r),
                     key=lambda r: r['roofline']['kernel_ms'])
-      leg = good[len(good) // 2] if good else runs[key][-1]
-      leg = {k: leg[k] for k in ('value', 'unit', 'steps', 'ms_per_step',
-                                 'config', 'roofline', 'error') if k in leg}
+      one = good[len(good) // 2] if good else runs[key][-1]
+      one = {k: one[k] for k in ('value', 'unit', 'steps', 'ms_per_step',
+                                 'config', 'roofline', 'error') if k in one}
       if good:
-        leg['roofline'].update(
+        one['roofline'].update(
             frac_min=good[-1]['roofline']['frac'],
             frac_max=good[0]['roofline']['frac'], repetitions=len(good))
       if '/' in key:
-        out.setdefault('spectrum', {})[key.split('/')[1]] = leg
+        out.setdefault('spectrum', {})[key.split('/')[1]] = one
       else:
-        out[key] = leg
-    try:
-      out['variants'] = k1_variants(dev, fpool, tpool, cpool, units, pool)
-    except Exception as e:
-      out['variants'] = {'error': f'{type(e).__name__}: {e}'}
-    torch.cuda.empty_cache()
-    try:  # K3's other instantiations (member counts, skipna, land masks)
-      sys.path.insert(0, os.path.join(ROOT, 'tools'))
-      import k3_variants
-      out['k3_variants'] = k3_variants.variants(dev)
-    except Exception as e:
-      out['k3_variants'] = {'error': f'{type(e).__name__}: {e}'}
-    torch.cuda.empty_cache()
-    try:  # the tier-2 kernels, each against its own roofline
-      import tier2_variants
-      out['tier2_variants'] = tier2_variants.variants(dev)
-    except Exception as e:
-      out['tier2_variants'] = {'error': f'{type(e).__name__}: {e}'}
-    torch.cuda.empty_cache()
-  if rank == 0 and world == 1 and not args.no_pcie:
-    try:
-      out['pcie_inclusive'] = pcie_leg(dev, pl, units, nr, total, count)
-    except Exception as e:
-      out['pcie_inclusive'] = {'error': f'{type(e).__name__}: {e}'}
-  if rank == 0 and world == 1 and not args.no_pmc and not strong:
+        out[key] = one
+  if solo and args.detail and not args.no_secondary:
+    # ---- every other instantiation against its own roofline (--detail only:
+    # minutes of GPU time that the contract run does not need)
+    leg('variants', k1_variants, dev, fpool, tpool, cpool, units, pool)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import k3_variants
+    import tier2_variants
+    leg('k3_variants', k3_variants.variants, dev)
+    leg('tier2_variants', tier2_variants.variants, dev)
+  if solo and not args.no_pcie:
+    leg('pcie_inclusive', pcie_leg, dev, pl, units, nr, total, count)
+  if solo and not args.no_pmc and not strong:
     # ---- roofline.traffic, live: the PMC passes run in child processes under
-    # rocprofv3 (their own 7.8 GB pools; 288 GB of HBM hold both)
-    live = live_traffic(units, pool, args.rows_per_chunk)
+    # rocprofv3 (their own 7.8 GB pools; 288 GB of HBM hold both).  The
+    # contract run collects K1's; --detail every benched kernel's.
+    live = live_traffic(units, pool, args.rows_per_chunk,
+                        'all' if args.detail else 'deterministic')
     source = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, '
               '--kernel-trace only) around this launch configuration, '
               'collected by this run: tools/live_traffic.py')
@@ -725,7 +765,7 @@ def main():
                     traffic_over_algorithmic=got['traffic_bytes'] /
                     roof['algorithmic_bytes_per_launch'],
                     traffic_source=source, traffic_detail=got)
-      else:
+      elif name == 'deterministic' or args.detail:
         roof['traffic_live_error'] = live.get('error', 'unavailable')
   if rank == 0:
     if world == 1 and not args.no_cpu_baseline:
@@ -740,10 +780,117 @@ def main():
             'sample': (f'NumPy oracle in-process, {one["units"]} unit(s) in '
                        f'{one["seconds"]:.1f} s (the multi-process leg failed: '
                        f'{type(e).__name__}: {e})')}
-    print(json.dumps(out))
+    emit(out, args)
   if ddp:
     dist.barrier()
     dist.destroy_process_group()
+
+
+DETAIL_FILE = 'bench_detail.json'
+LINE_LIMIT = 4096  # bytes: the contract line must stay readable by the driver
+
+
+def _pick(d, *keys):
+  return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact(out: dict) -> dict:
+  """The CONTRACT line: the headline with its roofline and cpu_baseline, and
+  one-number summaries of the other legs.  Everything else lives in
+  bench_detail.json (printed on the line before)."""
+  line = _pick(out, 'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup',
+               'ms_per_step', 'gpu_ms_per_step', 'higher_is_better', 'scaling',
+               'vs_baseline', 'dtype', 'data')
+  line['config'] = _pick(out['config'], 'workload', 'units_per_step_per_gpu',
+                         'pool_units', 'total_units', 'regions',
+                         'rows_per_chunk', 'step', 'parallelism', 'launcher')
+  line['roofline'] = _pick(
+      out['roofline'], 'bound', 'kernel', 'achieved', 'peak', 'unit', 'frac',
+      'kernel_ms', 'kernel_ms_samples', 'algorithmic_bytes_per_launch',
+      'step_frac', 'traffic', 'traffic_over_algorithmic', 'traffic_live_error')
+  if 'cpu_baseline' in out:
+    cb = out['cpu_baseline']
+    line['cpu_baseline'] = _pick(cb, 'value', 'unit', 'cores', 'kind',
+                                 'value_1core', 'logical_cores')
+    line['cpu_baseline']['sample'] = cb.get('sample_short') or str(
+        cb.get('sample', ''))[:200]
+  line['unramped'] = _pick(out.get('unramped', {}), 'value', 'ms_per_step')
+  if out['n_gpus'] > 1 or out['ranks']['backend']:
+    line['ranks'] = out['ranks']
+  if 'map_allreduce' in out:
+    line['map_allreduce'] = _pick(out['map_allreduce'], 'bytes_per_rank', 'ms',
+                                  'busbw_GBps', 'backend')
+  if 'full_suite' in out:
+    line['full_suite'] = _pick(out['full_suite'], 'value', 'ms_per_step',
+                               'scaling', 'steps', 'ms_per_step_per_rank',
+                               'error')
+    k3 = out['full_suite'].get('ensemble_kernel') or {}
+    if 'frac' in k3:
+      line['full_suite']['k3_frac'] = k3['frac']
+
+  def roof_of(leg_):
+    r = (leg_ or {}).get('roofline') or {}
+    return _pick(r, 'frac', 'kernel_ms', 'traffic_over_algorithmic')
+  if 'ensemble' in out:
+    line['ensemble'] = dict(_pick(out['ensemble'], 'value', 'error'),
+                            **roof_of(out['ensemble']))
+  if 'spectrum' in out:
+    sp = out['spectrum']
+    line['spectrum'] = dict(_pick(sp, 'value', 'error'), **roof_of(sp))
+    for sub in ('materialized', 'time_mean'):
+      if sub in sp:
+        line['spectrum'][sub + '_frac'] = roof_of(sp[sub]).get('frac')
+  if 'api' in out:
+    line['api'] = _pick(out['api'], 'value', 'ms_per_step', 'error')
+  if 'api_official_chunk' in out:
+    oc = out['api_official_chunk']
+    line['api_official_chunk'] = _pick(oc, 'value', 'batch_chunks',
+                                       'wall_ms_per_chunk', 'error')
+    by = oc.get('by_batch_chunks') or {}
+    if '1' in by:
+      line['api_official_chunk']['chunk_by_chunk'] = _pick(
+          by['1'], 'value', 'host_ms_per_chunk')
+    if 'host_fed' in oc:
+      line['api_official_chunk']['host_fed'] = _pick(
+          oc['host_fed'], 'value', 'h2d_GBps', 'wall_ms_per_chunk', 'error')
+  if 'pcie_inclusive' in out:
+    pc = out['pcie_inclusive']
+    line['pcie_inclusive'] = {
+        k: _pick(v, 'value', 'h2d_GBps') for k, v in pc.items()
+        if isinstance(v, dict)} or _pick(pc, 'error')
+  errors = [k for k, v in out.items() if isinstance(v, dict) and 'error' in v]
+  if errors:
+    line['errors'] = errors
+  line['detail'] = DETAIL_FILE
+  return line
+
+
+def emit(out: dict, args) -> None:
+  """Writes the full record to bench_detail.json (repo root, and gpurun_out/
+  when that exists) and prints the contract line -- ONE JSON object of less
+  than LINE_LIMIT bytes, the last (by default the only) stdout line."""
+  detail = json.dumps(out)
+  for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+    if os.path.isdir(d):
+      try:
+        with open(os.path.join(d, DETAIL_FILE), 'w') as f:
+          f.write(detail + '\n')
+      except OSError:
+        pass
+  if args.print_detail:
+    print('bench_detail ' + detail)
+  line = compact(out)
+  text = json.dumps(line)
+  if len(text) >= LINE_LIMIT:  # shed the optional summaries, never the contract
+    for key in ('pcie_inclusive', 'api', 'unramped', 'api_official_chunk',
+                'spectrum', 'ensemble', 'full_suite', 'map_allreduce'):
+      line.pop(key, None)
+      text = json.dumps(line)
+      if len(text) < LINE_LIMIT:
+        break
+  sys.stdout.flush()
+  print(text)
+  sys.stdout.flush()
 
 
 def full_suite(args, dev, pl_det, det_step, det_acc, timed_region, per_rank,

@@ -450,6 +450,64 @@ int wb2_time_accumulate_scatter(int dtype, const void* values, int64_t n_lead,
                                 void* stream);
 
 /*
+ * One chunk of the deterministic suite in ONE call: K1 (wb2_stream_partials_ex /
+ * _addr) -> K2 (wb2_det_combine) -> the running temporal mean
+ * (wb2_time_accumulate_scatter), enqueued back to back on `stream`.  This is
+ * what evaluation._evaluate_chunk + TemporalMean do for one chunk
+ * (evaluation.py:583-599, 735-744) and what a caller that evaluates many
+ * chunks on one grid should call: the host work per chunk is one function call
+ * (no per-kernel argument marshalling), and the kernels and their bits are
+ * exactly those of the three separate entry points.
+ *
+ * `plan` collects the tables that do not change between chunks of one grid and
+ * region set (every pointer DEV, meanings as in wb2_stream_partials_ex /
+ * wb2_det_combine); the struct itself lives in HOST memory and is only read
+ * during the call.
+ *
+ *  in / slab     as wb2_stream_partials_ex; in == NULL selects the by-address
+ *                form (slab[i][o] = byte address of input i's slab o,
+ *                `aligned16` as in wb2_stream_partials_addr; ignored otherwise)
+ *  partials      DEV scratch, double[n_outer][n_chunk][nwf][n_ts][K]
+ *  metrics       DEV double[NM][n_region][n_outer] (out; NM = WB2_NMETRIC for
+ *                DET / DET_ACC / WIND, KQ for the generic modes)
+ *  sum / count   DEV accumulators or NULL (no temporal accumulation).  `metrics`
+ *                is then read as [acc_lead][acc_time][acc_tail] (their product
+ *                must be NM * n_region * n_outer) and summed over acc_time into
+ *                sum / count [acc_lead][acc_tail], through `dst` if not NULL,
+ *                NaNs skipped when acc_skipna != 0 -- wb2_time_accumulate_scatter.
+ */
+typedef struct wb2_plan_tables {
+  int32_t n_row, n_col;
+  int32_t n_chunk, n_ctile;
+  int32_t n_seg, n_ts;
+  int32_t n_band, n_region;
+  const double* w_row;
+  const double* w_col;
+  const void* wfield;          /* NULL: no 2-D weight field (nwf = 1) */
+  int32_t wfield_dtype;        /* WB2_F64 / WB2_F32 */
+  int32_t reserved;            /* 0 */
+  const double* aux;           /* WB2_MODE_SEEPS: p1; else NULL */
+  double scalar;               /* WB2_MODE_SEEPS: dry threshold */
+  const int32_t* chunk_row0;
+  const int32_t* chunk_nrow;
+  const int32_t* seg_col0;
+  const int32_t* seg_eoff;
+  const int32_t* band_chunk0;
+  const double* coef_band;
+  const double* coef_seg;
+  const int32_t* region_wf;
+  const double* region_wsum;
+} wb2_plan_tables;
+
+int wb2_det_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
+                       int skipna, const void* const* in,
+                       const int64_t* const* slab, int aligned16,
+                       int64_t n_outer, double* partials, double* metrics,
+                       int64_t acc_lead, int64_t acc_time, int64_t acc_tail,
+                       int acc_skipna, const int64_t* dst, double* sum,
+                       double* count, void* stream);
+
+/*
  * K5: the Spatial* metrics (no spatial reduction): SpatialBias / SpatialMSE /
  * SpatialMAE (weatherbench2/metrics.py:304-374).
  *
@@ -569,6 +627,27 @@ int wb2_zonal_spectrum_latmean(void* plan, const void* x,
  * amplifies next to the poles (<= 5e-5 relative there).  The Python host keeps
  * using NumPy itself (plan.get_lat_weights). */
 int wb2_lat_weights(int dtype, const void* latitude, int64_t n, void* out);
+
+/* Staging of PAGEABLE host chunks: the Beam pipeline hands _evaluate_chunk
+ * NumPy-backed datasets (weatherbench2/evaluation.py:583-599, 693-705), i.e.
+ * malloc'ed pages a DMA engine cannot read.  An uploader owns a ring of
+ * `n_slots` page-locked slots of `slot_bytes` each and a pool of `n_threads`
+ * copy threads: wb2_uploader_upload cuts the source into slot-sized slices,
+ * the pool copies slice k + 1 into a free slot while the DMA of slice k
+ * (hipMemcpyAsync on `stream`) is in flight.  The call returns once the last
+ * slice has been STAGED -- `src` may be reused or freed; `dst` (DEV) is
+ * complete in `stream` order.  One uploader serves one calling thread at a
+ * time.  (HOST pointers: uploader_out, src.) */
+int wb2_uploader_create(int32_t n_threads, int64_t slot_bytes, int32_t n_slots,
+                        void** uploader_out);
+/* The pool's copy on its own: dst[0:nbytes] = src[0:nbytes] (HOST, HOST) by
+ * n_threads threads over 4 KiB-aligned pieces; for callers that keep their own
+ * pinned buffers (feeder.ChunkFeeder). */
+int wb2_host_copy(void* dst, const void* src, int64_t nbytes,
+                  int32_t n_threads);
+int wb2_uploader_destroy(void* uploader);
+int wb2_uploader_upload(void* uploader, void* dst, const void* src,
+                        int64_t nbytes, void* stream);
 
 /* RCCL communicator for callers that do not use torch.distributed: rank 0 makes
  * a 128-byte id (wb2_comm_unique_id), distributes it by any means (file, MPI,

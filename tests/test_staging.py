@@ -1,0 +1,98 @@
+"""Staging of pageable host chunks (csrc/staging.cpp): the copy pool on its own
+(CPU), and on the GPU the uploader round trip plus evaluate_chunks fed with
+NumPy forecast chunks -- the form in which the Beam pipeline hands chunks over
+(/root/reference/weatherbench2/evaluation.py:583-599, 693-705) -- bit-identical
+to the device-resident run."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def test_host_copy_pool_copies_every_byte():
+  from weatherbench2_amd import _lib
+  lib = _lib.load()
+  rs = np.random.default_rng(0)
+  src = rs.integers(0, 255, (9 << 20) + 77, dtype=np.uint8)
+  for n in (0, 1, 4095, 4096, 4097, (4 << 20) - 1, (4 << 20) + 123, src.size):
+    for threads in (1, 3, 8):
+      dst = np.zeros(src.size + 64, dtype=np.uint8)
+      assert lib.wb2_host_copy(dst.ctypes.data, src.ctypes.data, n,
+                               threads) == 0
+      assert np.array_equal(dst[:n], src[:n])
+      assert not dst[n:].any()
+  assert lib.wb2_host_copy(None, src.ctypes.data, 16, 2) != 0
+  assert lib.wb2_host_copy(src.ctypes.data, src.ctypes.data, -1, 2) != 0
+  assert lib.wb2_host_copy(src.ctypes.data, src.ctypes.data, 16, 0) != 0
+
+
+def test_uploader_needs_a_device_and_says_so():
+  import torch
+  from weatherbench2_amd import _lib
+  if torch.cuda.is_available():
+    pytest.skip('a HIP device is present')
+  lib = _lib.load()
+  handle = ctypes.c_void_p()
+  assert lib.wb2_uploader_create(4, 1 << 20, 3, ctypes.byref(handle)) != 0
+  assert b'pinned ring' in lib.wb2_last_error()
+  assert lib.wb2_uploader_create(0, 1 << 20, 3, ctypes.byref(handle)) != 0
+  assert lib.wb2_uploader_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_upload_round_trip():
+  import torch
+  from weatherbench2_amd import feeder
+  dev = torch.device('cuda')
+  rs = np.random.default_rng(1)
+  # below one slice, exactly one slice, several slices + a ragged tail
+  for n in (1, 1000, feeder._SLICE_BYTES // 4,
+            5 * feeder._SLICE_BYTES // 4 + 12345):
+    a = rs.standard_normal(n, dtype=np.float32)
+    got = feeder.upload(a, dev)
+    assert got.dtype == torch.float32 and tuple(got.shape) == a.shape
+    assert np.array_equal(got.cpu().numpy(), a)
+  a = rs.standard_normal((3, 5, 7))
+  assert np.array_equal(feeder.upload(a, dev).cpu().numpy(), a)
+  # many uploads back to back: the ring is reused, destinations stay intact
+  arrays = [rs.standard_normal(3_000_000, dtype=np.float32) for _ in range(6)]
+  devs = [feeder.upload(a, dev) for a in arrays]
+  torch.cuda.synchronize()
+  for a, d in zip(arrays, devs):
+    assert np.array_equal(d.cpu().numpy(), a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch', [1, 3, None])
+def test_host_fed_chunks_equal_device_resident_chunks(batch):
+  """The same chunk list once device-resident, once with every forecast
+  variable a pageable NumPy array (staged by the fetch thread): identical
+  results, bit for bit."""
+  import torch
+  from tests import helpers, official_chunks as oc
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  forecast, truth, clim = oc.make(n_init=3, n_lead=2, n_lat=61, n_lon=120)
+  lat, lon = forecast.coords['latitude'], forecast.coords['longitude']
+  oregions = oc.oracle_regions(lat, lon, oc.land_sea_mask(len(lat), len(lon)))
+  gregions = {k: helpers.to_gpu_region(v) for k, v in oregions.items()}
+  hf, ht, hc = (helpers.to_gpu_dataset(x) for x in (forecast, truth, clim))
+  gf, gt, gc = (evaluation.make_resident(x) for x in (hf, ht, hc))
+  cfg = config.Eval(metrics=oc.product_metrics(gm, gc), regions=gregions)
+  chunks = oc.chunk_pairs(gf, gt)
+  # forecast chunks as NumPy arrays, truth chunks device-resident
+  fed = [(hfc, tc) for (hfc, _), (_, tc) in zip(oc.chunk_pairs(hf, ht), chunks)]
+  assert all(isinstance(v.data, np.ndarray)
+             for v in fed[0][0].data_vars.values())
+  kwargs = {} if batch is None else {'batch_chunks': batch}
+  want = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, **kwargs)
+  old = evaluation._STAGE_MIN_BYTES
+  evaluation._STAGE_MIN_BYTES = 1024   # these test chunks are small
+  try:
+    got = evaluation.evaluate_chunks(fed, cfg, False, prefetch=2, **kwargs)
+  finally:
+    evaluation._STAGE_MIN_BYTES = old
+  assert sorted(got.data_vars) == sorted(want.data_vars)
+  for name in want.data_vars:
+    a, b = np.asarray(got[name].values), np.asarray(want[name].values)
+    assert a.dtype == b.dtype and a.shape == b.shape
+    assert np.array_equal(a, b, equal_nan=True), name

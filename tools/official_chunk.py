@@ -216,9 +216,79 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
   return leg
 
 
+def host_chunks(chunks, pool: int):
+  """The same chunk list with every FORECAST variable as a pageable NumPy
+  array (what xbeam.DatasetToChunks hands _evaluate_chunk, evaluation.py:
+  693-705); truth chunks stay device-resident views, the climatology resident.
+  `pool` distinct host chunks (353 MB each) come round."""
+  from weatherbench2_amd import xarray_lite as xl
+  host_pool = []
+  for f, _ in chunks[:pool]:
+    host_pool.append({k: v.data.cpu().numpy() for k, v in f.data_vars.items()})
+  out = []
+  for j, (f, t) in enumerate(chunks):
+    arrays = host_pool[j % pool]
+    fd = xl.Dataset({k: xl.DataArray(arrays[k], f.data_vars[k].dims)
+                     for k in f.data_vars}, dict(f.coords))
+    out.append((fd, t))
+  return out
+
+
+def measure_host_fed(chunks, cfg, n_chunks: int = 48, pool: int = 6,
+                     prefetch: int = 2) -> dict:
+  """`api_official_chunk.host_fed`: forecast chunks arrive as pageable NumPy
+  arrays and cross PCIe inside evaluate_chunks (the fetch thread stages them
+  through the uploader while the main thread evaluates the previous window);
+  reports evals/s, the H2D rate achieved and the wall time per chunk."""
+  import torch
+  from weatherbench2_amd import evaluation, feeder
+  fed = host_chunks(chunks[:n_chunks], pool)
+  nbytes = sum(v.data.nbytes for v in fed[0][0].data_vars.values())
+  legs = {}
+  for name, kwargs in (('default_window', {}), ('chunk_by_chunk',
+                                                {'batch_chunks': 1})):
+    evaluation.evaluate_chunks(fed[:8], cfg, False, prefetch=prefetch,
+                               **kwargs)  # uploader, ring, plans
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evaluation.evaluate_chunks(fed, cfg, False, prefetch=prefetch, **kwargs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    legs[name] = {
+        'value': len(fed) * PTS_PER_CHUNK / dt, 'unit': 'grid-point-evals/s',
+        'h2d_GBps': len(fed) * nbytes / dt / 1e9,
+        'wall_ms_per_chunk': dt / len(fed) * 1e3, 'chunks': len(fed)}
+  # the uploader alone: one chunk's arrays, back to back (no evaluation)
+  arrays = [v.data for v in fed[0][0].data_vars.values()]
+  for a in arrays:
+    feeder.upload(a, dev_of(chunks))
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(4):
+    for a in arrays:
+      feeder.upload(a, dev_of(chunks))
+  torch.cuda.synchronize()
+  up = 4 * nbytes / (time.perf_counter() - t0) / 1e9
+  out = dict(legs['default_window'])
+  out.update(
+      by_window=legs, uploader_alone_GBps=up,
+      copy_threads=feeder.copy_threads(), bytes_per_chunk=nbytes,
+      what=('forecast chunks as pageable NumPy arrays (13 variables, 353 MB '
+            'per chunk) through evaluate_chunks(prefetch=%d): staged by the '
+            'fetch thread (wb2_uploader_upload: %d copy threads into a pinned '
+            'ring, DMA overlapped), truth / climatology resident' % (
+                prefetch, feeder.copy_threads())))
+  return out
+
+
+def dev_of(chunks):
+  return next(iter(chunks[0][1].data_vars.values())).data.device
+
+
 def run(dev, n_chunks: int = 128, pool: int = 32,
-        batches=(1, 16, 32, None), headline_batch=None) -> dict:
-  """The `api_official_chunk` object of the bench line."""
+        batches=(1, 16, 32, None), headline_batch=None,
+        host_fed: bool = False) -> dict:
+  """The `api_official_chunk` object of the bench record."""
   import torch
   from weatherbench2_amd import metrics as gm
   chunks, cfg = build(dev, n_chunks, pool)
@@ -237,6 +307,11 @@ def run(dev, n_chunks: int = 128, pool: int = 32,
   head = legs[head_name] if head_name in legs else legs[list(legs)[-1]]
   out = dict(head)
   out['by_batch_chunks'] = legs
+  if host_fed:
+    try:
+      out['host_fed'] = measure_host_fed(chunks, cfg)
+    except Exception as e:
+      out['host_fed'] = {'error': f'{type(e).__name__}: {e}'}
   out['config'] = {
       'workload': ('official 0.25-degree deterministic chunking: '
                    'init_time=1,lead_time=1 chunks of 13 variables (6 x 13 '
@@ -256,6 +331,9 @@ def main():
   ap.add_argument('--pool', type=int, default=32,
                   help='distinct device-resident chunks (>= the largest window)')
   ap.add_argument('--batch', default='1,16,32,default')
+  ap.add_argument('--host-fed', action='store_true',
+                  help='also the leg whose forecast chunks are pageable NumPy '
+                       'arrays')
   ap.add_argument('--profile', action='store_true',
                   help='cProfile of the host path at the first batch size')
   ap.add_argument('--sections', action='store_true',
@@ -319,7 +397,7 @@ def main():
     pstats.Stats(pr).sort_stats("cumulative").print_stats(40); pstats.Stats(pr).sort_stats("tottime").print_stats(35)
     return
   print(json.dumps(run(dev, args.chunks, args.pool, batches,
-                       headline_batch=batches[-1])))
+                       headline_batch=batches[-1], host_fed=args.host_fed)))
 
 
 if __name__ == '__main__':

@@ -32,6 +32,21 @@ _c = ctypes
 _vp, _i32, _i64, _int = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_int
 _u64 = _c.c_uint64
 
+
+
+class PlanTables(_c.Structure):
+  """wb2_plan_tables of include/wb2hip.h (host struct of device pointers)."""
+  _fields_ = [
+      ('n_row', _i32), ('n_col', _i32), ('n_chunk', _i32), ('n_ctile', _i32),
+      ('n_seg', _i32), ('n_ts', _i32), ('n_band', _i32), ('n_region', _i32),
+      ('w_row', _vp), ('w_col', _vp), ('wfield', _vp),
+      ('wfield_dtype', _i32), ('reserved', _i32), ('aux', _vp),
+      ('scalar', _c.c_double), ('chunk_row0', _vp), ('chunk_nrow', _vp),
+      ('seg_col0', _vp), ('seg_eoff', _vp), ('band_chunk0', _vp),
+      ('coef_band', _vp), ('coef_seg', _vp), ('region_wf', _vp),
+      ('region_wsum', _vp)]
+
+
 _SIGNATURES = {
     'wb2_version': (_int, []),
     'wb2_last_error': (_c.c_char_p, []),
@@ -52,6 +67,10 @@ _SIGNATURES = {
     'wb2_det_combine': (_int, [
         _int, _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp,
         _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    'wb2_det_suite_step': (_int, [
+        _c.POINTER(PlanTables), _int, _int, _int, _c.POINTER(_vp),
+        _c.POINTER(_vp), _int, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp,
+        _vp, _vp, _vp]),
     'wb2_time_accumulate': (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp,
                                    _vp]),
     'wb2_time_accumulate_scatter': (_int, [_int, _vp, _i64, _i64, _i64, _int,
@@ -103,6 +122,10 @@ _SIGNATURES = {
     'wb2_zonal_spectrum_latmean': (_int, [_vp, _vp, _vp, _i32, _i32,
                                           _c.c_double, _vp, _vp, _vp]),
     'wb2_lat_weights': (_int, [_int, _vp, _i64, _vp]),
+    'wb2_uploader_create': (_int, [_i32, _i64, _i32, _c.POINTER(_vp)]),
+    'wb2_uploader_destroy': (_int, [_vp]),
+    'wb2_host_copy': (_int, [_vp, _vp, _i64, _i32]),
+    'wb2_uploader_upload': (_int, [_vp, _vp, _vp, _i64, _vp]),
     'wb2_comm_unique_id': (_int, [_vp]),
     'wb2_comm_init_rank': (_int, [_vp, _i32, _i32, _c.POINTER(_vp)]),
     'wb2_comm_destroy': (_int, [_vp]),

@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
-SOURCES = ('common.cpp', 'comm.cpp', 'stream_reduce.hip', 'ensemble.hip',
+SOURCES = ('common.cpp', 'comm.cpp', 'staging.cpp', 'stream_reduce.hip', 'ensemble.hip',
            'spectrum.hip', 'spectrum_fused.hip', 'spatial_maps.hip',
            'rank_histogram.hip', 'axis_reduce.hip')
 # compiled once per member count listed in sort3_networks.inc (WB2_SORT3_SIZES)
@@ -34,9 +34,15 @@ def exact_sizes() -> list[tuple]:
   import re
   text = open(os.path.join(CSRC, 'sort3_networks.inc')).read()
   block = text[text.index('#define WB2_SORT3_SIZES(X)'):]
-  block = block[:block.index('\n\n')]
+  # the macro body: the continuation lines (a blank line need not follow)
+  lines = block.split('\n')
+  body = [lines[0]]
+  for line in lines[1:]:
+    if not body[-1].rstrip().endswith('\\'):
+      break
+    body.append(line)
   return [(int(a), int(b)) for a, b in re.findall(r'X\((\d+),\s*(\d+)\)',
-                                                  block)]
+                                                  '\n'.join(body))]
 
 
 def translation_units() -> list[tuple]:
@@ -49,16 +55,22 @@ def translation_units() -> list[tuple]:
   return units
 
 
+def _headers() -> list[str]:
+  """Every header a translation unit may include: all of csrc/*.hpp, *.inc
+  and the public header (a glob, not a hand-kept list: a new or regenerated
+  header -- gauss_tables.inc, a sorter program -- can never leave a stale
+  library behind)."""
+  import glob
+  return sorted(glob.glob(os.path.join(CSRC, '*.hpp')) +
+                glob.glob(os.path.join(CSRC, '*.inc')) +
+                [os.path.join(ROOT, 'include', 'wb2hip.h')])
+
+
 def needs_rebuild() -> bool:
   if not os.path.exists(LIB_PATH):
     return True
   t = os.path.getmtime(LIB_PATH)
-  deps = sources() + [os.path.join(CSRC, EXACT_SOURCE)] + [
-      os.path.join(CSRC, h) for h in
-                      ('common.hpp', 'reduce_common.hpp', 'sort_networks.inc',
-                       'sort3_network_50.inc', 'sort3_networks.inc',
-                       'ensemble_kernels.hpp', 'fft_core.hpp', 'trace.hpp')
-                      ] + [os.path.join(ROOT, 'include', 'wb2hip.h')]
+  deps = sources() + [os.path.join(CSRC, EXACT_SOURCE)] + _headers()
   return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -98,13 +110,45 @@ def build(force: bool = False, verbose: bool = True) -> str:
            '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
   extra = os.environ.get('WB2HIP_CXXFLAGS', '').split()
 
+  stamp = ' '.join(flags + extra)
+  search = [CSRC, os.path.join(ROOT, 'include')]
+
+  def newest_dep(path, seen=None) -> float:
+    """mtime of the newest file `path` includes (quoted includes, followed
+    through csrc/ and include/), itself included."""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+      return 0.0
+    seen.add(path)
+    newest = os.path.getmtime(path)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(),
+                          re.M):
+      for d in [os.path.dirname(path)] + search:
+        cand = os.path.join(d, inc)
+        if os.path.exists(cand):
+          newest = max(newest, newest_dep(cand, seen))
+          break
+    return newest
+
   def compile_one(unit):
     src, name, defines = unit
     obj = os.path.join(obj_dir, name)
+    # an object newer than its source and every header, built with the same
+    # flags (recorded beside it), is reused: a one-file edit recompiles one
+    # unit (force=True recompiles everything)
+    flag_file = obj + '.flags'
+    mine = stamp + ' ' + ' '.join(defines)
+    if (not force and os.path.exists(obj) and os.path.exists(flag_file)
+        and open(flag_file).read() == mine
+        and os.path.getmtime(obj) > newest_dep(src)):
+      return obj
     cmd = [_hipcc()] + flags + extra + defines + ['-c', src, '-o', obj]
     if verbose:
       print('[wb2hip build]', ' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(flag_file, 'w') as f:
+      f.write(mine)
     return obj
 
   # the largest units first: the longest compile bounds the wall time
@@ -117,7 +161,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
           ] + objs
   if any(s.endswith('spectrum.hip') for s in sources()):
     link += ['-L/opt/rocm/lib', '-lhipfft']
-  link += ['-ldl']
+  link += ['-ldl', '-pthread']
   if verbose:
     print('[wb2hip build]', ' '.join(link), file=sys.stderr)
   subprocess.run(link, check=True)

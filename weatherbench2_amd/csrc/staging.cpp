@@ -1,0 +1,209 @@
+// Host -> HBM staging for chunks that arrive in PAGEABLE memory.
+//
+// The reference's Beam pipeline hands _evaluate_chunk NumPy-backed datasets
+// (xbeam.DatasetToChunks, /root/reference/weatherbench2/evaluation.py:693-705):
+// ordinary malloc'ed pages.  A DMA engine cannot read those, so every byte is
+// copied once into page-locked memory on its way to the device.  One thread's
+// memcpy runs at ~10 GB/s -- a sixth of what the PCIe 5.0 x16 link moves -- so
+// the staging copy is done by a small pool of threads, slice by slice through a
+// ring of pinned slots: while the DMA of slice k runs, the pool fills slice
+// k + 1.  hipHostRegister of the source was the alternative; pinning fresh
+// pages costs more than copying them (get_user_pages per 4 KiB page) and the
+// arrays are new every chunk.
+//
+//   wb2_uploader_create / _destroy     ring + pool, once per feeder thread
+//   wb2_uploader_upload                one pageable buffer -> device memory,
+//                                      asynchronous on the caller's stream;
+//                                      returns when the SOURCE may be reused
+#include "common.hpp"
+#include "trace.hpp"
+#include "wb2hip.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace wb2 {
+namespace {
+
+// A fork-join pool: run(job) executes job(part) for part = 0..n-1 on the
+// workers (the caller takes part 0) and returns when all parts are done.
+class CopyPool {
+ public:
+  explicit CopyPool(int n_threads) : n_(n_threads < 1 ? 1 : n_threads) {
+    for (int i = 1; i < n_; ++i) workers_.emplace_back([this, i] { loop(i); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+      ++generation_;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  int size() const { return n_; }
+
+  void copy(char* dst, const char* src, size_t nbytes) {
+    if (n_ == 1 || nbytes < (size_t)(4 << 20)) {
+      std::memcpy(dst, src, nbytes);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      dst_ = dst;
+      src_ = src;
+      nbytes_ = nbytes;
+      pending_ = n_ - 1;
+      ++generation_;
+    }
+    cv_.notify_all();
+    part(0);
+    std::unique_lock<std::mutex> lock(mu_);
+    done_.wait(lock, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void part(int i) {
+    // 4 KiB-aligned cuts: no two threads share a destination page
+    const size_t per = ((nbytes_ / n_) + 4095) & ~(size_t)4095;
+    const size_t lo = per * i < nbytes_ ? per * i : nbytes_;
+    const size_t hi = (i == n_ - 1) ? nbytes_
+                                    : (lo + per < nbytes_ ? lo + per : nbytes_);
+    if (hi > lo) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+  }
+  void loop(int i) {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+      }
+      part(i);
+      std::lock_guard<std::mutex> lock(mu_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  const int n_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  unsigned long generation_ = 0;
+  bool stop_ = false;
+  int pending_ = 0;
+  char* dst_ = nullptr;
+  const char* src_ = nullptr;
+  size_t nbytes_ = 0;
+};
+
+struct Uploader {
+  CopyPool pool;
+  size_t slot_bytes;
+  std::vector<char*> slots;
+  std::vector<hipEvent_t> events;
+  std::vector<bool> busy;
+  int next = 0;
+  Uploader(int n_threads, size_t slot) : pool(n_threads), slot_bytes(slot) {}
+};
+
+}  // namespace
+}  // namespace wb2
+
+extern "C" {
+
+int wb2_uploader_create(int32_t n_threads, int64_t slot_bytes, int32_t n_slots,
+                        void** uploader_out) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(uploader_out != nullptr, "null pointer argument");
+  WB2_REQUIRE(n_threads >= 1 && n_threads <= 256, "n_threads=%d", n_threads);
+  WB2_REQUIRE(slot_bytes >= 4096 && n_slots >= 2 && n_slots <= 64,
+              "slot_bytes=%lld n_slots=%d", (long long)slot_bytes, n_slots);
+  auto* up = new Uploader(n_threads, (size_t)slot_bytes);
+  for (int i = 0; i < n_slots; ++i) {
+    void* p = nullptr;
+    hipEvent_t ev = nullptr;
+    if (hipHostMalloc(&p, (size_t)slot_bytes, hipHostMallocDefault) !=
+            hipSuccess ||
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      if (p) (void)hipHostFree(p);
+      for (char* s : up->slots) (void)hipHostFree(s);
+      for (hipEvent_t e : up->events) (void)hipEventDestroy(e);
+      delete up;
+      return fail("pinned ring of %d x %lld bytes could not be allocated",
+                  n_slots, (long long)slot_bytes);
+    }
+    // first touch by this thread: the pages exist before the first upload
+    std::memset(p, 0, (size_t)slot_bytes);
+    up->slots.push_back(static_cast<char*>(p));
+    up->events.push_back(ev);
+    up->busy.push_back(false);
+  }
+  *uploader_out = up;
+  return 0;
+}
+
+int wb2_uploader_destroy(void* uploader) {
+  WB2_TRACE();
+  using namespace wb2;
+  if (!uploader) return 0;
+  auto* up = static_cast<Uploader*>(uploader);
+  for (size_t i = 0; i < up->slots.size(); ++i) {
+    if (up->busy[i]) (void)hipEventSynchronize(up->events[i]);
+    (void)hipEventDestroy(up->events[i]);
+    (void)hipHostFree(up->slots[i]);
+  }
+  delete up;
+  return 0;
+}
+
+int wb2_host_copy(void* dst, const void* src, int64_t nbytes,
+                  int32_t n_threads) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_EMPTY_OK(nbytes);
+  WB2_REQUIRE(dst && src, "null pointer argument");
+  WB2_REQUIRE(n_threads >= 1 && n_threads <= 256, "n_threads=%d", n_threads);
+  CopyPool pool(n_threads);
+  pool.copy(static_cast<char*>(dst), static_cast<const char*>(src),
+            (size_t)nbytes);
+  return 0;
+}
+
+int wb2_uploader_upload(void* uploader, void* dst, const void* src,
+                        int64_t nbytes, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(uploader != nullptr, "null uploader");
+  WB2_EMPTY_OK(nbytes);
+  WB2_REQUIRE(dst && src, "null pointer argument");
+  auto* up = static_cast<Uploader*>(uploader);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char* from = static_cast<const char*>(src);
+  char* to = static_cast<char*>(dst);
+  size_t left = (size_t)nbytes;
+  while (left) {
+    const size_t n = left < up->slot_bytes ? left : up->slot_bytes;
+    const int i = up->next;
+    up->next = (i + 1) % (int)up->slots.size();
+    if (up->busy[i]) {  // the DMA that last read this slot
+      WB2_HIP_OK(hipEventSynchronize(up->events[i]));
+      up->busy[i] = false;
+    }
+    up->pool.copy(up->slots[i], from, n);
+    WB2_HIP_OK(hipMemcpyAsync(to, up->slots[i], n, hipMemcpyHostToDevice, s));
+    WB2_HIP_OK(hipEventRecord(up->events[i], s));
+    up->busy[i] = true;
+    from += n;
+    to += n;
+    left -= n;
+  }
+  return 0;
+}
+
+}  // extern "C"

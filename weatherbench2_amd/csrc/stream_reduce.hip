@@ -1481,6 +1481,52 @@ int wb2_time_accumulate_scatter(int dtype, const void* values, int64_t n_lead,
   return 0;
 }
 
+int wb2_det_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
+                       int skipna, const void* const* in,
+                       const int64_t* const* slab, int aligned16,
+                       int64_t n_outer, double* partials, double* metrics,
+                       int64_t acc_lead, int64_t acc_time, int64_t acc_tail,
+                       int acc_skipna, const int64_t* dst, double* sum,
+                       double* count, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(plan != nullptr, "null plan");
+  WB2_EMPTY_OK(n_outer);
+  WB2_REQUIRE(in != nullptr || slab != nullptr, "null pointer argument");
+  WB2_REQUIRE(metrics != nullptr, "metrics is null");
+  const wb2_plan_tables& t = *plan;
+  const int nm = mode >= WB2_MODE_GAUSS
+                     ? (mode == WB2_MODE_GAUSS ? 2
+                        : mode == WB2_MODE_GAUSS_THR ? 3
+                        : mode == WB2_MODE_ENS_THR ? 4 : 1)
+                     : WB2_NMETRIC;
+  if (sum != nullptr || count != nullptr) {
+    WB2_REQUIRE(sum && count, "sum and count go together");
+    WB2_REQUIRE(acc_lead > 0 && acc_time > 0 && acc_tail > 0 &&
+                    acc_lead * acc_time * acc_tail ==
+                        (long long)nm * t.n_region * n_outer,
+                "accumulate view [%lld][%lld][%lld] does not cover metrics "
+                "[%d][%d][%lld]",
+                (long long)acc_lead, (long long)acc_time, (long long)acc_tail,
+                nm, t.n_region, (long long)n_outer);
+  }
+  int rc = stream_partials_impl(
+      mode, dtype, skipna, in, slab, aligned16, n_outer, t.n_row, t.n_col,
+      t.w_row, t.w_col, t.wfield, t.wfield_dtype, t.aux, t.scalar, t.chunk_row0,
+      t.chunk_nrow, t.n_chunk, t.n_ctile, t.seg_col0, t.seg_eoff, t.n_seg,
+      t.n_ts, partials, stream);
+  if (rc != 0) return rc;
+  rc = wb2_det_combine(mode, skipna, partials, n_outer, t.n_chunk,
+                       t.wfield ? 2 : 1, t.n_seg, t.seg_eoff, t.n_ts,
+                       t.band_chunk0, t.n_band, t.coef_band, t.coef_seg,
+                       t.region_wf, t.region_wsum, t.n_region, nullptr, metrics,
+                       stream);
+  if (rc != 0 || sum == nullptr) return rc;
+  return wb2_time_accumulate_scatter(WB2_F64, metrics, acc_lead, acc_time,
+                                     acc_tail, acc_skipna, dst, sum, count,
+                                     stream);
+}
+
 int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
                   int64_t n_outer, int64_t n_point, const double* aux,
                   double scalar, double* out, void* stream) {

@@ -356,6 +356,140 @@ def _stream_launch(plan, mode, dtype, n_outer, skipna, want_sums, aux, scalar,
   return metrics, sums
 
 
+class SuiteStep:
+  """One chunk of the deterministic suite per call: K1 -> K2 -> the running
+  temporal mean through wb2_det_suite_step -- ONE C-ABI call per chunk instead
+  of three calls with ~25 marshalled arguments each (the kernels and their
+  bits are those of stream_reduce + time_accumulate).
+
+  Prepared once per (plan, mode, dtype, skipna, n_outer): the plan's tables go
+  into a `wb2_plan_tables` struct, the partials / metrics scratch is allocated
+  here and reused by every call (calls are stream-ordered).  `run` takes the
+  chunk's inputs and, optionally, the accumulators.
+
+    step = SuiteStep(plan, MODE_DET_ACC, torch.float32, False, n_outer)
+    step.accumulate_into(total, count, (n_lead, n_time, n_tail))
+    step.run([f, t, c], [f_tab, t_tab, c_tab])     # per chunk
+  """
+
+  def __init__(self, plan: ReductionPlan, mode: int, dtype: torch.dtype,
+               skipna: bool, n_outer: int, aligned: bool = True,
+               aux: t.Optional[torch.Tensor] = None, scalar: float = 0.0,
+               by_address: bool = False):
+    import ctypes
+    lib = _lib.load()
+    if dtype not in _DTYPES:
+      raise TypeError(f'unsupported dtype {dtype}')
+    self.lib, self.plan, self.mode, self.skipna = lib, plan, mode, bool(skipna)
+    self.code, self.n_outer = _DTYPES[dtype], int(n_outer)
+    self.by_address, self.aligned = bool(by_address), bool(aligned)
+    dev = plan.device
+    k = lib.wb2_num_slots(mode, int(skipna))
+    field, field_code = plan.wfield, _lib.WB2_F64
+    if (dtype == torch.float32 and mode in _FIELD_F32_MODES and
+        getattr(plan, 'wfield32', None) is not None and
+        os.environ.get('WB2HIP_FIELD_F32', '1') != '0'):
+      field, field_code = plan.wfield32, _lib.WB2_F32
+    aligned = aligned and (field is None or field.data_ptr() % 16 == 0)
+    tile = lib.wb2_tile_cols_ex(mode, self.code, int(skipna),
+                                int(plan.wfield is not None), plan.n_col,
+                                int(aligned))
+    seg_eoff, n_ts = plan.seg_entries(tile)
+    self.n_metric = _lib.GENERIC_KQ.get(mode, _lib.NMETRIC)
+    self.partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
+                                dtype=torch.float64, device=dev)
+    self.metrics = torch.empty((self.n_metric, plan.n_region, n_outer),
+                               dtype=torch.float64, device=dev)
+    # everything the struct points at stays referenced from here
+    self._keep = (field, aux, seg_eoff)
+    self.tables = _lib.PlanTables(
+        n_row=plan.n_row, n_col=plan.n_col, n_chunk=plan.n_chunk,
+        n_ctile=-(-plan.n_col // tile), n_seg=plan.n_seg, n_ts=n_ts,
+        n_band=plan.n_band, n_region=plan.n_region,
+        w_row=_lib.ptr(plan.w_row) or None, w_col=_lib.ptr(plan.w_col) or None,
+        wfield=_lib.ptr(field) or None, wfield_dtype=field_code, reserved=0,
+        aux=_lib.ptr(aux) or None, scalar=float(scalar),
+        chunk_row0=_lib.ptr(plan.chunk_row0), chunk_nrow=_lib.ptr(plan.chunk_nrow),
+        seg_col0=_lib.ptr(plan.seg_col0), seg_eoff=_lib.ptr(seg_eoff),
+        band_chunk0=_lib.ptr(plan.band_chunk0),
+        coef_band=_lib.ptr(plan.coef_band), coef_seg=_lib.ptr(plan.coef_seg),
+        region_wf=_lib.ptr(plan.region_wf),
+        region_wsum=_lib.ptr(plan.region_wsum))
+    self._tables_ref = ctypes.byref(self.tables)
+    self._acc = (0, 0, 0, 0, None, None, None)
+    self._acc_keep = None
+    self._fn = lib.wb2_det_suite_step
+
+  def accumulate_into(self, total: t.Optional[torch.Tensor],
+                      count: t.Optional[torch.Tensor] = None,
+                      view: t.Optional[tuple] = None, skipna: bool = False,
+                      dst: t.Optional[torch.Tensor] = None) -> None:
+    """Every later run() adds its metrics, read as [lead][time][tail] = `view`,
+    to total / count over `time` (None: no accumulation)."""
+    if total is None:
+      self._acc, self._acc_keep = (0, 0, 0, 0, None, None, None), None
+      return
+    n_lead, n_time, n_tail = (int(v) for v in view)
+    if n_lead * n_time * n_tail != self.metrics.numel():
+      raise ValueError(f'view {view} does not cover the metrics '
+                       f'{tuple(self.metrics.shape)}')
+    for x in (total, count):
+      if x.dtype != torch.float64 or not x.is_contiguous():
+        raise ValueError('accumulators are contiguous float64 tensors')
+    if dst is None and total.numel() != n_lead * n_tail:
+      raise ValueError('accumulator shape mismatch')
+    if dst is not None and (dst.dtype != torch.int64 or
+                            dst.numel() != n_lead * n_tail):
+      raise ValueError('dst is int64 with one entry per result element')
+    self._acc = (n_lead, n_time, n_tail, int(skipna), _lib.ptr(dst) or None,
+                 total.data_ptr(), count.data_ptr())
+    self._acc_keep = (total, count, dst)
+
+  def run(self, inputs: t.Optional[t.Sequence[torch.Tensor]],
+          tables: t.Sequence[t.Optional[torch.Tensor]],
+          metrics: t.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Enqueues the step on the current stream.  `inputs` + slab-number
+    `tables` (None entries = identity), or inputs=None + address tables
+    (by_address).  Returns the metrics tensor [n_metric, n_region, n_outer]
+    (the step's own scratch unless `metrics` is given: valid until the next
+    run)."""
+    out = self.metrics if metrics is None else metrics
+    if self.by_address != (inputs is None):
+      raise ValueError('by_address steps take inputs=None and address tables')
+    status = self._fn(
+        self._tables_ref, self.mode, self.code, int(self.skipna),
+        None if inputs is None else _lib.ptr_array(inputs),
+        _lib.ptr_array(tables), int(self.aligned), self.n_outer,
+        self.partials.data_ptr(), out.data_ptr(), *self._acc,
+        current_stream_ptr(self.plan.device))
+    if status != 0:
+      _lib.check(status, 'wb2_det_suite_step')
+    return out
+
+  def bind(self, inputs, tables, stream_ptr: t.Optional[int] = None):
+    """The call for one fixed (inputs, tables) pair with its arguments
+    marshalled ONCE (the pointer arrays are built here, not per call): a
+    zero-argument callable for loops that come back to the same chunk buffers
+    (a ring of staging slots, a benchmark's table sets).  The accumulators are
+    the ones set when bind() is called; the stream is `stream_ptr` or the
+    current stream at bind time."""
+    if self.by_address != (inputs is None):
+      raise ValueError('by_address steps take inputs=None and address tables')
+    fn = self._fn
+    keep = (inputs, tables, self._acc_keep)
+    args = (self._tables_ref, self.mode, self.code, int(self.skipna),
+            None if inputs is None else _lib.ptr_array(inputs),
+            _lib.ptr_array(tables), int(self.aligned), self.n_outer,
+            self.partials.data_ptr(), self.metrics.data_ptr()) + self._acc + (
+                current_stream_ptr(self.plan.device) if stream_ptr is None
+                else stream_ptr,)
+
+    def call(_keep=keep):
+      if fn(*args) != 0:
+        _lib.check(-1, 'wb2_det_suite_step')
+    return call
+
+
 GATHER_MAX_MEMBERS = {torch.float32: 128, torch.float64: 64}  # register sort
 _NAN_SLABS: dict = {}
 _NAN_SLABS_LOCK = threading.Lock()

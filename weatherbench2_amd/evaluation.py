@@ -42,6 +42,7 @@ from __future__ import annotations
 
 import contextlib
 import logging
+import os
 import typing as t
 
 import numpy as np
@@ -494,17 +495,23 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
   return lo, lo + base + (1 if rank < extra else 0)
 
 
-def _prefetched(chunks, lo: int, hi: int, depth):
+def _prefetched(chunks, lo: int, hi: int, depth, stage=None):
   """Yields chunks[lo], ..., chunks[hi - 1] in order, fetching up to `depth`
   items ahead on ONE background thread (so the fetches themselves stay in
   order -- sequences that read a file sequentially keep doing so).  `depth` is
   an int or a callable read before every fetch (the window size of
-  evaluate_chunks is only known after the first chunk)."""
+  evaluate_chunks is only known after the first chunk).  `stage` (optional) is
+  applied to every fetched item ON the fetch thread (`_stage_on_device`: the
+  host -> HBM copy of chunk i + 1 runs while the main thread works on chunk
+  i); without a fetch thread it is not applied (the metrics upload what they
+  read)."""
   depth_now = depth if callable(depth) else (lambda: depth)
   if depth_now() <= 0 or hi - lo <= 1:
     for i in range(lo, hi):
       yield chunks[i]
     return
+  fetch = chunks.__getitem__ if stage is None else (
+      lambda i: stage(chunks[i]))
   import collections
   from concurrent import futures
   from weatherbench2_amd import engine
@@ -518,12 +525,66 @@ def _prefetched(chunks, lo: int, hi: int, depth):
     try:
       while nxt < hi or pending:
         while nxt < hi and len(pending) <= depth_now():
-          pending.append(pool.submit(chunks.__getitem__, nxt))
+          pending.append(pool.submit(fetch, nxt))
           nxt += 1
         yield pending.popleft().result()
     finally:
       for fut in pending:
         fut.cancel()
+
+
+# host arrays below this size are left to the metrics (coordinates, scalars)
+_STAGE_MIN_BYTES = 1 << 20
+
+
+class _Staged:
+  """A chunk pair whose host arrays have been sent to the device by the fetch
+  thread, with the event (on the copy stream) that completes the copies."""
+
+  def __init__(self, pair, event, tensors):
+    self.pair, self.event, self.tensors = pair, event, tensors
+
+
+def _stage_on_device(device):
+  """stage(pair) for `_prefetched`: every NumPy-backed variable of a chunk
+  pair that holds (latitude, longitude) slabs goes to HBM through the calling
+  (fetch) thread's uploader (feeder.upload: a pool of copy threads stages
+  slices into a pinned ring while the DMA of the previous slice runs;
+  evaluation.py:693-705 hands such pageable arrays to every chunk call).
+  Device-resident and lazy (gather / concat) variables pass through."""
+  import torch
+  from weatherbench2_amd import feeder
+  dev = torch.device(device)
+
+  def to_device(ds):
+    ds = xl.as_dataset(ds)
+    moved = []
+    hits = [n for n, da in ds.data_vars.items()
+            if isinstance(da.data, np.ndarray)
+            and da.data.nbytes >= _STAGE_MIN_BYTES
+            and da.data.dtype in (np.float32, np.float64)
+            and da.data.dtype.isnative]
+    if not hits:
+      return ds, moved
+    out = xl.Dataset(coords=ds.coords, attrs=dict(ds.attrs))
+    for name, da in ds.data_vars.items():
+      data = da.data
+      if name in hits:
+        data = feeder.upload(data, dev, wait=False)
+        moved.append(data)
+      out.data_vars[name] = xl.DataArray(data, da.dims, ds.coords, name)
+    return out, moved
+
+  def stage(pair):
+    staged = [to_device(ds) for ds in pair[:2]]
+    tensors = [x for _, moved in staged for x in moved]
+    if not tensors:
+      return pair
+    event = torch.cuda.Event()
+    event.record(feeder.copy_stream(dev))
+    return _Staged((staged[0][0], staged[1][0]) + tuple(pair[2:]), event,
+                   tensors)
+  return stage
 
 
 def _chunk_substitution(eval_config, truth, climatology, by_init: bool):
@@ -865,7 +926,24 @@ def evaluate_chunks(
     # fetched ahead; afterwards enough to fill a window
     depth = lambda: max(prefetch, (batch_chunks - 1)
                         if prefetch and not auto_batch else 0)
-    for forecast, truth_chunk in _prefetched(chunks, lo, hi, depth):
+    stage = None
+    if prefetch and os.environ.get('WB2HIP_STAGE_ON_FETCH', '1') != '0':
+      import torch
+      if torch.cuda.is_available() and (
+          device is None or torch.device(device).type == 'cuda'):
+        from weatherbench2_amd import engine
+        stage = _stage_on_device(device if device is not None
+                                 else engine.require_gpu())
+    for item in _prefetched(chunks, lo, hi, depth, stage):
+      if isinstance(item, _Staged):
+        # the pass over this chunk is ordered after its copies (no host wait)
+        import torch
+        cur = torch.cuda.current_stream()
+        cur.wait_event(item.event)
+        for x in item.tensors:  # allocated on the copy stream, read on this one
+          x.record_stream(cur)
+        item = item.pair
+      forecast, truth_chunk = item[0], item[1]
       forecast = xl.as_dataset(forecast)
       if substitute is not None:
         forecast = xl.as_dataset(substitute(forecast, truth_chunk))

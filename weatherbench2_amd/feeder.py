@@ -7,8 +7,9 @@ through page-locked staging buffers on a dedicated copy stream, so that the
 transfer of chunk i + 1 overlaps the fused pass over chunk i:
 
   * `upload(array, device)`: one pageable NumPy array -> device tensor, moved in
-    slices through a two-slot pinned ring (the host memcpy of slice k + 1
-    overlaps the DMA of slice k); used by engine.as_device_tensor.
+    slices through a pinned ring by a pool of copy threads (csrc/staging.cpp:
+    the staging copy of slice k + 1 overlaps the DMA of slice k; one thread's
+    memcpy is a sixth of the link); used by engine.as_device_tensor.
   * `ChunkFeeder`: a depth-N ring of device buffers for a stream of equally
     shaped chunks; `submit()` starts the copy of the next chunk on the copy
     stream, `acquire()` makes the compute stream wait for it (no host sync).
@@ -25,23 +26,44 @@ import typing as t
 import numpy as np
 import torch
 
-_SLICE_BYTES = 64 << 20
+# the pinned ring of an uploader: slices small enough that the first DMA starts
+# early, enough of them that the copy pool never waits for a free slot
+_SLICE_BYTES = 32 << 20
+_RING_SLOTS = 4
+
+
+def copy_threads() -> int:
+  """Threads of the staging copy (WB2HIP_COPY_THREADS; default: an eighth of
+  the logical cores, between 4 and 16 -- one thread's memcpy moves ~10 GB/s,
+  the link ~60)."""
+  import os
+  env = os.environ.get('WB2HIP_COPY_THREADS')
+  if env:
+    return max(1, int(env))
+  return int(min(16, max(4, (os.cpu_count() or 8) // 8)))
 
 
 class _Staging(threading.local):
-  """Per-thread pinned ring (two slots) and copy stream per device."""
+  """Per-thread uploader (pinned ring + copy pool in libwb2hip.so,
+  csrc/staging.cpp) and copy stream per device."""
 
   def __init__(self):
     self.rings: dict = {}
 
   def get(self, device: torch.device):
+    import ctypes
+    from weatherbench2_amd import _lib
     key = (device.type, device.index)
     ring = self.rings.get(key)
     if ring is None:
-      slots = [torch.empty(_SLICE_BYTES, dtype=torch.uint8).pin_memory()
-               for _ in range(2)]
-      ring = {'slots': slots, 'events': [None, None],
-              'stream': torch.cuda.Stream(device=device), 'next': 0}
+      lib = _lib.load()
+      handle = ctypes.c_void_p()
+      with torch.cuda.device(device):
+        _lib.check(lib.wb2_uploader_create(copy_threads(), _SLICE_BYTES,
+                                           _RING_SLOTS, ctypes.byref(handle)),
+                   'wb2_uploader_create')
+      ring = {'uploader': handle, 'lib': lib,
+              'stream': torch.cuda.Stream(device=device)}
       self.rings[key] = ring
     return ring
 
@@ -53,43 +75,40 @@ def copy_stream(device: torch.device) -> torch.cuda.Stream:
   return _STAGING.get(device)['stream']
 
 
-def upload(array: np.ndarray, device: torch.device) -> torch.Tensor:
-  """Contiguous NumPy array -> new device tensor of the same shape / dtype.
+def upload(array: np.ndarray, device: torch.device,
+           wait: bool = True) -> torch.Tensor:
+  """Contiguous (pageable) NumPy array -> new device tensor of the same shape /
+  dtype through the calling thread's uploader: the copy pool stages slice
+  k + 1 into the pinned ring while the DMA of slice k runs on the copy stream
+  (wb2_uploader_upload; ctypes releases the GIL for the whole call).
 
-  Asynchronous with respect to the host after the last slice has been staged;
-  the caller's current stream waits for the copy stream before it may read the
-  result (stream-ordered, no device synchronisation)."""
+  Returns once the last slice has been staged (the source may be reused); the
+  caller's current stream waits for the copy stream before it may read the
+  result (stream-ordered, no device synchronisation) unless `wait` is False --
+  then the caller orders the read itself (`copy_stream(device)`)."""
+  from weatherbench2_amd import _lib
   src = np.ascontiguousarray(array)
-  dst = torch.empty(src.shape, dtype=torch.from_numpy(np.empty(0, src.dtype)).dtype,
-                    device=device)
+  ring = _STAGING.get(device)
+  stream = ring['stream']
+  cur = torch.cuda.current_stream(device)
+  # The destination belongs to the COPY stream's pool: a recycled block is safe
+  # to overwrite in copy-stream order, so the copy never waits for kernels
+  # queued on the compute stream (the copy of chunk i + 1 overlaps the pass
+  # over chunk i); the consumer's use is recorded so that the block is not
+  # handed out again before that stream is done with it.
+  with torch.cuda.stream(stream):
+    dst = torch.empty(src.shape,
+                      dtype=torch.from_numpy(np.empty(0, src.dtype)).dtype,
+                      device=device)
+  dst.record_stream(cur)
   nbytes = src.nbytes
   if nbytes == 0:
     return dst
-  ring = _STAGING.get(device)
-  flat_src = src.reshape(-1).view(np.uint8)
-  flat_dst = dst.reshape(-1).view(torch.uint8)
-  stream = ring['stream']
-  # the destination was allocated on the current stream: the copy stream must
-  # not write before that allocation is safe to use
-  stream.wait_stream(torch.cuda.current_stream(device))
-  dst.record_stream(stream)
-  off = 0
-  while off < nbytes:
-    n = min(_SLICE_BYTES, nbytes - off)
-    i = ring['next']
-    ring['next'] = 1 - i
-    ev = ring['events'][i]
-    if ev is not None:
-      ev.synchronize()  # the DMA that last read this slot has finished
-    slot = ring['slots'][i]
-    np.copyto(slot.numpy()[:n], flat_src[off:off + n])
-    with torch.cuda.stream(stream):
-      flat_dst[off:off + n].copy_(slot[:n], non_blocking=True)
-      ev = torch.cuda.Event()
-      ev.record(stream)
-    ring['events'][i] = ev
-    off += n
-  torch.cuda.current_stream(device).wait_stream(stream)
+  _lib.check(ring['lib'].wb2_uploader_upload(
+      ring['uploader'], dst.data_ptr(), src.ctypes.data, nbytes,
+      stream.cuda_stream), 'wb2_uploader_upload')
+  if wait:
+    cur.wait_stream(stream)
   return dst
 
 
@@ -137,7 +156,10 @@ class ChunkFeeder:
                                      dtype=self.buffers[i].dtype).pin_memory()
       if self.ready[i] is not None:
         self.ready[i].synchronize()  # the previous DMA out of this buffer
-      np.copyto(self.pinned[i].numpy(), arr.reshape(self.pinned[i].shape))
+      from weatherbench2_amd import _lib
+      _lib.check(_lib.load().wb2_host_copy(
+          self.pinned[i].data_ptr(), arr.ctypes.data, arr.nbytes,
+          copy_threads()), 'wb2_host_copy')
       src = self.pinned[i]
     with torch.cuda.stream(self.stream):
       self.buffers[i].copy_(src.reshape(self.buffers[i].shape),
