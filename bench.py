@@ -1437,7 +1437,9 @@ def live_traffic(units, pool, rows_per_chunk, workload='all') -> dict:
         timeout=500)
     if res.returncode != 0:
       return {'error': (res.stderr or res.stdout).strip()[-300:]}
-    return json.loads(res.stdout.strip().splitlines()[-1])
+    got = json.loads(res.stdout.strip().splitlines()[-1])
+    # `--workload deterministic` prints K1's object flat
+    return {'deterministic': got} if workload == 'deterministic' else got
   except Exception as e:  # rocprofv3 missing, timeout, ...
     return {'error': f'{type(e).__name__}: {e}'}
 

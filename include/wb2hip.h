@@ -648,6 +648,12 @@ int wb2_host_copy(void* dst, const void* src, int64_t nbytes,
 int wb2_uploader_destroy(void* uploader);
 int wb2_uploader_upload(void* uploader, void* dst, const void* src,
                         int64_t nbytes, void* stream);
+/* The same for the n buffers of one chunk (its variables) in ONE call:
+ * dst[i] (DEV) <- src[i] (HOST), nbytes[i] each; the arrays themselves are
+ * HOST.  A Python caller holds no interpreter lock for the whole chunk. */
+int wb2_uploader_upload_many(void* uploader, int32_t n, void* const* dst,
+                             const void* const* src, const int64_t* nbytes,
+                             void* stream);
 
 /* RCCL communicator for callers that do not use torch.distributed: rank 0 makes
  * a 128-byte id (wb2_comm_unique_id), distributes it by any means (file, MPI,

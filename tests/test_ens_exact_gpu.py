@@ -18,6 +18,10 @@ from weatherbench2_amd import build as _build
 
 # every member count with a kernel of its own (WB2_SORT3_SIZES)
 EXACT = tuple(m for m, _ in _build.exact_sizes())
+# counts WITHOUT one: run inside the next larger program with the dead slots
+# at +inf (ens_point_hosted; without skipna) -- below, between and next to the
+# instantiated sizes, incl. the smallest (2, 3) and the last before 100
+HOSTED = (2, 3, 6, 7, 9, 13, 24, 33, 44, 47, 49, 63, 77, 99)
 N_LAT, N_LON = 721, 1440
 LAT = np.linspace(-90, 90, N_LAT)
 LON = np.linspace(0, 360, N_LON, endpoint=False)
@@ -45,7 +49,7 @@ def _oracle_fields(f, t, skipna):
 
 
 @pytest.mark.parametrize('skipna', [False, True])
-@pytest.mark.parametrize('m', EXACT)
+@pytest.mark.parametrize('m', EXACT + HOSTED)
 def test_exact_member_counts_match_oracle(dev, m, skipna):
   """Small grid (3 column tiles per row), ties, an infinite member, a NaN
   patch: with skipna some waves take the fast path and some the general one;
@@ -138,7 +142,7 @@ def test_skipna_fast_path_gives_the_general_paths_bits(dev, m):
   assert np.isfinite(a[:, :, :100]).all()
 
 
-@pytest.mark.parametrize('m', EXACT)
+@pytest.mark.parametrize('m', EXACT + (33, 44, 47, 63, 77))
 def test_exact_member_counts_full_size(dev, m):
   """One 721 x 1440 slab per member count at the benched geometry (5-row
   chunks, the 13 predefined regions): all eight metrics vs the oracle."""
@@ -173,3 +177,80 @@ def test_exact_member_counts_full_size(dev, m):
     for name, w in want.items():
       helpers.assert_close(got[idx[name], ri, 0], w, rtol=2e-6, atol=1e-7,
                            err_msg=f'M={m} {name}/{rname}')
+
+
+@pytest.mark.parametrize('m', [3, 7, 21, 44, 77, 100])
+def test_hosted_counts_give_the_padded_networks_values(dev, m, monkeypatch):
+  """The hosted program and the padded power-of-two network (WB2HIP_ENS_HOSTED
+  is read once per process, so the second form comes from a GATHERED launch
+  with the variable unset vs. a child process) do the same operations on the
+  live members in the same order: pointwise maps agree bit for bit, strided and
+  gathered members alike -- including an infinite member, ties and a NaN
+  member (every value NaN there)."""
+  import subprocess
+  import sys
+  import torch
+  from weatherbench2_amd import engine, plan as plan_lib
+  n_lat, n_lon = 9, 200
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  rs = np.random.RandomState(7 * m)
+  ens = rs.normal(size=(m, 2, n_lat, n_lon)).astype(np.float32)
+  ens[:, 0, :, 10:30] = np.round(ens[:, 0, :, 10:30] * 2) / 2
+  ens[min(1, m - 1), 0, 4, 150] = np.inf
+  ens[0, 1, 3, 77] = np.nan
+  ens[m - 1, 1, 6, 12] = np.nan
+  truth = rs.normal(size=(2, n_lat, n_lon)).astype(np.float32)
+  truth[1, 2, 2] = np.nan
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, None, dev,
+                           rows_per_chunk=plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+  d_ens = torch.as_tensor(ens, device=dev)
+  d_truth = torch.as_tensor(truth, device=dev)
+  slab = n_lat * n_lon
+
+  def run(gather):
+    maps = torch.empty((6, 2, slab), dtype=torch.float64, device=dev)
+    ptrs = None
+    if gather:
+      index = np.arange(m)[None, :] * 2 + np.arange(2)[:, None]  # [outer, m]
+      ptrs = torch.as_tensor(engine.gather_pointers(d_ens, index, slab),
+                             device=dev)
+    engine.ensemble_reduce(pl, d_ens, 2 * slab, m, None, d_truth, None, 2,
+                           False, maps=maps, member_ptrs=ptrs)
+    return maps.cpu().numpy()
+  strided, gathered = run(False), run(True)
+  if m in EXACT:
+    # a strided exact size has a kernel of its own (compile-time divisions,
+    # 2 / (M (M - 1)) as one constant): equal to float32 rounding
+    helpers.assert_close(strided, gathered, rtol=2e-6, atol=1e-7)
+  else:
+    assert np.array_equal(strided, gathered, equal_nan=True)
+  for maps in (strided, gathered):
+    assert np.isnan(maps[:, 1, 3 * n_lon + 77]).all()
+    assert np.isnan(maps[:, 1, 6 * n_lon + 12]).all()
+    assert np.isfinite(maps[:, 0, :100]).all()
+  # the padded runtime network in a process of its own
+  np.save('/tmp/wb2_hosted_ens.npy', ens)
+  np.save('/tmp/wb2_hosted_truth.npy', truth)
+  code = f'''
+import numpy as np, torch
+from weatherbench2_amd import engine, plan as plan_lib
+ens = np.load('/tmp/wb2_hosted_ens.npy'); truth = np.load('/tmp/wb2_hosted_truth.npy')
+dev = torch.device('cuda', 0)
+lat = np.linspace(-90, 90, {n_lat}); lon = np.linspace(0, 360, {n_lon}, endpoint=False)
+pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, None, dev, rows_per_chunk=plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+maps = torch.empty((6, 2, {slab}), dtype=torch.float64, device=dev)
+engine.ensemble_reduce(pl, torch.as_tensor(ens, device=dev), 2 * {slab}, {m}, None, torch.as_tensor(truth, device=dev), None, 2, False, maps=maps)
+np.save('/tmp/wb2_hosted_padded.npy', maps.cpu().numpy())
+'''
+  import os
+  env = dict(os.environ, WB2HIP_ENS_HOSTED='0')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  res = subprocess.run([sys.executable, '-c', code], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stderr[-2000:]
+  padded = np.load('/tmp/wb2_hosted_padded.npy')
+  if m in EXACT:  # (the child's strided launch took the exact kernel too)
+    assert np.array_equal(strided, padded, equal_nan=True)
+  else:
+    assert np.array_equal(gathered, padded, equal_nan=True)

@@ -21,6 +21,14 @@ def test_host_copy_pool_copies_every_byte():
                                threads) == 0
       assert np.array_equal(dst[:n], src[:n])
       assert not dst[n:].any()
+  # unaligned destinations and sources (the streaming stores align themselves)
+  for d_off, s_off in ((3, 0), (0, 5), (17, 9), (31, 33)):
+    dst = np.zeros(src.size + 64, dtype=np.uint8)
+    n = (5 << 20) + 11
+    assert lib.wb2_host_copy(dst.ctypes.data + d_off, src.ctypes.data + s_off,
+                             n, 4) == 0
+    assert np.array_equal(dst[d_off:d_off + n], src[s_off:s_off + n])
+    assert not dst[:d_off].any() and not dst[d_off + n:].any()
   assert lib.wb2_host_copy(None, src.ctypes.data, 16, 2) != 0
   assert lib.wb2_host_copy(src.ctypes.data, src.ctypes.data, -1, 2) != 0
   assert lib.wb2_host_copy(src.ctypes.data, src.ctypes.data, 16, 0) != 0
@@ -54,6 +62,10 @@ def test_upload_round_trip():
     assert np.array_equal(got.cpu().numpy(), a)
   a = rs.standard_normal((3, 5, 7))
   assert np.array_equal(feeder.upload(a, dev).cpu().numpy(), a)
+  many = [rs.standard_normal(n, dtype=np.float32)
+          for n in (7, 0, 2_000_000, 9_000_001)] + [rs.standard_normal((4, 9))]
+  for a, d in zip(many, feeder.upload_many(many, dev)):
+    assert tuple(d.shape) == a.shape and np.array_equal(d.cpu().numpy(), a)
   # many uploads back to back: the ring is reused, destinations stay intact
   arrays = [rs.standard_normal(3_000_000, dtype=np.float32) for _ in range(6)]
   devs = [feeder.upload(a, dev) for a in arrays]

@@ -5,6 +5,7 @@
 compiles SOURCE with the extra flags and links it with the default objects of
 every other translation unit into build/variants/libwb2hip_NAME.so (git-ignored,
 travels with gpurun).  Select it with WB2HIP_LIB=<path> (see _lib.lib_path).
+SOURCE = ensemble_exact.hip recompiles every per-member-count unit of K3.
 """
 import os
 import subprocess
@@ -24,15 +25,21 @@ def main():
   os.makedirs(var_dir, exist_ok=True)
   flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
            '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + b.CSRC]
-  obj = os.path.join(var_dir, f'{name}.o')
-  subprocess.run([b._hipcc()] + flags + extra +
-                 ['-c', os.path.join(b.CSRC, src), '-o', obj], check=True)
-  objs = [obj if (os.path.basename(s) == src and not defines) else
-          os.path.join(obj_dir, name)
-          for s, name, defines in b.translation_units()]
+  import concurrent.futures
+  jobs, objs = [], []
+  for s, oname, defines in b.translation_units():
+    if os.path.basename(s) == src:
+      obj = os.path.join(var_dir, f'{name}_{oname}')
+      jobs.append([b._hipcc()] + flags + extra + defines +
+                  ['-c', s, '-o', obj])
+      objs.append(obj)
+    else:
+      objs.append(os.path.join(obj_dir, oname))
+  with concurrent.futures.ThreadPoolExecutor(max_workers=8) as pool:
+    list(pool.map(lambda cmd: subprocess.run(cmd, check=True), jobs))
   out = os.path.join(var_dir, f'libwb2hip_{name}.so')
   subprocess.run([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC',
-                  '-o', out] + objs + ['-L/opt/rocm/lib', '-lhipfft', '-ldl'],
+                  '-o', out] + objs + ['-L/opt/rocm/lib', '-lhipfft', '-ldl', '-pthread'],
                  check=True)
   print(out)
 

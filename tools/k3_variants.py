@@ -53,8 +53,13 @@ def variants(dev, reps: int = 3, launches: int = 30, only=None) -> dict:
            ('skipna_nan_patches', 'slice13', 50, torch.float32, True, 0.125)]
   specs += [(f'members{m}', 'slice13', m, torch.float32, False, 0.0)
             for m in exact_sizes]
+  # member counts without a program of their own: hosted by the next larger
+  # one (ens_point_hosted); 44 with skipna stays on the padded runtime network
+  specs += [(f'members{m}_hosted', 'slice13', m, torch.float32, False, 0.0)
+            for m in (7, 13, 24, 33, 44, 47, 63, 77)]
   specs += [('members51_skipna', 'slice13', 51, torch.float32, True, 0.0),
-            ('members44_runtime', 'slice13', 44, torch.float32, False, 0.0),
+            ('members44_skipna_runtime', 'slice13', 44, torch.float32, True,
+             0.0),
             ('f64_members50', 'slice13', 50, torch.float64, False, 0.0)]
   if only:
     specs = [s for s in specs if s[0] in only]
@@ -114,8 +119,16 @@ def variants(dev, reps: int = 3, launches: int = 30, only=None) -> dict:
 
 
 def main():
+  import argparse
   import torch
-  print(json.dumps(variants(torch.device('cuda', 0))))
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--only', default='',
+                  help='comma-separated variant names (default: all)')
+  ap.add_argument('--reps', type=int, default=3)
+  args = ap.parse_args()
+  only = [s for s in args.only.split(',') if s] or None
+  print(json.dumps(variants(torch.device('cuda', 0), reps=args.reps,
+                            only=only)))
 
 
 if __name__ == '__main__':

@@ -247,8 +247,10 @@ def measure_host_fed(chunks, cfg, n_chunks: int = 48, pool: int = 6,
   legs = {}
   for name, kwargs in (('default_window', {}), ('chunk_by_chunk',
                                                 {'batch_chunks': 1})):
-    evaluation.evaluate_chunks(fed[:8], cfg, False, prefetch=prefetch,
-                               **kwargs)  # uploader, ring, plans
+    # uploader, ring, plans -- and the allocator: a window in flight plus the
+    # next one being staged hold ~2 x 24 chunks of device memory, which the
+    # first pass over the list has to hipMalloc
+    evaluation.evaluate_chunks(fed, cfg, False, prefetch=prefetch, **kwargs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evaluation.evaluate_chunks(fed, cfg, False, prefetch=prefetch, **kwargs)

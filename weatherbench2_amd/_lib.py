@@ -126,6 +126,9 @@ _SIGNATURES = {
     'wb2_uploader_destroy': (_int, [_vp]),
     'wb2_host_copy': (_int, [_vp, _vp, _i64, _i32]),
     'wb2_uploader_upload': (_int, [_vp, _vp, _vp, _i64, _vp]),
+    'wb2_uploader_upload_many': (_int, [_vp, _i32, _c.POINTER(_vp),
+                                        _c.POINTER(_vp), _c.POINTER(_i64),
+                                        _vp]),
     'wb2_comm_unique_id': (_int, [_vp]),
     'wb2_comm_init_rank': (_int, [_vp, _i32, _i32, _c.POINTER(_vp)]),
     'wb2_comm_destroy': (_int, [_vp]),

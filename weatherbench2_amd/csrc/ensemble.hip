@@ -262,6 +262,22 @@ int launch_ens_npad(const EnsParams& p, bool skipna, bool wf,
       }
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    // any other float32 member count up to the largest program (and gathered
+    // members of any count): hosted by the smallest exact program that holds
+    // it -- the dead slots at +inf -- instead of a padded power-of-two network
+    // (WB2HIP_ENS_HOSTED=0: the padded networks, for A/B runs)
+    static const bool hosted = [] {
+      const char* v = getenv("WB2HIP_ENS_HOSTED");
+      return !(v && v[0] == '0');
+    }();
+    if (hosted && !skipna && m >= 2) {
+#define WB2_ENS_HOST_CASE(M, NPAD) \
+  if (m <= M) return launch_ens_hosted_f32_##M(p, wf, stream);
+      WB2_ENS_EXACT_SIZES(WB2_ENS_HOST_CASE)
+#undef WB2_ENS_HOST_CASE
+    }
+  }
   if (m <= 4) return launch_ens<T, 4, 0>(p, skipna, wf, stream);
   if (m <= 16) return launch_ens<T, 16, 0>(p, skipna, wf, stream);
   if (m <= 32) return launch_ens<T, 32, 0>(p, skipna, wf, stream);

@@ -51,6 +51,14 @@ struct EnsParams {
                                hipStream_t stream);
 WB2_ENS_EXACT_SIZES(WB2_ENS_DECLARE)
 #undef WB2_ENS_DECLARE
+// The same programs as HOSTS of smaller ensembles: a runtime member count
+// m <= M runs in the M-member program with the slots m..M-1 held at +inf (they
+// sort behind every live member and carry no rank weight); statistics over the
+// first m members.  float32, no NaN skipping; strided or gathered members.
+#define WB2_ENS_DECLARE_HOSTED(M, NPAD)                             \
+  int launch_ens_hosted_f32_##M(const EnsParams& p, bool wf, hipStream_t stream);
+WB2_ENS_EXACT_SIZES(WB2_ENS_DECLARE_HOSTED)
+#undef WB2_ENS_DECLARE_HOSTED
 
 namespace {
 
@@ -614,6 +622,253 @@ __device__ __forceinline__ void ens_point_runtime(T (&x)[NPAD], const T t,
 }
 
 
+// Runtime member count M <= MS inside the exact MS-member sorting program
+// (the 2- / 3-sorter programs of sort3_networks.inc): what ens_point_runtime
+// does with a padded Batcher network -- the statistics over the first M members
+// in groups of four behind wave-uniform branches, the dead slots (+inf, set by
+// the caller) sorted to the end -- at the cost of the host program, not of the
+// next power of two (44 members: the 51-member program's 585 instructions
+// instead of the 64-network's 1 086).  Same operations in the same order as
+// ens_point's generic path for the M live members.
+#ifndef WB2_ENS_HOSTED_FLAGS
+// 1: ens_point_hosted without control flow (per-member 0 / 1 flags in SGPRs and
+// legacy multiplies); 0: the statistics in groups of four behind wave-uniform
+// branches, like ens_point_runtime
+#define WB2_ENS_HOSTED_FLAGS 1
+#endif
+
+#if WB2_ENS_HOSTED_FLAGS
+// v_max_f32 / v_mul_legacy_f32 with the wave-uniform operand read straight
+// from an SGPR (src0 of a VOP2): no v_mov, no lane mask per member.  (The
+// operand goes in as an int: hipcc gives a FLOAT "s" operand a VGPR -- and
+// builds it with a v_cndmask under a 64-bit lane mask, one SGPR pair per
+// member.)
+__device__ __forceinline__ float vmax_s(float x, float uniform) {
+  float r;
+  asm("v_max_f32 %0, %1, %2"
+      : "=v"(r)
+      : "s"(__builtin_bit_cast(int, uniform)), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float times_sflag(float v, float uniform_flag) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2"
+      : "=v"(r)
+      : "s"(__builtin_bit_cast(int, uniform_flag)), "v"(v));
+  return r;
+}
+
+// Straight-line form.  The caller hands over the RAW loads: a dead slot holds
+// member 0 again, so "any NaN among all MS slots" is "any NaN among the live
+// members" and needs no member count.  Then, per slot m, one scalar select
+// makes f_m = (m < M) ? 1 : 0 (an SGPR) and
+//   dead slots -> +inf      v_max_f32 x, (m < M ? -inf : +inf)    (no lane mask)
+//   live-only sums          v_mul_legacy_f32 v, f_m               (0 * inf = 0)
+// so the +inf padding drops out of every sum and the program never branches:
+// hipcc allocates registers for ONE basic block, as for the exact kernels.
+// The per-member scalars are made where they are used: every group of eight
+// members compares against a copy of M of its own (an empty asm the optimiser
+// cannot look through) between two scheduling fences -- left alone hipcc does
+// every select of a member next to the first compare of that member (the one
+// of its load address) and spills ~230 scalars per row through VGPR lanes.
+template <int NPAD, int MS>
+__device__ __forceinline__ void ens_point_hosted(float (&x)[NPAD], const float t,
+                                                 const int M,
+                                                 double (&out)[6]) {
+  static_assert(Sort3<MS>::has, "no sorting program for this member count");
+  using T = float;
+  constexpr int G = 8;
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  const T inf = std::numeric_limits<T>::infinity();
+  bool bad = false;
+  T sum = 0, sk = 0, sq = 0;
+#pragma unroll
+  for (int g = 0; g < MS; g += G) {
+    int Mg = M;
+    asm volatile("" : "+s"(Mg));
+#pragma unroll
+    for (int m = g; m < g + G && m < MS; ++m) {
+      // the RAW pair first (dead slots repeat member 0: no NaN of their own)
+      if (m % 2 == 0)
+        bad = bad || (m + 1 < MS ? __builtin_isunordered(x[m], x[m + 1])
+                                 : is_nan(x[m]));
+      const T f = m < Mg ? (T)1 : (T)0;  // wave-uniform: s_cselect
+      // dead slot -> +inf (a live NaN has been seen by `bad`)
+      const T xm = vmax_s(x[m], m < Mg ? -inf : inf);
+      sum += times_sflag(xm, f);
+      sk += times_sflag(abs_of(t - xm), f);
+      if (m % 2 == 1 || m + 1 == MS) {
+        x[m] = xm;
+      } else {
+        // (the pair's NaN test reads the raw x[m + 1]: the odd member's fill
+        // happens in the next iteration, the even one's may be stored now)
+        x[m] = xm;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const T mean = sum / (T)M;
+#pragma unroll
+  for (int g = 0; g < MS; g += G) {
+    int Mg = M;
+    asm volatile("" : "+s"(Mg));
+#pragma unroll
+    for (int m = g; m < g + G && m < MS; ++m) {
+      const T f = m < Mg ? (T)1 : (T)0;
+      const T d = x[m] - mean;
+      sq += times_sflag(d * d, f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    int pinned = bad ? 1 : 0;
+    asm volatile("" : "+v"(sq), "+v"(sum), "+v"(sk), "+v"(pinned));
+    bad = pinned != 0;
+  }
+  const T var = sq / (T)(M - 1);
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  const T deb = mse - var / (T)M;
+  const T skill = sk / (T)M;
+  double spread = 0.0;
+  if (M >= 2) {
+    Sort3<MS>::template run<NPAD>(x);  // rank r: register Sort3<MS>::order[r]
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < MS; g += G) {
+      int Mg = M;
+      asm volatile("" : "+s"(Mg));
+      const int c0 = -Mg - 1;  // weight of rank r (0-based): 2 (r + 1) - M - 1
+#pragma unroll
+      for (int m = g; m < g + G && m < MS; ++m) {
+        const T f = m < Mg ? (T)1 : (T)0;
+        s = __builtin_fma((double)(2 * (m + 1) + c0),
+                          (double)times_sflag(x[Sort3<MS>::order[m]], f), s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    spread = 2.0 * (s / (double)M) / (double)(M - 1);
+  }
+  // a NaN member poisons the mean and with it every value (the fill above
+  // turned it into -inf: nothing computed from it is looked at)
+  out[0] = bad ? (double)nan : (double)skill;
+  out[1] = bad ? (double)nan : spread;
+  out[2] = bad ? (double)nan : (double)mse;
+  out[3] = bad ? (double)nan : (double)var;
+  out[4] = bad ? (double)nan : (double)(sd * sd);
+  out[5] = bad ? (double)nan : (double)deb;
+}
+#else
+template <int NPAD, int MS>
+__device__ __forceinline__ void ens_point_hosted(float (&x)[NPAD], const float t,
+                                                 const int M,
+                                                 double (&out)[6]) {
+  static_assert(Sort3<MS>::has, "no sorting program for this member count");
+  using T = float;
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  T sum = 0, sk = 0, sq = 0;
+  bool bad = false;
+  constexpr int G = 4;
+#pragma unroll
+  for (int g = 0; g < MS; g += G) {
+    if (g < M) {  // wave-uniform
+      if (g + G <= M && g + G <= MS) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          sum += x[g + u];
+          sk += abs_of(t - x[g + u]);
+        }
+        bad = bad || __builtin_isunordered(x[g], x[g + 1]) ||
+              __builtin_isunordered(x[g + 2], x[g + 3]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (g + u < MS) {
+            if (g + u < M) {
+              sum += x[g + u];
+              sk += abs_of(t - x[g + u]);
+              bad = bad || is_nan(x[g + u]);
+            }
+          }
+        }
+      }
+    }
+  }
+  const T mean = sum / (T)M;
+#pragma unroll
+  for (int g = 0; g < MS; g += G) {
+    if (g < M) {
+      if (g + G <= M && g + G <= MS) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const T d = x[g + u] - mean;
+          sq += d * d;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (g + u < MS) {
+            if (g + u < M) {
+              const T d = x[g + u] - mean;
+              sq += d * d;
+            }
+          }
+        }
+      }
+    }
+  }
+  // everything that reads the members in MEMBER order is finished before the
+  // sort starts (or the unsorted ensemble stays alive beside the sorted one)
+  {
+    int pinned = bad ? 1 : 0;
+    asm volatile("" : "+v"(sq), "+v"(sum), "+v"(sk), "+v"(pinned));
+    bad = pinned != 0;
+  }
+  const T var = sq / (T)(M - 1);
+  const T sd = sqrt_of(var);
+  const T err = t - mean;
+  const T mse = err * err;
+  const T deb = mse - var / (T)M;
+  const T skill = sk / (T)M;
+  double spread = 0.0;
+  if (M >= 2) {
+    Sort3<MS>::template run<NPAD>(x);  // rank r: register Sort3<MS>::order[r]
+    double s = 0.0;
+    const int c0 = -M - 1;  // weight of rank r (0-based): 2 (r + 1) - M - 1
+#pragma unroll
+    for (int g = 0; g < MS; g += G) {
+      if (g < M) {
+        if (g + G <= M && g + G <= MS) {
+#pragma unroll
+          for (int u = 0; u < G; ++u)
+            s = __builtin_fma((double)(2 * (g + u + 1) + c0),
+                              (double)x[Sort3<MS>::order[g + u]], s);
+        } else {
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            if (g + u < MS) {
+              if (g + u < M)
+                s = __builtin_fma((double)(2 * (g + u + 1) + c0),
+                                  (double)x[Sort3<MS>::order[g + u]], s);
+            }
+          }
+        }
+      }
+    }
+    spread = 2.0 * (s / (double)M) / (double)(M - 1);
+    if (bad) spread = (double)nan;  // a NaN member poisons the mean
+  }
+  out[0] = (double)skill;
+  out[1] = spread;
+  out[2] = (double)mse;
+  out[3] = (double)var;
+  out[4] = (double)(sd * sd);
+  out[5] = (double)deb;
+}
+#endif  // WB2_ENS_HOSTED_FLAGS
+
+
 // Ensembles too large for the register sort (M > 128 float32 / 64 float64):
 // the same six values from three streaming passes over the members (cache
 // resident after the first) -- no sort at all.  The rank-weighted sum is
@@ -729,9 +984,21 @@ __device__ __forceinline__ void ens_point_large(
 #endif
 
 
-template <typename T, int NPAD, int MS, bool SKIPNA, bool WF>
+// HOSTED: the member count is p.n_member <= MS at run time inside the exact
+// MS-member program (ens_point_hosted); RT = the member count is a run-time
+// value (members addressed one after the other, strided or gathered).
+// GATHER (HOSTED only; the MS == 0 kernels decide at run time): the members are
+// addressed through p.member_ptr -- a compile-time flag, because a run-time
+// branch per member turns the member bases into per-lane values (two
+// v_cndmask + a branch per member).
+template <typename T, int NPAD, int MS, bool SKIPNA, bool WF,
+          bool HOSTED = false, bool GATHER = false>
 __global__ void __launch_bounds__(256)
     ens_partials_kernel(const EnsParams p) {
+  static_assert(!HOSTED || (MS > 0 && !SKIPNA && sizeof(T) == 4),
+                "hosted member counts: float32, no NaN skipping");
+  static_assert(HOSTED || !GATHER, "GATHER is a flag of the hosted kernels");
+  constexpr bool RT = MS == 0 || HOSTED;
   constexpr int K = SKIPNA ? 10 : 6, NWF = WF ? 2 : 1;
   constexpr int NM = MS > 0 ? MS : NPAD;
   const int lane = threadIdx.x & (kWave - 1);
@@ -758,7 +1025,7 @@ __global__ void __launch_bounds__(256)
   const int col0 = tile * kWave + lane;
   const bool active = tile < p.n_ctile && col0 < p.n_col;
   if (nrow <= 0 || tile >= p.n_ctile || !o_ok) return;
-  const int M = MS > 0 ? MS : p.n_member;
+  const int M = RT ? p.n_member : MS;
 
   double acc[NWF][1][K];
 #pragma unroll
@@ -773,10 +1040,11 @@ __global__ void __launch_bounds__(256)
   // each be a dependent round trip (measured: 6 x slower).  Loaded by EVERY
   // lane (in a row-end tile lane m may own no column; the row loop below runs
   // in wave-uniform control flow for the same reason).
-  constexpr int NMP = (MS == 0 && NPAD > 0) ? (NPAD + kWave - 1) / kWave : 1;
+  constexpr bool MAY_GATHER = HOSTED ? GATHER : (MS == 0 && NPAD > 0);
+  constexpr int NMP = MAY_GATHER ? (NPAD + kWave - 1) / kWave : 1;
   unsigned mp_lo[NMP], mp_hi[NMP];
-  const bool gathered = MS == 0 && NPAD > 0 && p.member_ptr != nullptr;
-  if constexpr (MS == 0 && NPAD > 0) {
+  const bool gathered = HOSTED ? GATHER : (MAY_GATHER && p.member_ptr != nullptr);
+  if constexpr (MAY_GATHER) {
 #pragma unroll
     for (int j = 0; j < NMP; ++j) {
       mp_lo[j] = mp_hi[j] = 0;
@@ -837,44 +1105,76 @@ __global__ void __launch_bounds__(256)
         int Mr = M;  // runtime M, opaque per row: the per-member `m < M` lane
                      // masks are recomputed (scalar compares) instead of being
                      // kept in SGPR pairs across the whole row loop
-        if constexpr (MS == 0) {
+        if constexpr (RT) {
           asm volatile("" : "+s"(Mr));
           asm volatile("" : "+s"(stride_r));
+          if constexpr (MAY_GATHER) {
 #pragma unroll
-          for (int j = 0; j < NMP; ++j)
-            asm volatile("" : "+v"(mp_lo[j]), "+v"(mp_hi[j]));
+            for (int j = 0; j < NMP; ++j)
+              asm volatile("" : "+v"(mp_lo[j]), "+v"(mp_hi[j]));
+          }
         }
         const T* mb = xrow;
+        // hosted, strided: the row base as two SGPRs for certain (readfirstlane
+        // once per row), the member bases as a scalar add chain beside it
+        unsigned long long hb0 = 0, hcur = 0, hstep = 0;
+        if constexpr (HOSTED && !GATHER) {
+          const unsigned long long a = reinterpret_cast<unsigned long long>(xrow);
+          const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+          const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+          hb0 = hcur = ((unsigned long long)hi << 32) | lo;
+          hstep = (unsigned long long)stride_r * sizeof(T);
+        }
 #pragma unroll
         for (int m = 0; m < NPAD; ++m) {
           if (m < NM) {
             const T* mrow;
-            if constexpr (MS > 0) {
+            if constexpr (!RT) {
               mrow = xrow + m * p.member_stride;
             } else {
               // slots >= M read member 0 again (cache hit; replaced by +inf or
               // ignored); the base itself advances unconditionally -- a select
               // inside the chain made every load wait for 5 dependent scalar
               // instructions per member before it
-              mrow = m < Mr ? mb : xrow;
-              if (gathered) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(
-                    (int)mp_lo[m / kWave], m % kWave);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane(
-                    (int)mp_hi[m / kWave], m % kWave);
-                mrow = reinterpret_cast<const T*>(
-                           ((unsigned long long)hi << 32) | lo) +
-                       (long long)(row0 + r) * p.n_col;
+              if constexpr (HOSTED && !GATHER) {
+                // dead slots read member 0 again
+                mrow = reinterpret_cast<const T*>(m < Mr ? hcur : hb0);
+                hcur += hstep;
+              } else if constexpr (!HOSTED) {
+                mrow = m < Mr ? mb : xrow;
+              }
+              if constexpr (MAY_GATHER) {
+                if (gathered) {
+                  const unsigned lo = (unsigned)__builtin_amdgcn_readlane(
+                      (int)mp_lo[m / kWave], m % kWave);
+                  const unsigned hi = (unsigned)__builtin_amdgcn_readlane(
+                      (int)mp_hi[m / kWave], m % kWave);
+                  mrow = reinterpret_cast<const T*>(
+                             ((unsigned long long)hi << 32) | lo) +
+                         (long long)(row0 + r) * p.n_col;
+                }
               }
               mb += stride_r;
             }
             x[m] = member_load<T, true>(mrow, lane_bytes);
+            // a fence every eight loads: the bases are made next to their
+            // loads (hipcc would compute all of them first and spill them)
+            if constexpr (HOSTED)
+              if (m % 8 == 7) __builtin_amdgcn_sched_barrier(0);
           } else {
             x[m] = (T)0;
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MS == 0 && !SKIPNA) {
+        if constexpr (HOSTED) {
+#if !WB2_ENS_HOSTED_FLAGS
+          // dead slots (a wave-uniform suffix) become +inf ONCE, here
+#pragma unroll
+          for (int m = 0; m < MS; ++m)
+            x[m] = m < Mr ? x[m] : std::numeric_limits<T>::infinity();
+#endif
+          ens_point_hosted<NPAD, MS>(x, t, Mr, v);
+        } else if constexpr (MS == 0 && !SKIPNA) {
           // dead slots (a wave-uniform suffix) become +inf ONCE, here
 #pragma unroll
           for (int m = 0; m < NPAD; ++m)
@@ -993,6 +1293,28 @@ int launch_ens(const EnsParams& p, bool skipna, bool wf, hipStream_t stream) {
     if (wf) WB2_L(true, true); else WB2_L(true, false);
   } else {
     if (wf) WB2_L(false, true); else WB2_L(false, false);
+  }
+#undef WB2_L
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <int NPAD, int MS>
+int launch_ens_hosted(const EnsParams& p, bool wf, hipStream_t stream) {
+  int nwave = p.n_ctile < WB2_ENS_WG_WAVES ? p.n_ctile : WB2_ENS_WG_WAVES;
+  const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
+  const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
+  const long long gz = (p.n_outer + gy - 1) / gy;
+  const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
+  const dim3 block(nwave * kWave);
+#define WB2_L(W, G)                                                         \
+  hipLaunchKernelGGL(                                                      \
+      (ens_partials_kernel<float, NPAD, MS, false, W, true, G>), grid, block, \
+      0, stream, p)
+  if (p.member_ptr) {
+    if (wf) WB2_L(true, true); else WB2_L(false, true);
+  } else {
+    if (wf) WB2_L(true, false); else WB2_L(false, false);
   }
 #undef WB2_L
   WB2_HIP_OK(hipGetLastError());

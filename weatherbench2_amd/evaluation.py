@@ -566,13 +566,15 @@ def _stage_on_device(device):
             and da.data.dtype.isnative]
     if not hits:
       return ds, moved
+    # every variable of the chunk in one foreign call (no interpreter lock
+    # taken between two variables)
+    moved = feeder.upload_many([ds.data_vars[n].data for n in hits], dev,
+                               wait=False)
+    on_device = dict(zip(hits, moved))
     out = xl.Dataset(coords=ds.coords, attrs=dict(ds.attrs))
     for name, da in ds.data_vars.items():
-      data = da.data
-      if name in hits:
-        data = feeder.upload(data, dev, wait=False)
-        moved.append(data)
-      out.data_vars[name] = xl.DataArray(data, da.dims, ds.coords, name)
+      out.data_vars[name] = xl.DataArray(on_device.get(name, da.data), da.dims,
+                                         ds.coords, name)
     return out, moved
 
   def stage(pair):

@@ -28,8 +28,10 @@ import torch
 
 # the pinned ring of an uploader: slices small enough that the first DMA starts
 # early, enough of them that the copy pool never waits for a free slot
-_SLICE_BYTES = 32 << 20
-_RING_SLOTS = 4
+import os as _os
+
+_SLICE_BYTES = int(_os.environ.get('WB2HIP_STAGE_SLICE_MIB', 32)) << 20
+_RING_SLOTS = int(_os.environ.get('WB2HIP_STAGE_SLOTS', 4))
 
 
 def copy_threads() -> int:
@@ -110,6 +112,38 @@ def upload(array: np.ndarray, device: torch.device,
   if wait:
     cur.wait_stream(stream)
   return dst
+
+
+def upload_many(arrays: t.Sequence[np.ndarray], device: torch.device,
+                wait: bool = True) -> list:
+  """`upload` for the variables of one chunk in ONE C-ABI call
+  (wb2_uploader_upload_many): the calling thread does not come back to the
+  interpreter -- and does not queue for its lock behind a busy main thread --
+  between two variables."""
+  import ctypes
+  from weatherbench2_amd import _lib
+  srcs = [np.ascontiguousarray(a) for a in arrays]
+  ring = _STAGING.get(device)
+  stream = ring['stream']
+  cur = torch.cuda.current_stream(device)
+  with torch.cuda.stream(stream):
+    dsts = [torch.empty(a.shape,
+                        dtype=torch.from_numpy(np.empty(0, a.dtype)).dtype,
+                        device=device) for a in srcs]
+  for d in dsts:
+    d.record_stream(cur)
+  n = len(srcs)
+  if n:
+    _lib.check(ring['lib'].wb2_uploader_upload_many(
+        ring['uploader'], n, (ctypes.c_void_p * n)(*[d.data_ptr() or None
+                                                     for d in dsts]),
+        (ctypes.c_void_p * n)(*[a.ctypes.data if a.nbytes else None
+                                for a in srcs]),
+        (ctypes.c_int64 * n)(*[a.nbytes for a in srcs]), stream.cuda_stream),
+               'wb2_uploader_upload_many')
+  if wait:
+    cur.wait_stream(stream)
+  return dsts
 
 
 class ChunkFeeder:
