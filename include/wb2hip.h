@@ -508,6 +508,36 @@ int wb2_det_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
                        double* count, void* stream);
 
 /*
+ * The energy score in ONE read of the ensemble (metrics.py:1403-1517;
+ * scripts/evaluate.py:541-565 evaluates score, spread and skill per chunk):
+ *   skill  = mean_m     sqrt(_spatial_average((x_m - y)^2))
+ *   spread = mean_{m<M-1} sqrt(_spatial_average((x_m - x_{m+1})^2))   (0 for M = 1)
+ *   score  = skill - 0.5 spread
+ * for every region of `plan` at once: out[3][n_region][n_outer] = (score,
+ * spread, skill), fp64.  The 2 M - 1 weighted sums per region are accumulated
+ * by blocks of `block` consecutive members (one wave per block, the blocks of a
+ * row chunk side by side in one workgroup: HBM traffic (M + 1) elements per
+ * point), folded by the combine kernel and finished by a small third kernel.
+ * skipna as in _spatial_average / .mean(ensemble_dim, skipna): NaNs drop out of
+ * the spatial means and NaN members out of the member means.
+ *
+ *  plan      tables as for wb2_det_suite_step, with n_ctile / n_ts / seg_eoff
+ *            for the ENSEMBLE tile width (wb2_ens_tile_cols), wfield float64
+ *  ens, ens_slab, truth, truth_slab, n_member, member_stride: as wb2_ens_partials
+ *  partials  DEV scratch double[n_outer * n_block][n_chunk][nwf][n_ts][n_slot]
+ *  means     DEV scratch double[2 * block][n_region][n_outer * n_block]
+ *            (block, n_block, n_slot from wb2_energy_layout)
+ */
+int wb2_energy_layout(int32_t n_member, int skipna, int has_wfield,
+                      int32_t* block, int32_t* n_block, int32_t* n_slot);
+int wb2_energy_score(int dtype, int skipna, const void* ens,
+                     const int64_t* ens_slab, const void* truth,
+                     const int64_t* truth_slab, int32_t n_member,
+                     int64_t member_stride, int64_t n_outer,
+                     const wb2_plan_tables* plan, double* partials,
+                     double* means, double* out, void* stream);
+
+/*
  * K5: the Spatial* metrics (no spatial reduction): SpatialBias / SpatialMSE /
  * SpatialMAE (weatherbench2/metrics.py:304-374).
  *

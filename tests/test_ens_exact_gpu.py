@@ -63,7 +63,7 @@ def test_exact_member_counts_match_oracle(dev, m, skipna):
   ens = rs.normal(size=(m, n_slab, n_lat, n_lon)).astype(np.float32)
   ens[:, 0, :, 100:140] = np.round(ens[:, 0, :, 100:140] * 2) / 2   # ties
   truth = rs.normal(size=(n_slab, n_lat, n_lon)).astype(np.float32)
-  ens[3, 1, 5, 70] = np.inf
+  ens[min(3, m - 1), 1, 5, 70] = np.inf
   # NaN patches: columns 0..19 of some rows (the first wave of those rows)
   ens[rs.randint(0, m, size=40), 2, rs.randint(0, n_lat, size=40),
       rs.randint(0, 20, size=40)] = np.nan

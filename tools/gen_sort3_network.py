@@ -312,9 +312,11 @@ if __name__ == '__main__':
 # member counts K3 instantiates with a compile-time M (50 has its own file):
 # small test ensembles, 10 / 11 / 20 / 21 / 31 (operational centres with and
 # without the control), 25, 30 (the 1990-2019 probabilistic climatology), 32,
-# 40, 51 / 56 (IFS ENS + control, GenCast-style), 64, 100
-EXACT_SIZES = (4, 5, 8, 10, 11, 16, 20, 21, 25, 30, 31, 32, 40, 51, 56, 64,
-               100)
+# 40, 51 / 56 (IFS ENS + control, GenCast-style), 64, 100 -- and 36, 45, 48,
+# 72, 80, 90 so that every other count up to 100 finds a HOST program at most
+# ~10 % larger than itself (ens_point_hosted: dead slots at +inf)
+EXACT_SIZES = (4, 5, 8, 10, 11, 16, 20, 21, 25, 30, 31, 32, 36, 40, 45, 48,
+               51, 56, 64, 72, 80, 90, 100)
 
 
 def _sorted_by(builder, n_wires, n_real):

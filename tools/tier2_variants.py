@@ -11,6 +11,8 @@ algorithmic bytes:
   gaussian_crps           K1 mode GAUSS                 read 12 B/pt
   gaussian_thresholds     K1 mode GAUSS_THR             read 16 B/pt
   seeps                   K1 mode SEEPS                 read 12 B/pt (+ p1 from L2)
+  energy_score            score + spread + skill, M = 50, fused (one read of
+                          the ensemble)                 read (M + 1) * 4 B/pt
   ens_thresholds          Brier / RPS partials, M = 50  read (M + 2) * 4 B/pt
   ens_threshold_maps      the same, unreduced           + 32 B/pt written
   rank_histogram          M = 50, 51 bins, mean over the 13 slabs
@@ -125,6 +127,13 @@ def variants(dev, reps: int = 3, calls: int = 10, only=None) -> dict:
     truth = randn(epool * n_eslab, n_lat, n_lon)
     return ens, truth
 
+  @maker('energy_score', epts * (n_member + 1) * 4.0)
+  def _():
+    ens, truth = ens_inputs()
+    return lambda i: engine.energy_score(
+        eplan, ens, stride, n_member, etabs[i % epool], truth,
+        etabs[i % epool], n_eslab, False)
+
   @maker('ens_thresholds', epts * (n_member + 2) * 4.0)
   def _():
     ens, truth = ens_inputs()
@@ -202,8 +211,15 @@ def variants(dev, reps: int = 3, calls: int = 10, only=None) -> dict:
 
 
 def main():
+  import argparse
   import torch
-  print(json.dumps(variants(torch.device('cuda', 0))))
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--only', default='')
+  ap.add_argument('--reps', type=int, default=3)
+  args = ap.parse_args()
+  only = [x for x in args.only.split(',') if x] or None
+  print(json.dumps(variants(torch.device('cuda', 0), reps=args.reps,
+                            only=only)))
 
 
 if __name__ == '__main__':

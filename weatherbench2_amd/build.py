@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
-SOURCES = ('common.cpp', 'comm.cpp', 'staging.cpp', 'stream_reduce.hip', 'ensemble.hip',
+SOURCES = ('common.cpp', 'comm.cpp', 'staging.cpp', 'stream_reduce.hip', 'ensemble.hip', 'energy_score.hip',
            'spectrum.hip', 'spectrum_fused.hip', 'spatial_maps.hip',
            'rank_histogram.hip', 'axis_reduce.hip')
 # compiled once per member count listed in sort3_networks.inc (WB2_SORT3_SIZES)
@@ -50,8 +50,12 @@ def translation_units() -> list[tuple]:
   units = [(s, os.path.basename(s) + '.o', []) for s in sources()]
   exact = os.path.join(CSRC, EXACT_SOURCE)
   for m, npad in exact_sizes():
+    # -fno-slp-vectorize: merged into packed adds, the hosted kernels' sum /
+    # |t - x| chains cost register pairs and copies (146 -> 108 VGPRs, + 5-10 %
+    # measured); the exact kernels compile to the same code either way
     units.append((exact, f'ensemble_exact_{m}.o',
-                  [f'-DWB2_ENS_M={m}', f'-DWB2_ENS_NPAD={npad}']))
+                  [f'-DWB2_ENS_M={m}', f'-DWB2_ENS_NPAD={npad}',
+                   '-fno-slp-vectorize']))
   return units
 
 

@@ -112,10 +112,15 @@ __device__ __forceinline__ double abs_or_zero(double d) {
 // 2 nt, 16 sc1)
 constexpr int kNtPolicy = 2;
 
+// `num_records` (bytes addressable through the descriptor): 0 turns the load
+// into a no-op that returns 0 -- the range check happens before any memory
+// access -- which is how the hosted kernels skip their dead member slots with
+// ONE scalar select that is not part of the address chain.
 template <typename T, bool ONCE = false>
-__device__ __forceinline__ T member_load(const T* uniform_base, int lane_bytes) {
+__device__ __forceinline__ T member_load(const T* uniform_base, int lane_bytes,
+                                         int num_records = 0x7fffffff) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(uniform_base), 0, 0x7fffffff, 0x00020000);
+      const_cast<T*>(uniform_base), 0, num_records, 0x00020000);
   // cache policy (gfx940+): bit 1 = nt -- the members are read once
   if constexpr (sizeof(T) == 4) {
     return __builtin_bit_cast(
@@ -630,14 +635,6 @@ __device__ __forceinline__ void ens_point_runtime(T (&x)[NPAD], const T t,
 // next power of two (44 members: the 51-member program's 585 instructions
 // instead of the 64-network's 1 086).  Same operations in the same order as
 // ens_point's generic path for the M live members.
-#ifndef WB2_ENS_HOSTED_FLAGS
-// 1: ens_point_hosted without control flow (per-member 0 / 1 flags in SGPRs and
-// legacy multiplies); 0: the statistics in groups of four behind wave-uniform
-// branches, like ens_point_runtime
-#define WB2_ENS_HOSTED_FLAGS 1
-#endif
-
-#if WB2_ENS_HOSTED_FLAGS
 // v_max_f32 / v_mul_legacy_f32 with the wave-uniform operand read straight
 // from an SGPR (src0 of a VOP2): no v_mov, no lane mask per member.  (The
 // operand goes in as an int: hipcc gives a FLOAT "s" operand a VGPR -- and
@@ -658,19 +655,21 @@ __device__ __forceinline__ float times_sflag(float v, float uniform_flag) {
   return r;
 }
 
-// Straight-line form.  The caller hands over the RAW loads: a dead slot holds
-// member 0 again, so "any NaN among all MS slots" is "any NaN among the live
-// members" and needs no member count.  Then, per slot m, one scalar select
-// makes f_m = (m < M) ? 1 : 0 (an SGPR) and
-//   dead slots -> +inf      v_max_f32 x, (m < M ? -inf : +inf)    (no lane mask)
-//   live-only sums          v_mul_legacy_f32 v, f_m               (0 * inf = 0)
-// so the +inf padding drops out of every sum and the program never branches:
-// hipcc allocates registers for ONE basic block, as for the exact kernels.
-// The per-member scalars are made where they are used: every group of eight
-// members compares against a copy of M of its own (an empty asm the optimiser
-// cannot look through) between two scheduling fences -- left alone hipcc does
-// every select of a member next to the first compare of that member (the one
-// of its load address) and spills ~230 scalars per row through VGPR lanes.
+// Runtime member count M <= MS inside the exact MS-member sorting program
+// (the 2- / 3-sorter programs of sort3_networks.inc) instead of a padded
+// power-of-two network (44 members: the 45-member program, not the
+// 64-network's 1 086 instructions).  The caller hands over the RAW loads: a dead
+// slot holds 0 (its load was switched off through the buffer descriptor).
+// Groups of eight members behind wave-uniform branches: a group that lies
+// inside [0, M) runs the exact kernels' plain code, a group beyond M is skipped
+// (its slots become +inf for the sort: they end up behind every live member
+// and carry no rank weight), and only the ONE group that straddles M pays for
+// flags -- f_m = (m < M) ? 1 : 0 in an SGPR, v_max_f32 against -+inf for the
+// fill and v_mul_legacy_f32 (0 * inf = 0) for the sums, no lane masks.  (A
+// straight-line form with flags on every member cost four VALU instructions
+// per member and ~130 scalar spills per row; measured 5-10 % slower.)  Same
+// operations in the same order as ens_point's generic path for the M live
+// members: bit-identical to the padded runtime networks (tested).
 template <int NPAD, int MS>
 __device__ __forceinline__ void ens_point_hosted(float (&x)[NPAD], const float t,
                                                  const int M,
@@ -684,41 +683,61 @@ __device__ __forceinline__ void ens_point_hosted(float (&x)[NPAD], const float t
   T sum = 0, sk = 0, sq = 0;
 #pragma unroll
   for (int g = 0; g < MS; g += G) {
-    int Mg = M;
-    asm volatile("" : "+s"(Mg));
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int hi = g + G < MS ? g + G : MS;  // compile time after unrolling
+    if (hi <= M) {                            // wave-uniform: all live
+      // member pairs, written as the exact kernels write them (separate
+      // chains for the sum and the |t - x| sum: merged into packed adds by the
+      // vectoriser they cost register pairs and copies)
 #pragma unroll
-    for (int m = g; m < g + G && m < MS; ++m) {
-      // the RAW pair first (dead slots repeat member 0: no NaN of their own)
-      if (m % 2 == 0)
-        bad = bad || (m + 1 < MS ? __builtin_isunordered(x[m], x[m + 1])
-                                 : is_nan(x[m]));
-      const T f = m < Mg ? (T)1 : (T)0;  // wave-uniform: s_cselect
-      // dead slot -> +inf (a live NaN has been seen by `bad`)
-      const T xm = vmax_s(x[m], m < Mg ? -inf : inf);
-      sum += times_sflag(xm, f);
-      sk += times_sflag(abs_of(t - xm), f);
-      if (m % 2 == 1 || m + 1 == MS) {
-        x[m] = xm;
-      } else {
-        // (the pair's NaN test reads the raw x[m + 1]: the odd member's fill
-        // happens in the next iteration, the even one's may be stored now)
-        x[m] = xm;
+      for (int m = g; m + 1 < hi; m += 2) {
+        const T d0 = t - x[m], d1 = t - x[m + 1];
+        sum += x[m];
+        sk += abs_of(d0);
+        sum += x[m + 1];
+        sk += abs_of(d1);
+        bad = bad || __builtin_isunordered(x[m], x[m + 1]);
       }
+      if ((hi - g) % 2 == 1) {
+        sum += x[hi - 1];
+        sk += abs_of(t - x[hi - 1]);
+        bad = bad || is_nan(x[hi - 1]);
+      }
+    } else if (g < M) {                       // the straddling group
+#pragma unroll
+      for (int m = g; m < hi; ++m) {
+        const T f = m < M ? (T)1 : (T)0;
+        const T floor_m = __builtin_bit_cast(
+            T, (__builtin_bit_cast(unsigned, f) << 8) | 0x7f800000u);
+        bad = bad || is_nan(x[m]);            // a dead slot holds 0
+        x[m] = vmax_s(x[m], floor_m);         // dead -> +inf
+        sum += times_sflag(x[m], f);
+        sk += times_sflag(abs_of(t - x[m]), f);
+      }
+    } else {                                  // all dead
+#pragma unroll
+      for (int m = g; m < hi; ++m) x[m] = inf;
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   const T mean = sum / (T)M;
 #pragma unroll
   for (int g = 0; g < MS; g += G) {
-    int Mg = M;
-    asm volatile("" : "+s"(Mg));
+    const int hi = g + G < MS ? g + G : MS;
+    if (hi <= M) {
 #pragma unroll
-    for (int m = g; m < g + G && m < MS; ++m) {
-      const T f = m < Mg ? (T)1 : (T)0;
-      const T d = x[m] - mean;
-      sq += times_sflag(d * d, f);
+      for (int m = g; m < hi; ++m) {
+        const T d = x[m] - mean;
+        sq += d * d;
+      }
+    } else if (g < M) {
+#pragma unroll
+      for (int m = g; m < hi; ++m) {
+        const T f = m < M ? (T)1 : (T)0;
+        const T d = x[m] - mean;
+        sq += times_sflag(d * d, f);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   {
     int pinned = bad ? 1 : 0;
@@ -735,23 +754,32 @@ __device__ __forceinline__ void ens_point_hosted(float (&x)[NPAD], const float t
   if (M >= 2) {
     Sort3<MS>::template run<NPAD>(x);  // rank r: register Sort3<MS>::order[r]
     double s = 0.0;
+    // weight of rank r (0-based): 2 (r + 1) - M - 1, stepped by 2 (exact in
+    // fp64) from 1 - M: one add per rank and ONE live value -- converted from
+    // the integer per rank, hipcc makes all the weights first (2 VGPRs each)
+    double w = (double)(1 - M);
 #pragma unroll
     for (int g = 0; g < MS; g += G) {
-      int Mg = M;
-      asm volatile("" : "+s"(Mg));
-      const int c0 = -Mg - 1;  // weight of rank r (0-based): 2 (r + 1) - M - 1
+      const int hi = g + G < MS ? g + G : MS;
+      if (hi <= M) {
 #pragma unroll
-      for (int m = g; m < g + G && m < MS; ++m) {
-        const T f = m < Mg ? (T)1 : (T)0;
-        s = __builtin_fma((double)(2 * (m + 1) + c0),
-                          (double)times_sflag(x[Sort3<MS>::order[m]], f), s);
+        for (int m = g; m < hi; ++m) {
+          s = __builtin_fma(w, (double)x[Sort3<MS>::order[m]], s);
+          w += 2.0;
+        }
+      } else if (g < M) {
+#pragma unroll
+        for (int m = g; m < hi; ++m) {
+          const T f = m < M ? (T)1 : (T)0;
+          s = __builtin_fma(w, (double)times_sflag(x[Sort3<MS>::order[m]], f),
+                            s);
+          w += 2.0;
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     spread = 2.0 * (s / (double)M) / (double)(M - 1);
   }
-  // a NaN member poisons the mean and with it every value (the fill above
-  // turned it into -inf: nothing computed from it is looked at)
+  // a NaN member poisons the mean and with it every value
   out[0] = bad ? (double)nan : (double)skill;
   out[1] = bad ? (double)nan : spread;
   out[2] = bad ? (double)nan : (double)mse;
@@ -759,114 +787,6 @@ __device__ __forceinline__ void ens_point_hosted(float (&x)[NPAD], const float t
   out[4] = bad ? (double)nan : (double)(sd * sd);
   out[5] = bad ? (double)nan : (double)deb;
 }
-#else
-template <int NPAD, int MS>
-__device__ __forceinline__ void ens_point_hosted(float (&x)[NPAD], const float t,
-                                                 const int M,
-                                                 double (&out)[6]) {
-  static_assert(Sort3<MS>::has, "no sorting program for this member count");
-  using T = float;
-  const T nan = std::numeric_limits<T>::quiet_NaN();
-  T sum = 0, sk = 0, sq = 0;
-  bool bad = false;
-  constexpr int G = 4;
-#pragma unroll
-  for (int g = 0; g < MS; g += G) {
-    if (g < M) {  // wave-uniform
-      if (g + G <= M && g + G <= MS) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-          sum += x[g + u];
-          sk += abs_of(t - x[g + u]);
-        }
-        bad = bad || __builtin_isunordered(x[g], x[g + 1]) ||
-              __builtin_isunordered(x[g + 2], x[g + 3]);
-      } else {
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-          if (g + u < MS) {
-            if (g + u < M) {
-              sum += x[g + u];
-              sk += abs_of(t - x[g + u]);
-              bad = bad || is_nan(x[g + u]);
-            }
-          }
-        }
-      }
-    }
-  }
-  const T mean = sum / (T)M;
-#pragma unroll
-  for (int g = 0; g < MS; g += G) {
-    if (g < M) {
-      if (g + G <= M && g + G <= MS) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-          const T d = x[g + u] - mean;
-          sq += d * d;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-          if (g + u < MS) {
-            if (g + u < M) {
-              const T d = x[g + u] - mean;
-              sq += d * d;
-            }
-          }
-        }
-      }
-    }
-  }
-  // everything that reads the members in MEMBER order is finished before the
-  // sort starts (or the unsorted ensemble stays alive beside the sorted one)
-  {
-    int pinned = bad ? 1 : 0;
-    asm volatile("" : "+v"(sq), "+v"(sum), "+v"(sk), "+v"(pinned));
-    bad = pinned != 0;
-  }
-  const T var = sq / (T)(M - 1);
-  const T sd = sqrt_of(var);
-  const T err = t - mean;
-  const T mse = err * err;
-  const T deb = mse - var / (T)M;
-  const T skill = sk / (T)M;
-  double spread = 0.0;
-  if (M >= 2) {
-    Sort3<MS>::template run<NPAD>(x);  // rank r: register Sort3<MS>::order[r]
-    double s = 0.0;
-    const int c0 = -M - 1;  // weight of rank r (0-based): 2 (r + 1) - M - 1
-#pragma unroll
-    for (int g = 0; g < MS; g += G) {
-      if (g < M) {
-        if (g + G <= M && g + G <= MS) {
-#pragma unroll
-          for (int u = 0; u < G; ++u)
-            s = __builtin_fma((double)(2 * (g + u + 1) + c0),
-                              (double)x[Sort3<MS>::order[g + u]], s);
-        } else {
-#pragma unroll
-          for (int u = 0; u < G; ++u) {
-            if (g + u < MS) {
-              if (g + u < M)
-                s = __builtin_fma((double)(2 * (g + u + 1) + c0),
-                                  (double)x[Sort3<MS>::order[g + u]], s);
-            }
-          }
-        }
-      }
-    }
-    spread = 2.0 * (s / (double)M) / (double)(M - 1);
-    if (bad) spread = (double)nan;  // a NaN member poisons the mean
-  }
-  out[0] = (double)skill;
-  out[1] = spread;
-  out[2] = (double)mse;
-  out[3] = (double)var;
-  out[4] = (double)(sd * sd);
-  out[5] = (double)deb;
-}
-#endif  // WB2_ENS_HOSTED_FLAGS
 
 
 // Ensembles too large for the register sort (M > 128 float32 / 64 float64):
@@ -1137,8 +1057,9 @@ __global__ void __launch_bounds__(256)
               // inside the chain made every load wait for 5 dependent scalar
               // instructions per member before it
               if constexpr (HOSTED && !GATHER) {
-                // dead slots read member 0 again
-                mrow = reinterpret_cast<const T*>(m < Mr ? hcur : hb0);
+                // the base advances unconditionally; a dead slot's load is
+                // switched off through its descriptor (below)
+                mrow = reinterpret_cast<const T*>(hcur);
                 hcur += hstep;
               } else if constexpr (!HOSTED) {
                 mrow = m < Mr ? mb : xrow;
@@ -1156,7 +1077,11 @@ __global__ void __launch_bounds__(256)
               }
               mb += stride_r;
             }
-            x[m] = member_load<T, true>(mrow, lane_bytes);
+            if constexpr (HOSTED)
+              x[m] = member_load<T, true>(mrow, lane_bytes,
+                                          m < Mr ? 0x7fffffff : 0);
+            else
+              x[m] = member_load<T, true>(mrow, lane_bytes);
             // a fence every eight loads: the bases are made next to their
             // loads (hipcc would compute all of them first and spill them)
             if constexpr (HOSTED)
@@ -1167,12 +1092,6 @@ __global__ void __launch_bounds__(256)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HOSTED) {
-#if !WB2_ENS_HOSTED_FLAGS
-          // dead slots (a wave-uniform suffix) become +inf ONCE, here
-#pragma unroll
-          for (int m = 0; m < MS; ++m)
-            x[m] = m < Mr ? x[m] : std::numeric_limits<T>::infinity();
-#endif
           ens_point_hosted<NPAD, MS>(x, t, Mr, v);
         } else if constexpr (MS == 0 && !SKIPNA) {
           // dead slots (a wave-uniform suffix) become +inf ONCE, here

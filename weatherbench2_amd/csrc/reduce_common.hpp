@@ -3,6 +3,8 @@
 
 #include "common.hpp"
 
+#include <cstdint>
+
 #ifndef WB2_ROTATE_CHUNKS
 // 1: kernels whose workgroup index runs over the chunks of a slab first (grid
 // x = chunk, y = slab: K1 without a 2-D field, the ensemble kernels) take chunk
@@ -13,6 +15,16 @@
 #endif
 
 namespace wb2 {
+
+// wb2_det_combine with the slot count given (stream_reduce.hip)
+int combine_slots(int mode, int skipna, int k_slots, const double* partials,
+                  int64_t n_outer, int32_t n_chunk, int32_t nwf, int32_t n_seg,
+                  const int32_t* seg_eoff, int32_t n_ts,
+                  const int32_t* band_chunk0, int32_t n_band,
+                  const double* coef_band, const double* coef_seg,
+                  const int32_t* region_wf, const double* region_wsum,
+                  int32_t n_region, double* sums, double* metrics,
+                  void* stream);
 
 // ---- many sums at once -------------------------------------------------------
 // Sums N per-lane doubles v[0..N) across the 64 lanes of a wave with a HALVING

@@ -1379,6 +1379,27 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
   WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(mode >= 0 && mode <= WB2_MODE_SEEPS, "unknown mode %d", mode);
+  const int k = mode == WB2_MODE_ENS ? wb2_ens_num_slots(skipna)
+                                     : wb2_num_slots(mode, skipna);
+  return combine_slots(mode, skipna, k, partials, n_outer, n_chunk, nwf, n_seg,
+                       seg_eoff, n_ts, band_chunk0, n_band, coef_band, coef_seg,
+                       region_wf, region_wsum, n_region, sums, metrics, stream);
+}
+
+}  // extern "C"
+
+namespace wb2 {
+// The body of wb2_det_combine with the slot count given (the energy-score pass
+// folds 2 x block member sums per virtual slab: a generic mode whose slot
+// count is not a function of the mode alone).
+int combine_slots(int mode, int skipna, int k_slots, const double* partials,
+                  int64_t n_outer, int32_t n_chunk, int32_t nwf, int32_t n_seg,
+                  const int32_t* seg_eoff, int32_t n_ts,
+                  const int32_t* band_chunk0, int32_t n_band,
+                  const double* coef_band, const double* coef_seg,
+                  const int32_t* region_wf, const double* region_wsum,
+                  int32_t n_region, double* sums, double* metrics,
+                  void* stream) {
   WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
                   region_wf && region_wsum,
@@ -1405,8 +1426,7 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
   p.n_ts = n_ts;
   p.n_band = n_band;
   p.n_region = n_region;
-  p.K = mode == WB2_MODE_ENS ? wb2_ens_num_slots(skipna)
-                             : wb2_num_slots(mode, skipna);
+  p.K = k_slots;
   p.mode = mode;
   p.skipna = skipna != 0;
   // lanes per cell: as many as keep the 1024 threads busy at a nominal K of 8
@@ -1427,6 +1447,9 @@ int wb2_det_combine(int mode, int skipna, const double* partials,
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }
+}  // namespace wb2
+
+extern "C" {
 
 int wb2_ens_combine(int skipna, const double* partials, int64_t n_outer,
                     int32_t n_chunk, int32_t nwf, int32_t n_seg,

@@ -394,27 +394,14 @@ class SuiteStep:
     tile = lib.wb2_tile_cols_ex(mode, self.code, int(skipna),
                                 int(plan.wfield is not None), plan.n_col,
                                 int(aligned))
-    seg_eoff, n_ts = plan.seg_entries(tile)
+    self.tables, self._keep = plan_tables(plan, tile, field, field_code, aux,
+                                          scalar)
+    n_ts = self._keep[3]
     self.n_metric = _lib.GENERIC_KQ.get(mode, _lib.NMETRIC)
     self.partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
                                 dtype=torch.float64, device=dev)
     self.metrics = torch.empty((self.n_metric, plan.n_region, n_outer),
                                dtype=torch.float64, device=dev)
-    # everything the struct points at stays referenced from here
-    self._keep = (field, aux, seg_eoff)
-    self.tables = _lib.PlanTables(
-        n_row=plan.n_row, n_col=plan.n_col, n_chunk=plan.n_chunk,
-        n_ctile=-(-plan.n_col // tile), n_seg=plan.n_seg, n_ts=n_ts,
-        n_band=plan.n_band, n_region=plan.n_region,
-        w_row=_lib.ptr(plan.w_row) or None, w_col=_lib.ptr(plan.w_col) or None,
-        wfield=_lib.ptr(field) or None, wfield_dtype=field_code, reserved=0,
-        aux=_lib.ptr(aux) or None, scalar=float(scalar),
-        chunk_row0=_lib.ptr(plan.chunk_row0), chunk_nrow=_lib.ptr(plan.chunk_nrow),
-        seg_col0=_lib.ptr(plan.seg_col0), seg_eoff=_lib.ptr(seg_eoff),
-        band_chunk0=_lib.ptr(plan.band_chunk0),
-        coef_band=_lib.ptr(plan.coef_band), coef_seg=_lib.ptr(plan.coef_seg),
-        region_wf=_lib.ptr(plan.region_wf),
-        region_wsum=_lib.ptr(plan.region_wsum))
     self._tables_ref = ctypes.byref(self.tables)
     self._acc = (0, 0, 0, 0, None, None, None)
     self._acc_keep = None
@@ -600,6 +587,73 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
       _lib.ptr(plan.region_wf), _lib.ptr(plan.region_wsum), plan.n_region,
       _lib.ptr(sums), _lib.ptr(metrics), stream), 'wb2_ens_combine')
   return metrics, sums
+
+
+def plan_tables(plan: ReductionPlan, tile_cols: int, field=None,
+                field_code: int = _lib.WB2_F64, aux=None, scalar: float = 0.0):
+  """(`wb2_plan_tables` struct of `plan` for a column-tile width, what it
+  points at -- keep both alive until the call has been enqueued)."""
+  seg_eoff, n_ts = plan.seg_entries(tile_cols)
+  tables = _lib.PlanTables(
+      n_row=plan.n_row, n_col=plan.n_col, n_chunk=plan.n_chunk,
+      n_ctile=-(-plan.n_col // tile_cols), n_seg=plan.n_seg, n_ts=n_ts,
+      n_band=plan.n_band, n_region=plan.n_region,
+      w_row=_lib.ptr(plan.w_row) or None, w_col=_lib.ptr(plan.w_col) or None,
+      wfield=_lib.ptr(field) or None, wfield_dtype=field_code, reserved=0,
+      aux=_lib.ptr(aux) or None, scalar=float(scalar),
+      chunk_row0=_lib.ptr(plan.chunk_row0), chunk_nrow=_lib.ptr(plan.chunk_nrow),
+      seg_col0=_lib.ptr(plan.seg_col0), seg_eoff=_lib.ptr(seg_eoff),
+      band_chunk0=_lib.ptr(plan.band_chunk0),
+      coef_band=_lib.ptr(plan.coef_band), coef_seg=_lib.ptr(plan.coef_seg),
+      region_wf=_lib.ptr(plan.region_wf),
+      region_wsum=_lib.ptr(plan.region_wsum))
+  return tables, (field, aux, seg_eoff, n_ts)
+
+
+def energy_score(plan: ReductionPlan, ens: torch.Tensor, member_stride: int,
+                 n_member: int, ens_slab: t.Optional[torch.Tensor],
+                 truth: torch.Tensor, truth_slab: t.Optional[torch.Tensor],
+                 n_outer: int, skipna: bool) -> torch.Tensor:
+  """wb2_energy_score: (score, spread, skill)[3, n_region, n_outer] float64 of
+  a member-major ensemble (`member_stride` elements between members) in one
+  read of the members.  Asynchronous on the current stream."""
+  import ctypes
+  lib = _lib.load()
+  dev = plan.device
+  dtype = ens.dtype
+  if dtype not in _DTYPES or truth.dtype != dtype:
+    raise TypeError(f'unsupported / mismatched dtypes {ens.dtype} {truth.dtype}')
+  for x in (ens, truth):
+    if x.device != dev or not x.is_contiguous():
+      raise ValueError('inputs must be contiguous on the plan device')
+  for s in (ens_slab, truth_slab):
+    if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
+      raise ValueError('slab tables are int64[n_outer]')
+  block, n_block, k = (ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32())
+  _lib.check(lib.wb2_energy_layout(
+      n_member, int(skipna), int(plan.wfield is not None), ctypes.byref(block),
+      ctypes.byref(n_block), ctypes.byref(k)), 'wb2_energy_layout')
+  tables, keep = plan_tables(plan, lib.wb2_ens_tile_cols(plan.n_col),
+                             plan.wfield)
+  n_ts = keep[3]
+  n_virtual = n_outer * n_block.value
+  partials = torch.empty((n_virtual, plan.n_chunk, plan.nwf, n_ts, k.value),
+                         dtype=torch.float64, device=dev)
+  means = torch.empty((2 * block.value, plan.n_region, n_virtual),
+                      dtype=torch.float64, device=dev)
+  out = torch.empty((3, plan.n_region, n_outer), dtype=torch.float64,
+                    device=dev)
+  if _LAUNCH_HOOK is not None:
+    _LAUNCH_HOOK('begin', 'energy_score')
+  _lib.check(lib.wb2_energy_score(
+      _DTYPES[dtype], int(skipna), _lib.ptr(ens), _lib.ptr(ens_slab),
+      _lib.ptr(truth), _lib.ptr(truth_slab), n_member, member_stride, n_outer,
+      ctypes.byref(tables), _lib.ptr(partials), _lib.ptr(means), _lib.ptr(out),
+      current_stream_ptr(dev)), 'wb2_energy_score')
+  if _LAUNCH_HOOK is not None:
+    _LAUNCH_HOOK('end', 'energy_score')
+  del keep
+  return out
 
 
 def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,

@@ -1982,61 +1982,85 @@ class GaussianVariance(_GaussianMetric):
   _row = 1
 
 
+def _energy_pass(forecast, truth, name, ensemble_dim, region, skipna):
+  """(score, spread, skill) of one variable for the active regions from ONE
+  read of the ensemble (wb2_energy_score: the 2 M - 1 per-member sums of
+  metrics.py:1468-1517 accumulated by blocks of members)."""
+  fvar, tvar = forecast[name], truth[name]
+  pins = [fvar.data, tvar.data]
+  key = _result_key(('energy', ensemble_dim), pins, region, skipna,
+                    (forecast, truth))
+  hit = _RESULTS.get(key)
+  if hit is not None:
+    return hit
+  (geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device,
+   _) = _ens_layout(forecast, fvar, tvar, ensemble_dim)
+  regions, _ = _region_set_for(region)
+  pl = plan_lib.cached_plan(
+      geo.latitude, geo.longitude, geo.layout, regions, device,
+      plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+  slab_elems = pl.n_row * pl.n_col
+  out = engine.energy_score(
+      pl, ften, member_slabs * slab_elems, n_member, ens_table,
+      tten.reshape(-1, pl.n_row, pl.n_col), truth_table, geo.n_outer, skipna)
+  dev = out.reshape((3, pl.n_region) + geo.out_shape)
+  value = (geo, {nm: dev[:, i] for i, nm in enumerate(pl.region_names)},
+           n_member)
+  _RESULTS.put(key, tuple(pins), value)
+  return value
+
+
 @dataclasses.dataclass
-class EnergyScoreSkill(EnsembleMetric):
+class _EnergyMetric(EnsembleMetric):
+  """Shared body of the three energy-score metrics: rows of the fused pass."""
+  _row = 0
+  _truth_first = False  # `forecast - truth` / the forecast alone come first
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False,
+                    regions: t.Optional[dict] = None):
+    forecast, truth = _inputs(forecast, truth)
+    _get_n_ensemble(forecast, self.ensemble_dim)  # raises like the reference
+    per_var = {}
+    with _all_regions(regions):
+      for name in _common_vars(forecast, truth):
+        geo, by_region, _ = _fused(
+            lambda r, name=name: _energy_pass(forecast, truth, name,
+                                              self.ensemble_dim, r, skipna),
+            region, regions)
+        dtype = _reference_result_dtype(
+            forecast, [_np_dtype(forecast[name].data),
+                       _np_dtype(truth[name].data)], region, regions)
+        lead, values = _pick(by_region, region, self._row, regions)
+        per_var[name] = (lead + geo.out_dims, values, dtype)
+    return _assemble(forecast, per_var, regions)
+
+  def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
+    return self.compute_chunk(forecast, truth, None, skipna, regions)
+
+  def compute_regions(self, forecast, truth, regions, skipna=False):
+    forecast = xl.as_dataset(forecast)
+    return self._mean_regions(forecast, truth, regions, skipna).assign_attrs(
+        ensemble_size=forecast.sizes[self.ensemble_dim])
+
+
+@dataclasses.dataclass
+class EnergyScoreSkill(_EnergyMetric):
   """E||X - Y||: member-wise area-weighted L2 norms, averaged over members
-  (metrics.py:1501-1517).  Each member is one slab set of the fused
-  deterministic pass -- no new kernel."""
-
-  def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    forecast, truth = _inputs(forecast, truth)
-    _get_n_ensemble(forecast, self.ensemble_dim)
-    rmse = RMSESqrtBeforeTimeAvg().compute_chunk(forecast, truth, region=region,
-                                                 skipna=skipna)
-    return rmse.mean(self.ensemble_dim, skipna=skipna)
+  (metrics.py:1501-1517)."""
+  _row = 2
 
 
 @dataclasses.dataclass
-class EnergyScoreSpread(EnsembleMetric):
+class EnergyScoreSpread(_EnergyMetric):
   """E||X - X'|| from the N-1 adjacent member differences
-  (metrics.py:1468-1498)."""
-
-  def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    forecast, truth = _inputs(forecast, truth)
-    n_ensemble = _get_n_ensemble(forecast, self.ensemble_dim)
-    if n_ensemble == 1:
-      base = RMSESqrtBeforeTimeAvg().compute_chunk(
-          forecast, truth, region=region, skipna=skipna).mean(
-              self.ensemble_dim, skipna=skipna)
-      return base.map(lambda v: xl.DataArray(np.zeros_like(v.values), v.dims,
-                                             v.coords, v.name))
-    key = ('escore_slices', id(forecast))
-    hit = _ALIGNED.get(key)
-    if hit is None:
-      relabel = lambda ds: xl.Dataset(
-          dict(ds.data_vars),
-          {**ds.coords,
-           self.ensemble_dim: np.arange(ds.sizes[self.ensemble_dim])})
-      hit = (relabel(forecast.isel(**{self.ensemble_dim: slice(None, -1)})),
-             relabel(forecast.isel(**{self.ensemble_dim: slice(1, None)})))
-      _ALIGNED.put(key, (forecast,), hit)
-    lo, hi = hit
-    rmse = RMSESqrtBeforeTimeAvg().compute_chunk(lo, hi, region=region,
-                                                 skipna=skipna)
-    return rmse.mean(self.ensemble_dim, skipna=skipna)
+  (metrics.py:1468-1498); zeros for one member."""
+  _row = 1
 
 
 @dataclasses.dataclass
-class EnergyScore(EnsembleMetric):
+class EnergyScore(_EnergyMetric):
   """ES = E||X - Y|| - 0.5 E||X - X'|| (metrics.py:1402-1465)."""
-
-  def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    forecast, truth = xl.as_dataset(forecast), xl.as_dataset(truth)
-    skill = EnergyScoreSkill(self.ensemble_dim).compute_chunk(
-        forecast, truth, region=region, skipna=skipna)
-    spread = EnergyScoreSpread(self.ensemble_dim).compute_chunk(
-        forecast, truth, region=region, skipna=skipna)
-    return skill - 0.5 * spread
+  _row = 0
 
 
 # ---------------------------------------------------------------------------
