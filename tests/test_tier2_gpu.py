@@ -237,3 +237,40 @@ def test_fused_energy_score_full_size_and_float64():
                                                   region=oregions[rname])
         helpers.assert_close(out[row, ri, 0], want['z'].data, rtol=1e-9,
                              atol=1e-12, err_msg=f'{oname}/{rname}/{dtype}')
+
+
+@pytest.mark.parametrize('with_land', [False, True])
+def test_fused_energy_score_skipna_with_the_official_region_sets(with_land):
+  """skipna doubles the sums per member block (32 slots) and the 13 predefined
+  regions cut the grid into 14 bands x 13 segs: the combine kernel then needs
+  more than the default 64 KiB of LDS (gfx950 lets a workgroup take 160 KiB);
+  with a land-sea mask on top the blocks shrink to 4 members."""
+  from oracle.named import DS, NA
+  from weatherbench2_amd import metrics as gm
+  n_lat, n_lon, m = 37, 144, 10
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  rs = np.random.RandomState(77)
+  ens = rs.normal(size=(m, n_lat, n_lon)).astype(np.float32)
+  tru = rs.normal(size=(n_lat, n_lon)).astype(np.float32)
+  ens[rs.randint(0, m, 40), rs.randint(0, n_lat, 40),
+      rs.randint(0, n_lon, 40)] = np.nan
+  coords = {'latitude': lat, 'longitude': lon}
+  forecast = DS({'z': NA(ens, ('realization', 'latitude', 'longitude'))},
+                dict(coords, realization=np.arange(m)))
+  truth = DS({'z': NA(tru, ('latitude', 'longitude'))}, coords)
+  oregions = helpers.predefined_regions(oracle=True)
+  if with_land:
+    lsm = np.clip(rs.uniform(-0.5, 1.3, size=(n_lat, n_lon)), 0, 1)
+    oregions['land'] = oreg.LandRegion(NA(lsm, ('latitude', 'longitude')),
+                                       lat, lon)
+  gregions = {k: helpers.to_gpu_region(v) for k, v in oregions.items()}
+  got = gm.EnergyScore().compute_chunk_regions(
+      helpers.to_gpu_dataset(forecast), helpers.to_gpu_dataset(truth),
+      gregions, True)
+  for ri, (rname, region) in enumerate(oregions.items()):
+    with np.errstate(all='ignore'):
+      want = om.EnergyScore().compute_chunk(forecast, truth, region=region,
+                                            skipna=True)
+    helpers.assert_close(got['z'].values[ri], want['z'].data, rtol=1e-9,
+                         atol=1e-12, err_msg=rname)

@@ -130,8 +130,10 @@ def variants(dev, reps: int = 3, calls: int = 10, only=None) -> dict:
   @maker('energy_score', epts * (n_member + 1) * 4.0)
   def _():
     ens, truth = ens_inputs()
+    gplan = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev,
+                                rows_per_chunk=plan_lib.ENERGY_ROWS_PER_CHUNK)
     return lambda i: engine.energy_score(
-        eplan, ens, stride, n_member, etabs[i % epool], truth,
+        gplan, ens, stride, n_member, etabs[i % epool], truth,
         etabs[i % epool], n_eslab, False)
 
   @maker('ens_thresholds', epts * (n_member + 2) * 4.0)

@@ -26,6 +26,12 @@ namespace wb2 {
 namespace {
 
 constexpr int kEnergyWaves = 8;  // member blocks per workgroup
+#ifndef WB2_ENERGY_B
+#define WB2_ENERGY_B 8   // members per block (wave): 2 B sums per lane
+#endif
+#ifndef WB2_ENERGY_ROWS
+#define WB2_ENERGY_ROWS 4  // rows in flight per wave: their loads before the sums
+#endif
 
 template <typename T, int B, bool SKIPNA, bool WF>
 __global__ void __launch_bounds__(kEnergyWaves* kWave)
@@ -69,49 +75,65 @@ __global__ void __launch_bounds__(kEnergyWaves* kWave)
                 (long long)row0 * p.n_col + colc;
   const double* wfp =
       WF ? p.wfield + (long long)row0 * p.n_col + colc : nullptr;
-#pragma clang loop unroll(disable)
-  for (int r = 0; r < nrow; ++r) {
-    const long long off = (long long)r * p.n_col;
-    const T* xrow = xrow0 + off;
-    T x[B + 1];
+  // U rows per iteration: their (B + 1) + 1 loads each are issued before the
+  // first sum (a wave has only ~10 loads per row to hide the latency with)
+  constexpr int U = WB2_ENERGY_ROWS;
+  auto rows = [&](const int r, auto count_tag) {
+    constexpr int N = decltype(count_tag)::value;
+    T x[N][B + 1], t[N];
+    double wr[N], wf[N];
 #pragma unroll
-    for (int j = 0; j <= B; ++j)  // a load past the block's members is off
-      x[j] = member_load<T, true>(xrow + j * p.member_stride, lane_bytes,
-                                  j < nload ? 0x7fffffff : 0);
-    const T t = __builtin_nontemporal_load(tb + off);
-    const double wr = p.w_row[row0 + r];
-    double wf = 1.0;
-    if constexpr (WF) wf = wfp[off];
-    const bool inside = !WF || wf > 0.0;
-    const double w2 = (WF && inside) ? wr * wf : 0.0;
-    // (forecast - truth) ** 2 and (x_m - x_{m+1}) ** 2 in the input dtype like
-    // NumPy (metrics.py:1489-1493, 1512); the weighted sums in fp64 (:161-163)
-    auto add = [&](int k, T q, bool live) {
-      if (!live) return;  // wave-uniform
-      double v = (double)q, c = 1.0;
-      if constexpr (SKIPNA) {
-        const bool ok = !is_nan(q);
-        v = ok ? v : 0.0;
-        c = ok ? 1.0 : 0.0;
-      }
-      acc[0][0][k] = __builtin_fma(wr, v, acc[0][0][k]);
-      if constexpr (SKIPNA)
-        acc[0][0][KQ + k] = __builtin_fma(wr, c, acc[0][0][KQ + k]);
-      if constexpr (WF) {
-        acc[1][0][k] = __builtin_fma(w2, inside ? v : 0.0, acc[1][0][k]);
-        if constexpr (SKIPNA)
-          acc[1][0][KQ + k] =
-              __builtin_fma(w2, inside ? c : 0.0, acc[1][0][KQ + k]);
-      }
-    };
+    for (int u = 0; u < N; ++u) {
+      const long long off = (long long)(r + u) * p.n_col;
+      const T* xrow = xrow0 + off;
 #pragma unroll
-    for (int j = 0; j < B; ++j) {
-      const T d = x[j] - t;
-      add(j, d * d, j < nm);
-      const T e = x[j] - x[j + 1];
-      add(B + j, e * e, j < np);
+      for (int j = 0; j <= B; ++j)  // a load past the block's members is off
+        x[u][j] = member_load<T, true>(xrow + j * p.member_stride, lane_bytes,
+                                       j < nload ? 0x7fffffff : 0);
+      t[u] = __builtin_nontemporal_load(tb + off);
+      wr[u] = p.w_row[row0 + r + u];
+      wf[u] = 1.0;
+      if constexpr (WF) wf[u] = wfp[off];
     }
-  }
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const bool inside = !WF || wf[u] > 0.0;
+      const double w2 = (WF && inside) ? wr[u] * wf[u] : 0.0;
+      // (forecast - truth) ** 2 and (x_m - x_{m+1}) ** 2 in the input dtype
+      // like NumPy (metrics.py:1489-1493, 1512); the weighted sums in fp64
+      // (:161-163)
+      auto add = [&](int k, T q, bool live) {
+        if (!live) return;  // wave-uniform
+        double v = (double)q, c = 1.0;
+        if constexpr (SKIPNA) {
+          const bool ok = !is_nan(q);
+          v = ok ? v : 0.0;
+          c = ok ? 1.0 : 0.0;
+        }
+        acc[0][0][k] = __builtin_fma(wr[u], v, acc[0][0][k]);
+        if constexpr (SKIPNA)
+          acc[0][0][KQ + k] = __builtin_fma(wr[u], c, acc[0][0][KQ + k]);
+        if constexpr (WF) {
+          acc[1][0][k] = __builtin_fma(w2, inside ? v : 0.0, acc[1][0][k]);
+          if constexpr (SKIPNA)
+            acc[1][0][KQ + k] =
+                __builtin_fma(w2, inside ? c : 0.0, acc[1][0][KQ + k]);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const T d = x[u][j] - t[u];
+        add(j, d * d, j < nm);
+        const T e = x[u][j] - x[u][j + 1];
+        add(B + j, e * e, j < np);
+      }
+    }
+  };
+  int r = 0;
+#pragma clang loop unroll(disable)
+  for (; r + U <= nrow; r += U) rows(r, std::integral_constant<int, U>{});
+#pragma clang loop unroll(disable)
+  for (; r < nrow; ++r) rows(r, std::integral_constant<int, 1>{});
   if (p.w_col) {
     const double wc = p.w_col[colc];
 #pragma unroll
@@ -133,33 +155,42 @@ __global__ void __launch_bounds__(kEnergyWaves* kWave)
 }
 
 // means[KQ][n_region][n_outer * n_block] -> out[3][n_region][n_outer]:
-// (score, spread, skill); one thread per (region, outer slab).  The member mean
-// runs in member order in fp64 (NumPy's reduction over the leading axis).
-__global__ void __launch_bounds__(256)
+// (score, spread, skill); one wave per (region, outer slab): the lanes fetch
+// the 2 M - 1 spatial means and take the square roots side by side, lane 0 adds
+// them in member order in fp64 (NumPy's reduction over the leading axis) --
+// one thread walking them alone took 26 us on dependent loads.
+constexpr int kEnergyMaxMembers = 1024;
+__global__ void __launch_bounds__(kWave)
     energy_finalize_kernel(const double* __restrict__ means, int block,
                            int n_block, int n_member, int skipna, int n_region,
                            long long n_outer, double* __restrict__ out) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)n_region * n_outer) return;
+  __shared__ double root[2][kEnergyMaxMembers];
+  const long long idx = blockIdx.x;
+  const int lane = threadIdx.x;
   const int r = (int)(idx / n_outer);
   const long long o = idx - (long long)r * n_outer;
   const long long n_virtual = n_outer * n_block;
   const long long row = (long long)n_region * n_virtual;  // one slot's plane
   const double* base = means + (long long)r * n_virtual + o * n_block;
-  auto member_mean = [&](int first_slot, int count) {
+  for (int m = lane; m < n_member; m += kWave) {
+    root[0][m] = sqrt(base[(long long)(m % block) * row + m / block]);
+    if (m + 1 < n_member)
+      root[1][m] = sqrt(base[(long long)(block + m % block) * row + m / block]);
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  auto member_mean = [&](const double* v, int count) {
     double s = 0.0, n = 0.0;
     for (int m = 0; m < count; ++m) {
-      const double v =
-          sqrt(base[(long long)(first_slot + m % block) * row + m / block]);
-      const bool keep = !(skipna && is_nan(v));
-      s += keep ? v : 0.0;
+      const bool keep = !(skipna && is_nan(v[m]));
+      s += keep ? v[m] : 0.0;
       n += keep ? 1.0 : 0.0;
     }
     return s / n;  // 0 / 0: an all-NaN mean is NaN (xarray, skipna)
   };
-  const double skill = member_mean(0, n_member);
+  const double skill = member_mean(root[0], n_member);
   // metrics.py:1479-1488: one member has no spread -- zeros, whatever the data
-  const double spread = n_member == 1 ? 0.0 : member_mean(block, n_member - 1);
+  const double spread = n_member == 1 ? 0.0 : member_mean(root[1], n_member - 1);
   const long long plane = (long long)n_region * n_outer;
   out[idx] = skill - 0.5 * spread;
   out[plane + idx] = spread;
@@ -191,7 +222,9 @@ int launch_energy(const EnsParams& p, int n_block, bool skipna, bool wf,
 
 // Members per block: 8 (16 sums per lane; 32 with skipna), 4 when a 2-D weight
 // field AND NaN skipping double the sums twice over.
-int energy_block(bool skipna, bool wf) { return (skipna && wf) ? 4 : 8; }
+int energy_block(bool skipna, bool wf) {
+  return (skipna && wf) ? 4 : WB2_ENERGY_B;
+}
 
 }  // namespace
 }  // namespace wb2
@@ -222,7 +255,8 @@ int wb2_energy_score(int dtype, int skipna, const void* ens,
   WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(plan != nullptr, "null plan");
   WB2_REQUIRE(ens && truth && partials && means && out, "null pointer argument");
-  WB2_REQUIRE(n_member >= 1, "n_member=%d", n_member);
+  WB2_REQUIRE(n_member >= 1 && n_member <= kEnergyMaxMembers,
+              "n_member=%d (1 ... %d)", n_member, kEnergyMaxMembers);
   const wb2_plan_tables& t = *plan;
   WB2_REQUIRE(t.w_row && t.chunk_row0 && t.chunk_nrow && t.seg_col0 &&
                   t.seg_eoff && t.band_chunk0 && t.coef_band && t.coef_seg &&
@@ -271,10 +305,10 @@ int wb2_energy_score(int dtype, int skipna, const void* ens,
   const bool sk = skipna != 0, wf = t.wfield != nullptr;
   int rc;
   if (dtype == WB2_F32)
-    rc = block == 8 ? launch_energy<float, 8>(p, n_block, sk, wf, s)
+    rc = block != 4 ? launch_energy<float, WB2_ENERGY_B>(p, n_block, sk, wf, s)
                     : launch_energy<float, 4>(p, n_block, sk, wf, s);
   else
-    rc = block == 8 ? launch_energy<double, 8>(p, n_block, sk, wf, s)
+    rc = block != 4 ? launch_energy<double, WB2_ENERGY_B>(p, n_block, sk, wf, s)
                     : launch_energy<double, 4>(p, n_block, sk, wf, s);
   if (rc != 0) return rc;
   // spatial means of every (virtual slab, slot): the generic combine
@@ -285,9 +319,10 @@ int wb2_energy_score(int dtype, int skipna, const void* ens,
                      stream);
   if (rc != 0) return rc;
   const long long n = (long long)t.n_region * n_outer;
-  hipLaunchKernelGGL(energy_finalize_kernel, dim3((unsigned)((n + 255) / 256)),
-                     dim3(256), 0, s, means, block, n_block, n_member, skipna,
-                     t.n_region, (long long)n_outer, out);
+  WB2_REQUIRE(n < (1ll << 31), "n_region * n_outer too large");
+  hipLaunchKernelGGL(energy_finalize_kernel, dim3((unsigned)n), dim3(kWave), 0,
+                     s, means, block, n_block, n_member, skipna, t.n_region,
+                     (long long)n_outer, out);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }

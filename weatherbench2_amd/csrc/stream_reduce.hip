@@ -28,6 +28,7 @@
 #include "gauss_math.hpp"
 #include "wb2hip.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1438,10 +1439,21 @@ int combine_slots(int mode, int skipna, int k_slots, const double* partials,
                       (size_t)n_region * p.K * (1 + (size_t)n_band) +
                       (size_t)n_region * ((size_t)n_seg + n_band)) *
                      sizeof(double);
-  WB2_REQUIRE(lds <= 64 * 1024,
+  // gfx950: a workgroup may take all 160 KiB of a CU's LDS; beyond the default
+  // 64 KiB of dynamic LDS the kernel has to be told once
+  WB2_REQUIRE(lds <= 160 * 1024,
               "region decomposition too fine for the combine kernel's LDS "
-              "(%zu bytes > 64 KiB): n_band=%d n_seg=%d",
-              lds, n_band, n_seg);
+              "(%zu bytes > 160 KiB): n_band=%d n_seg=%d slots=%d",
+              lds, n_band, n_seg, p.K);
+  if (lds > 64 * 1024) {
+    static std::atomic<size_t> allowed{64 * 1024};
+    if (lds > allowed.load()) {
+      WB2_HIP_OK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(det_combine_kernel),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      allowed.store(160 * 1024);
+    }
+  }
   hipLaunchKernelGGL(det_combine_kernel, dim3((unsigned)n_outer), dim3(1024),
                      lds, static_cast<hipStream_t>(stream), p);
   WB2_HIP_OK(hipGetLastError());

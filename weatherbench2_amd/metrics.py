@@ -1998,7 +1998,7 @@ def _energy_pass(forecast, truth, name, ensemble_dim, region, skipna):
   regions, _ = _region_set_for(region)
   pl = plan_lib.cached_plan(
       geo.latitude, geo.longitude, geo.layout, regions, device,
-      plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+      plan_lib.ENERGY_ROWS_PER_CHUNK)
   slab_elems = pl.n_row * pl.n_col
   out = engine.energy_score(
       pl, ften, member_slabs * slab_elems, n_member, ens_table,

@@ -42,6 +42,11 @@ DEFAULT_ROWS_PER_CHUNK = 16
 ENSEMBLE_ROWS_PER_CHUNK = int(os.environ.get('WB2HIP_ENS_ROWS_PER_CHUNK', 5))
 
 
+# The fused energy-score pass (one wave per block of 8 members: ~100 VALU per
+# row, a 16-sum fold per chunk): longer chunks than K3's amortise the fold.
+ENERGY_ROWS_PER_CHUNK = int(os.environ.get('WB2HIP_ENERGY_ROWS_PER_CHUNK', 16))
+
+
 def auto_rows_per_chunk(n_row: int, n_outer: int) -> int:
   """Rows per workgroup-chunk of the streaming kernel K1 for a launch of
   `n_outer` slabs (the ensemble kernels use ENSEMBLE_ROWS_PER_CHUNK).
