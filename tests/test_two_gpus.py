@@ -44,6 +44,42 @@ def test_bench_two_ranks_over_rccl():
   assert line['map_allreduce']['ms'] > 0
 
 
+def test_strong_scaling_2920_units_over_two_ranks():
+  """BASELINE configs[4] as written: a FIXED job of 2920 (init, lead) units in
+  contiguous shards over the ranks (evaluation.shard_bounds: 1460 + 1460), 16
+  units per step => K = ceil(1460 / 16) = 92 steps of the largest shard, the
+  last one partial (4 units); `value` is the 2920-unit job over the max-over-
+  ranks time, every collective on RCCL."""
+  if not _two_gpus():
+    pytest.skip('needs two GPUs (RCCL ranks cannot share a device)')
+  from weatherbench2_amd.evaluation import shard_bounds
+  assert [shard_bounds(2920, 2, r) for r in (0, 1)] == [(0, 1460), (1460, 2920)]
+  env = dict(os.environ)
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT',
+            'WB2_BENCH_SAME_GPU', 'WB2_BENCH_DIST_BACKEND'):
+    env.pop(k, None)
+  out = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+       '--total-units', '2920', '--warmup', '3', '--no-cpu-baseline'],
+      env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+  assert out.returncode == 0, out.stderr[-2000:]
+  last = out.stdout.strip().splitlines()[-1]
+  assert len(last.encode()) < 4096
+  line = json.loads(last)
+  assert line['scaling'] == 'strong' and line['n_gpus'] == 2
+  assert line['config']['total_units'] == 2920
+  assert line['steps'] == 92   # ceil(1460 / 16)
+  pts = 2920 * 13 * 721 * 1440
+  assert abs(line['value'] - pts / (line['ms_per_step'] * line['steps'] * 1e-3)
+             ) < 1e-6 * line['value']
+  assert line['ranks']['world_size_seen'] == 2
+  assert line['ranks']['backend'].startswith('rccl')
+  assert all(v == 'rccl' for v in line['ranks']['collectives'].values())
+  assert len(line['ranks']['ms_per_step_per_rank']) == 2
+  assert line['full_suite']['scaling'] == 'strong'
+  assert line['full_suite']['value'] > 0
+
+
 def test_c_abi_allreduce_with_two_ranks(tmp_path):
   if not _two_gpus():
     pytest.skip('needs two GPUs (RCCL ranks cannot share a device)')

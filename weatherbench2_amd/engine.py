@@ -677,6 +677,9 @@ def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
   elif (dst.dtype != torch.int64 or dst.numel() != n_lead * n_tail
         or total.numel() != count.numel()):
     raise ValueError('dst is int64 with one entry per result element')
+  # (the entries of `dst` must be distinct and < total.numel(): the kernel
+  # reads, adds and writes each destination without atomics.  RunningMean
+  # builds them on the host -- _Accumulator.destinations -- and checks there.)
   _lib.check(lib.wb2_time_accumulate_scatter(
       _DTYPES[values.dtype], _lib.ptr(values), n_lead, n_time, n_tail,
       int(skipna), _lib.ptr(dst),

@@ -251,6 +251,11 @@ class _Accumulator:
 
   def rows(self, labels: np.ndarray) -> np.ndarray:
     import torch
+    if len(set(labels.tolist())) != len(labels):
+      # two entries of one chunk would share an accumulator row: the scatter
+      # kernel's read-modify-write per element would lose one of them
+      raise ValueError(f'repeated {self.split} labels in one chunk result: '
+                       f'{labels}')
     out = np.empty(len(labels), dtype=np.int64)
     for j, (value, label) in enumerate(zip(labels.tolist(), labels)):
       row = self.row_of.get(value)
@@ -270,7 +275,10 @@ class _Accumulator:
     rest = np.arange(block, dtype=np.int64).reshape(self.rest_shape)
     where = [1] * len(self.shape)
     where[self.pos] = len(rows)
-    return (rows.reshape(where) * block + np.expand_dims(rest, self.pos)).ravel()
+    dst = (rows.reshape(where) * block + np.expand_dims(rest, self.pos)).ravel()
+    if dst.size and (dst.min() < 0 or dst.max() >= self.total.numel()):
+      raise ValueError('accumulator destination out of range')  # (host check)
+    return dst
 
 
 class RunningMean:
@@ -291,11 +299,24 @@ class RunningMean:
   """
 
   def __init__(self, dim: str, skipna: bool = False, device=None, comm=None,
-               split_dim: t.Optional[str] = None):
+               split_dim: t.Optional[str] = None, split_labels=None,
+               split_order: str = 'sorted'):
     self.dim = dim
     self.skipna = skipna
     self.device = device
     self.split_dim = split_dim
+    # the FULL list of `split_dim` labels, in output order: required with an
+    # RCCL `comm` (which can exchange numbers, not label lists), optional
+    # otherwise (the ranks' label sets are then united, first seen first)
+    self.split_labels = (None if split_labels is None
+                         else np.asarray(split_labels))
+    # without the full list: 'sorted' (whatever order the chunks arrive in) or
+    # 'first_seen' (rank 0's labels first -- the dataset's own order when the
+    # chunk list is walked in order, like xbeam.Mean's output, also for lead
+    # coordinates that are not monotonic; evaluate_chunks uses it)
+    if split_order not in ('sorted', 'first_seen'):
+      raise ValueError(f'split_order={split_order!r}')
+    self.split_order = split_order
     # an RCCL communicator from engine.comm_init_rank: the exchange then goes
     # through the C ABI (wb2_time_mean_allreduce) instead of torch.distributed
     self.comm = comm
@@ -379,19 +400,45 @@ class RunningMean:
           acc.count.index_add_(0, idx, c.movedim(acc.pos, 0))
 
   def _split_labels(self, names) -> dict:
-    """{var: labels in output order}: the union over the ranks, sorted."""
+    """{var: labels in output order}: the caller's full list if given, else
+    the union over the ranks, sorted or in order of first appearance
+    (`split_order`)."""
     import torch.distributed as dist
     mine = {n: np.array(self._acc[n].labels) for n in names
             if self._acc[n].split is not None}
+    if self.split_labels is not None:
+      for n, have in mine.items():
+        extra = set(have.tolist()) - set(self.split_labels.tolist())
+        if extra:
+          raise ValueError(f'{n}: {self.split_dim} labels {sorted(extra)} are '
+                           'not in the split_labels given')
+      return {n: self.split_labels for n in mine}
+    if self.comm is not None and mine:
+      # every rank must lay its rows out alike and an RCCL communicator cannot
+      # tell the ranks each other's labels
+      raise ValueError(
+          f'RunningMean(comm=..., split_dim={self.split_dim!r}) needs '
+          'split_labels: the full list of labels, the same on every rank')
+
+    def first_seen(parts):
+      if self.split_order == 'sorted':
+        return np.unique(np.concatenate(parts))
+      seen, order = set(), []
+      for part in parts:
+        for value, label in zip(part.tolist(), part):
+          if value not in seen:
+            seen.add(value)
+            order.append(label)
+      return np.array(order, dtype=parts[0].dtype) if order else parts[0][:0]
     out = {}
-    if self.comm is None and dist.is_available() and dist.is_initialized() and (
+    if dist.is_available() and dist.is_initialized() and (
         dist.get_world_size() > 1):
       everyone: list = [None] * dist.get_world_size()
       dist.all_gather_object(everyone, mine)
       for n in mine:
-        out[n] = np.unique(np.concatenate([e[n] for e in everyone if n in e]))
+        out[n] = first_seen([e[n] for e in everyone if n in e])
     else:
-      out = {n: np.unique(v) for n, v in mine.items()}
+      out = {n: first_seen([v]) for n, v in mine.items()}
     return out
 
   def result(self) -> xl.Dataset:
@@ -917,7 +964,8 @@ def evaluate_chunks(
     lead_dim = _lead_dim(first)
     lead_dim = lead_dim if lead_dim in first.dims else None
     if mean is None:
-      mean = RunningMean(time_dim, skipna, device, split_dim=lead_dim)
+      mean = RunningMean(time_dim, skipna, device, split_dim=lead_dim,
+                         split_order='first_seen')
     for forecast, truth_chunk in _batches(window, time_dim, lead_dim):
       mean.add(_metric_and_region_loop(forecast, truth_chunk, eval_config,
                                        skipna, compute_chunk=True))
@@ -952,8 +1000,14 @@ def evaluate_chunks(
       window.append((forecast, xl.as_dataset(truth_chunk)))
       if auto_batch:  # sized by the first chunk: its inputs' bytes
         nbytes = max(1, sum(_input_bytes(ds) for ds in window[0]))
-        batch_chunks = int(min(AUTO_BATCH_MAX,
-                               max(1, AUTO_BATCH_BYTES // nbytes)))
+        budget = AUTO_BATCH_BYTES
+        try:  # a window in flight + the next one being staged must fit: at
+          import torch  # most a quarter of the free device memory per window
+          if torch.cuda.is_available():
+            budget = min(budget, torch.cuda.mem_get_info()[0] // 4)
+        except Exception:
+          pass
+        batch_chunks = int(min(AUTO_BATCH_MAX, max(1, budget // nbytes)))
         auto_batch = False
       if len(window) >= batch_chunks:
         flush()

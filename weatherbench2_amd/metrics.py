@@ -26,6 +26,7 @@ metrics of the pass for all regions announced through `fused_regions(...)`
 from __future__ import annotations
 
 import contextlib
+import logging
 import dataclasses
 import functools
 import os
@@ -217,6 +218,13 @@ def _region_set_sig(region) -> tuple[dict, str, tuple]:
 
 
 _ALL = '__all_regions__'  # by_region key: (stacked tensor, region names)
+
+# What a COMPANION variable of a fused launch (another variable of the chunk, a
+# second wind pair) may raise while its inputs are prepared -- a foreign dtype,
+# a grid that does not match, a missing label: such a variable is left out and
+# reports when it is asked for.  Anything else (a failed launch, an allocator
+# or library fault) is not an input error and propagates.
+_INPUT_ERRORS = (TypeError, ValueError, KeyError, NotImplementedError)
 
 
 def _fused(pass_fn, region, regions: t.Optional[dict]):
@@ -744,7 +752,10 @@ class _ByRegion(dict):
     dict.__setitem__(self, _ALL, (dev, self._names))
 
   def __missing__(self, key):
-    value = self._dev[:, self._names.index(key)]  # ValueError -> KeyError below
+    try:
+      value = self._dev[:, self._names.index(key)]
+    except ValueError:
+      raise KeyError(key) from None
     self[key] = value
     return value
 
@@ -954,7 +965,7 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
         if _RESULTS.get(_det_key(forecast, truth, other, region, skipna)):
           continue  # an earlier (narrower) pass already answered it
         plans[other] = _det_plan(forecast, truth, other, climatology)
-      except Exception:  # reported when that variable is asked for
+      except _INPUT_ERRORS:  # reported when that variable is asked for
         continue
   by_mode: dict = {}
   for n, pl in plans.items():
@@ -962,9 +973,12 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
   for mode, names in by_mode.items():
     try:
       results = _run_group(mode, [plans[n][:3] for n in names], region, skipna)
-    except Exception:
+    except _INPUT_ERRORS as e:
       if len(names) == 1 and names[0] == name:
         raise
+      logging.getLogger(__name__).info(
+          'fused launch over %s fell back to %r alone: %s: %s', names, name,
+          type(e).__name__, e)
       # a companion variable cannot be read (foreign dtype, bad grid): the
       # requested one goes alone, the others report when they are asked for
       names = [n for n in names if n == name]
@@ -1305,16 +1319,19 @@ def _wind_pass(forecast, truth, u_name, v_name, region, skipna):
           _wind_key(forecast, truth, *pair, region, skipna)):
         continue
       plans[pair] = _wind_plan(forecast, truth, *pair)
-    except Exception:
+    except _INPUT_ERRORS:
       if pair == pairs[0]:
         raise
   names = list(plans)
   try:
     results = _run_group(_lib.MODE_WIND, [plans[p][:3] for p in names], region,
                          skipna)
-  except Exception:
+  except _INPUT_ERRORS as e:
     if len(names) == 1:
       raise
+    logging.getLogger(__name__).info(
+        'fused wind-vector launch over %s fell back to %s alone: %s: %s',
+        names, names[0], type(e).__name__, e)
     names = names[:1]
     results = _run_group(_lib.MODE_WIND, [plans[names[0]][:3]], region, skipna)
   for pair, by_region in zip(names, results):
