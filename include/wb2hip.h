@@ -507,6 +507,22 @@ int wb2_det_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
                        int acc_skipna, const int64_t* dst, double* sum,
                        double* count, void* stream);
 
+/* The running temporal mean of a whole chunk result in ONE launch (what
+ * TemporalMean / xbeam.Mean does with the Dataset _evaluate_chunk returns,
+ * evaluation.py:583-599, 735-744, for every variable of it at once): output
+ * element e sums, over the chunk's n_time time steps in order,
+ *   v = src[e * n_time + t] < 0 ? NaN : arena[src[e * n_time + t]]
+ * (rounded to float32 first where round32[e] != 0: the reference's float32
+ * result dtype) into the accumulators at the DEVICE ADDRESSES sum_addr[e] /
+ * count_addr[e] (distinct per e), NaNs skipped when skipna != 0.  `arena` holds
+ * the `metrics` outputs of the chunk's wb2_det_suite_step calls side by side;
+ * the caller derives `src` once per chunk structure (which result element
+ * reads which metrics element).  All pointers DEV. */
+int wb2_gather_accumulate(const double* arena, const int32_t* src,
+                          const uint8_t* round32, int64_t n_out, int64_t n_time,
+                          int skipna, const int64_t* sum_addr,
+                          const int64_t* count_addr, void* stream);
+
 /*
  * The energy score in ONE read of the ensemble (metrics.py:1403-1517;
  * scripts/evaluate.py:541-565 evaluates score, spread and skill per chunk):

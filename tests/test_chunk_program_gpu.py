@@ -1,0 +1,140 @@
+"""Chunk programs (weatherbench2_amd/program.py): the loop over one chunk
+structure recorded once and replayed with new addresses must give the bits of
+the generic path -- for every window size, chunk order, number of leads (the
+accumulators grow), host-fed chunks -- and must actually be what runs.
+Reference: /root/reference/weatherbench2/evaluation.py:583-599 (the per-chunk
+call), 693-705 (chunk source), 735-744 (the temporal mean)."""
+import numpy as np
+import pytest
+
+from tests import helpers, official_chunks as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(**kw):
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  forecast, truth, clim = oc.make(**kw)
+  lat, lon = forecast.coords['latitude'], forecast.coords['longitude']
+  lsm = oc.land_sea_mask(len(lat), len(lon))
+  oregions = oc.oracle_regions(lat, lon, lsm)
+  gregions = {k: helpers.to_gpu_region(v) for k, v in oregions.items()}
+  hf, ht, hc = (helpers.to_gpu_dataset(x) for x in (forecast, truth, clim))
+  gf, gt, gc = (evaluation.make_resident(x) for x in (hf, ht, hc))
+  cfg = config.Eval(metrics=oc.product_metrics(gm, gc), regions=gregions)
+  return hf, ht, gf, gt, cfg
+
+
+def _same(a, b):
+  assert sorted(a.data_vars) == sorted(b.data_vars)
+  for k in a.coords:
+    ca, cb = a.coords[k], b.coords[k]
+    np.testing.assert_array_equal(np.asarray(getattr(ca, 'values', ca)),
+                                  np.asarray(getattr(cb, 'values', cb)))
+  for name in a.data_vars:
+    x, y = np.asarray(a[name].values), np.asarray(b[name].values)
+    assert a[name].dims == b[name].dims and x.dtype == y.dtype
+    assert np.array_equal(x, y, equal_nan=True), name
+
+
+def _count_runs(monkeypatch):
+  from weatherbench2_amd import program
+  calls = []
+  real = program.ChunkProgram.run
+
+  def run(self, *a, **k):
+    calls.append(1)
+    return real(self, *a, **k)
+  monkeypatch.setattr(program.ChunkProgram, 'run', run)
+  return calls
+
+
+@pytest.mark.parametrize('order', ['init', 'lead'])
+@pytest.mark.parametrize('batch', [1, 2, 4, None])
+def test_programs_give_the_generic_paths_bits(batch, order, monkeypatch):
+  from weatherbench2_amd import evaluation
+  _, _, gf, gt, cfg = _setup(n_init=5, n_lead=3, n_lat=31, n_lon=72)
+  chunks = oc.chunk_pairs(gf, gt, order=order)
+  kwargs = {} if batch is None else {'batch_chunks': batch}
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, **kwargs)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+  calls = _count_runs(monkeypatch)
+  got = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, **kwargs)
+  _same(got, want)
+  if batch == 1:
+    # 15 chunks of one structure: the first builds the program, 14 replay it
+    assert len(calls) == len(chunks) - 1
+  elif batch == 2:
+    assert len(calls) >= 1   # windows of 2 (and a ragged last one)
+  # and with both paths run on every chunk
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', 'verify')
+  again = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, **kwargs)
+  _same(again, want)
+
+
+def test_programs_with_skipna_nans_and_growing_accumulators(monkeypatch):
+  """11 leads (the accumulators start with 8 rows and grow), NaN patches,
+  skipna: chunk by chunk, programs on and off."""
+  from weatherbench2_amd import evaluation
+  _, _, gf, gt, cfg = _setup(n_init=3, n_lead=11, n_lat=19, n_lon=36,
+                             nan_frac=0.01)
+  chunks = oc.chunk_pairs(gf, gt)
+  for skipna in (False, True):
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+    want = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                      batch_chunks=1)
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+    calls = _count_runs(monkeypatch)
+    got = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                     batch_chunks=1)
+    _same(got, want)
+    assert len(calls) == len(chunks) - 1
+    assert len(got.coords['lead_time']) == 11
+
+
+def test_host_fed_chunks_replay_too(monkeypatch):
+  """Forecast chunks as NumPy arrays, staged by the fetch thread: the staged
+  device tensors have one structure, so the program serves them as well."""
+  from weatherbench2_amd import evaluation
+  hf, ht, gf, gt, cfg = _setup(n_init=4, n_lead=2, n_lat=31, n_lon=72)
+  chunks = oc.chunk_pairs(gf, gt)
+  fed = [(h, t) for (h, _), (_, t) in zip(oc.chunk_pairs(hf, ht), chunks)]
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                                    batch_chunks=1)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+  monkeypatch.setattr(evaluation, '_STAGE_MIN_BYTES', 1024)
+  calls = _count_runs(monkeypatch)
+  got = evaluation.evaluate_chunks(fed, cfg, False, prefetch=2, batch_chunks=1)
+  _same(got, want)
+  assert len(calls) == len(chunks) - 1
+
+
+def test_a_change_of_structure_gets_a_program_of_its_own(monkeypatch):
+  """Two chunk lists of different grids through one evaluation each, and one
+  list whose last chunk drops a variable: the odd chunk takes the generic path
+  (or its own program), the result is that of the generic path."""
+  from weatherbench2_amd import evaluation
+  from weatherbench2_amd import xarray_lite as xl
+  _, _, gf, gt, cfg = _setup(n_init=4, n_lead=2, n_lat=31, n_lon=72)
+  chunks = oc.chunk_pairs(gf, gt)
+  f, t = chunks[-1]
+  drop = '2m_temperature'
+  chunks[-1] = (
+      xl.Dataset({k: v for k, v in f.data_vars.items() if k != drop},
+                 dict(f.coords)),
+      xl.Dataset({k: v for k, v in t.data_vars.items() if k != drop},
+                 dict(t.coords)))
+  outs = []
+  for how in ('0', '1'):
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', how)
+    try:
+      outs.append(evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                                             batch_chunks=1))
+    except Exception as e:   # the generic path's own complaint, both times
+      outs.append(type(e))
+  if isinstance(outs[0], type):
+    assert outs[1] is outs[0]
+  else:
+    _same(outs[1], outs[0])

@@ -71,6 +71,8 @@ _SIGNATURES = {
         _c.POINTER(PlanTables), _int, _int, _int, _c.POINTER(_vp),
         _c.POINTER(_vp), _int, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp,
         _vp, _vp, _vp]),
+    'wb2_gather_accumulate': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp,
+                                     _vp]),
     'wb2_energy_layout': (_int, [_i32, _int, _int, _c.POINTER(_i32),
                                  _c.POINTER(_i32), _c.POINTER(_i32)]),
     'wb2_energy_score': (_int, [

@@ -994,6 +994,41 @@ __global__ void __launch_bounds__(256)
   count[out] = c;
 }
 
+// The running temporal mean of a whole chunk RESULT in one launch: output
+// element e (of every variable of the result Dataset alike) is the sum over the
+// chunk's time steps of arena[src[e][t]] -- the K2 outputs of the chunk's
+// launches, side by side in `arena` --, rounded to float32 first where the
+// reference's result dtype is float32, added to the accumulator at the device
+// ADDRESS sum_addr[e] / count_addr[e] (the accumulators of the variables are
+// separate allocations).  src < 0: the element is a NaN fill (a metric that
+// lacks the variable, evaluation.py:424-437).  Same arithmetic, value by value
+// in time order, as time_accumulate_kernel.
+__global__ void __launch_bounds__(256)
+    gather_accumulate_kernel(const double* __restrict__ arena,
+                             const int* __restrict__ src,
+                             const unsigned char* __restrict__ round32,
+                             long long n_out, long long n_time, int skipna,
+                             const long long* __restrict__ sum_addr,
+                             const long long* __restrict__ count_addr) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_out) return;
+  double* sp = reinterpret_cast<double*>(sum_addr[e]);
+  double* cp = reinterpret_cast<double*>(count_addr[e]);
+  double s = *sp, c = *cp;
+  const bool r32 = round32[e] != 0;
+  const int* q = src + e * n_time;
+  for (long long t = 0; t < n_time; ++t) {
+    const int k = q[t];
+    double v = k < 0 ? __builtin_nan("") : arena[k];
+    if (r32) v = (double)(float)v;
+    const bool keep = !(skipna && is_nan(v));
+    s += keep ? v : 0.0;
+    c += keep ? 1.0 : 0.0;
+  }
+  *sp = s;
+  *cp = c;
+}
+
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
@@ -1560,6 +1595,26 @@ int wb2_det_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
   return wb2_time_accumulate_scatter(WB2_F64, metrics, acc_lead, acc_time,
                                      acc_tail, acc_skipna, dst, sum, count,
                                      stream);
+}
+
+int wb2_gather_accumulate(const double* arena, const int32_t* src,
+                          const uint8_t* round32, int64_t n_out, int64_t n_time,
+                          int skipna, const int64_t* sum_addr,
+                          const int64_t* count_addr, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_EMPTY_OK(n_out);
+  WB2_EMPTY_OK(n_time);
+  WB2_REQUIRE(arena && src && round32 && sum_addr && count_addr,
+              "null pointer argument");
+  hipLaunchKernelGGL(gather_accumulate_kernel,
+                     dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), arena, src, round32,
+                     (long long)n_out, (long long)n_time, skipna,
+                     reinterpret_cast<const long long*>(sum_addr),
+                     reinterpret_cast<const long long*>(count_addr));
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
 }
 
 int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,

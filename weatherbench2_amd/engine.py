@@ -182,7 +182,7 @@ _TABLES = _TableUploads()
 _TABLE_SLOT_BYTES = 1 << 18
 
 
-def upload_table(table: np.ndarray, device) -> torch.Tensor:
+def upload_table(table: np.ndarray, device, cache: bool = True) -> torch.Tensor:
   """int64 slab table -> device tensor WITHOUT stalling the queue.
 
   `torch.from_numpy(t).to(device)` is a synchronous pageable copy: with kernels
@@ -195,13 +195,15 @@ def upload_table(table: np.ndarray, device) -> torch.Tensor:
   table = np.ascontiguousarray(table, dtype=np.int64)
   device = torch.device(device)
   st = _TABLES
-  key = (str(device), table.shape, digest(table))
-  hit = st.cache.get(key)
-  if hit is not None:
-    dev, ev = hit
-    if ev is not None:
-      torch.cuda.current_stream(device).wait_event(ev)
-    return dev
+  key = None
+  if cache:  # (cache=False: a table that will not come again -- addresses)
+    key = (str(device), table.shape, digest(table))
+    hit = st.cache.get(key)
+    if hit is not None:
+      dev, ev = hit
+      if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
+      return dev
   nbytes = table.nbytes
   ev = None
   if nbytes > _TABLE_SLOT_BYTES or nbytes == 0 or device.type != 'cuda':
@@ -225,9 +227,10 @@ def upload_table(table: np.ndarray, device) -> torch.Tensor:
     ev = torch.cuda.Event()
     ev.record(stream)
     events[nxt] = ev
-  if len(st.cache) >= 512:
-    st.cache.clear()
-  st.cache[key] = (dev, ev)
+  if key is not None:
+    if len(st.cache) >= 512:
+      st.cache.clear()
+    st.cache[key] = (dev, ev)
   return dev
 
 

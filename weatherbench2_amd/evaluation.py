@@ -327,6 +327,10 @@ class RunningMean:
     import torch
     return self.device is not None and torch.device(self.device).type == 'cuda'
 
+  def _on_gpu_or_unset(self) -> bool:
+    """(the device is adopted from the first device-resident result)"""
+    return self.device is None or self._on_gpu()
+
   def add(self, chunk: xl.Dataset):
     import torch
     from weatherbench2_amd import engine
@@ -861,6 +865,64 @@ def _batches(pairs: list, time_dim: str, lead_dim: t.Optional[str]):
   return [(p[0], p[1]) for p in pairs]
 
 
+def _evaluate_piece(forecast, truth_chunk, eval_config, skipna, mean,
+                    programs: dict) -> None:
+  """One (forecast, truth) piece of a window through the metric x region loop
+  and into the running mean: the generic path for the first piece of every
+  chunk STRUCTURE (recorded), the recorded program for the rest (program.py --
+  same launches, same accumulation order, same bits)."""
+  from weatherbench2_amd import program
+  how = program.mode()
+  sig = None
+  if how != '0' and mean._on_gpu_or_unset():
+    sig = program.signature(forecast, truth_chunk)
+  prog = programs.get(sig) if sig is not None else False
+  if prog:
+    if how == 'verify':
+      _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean)
+    else:
+      prog.run(forecast, truth_chunk, mean)
+    return
+  loop = lambda: _metric_and_region_loop(forecast, truth_chunk, eval_config,
+                                         skipna, compute_chunk=True)
+  if prog is False:      # not replayable (or programs are off)
+    mean.add(loop())
+    return
+  with program.Recorder() as rec:
+    result = loop()
+  mean.add(result)
+  built = None
+  if mean._on_gpu():
+    built = program.build(rec, forecast, truth_chunk, xl.as_dataset(result),
+                          mean, loop)
+  programs[sig] = built or False
+
+
+def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
+  """WB2HIP_CHUNK_PROGRAM=verify: the program and the generic path on the same
+  chunk, into copies of the accumulators -- they must agree bit for bit."""
+  import torch
+  names = sorted(mean._acc)
+  before = {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone())
+            for n in names}
+  prog.run(forecast, truth_chunk, mean)
+  got = {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone())
+         for n in names}
+  for n in names:   # rows may have been added: restore what existed
+    t0, c0 = before[n]
+    mean._acc[n].total.zero_()
+    mean._acc[n].count.zero_()
+    mean._acc[n].total[:t0.shape[0]] = t0 if t0.dim() else t0
+    mean._acc[n].count[:c0.shape[0]] = c0 if c0.dim() else c0
+  mean.add(_metric_and_region_loop(forecast, truth_chunk, eval_config, skipna,
+                                   compute_chunk=True))
+  for n in names:
+    for a, b in zip(got[n], (mean._acc[n].total, mean._acc[n].count)):
+      same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+      if a.shape != b.shape or not bool(same.all().item()):
+        raise AssertionError(f'chunk program and generic path differ on {n}')
+
+
 # K1 chunking of evaluate_chunks (pinned: the result must not depend on how
 # many chunks share a launch); 32 rows is the measured optimum of launches of
 # 100+ slabs (profiles/r01_rows_per_chunk.md)
@@ -954,6 +1016,9 @@ def evaluate_chunks(
     batch_chunks, auto_batch = 1, False
   mean: t.Optional[RunningMean] = None
   window: list = []
+  # chunk structures seen so far -> their replayable program (program.py), or
+  # False where the generic path has to stay
+  programs: dict = {}
 
   def flush():
     nonlocal mean
@@ -967,8 +1032,8 @@ def evaluate_chunks(
       mean = RunningMean(time_dim, skipna, device, split_dim=lead_dim,
                          split_order='first_seen')
     for forecast, truth_chunk in _batches(window, time_dim, lead_dim):
-      mean.add(_metric_and_region_loop(forecast, truth_chunk, eval_config,
-                                       skipna, compute_chunk=True))
+      _evaluate_piece(forecast, truth_chunk, eval_config, skipna, mean,
+                      programs)
     window.clear()
 
   with metrics_lib.pinned_rows_per_chunk(EVALUATE_ROWS_PER_CHUNK):

@@ -39,6 +39,7 @@ import torch
 from weatherbench2_amd import _lib
 from weatherbench2_amd import engine
 from weatherbench2_amd import plan as plan_lib
+from weatherbench2_amd import program
 from weatherbench2_amd import xarray_lite as xl
 from weatherbench2_amd.regions import Region
 
@@ -812,7 +813,12 @@ def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
                               regions, device, _rows_per_chunk(n_row, n_total))
     lazy = any(isinstance(x, xl.SlabConcat)
                for i in members for x in prepped[i][0])
-    if len(members) == 1 and not lazy:
+    rec = program.recorder()
+    if rec is not None and rec.probe:
+      # program.py's probe pass: no launch, index-valued results
+      metrics = rec.fake_metrics(_lib.GENERIC_KQ.get(mode, _lib.NMETRIC),
+                                 pl.n_region, n_total, device)
+    elif len(members) == 1 and not lazy:
       # one variable in one allocation: slab NUMBERS (wb2_stream_partials_ex)
       i = members[0]
       tensors, tables, _ = prepped[i]
@@ -840,6 +846,12 @@ def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
           pl, mode, prepped[members[0]][2], list(dev_addr), aligned, n_total,
           skipna, aux=aux, scalar=scalar)
       del keep  # the launch is enqueued: the allocator orders any reuse after it
+    if rec is not None and not rec.probe:
+      rec.record(plan=pl, mode=mode, dtype=prepped[members[0]][2],
+                 n_total=n_total, skipna=bool(skipna), aux=aux, scalar=scalar,
+                 members=[(entries[i][0], list(entries[i][1]),
+                           list(prepped[i][1]), list(prepped[i][0]))
+                          for i in members], metrics=metrics)
     casts = {metrics.dtype: metrics}
 
     def view(dtype, off, n, shape, casts=casts, metrics=metrics):
@@ -910,6 +922,20 @@ def _det_plan(forecast, truth, name, climatology):
       crest = tuple(d for d in cvar.dims if d not in _SPATIAL)
       cdata, _, _ = _spatial_last(cvar, geo.layout)
       ctable = _climatology_slabs(climatology, cvar, forecast, geo, crest)
+      rec = program.recorder()
+      if rec is not None and not rec.probe:
+        # how another chunk of this structure gets ITS table (program.py);
+        # variables with the same climatology dims share one table per chunk
+        sizes = tuple(cvar.sizes[d] for d in crest)
+
+        def recompute(other, memo, climatology=climatology, cvar=cvar,
+                      geo=geo, crest=crest, sizes=sizes):
+          key = (id(climatology), crest, sizes, geo.out_dims, geo.out_shape)
+          if key not in memo:
+            memo[key] = _climatology_slabs_by_content(climatology, cvar, other,
+                                                      geo, crest)
+          return memo[key]
+        rec.note_table(ctable, recompute)
     except (KeyError, ValueError):
       if not announced:
         raise

@@ -1,0 +1,416 @@
+"""Chunk programs: the metric x region loop of ONE chunk structure, recorded
+once and replayed with new addresses.
+
+The reference's pipeline calls `_evaluate_chunk` once per chunk -- 2 920 init
+times x 40 leads of `init_time=1,lead_time=1` chunks in the official 0.25-degree
+run (/root/reference/weatherbench2/evaluation.py:583-599, 693-705, 735-744;
+docs/source/official-evaluation.md:537-556) -- and every call walks the same
+Python: 13 variables x 5 metrics x 16 regions of dims, labels, dtypes and
+result assembly, ~14 000 function calls for 0.26 ms of GPU work.  Chunks of one
+evaluation all have the SAME structure: only the addresses of their arrays and
+the valid times (which climatology slabs to subtract, which lead rows to add
+to) change.  So `evaluation.evaluate_chunks` lets the generic path run the
+first chunk of a structure while a recorder watches, and replays the rest:
+
+  record   every fused launch of the loop (metrics._run_group): plan, mode and,
+           per input slab, WHERE its address comes from -- a variable of the
+           forecast / truth chunk (new pointer, same offsets), or a resident
+           array gathered by valid time (same pointer, table recomputed by the
+           function the generic path used: metrics._climatology_slabs);
+  probe    the same loop once more on FAKE launch results u_k = k + 1/3 (k =
+           the element's position in the launches' outputs): whatever slicing,
+           stacking, transposing, NaN-filling and dtype conversion the metric
+           classes, `_assemble` and `merge_metrics` do to build the result
+           Dataset, element e of it then says which output element it shows
+           (floor) and whether it went through float32 (k + 1/3 is not a
+           float32 number);
+  verify   the mapping reproduces the first chunk's real result bit for bit
+           (NaN == NaN), else the structure keeps the generic path;
+  replay   per chunk: pointers -> address tables (NumPy), one
+           wb2_det_suite_step per recorded launch, ONE wb2_gather_accumulate
+           that feeds every variable's (sum, count) accumulators.
+
+The replayed launches are the recorded ones (same plan, same chunking, same
+kernels) and the accumulation adds the same values in the same order, so a run
+with programs equals a run without them bit for bit
+(tests/test_chunk_program_gpu.py; WB2HIP_CHUNK_PROGRAM=0 disables, =verify
+runs both paths on every chunk and compares).
+"""
+from __future__ import annotations
+
+import os
+import threading
+import typing as t
+
+import numpy as np
+import torch
+
+from weatherbench2_amd import _lib, engine
+from weatherbench2_amd import xarray_lite as xl
+
+_THIRD = 1.0 / 3.0
+_MAX_ELEMENTS = 1 << 21   # k + 1/3 must survive float32 with floor(.) == k
+
+
+class _Active(threading.local):
+
+  def __init__(self):
+    self.recorder = None
+
+
+_ACTIVE = _Active()
+
+
+def recorder():
+  """The recorder watching the calling thread's launches, or None."""
+  return _ACTIVE.recorder
+
+
+def mode() -> str:
+  return os.environ.get('WB2HIP_CHUNK_PROGRAM', '1')
+
+
+class Recorder:
+  """Collects the fused launches of one pass of the loop (`probe` = False) or
+  stands in for them with index-valued results (`probe` = True)."""
+
+  def __init__(self, probe: bool = False):
+    self.probe = probe
+    self.launches: list = []      # dicts, in launch order
+    self.tables: dict = {}        # id(table) -> (table, recompute(forecast))
+    self.offset = 0               # probe: elements handed out so far
+
+  def __enter__(self):
+    self._old = _ACTIVE.recorder
+    _ACTIVE.recorder = self
+    return self
+
+  def __exit__(self, *exc):
+    _ACTIVE.recorder = self._old
+
+  def note_table(self, table, recompute) -> None:
+    """`table` (a slab table the generic path derived from the chunk's LABELS)
+    is what `recompute(forecast)` returns for another chunk."""
+    if table is not None:
+      self.tables[id(table)] = (table, recompute)
+
+  def fake_metrics(self, n_metric, n_region, n_outer, device):
+    n = n_metric * n_region * n_outer
+    out = (torch.arange(self.offset, self.offset + n, dtype=torch.float64,
+                        device=device) + _THIRD).reshape(n_metric, n_region,
+                                                         n_outer)
+    self.offset += n
+    self.launches.append({'n': n})
+    return out
+
+  def record(self, **launch) -> None:
+    self.launches.append(launch)
+
+
+# ---------------------------------------------------------------------------
+# structure signature
+# ---------------------------------------------------------------------------
+_VARYING = ('time', 'init_time', 'valid_time', 'lead_time',
+            'prediction_timedelta')
+
+
+def _data_sig(data):
+  if isinstance(data, torch.Tensor):
+    return ('t', tuple(data.shape), data.stride(), str(data.dtype),
+            str(data.device), data.data_ptr() % 16)
+  if isinstance(data, xl.SlabConcat) and data.on_device:
+    b = data.bases[0]
+    return ('c', tuple(data.shape), len(data.bases), tuple(b.shape),
+            str(b.dtype), engine.digest(data.index))
+  return None
+
+
+def signature(forecast: xl.Dataset, truth: xl.Dataset):
+  """Everything about a (forecast, truth) pair that shapes the loop's host
+  work EXCEPT the addresses of its arrays and the values of its time
+  coordinates; None if the pair holds anything a program cannot address
+  (host arrays, lazy gathers)."""
+  parts = []
+  for ds in (forecast, truth):
+    for name, da in ds.data_vars.items():
+      sig = _data_sig(da.data)
+      if sig is None:
+        return None
+      parts.append((name, tuple(da.dims), sig))
+    for k, c in ds.coords.items():
+      if isinstance(c, xl.DataArray):
+        v, dims = np.asarray(c.values), tuple(c.dims)
+      else:
+        v, dims = np.asarray(c), None
+      if k in _VARYING or (dims and any(d in _VARYING for d in dims)):
+        parts.append((k, dims, v.shape, v.dtype.str))
+      elif v.dtype == object:
+        parts.append((k, dims, tuple(v.ravel().tolist())))
+      else:
+        parts.append((k, dims, v.shape, v.dtype.str, engine.digest(v)))
+    parts.append(None)
+  return tuple(parts)
+
+
+# ---------------------------------------------------------------------------
+# building
+# ---------------------------------------------------------------------------
+class _Launch:
+  """One recorded launch, ready to be re-addressed."""
+
+  def __init__(self, rec: dict, fmap: dict, tmap: dict, device):
+    pl, n_total = rec['plan'], rec['n_total']
+    if rec.get('aux') is not None:
+      raise _NotReplayable('a launch with an auxiliary field')
+    members = rec['members']   # [(geo, arrays, tables, tensors)]
+    n_in = len(members[0][1])
+    self.plan, self.mode, self.skipna = pl, rec['mode'], rec['skipna']
+    self.dtype, self.n_total, self.n_in = rec['dtype'], n_total, n_in
+    self.slot = np.zeros((n_in, n_total), dtype=np.int64)
+    self.rel = np.zeros((n_in, n_total), dtype=np.int64)
+    self.sources: list = []    # how to get pointer `slot` of a new chunk
+    self.dynamic: list = []    # (j, off, n, tensor, recompute, geo)
+    self.keep: list = []
+    source_of: dict = {}
+
+    def slot_for(key, getter):
+      if key not in source_of:
+        source_of[key] = len(self.sources)
+        self.sources.append(getter)
+      return source_of[key]
+    off = 0
+    for geo, arrays, tables, tensors in members:
+      n = geo.n_outer
+      for j, (raw, tb, x) in enumerate(zip(arrays, tables, tensors)):
+        role = fmap.get(id(raw)) or tmap.get(id(raw))
+        if role is not None:
+          which, name = role
+          if isinstance(x, xl.SlabConcat):
+            step = (x.slab_shape[0] * x.slab_shape[1] *
+                    x.bases[0].element_size())
+            index = x.index.ravel() if tb is None else x.index.ravel()[tb]
+            base = np.searchsorted(x.offsets, index, side='right') - 1
+            self.rel[j, off:off + n] = (index - x.offsets[base]) * step
+            for k in np.unique(base):
+              s = slot_for((which, name, int(k)),
+                           lambda f, t_, w=which, nm=name, k=int(k): (
+                               f if w == 'f' else t_)[nm].data.bases[k])
+              self.slot[j, off:off + n][base == k] = s
+          else:
+            from weatherbench2_amd import metrics as gm
+            addr, _ = gm._slab_addresses(x, tb, pl.n_row, pl.n_col, n)
+            self.rel[j, off:off + n] = addr - x.data_ptr()
+            self.slot[j, off:off + n] = slot_for(
+                (which, name), lambda f, t_, w=which, nm=name: (
+                    f if w == 'f' else t_)[nm].data)
+          continue
+        # not a variable of the chunk: a resident array (the climatology)
+        if not isinstance(x, (torch.Tensor, xl.SlabGather)):
+          raise _NotReplayable(f'input {j}: {type(x).__name__}')
+        hit = rec['tables'].get(id(tb)) if tb is not None else None
+        base_tensor = x.base if isinstance(x, xl.SlabGather) else x
+        self.keep.append(base_tensor)
+        self.slot[j, off:off + n] = slot_for(
+            ('r', id(base_tensor)), lambda f, t_, b=base_tensor: b)
+        from weatherbench2_amd import metrics as gm
+        addr, _ = gm._slab_addresses(x, tb, pl.n_row, pl.n_col, n)
+        self.rel[j, off:off + n] = addr - base_tensor.data_ptr()
+        if hit is not None:  # its table follows the chunk's labels
+          self.dynamic.append((j, off, n, x, hit[1], geo, base_tensor))
+        elif tb is not None and n > 1 and _label_dependent(geo):
+          # a table nobody explained, over dims that carry time labels
+          raise _NotReplayable(f'input {j}: unexplained slab table')
+      off += n
+    self.n_metric = _lib.GENERIC_KQ.get(self.mode, _lib.NMETRIC)
+    self.n_values = self.n_metric * pl.n_region * n_total
+    self.step = engine.SuiteStep(pl, self.mode, self.dtype, self.skipna,
+                                 n_total, by_address=True)
+    self._dyn_groups: dict = {}
+
+  def addresses(self, forecast, truth) -> np.ndarray:
+    ptrs = np.fromiter((g(forecast, truth).data_ptr() for g in self.sources),
+                       dtype=np.int64, count=len(self.sources))
+    addr = ptrs[self.slot] + self.rel
+    if self.dynamic:
+      from weatherbench2_amd import metrics as gm
+      memo: dict = {}
+      for j, off, n, x, recompute, geo, base in self.dynamic:
+        table = recompute(forecast, memo)
+        a, _ = gm._slab_addresses(x, table, self.plan.n_row, self.plan.n_col, n)
+        addr[j, off:off + n] = a
+    return addr
+
+
+class _NotReplayable(Exception):
+  pass
+
+
+def _label_dependent(geo) -> bool:
+  return any(d in _VARYING for d in geo.out_dims)
+
+
+def _nan_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
+  if a.shape != b.shape or a.dtype != b.dtype:
+    return False
+  return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
+
+
+class ChunkProgram:
+  """The replayable form of one chunk structure (see the module docstring)."""
+
+  def __init__(self, launches, variables, arena, device, time_dim, split_dim):
+    self.launches = launches       # [_Launch]
+    self.variables = variables     # [(name, dims, shape, axis, src, round32)]
+    self.arena = arena             # float64 device tensor: launch outputs
+    self.device = device
+    self.time_dim, self.split_dim = time_dim, split_dim
+    off = 0
+    self.slices = []
+    for la in launches:
+      self.slices.append(arena[off:off + la.n_values].view(
+          la.n_metric, la.plan.n_region, la.n_total))
+      off += la.n_values
+    # every variable's [element][time] source table, one after the other
+    src = np.concatenate([v[4].ravel() for v in variables]).astype(np.int32)
+    r32 = np.concatenate([v[5] for v in variables]).astype(np.uint8)
+    self.n_time = variables[0][4].shape[1]
+    self.n_out = int(r32.size)
+    self.src = torch.as_tensor(src).to(device)
+    self.round32 = torch.as_tensor(r32).to(device)
+    self._targets: dict = {}  # lead-label bytes -> (ptr stamp, sum, count)
+    self._lib = _lib.load()
+
+  # -- accumulator addresses --------------------------------------------------
+  def _accumulator_tables(self, mean, labels):
+    """Device tables of the (sum, count) ADDRESS of every output element for
+    chunks that carry the split-dim (lead) labels `labels`; cached per label
+    set, rebuilt when an accumulator has been reallocated (grown)."""
+    key = None if labels is None else (labels.dtype.str, labels.tobytes())
+    accs = [mean._acc[v[0]] for v in self.variables]
+    hit = self._targets.get(key)
+    if hit is not None and hit[0] == tuple(a.total.data_ptr() for a in accs):
+      return hit[1], hit[2]
+    sums, counts = [], []
+    for (name, dims, shape, axis, src, _), acc in zip(self.variables, accs):
+      if acc.split is not None:
+        rows = acc.rows(labels)   # (may grow the accumulator: pointers below)
+        acc.shape = tuple(n for d, n in zip(dims, shape) if d != self.time_dim)
+        dst = acc.destinations(rows)
+      else:
+        dst = np.arange(src.shape[0], dtype=np.int64)
+      if dst.size != src.shape[0]:
+        raise ValueError(f'{name}: accumulator layout changed')
+      sums.append(acc.total.data_ptr() + 8 * dst)
+      counts.append(acc.count.data_ptr() + 8 * dst)
+    stamp = tuple(a.total.data_ptr() for a in accs)
+    d_sum = engine.upload_table(np.concatenate(sums), self.device, cache=False)
+    d_cnt = engine.upload_table(np.concatenate(counts), self.device,
+                                cache=False)
+    if len(self._targets) > 256:
+      self._targets.clear()
+    self._targets[key] = (stamp, d_sum, d_cnt)
+    return d_sum, d_cnt
+
+  # -- replay -------------------------------------------------------------------
+  def run(self, forecast: xl.Dataset, truth: xl.Dataset, mean) -> None:
+    stream = engine.current_stream_ptr(self.device)
+    for la, out in zip(self.launches, self.slices):
+      addr = la.addresses(forecast, truth)
+      aligned = not (addr & 15).any()
+      dev_addr = engine.upload_table(addr, self.device, cache=False)
+      la.step.aligned = bool(aligned)
+      la.step.run(None, list(dev_addr), metrics=out)
+    labels = None
+    if self.split_dim is not None:
+      labels = np.asarray(forecast.coords[self.split_dim])
+    d_sum, d_cnt = self._accumulator_tables(mean, labels)
+    status = self._lib.wb2_gather_accumulate(
+        self.arena.data_ptr(), self.src.data_ptr(), self.round32.data_ptr(),
+        self.n_out, self.n_time, int(mean.skipna), d_sum.data_ptr(),
+        d_cnt.data_ptr(), stream)
+    if status != 0:
+      _lib.check(status, 'wb2_gather_accumulate')
+
+
+def build(first: Recorder, forecast: xl.Dataset, truth: xl.Dataset, result,
+          mean, loop) -> t.Optional[ChunkProgram]:
+  """The program of the structure of (forecast, truth), from the recorder that
+  watched the generic pass over it (`result` = what that pass returned, already
+  added to `mean`), or None when the structure cannot be replayed.  `loop()`
+  runs the generic pass again (under the probe recorder)."""
+  try:
+    return _build(first, forecast, truth, result, mean, loop)
+  except _NotReplayable:
+    return None
+
+
+def _build(first, forecast, truth, result, mean, loop):
+  launches_rec = [l for l in first.launches if 'plan' in l]
+  if not launches_rec:
+    return None
+  device = launches_rec[0]['plan'].device
+  total = sum(int(l['metrics'].numel()) for l in launches_rec)
+  if total >= _MAX_ELEMENTS:
+    return None
+  time_dim, split_dim = mean.dim, mean.split_dim
+  fmap = {id(v.data): ('f', k) for k, v in forecast.data_vars.items()}
+  tmap = {id(v.data): ('t', k) for k, v in truth.data_vars.items()}
+  for l in launches_rec:
+    l['tables'] = first.tables
+  launches = [_Launch(l, fmap, tmap, device) for l in launches_rec]
+  # ---- probe: which output element does every result element show?
+  with Recorder(probe=True) as probe:
+    shown = xl.as_dataset(loop())
+  if [l['n'] for l in probe.launches] != [la.n_values for la in launches]:
+    return None
+  variables = []
+  flat_real = torch.cat([l['metrics'].reshape(-1) for l in launches_rec])
+  for name, da in shown.data_vars.items():
+    real = result.data_vars.get(name)
+    if real is None or not isinstance(da.data, torch.Tensor) or not isinstance(
+        real.data, torch.Tensor) or tuple(real.dims) != tuple(da.dims):
+      return None
+    if time_dim not in da.dims:
+      return None
+    axis = da.dims.index(time_dim)
+    v = da.data.to(torch.float64)
+    k = torch.floor(v)
+    fill = torch.isnan(v)
+    frac = v - k
+    exact = frac == torch.tensor(_THIRD, dtype=torch.float64, device=v.device)
+    # exact: the element is an output element as it is; otherwise it must be
+    # that element rounded to float32 (k + 1/3 in float32, widened again)
+    as32 = (k + _THIRD).to(torch.float32).to(torch.float64)
+    rounded = (~exact) & (v == as32)
+    if not bool((fill | exact | rounded).all().item()):
+      return None   # some arithmetic happened on the way: not a program
+    src = torch.where(fill, torch.full_like(k, -1.0), k).to(torch.int64)
+    if bool((src >= total).any().item()):
+      return None
+    # verify on the real first chunk
+    picked = flat_real[src.clamp(min=0)]
+    picked = torch.where(rounded,
+                         picked.to(torch.float32).to(torch.float64), picked)
+    picked = torch.where(fill, torch.full_like(picked, float('nan')), picked)
+    if not _nan_equal(picked.to(real.data.dtype), real.data):
+      return None
+    if real.data.dtype == torch.float32 and bool(exact.any().item()):
+      return None   # a float32 result the rounding rule does not explain
+    moved = src.movedim(axis, -1)          # [..., time]
+    n_time = moved.shape[-1]
+    # an element's time steps come from one metric row: one flag per element
+    flags = rounded.movedim(axis, -1).reshape(-1, n_time)
+    if not bool((flags == flags[:, :1]).all().item()):
+      return None
+    variables.append((name, tuple(da.dims), tuple(da.shape), axis,
+                      moved.reshape(-1, n_time).cpu().numpy(),
+                      flags[:, 0].cpu().numpy()))
+    acc = mean._acc.get(name)
+    if acc is None or acc.dims != tuple(d for d in da.dims if d != time_dim):
+      return None
+  if set(result.data_vars) != {v[0] for v in variables}:
+    return None
+  if len({v[4].shape[1] for v in variables}) != 1:
+    return None
+  arena = torch.empty((total,), dtype=torch.float64, device=device)
+  return ChunkProgram(launches, variables, arena, device, time_dim, split_dim)
