@@ -234,7 +234,7 @@ def host_chunks(chunks, pool: int):
   return out
 
 
-def measure_host_fed(chunks, cfg, n_chunks: int = 48, pool: int = 6,
+def measure_host_fed(chunks, cfg, n_chunks: int = 144, pool: int = 6,
                      prefetch: int = 2) -> dict:
   """`api_official_chunk.host_fed`: forecast chunks arrive as pageable NumPy
   arrays and cross PCIe inside evaluate_chunks (the fetch thread stages them
@@ -287,7 +287,7 @@ def dev_of(chunks):
   return next(iter(chunks[0][1].data_vars.values())).data.device
 
 
-def run(dev, n_chunks: int = 128, pool: int = 32,
+def run(dev, n_chunks: int = 512, pool: int = 32,
         batches=(1, 16, 32, None), headline_batch=None,
         host_fed: bool = False) -> dict:
   """The `api_official_chunk` object of the bench record."""
@@ -299,12 +299,11 @@ def run(dev, n_chunks: int = 128, pool: int = 32,
   for b in batches:
     gm.clear_caches()
     measure(chunks[:max(2 * (b or 24), 8)], cfg, b, timed_events=False)  # warm
-    # host-bound small batches: a 64-chunk sample (3 ms per chunk); the rest
-    # run the whole list (the first window's host time is not overlapped: a
-    # fill effect of 1 / windows)
+    # the whole list: the first chunk (window) of a structure runs the generic
+    # path twice to build its program (program.py) -- a one-off that a
+    # production run spreads over ~10^5 chunks, here over 512
     name = 'default' if b is None else str(b)
-    legs[name] = measure(chunks if (b is None or b >= 8) else chunks[:64],
-                         cfg, b)
+    legs[name] = measure(chunks, cfg, b)
   head_name = 'default' if headline_batch is None else str(headline_batch)
   head = legs[head_name] if head_name in legs else legs[list(legs)[-1]]
   out = dict(head)
@@ -329,7 +328,7 @@ def run(dev, n_chunks: int = 128, pool: int = 32,
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--chunks', type=int, default=128)
+  ap.add_argument('--chunks', type=int, default=512)
   ap.add_argument('--pool', type=int, default=32,
                   help='distinct device-resident chunks (>= the largest window)')
   ap.add_argument('--batch', default='1,16,32,default')

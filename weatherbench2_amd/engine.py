@@ -220,12 +220,11 @@ def upload_table(table: np.ndarray, device, cache: bool = True) -> torch.Tensor:
       events[nxt].synchronize()
     slot = slots[nxt][:table.size]
     slot.numpy()[...] = table.reshape(-1)
-    stream = torch.cuda.current_stream(device)
-    with torch.cuda.stream(stream):
-      dev = torch.empty(table.shape, dtype=torch.int64, device=device)
-      dev.view(-1).copy_(slot, non_blocking=True)
+    # (the current stream of `device`: allocation and copy are queued on it)
+    dev = torch.empty(table.shape, dtype=torch.int64, device=device)
+    dev.view(-1).copy_(slot, non_blocking=True)
     ev = torch.cuda.Event()
-    ev.record(stream)
+    ev.record()
     events[nxt] = ev
   if key is not None:
     if len(st.cache) >= 512:
@@ -437,7 +436,8 @@ class SuiteStep:
 
   def run(self, inputs: t.Optional[t.Sequence[torch.Tensor]],
           tables: t.Sequence[t.Optional[torch.Tensor]],
-          metrics: t.Optional[torch.Tensor] = None) -> torch.Tensor:
+          metrics: t.Optional[torch.Tensor] = None,
+          stream_ptr: t.Optional[int] = None) -> torch.Tensor:
     """Enqueues the step on the current stream.  `inputs` + slab-number
     `tables` (None entries = identity), or inputs=None + address tables
     (by_address).  Returns the metrics tensor [n_metric, n_region, n_outer]
@@ -446,12 +446,18 @@ class SuiteStep:
     out = self.metrics if metrics is None else metrics
     if self.by_address != (inputs is None):
       raise ValueError('by_address steps take inputs=None and address tables')
+    hook = _LAUNCH_HOOK
+    if hook is not None:  # (brackets K1 + K2 [+ the accumulation] here)
+      hook('begin', 'stream_partials')
     status = self._fn(
         self._tables_ref, self.mode, self.code, int(self.skipna),
         None if inputs is None else _lib.ptr_array(inputs),
         _lib.ptr_array(tables), int(self.aligned), self.n_outer,
         self.partials.data_ptr(), out.data_ptr(), *self._acc,
-        current_stream_ptr(self.plan.device))
+        current_stream_ptr(self.plan.device) if stream_ptr is None
+        else stream_ptr)
+    if hook is not None:
+      hook('end', 'stream_partials')
     if status != 0:
       _lib.check(status, 'wb2_det_suite_step')
     return out

@@ -114,6 +114,23 @@ _VARYING = ('time', 'init_time', 'valid_time', 'lead_time',
             'prediction_timedelta')
 
 
+_DIGESTS: dict = {}   # id(array) -> (array, digest): coordinates recur
+
+
+def _digest(v: np.ndarray):
+  """Content digest of a coordinate array, remembered per array OBJECT (kept
+  alive here, so the id cannot be reused): chunks of one dataset share their
+  latitude / longitude / level arrays, and nobody writes into coordinates."""
+  hit = _DIGESTS.get(id(v))
+  if hit is not None and hit[0] is v:
+    return hit[1]
+  d = engine.digest(v)
+  if len(_DIGESTS) > 256:
+    _DIGESTS.clear()
+  _DIGESTS[id(v)] = (v, d)
+  return d
+
+
 def _data_sig(data):
   if isinstance(data, torch.Tensor):
     return ('t', tuple(data.shape), data.stride(), str(data.dtype),
@@ -139,15 +156,17 @@ def signature(forecast: xl.Dataset, truth: xl.Dataset):
       parts.append((name, tuple(da.dims), sig))
     for k, c in ds.coords.items():
       if isinstance(c, xl.DataArray):
-        v, dims = np.asarray(c.values), tuple(c.dims)
+        v, dims = c.values, tuple(c.dims)
       else:
-        v, dims = np.asarray(c), None
+        v, dims = c, None
+      if not isinstance(v, np.ndarray):
+        v = np.asarray(v)
       if k in _VARYING or (dims and any(d in _VARYING for d in dims)):
         parts.append((k, dims, v.shape, v.dtype.str))
       elif v.dtype == object:
         parts.append((k, dims, tuple(v.ravel().tolist())))
       else:
-        parts.append((k, dims, v.shape, v.dtype.str, engine.digest(v)))
+        parts.append((k, dims, v.shape, v.dtype.str, _digest(v)))
     parts.append(None)
   return tuple(parts)
 
@@ -245,6 +264,16 @@ class _NotReplayable(Exception):
   pass
 
 
+# why the last structures were not given a program (diagnostics, tests)
+REASONS: list = []
+
+
+def _no(reason: str):
+  REASONS.append(reason)
+  del REASONS[:-16]
+  return None
+
+
 def _label_dependent(geo) -> bool:
   return any(d in _VARYING for d in geo.out_dims)
 
@@ -319,7 +348,7 @@ class ChunkProgram:
       aligned = not (addr & 15).any()
       dev_addr = engine.upload_table(addr, self.device, cache=False)
       la.step.aligned = bool(aligned)
-      la.step.run(None, list(dev_addr), metrics=out)
+      la.step.run(None, list(dev_addr), metrics=out, stream_ptr=stream)
     labels = None
     if self.split_dim is not None:
       labels = np.asarray(forecast.coords[self.split_dim])
@@ -340,18 +369,18 @@ def build(first: Recorder, forecast: xl.Dataset, truth: xl.Dataset, result,
   runs the generic pass again (under the probe recorder)."""
   try:
     return _build(first, forecast, truth, result, mean, loop)
-  except _NotReplayable:
-    return None
+  except _NotReplayable as e:
+    return _no(f'not replayable: {e}')
 
 
 def _build(first, forecast, truth, result, mean, loop):
   launches_rec = [l for l in first.launches if 'plan' in l]
   if not launches_rec:
-    return None
+    return _no('no launch recorded')
   device = launches_rec[0]['plan'].device
   total = sum(int(l['metrics'].numel()) for l in launches_rec)
   if total >= _MAX_ELEMENTS:
-    return None
+    return _no('too many output elements')
   time_dim, split_dim = mean.dim, mean.split_dim
   fmap = {id(v.data): ('f', k) for k, v in forecast.data_vars.items()}
   tmap = {id(v.data): ('t', k) for k, v in truth.data_vars.items()}
@@ -362,55 +391,55 @@ def _build(first, forecast, truth, result, mean, loop):
   with Recorder(probe=True) as probe:
     shown = xl.as_dataset(loop())
   if [l['n'] for l in probe.launches] != [la.n_values for la in launches]:
-    return None
+    return _no('probe saw other launches')
   variables = []
   flat_real = torch.cat([l['metrics'].reshape(-1) for l in launches_rec])
   for name, da in shown.data_vars.items():
     real = result.data_vars.get(name)
     if real is None or not isinstance(da.data, torch.Tensor) or not isinstance(
         real.data, torch.Tensor) or tuple(real.dims) != tuple(da.dims):
-      return None
+      return _no('result variable missing / not a device tensor / other dims')
     if time_dim not in da.dims:
-      return None
+      return _no('no time dim in a result variable')
     axis = da.dims.index(time_dim)
     v = da.data.to(torch.float64)
     k = torch.floor(v)
     fill = torch.isnan(v)
-    frac = v - k
-    exact = frac == torch.tensor(_THIRD, dtype=torch.float64, device=v.device)
+    u = k + _THIRD                # what launch element k holds, in float64
+    exact = v == u
     # exact: the element is an output element as it is; otherwise it must be
     # that element rounded to float32 (k + 1/3 in float32, widened again)
-    as32 = (k + _THIRD).to(torch.float32).to(torch.float64)
+    as32 = u.to(torch.float32).to(torch.float64)
     rounded = (~exact) & (v == as32)
     if not bool((fill | exact | rounded).all().item()):
-      return None   # some arithmetic happened on the way: not a program
+      return _no('values were computed, not moved')
     src = torch.where(fill, torch.full_like(k, -1.0), k).to(torch.int64)
     if bool((src >= total).any().item()):
-      return None
+      return _no('source index out of range')
     # verify on the real first chunk
     picked = flat_real[src.clamp(min=0)]
     picked = torch.where(rounded,
                          picked.to(torch.float32).to(torch.float64), picked)
     picked = torch.where(fill, torch.full_like(picked, float('nan')), picked)
     if not _nan_equal(picked.to(real.data.dtype), real.data):
-      return None
+      return _no('mapping does not reproduce the first chunk')
     if real.data.dtype == torch.float32 and bool(exact.any().item()):
-      return None   # a float32 result the rounding rule does not explain
+      return _no('float32 result without float32 rounding')
     moved = src.movedim(axis, -1)          # [..., time]
     n_time = moved.shape[-1]
     # an element's time steps come from one metric row: one flag per element
     flags = rounded.movedim(axis, -1).reshape(-1, n_time)
     if not bool((flags == flags[:, :1]).all().item()):
-      return None
+      return _no('time steps of an element differ in rounding')
     variables.append((name, tuple(da.dims), tuple(da.shape), axis,
                       moved.reshape(-1, n_time).cpu().numpy(),
                       flags[:, 0].cpu().numpy()))
     acc = mean._acc.get(name)
     if acc is None or acc.dims != tuple(d for d in da.dims if d != time_dim):
-      return None
+      return _no('accumulator layout differs')
   if set(result.data_vars) != {v[0] for v in variables}:
-    return None
+    return _no('result variables differ')
   if len({v[4].shape[1] for v in variables}) != 1:
-    return None
+    return _no('time lengths differ')
   arena = torch.empty((total,), dtype=torch.float64, device=device)
   return ChunkProgram(launches, variables, arena, device, time_dim, split_dim)
