@@ -295,7 +295,8 @@ def parse_args():
                        'for A/B runs of kernel changes')
   ap.add_argument('--workload', default='deterministic',
                   choices=['deterministic', 'ensemble', 'spectrum',
-                           'spectrum_materialized', 'spectrum_mean'],
+                           'spectrum_materialized', 'spectrum_mean',
+                           'spectrum_materialized_f64', 'spectrum_mean_f64'],
                   help='deterministic = BASELINE configs[1] (the headline '
                        'metric); ensemble / spectrum = configs[2] / [3] '
                        '(spectrum + area-weighted latitude mean, fused); '
@@ -732,6 +733,12 @@ def main():
   if solo and args.detail and not args.no_secondary:
     # ---- every other instantiation against its own roofline (--detail only:
     # minutes of GPU time that the contract run does not need)
+    for name in ('spectrum_materialized_f64', 'spectrum_mean_f64'):
+      leg(name, lambda name=name: {
+          k: v for k, v in secondary(name, 20, 5, 20.0, args.members,
+                                     0).items()
+          if k in ('value', 'unit', 'ms_per_step', 'config', 'roofline',
+                   'dtype')})
     leg('variants', k1_variants, dev, fpool, tpool, cpool, units, pool)
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import k3_variants
@@ -1139,6 +1146,7 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
   gen = torch.Generator(device=dev).manual_seed(99)
   events = []
   timer = KernelTimer()
+  f64 = False
   if args.workload == 'ensemble':
     m = args.members
     n_slab = 13            # one unit of 13 levels per step
@@ -1166,10 +1174,15 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
                 'spread/skill + ensemble-mean MSE + variance + debiased MSE, '
                 '13 regions')
   else:
+    # `_f64`: float64 rows (complex128 transform, fft_core.hpp templated on
+    # the scalar type): 8 B/pt read
+    f64 = args.workload.endswith('_f64')
+    if f64:
+      args.workload = args.workload[:-4]
     units = args.spectrum_units
     pool = max(2, 48 // units)   # 2.6 GB of distinct input >> Infinity Cache
     x = torch.randn((pool * units, N_LEV, N_LAT, N_LON), generator=gen,
-                    device=dev)
+                    device=dev, dtype=torch.float64 if f64 else torch.float32)
     from weatherbench2_amd.derived_variables import ZonalEnergySpectrum
     circ = torch.as_tensor(ZonalEnergySpectrum._circumference(lat)).to(dev)
     w_host = plan_lib.get_lat_weights(lat)
@@ -1178,15 +1191,16 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
     w_row = (w_lat * circ).contiguous()
     pts = units * PTS_PER_UNIT
     n_bins = N_LON // 2 + 1
-    bytes_per_pt = 4.0 + n_bins * 8.0 / N_LON
+    in_bytes = 8.0 if f64 else 4.0
+    bytes_per_pt = in_bytes + n_bins * 8.0 / N_LON
     if args.workload == 'spectrum_mean':
-      bytes_per_pt = 4.0 + n_bins * 8.0 / N_LON / units
+      bytes_per_pt = in_bytes + n_bins * 8.0 / N_LON / units
     if args.workload == 'spectrum':
       # fused latitude mean, SURVEY 8d strictly: 4 B/pt read + the ONE reduced
       # 721-bin float64 spectrum per field.  The per-segment partial spectra
       # the two-step reduction writes and re-reads are scratch: they show up
       # in `traffic` (1.04 x), not here
-      bytes_per_pt = 4.0 + n_bins * 8.0 / (N_LAT * N_LON)
+      bytes_per_pt = in_bytes + n_bins * 8.0 / (N_LAT * N_LON)
 
     def step(i, timed):
       xs = x[(i % pool) * units:(i % pool + 1) * units]
@@ -1247,6 +1261,9 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
                                  'materialised, 8 B/pt), then their area-weighted '
                                  'latitude mean (K7; the roofline entry is the '
                                  'spectrum kernel alone)'}[args.workload]
+  if f64:
+    kernel = kernel.replace('<720,', '<720 complex128 points,')
+    workload = workload.replace(' f32', ' f64 (complex128 transform)')
   ramp(lambda: step(0, False), args.ramp_ms)
   for i in range(args.warmup):
     step(i, False)
@@ -1265,7 +1282,8 @@ def secondary(workload_name, steps, warmup, ramp_ms, members=50,
       'value': pts * args.steps / dt, 'unit': 'grid-point-evals/s',
       'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f64' if f64 else 'f32', 'data': 'synthetic',
       'config': {'workload': workload},
       'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved,
                    'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -138,3 +138,63 @@ def test_a_change_of_structure_gets_a_program_of_its_own(monkeypatch):
     assert outs[1] is outs[0]
   else:
     _same(outs[1], outs[0])
+
+
+@pytest.mark.parametrize('batch', [1, 3, None])
+def test_seeps_in_windows_and_programs(batch, monkeypatch):
+  """SEEPS (metrics.py:417-524; `--compute_seeps=True` of the official command
+  line) beside the deterministic suite: its pass has an auxiliary field (the
+  masked dry fraction, resident per climatology) and a table that follows the
+  valid time -- windows of chunks and replayed programs give the bits of the
+  chunk-by-chunk generic path, which equals the oracle's SEEPS."""
+  import torch
+  from oracle import metrics_np as om
+  from oracle.named import DS, NA
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  forecast, truth, clim = oc.make(n_init=4, n_lead=2, n_lat=31, n_lon=72)
+  name = '2m_temperature'
+  rs = np.random.RandomState(5)
+  shape = clim[name].data.shape
+  cdims = clim[name].dims
+  cvars = dict(clim.items())
+  cvars[f'{name}_seeps_threshold'] = NA(
+      rs.uniform(0.3, 1.2, size=shape).astype(np.float32), cdims)  # > dry
+  frac = rs.uniform(0.0, 1.0, size=shape).astype(np.float32)
+  frac[:, :, 3, 5] = np.nan
+  cvars[f'{name}_seeps_dry_fraction'] = NA(frac, cdims)
+  clim = DS(cvars, clim.coords)
+  lat, lon = forecast.coords['latitude'], forecast.coords['longitude']
+  oregions = {'global': None, 'tropics': None}
+  from oracle import regions_np as oreg
+  oregions = {'global': oreg.SliceRegion(),
+              'tropics': oreg.SliceRegion(lat_slice=slice(-20, 20))}
+  gregions = {k: helpers.to_gpu_region(v) for k, v in oregions.items()}
+  gf, gt, gc = (evaluation.make_resident(helpers.to_gpu_dataset(x))
+                for x in (forecast, truth, clim))
+  metrics = oc.product_metrics(gm, gc)
+  metrics['seeps'] = gm.SEEPS(climatology=gc, precip_name=name,
+                              dry_threshold_mm=100.0)
+  cfg = config.Eval(metrics=metrics, regions=gregions)
+  chunks = oc.chunk_pairs(gf, gt)
+  kwargs = {} if batch is None else {'batch_chunks': batch}
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                                    batch_chunks=1)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+  calls = _count_runs(monkeypatch)
+  got = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, **kwargs)
+  _same(got, want)
+  if batch == 1:
+    assert len(calls) == len(chunks) - 1
+  # against the oracle: the time mean of the per-chunk SEEPS
+  oseeps = om.SEEPS(climatology=clim, precip_name=name, dry_threshold_mm=100.0)
+  mi = list(got.coords['metric']).index('seeps')
+  for ri, (rname, region) in enumerate(oregions.items()):
+    with np.errstate(all='ignore'):
+      per = oseeps.compute_chunk(forecast, truth, region=region)[name]
+    ax = per.dims.index('init_time')
+    want_mean = np.asarray(per.data, dtype=np.float64).mean(axis=ax)
+    vals = got[name].values[mi, ri]
+    helpers.assert_close(vals, want_mean.reshape(vals.shape), rtol=1e-9,
+                         atol=1e-12, err_msg=rname)

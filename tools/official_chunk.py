@@ -45,12 +45,19 @@ WIND = (('u_component_of_wind', 'v_component_of_wind', 'wind_vector'),
          '10m_wind_vector'))
 SLABS_PER_CHUNK = len(VARS_3D) * N_LEV + len(VARS_2D)           # 85
 WIND_SLABS_PER_CHUNK = N_LEV + 1                                # 14 (u, v) pairs
+SEEPS = (('seeps_24hr', 'total_precipitation_24hr', 0.25),
+         ('seeps_6hr', 'total_precipitation_6hr', 0.1))
 PTS_PER_CHUNK = SLABS_PER_CHUNK * N_LAT * N_LON
-# algorithmic bytes: 12 B per point of every variable (forecast +
-# truth + climatology) + 16 B per point of every wind-vector pair (u, v of
-# forecast and truth, read again by the wind-vector pass)
+# ALGORITHMIC bytes, strictly (every metric shares one read of its
+# inputs): 12 B per point of every variable (forecast + truth + climatology)
+# + the two SEEPS wet-threshold fields (4 B per point each).  What the passes
+# read on top of that is re-read traffic, not algorithm: the wind-vector pass
+# reads u, v of forecast and truth again (16 B per point of 14 pairs), the two
+# SEEPS passes their forecast / truth precipitation (8 B per point each).
 DET_BYTES_PER_CHUNK = PTS_PER_CHUNK * 12.0
+SEEPS_BYTES_PER_CHUNK = len(SEEPS) * N_LAT * N_LON * 4.0
 WIND_BYTES_PER_CHUNK = WIND_SLABS_PER_CHUNK * N_LAT * N_LON * 16.0
+SEEPS_REREAD_PER_CHUNK = len(SEEPS) * N_LAT * N_LON * 8.0
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -78,9 +85,12 @@ class _Events:
       self.pairs.append(self.cur)
 
 
-def build(dev, n_chunks: int, pool: int, n_lead: int = 4):
+def build(dev, n_chunks: int, pool: int, n_lead: int = 4, seeps: bool = True):
   """(chunks, eval config): `n_chunks` (init_time=1, lead_time=1) chunk pairs
-  in init-major order over a pool of `pool` distinct device-resident chunks."""
+  in init-major order over a pool of `pool` distinct device-resident chunks;
+  `seeps`: the two SEEPS metrics of `--compute_seeps=True`
+  (scripts/evaluate.py:436-445) with their climatological wet thresholds and
+  dry fractions."""
   import torch
   import bench
   from weatherbench2_amd import config, metrics as gm
@@ -110,6 +120,9 @@ def build(dev, n_chunks: int, pool: int, n_lead: int = 4):
     f.update({k: randn(1, 1, N_LAT, N_LON) for k in VARS_2D})
     t = {k: randn(1, 1, N_LEV, N_LAT, N_LON) for k in VARS_3D}
     t.update({k: randn(1, 1, N_LAT, N_LON) for k in VARS_2D})
+    for _, precip, _ in SEEPS:   # precipitation is not negative
+      f[precip].abs_()
+      t[precip].abs_()
     pooled.append((f, t))
   ccoords = {'hour': np.array([0, 6, 12, 18]),
              'dayofyear': 1 + np.arange(n_day), 'level': level,
@@ -122,6 +135,14 @@ def build(dev, n_chunks: int, pool: int, n_lead: int = 4):
   for k in VARS_2D:
     clim[k] = xl.DataArray(randn(4, n_day, N_LAT, N_LON),
                            ('hour', 'dayofyear', 'latitude', 'longitude'))
+  if seeps:
+    for _, precip, _ in SEEPS:
+      clim[f'{precip}_seeps_threshold'] = xl.DataArray(
+          randn(4, n_day, N_LAT, N_LON).abs_() * 0.7 + 0.1,
+          ('hour', 'dayofyear', 'latitude', 'longitude'))
+      clim[f'{precip}_seeps_dry_fraction'] = xl.DataArray(
+          torch.rand((4, n_day, N_LAT, N_LON), device=dev, generator=g) * 0.9
+          + 0.02, ('hour', 'dayofyear', 'latitude', 'longitude'))
   chunks = []
   for j in range(n_chunks):
     i, l = divmod(j, n_lead)
@@ -137,11 +158,14 @@ def build(dev, n_chunks: int, pool: int, n_lead: int = 4):
     chunks.append((fd, td))
   wv = [gm.WindVectorMSE(u_name=u, v_name=v, vector_name=n)
         for u, v, n in WIND]
-  cfg = config.Eval(
-      metrics={'mse': gm.MSE(wind_vector_mse=wv),
-               'acc': gm.ACC(climatology=clim), 'bias': gm.Bias(),
-               'mae': gm.MAE()},
-      regions=bench.official_regions())
+  metrics = {'mse': gm.MSE(wind_vector_mse=wv),
+             'acc': gm.ACC(climatology=clim), 'bias': gm.Bias(),
+             'mae': gm.MAE()}
+  if seeps:
+    for key, precip, dry in SEEPS:
+      metrics[key] = gm.SEEPS(climatology=clim, precip_name=precip,
+                              dry_threshold_mm=dry)
+  cfg = config.Eval(metrics=metrics, regions=bench.official_regions())
   return chunks, cfg
 
 
@@ -187,31 +211,26 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
   }
   if timed_events and ev.pairs:
     ms = [a.elapsed_time(b) for a, b in ev.pairs]
-    # launches alternate (deterministic suite, wind vectors) per window
-    det, wind = sum(ms[0::2]), sum(ms[1::2])
-    if ev.launches == 2 * (len(ms) // 2) and len(ms) % 2 == 0:
-      leg['roofline'] = {
-          'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
-          'kernel': 'stream_partials_kernel<float,4,DET_ACC,WF> over '
-                    f'{SLABS_PER_CHUNK * batch} slabs + <float,4,WIND,WF> over '
-                    f'{WIND_SLABS_PER_CHUNK * batch} slabs per window',
-          'k1_ms_per_chunk': (det + wind) / n,
-          'det_acc': {'ms_per_launch': det / (len(ms) // 2),
-                      'achieved': n * DET_BYTES_PER_CHUNK / det / 1e6,
-                      'frac': n * DET_BYTES_PER_CHUNK / det / 1e6 /
-                              HBM_PEAK_GBPS},
-          'wind': {'ms_per_launch': wind / (len(ms) // 2),
-                   'achieved': n * WIND_BYTES_PER_CHUNK / wind / 1e6,
-                   'frac': n * WIND_BYTES_PER_CHUNK / wind / 1e6 /
-                           HBM_PEAK_GBPS},
-          'algorithmic_bytes_per_chunk': DET_BYTES_PER_CHUNK +
-                                         WIND_BYTES_PER_CHUNK,
-          'achieved': n * (DET_BYTES_PER_CHUNK + WIND_BYTES_PER_CHUNK) /
-                      (det + wind) / 1e6,
-      }
-      leg['roofline']['frac'] = leg['roofline']['achieved'] / HBM_PEAK_GBPS
-    else:
-      leg['k1_ms_per_chunk'] = sum(ms) / n
+    # every event pair brackets one fused launch (+ its K2): the deterministic
+    # suite over all variables, the wind vectors, the SEEPS passes
+    total_ms = sum(ms)
+    strict = DET_BYTES_PER_CHUNK + SEEPS_BYTES_PER_CHUNK
+    read = strict + WIND_BYTES_PER_CHUNK + SEEPS_REREAD_PER_CHUNK
+    leg['roofline'] = {
+        'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
+        'kernel': 'stream_partials_kernel<float,4,DET_ACC,WF> over '
+                  f'{SLABS_PER_CHUNK * batch} slabs + <float,4,WIND,WF> over '
+                  f'{WIND_SLABS_PER_CHUNK * batch} + 2 x <float,4,SEEPS> over '
+                  f'{batch} per window (K2 inside the brackets)',
+        'k1_ms_per_chunk': total_ms / n,
+        'algorithmic_bytes_per_chunk': strict,
+        'bytes_read_per_chunk': read,
+        # the wind-vector and SEEPS passes read inputs the first pass has read
+        'traffic_over_algorithmic': read / strict,
+        'achieved': n * strict / total_ms / 1e6,
+        'frac': n * strict / total_ms / 1e6 / HBM_PEAK_GBPS,
+        'frac_of_bytes_read': n * read / total_ms / 1e6 / HBM_PEAK_GBPS,
+    }
   del out
   return leg
 
@@ -318,8 +337,12 @@ def run(dev, n_chunks: int = 512, pool: int = 32,
                    'init_time=1,lead_time=1 chunks of 13 variables (6 x 13 '
                    f'levels + 7 surface = {SLABS_PER_CHUNK} slabs of '
                    f'{N_LAT}x{N_LON} f32), 16 regions incl. 3 land-sea-mask '
-                   'regions, mse (+ 2 wind vectors) + acc + bias + mae, '
-                   'evaluation.evaluate_chunks from device-resident chunks'),
+                   'regions, mse (+ 2 wind vectors) + acc + bias + mae + '
+                   'seeps_24hr + seeps_6hr (--compute_seeps=True), '
+                   'evaluation.evaluate_chunks from device-resident chunks; '
+                   'the `deterministic_temporal` config of the documented '
+                   'command line (the same passes without the time mean) is '
+                   'not in this leg'),
       'pool_chunks': pool, 'points_per_chunk': PTS_PER_CHUNK}
   del chunks, cfg
   torch.cuda.empty_cache()

@@ -810,6 +810,25 @@ class _ByRegion(dict):
     return self._as[want]
 
 
+_AUX: dict = {}   # id(host field) -> (host field, device tensor)
+
+
+def _resident_aux(aux, device) -> torch.Tensor:
+  """A mode's auxiliary 2-D field (SEEPS: the masked dry fraction, one per
+  climatology) on the device, uploaded once per host array OBJECT (kept alive
+  here; the metric objects cache their fields)."""
+  if isinstance(aux, torch.Tensor):
+    return aux
+  hit = _AUX.get((id(aux), str(device)))
+  if hit is not None and hit[0] is aux:
+    return hit[1]
+  ten = torch.as_tensor(np.ascontiguousarray(aux, dtype=np.float64)).to(device)
+  if len(_AUX) >= 16:
+    _AUX.clear()
+  _AUX[(id(aux), str(device))] = (aux, ten)
+  return ten
+
+
 def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
   """One fused pass (K1 + K2) per launch signature over the variables in
   `entries` = [(geo, arrays, tables)]: variables that share grid, layout and
@@ -831,7 +850,7 @@ def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
            geo.longitude.tobytes(), str(geo.longitude.dtype), dtype)
     groups.setdefault(sig, []).append(i)
   if aux is not None:
-    aux = torch.as_tensor(np.ascontiguousarray(aux, dtype=np.float64)).to(device)
+    aux = _resident_aux(aux, device)
   out: list = [None] * len(entries)
   for members in groups.values():
     geo0 = entries[members[0]][0]
@@ -2438,6 +2457,29 @@ class SEEPS(Metric):
     # are skipped (a point is masked only if it is NaN at every hour and day)
     return frac.mean(('hour', 'dayofyear'), skipna=True)
 
+  # reads concatenated chunks in place like the deterministic suite (one fused
+  # pass through slab addresses): evaluate_chunks may batch chunks for it
+  _reads_slabs_in_place = True
+
+  def _masked_p1(self, climatology, layout) -> np.ndarray:
+    """p1 (the climatological dry fraction averaged over hour and day of year,
+    metrics.py:443-444) with NaN outside (min_p1, max_p1) (:504-506), in slab
+    orientation -- a property of the climatology, computed once per metric
+    object and climatology (the mean runs over the whole
+    (hour, dayofyear, lat, lon) array: it must not be redone per chunk)."""
+    key = (id(climatology), layout, self.precip_name, self.min_p1, self.max_p1)
+    hit = getattr(self, '_p1_cache', None)
+    if hit is not None and hit[0] == key and hit[1] is climatology:
+      return hit[2]
+    p1 = self._p1(climatology)
+    want = _SPATIAL if layout == plan_lib.LATLON else _SPATIAL[::-1]
+    p1v = p1.transpose(*want).values
+    with np.errstate(invalid='ignore'):
+      keep = np.logical_and(p1v < self.max_p1, p1v > self.min_p1)
+    aux = np.where(keep, p1v.astype(np.float64), np.nan)
+    object.__setattr__(self, '_p1_cache', (key, climatology, aux))
+    return aux
+
   def _prepare(self, forecast, truth):
     """(geo, [forecast, truth, wet threshold], slab tables, masked p1)."""
     climatology = xl.as_dataset(self.climatology)
@@ -2450,24 +2492,59 @@ class SEEPS(Metric):
     wrest = tuple(d for d in wvar.dims if d not in _SPATIAL)
     wdata, _, _ = _spatial_last(wvar, geo.layout)
     prepared.append((wdata, wrest))
-    tables.append(_climatology_slabs(climatology, wvar, forecast, geo, wrest))
-    p1 = self._p1(climatology)
-    want = _SPATIAL if geo.layout == plan_lib.LATLON else _SPATIAL[::-1]
-    p1v = p1.transpose(*want).values
-    with np.errstate(invalid='ignore'):
-      keep = np.logical_and(p1v < self.max_p1, p1v > self.min_p1)
-    aux = np.where(keep, p1v.astype(np.float64), np.nan)
+    wtable = _climatology_slabs(climatology, wvar, forecast, geo, wrest)
+    rec = program.recorder()
+    if rec is not None and not rec.probe:
+      sizes = tuple(wvar.sizes[d] for d in wrest)
+
+      def recompute(other, memo, climatology=climatology, wvar=wvar, geo=geo,
+                    wrest=wrest, sizes=sizes):
+        key = (id(climatology), wrest, sizes, geo.out_dims, geo.out_shape)
+        if key not in memo:
+          memo[key] = _climatology_slabs_by_content(climatology, wvar, other,
+                                                    geo, wrest)
+        return memo[key]
+      rec.note_table(wtable, recompute)
+    tables.append(wtable)
+    aux = self._masked_p1(climatology, geo.layout)
     return geo, [p[0] for p in prepared], tables, aux
 
-  def compute_chunk(self, forecast, truth, region=None, skipna=False):
-    del skipna  # Ignored, must be effectively True because of p1 mask.
-    forecast, truth = _inputs(forecast, truth)
+  def _pass(self, forecast, truth, region):
+    """(geo, by_region) of the fused SEEPS pass for the active regions: one
+    launch per weight-field group answers every region of it (cached for the
+    chunk, like the deterministic passes)."""
+    name = self.precip_name
+    pins = [forecast[name].data, truth[name].data]
+    key = _result_key(('seeps', name, self.dry_threshold_mm, self.min_p1,
+                       self.max_p1, id(self.climatology)), pins, region, True,
+                      (forecast, truth))
+    hit = _RESULTS.get(key)
+    if hit is not None:
+      return hit
     geo, arrays, tables, aux = self._prepare(forecast, truth)
-    by_region, rkey = _run_pass(
+    by_region, _ = _run_pass(
         _lib.MODE_SEEPS, geo, arrays, tables, region, True,
         aux=aux, scalar=self.dry_threshold_mm / 1000.0)
-    return _assemble(forecast, {self.precip_name:
-                                (geo.out_dims, by_region[rkey][0])})
+    value = (geo, by_region)
+    _RESULTS.put(key, tuple(pins), value)
+    return value
+
+  def compute_chunk(self, forecast, truth, region=None, skipna=False,
+                    regions: t.Optional[dict] = None):
+    del skipna  # Ignored, must be effectively True because of p1 mask.
+    forecast, truth = _inputs(forecast, truth)
+    with _all_regions(regions):
+      geo, by_region = _fused(lambda r: self._pass(forecast, truth, r), region,
+                              regions)
+      lead, values = _pick(by_region, region, 0, regions)
+    return _assemble(forecast, {self.precip_name: (lead + geo.out_dims,
+                                                   values)}, regions)
+
+  def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
+    return self.compute_chunk(forecast, truth, None, skipna, regions)
+
+  def compute_regions(self, forecast, truth, regions, skipna=False):
+    return self._mean_regions(forecast, truth, regions, skipna)
 
 
 # ---------------------------------------------------------------------------
@@ -2672,6 +2749,11 @@ class SpatialEnsembleRPS(_SpatialEnsembleThresholdMetric):
 @dataclasses.dataclass
 class SpatialSEEPS(SEEPS):
   """SEEPS without spatial averaging (metrics.py:418-509): float64 map."""
+
+  _reads_slabs_in_place = False  # the map kernel reads whole arrays
+  # maps have no regions: the generic per-region fan-out of the base class
+  compute_chunk_regions = Metric.compute_chunk_regions
+  compute_regions = Metric.compute_regions
 
   def compute_chunk(self, forecast, truth, region=None, skipna=False):
     del region, skipna

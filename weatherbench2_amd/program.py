@@ -179,8 +179,9 @@ class _Launch:
 
   def __init__(self, rec: dict, fmap: dict, tmap: dict, device):
     pl, n_total = rec['plan'], rec['n_total']
-    if rec.get('aux') is not None:
-      raise _NotReplayable('a launch with an auxiliary field')
+    aux = rec.get('aux')
+    if aux is not None and not isinstance(aux, torch.Tensor):
+      raise _NotReplayable('a launch with a host auxiliary field')
     members = rec['members']   # [(geo, arrays, tables, tensors)]
     n_in = len(members[0][1])
     self.plan, self.mode, self.skipna = pl, rec['mode'], rec['skipna']
@@ -242,8 +243,11 @@ class _Launch:
       off += n
     self.n_metric = _lib.GENERIC_KQ.get(self.mode, _lib.NMETRIC)
     self.n_values = self.n_metric * pl.n_region * n_total
+    # (an auxiliary field -- SEEPS' masked dry fraction -- is a property of
+    # the metric's climatology: resident, the same for every chunk)
     self.step = engine.SuiteStep(pl, self.mode, self.dtype, self.skipna,
-                                 n_total, by_address=True)
+                                 n_total, by_address=True, aux=aux,
+                                 scalar=float(rec.get('scalar') or 0.0))
     self._dyn_groups: dict = {}
 
   def addresses(self, forecast, truth) -> np.ndarray:
