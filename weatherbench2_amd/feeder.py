@@ -35,14 +35,15 @@ _RING_SLOTS = int(_os.environ.get('WB2HIP_STAGE_SLOTS', 4))
 
 
 def copy_threads() -> int:
-  """Threads of the staging copy (WB2HIP_COPY_THREADS; default: an eighth of
-  the logical cores, between 4 and 16 -- one thread's memcpy moves ~10 GB/s,
-  the link ~60)."""
+  """Threads of the staging copy (WB2HIP_COPY_THREADS; default 8, fewer on
+  small hosts): one thread's streaming copy moves ~8-10 GB/s, the link ~57;
+  measured 53.7 / 52.9 / 52.8 / 48.8 GB/s with 8 / 16 / 32 / 64 threads against
+  57.2 GB/s from pinned memory (profiles/r05_upload_sweep.txt)."""
   import os
   env = os.environ.get('WB2HIP_COPY_THREADS')
   if env:
     return max(1, int(env))
-  return int(min(16, max(4, (os.cpu_count() or 8) // 8)))
+  return int(min(8, max(2, (os.cpu_count() or 8) // 2)))
 
 
 class _Staging(threading.local):
