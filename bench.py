@@ -194,9 +194,9 @@ def cpu_baseline(seconds: float = 6.0) -> dict:
     return outs
 
   # 1 process, 32 (where round 1 found the memory-bandwidth knee), one per
-  # physical core, one per logical core
-  counts = sorted({1, min(cap, 32, ncpu), min(cap, max(1, ncpu // 2)),
-                   min(cap, ncpu)})
+  # logical core (a leg at one per physical core sat BELOW both in every run --
+  # 15-19 M evals/s against 47-50 M and 50-58 M -- and cost 10 s: dropped)
+  counts = sorted({1, min(cap, 32, ncpu), min(cap, ncpu)})
   legs = []
   for n in counts:
     outs = launch(n)
