@@ -62,6 +62,63 @@ def test_argument_validation_without_a_gpu(lib):
   assert rc < 0 and b'null pointer' in h.wb2_last_error()
 
 
+def test_new_entry_points_validate_their_arguments(lib):
+  """The round-5 entry points without a device: layout arithmetic, the struct
+  and every precondition that is checked before anything is enqueued."""
+  import ctypes
+  h = lib.load()
+  block, n_block, slots = (ctypes.c_int32(), ctypes.c_int32(),
+                           ctypes.c_int32())
+  ref = ctypes.byref
+  # 50 members: 7 blocks of 8 (16 sums per lane; 32 with NaN skipping), blocks
+  # of 4 when a weight field AND skipna double the sums twice
+  assert h.wb2_energy_layout(50, 0, 0, ref(block), ref(n_block),
+                             ref(slots)) == 0
+  assert (block.value, n_block.value, slots.value) == (8, 7, 16)
+  assert h.wb2_energy_layout(50, 1, 0, ref(block), ref(n_block),
+                             ref(slots)) == 0
+  assert (block.value, n_block.value, slots.value) == (8, 7, 32)
+  assert h.wb2_energy_layout(50, 1, 1, ref(block), ref(n_block),
+                             ref(slots)) == 0
+  assert (block.value, n_block.value, slots.value) == (4, 13, 16)
+  assert h.wb2_energy_layout(1, 0, 0, ref(block), ref(n_block),
+                             ref(slots)) == 0 and n_block.value == 1
+  assert h.wb2_energy_layout(0, 0, 0, ref(block), ref(n_block),
+                             ref(slots)) < 0
+  assert h.wb2_energy_layout(5, 0, 0, None, None, None) < 0
+  # empty chunks are legal no-ops whatever the pointers are
+  assert h.wb2_det_suite_step(ref(lib.PlanTables()), lib.MODE_DET, lib.WB2_F32,
+                              0, None, None, 1, 0, None, None, 0, 0, 0, 0, None,
+                              None, None, None) == 0
+  assert h.wb2_energy_score(lib.WB2_F32, 0, None, None, None, None, 5, 0, 0,
+                            ref(lib.PlanTables()), None, None, None, None) == 0
+  assert h.wb2_gather_accumulate(None, None, None, 0, 3, 0, None, None,
+                                 None) == 0
+  # a null plan, missing outputs, a negative count
+  rc = h.wb2_det_suite_step(None, lib.MODE_DET, lib.WB2_F32, 0, None, None, 1,
+                            4, None, None, 0, 0, 0, 0, None, None, None, None)
+  assert rc < 0 and b'null plan' in h.wb2_last_error()
+  rc = h.wb2_det_suite_step(ref(lib.PlanTables()), lib.MODE_DET, lib.WB2_F32,
+                            0, None, None, 1, 4, None, None, 0, 0, 0, 0, None,
+                            None, None, None)
+  assert rc < 0 and b'null pointer' in h.wb2_last_error()
+  rc = h.wb2_energy_score(lib.WB2_F32, 0, None, None, None, None, 5, 0, 3,
+                          ref(lib.PlanTables()), None, None, None, None)
+  assert rc < 0 and b'null pointer' in h.wb2_last_error()
+  rc = h.wb2_energy_score(7, 0, None, None, None, None, 5, 0, 3,
+                          ref(lib.PlanTables()), None, None, None, None)
+  assert rc < 0 and b'unknown dtype' in h.wb2_last_error()
+  rc = h.wb2_gather_accumulate(None, None, None, 5, 1, 0, None, None, None)
+  assert rc < 0 and b'null pointer' in h.wb2_last_error()
+  assert h.wb2_gather_accumulate(None, None, None, -1, 1, 0, None, None,
+                                 None) < 0
+  assert h.wb2_uploader_upload(None, None, None, 16, None) < 0
+  assert b'null uploader' in h.wb2_last_error()
+  # the struct is the header's: 8 int32, 3 pointers, 2 int32, pointer, double,
+  # 9 pointers
+  assert ctypes.sizeof(lib.PlanTables) == 8 * 4 + 3 * 8 + 2 * 4 + 8 + 8 + 9 * 8
+
+
 def test_product_never_imports_the_oracle():
   pkg = os.path.join(ROOT, 'weatherbench2_amd')
   for dirpath, _, files in os.walk(pkg):

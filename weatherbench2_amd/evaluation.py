@@ -899,28 +899,35 @@ def _evaluate_piece(forecast, truth_chunk, eval_config, skipna, mean,
 
 
 def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
-  """WB2HIP_CHUNK_PROGRAM=verify: the program and the generic path on the same
-  chunk, into copies of the accumulators -- they must agree bit for bit."""
+  """WB2HIP_CHUNK_PROGRAM=verify: the chunk through the program AND through the
+  generic path, each from the same accumulator state -- they must leave the
+  same bits behind (NaN == NaN)."""
   import torch
   names = sorted(mean._acc)
-  before = {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone())
+
+  def snapshot():
+    return {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone(),
+                list(mean._acc[n].labels), dict(mean._acc[n].row_of))
             for n in names}
+
+  def restore(state):
+    for n, (total, count, labels, row_of) in state.items():
+      acc = mean._acc[n]
+      acc.total, acc.count = total.clone(), count.clone()
+      acc.labels, acc.row_of, acc.dst = list(labels), dict(row_of), {}
+  before = snapshot()
   prog.run(forecast, truth_chunk, mean)
-  got = {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone())
-         for n in names}
-  for n in names:   # rows may have been added: restore what existed
-    t0, c0 = before[n]
-    mean._acc[n].total.zero_()
-    mean._acc[n].count.zero_()
-    mean._acc[n].total[:t0.shape[0]] = t0 if t0.dim() else t0
-    mean._acc[n].count[:c0.shape[0]] = c0 if c0.dim() else c0
+  replayed = snapshot()
+  restore(before)
   mean.add(_metric_and_region_loop(forecast, truth_chunk, eval_config, skipna,
                                    compute_chunk=True))
   for n in names:
-    for a, b in zip(got[n], (mean._acc[n].total, mean._acc[n].count)):
-      same = (a == b) | (torch.isnan(a) & torch.isnan(b))
-      if a.shape != b.shape or not bool(same.all().item()):
+    for a, b in zip(replayed[n][:2], (mean._acc[n].total, mean._acc[n].count)):
+      same = a.shape == b.shape and bool(
+          ((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
+      if not same:
         raise AssertionError(f'chunk program and generic path differ on {n}')
+  prog._targets.clear()   # (the accumulators were replaced: new addresses)
 
 
 # K1 chunking of evaluate_chunks (pinned: the result must not depend on how

@@ -189,7 +189,7 @@ class _Launch:
     self.slot = np.zeros((n_in, n_total), dtype=np.int64)
     self.rel = np.zeros((n_in, n_total), dtype=np.int64)
     self.sources: list = []    # how to get pointer `slot` of a new chunk
-    self.dynamic: list = []    # (j, off, n, tensor, recompute, geo)
+    self.dynamic: list = []    # (input, offset, count, resident array, recompute)
     self.keep: list = []
     source_of: dict = {}
 
@@ -205,6 +205,10 @@ class _Launch:
         role = fmap.get(id(raw)) or tmap.get(id(raw))
         if role is not None:
           which, name = role
+          if x is not raw:
+            # the pass read a CONVERTED copy (a cast, an upload): the chunk's
+            # own array is not what the kernel saw
+            raise _NotReplayable(f'{name}: the pass read a copy of the chunk')
           if isinstance(x, xl.SlabConcat):
             step = (x.slab_shape[0] * x.slab_shape[1] *
                     x.bases[0].element_size())
@@ -224,22 +228,20 @@ class _Launch:
                 (which, name), lambda f, t_, w=which, nm=name: (
                     f if w == 'f' else t_)[nm].data)
           continue
-        # not a variable of the chunk: a resident array (the climatology)
-        if not isinstance(x, (torch.Tensor, xl.SlabGather)):
-          raise _NotReplayable(f'input {j}: {type(x).__name__}')
+        # Not a variable of the chunk: it must be a RESIDENT array whose slab
+        # table the generic path derived from the chunk's labels and told the
+        # recorder how to recompute (the climatology of ACC / SEEPS).  Anything
+        # else -- a temporary the pass made for this chunk -- has an address
+        # that means nothing for the next chunk.
         hit = rec['tables'].get(id(tb)) if tb is not None else None
+        if hit is None or not isinstance(x, (torch.Tensor, xl.SlabGather)):
+          raise _NotReplayable(f'input {j} of a launch is neither a variable '
+                               'of the chunk nor an explained resident gather')
         base_tensor = x.base if isinstance(x, xl.SlabGather) else x
         self.keep.append(base_tensor)
         self.slot[j, off:off + n] = slot_for(
             ('r', id(base_tensor)), lambda f, t_, b=base_tensor: b)
-        from weatherbench2_amd import metrics as gm
-        addr, _ = gm._slab_addresses(x, tb, pl.n_row, pl.n_col, n)
-        self.rel[j, off:off + n] = addr - base_tensor.data_ptr()
-        if hit is not None:  # its table follows the chunk's labels
-          self.dynamic.append((j, off, n, x, hit[1], geo, base_tensor))
-        elif tb is not None and n > 1 and _label_dependent(geo):
-          # a table nobody explained, over dims that carry time labels
-          raise _NotReplayable(f'input {j}: unexplained slab table')
+        self.dynamic.append((j, off, n, x, hit[1]))
       off += n
     self.n_metric = _lib.GENERIC_KQ.get(self.mode, _lib.NMETRIC)
     self.n_values = self.n_metric * pl.n_region * n_total
@@ -248,7 +250,6 @@ class _Launch:
     self.step = engine.SuiteStep(pl, self.mode, self.dtype, self.skipna,
                                  n_total, by_address=True, aux=aux,
                                  scalar=float(rec.get('scalar') or 0.0))
-    self._dyn_groups: dict = {}
 
   def addresses(self, forecast, truth) -> np.ndarray:
     ptrs = np.fromiter((g(forecast, truth).data_ptr() for g in self.sources),
@@ -257,7 +258,7 @@ class _Launch:
     if self.dynamic:
       from weatherbench2_amd import metrics as gm
       memo: dict = {}
-      for j, off, n, x, recompute, geo, base in self.dynamic:
+      for j, off, n, x, recompute in self.dynamic:
         table = recompute(forecast, memo)
         a, _ = gm._slab_addresses(x, table, self.plan.n_row, self.plan.n_col, n)
         addr[j, off:off + n] = a
@@ -276,10 +277,6 @@ def _no(reason: str):
   REASONS.append(reason)
   del REASONS[:-16]
   return None
-
-
-def _label_dependent(geo) -> bool:
-  return any(d in _VARYING for d in geo.out_dims)
 
 
 def _nan_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
