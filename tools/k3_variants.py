@@ -54,11 +54,12 @@ def variants(dev, reps: int = 3, launches: int = 30, only=None) -> dict:
   specs += [(f'members{m}', 'slice13', m, torch.float32, False, 0.0)
             for m in exact_sizes]
   # member counts without a program of their own: hosted by the next larger
-  # one (ens_point_hosted); 44 with skipna stays on the padded runtime network
+  # one (ens_point_hosted; with skipna the dead slots are NaN members of the
+  # general exact code)
   specs += [(f'members{m}_hosted', 'slice13', m, torch.float32, False, 0.0)
             for m in (7, 13, 24, 33, 44, 47, 63, 77)]
   specs += [('members51_skipna', 'slice13', 51, torch.float32, True, 0.0),
-            ('members44_skipna_runtime', 'slice13', 44, torch.float32, True,
+            ('members44_skipna_hosted', 'slice13', 44, torch.float32, True,
              0.0),
             ('f64_members50', 'slice13', 50, torch.float64, False, 0.0)]
   if only:

@@ -271,9 +271,9 @@ int launch_ens_npad(const EnsParams& p, bool skipna, bool wf,
       const char* v = getenv("WB2HIP_ENS_HOSTED");
       return !(v && v[0] == '0');
     }();
-    if (hosted && !skipna && m >= 2) {
+    if (hosted && m >= 2) {
 #define WB2_ENS_HOST_CASE(M, NPAD) \
-  if (m <= M) return launch_ens_hosted_f32_##M(p, wf, stream);
+  if (m <= M) return launch_ens_hosted_f32_##M(p, skipna, wf, stream);
       WB2_ENS_EXACT_SIZES(WB2_ENS_HOST_CASE)
 #undef WB2_ENS_HOST_CASE
     }

@@ -20,9 +20,9 @@ int WB2_CAT(launch_ens_exact_f32_, WB2_ENS_M)(const EnsParams& p, bool skipna,
 }
 
 // ... and as the host of every smaller runtime member count (ens_point_hosted)
-int WB2_CAT(launch_ens_hosted_f32_, WB2_ENS_M)(const EnsParams& p, bool wf,
-                                               hipStream_t stream) {
-  return launch_ens_hosted<WB2_ENS_NPAD, WB2_ENS_M>(p, wf, stream);
+int WB2_CAT(launch_ens_hosted_f32_, WB2_ENS_M)(const EnsParams& p, bool skipna,
+                                               bool wf, hipStream_t stream) {
+  return launch_ens_hosted<WB2_ENS_NPAD, WB2_ENS_M>(p, skipna, wf, stream);
 }
 
 }  // namespace wb2

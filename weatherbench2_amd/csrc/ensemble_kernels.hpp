@@ -54,9 +54,11 @@ WB2_ENS_EXACT_SIZES(WB2_ENS_DECLARE)
 // The same programs as HOSTS of smaller ensembles: a runtime member count
 // m <= M runs in the M-member program with the slots m..M-1 held at +inf (they
 // sort behind every live member and carry no rank weight); statistics over the
-// first m members.  float32, no NaN skipping; strided or gathered members.
-#define WB2_ENS_DECLARE_HOSTED(M, NPAD)                             \
-  int launch_ens_hosted_f32_##M(const EnsParams& p, bool wf, hipStream_t stream);
+// first m members.  float32; strided or gathered members; with NaN skipping the
+// dead slots are NaN members of the general exact code.
+#define WB2_ENS_DECLARE_HOSTED(M, NPAD)                                 \
+  int launch_ens_hosted_f32_##M(const EnsParams& p, bool skipna, bool wf, \
+                                hipStream_t stream);
 WB2_ENS_EXACT_SIZES(WB2_ENS_DECLARE_HOSTED)
 #undef WB2_ENS_DECLARE_HOSTED
 
@@ -302,13 +304,20 @@ __device__ __forceinline__ T div_const(T x) {
 // rank-weighted sum as the reference's fp64 chain and the final divisions as
 // the skipna form writes them, so that a point's value does not depend on
 // whether its wave took the fast path.
-template <typename T, int NPAD, int MS, bool SKIPNA, bool REFCHAIN = false>
+// RTM (MS > 0, SKIPNA): the MS slots hold a RUNTIME member count Mrt <= MS --
+// the slots beyond it arrive as NaN and drop out like NaN members do (they are
+// not counted, sort last, carry no rank weight), only the ensemble size in the
+// rank weights and the debiasing term is the run-time one (hosted counts).
+template <typename T, int NPAD, int MS, bool SKIPNA, bool REFCHAIN = false,
+          bool RTM = false>
 __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt,
                                           double (&out)[SKIPNA ? 10 : 6]) {
+  static_assert(!RTM || (MS > 0 && SKIPNA && !REFCHAIN),
+                "a run-time count inside an exact program: NaN skipping only");
   const T nan = std::numeric_limits<T>::quiet_NaN();
   const T inf = std::numeric_limits<T>::infinity();
   constexpr int NM = MS > 0 ? MS : NPAD;  // slots visited
-  const int M = MS > 0 ? MS : Mrt;
+  const int M = (MS > 0 && !RTM) ? MS : Mrt;
   auto live = [&](int m) { return MS > 0 ? true : m < M; };
   T sum = 0, sk = 0;
   int n = 0;          // valid members (SKIPNA)
@@ -404,7 +413,7 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
   const T err = t - mean;
   const T mse = err * err;
   T deb, skill;
-  if constexpr (MS > 0) deb = mse - div_const<MS>(var);
+  if constexpr (MS > 0 && !RTM) deb = mse - div_const<MS>(var);
   else deb = mse - var / (T)M;
   if constexpr (MS > 0 && !SKIPNA) skill = div_const<MS>(sk);
   else skill = sk / (T)cnt;
@@ -468,10 +477,21 @@ __device__ __forceinline__ void ens_point(T (&x)[NPAD], const T t, const int Mrt
       }
     } else if constexpr (Sort3<MS>::has && sizeof(T) == 4) {
       Sort3<MS>::template run<NPAD>(x);  // rank m: register Sort3<MS>::order[m]
+      if constexpr (RTM) {
+        // run-time ensemble size: the weight steps by 2 from 1 - M (exact in
+        // fp64) -- converted per rank, hipcc makes all the weights first
+        double w = (double)(1 - M);
 #pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        s = __builtin_fma((double)(2 * (m + 1) - M - 1),
-                          (double)ranked(m, x[Sort3<MS>::order[m]]), s);
+        for (int m = 0; m < NM; ++m) {
+          s = __builtin_fma(w, (double)ranked(m, x[Sort3<MS>::order[m]]), s);
+          w += 2.0;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          s = __builtin_fma((double)(2 * (m + 1) - M - 1),
+                            (double)ranked(m, x[Sort3<MS>::order[m]]), s);
+        }
       }
     } else {
       sort_network<NPAD, NM>(x);
@@ -643,6 +663,13 @@ __device__ __forceinline__ void ens_point_runtime(T (&x)[NPAD], const T t,
 __device__ __forceinline__ float vmax_s(float x, float uniform) {
   float r;
   asm("v_max_f32 %0, %1, %2"
+      : "=v"(r)
+      : "s"(__builtin_bit_cast(int, uniform)), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float add_s(float x, float uniform) {
+  float r;  // x + (0 | NaN): a live slot keeps its value, a dead one turns NaN
+  asm("v_add_f32 %0, %1, %2"
       : "=v"(r)
       : "s"(__builtin_bit_cast(int, uniform)), "v"(x));
   return r;
@@ -915,8 +942,8 @@ template <typename T, int NPAD, int MS, bool SKIPNA, bool WF,
           bool HOSTED = false, bool GATHER = false>
 __global__ void __launch_bounds__(256)
     ens_partials_kernel(const EnsParams p) {
-  static_assert(!HOSTED || (MS > 0 && !SKIPNA && sizeof(T) == 4),
-                "hosted member counts: float32, no NaN skipping");
+  static_assert(!HOSTED || (MS > 0 && sizeof(T) == 4),
+                "hosted member counts: float32 programs");
   static_assert(HOSTED || !GATHER, "GATHER is a flag of the hosted kernels");
   constexpr bool RT = MS == 0 || HOSTED;
   constexpr int K = SKIPNA ? 10 : 6, NWF = WF ? 2 : 1;
@@ -1091,7 +1118,17 @@ __global__ void __launch_bounds__(256)
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (HOSTED) {
+        if constexpr (HOSTED && SKIPNA) {
+          // NaN skipping: the dead slots (their loads returned 0) become NaN
+          // and are skipped like NaN members; one pass of the general code
+          const T nanv = std::numeric_limits<T>::quiet_NaN();
+#pragma unroll
+          for (int m = 0; m < MS; ++m) {
+            x[m] = add_s(x[m], m < Mr ? (T)0 : nanv);
+            if ((m & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+          }
+          ens_point<T, NPAD, MS, true, false, true>(x, t, Mr, v);
+        } else if constexpr (HOSTED) {
           ens_point_hosted<NPAD, MS>(x, t, Mr, v);
         } else if constexpr (MS == 0 && !SKIPNA) {
           // dead slots (a wave-uniform suffix) become +inf ONCE, here
@@ -1155,7 +1192,7 @@ __global__ void __launch_bounds__(256)
       return false;
     };
     constexpr bool TWO_PASS =
-        SKIPNA && MS > 1 && NPAD > 0;
+        SKIPNA && MS > 1 && NPAD > 0 && !HOSTED;
     if constexpr (TWO_PASS) {
       // rows with a NaN somewhere in the wave wait for a loop of their own:
       // two loops, two register allocations -- the NaN-free rows are not held
@@ -1219,22 +1256,30 @@ int launch_ens(const EnsParams& p, bool skipna, bool wf, hipStream_t stream) {
 }
 
 template <int NPAD, int MS>
-int launch_ens_hosted(const EnsParams& p, bool wf, hipStream_t stream) {
+int launch_ens_hosted(const EnsParams& p, bool skipna, bool wf,
+                      hipStream_t stream) {
   int nwave = p.n_ctile < WB2_ENS_WG_WAVES ? p.n_ctile : WB2_ENS_WG_WAVES;
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
   const long long gz = (p.n_outer + gy - 1) / gy;
   const dim3 grid((unsigned)(p.n_chunk * n_tblk), (unsigned)gy, (unsigned)gz);
   const dim3 block(nwave * kWave);
-#define WB2_L(W, G)                                                         \
-  hipLaunchKernelGGL(                                                      \
-      (ens_partials_kernel<float, NPAD, MS, false, W, true, G>), grid, block, \
-      0, stream, p)
-  if (p.member_ptr) {
-    if (wf) WB2_L(true, true); else WB2_L(false, true);
-  } else {
-    if (wf) WB2_L(true, false); else WB2_L(false, false);
+#define WB2_L(S, W, G)                                                  \
+  hipLaunchKernelGGL(                                                   \
+      (ens_partials_kernel<float, NPAD, MS, S, W, true, G>), grid, block, 0, \
+      stream, p)
+#define WB2_LS(S)                                            \
+  if (p.member_ptr) {                                        \
+    if (wf) WB2_L(S, true, true); else WB2_L(S, false, true);   \
+  } else {                                                   \
+    if (wf) WB2_L(S, true, false); else WB2_L(S, false, false); \
   }
+  if (skipna) {
+    WB2_LS(true)
+  } else {
+    WB2_LS(false)
+  }
+#undef WB2_LS
 #undef WB2_L
   WB2_HIP_OK(hipGetLastError());
   return 0;
