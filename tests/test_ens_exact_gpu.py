@@ -109,7 +109,7 @@ def test_exact_member_counts_match_oracle(dev, m, skipna):
     assert np.isnan(got[idx['crps'], 0, 2])
 
 
-@pytest.mark.parametrize('m', [10, 30, 50, 51])
+@pytest.mark.parametrize('m', [10, 30, 50, 51, 3, 13, 44, 77])  # + hosted counts
 def test_skipna_fast_path_gives_the_general_paths_bits(dev, m):
   """Pointwise maps: the same ensemble twice, once clean (every wave takes the
   NaN-free fast path) and once with one NaN per 64-column tile and row (every

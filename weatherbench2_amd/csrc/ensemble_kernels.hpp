@@ -1119,8 +1119,35 @@ __global__ void __launch_bounds__(256)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HOSTED && SKIPNA) {
-          // NaN skipping: the dead slots (their loads returned 0) become NaN
-          // and are skipped like NaN members; one pass of the general code
+         if constexpr (PASS == 1) {
+          // NaN skipping, a wave without a NaN (the dead slots hold 0): the
+          // no-skipna hosted code -- the same operations in the same order as
+          // the general code performs for NaN-free points, so a point's value
+          // does not depend on which pass its wave took (tested pointwise)
+          bool dirty = is_nan(t);
+#pragma unroll
+          for (int m = 0; m + 1 < MS; m += 2)
+            dirty = dirty || __builtin_isunordered(x[m], x[m + 1]);
+          if constexpr (MS % 2 == 1) dirty = dirty || is_nan(x[MS - 1]);
+          if (__builtin_amdgcn_ballot_w64(dirty) != 0) return true;
+          double q[6];
+          ens_point_hosted<NPAD, MS>(x, t, Mr, q);
+          const bool ok_skill = !is_nan(q[0]), ok_spread = !is_nan(q[1]),
+                     ok_mse = !is_nan(q[2]), ok_var = !is_nan(q[3]),
+                     ok_deb = !is_nan(q[5]);
+          v[0] = ok_skill ? q[0] : 0.0;
+          v[1] = ok_spread ? q[1] : 0.0;
+          v[2] = ok_mse ? q[2] : 0.0;
+          v[3] = ok_var ? q[3] : 0.0;
+          v[4] = ok_var ? q[4] : 0.0;
+          v[5] = ok_deb ? q[5] : 0.0;
+          v[K - 4] = ok_skill ? 1.0 : 0.0;
+          v[K - 3] = ok_spread ? 1.0 : 0.0;
+          v[K - 2] = ok_var ? 1.0 : 0.0;
+          v[K - 1] = ok_deb ? 1.0 : 0.0;
+         } else {
+          // a wave that holds a NaN: the dead slots (their loads returned 0)
+          // become NaN and are skipped like NaN members by the general code
           const T nanv = std::numeric_limits<T>::quiet_NaN();
 #pragma unroll
           for (int m = 0; m < MS; ++m) {
@@ -1128,6 +1155,7 @@ __global__ void __launch_bounds__(256)
             if ((m & 7) == 7) __builtin_amdgcn_sched_barrier(0);
           }
           ens_point<T, NPAD, MS, true, false, true>(x, t, Mr, v);
+         }
         } else if constexpr (HOSTED) {
           ens_point_hosted<NPAD, MS>(x, t, Mr, v);
         } else if constexpr (MS == 0 && !SKIPNA) {
@@ -1191,8 +1219,7 @@ __global__ void __launch_bounds__(256)
       }
       return false;
     };
-    constexpr bool TWO_PASS =
-        SKIPNA && MS > 1 && NPAD > 0 && !HOSTED;
+    constexpr bool TWO_PASS = SKIPNA && MS > 1 && NPAD > 0;
     if constexpr (TWO_PASS) {
       // rows with a NaN somewhere in the wave wait for a loop of their own:
       // two loops, two register allocations -- the NaN-free rows are not held
