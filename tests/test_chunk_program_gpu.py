@@ -198,3 +198,76 @@ def test_seeps_in_windows_and_programs(batch, monkeypatch):
     vals = got[name].values[mi, ri]
     helpers.assert_close(vals, want_mean.reshape(vals.shape), rtol=1e-9,
                          atol=1e-12, err_msg=rname)
+
+
+@pytest.mark.parametrize('order', ['init', 'lead'])
+@pytest.mark.parametrize('batch', [1, 2, None])
+def test_temporal_mean_false_keeps_every_chunk(batch, order, monkeypatch):
+  """`temporal_mean=False` (config.py:55; the `deterministic_temporal` config
+  of scripts/evaluate.py:479-487; evaluation.py:735 skips the mean): the
+  per-chunk values filed under (init_time, lead_time) -- the program path, the
+  generic path and whole-dataset evaluation give the same bits, and those are
+  the oracle's per-chunk values."""
+  import dataclasses
+  from oracle import evaluation_np as oe
+  from weatherbench2_amd import evaluation
+  forecast, truth, clim = oc.make(n_init=5, n_lead=3, n_lat=31, n_lon=72)
+  hf, ht, gf, gt, cfg = _setup(n_init=5, n_lead=3, n_lat=31, n_lon=72)
+  cfg = dataclasses.replace(cfg, temporal_mean=False)
+  chunks = oc.chunk_pairs(gf, gt, order=order)
+  kwargs = {} if batch is None else {'batch_chunks': batch}
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                                    batch_chunks=1)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+  calls = _count_runs(monkeypatch)
+  got = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, **kwargs)
+  _same(got, want)
+  if batch == 1:
+    assert len(calls) == len(chunks) - 1
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', 'verify')
+  _same(evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, **kwargs),
+        want)
+  # the labels in dataset order whichever way the chunks came
+  np.testing.assert_array_equal(
+      np.sort(np.asarray(got.coords['init_time'])),
+      np.asarray(gf.coords['init_time']))
+  assert got['geopotential'].dims[:2] == ('metric', 'region')
+  assert 'init_time' in got['geopotential'].dims
+  # against the oracle: per-chunk values of the whole dataset
+  lat, lon = forecast.coords['latitude'], forecast.coords['longitude']
+  oregions = oc.oracle_regions(lat, lon, oc.land_sea_mask(len(lat), len(lon)))
+  per_chunk = oe.metric_and_region_loop(
+      forecast, truth, oc.oracle_metrics(clim), oregions, False,
+      compute_chunk=True)
+  labels_m, labels_r = list(got.coords['metric']), list(got.coords['region'])
+  init_pos = [list(np.asarray(got.coords['init_time'])).index(x)
+              for x in np.asarray(forecast.coords['init_time'])]
+  lead_pos = [list(np.asarray(got.coords['lead_time'])).index(x)
+              for x in np.asarray(forecast.coords['lead_time'])]
+  checked = 0
+  for (mname, rname), ds in per_chunk.items():
+    for var, v in ds.items():
+      res = got[var]
+      order_ = [d for d in res.dims if d not in ('metric', 'region')]
+      vals = res.values[labels_m.index(mname), labels_r.index(rname)]
+      vals = np.take(vals, init_pos, axis=order_.index('init_time'))
+      vals = np.take(vals, lead_pos, axis=order_.index('lead_time'))
+      vals = np.transpose(vals, [order_.index(d) for d in v.dims])
+      helpers.assert_close(vals, v.data, rtol=1e-9, atol=1e-12,
+                           err_msg=f'{mname}/{rname}/{var}')
+      checked += 1
+  assert checked > 10
+
+
+def test_temporal_mean_false_rejects_a_chunk_that_comes_twice(monkeypatch):
+  import dataclasses
+  from weatherbench2_amd import evaluation
+  _, _, gf, gt, cfg = _setup(n_init=3, n_lead=2, n_lat=19, n_lon=36)
+  cfg = dataclasses.replace(cfg, temporal_mean=False)
+  chunks = oc.chunk_pairs(gf, gt)
+  for how in ('0', '1'):
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', how)
+    with pytest.raises(ValueError, match='came twice'):
+      evaluation.evaluate_chunks(chunks + chunks[2:3], cfg, False, prefetch=0,
+                                 batch_chunks=1)

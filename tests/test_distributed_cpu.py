@@ -135,6 +135,48 @@ def test_two_ranks_with_different_lead_labels_agree_on_the_layout():
     np.testing.assert_allclose(z, values.mean(0), rtol=1e-14)
 
 
+def _concat_worker(rank, world, port, queue):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    chunks, _, _ = _lead_chunks()
+    lo, hi = evaluation.shard_bounds(len(chunks), world, rank)
+    sink = evaluation.RunningConcat('init_time', device='cpu',
+                                    split_dim='lead_time')
+    for i in range(lo, hi):
+      sink.add(chunks[i])
+    res = sink.result()
+    queue.put((rank, res['z'].values, np.asarray(res.coords['lead_time']),
+               np.asarray(res.coords['init_time']), res['z'].dims))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_two_ranks_keep_every_chunk_without_the_temporal_mean():
+  """`temporal_mean=False` over two ranks: each rank files its shard's chunks,
+  result() exchanges the kept slices and every rank ends with all of them under
+  the same labels (rank order = list order)."""
+  world = 2
+  ctx = mp.get_context('spawn')
+  queue = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_concat_worker, args=(r, world, port, queue))
+           for r in range(world)]
+  for p in procs:
+    p.start()
+  got = [queue.get(timeout=120) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  _, values, leads = _lead_chunks()
+  for _, z, lead_labels, init_labels, dims in got:
+    assert dims == ('init_time', 'lead_time', 'level')
+    np.testing.assert_array_equal(lead_labels, leads)
+    np.testing.assert_array_equal(init_labels, np.arange(values.shape[0]))
+    np.testing.assert_array_equal(z, values)
+
+
 def test_shard_bounds_cover_everything():
   for n in (1, 7, 8, 2920):
     for world in (1, 2, 3, 8):

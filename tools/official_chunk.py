@@ -169,20 +169,37 @@ def build(dev, n_chunks: int, pool: int, n_lead: int = 4, seeps: bool = True):
   return chunks, cfg
 
 
+def temporal_config(cfg):
+  """The `deterministic_temporal` config of the documented command line
+  (scripts/evaluate.py:479-487): the deterministic metrics + RMSE with the
+  square root per chunk, `temporal_mean=False` -- every chunk's values are
+  kept under their (init_time, lead_time) labels."""
+  import dataclasses
+  from weatherbench2_amd import metrics as gm
+  wv = [gm.WindVectorRMSESqrtBeforeTimeAvg(u_name=u, v_name=v, vector_name=n)
+        for u, v, n in WIND]
+  metrics = dict(cfg.metrics)
+  metrics['rmse_sqrt_before_time_avg'] = gm.RMSESqrtBeforeTimeAvg(
+      wind_vector_rmse=wv)
+  return dataclasses.replace(cfg, metrics=metrics, temporal_mean=False)
+
+
 def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
   """`batch`: chunks per window, or None = evaluate_chunks' default (as many
   as hold 16 GiB of input: 24 of these chunks)."""
   import torch
   from weatherbench2_amd import engine, evaluation
   marks = {}
-  real_result = evaluation.RunningMean.result
+  sink = (evaluation.RunningMean if getattr(cfg, 'temporal_mean', True)
+          else evaluation.RunningConcat)
+  real_result = sink.result
 
   def result(self):
     marks['enqueued'] = time.perf_counter()  # the host is done with the chunks
     return real_result(self)
   ev = _Events(timed_events)
   old = engine.set_launch_hook(ev)
-  evaluation.RunningMean.result = result
+  sink.result = result
   try:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -192,7 +209,7 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
     torch.cuda.synchronize()
     t1 = time.perf_counter()
   finally:
-    evaluation.RunningMean.result = real_result
+    sink.result = real_result
     engine.set_launch_hook(old)
   n = len(chunks)
   if batch is None:
@@ -327,6 +344,19 @@ def run(dev, n_chunks: int = 512, pool: int = 32,
   head = legs[head_name] if head_name in legs else legs[list(legs)[-1]]
   out = dict(head)
   out['by_batch_chunks'] = legs
+  # the same chunks through the `deterministic_temporal` config: every launch
+  # of `deterministic` (rmse is one more row of the same fold), the results
+  # kept per (init_time, lead_time) instead of averaged
+  try:
+    cfg_t = temporal_config(cfg)
+    temporal = {}
+    for b in (1, None):
+      gm.clear_caches()
+      measure(chunks[:max(2 * (b or 24), 8)], cfg_t, b, timed_events=False)
+      temporal['default' if b is None else str(b)] = measure(chunks, cfg_t, b)
+    out['deterministic_temporal'] = temporal
+  except Exception as e:
+    out['deterministic_temporal'] = {'error': f'{type(e).__name__}: {e}'}
   if host_fed:
     try:
       out['host_fed'] = measure_host_fed(chunks, cfg)
@@ -340,9 +370,8 @@ def run(dev, n_chunks: int = 512, pool: int = 32,
                    'regions, mse (+ 2 wind vectors) + acc + bias + mae + '
                    'seeps_24hr + seeps_6hr (--compute_seeps=True), '
                    'evaluation.evaluate_chunks from device-resident chunks; '
-                   'the `deterministic_temporal` config of the documented '
-                   'command line (the same passes without the time mean) is '
-                   'not in this leg'),
+                   '`deterministic_temporal`: the same + '
+                   'rmse_sqrt_before_time_avg with temporal_mean=False'),
       'pool_chunks': pool, 'points_per_chunk': PTS_PER_CHUNK}
   del chunks, cfg
   torch.cuda.empty_cache()

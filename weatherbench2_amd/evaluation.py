@@ -518,6 +518,205 @@ class RunningMean:
     return out
 
 
+class _KeptRows:
+  """Storage of one result variable of `RunningConcat`: [row, *rest], the rows
+  are those of the sink's registry for the variable's key dims (one per (time
+  label, split label) pair in order of first appearance)."""
+
+  def __init__(self, dims, shape, key_dims, device):
+    import torch
+    self.dims, self.key_dims = tuple(dims), tuple(key_dims)
+    self.key_pos = [self.dims.index(d) for d in self.key_dims]
+    self.rest_dims = tuple(d for d in self.dims if d not in self.key_dims)
+    self.rest_shape = tuple(n for d, n in zip(dims, shape)
+                            if d not in self.key_dims)
+    self.filled: set = set()   # rows this variable has a value for
+    self.total = torch.zeros((64,) + self.rest_shape, dtype=torch.float64,
+                             device=device)
+    self.count = torch.zeros_like(self.total)
+
+  def claim(self, rows: list, n_rows: int, name: str):
+    """`rows` are about to be written: none may hold a value yet; the storage
+    doubles until it has `n_rows` rows."""
+    import torch
+    if not self.filled.isdisjoint(rows) or len(set(rows)) != len(rows):
+      raise ValueError(f'{name}: a ({", ".join(self.key_dims)}) combination '
+                       'came twice')
+    self.filled.update(rows)
+    while n_rows > self.total.shape[0]:
+      self.total = torch.cat([self.total, torch.zeros_like(self.total)])
+      self.count = torch.cat([self.count, torch.zeros_like(self.count)])
+
+
+class RunningConcat:
+  """`temporal_mean=False` (config.py:55; the `deterministic_temporal` config of
+  scripts/evaluate.py:479-487): the per-chunk results are KEPT along the time
+  dim instead of averaged -- what the Beam pipeline writes chunk by chunk when
+  it skips `TemporalMean` (evaluation.py:735-752).  Same interface as
+  `RunningMean`: add(chunk_result) files every (time, lead) slice of a chunk
+  result under its labels (on the device, no host round trip), result() puts
+  the slices together in order of first appearance (the dataset's order when
+  the chunk list is walked in order; NaN where a combination never came).
+  Chunk programs feed it through `wb2_gather_accumulate` like the mean (each
+  destination gets exactly one value: 0 + v, exact)."""
+
+  keeps_time = True
+
+  def __init__(self, dim: str, device=None, split_dim: t.Optional[str] = None):
+    self.dim, self.device, self.split_dim = dim, device, split_dim
+    self.skipna = False
+    self._acc: dict = {}      # var -> _KeptRows
+    self._rows: dict = {}     # key dims -> {label combination: row}
+    self._coords: dict = {}
+    self._dtypes: dict = {}
+    self._seen: dict = {}     # key dim -> labels in order of first appearance
+
+  def _on_gpu(self) -> bool:
+    import torch
+    return self.device is not None and torch.device(self.device).type == 'cuda'
+
+  def _on_gpu_or_unset(self) -> bool:
+    return self.device is None or self._on_gpu()
+
+  def key_dims(self, dims) -> tuple:
+    return tuple(d for d in (self.dim, self.split_dim) if d and d in dims)
+
+  def rows(self, chunk: xl.Dataset, key_dims) -> np.ndarray:
+    """Rows of the chunk's label combinations along `key_dims` (C order), new
+    combinations appended to the registry (shared by every variable with these
+    key dims); the labels are remembered in first-seen order."""
+    import itertools
+    lists = []
+    for d in key_dims:
+      labels = chunk.coords.get(d)
+      if labels is None or isinstance(labels, xl.DataArray):
+        raise ValueError(f'chunk result has no {d!r} labels')
+      labels = np.asarray(labels)
+      values = labels.tolist()
+      seen = self._seen.setdefault(d, {})
+      for value, label in zip(values, labels):
+        if value not in seen:
+          seen[value] = label
+      lists.append(values)
+    row_of = self._rows.setdefault(tuple(key_dims), {})
+    out = np.empty([len(x) for x in lists], dtype=np.int64)
+    flat = out.reshape(-1)
+    for i, key in enumerate(itertools.product(*lists)):
+      row = row_of.get(key)
+      if row is None:
+        row = row_of[key] = len(row_of)
+      flat[i] = row
+    return out
+
+  def storage(self, name, dims, shape, dtype) -> _KeptRows:
+    acc = self._acc.get(name)
+    if acc is None:
+      acc = self._acc[name] = _KeptRows(dims, shape, self.key_dims(dims),
+                                        self.device)
+      self._dtypes[name] = dtype
+    if acc.dims != tuple(dims) or acc.rest_shape != tuple(
+        n for d, n in zip(dims, shape) if d not in acc.key_dims):
+      raise ValueError(f'{name}: chunk layout changed {acc.dims} -> {dims}')
+    return acc
+
+  def snapshot(self):
+    return ({n: (a.total.clone(), a.count.clone(), set(a.filled))
+             for n, a in self._acc.items()},
+            {k: dict(v) for k, v in self._rows.items()},
+            {k: dict(v) for k, v in self._seen.items()})
+
+  def restore(self, state):
+    accs, rows, seen = state
+    for n, (total, count, filled) in accs.items():
+      a = self._acc[n]
+      a.total, a.count, a.filled = total.clone(), count.clone(), set(filled)
+    self._rows = {k: dict(v) for k, v in rows.items()}
+    self._seen = {k: dict(v) for k, v in seen.items()}
+
+  def add(self, chunk: xl.Dataset):
+    import torch
+    from weatherbench2_amd import engine
+    for k, c in chunk.coords.items():
+      if k not in (self.dim, self.split_dim) and not (
+          isinstance(c, xl.DataArray) and any(
+              d in (self.dim, self.split_dim) for d in c.dims)):
+        self._coords.setdefault(k, c)
+    rows_of_group: dict = {}
+    for name, da in chunk.data_vars.items():
+      if self.dim not in da.dims:
+        raise ValueError(f'{name} has no {self.dim!r} dim: {da.dims}')
+      raw = da.data
+      if isinstance(raw, torch.Tensor):
+        if self.device is None and raw.is_cuda:
+          self.device = raw.device
+        engine.order_read(raw)
+        values = raw
+        np_dtype = np.dtype(str(raw.dtype).replace('torch.', ''))
+      else:
+        values = torch.as_tensor(np.ascontiguousarray(da.values))
+        np_dtype = np.asarray(da.values).dtype
+      acc = self.storage(name, da.dims, da.shape, np_dtype)
+      rows = rows_of_group.get(acc.key_dims)
+      if rows is None:
+        rows = rows_of_group[acc.key_dims] = self.rows(
+            chunk, acc.key_dims).ravel()
+      acc.claim(rows.tolist(), len(self._rows[acc.key_dims]), name)
+      moved = values.to(acc.total.device, torch.float64).movedim(
+          acc.key_pos, list(range(len(acc.key_pos))))
+      moved = moved.reshape((rows.size,) + acc.rest_shape)
+      index = torch.as_tensor(rows, device=acc.total.device)
+      acc.total.index_copy_(0, index, moved)
+      acc.count.index_fill_(0, index, 1.0)
+
+  def result(self) -> xl.Dataset:
+    import torch.distributed as dist
+    pieces = {}
+    for name, acc in self._acc.items():
+      keys = list(self._rows[acc.key_dims])
+      rows = sorted(acc.filled)
+      pieces[name] = (acc.dims, acc.key_dims, acc.rest_shape,
+                      [keys[r] for r in rows],
+                      acc.total[rows].cpu().numpy() if rows else
+                      np.zeros((0,) + acc.rest_shape), self._dtypes[name])
+    seen = {d: list(v.values()) for d, v in self._seen.items()}
+    everyone = [(pieces, seen)]
+    if dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size() > 1):
+      everyone = [None] * dist.get_world_size()
+      dist.all_gather_object(everyone, (pieces, seen))
+    labels: dict = {}
+    for _, rank_seen in everyone:
+      for d, values in rank_seen.items():
+        known = labels.setdefault(d, {})
+        for label in values:
+          known.setdefault(np.asarray(label).tolist(), label)
+    coords = dict(self._coords)
+    for d, known in labels.items():
+      first = next(iter(known.values()))
+      coords[d] = np.array(list(known.values()), dtype=np.asarray(first).dtype)
+    out = xl.Dataset(coords=coords)
+    names = []
+    for rank_pieces, _ in everyone:
+      names += [n for n in rank_pieces if n not in names]
+    for name in names:
+      ref = next(p[name] for p, _ in everyone if name in p)
+      dims, key_dims, rest_shape, _, _, dtype = ref
+      pos = [{v: i for i, v in enumerate(labels[d])} for d in key_dims]
+      full = np.full(tuple(len(labels[d]) for d in key_dims) + rest_shape,
+                     np.nan, dtype=np.float64)
+      for rank_pieces, _ in everyone:
+        if name not in rank_pieces:
+          continue
+        _, _, _, keys, values, _ = rank_pieces[name]
+        for key, value in zip(keys, values):
+          full[tuple(p[k] for p, k in zip(pos, key))] = value
+      rest_dims = [d for d in dims if d not in key_dims]
+      order = list(key_dims) + rest_dims
+      full = np.transpose(full, [order.index(d) for d in dims])
+      out.data_vars[name] = xl.DataArray(full.astype(dtype), dims, coords, name)
+    return out
+
+
 def make_resident(dataset, device=None) -> xl.Dataset:
   """Uploads every data variable of `dataset` to HBM once and returns a Dataset
   of device tensors with the same dims and coordinates.
@@ -904,13 +1103,18 @@ def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
   same bits behind (NaN == NaN)."""
   import torch
   names = sorted(mean._acc)
+  kept = getattr(mean, 'keeps_time', False)
 
   def snapshot():
+    if kept:
+      return mean.snapshot()
     return {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone(),
                 list(mean._acc[n].labels), dict(mean._acc[n].row_of))
             for n in names}
 
   def restore(state):
+    if kept:
+      return mean.restore(state)
     for n, (total, count, labels, row_of) in state.items():
       acc = mean._acc[n]
       acc.total, acc.count = total.clone(), count.clone()
@@ -921,6 +1125,8 @@ def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
   restore(before)
   mean.add(_metric_and_region_loop(forecast, truth_chunk, eval_config, skipna,
                                    compute_chunk=True))
+  if kept:
+    replayed = replayed[0]
   for n in names:
     for a, b in zip(replayed[n][:2], (mean._acc[n].total, mean._acc[n].count)):
       same = a.shape == b.shape and bool(
@@ -928,6 +1134,8 @@ def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
       if not same:
         raise AssertionError(f'chunk program and generic path differ on {n}')
   prog._targets.clear()   # (the accumulators were replaced: new addresses)
+  if prog._kept is not None:
+    prog._kept['stamp'] = None
 
 
 # K1 chunking of evaluate_chunks (pinned: the result must not depend on how
@@ -1021,7 +1229,7 @@ def evaluate_chunks(
     # chunk by chunk.  Derived variables are computed on (and assigned into)
     # each chunk as the caller handed it in (evaluation.py:402-405).
     batch_chunks, auto_batch = 1, False
-  mean: t.Optional[RunningMean] = None
+  mean = None   # RunningMean, or RunningConcat for temporal_mean=False
   window: list = []
   # chunk structures seen so far -> their replayable program (program.py), or
   # False where the generic path has to stay
@@ -1036,8 +1244,11 @@ def evaluate_chunks(
     lead_dim = _lead_dim(first)
     lead_dim = lead_dim if lead_dim in first.dims else None
     if mean is None:
-      mean = RunningMean(time_dim, skipna, device, split_dim=lead_dim,
-                         split_order='first_seen')
+      if getattr(eval_config, 'temporal_mean', True) is False:
+        mean = RunningConcat(time_dim, device, split_dim=lead_dim)
+      else:
+        mean = RunningMean(time_dim, skipna, device, split_dim=lead_dim,
+                           split_order='first_seen')
     for forecast, truth_chunk in _batches(window, time_dim, lead_dim):
       _evaluate_piece(forecast, truth_chunk, eval_config, skipna, mean,
                       programs)

@@ -309,6 +309,69 @@ class ChunkProgram:
     self.round32 = torch.as_tensor(r32).to(device)
     self._targets: dict = {}  # lead-label bytes -> (ptr stamp, sum, count)
     self._lib = _lib.load()
+    self._kept = None         # RunningConcat sinks: see _kept_tables
+
+  def _kept_tables(self, sink, forecast):
+    """A sink that KEEPS the time steps (evaluation.RunningConcat): every
+    (element, time step) entry of the source table has a destination of its
+    own, row(time label, lead label) * rest size + rest index.  Structural, on
+    the device once: which row of the chunk an entry goes to (`sel`), its rest
+    size and rest offset in bytes.  Per chunk: the rows of the chunk's label
+    combinations (a handful of integers) and four small device ops."""
+    if self._kept is None:
+      sel, rsz8, rest8, vid, groups = [], [], [], [], {}
+      for i, (name, dims, shape, axis, src, r32) in enumerate(self.variables):
+        key_dims = sink.key_dims(dims)
+        sizes = [shape[dims.index(d)] for d in key_dims]
+        if key_dims not in groups:
+          groups[key_dims] = (sum(g[1] for g in groups.values()),
+                              int(np.prod(sizes)))
+        first = groups[key_dims][0]
+        inner = [(d, n) for d, n in zip(dims, shape) if d != self.time_dim]
+        grid = np.indices([n for _, n in inner]).reshape(len(inner), -1)
+        lead = np.zeros(grid.shape[1], dtype=np.int64)
+        rest = np.zeros(grid.shape[1], dtype=np.int64)
+        rest_size = 1
+        for (d, n), idx in zip(inner, grid):
+          if d == self.split_dim:
+            lead = idx
+          else:
+            rest, rest_size = rest * n + idx, rest_size * n
+        n_lead = sizes[1] if len(sizes) == 2 else 1
+        steps = np.arange(self.n_time, dtype=np.int64)
+        # [element][time]: row (t, lead of the element) of the chunk's group
+        sel.append((first + steps[None, :] * n_lead + lead[:, None]).ravel())
+        rest8.append(np.repeat(8 * rest, self.n_time))
+        rsz8.append(np.full(rest.size * self.n_time, 8 * rest_size, np.int64))
+        vid.append(np.full(rest.size * self.n_time, i, np.int64))
+      dev = lambda parts: torch.as_tensor(np.concatenate(parts)).to(self.device)
+      each = np.concatenate([np.repeat(v[5], self.n_time)
+                             for v in self.variables]).astype(np.uint8)
+      self._kept = {'sel': dev(sel), 'rsz8': dev(rsz8), 'rest8': dev(rest8),
+                    'vid': dev(vid), 'groups': groups, 'stamp': None,
+                    'round': torch.as_tensor(each).to(self.device)}
+    k = self._kept
+    rows = {g: sink.rows(forecast, g).ravel() for g in k['groups']}
+    accs = []
+    for name, dims, shape, axis, src, _ in self.variables:
+      acc = sink.storage(name, dims, shape, None)
+      acc.claim(rows[acc.key_dims].tolist(), len(sink._rows[acc.key_dims]),
+                name)
+      accs.append(acc)
+    stamp = tuple(a.total.data_ptr() for a in accs)
+    if stamp != k['stamp']:   # first chunk, or a storage has grown
+      sums = engine.upload_table(np.array(stamp, dtype=np.int64), self.device,
+                                 cache=False)
+      counts = engine.upload_table(
+          np.array([a.count.data_ptr() for a in accs], dtype=np.int64),
+          self.device, cache=False)
+      k['sum0'] = sums[k['vid']] + k['rest8']
+      k['count0'] = counts[k['vid']] + k['rest8']
+      k['stamp'] = stamp
+    chunk_rows = engine.upload_table(np.concatenate(list(rows.values())),
+                                     self.device, cache=False)
+    offset = chunk_rows[k['sel']] * k['rsz8']
+    return k['sum0'] + offset, k['count0'] + offset, k['round']
 
   # -- accumulator addresses --------------------------------------------------
   def _accumulator_tables(self, mean, labels):
@@ -350,6 +413,16 @@ class ChunkProgram:
       dev_addr = engine.upload_table(addr, self.device, cache=False)
       la.step.aligned = bool(aligned)
       la.step.run(None, list(dev_addr), metrics=out, stream_ptr=stream)
+    if getattr(mean, 'keeps_time', False):
+      # one destination per (element, time step): 0 + value, exact
+      d_sum, d_cnt, round_each = self._kept_tables(mean, forecast)
+      status = self._lib.wb2_gather_accumulate(
+          self.arena.data_ptr(), self.src.data_ptr(), round_each.data_ptr(),
+          self.n_out * self.n_time, 1, 0, d_sum.data_ptr(), d_cnt.data_ptr(),
+          stream)
+      if status != 0:
+        _lib.check(status, 'wb2_gather_accumulate')
+      return
     labels = None
     if self.split_dim is not None:
       labels = np.asarray(forecast.coords[self.split_dim])
@@ -436,8 +509,18 @@ def _build(first, forecast, truth, result, mean, loop):
                       moved.reshape(-1, n_time).cpu().numpy(),
                       flags[:, 0].cpu().numpy()))
     acc = mean._acc.get(name)
-    if acc is None or acc.dims != tuple(d for d in da.dims if d != time_dim):
+    kept = getattr(mean, 'keeps_time', False)
+    if acc is None or acc.dims != tuple(
+        d for d in da.dims if kept or d != time_dim):
       return _no('accumulator layout differs')
+    if kept:
+      # the program files a chunk under the FORECAST's labels
+      for d in acc.key_dims:
+        mine, theirs = forecast.coords.get(d), result.coords.get(d)
+        if mine is None or theirs is None or isinstance(
+            mine, xl.DataArray) or isinstance(theirs, xl.DataArray) or not (
+                np.array_equal(np.asarray(mine), np.asarray(theirs))):
+          return _no(f'result {d!r} labels are not the forecast chunk\'s')
   if set(result.data_vars) != {v[0] for v in variables}:
     return _no('result variables differ')
   if len({v[4].shape[1] for v in variables}) != 1:
