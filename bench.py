@@ -865,6 +865,13 @@ def compact(out: dict) -> dict:
       line['api_official_chunk']['deterministic_temporal'] = (
           _pick(dt, 'error') if 'error' in dt else
           {k: _pick(v, 'value', 'host_ms_per_chunk') for k, v in dt.items()})
+    if 'deterministic_spatial' in oc:
+      ds = oc['deterministic_spatial']
+      line['api_official_chunk']['deterministic_spatial'] = _pick(
+          ds, 'value', 'steady_ms_per_chunk', 'error')
+      if 'roofline' in ds:
+        line['api_official_chunk']['deterministic_spatial']['frac'] = (
+            ds['roofline'].get('frac'))
   if 'pcie_inclusive' in out:
     pc = out['pcie_inclusive']
     line['pcie_inclusive'] = {

@@ -448,6 +448,16 @@ int wb2_time_accumulate_scatter(int dtype, const void* values, int64_t n_lead,
                                 int64_t n_time, int64_t n_tail, int skipna,
                                 const int64_t* dst, double* sum, double* count,
                                 void* stream);
+/* The same with one table entry per RUN of `run` consecutive result elements
+ * that go to consecutive accumulator elements: element idx goes to
+ * dst[idx / run] + idx % run (dst: DEV int64[n_lead * n_tail / run]; run must
+ * divide n_lead * n_tail; the destination ranges must not overlap).  Map-valued
+ * results (the Spatial* metrics, metrics.py:304-374) split by lead time need
+ * one entry per slab instead of one per grid point. */
+int wb2_time_accumulate_runs(int dtype, const void* values, int64_t n_lead,
+                             int64_t n_time, int64_t n_tail, int skipna,
+                             const int64_t* dst, int64_t run, double* sum,
+                             double* count, void* stream);
 
 /*
  * One chunk of the deterministic suite in ONE call: K1 (wb2_stream_partials_ex /
@@ -568,7 +578,28 @@ int wb2_energy_score(int dtype, int skipna, const void* ens,
  *   sum[3][n_rest][n_point] (order bias, mse, mae) and, when skipna, the number
  *   of non-NaN terms to count[3][n_rest][n_point].  Slab of (time i, rest j) =
  *   table[i * n_rest + j] (identity when NULL).
+ * wb2_spatial_accumulate_addr: the same for EVERY variable of a chunk (or of a
+ *   window of chunks) in one launch, into accumulators that are separate
+ *   allocations -- what `deterministic_spatial` (scripts/evaluate.py:471-478)
+ *   does per `init_time=1,lead_time=1` chunk before xbeam.Mean.  Destination j
+ *   (a (variable, lead, level) slab of the running mean) receives the chunk's
+ *   n_time steps in order; the sums CONTINUE from the accumulators value by
+ *   value (sum = ((sum + v_0) + v_1) ...: the bits do not depend on how many
+ *   steps a call brings).
+ *     f_addr, t_addr  DEV int64[n_time][n_dst]: byte address of the slab
+ *                     (n_point elements of `dtype`) of step i for destination j
+ *     sum_addr        DEV int64[3][n_dst]: byte address of double[n_point] for
+ *                     bias / mse / mae of destination j; 0 = not wanted
+ *     count_addr      the same for the counts of non-NaN terms (skipna != 0
+ *                     only; NULL otherwise: the caller adds n_time itself)
+ *     aligned16       != 0: every slab address is 16-byte aligned and n_point
+ *                     is a multiple of 16 / sizeof(dtype)
  */
+int wb2_spatial_accumulate_addr(int dtype, int skipna, int aligned16,
+                                const int64_t* f_addr, const int64_t* t_addr,
+                                int64_t n_time, int64_t n_dst, int64_t n_point,
+                                const int64_t* sum_addr,
+                                const int64_t* count_addr, void* stream);
 int wb2_spatial_maps(int dtype, const void* forecast, const int64_t* f_slab,
                      const void* truth, const int64_t* t_slab, int64_t n_outer,
                      int64_t n_point, void* bias, void* mse, void* mae,

@@ -64,15 +64,16 @@ HBM_PEAK_GBPS = 8000.0
 class _Events:
   """HIP events around every K1 launch (engine's launch hook) + a count."""
 
-  def __init__(self, timed: bool):
+  def __init__(self, timed: bool, kernel: str = 'stream_partials'):
     self.timed = timed
+    self.kernel = kernel
     self.pairs: list = []
     self.launches = 0
     self.cur = None
 
   def __call__(self, when, kernel):
     import torch
-    if kernel != 'stream_partials':
+    if kernel != self.kernel:
       return
     if when == 'begin':
       self.launches += 1
@@ -182,6 +183,82 @@ def temporal_config(cfg):
   metrics['rmse_sqrt_before_time_avg'] = gm.RMSESqrtBeforeTimeAvg(
       wind_vector_rmse=wv)
   return dataclasses.replace(cfg, metrics=metrics, temporal_mean=False)
+
+
+def spatial_config():
+  """The `deterministic_spatial` config of the documented command line
+  (scripts/evaluate.py:431-435, 471-478) without the SpatialSEEPS pair: bias,
+  mse and mae maps of every variable, no regions, temporal mean."""
+  from weatherbench2_amd import config, metrics as gm
+  return config.Eval(metrics={'bias': gm.SpatialBias(), 'mse': gm.SpatialMSE(),
+                              'mae': gm.SpatialMAE()})
+
+
+# read forecast + truth, read and write three float64 running sums
+SPATIAL_BYTES_PER_POINT = 8.0 + 3 * 16.0
+
+
+def measure_spatial(chunks, short: int = 64, long: int = 256) -> dict:
+  """`deterministic_spatial` through evaluate_chunks, chunk by chunk (windows
+  of map-metric chunks are not joined).  The first chunk of a structure takes
+  the generic path and result() brings 8.5 GB of mean maps to the host --
+  one-offs that a production run spreads over ~10^4 chunks: reported are the
+  fused kernel (map_suite.py) under HIP events, the host time per chunk from
+  two list lengths (up to the moment result() is called), and the walls."""
+  import torch
+  from weatherbench2_amd import engine, evaluation
+  cfg = spatial_config()
+  evaluation.evaluate_chunks(chunks[:4], cfg, False, prefetch=0, batch_chunks=1)
+  walls, hosts = {}, {}
+  marks = {}
+  real_result = evaluation.RunningMean.result
+
+  def result(self):
+    marks['enqueued'] = time.perf_counter()
+    return real_result(self)
+  ev = None
+  for n in (short, long):
+    ev = _Events(True, 'spatial_accumulate')
+    old = engine.set_launch_hook(ev)
+    evaluation.RunningMean.result = result
+    try:
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      out = evaluation.evaluate_chunks(chunks[:n], cfg, False, prefetch=0,
+                                       batch_chunks=1)
+      torch.cuda.synchronize()
+      walls[n] = time.perf_counter() - t0
+      hosts[n] = marks['enqueued'] - t0
+    finally:
+      evaluation.RunningMean.result = real_result
+      engine.set_launch_hook(old)
+    del out
+  host_ms = (hosts[long] - hosts[short]) / (long - short) * 1e3
+  ms = [a.elapsed_time(b) for a, b in ev.pairs]
+  kernel_ms = sum(ms) / max(len(ms), 1)
+  bytes_per_chunk = PTS_PER_CHUNK * SPATIAL_BYTES_PER_POINT
+  steady_ms = max(kernel_ms, host_ms)
+  return {
+      'batch_chunks': 1, 'value': PTS_PER_CHUNK / steady_ms * 1e3,
+      'unit': 'grid-point-evals/s',
+      'steady_ms_per_chunk': steady_ms, 'host_ms_per_chunk': host_ms,
+      'wall_s': {str(k): v for k, v in walls.items()},
+      'fused_launches': len(ms),
+      'roofline': {
+          'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
+          'kernel': 'spatial_accumulate_addr_kernel<float,4,false> over '
+                    f'{SLABS_PER_CHUNK} destinations x 1 step',
+          'kernel_ms_per_chunk': kernel_ms,
+          'algorithmic_bytes_per_chunk': bytes_per_chunk,
+          'achieved': bytes_per_chunk / kernel_ms / 1e6,
+          'frac': bytes_per_chunk / kernel_ms / 1e6 / HBM_PEAK_GBPS,
+      },
+      'what': 'bias + mse + mae maps of 13 variables (85 slabs) per chunk '
+              'into the float64 running means: 8 B/pt read + 3 x 16 B/pt '
+              'read-modify-write; `value` = points per chunk / max(kernel, '
+              'host) time per chunk (the walls include the generic first '
+              'chunk and the 8.5 GB result copy)',
+  }
 
 
 def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
@@ -357,6 +434,10 @@ def run(dev, n_chunks: int = 512, pool: int = 32,
     out['deterministic_temporal'] = temporal
   except Exception as e:
     out['deterministic_temporal'] = {'error': f'{type(e).__name__}: {e}'}
+  try:
+    out['deterministic_spatial'] = measure_spatial(chunks)
+  except Exception as e:
+    out['deterministic_spatial'] = {'error': f'{type(e).__name__}: {e}'}
   if host_fed:
     try:
       out['host_fed'] = measure_host_fed(chunks, cfg)

@@ -82,6 +82,8 @@ _SIGNATURES = {
                                    _vp]),
     'wb2_time_accumulate_scatter': (_int, [_int, _vp, _i64, _i64, _i64, _int,
                                            _vp, _vp, _vp, _vp]),
+    'wb2_time_accumulate_runs': (_int, [_int, _vp, _i64, _i64, _i64, _int,
+                                        _vp, _i64, _vp, _vp, _vp]),
     'wb2_ens_partials': (_int, [
         _int, _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp,
         _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -120,6 +122,8 @@ _SIGNATURES = {
                                 _vp, _vp]),
     'wb2_spatial_accumulate': (_int, [_int, _int, _vp, _vp, _vp, _vp, _i64,
                                       _i64, _i64, _vp, _vp, _vp]),
+    'wb2_spatial_accumulate_addr': (_int, [_int, _int, _int, _vp, _vp, _i64,
+                                           _i64, _i64, _vp, _vp, _vp]),
     'wb2_spectrum_plan_create': (_int, [_int, _i32, _i64, _c.POINTER(_vp)]),
     'wb2_spectrum_plan_destroy': (_int, [_vp]),
     'wb2_spectrum_plan_workspace': (_i64, [_vp]),

@@ -160,6 +160,89 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+struct SpatialAddrParams {
+  const long long* f_addr;      // [n_time][n_dst]
+  const long long* t_addr;
+  const long long* sum_addr;    // [3][n_dst], 0 = not wanted
+  const long long* count_addr;  // [3][n_dst] (skipna only)
+  long long n_time, n_dst, n_point;
+};
+
+// grid: x = point blocks, y = destination.  The thread owns VEC points of one
+// destination: it reads the (up to three) running sums, adds the chunk's time
+// steps value by value and writes them back.
+template <typename T, int VEC, bool SKIPNA>
+__global__ void __launch_bounds__(256)
+    spatial_accumulate_addr_kernel(const SpatialAddrParams p) {
+  const long long q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (q >= p.n_point) return;
+  const long long j = blockIdx.y + (long long)blockIdx.z * gridDim.y;
+  if (j >= p.n_dst) return;
+  double* sp[3];
+  double* cp[3];
+  double s[3][VEC], c[3][VEC];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    sp[m] = reinterpret_cast<double*>(p.sum_addr[m * p.n_dst + j]);
+    cp[m] = SKIPNA ? reinterpret_cast<double*>(p.count_addr[m * p.n_dst + j])
+                   : nullptr;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      s[m][e] = sp[m] ? sp[m][q + e] : 0.0;
+      c[m][e] = (SKIPNA && cp[m]) ? cp[m][q + e] : 0.0;
+    }
+  }
+  auto body = [&](const T (&f)[VEC], const T (&t)[VEC]) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const T d = f[e] - t[e];
+      const T d2 = d * d;
+      const T ad = abs_of(d);
+      const bool keep = !(SKIPNA && is_nan(d));
+      s[0][e] += keep ? (double)d : 0.0;
+      s[1][e] += keep ? (double)d2 : 0.0;
+      s[2][e] += keep ? (double)ad : 0.0;
+      if constexpr (SKIPNA) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) c[m][e] += keep ? 1.0 : 0.0;
+      }
+    }
+  };
+  constexpr int U = 4;  // time steps in flight
+  long long i = 0;
+  for (; i + U <= p.n_time; i += U) {
+    T f[U][VEC], t[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long o = (i + u) * p.n_dst + j;
+      load_v<T, VEC>(reinterpret_cast<const T*>(p.f_addr[o]) + q, f[u]);
+      load_v<T, VEC>(reinterpret_cast<const T*>(p.t_addr[o]) + q, t[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) body(f[u], t[u]);
+  }
+  for (; i < p.n_time; ++i) {
+    const long long o = i * p.n_dst + j;
+    T f[VEC], t[VEC];
+    load_v<T, VEC>(reinterpret_cast<const T*>(p.f_addr[o]) + q, f);
+    load_v<T, VEC>(reinterpret_cast<const T*>(p.t_addr[o]) + q, t);
+    body(f, t);
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    if (sp[m]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sp[m][q + e] = s[m][e];
+    }
+    if constexpr (SKIPNA) {
+      if (cp[m]) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) cp[m][q + e] = c[m][e];
+      }
+    }
+  }
+}
+
 int pick_vec(int dtype, long long n_point, const void* a, const void* b,
              void* const* outs) {
   const int w = dtype == WB2_F32 ? 4 : 2;
@@ -247,6 +330,48 @@ int wb2_spatial_accumulate(int dtype, int skipna, const void* forecast,
     else                                                                     \
       hipLaunchKernelGGL((spatial_accumulate_kernel<T, V, false>), grid,     \
                          dim3(256), 0, s, p);                                \
+  } while (0)
+  if (dtype == WB2_F32) { if (vec > 1) WB2_L(float, 4); else WB2_L(float, 1); }
+  else { if (vec > 1) WB2_L(double, 2); else WB2_L(double, 1); }
+#undef WB2_L
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int wb2_spatial_accumulate_addr(int dtype, int skipna, int aligned16,
+                                const int64_t* f_addr, const int64_t* t_addr,
+                                int64_t n_time, int64_t n_dst, int64_t n_point,
+                                const int64_t* sum_addr,
+                                const int64_t* count_addr, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_time);
+  WB2_EMPTY_OK(n_dst);
+  WB2_REQUIRE(f_addr && t_addr && sum_addr && (count_addr || !skipna),
+              "null pointer argument");
+  WB2_REQUIRE(n_point > 0, "bad sizes");
+  if (n_time == 0 || n_dst == 0) return 0;
+  SpatialAddrParams p{};
+  p.f_addr = reinterpret_cast<const long long*>(f_addr);
+  p.t_addr = reinterpret_cast<const long long*>(t_addr);
+  p.sum_addr = reinterpret_cast<const long long*>(sum_addr);
+  p.count_addr = reinterpret_cast<const long long*>(count_addr);
+  p.n_time = n_time;
+  p.n_dst = n_dst;
+  p.n_point = n_point;
+  const int w = dtype == WB2_F32 ? 4 : 2;
+  const int vec = (aligned16 && n_point % w == 0) ? w : 1;
+  const dim3 grid = grid_for(n_point, vec, n_dst);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define WB2_L(T, V)                                                          \
+  do {                                                                       \
+    if (skipna)                                                              \
+      hipLaunchKernelGGL((spatial_accumulate_addr_kernel<T, V, true>), grid, \
+                         dim3(256), 0, s, p);                                \
+    else                                                                     \
+      hipLaunchKernelGGL((spatial_accumulate_addr_kernel<T, V, false>),      \
+                         grid, dim3(256), 0, s, p);                          \
   } while (0)
   if (dtype == WB2_F32) { if (vec > 1) WB2_L(float, 4); else WB2_L(float, 1); }
   else { if (vec > 1) WB2_L(double, 2); else WB2_L(double, 1); }

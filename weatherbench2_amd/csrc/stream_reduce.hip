@@ -966,13 +966,19 @@ template <typename T>
 __global__ void __launch_bounds__(256)
     time_accumulate_kernel(const T* __restrict__ values, long long n_lead,
                            long long n_time, long long n_tail, int skipna,
-                           const long long* __restrict__ dst,
+                           const long long* __restrict__ dst, long long run,
                            double* __restrict__ sum,
                            double* __restrict__ count) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_lead * n_tail) return;
   const long long l = idx / n_tail, j = idx - l * n_tail;
-  const long long out = dst ? dst[idx] : idx;
+  // `run` consecutive result elements go to consecutive accumulator elements:
+  // one table entry per run (maps: one per slab, not one per grid point)
+  long long out = idx;
+  if (dst) {
+    const long long r = run > 1 ? idx / run : idx;
+    out = dst[r] + (idx - r * run);
+  }
   double s = sum[out], c = count[out];
   const T* base = values + l * n_time * n_tail + j;
   auto add = [&](double v) {  // float32 values widen exactly
@@ -1526,27 +1532,39 @@ int wb2_time_accumulate_scatter(int dtype, const void* values, int64_t n_lead,
                                 const int64_t* dst, double* sum, double* count,
                                 void* stream) {
   WB2_TRACE();
+  return wb2_time_accumulate_runs(dtype, values, n_lead, n_time, n_tail, skipna,
+                                  dst, 1, sum, count, stream);
+}
+
+int wb2_time_accumulate_runs(int dtype, const void* values, int64_t n_lead,
+                             int64_t n_time, int64_t n_tail, int skipna,
+                             const int64_t* dst, int64_t run, double* sum,
+                             double* count, void* stream) {
+  WB2_TRACE();
   using namespace wb2;
   WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE(run >= 1, "run=%lld", (long long)run);
   WB2_EMPTY_OK(n_lead);
   WB2_EMPTY_OK(n_time);
   WB2_EMPTY_OK(n_tail);
   WB2_REQUIRE(values && sum && count, "null pointer argument");
   const long long n = n_lead * n_tail;
   if (n == 0 || n_time == 0) return 0;
+  WB2_REQUIRE(!dst || n % run == 0, "run=%lld does not divide %lld elements",
+              (long long)run, n);
   const dim3 grid((unsigned)((n + 255) / 256));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long long* d = reinterpret_cast<const long long*>(dst);
   if (dtype == WB2_F32)
     hipLaunchKernelGGL(time_accumulate_kernel<float>, grid, dim3(256), 0, s,
                        static_cast<const float*>(values), (long long)n_lead,
-                       (long long)n_time, (long long)n_tail, skipna, d, sum,
-                       count);
+                       (long long)n_time, (long long)n_tail, skipna, d,
+                       (long long)run, sum, count);
   else
     hipLaunchKernelGGL(time_accumulate_kernel<double>, grid, dim3(256), 0, s,
                        static_cast<const double*>(values), (long long)n_lead,
-                       (long long)n_time, (long long)n_tail, skipna, d, sum,
-                       count);
+                       (long long)n_time, (long long)n_tail, skipna, d,
+                       (long long)run, sum, count);
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -667,11 +667,12 @@ def energy_score(plan: ReductionPlan, ens: torch.Tensor, member_stride: int,
 
 def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
                     total: torch.Tensor, count: torch.Tensor,
-                    dst: t.Optional[torch.Tensor] = None):
+                    dst: t.Optional[torch.Tensor] = None, run: int = 1):
   """total/count += sum/notnull-count of `values` (float32 or float64) over
   `time_axis` (device); the sums continue from the accumulators value by value.  `dst` (int64 device
-  tensor, one entry per element of `values` without its time axis): where in
-  `total` / `count` each result element goes (identity without it)."""
+  tensor, one entry per RUN of `run` consecutive elements of `values` without
+  its time axis): where in `total` / `count` the run goes (identity without
+  it)."""
   lib = _lib.load()
   if values.dtype not in _DTYPES:
     values = values.to(torch.float64)
@@ -683,15 +684,16 @@ def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
   if dst is None:
     if total.numel() != n_lead * n_tail or count.numel() != n_lead * n_tail:
       raise ValueError('accumulator shape mismatch')
-  elif (dst.dtype != torch.int64 or dst.numel() != n_lead * n_tail
+  elif (dst.dtype != torch.int64 or run < 1 or (n_lead * n_tail) % run
+        or dst.numel() != n_lead * n_tail // run
         or total.numel() != count.numel()):
-    raise ValueError('dst is int64 with one entry per result element')
+    raise ValueError('dst is int64 with one entry per run of result elements')
   # (the entries of `dst` must be distinct and < total.numel(): the kernel
   # reads, adds and writes each destination without atomics.  RunningMean
   # builds them on the host -- _Accumulator.destinations -- and checks there.)
-  _lib.check(lib.wb2_time_accumulate_scatter(
+  _lib.check(lib.wb2_time_accumulate_runs(
       _DTYPES[values.dtype], _lib.ptr(values), n_lead, n_time, n_tail,
-      int(skipna), _lib.ptr(dst),
+      int(skipna), _lib.ptr(dst), int(run),
       _lib.ptr(total), _lib.ptr(count), current_stream_ptr(values.device)),
              'wb2_time_accumulate')
 

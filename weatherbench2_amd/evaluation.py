@@ -228,6 +228,11 @@ def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
   return xl.like_input(out, *given)
 
 
+# destination tables of RunningMean: one entry per run of this many (or more)
+# consecutive elements behind the split dim, one per element below
+_RUN_MIN = 256
+
+
 class _Accumulator:
   """(sum, count) of one result variable.  Without a split dim: tensors of the
   result's shape (minus the averaged dim).  With one: [row, *rest], one row per
@@ -239,6 +244,10 @@ class _Accumulator:
     self.labels: list = []     # label arrays (0-d), row order
     self.row_of: dict = {}     # label value -> row
     self.dst: dict = {}        # label-vector key -> device int64 table
+    # time steps counted on the host (map_suite.py: without skipna every
+    # element of a row gains the same count -- no pass over the count maps per
+    # chunk): row (None without a split dim) -> steps not yet in `count`
+    self.pending: dict = {}
     if split is None:
       self.rest_shape = shape
       alloc = shape
@@ -268,6 +277,28 @@ class _Accumulator:
       self.total = torch.cat([self.total, grow])
       self.count = torch.cat([self.count, torch.zeros_like(grow)])
     return out
+
+  def settle(self):
+    """Brings the host-side step counts into `count`."""
+    for row, steps in self.pending.items():
+      if row is None:
+        self.count += float(steps)
+      else:
+        self.count[row] += float(steps)
+    self.pending = {}
+
+  def destination_runs(self, rows: np.ndarray) -> tuple:
+    """(first accumulator element of every RUN of result elements, run
+    length): the elements behind the split dim are consecutive in the result
+    and in the accumulator -- a map-valued result needs one entry per slab."""
+    block = int(np.prod(self.rest_shape, dtype=np.int64))
+    run = int(np.prod(self.shape[self.pos + 1:], dtype=np.int64))
+    n_outer = int(np.prod(self.shape[:self.pos], dtype=np.int64))
+    dst = (rows[None, :] * block +
+           np.arange(n_outer, dtype=np.int64)[:, None] * run).ravel()
+    if dst.size and (dst.min() < 0 or dst.max() + run > self.total.numel()):
+      raise ValueError('accumulator destination out of range')  # (host check)
+    return dst, run
 
   def destinations(self, rows: np.ndarray) -> np.ndarray:
     """Accumulator element of every element of a result of `self.shape`."""
@@ -369,6 +400,8 @@ class RunningMean:
       if acc is None:
         acc = self._acc[name] = _Accumulator(dims, shape if split is None
                                              else shape, split, self.device)
+      if acc.pending:
+        acc.settle()
       if acc.dims != dims or acc.split != split or (
           acc.rest_shape != (shape if split is None else
                              shape[:acc.pos] + shape[acc.pos + 1:])):
@@ -379,16 +412,20 @@ class RunningMean:
         labels = np.asarray(labels)
         rows = acc.rows(labels)
       if self._on_gpu():
-        dst = None
+        dst, run = None, 1
         if rows is not None:
           key = (shape, rows.tobytes())
-          dst = acc.dst.get(key)
-          if dst is None:
+          hit = acc.dst.get(key)
+          if hit is None:
             acc.shape = shape
-            dst = acc.dst[key] = engine.upload_table(acc.destinations(rows),
-                                                     self.device)
+            # long runs behind the split dim (maps): one entry per run
+            inner = int(np.prod(shape[acc.pos + 1:], dtype=np.int64))
+            table, run = (acc.destination_runs(rows) if inner >= _RUN_MIN
+                          else (acc.destinations(rows), 1))
+            hit = acc.dst[key] = (engine.upload_table(table, self.device), run)
+          dst, run = hit
         engine.time_accumulate(values.to(self.device).contiguous(), axis,
-                               self.skipna, acc.total, acc.count, dst)
+                               self.skipna, acc.total, acc.count, dst, run)
       else:  # host accumulators (CPU tests of the sharding logic)
         values = values.cpu()
         ok = ~torch.isnan(values) if self.skipna else torch.ones_like(
@@ -458,6 +495,8 @@ class RunningMean:
                        'nothing: give every rank at least one chunk '
                        '(evaluate_chunks checks this up front)')
     names = sorted(self._acc)
+    for n in names:
+      self._acc[n].settle()
     labels = self._split_labels(names)
     # (sum, count) in output layout: rows in label order, labels a rank never
     # met (lead-major chunk lists) as zeros
@@ -1092,8 +1131,14 @@ def _evaluate_piece(forecast, truth_chunk, eval_config, skipna, mean,
   mean.add(result)
   built = None
   if mean._on_gpu():
-    built = program.build(rec, forecast, truth_chunk, xl.as_dataset(result),
-                          mean, loop)
+    from weatherbench2_amd import map_suite
+    if map_suite.applies(eval_config):
+      # map metrics (`deterministic_spatial`): one fused launch per chunk
+      built = map_suite.build(eval_config, forecast, truth_chunk, result, mean,
+                              skipna)
+    else:
+      built = program.build(rec, forecast, truth_chunk, xl.as_dataset(result),
+                            mean, loop)
   programs[sig] = built or False
 
 
@@ -1108,6 +1153,8 @@ def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
   def snapshot():
     if kept:
       return mean.snapshot()
+    for n in names:
+      mean._acc[n].settle()
     return {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone(),
                 list(mean._acc[n].labels), dict(mean._acc[n].row_of))
             for n in names}
@@ -1133,9 +1180,7 @@ def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
           ((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
       if not same:
         raise AssertionError(f'chunk program and generic path differ on {n}')
-  prog._targets.clear()   # (the accumulators were replaced: new addresses)
-  if prog._kept is not None:
-    prog._kept['stamp'] = None
+  prog.reset()   # (the accumulators were replaced: new addresses)
 
 
 # K1 chunking of evaluate_chunks (pinned: the result must not depend on how

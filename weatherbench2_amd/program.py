@@ -373,6 +373,12 @@ class ChunkProgram:
     offset = chunk_rows[k['sel']] * k['rsz8']
     return k['sum0'] + offset, k['count0'] + offset, k['round']
 
+  def reset(self):
+    """Forget cached accumulator addresses (the accumulators were replaced)."""
+    self._targets.clear()
+    if self._kept is not None:
+      self._kept['stamp'] = None
+
   # -- accumulator addresses --------------------------------------------------
   def _accumulator_tables(self, mean, labels):
     """Device tables of the (sum, count) ADDRESS of every output element for
