@@ -453,7 +453,9 @@ int wb2_time_accumulate_scatter(int dtype, const void* values, int64_t n_lead,
  * dst[idx / run] + idx % run (dst: DEV int64[n_lead * n_tail / run]; run must
  * divide n_lead * n_tail; the destination ranges must not overlap).  Map-valued
  * results (the Spatial* metrics, metrics.py:304-374) split by lead time need
- * one entry per slab instead of one per grid point. */
+ * one entry per slab instead of one per grid point.  count may be NULL when
+ * skipna == 0 (every element gains n_time: a caller may keep that number on
+ * the host). */
 int wb2_time_accumulate_runs(int dtype, const void* values, int64_t n_lead,
                              int64_t n_time, int64_t n_tail, int skipna,
                              const int64_t* dst, int64_t run, double* sum,

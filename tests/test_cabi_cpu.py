@@ -114,6 +114,22 @@ def test_new_entry_points_validate_their_arguments(lib):
                                  None) < 0
   assert h.wb2_uploader_upload(None, None, None, 16, None) < 0
   assert b'null uploader' in h.wb2_last_error()
+  # the map entries: empty chunks are no-ops, the rest is checked up front
+  assert h.wb2_spatial_accumulate_addr(lib.WB2_F32, 0, 1, None, None, 0, 5,
+                                       100, None, None, None) == 0
+  assert h.wb2_spatial_accumulate_addr(lib.WB2_F32, 0, 1, None, None, 2, 0,
+                                       100, None, None, None) == 0
+  rc = h.wb2_spatial_accumulate_addr(lib.WB2_F32, 0, 1, None, None, 2, 5, 100,
+                                     None, None, None)
+  assert rc < 0 and b'null pointer' in h.wb2_last_error()
+  rc = h.wb2_spatial_accumulate_addr(9, 0, 1, None, None, 2, 5, 100, None,
+                                     None, None)
+  assert rc < 0 and b'unknown dtype' in h.wb2_last_error()
+  rc = h.wb2_time_accumulate_runs(lib.WB2_F32, None, 2, 1, 8, 0, None, 0, None,
+                                  None, None)
+  assert rc < 0 and b'run=0' in h.wb2_last_error()
+  assert h.wb2_time_accumulate_runs(lib.WB2_F32, None, 0, 1, 8, 0, None, 4,
+                                    None, None, None) == 0
   # the struct is the header's: 8 int32, 3 pointers, 2 int32, pointer, double,
   # 9 pointers
   assert ctypes.sizeof(lib.PlanTables) == 8 * 4 + 3 * 8 + 2 * 4 + 8 + 8 + 9 * 8

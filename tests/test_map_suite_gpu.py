@@ -132,6 +132,76 @@ def test_float64_inputs_and_the_unaligned_layout(monkeypatch):
     assert calls
 
 
+@pytest.mark.parametrize('skipna', [False, True])
+@pytest.mark.parametrize('order', ['init', 'lead'])
+def test_with_the_spatial_seeps_pair_of_compute_seeps(order, skipna,
+                                                      monkeypatch):
+  """`--compute_seeps=True` adds two SpatialSEEPS entries to the config
+  (scripts/evaluate.py:446-457): maps of their precipitation variable only,
+  NaN for every other variable in the merged result.  The suite fuses the three
+  map metrics, lets SpatialSEEPS compute its own map and accumulates it slab by
+  slab; rows of new lead labels get their NaN fills -- the generic path's bits,
+  and the oracle's SpatialSEEPS time mean."""
+  import warnings
+  from oracle import metrics_np as om
+  from oracle.named import DS, NA
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  forecast, truth, clim = oc.make(n_init=4, n_lead=3, n_lat=19, n_lon=36)
+  rs = np.random.RandomState(5)
+  names = ('2m_temperature', '10m_u_component_of_wind')
+  cvars = dict(clim.items())
+  for name in names:
+    shape, cdims = clim[name].data.shape, clim[name].dims
+    cvars[f'{name}_seeps_threshold'] = NA(
+        rs.uniform(0.3, 1.2, size=shape).astype(np.float32), cdims)
+    frac = rs.uniform(0.0, 1.0, size=shape).astype(np.float32)
+    frac[:, :, 3, 5] = np.nan
+    cvars[f'{name}_seeps_dry_fraction'] = NA(frac, cdims)
+  clim = DS(cvars, clim.coords)
+  gf, gt, gc = (evaluation.make_resident(helpers.to_gpu_dataset(x))
+                for x in (forecast, truth, clim))
+  metrics = {'bias': gm.SpatialBias(), 'mse': gm.SpatialMSE(),
+             'mae': gm.SpatialMAE()}
+  for key, name in zip(('seeps_a', 'seeps_b'), names):
+    metrics[key] = gm.SpatialSEEPS(climatology=gc, precip_name=name,
+                                   dry_threshold_mm=100.0)
+  cfg = config.Eval(metrics=metrics)
+  chunks = oc.chunk_pairs(gf, gt, order=order)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                    batch_chunks=1)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+  calls = _count_runs(monkeypatch)
+  got = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                   batch_chunks=1)
+  _same(got, want)
+  assert len(calls) == len(chunks) - 1
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', 'verify')
+  _same(evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                   batch_chunks=1), want)
+  labels = list(got.coords['metric'])
+  # every other variable is NaN under the SEEPS labels
+  assert np.isnan(got['geopotential'].values[labels.index('seeps_a')]).all()
+  assert np.isnan(got[names[1]].values[labels.index('seeps_a')]).all()
+  assert np.isfinite(got['geopotential'].values[labels.index('mse')]).all()
+  for key, name in zip(('seeps_a', 'seeps_b'), names):
+    oseeps = om.SpatialSEEPS(climatology=clim, precip_name=name,
+                             dry_threshold_mm=100.0)
+    with np.errstate(all='ignore'):
+      per = oseeps.compute_chunk(forecast, truth)[name]
+    ax = per.dims.index('init_time')
+    data = np.asarray(per.data, dtype=np.float64)
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      mean = (np.nanmean if skipna else np.mean)(data, axis=ax)
+    dims = tuple(d for d in per.dims if d != 'init_time')
+    res = got[name]
+    rdims = [d for d in res.dims if d != 'metric']
+    vals = np.transpose(res.values[labels.index(key)],
+                        [rdims.index(d) for d in dims])
+    helpers.assert_close(vals, mean, rtol=1e-9, atol=1e-12, err_msg=key)
+
+
 def test_later_chunks_reuse_the_first_chunks_offsets(monkeypatch):
   """Device-resident chunks of one structure: the slab offsets and destination
   offsets are worked out once (MapSuite._first), later chunks add their base
@@ -170,6 +240,10 @@ def test_other_configs_keep_the_generic_path(monkeypatch):
   more = dict(cfg.metrics)
   more['mse_scalar'] = gm.MSE()
   assert not map_suite.applies(dataclasses.replace(cfg, metrics=more))
+  assert map_suite.applies(dataclasses.replace(cfg, metrics={
+      **cfg.metrics, 'seeps': gm.SpatialSEEPS(climatology=None)}))
+  assert not map_suite.applies(dataclasses.replace(cfg, metrics={
+      'seeps': gm.SpatialSEEPS(climatology=None)}))
   twice = dict(cfg.metrics)
   twice['mse_again'] = gm.SpatialMSE()
   assert not map_suite.applies(dataclasses.replace(cfg, metrics=twice))

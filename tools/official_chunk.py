@@ -185,20 +185,29 @@ def temporal_config(cfg):
   return dataclasses.replace(cfg, metrics=metrics, temporal_mean=False)
 
 
-def spatial_config():
+def spatial_config(cfg=None):
   """The `deterministic_spatial` config of the documented command line
-  (scripts/evaluate.py:431-435, 471-478) without the SpatialSEEPS pair: bias,
-  mse and mae maps of every variable, no regions, temporal mean."""
+  (scripts/evaluate.py:431-457, 471-478): bias, mse and mae maps of every
+  variable + (`--compute_seeps=True`, given `cfg` with the scalar SEEPS pair)
+  the two SpatialSEEPS maps under the reference's keys; no regions, temporal
+  mean."""
   from weatherbench2_amd import config, metrics as gm
-  return config.Eval(metrics={'bias': gm.SpatialBias(), 'mse': gm.SpatialMSE(),
-                              'mae': gm.SpatialMAE()})
+  metrics = {'bias': gm.SpatialBias(), 'mse': gm.SpatialMSE(),
+             'mae': gm.SpatialMAE()}
+  if cfg is not None:
+    for (key, precip, dry), out_key in zip(SEEPS, ('seeps_24hr', 'seels_6hr')):
+      if key in cfg.metrics:
+        metrics[out_key] = gm.SpatialSEEPS(
+            climatology=cfg.metrics[key].climatology, precip_name=precip,
+            dry_threshold_mm=dry)
+  return config.Eval(metrics=metrics)
 
 
 # read forecast + truth, read and write three float64 running sums
 SPATIAL_BYTES_PER_POINT = 8.0 + 3 * 16.0
 
 
-def measure_spatial(chunks, short: int = 64, long: int = 256) -> dict:
+def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256) -> dict:
   """`deterministic_spatial` through evaluate_chunks, chunk by chunk (windows
   of map-metric chunks are not joined).  The first chunk of a structure takes
   the generic path and result() brings 8.5 GB of mean maps to the host --
@@ -207,7 +216,7 @@ def measure_spatial(chunks, short: int = 64, long: int = 256) -> dict:
   two list lengths (up to the moment result() is called), and the walls."""
   import torch
   from weatherbench2_amd import engine, evaluation
-  cfg = spatial_config()
+  cfg = spatial_config(cfg)
   evaluation.evaluate_chunks(chunks[:4], cfg, False, prefetch=0, batch_chunks=1)
   walls, hosts = {}, {}
   marks = {}
@@ -253,9 +262,12 @@ def measure_spatial(chunks, short: int = 64, long: int = 256) -> dict:
           'achieved': bytes_per_chunk / kernel_ms / 1e6,
           'frac': bytes_per_chunk / kernel_ms / 1e6 / HBM_PEAK_GBPS,
       },
+      'metrics': list(cfg.metrics),
       'what': 'bias + mse + mae maps of 13 variables (85 slabs) per chunk '
               'into the float64 running means: 8 B/pt read + 3 x 16 B/pt '
-              'read-modify-write; `value` = points per chunk / max(kernel, '
+              'read-modify-write (the fused kernel; the two SpatialSEEPS maps '
+              'of --compute_seeps are computed and accumulated per slab beside '
+              'it); `value` = points per chunk / max(kernel, '
               'host) time per chunk (the walls include the generic first '
               'chunk and the 8.5 GB result copy)',
   }
@@ -435,7 +447,7 @@ def run(dev, n_chunks: int = 512, pool: int = 32,
   except Exception as e:
     out['deterministic_temporal'] = {'error': f'{type(e).__name__}: {e}'}
   try:
-    out['deterministic_spatial'] = measure_spatial(chunks)
+    out['deterministic_spatial'] = measure_spatial(chunks, cfg)
   except Exception as e:
     out['deterministic_spatial'] = {'error': f'{type(e).__name__}: {e}'}
   if host_fed:

@@ -44,13 +44,20 @@ struct SpatialParams {
 #define WB2_MAPS_STORE(v, p) (*(p) = (v))
 #endif
 
+#ifndef WB2_SPATIAL_IN_NT
+#define WB2_SPATIAL_IN_NT 1
+#endif
 template <typename T, int VEC>
 __device__ __forceinline__ void load_v(const T* p, T (&v)[VEC]) {
   if constexpr (VEC == 1) {
     v[0] = __builtin_nontemporal_load(p);
   } else {
     typedef T V __attribute__((ext_vector_type(VEC)));
+#if WB2_SPATIAL_IN_NT
     const V x = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#else
+    const V x = *reinterpret_cast<const V*>(p);
+#endif
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = x[e];
   }
@@ -160,6 +167,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// the running sums of wb2_spatial_accumulate_addr are touched once per chunk
+// (4+ GB of other traffic in between): streamed past the caches or not
+#ifndef WB2_SPATIAL_ACC_NT
+#define WB2_SPATIAL_ACC_NT 0
+#endif
+__device__ __forceinline__ double acc_load(const double* p) {
+#if WB2_SPATIAL_ACC_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void acc_store(double v, double* p) {
+#if WB2_SPATIAL_ACC_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 struct SpatialAddrParams {
   const long long* f_addr;      // [n_time][n_dst]
   const long long* t_addr;
@@ -188,8 +215,8 @@ __global__ void __launch_bounds__(256)
                    : nullptr;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      s[m][e] = sp[m] ? sp[m][q + e] : 0.0;
-      c[m][e] = (SKIPNA && cp[m]) ? cp[m][q + e] : 0.0;
+      s[m][e] = sp[m] ? acc_load(sp[m] + q + e) : 0.0;
+      c[m][e] = (SKIPNA && cp[m]) ? acc_load(cp[m] + q + e) : 0.0;
     }
   }
   auto body = [&](const T (&f)[VEC], const T (&t)[VEC]) {
@@ -232,12 +259,12 @@ __global__ void __launch_bounds__(256)
   for (int m = 0; m < 3; ++m) {
     if (sp[m]) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) sp[m][q + e] = s[m][e];
+      for (int e = 0; e < VEC; ++e) acc_store(s[m][e], sp[m] + q + e);
     }
     if constexpr (SKIPNA) {
       if (cp[m]) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) cp[m][q + e] = c[m][e];
+        for (int e = 0; e < VEC; ++e) acc_store(c[m][e], cp[m] + q + e);
       }
     }
   }

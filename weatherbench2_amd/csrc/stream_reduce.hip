@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(256)
     const long long r = run > 1 ? idx / run : idx;
     out = dst[r] + (idx - r * run);
   }
-  double s = sum[out], c = count[out];
+  double s = sum[out], c = count ? count[out] : 0.0;
   const T* base = values + l * n_time * n_tail + j;
   auto add = [&](double v) {  // float32 values widen exactly
     const bool keep = !(skipna && is_nan(v));
@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(256)
   }
   for (; t < n_time; ++t) add(base[t * n_tail]);
   sum[out] = s;
-  count[out] = c;
+  if (count) count[out] = c;
 }
 
 // The running temporal mean of a whole chunk RESULT in one launch: output
@@ -1547,7 +1547,8 @@ int wb2_time_accumulate_runs(int dtype, const void* values, int64_t n_lead,
   WB2_EMPTY_OK(n_lead);
   WB2_EMPTY_OK(n_time);
   WB2_EMPTY_OK(n_tail);
-  WB2_REQUIRE(values && sum && count, "null pointer argument");
+  // count == NULL without skipna: the caller counts the time steps itself
+  WB2_REQUIRE(values && sum && (count || !skipna), "null pointer argument");
   const long long n = n_lead * n_tail;
   if (n == 0 || n_time == 0) return 0;
   WB2_REQUIRE(!dst || n % run == 0, "run=%lld does not divide %lld elements",

@@ -681,12 +681,15 @@ def time_accumulate(values: torch.Tensor, time_axis: int, skipna: bool,
   n_lead = int(np.prod(shape[:time_axis], dtype=np.int64))
   n_time = shape[time_axis]
   n_tail = int(np.prod(shape[time_axis + 1:], dtype=np.int64))
+  if count is None and skipna:
+    raise ValueError('skipna needs the count accumulator')
   if dst is None:
-    if total.numel() != n_lead * n_tail or count.numel() != n_lead * n_tail:
+    if total.numel() != n_lead * n_tail or (
+        count is not None and count.numel() != n_lead * n_tail):
       raise ValueError('accumulator shape mismatch')
   elif (dst.dtype != torch.int64 or run < 1 or (n_lead * n_tail) % run
         or dst.numel() != n_lead * n_tail // run
-        or total.numel() != count.numel()):
+        or (count is not None and total.numel() != count.numel())):
     raise ValueError('dst is int64 with one entry per run of result elements')
   # (the entries of `dst` must be distinct and < total.numel(): the kernel
   # reads, adds and writes each destination without atomics.  RunningMean

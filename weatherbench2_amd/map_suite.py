@@ -31,27 +31,42 @@ _KINDS = {gm.SpatialBias: 0, gm.SpatialMSE: 1, gm.SpatialMAE: 2}
 
 
 def applies(eval_config) -> bool:
-  """Only the three map metrics, no regions, no derived variables, a temporal
-  mean: the `deterministic_spatial` config."""
+  """The `deterministic_spatial` config: the three map metrics (each at most
+  once, at least one), optionally SpatialSEEPS entries (`--compute_seeps`:
+  maps of their precipitation variable only), no regions, no derived
+  variables, a temporal mean."""
   metrics = getattr(eval_config, 'metrics', None) or {}
   kinds = [_KINDS.get(type(m)) for m in metrics.values()]
-  return bool(kinds) and None not in kinds and len(set(kinds)) == len(kinds) and (
-      not getattr(eval_config, 'regions', None)) and (
-          not getattr(eval_config, 'derived_variables', None)) and getattr(
-              eval_config, 'temporal_mean', True)
+  fused = [k for k in kinds if k is not None]
+  others = [m for m, k in zip(metrics.values(), kinds) if k is None]
+  return bool(fused) and len(set(fused)) == len(fused) and all(
+      type(m) is gm.SpatialSEEPS for m in others) and (
+          not getattr(eval_config, 'regions', None)) and (
+              not getattr(eval_config, 'derived_variables', None)) and getattr(
+                  eval_config, 'temporal_mean', True)
 
 
 class MapSuite:
   """The replayable form of one chunk structure of a map-metric config."""
 
-  def __init__(self, variables, kinds, time_dim, split_dim, skipna, device):
+  def __init__(self, variables, kinds, time_dim, split_dim, skipna, device,
+               extras=(), fills=None):
     self.variables = variables   # [(name, result dims, result shape)]
-    self.kinds = kinds           # metric index -> 0 bias / 1 mse / 2 mae
+    # metric index -> 0 bias / 1 mse / 2 mae, None for the others
+    self.kinds = kinds
+    # [(variable, metric index, metric)]: map metrics of single variables
+    # (SpatialSEEPS), computed by the metric itself and accumulated per slab
+    self.extras = list(extras)
+    # variable -> metric indices it has no values for (NaN in the merged
+    # result, evaluation.py:424-437): their sums are NaN from the first step
+    self.fills = dict(fills or {})
+    self._nan_rows: dict = {}    # variable -> rows whose fills are NaN
     self.time_dim, self.split_dim = time_dim, split_dim
     self.skipna, self.device = bool(skipna), device
     self._lib = _lib.load()
     self._plan = None   # _Plan of the structure, after the first run
     self._keep = None
+    self._const: dict = {}  # variable -> (offsets [metric][dst], lead, block)
 
   def reset(self):
     pass
@@ -85,6 +100,41 @@ class MapSuite:
     else:
       groups, self._plan = self._first(forecast, truth, mean)
     self._launch(groups)
+    self._fill(mean)
+    for name, m, metric in self.extras:
+      self._extra(name, m, metric, forecast, truth, mean)
+
+  def _fill(self, mean):
+    """Without skipna a metric that lacks the variable leaves NaN sums (NaN
+    maps were added): rows this suite meets first get them here."""
+    if self.skipna:
+      return
+    for name, ms in self.fills.items():
+      acc = mean._acc[name]
+      if acc.split is None:
+        continue   # (the generic first chunk has written them)
+      done = self._nan_rows.setdefault(name, set())
+      for row in set(acc.row_of.values()) - done:
+        for m in ms:
+          acc.total[row, m] = float('nan')
+        done.add(row)
+
+  def _extra(self, name, m, metric, forecast, truth, mean):
+    """A single-variable map metric (SpatialSEEPS): its own chunk map, added to
+    the slabs of (metric m, variable) -- one destination entry per slab."""
+    ds = metric.compute_chunk(forecast, truth)
+    da = ds[name]
+    const, lead, block, n_point = self._const[name]
+    acc = mean._acc[name]
+    rows = 0
+    if acc.split is not None:
+      rows = acc.rows(np.asarray(forecast.coords[acc.split]))[lead]
+    dst = engine.upload_table(rows * block + const[m], self.device,
+                              cache=False)
+    engine.order_read(da.data)
+    engine.time_accumulate(da.data, da.dims.index(self.time_dim), self.skipna,
+                           acc.total, acc.count if self.skipna else None, dst,
+                           n_point)
 
   def _first(self, forecast, truth, mean):
     """The address tables of one chunk from scratch (label work, views, slab
@@ -140,10 +190,12 @@ class MapSuite:
             [sizes[full.index(d)] for d in order]).ravel()
       by_kind = np.full((3, n_dst), -1, dtype=np.int64)
       for m, kind in enumerate(self.kinds):
-        by_kind[kind] = const[m]
+        if kind is not None:
+          by_kind[kind] = const[m]
       key = (dtype, n_row * n_col, sizes[0])
       parts.append((key, vi, name, rel, by_kind, lead, block, rows is not None,
                     _layout(fvar.data), _layout(tvar.data)))
+      self._const[name] = (const, lead, block, n_row * n_col)
       g = groups.setdefault(key, [[], [], [], []])
       row_of_dst = 0 if rows is None else rows[lead]
       live = by_kind >= 0
@@ -281,8 +333,9 @@ def build(eval_config, forecast: xl.Dataset, truth: xl.Dataset, result,
   # (the merge of the per-metric results sorts the labels: map by name)
   if labels is None or sorted(labels) != sorted(eval_config.metrics):
     return _no(f'map suite: metric labels {labels}')
-  kinds = [_KINDS[type(eval_config.metrics[k])] for k in labels]
-  variables = []
+  labels = [str(k) for k in labels]
+  kinds = [_KINDS.get(type(eval_config.metrics[k])) for k in labels]
+  variables, extras, fills = [], [], {}
   device = None
   for name, da in result.data_vars.items():
     acc = mean._acc.get(name)
@@ -299,7 +352,22 @@ def build(eval_config, forecast: xl.Dataset, truth: xl.Dataset, result,
       return _no(f'map suite: {name} is {type(da.data).__name__}')
     device = da.data.device
     variables.append((name, dims, tuple(da.shape)))
+    for m, (label, kind) in enumerate(zip(labels, kinds)):
+      if kind is not None:
+        continue
+      metric = eval_config.metrics[label]
+      if metric.precip_name == name:
+        extras.append((name, m, metric))
+      elif bool(torch.isnan(da.data[m]).all().item()):
+        fills.setdefault(name, []).append(m)
+      else:
+        return _no(f'map suite: {label} has values for {name}')
   if not variables or set(result.data_vars) != set(
       gm._common_vars(forecast, truth)):
     return _no('map suite: result variables differ from the common variables')
-  return MapSuite(variables, kinds, mean.dim, mean.split_dim, skipna, device)
+  suite = MapSuite(variables, kinds, mean.dim, mean.split_dim, skipna, device,
+                   extras, fills)
+  # every accumulator row that exists was written by the generic path
+  for name in fills:
+    suite._nan_rows[name] = set(mean._acc[name].row_of.values())
+  return suite

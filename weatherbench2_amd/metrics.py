@@ -2771,8 +2771,7 @@ class SpatialSEEPS(SEEPS):
     n_point = tensors[0].shape[-2] * tensors[0].shape[-1]
     slabs = [None if tb is None else engine.upload_table(tb, device)
              for tb in tables]
-    aux_dev = torch.as_tensor(
-        np.ascontiguousarray(aux, dtype=np.float64)).to(device).reshape(-1)
+    aux_dev = _resident_aux(aux, device).reshape(-1)  # (one copy per p1)
     out_map = engine.seeps_map(
         [x.reshape(-1, n_point) for x in tensors], slabs, geo.n_outer, n_point,
         aux_dev, self.dry_threshold_mm / 1000.0)
