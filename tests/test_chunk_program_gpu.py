@@ -271,3 +271,92 @@ def test_temporal_mean_false_rejects_a_chunk_that_comes_twice(monkeypatch):
     with pytest.raises(ValueError, match='came twice'):
       evaluation.evaluate_chunks(chunks + chunks[2:3], cfg, False, prefetch=0,
                                  batch_chunks=1)
+
+
+def _ensemble_chunks(n_init=4, n_lead=3, n_member=5, n_lat=19, n_lon=36,
+                     member_first=True, nan=False, seed=0):
+  """(oracle forecast, truth) + device-resident product chunks of an ensemble
+  forecast: two variables (one with levels), `number` members."""
+  from oracle.named import DS, NA
+  from weatherbench2_amd import evaluation
+  rs = np.random.RandomState(seed)
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  level = np.array([500, 850])
+  init = (np.datetime64('2020-01-01T00', 'ns') +
+          np.arange(n_init) * np.timedelta64(12, 'h'))
+  lead = (np.arange(n_lead) * np.timedelta64(6, 'h')).astype('timedelta64[ns]')
+  core3 = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+  core2 = ('init_time', 'lead_time', 'latitude', 'longitude')
+  put = (lambda dims: ('number',) + dims) if member_first else (
+      lambda dims: dims[:2] + ('number',) + dims[2:])
+  size = {'number': n_member, 'init_time': n_init, 'lead_time': n_lead,
+          'level': 2, 'latitude': n_lat, 'longitude': n_lon}
+
+  def field(dims):
+    x = rs.normal(size=[size[d] for d in dims]).astype(np.float32)
+    if nan:
+      x[rs.rand(*x.shape) < 0.01] = np.nan
+    return NA(x, dims)
+  coords = {'init_time': init, 'lead_time': lead, 'level': level,
+            'latitude': lat, 'longitude': lon, 'number': np.arange(n_member)}
+  forecast = DS({'z': field(put(core3)), 't2m': field(put(core2))}, coords)
+  tcoords = {k: v for k, v in coords.items() if k != 'number'}
+  truth = DS({'z': field(core3), 't2m': field(core2)}, tcoords)
+  gf, gt = (evaluation.make_resident(helpers.to_gpu_dataset(x))
+            for x in (forecast, truth))
+  return forecast, truth, oc.chunk_pairs(gf, gt)
+
+
+@pytest.mark.parametrize('member_first', [True, False])
+@pytest.mark.parametrize('skipna', [False, True])
+def test_ensemble_passes_replay_too(skipna, member_first, monkeypatch):
+  """The `probabilistic` config (scripts/evaluate.py:496-520) at the chunking
+  of its command lines (`init_time=1,lead_time=1`,
+  docs/source/official-evaluation.md:826-860): the K3 pass of every variable
+  + its fold are recorded and replayed with new base pointers -- same bits as
+  the generic path, which equals the oracle's time mean."""
+  from oracle import evaluation_np as oe, metrics_np as om, regions_np as oreg
+  from weatherbench2_amd import config, evaluation, metrics as gm, program
+  forecast, truth, chunks = _ensemble_chunks(member_first=member_first,
+                                             nan=skipna)
+  dim = 'number'
+  names = {'crps': 'CRPS', 'crps_spread': 'CRPSSpread',
+           'crps_skill': 'CRPSSkill', 'ensemble_mean_mse': 'EnsembleMeanMSE',
+           'debiased_ensemble_mean_mse': 'DebiasedEnsembleMeanMSE',
+           'ensemble_variance': 'EnsembleVariance'}
+  oregions = {'global': oreg.SliceRegion(),
+              'tropics': oreg.SliceRegion(lat_slice=slice(-20, 20))}
+  cfg = config.Eval(
+      metrics={k: getattr(gm, v)(ensemble_dim=dim) for k, v in names.items()},
+      regions={k: helpers.to_gpu_region(v) for k, v in oregions.items()})
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                    batch_chunks=1)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+  calls = _count_runs(monkeypatch)
+  got = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                   batch_chunks=1)
+  _same(got, want)
+  assert len(calls) == len(chunks) - 1, program.REASONS
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', 'verify')
+  _same(evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                   batch_chunks=1), want)
+  # against the oracle
+  ometrics = {k: getattr(om, v)(ensemble_dim=dim) for k, v in names.items()}
+  per_chunk = oe.metric_and_region_loop(forecast, truth, ometrics, oregions,
+                                        skipna, compute_chunk=True)
+  labels_m, labels_r = list(got.coords['metric']), list(got.coords['region'])
+  for (mname, rname), ds in per_chunk.items():
+    for var, v in ds.items():
+      ax = v.dims.index('init_time')
+      data = np.asarray(v.data, dtype=np.float64)
+      with np.errstate(all='ignore'):
+        mean = (np.nanmean if skipna else np.mean)(data, axis=ax)
+      dims = tuple(d for d in v.dims if d != 'init_time')
+      res = got[var]
+      rdims = [d for d in res.dims if d not in ('metric', 'region')]
+      vals = res.values[labels_m.index(mname), labels_r.index(rname)]
+      vals = np.transpose(vals, [rdims.index(d) for d in dims])
+      helpers.assert_close(vals, mean, rtol=1e-6, atol=1e-9,
+                           err_msg=f'{mname}/{rname}/{var}')

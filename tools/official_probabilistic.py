@@ -1,0 +1,117 @@
+"""The `probabilistic` config of the documented command lines at THEIR chunking
+(docs/source/official-evaluation.md:826-860: IFS ENS at 240 x 121,
+`--input_chunks=init_time=1,lead_time=1`, 50 members, `--regions=all`;
+scripts/evaluate.py:496-520: crps, crps_spread, crps_skill, ensemble_mean_mse,
+debiased_ensemble_mean_mse, ensemble_variance) through
+evaluation.evaluate_chunks, chunk by chunk, from device-resident chunks.
+
+At this grid a chunk is 23 slabs x 51 arrays x 116 kB = 136 MB: the GPU needs
+tens of microseconds, the host work per chunk is the whole cost.
+
+  python tools/official_probabilistic.py [--chunks N] [--grid 240x121|64x32]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+VARS_3D = ['geopotential', 'temperature', 'u_component_of_wind',
+           'v_component_of_wind', 'specific_humidity', 'wind_speed']
+VARS_2D = ['2m_temperature', '10m_u_component_of_wind',
+           '10m_v_component_of_wind', 'mean_sea_level_pressure',
+           '10m_wind_speed']
+LEVELS = np.array([500, 700, 850])
+N_MEMBER = 50
+
+
+def build(dev, n_chunks: int, n_lon: int, n_lat: int, pool: int = 8,
+          n_lead: int = 4):
+  import torch
+  import bench
+  from weatherbench2_amd import config, metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  n_init = -(-n_chunks // n_lead)
+  init = (np.datetime64('2020-01-01T00', 'ns') +
+          np.arange(n_init) * np.timedelta64(24, 'h'))
+  lead = (np.arange(n_lead) * np.timedelta64(6, 'h')).astype('timedelta64[ns]')
+  g = torch.Generator(device=dev).manual_seed(5)
+  d3 = ('number', 'init_time', 'lead_time', 'level', 'latitude', 'longitude')
+  d2 = ('number', 'init_time', 'lead_time', 'latitude', 'longitude')
+  pooled = []
+  for _ in range(pool):
+    f = {k: torch.randn((N_MEMBER, 1, 1, len(LEVELS), n_lat, n_lon),
+                        generator=g, device=dev) for k in VARS_3D}
+    f.update({k: torch.randn((N_MEMBER, 1, 1, n_lat, n_lon), generator=g,
+                             device=dev) for k in VARS_2D})
+    t = {k: torch.randn((1, 1, len(LEVELS), n_lat, n_lon), generator=g,
+                        device=dev) for k in VARS_3D}
+    t.update({k: torch.randn((1, 1, n_lat, n_lon), generator=g, device=dev)
+              for k in VARS_2D})
+    pooled.append((f, t))
+  chunks = []
+  for j in range(n_chunks):
+    i, l = divmod(j, n_lead)
+    coords = {'init_time': init[i:i + 1], 'lead_time': lead[l:l + 1],
+              'level': LEVELS, 'latitude': lat, 'longitude': lon,
+              'number': np.arange(N_MEMBER)}
+    f, t = pooled[j % pool]
+    fd = xl.Dataset({k: xl.DataArray(v, d3 if v.dim() == 6 else d2)
+                     for k, v in f.items()}, coords)
+    tcoords = {k: v for k, v in coords.items() if k != 'number'}
+    td = xl.Dataset({k: xl.DataArray(v, d3[1:] if v.dim() == 5 else d2[1:])
+                     for k, v in t.items()}, tcoords)
+    chunks.append((fd, td))
+  dim = 'number'
+  metrics = {
+      'crps': gm.CRPS(ensemble_dim=dim),
+      'crps_spread': gm.CRPSSpread(ensemble_dim=dim),
+      'crps_skill': gm.CRPSSkill(ensemble_dim=dim),
+      'ensemble_mean_mse': gm.EnsembleMeanMSE(ensemble_dim=dim),
+      'debiased_ensemble_mean_mse': gm.DebiasedEnsembleMeanMSE(
+          ensemble_dim=dim),
+      'ensemble_variance': gm.EnsembleVariance(ensemble_dim=dim),
+  }
+  # (these command lines pass no --lsm_dataset: the 13 slice regions)
+  return chunks, metrics, bench.predefined_regions(), lat, lon
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--chunks', type=int, default=256)
+  ap.add_argument('--grid', default='240x121')
+  args = ap.parse_args()
+  import torch
+  from weatherbench2_amd import config, engine, evaluation, program
+  dev = torch.device('cuda:0')
+  n_lon, n_lat = (int(x) for x in args.grid.split('x'))
+  chunks, metrics, regions, lat, lon = build(dev, args.chunks, n_lon, n_lat)
+  cfg = config.Eval(metrics=metrics, regions=regions)
+  out = {'grid': args.grid, 'members': N_MEMBER, 'chunks': args.chunks,
+         'slabs_per_chunk': len(VARS_3D) * len(LEVELS) + len(VARS_2D),
+         'regions': None if regions is None else len(regions)}
+  pts = out['slabs_per_chunk'] * n_lon * n_lat
+  for how in ('0', '1'):
+    os.environ['WB2HIP_CHUNK_PROGRAM'] = how
+    evaluation.evaluate_chunks(chunks[:8], cfg, False, prefetch=0,
+                               batch_chunks=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, batch_chunks=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['programs_' + how] = {
+        'ms_per_chunk': dt / len(chunks) * 1e3,
+        'value': len(chunks) * pts / dt, 'unit': 'grid-point-evals/s'}
+  out['reasons'] = program.REASONS[-3:]
+  print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()

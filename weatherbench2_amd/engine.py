@@ -542,9 +542,11 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
   dtype = ens.dtype
   if dtype not in _DTYPES or truth.dtype != dtype:
     raise TypeError(f'unsupported / mismatched dtypes {ens.dtype} {truth.dtype}')
-  for x in (ens, truth):
-    if x.device != dev or not x.is_contiguous():
-      raise ValueError('inputs must be contiguous on the plan device')
+  # (a non-contiguous `ens` is a view with intact slabs that the caller
+  # addresses through member_stride + ens_slab: metrics._ens_layout)
+  if ens.device != dev or truth.device != dev or not truth.is_contiguous() or (
+      not ens.is_contiguous() and ens_slab is None and member_ptrs is None):
+    raise ValueError('inputs must be contiguous on the plan device')
   for s in (ens_slab, truth_slab):
     if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
       raise ValueError('slab tables are int64[n_outer]')
@@ -632,9 +634,11 @@ def energy_score(plan: ReductionPlan, ens: torch.Tensor, member_stride: int,
   dtype = ens.dtype
   if dtype not in _DTYPES or truth.dtype != dtype:
     raise TypeError(f'unsupported / mismatched dtypes {ens.dtype} {truth.dtype}')
-  for x in (ens, truth):
-    if x.device != dev or not x.is_contiguous():
-      raise ValueError('inputs must be contiguous on the plan device')
+  # (a non-contiguous `ens` is a view with intact slabs that the caller
+  # addresses through member_stride + ens_slab: metrics._ens_layout)
+  if ens.device != dev or truth.device != dev or not truth.is_contiguous() or (
+      not ens.is_contiguous() and ens_slab is None and member_ptrs is None):
+    raise ValueError('inputs must be contiguous on the plan device')
   for s in (ens_slab, truth_slab):
     if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):
       raise ValueError('slab tables are int64[n_outer]')

@@ -1614,6 +1614,18 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim, allow_gather=False):
   for d in reversed(frest):
     strides[d] = stride
     stride *= fsizes[d]
+  strided = False
+  if isinstance(fdata, torch.Tensor) and not fdata.is_contiguous():
+    # a VIEW with intact 2-D slabs (an (init_time=1, lead_time=1) chunk sliced
+    # out of a resident forecast): addressed through its own strides, no copy
+    se = int(fdata.shape[-2]) * int(fdata.shape[-1])
+    st = fdata.stride()
+    if fdata.dim() >= 2 and st[-1] == 1 and st[-2] == fdata.shape[-1] and all(
+        x >= 0 and x % se == 0 for x in st[:-2]) and se > 0:
+      strides = {d: x // se for d, x in zip(frest, st[:-2])}
+      strided = True
+    else:
+      fdata = fdata.contiguous()
   ens_table = np.zeros(out_shape, dtype=np.int64)
   for d in frest:
     if d == ensemble_dim:
@@ -1623,7 +1635,8 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim, allow_gather=False):
     ens_table = ens_table + (np.arange(fsizes[d], dtype=np.int64)
                              * strides[d]).reshape(shape)
   ens_table = np.ascontiguousarray(ens_table).ravel()
-  identity = np.array_equal(ens_table, np.arange(ens_table.size))
+  identity = (not strided) and np.array_equal(ens_table,
+                                              np.arange(ens_table.size))
   truth_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
 
   device = engine.require_gpu()
@@ -1693,12 +1706,28 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   slab_elems = pl.n_row * pl.n_col
   maps = (torch.empty((6, geo.n_outer, slab_elems), dtype=torch.float64,
                       device=device) if want_maps else None)
-  metrics, _ = engine.ensemble_reduce(
-      pl, ften, member_slabs * slab_elems, n_member, ens_table,
-      tten.reshape(-1, pl.n_row, pl.n_col), truth_table,
-      geo.n_outer, skipna, maps=maps,
-      member_ptrs=(None if member_ptrs is None
-                   else member_ptrs.reshape(geo.n_outer, n_member)))
+  rec = program.recorder()
+  plain = maps is None and member_ptrs is None
+  if rec is not None and rec.probe and plain:
+    # program.py's probe pass: no launch, index-valued results
+    metrics = rec.fake_metrics(_lib.NMETRIC_ENS, pl.n_region, geo.n_outer,
+                               device)
+  else:
+    truth3 = tten.reshape(-1, pl.n_row, pl.n_col)
+    metrics, _ = engine.ensemble_reduce(
+        pl, ften, member_slabs * slab_elems, n_member, ens_table, truth3,
+        truth_table, geo.n_outer, skipna, maps=maps,
+        member_ptrs=(None if member_ptrs is None
+                     else member_ptrs.reshape(geo.n_outer, n_member)))
+    if rec is not None and not rec.probe:
+      if plain:
+        rec.record(kind='ens', plan=pl, ens=ften, ens_raw=fvar.data,
+                   truth=truth3, truth_raw=tvar.data,
+                   member_stride=member_slabs * slab_elems, n_member=n_member,
+                   ens_table=ens_table, truth_table=truth_table,
+                   n_outer=geo.n_outer, skipna=bool(skipna), metrics=metrics)
+      else:
+        rec.record(kind='unsupported')
   dev = metrics.reshape((_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
   # total weight of each region: a spatial average of zeros is 0/0 = NaN over
   # an empty region (CRPSSpread with one member, metrics.py:689-693, 783-784)
@@ -2313,7 +2342,8 @@ def _ens_threshold_layout(forecast, truth, threshold_ds, name, ensemble_dim):
     ens_table = ens_table + (np.arange(fsizes[d], dtype=np.int64)
                              * strides[d]).reshape(shape)
   ens_table = np.ascontiguousarray(ens_table).ravel()
-  identity = np.array_equal(ens_table, np.arange(ens_table.size))
+  identity = (not strided) and np.array_equal(ens_table,
+                                              np.arange(ens_table.size))
   t_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
   h_table = _slab_table(out_dims, out_shape, hrest, hdata.shape[:-2])
   device = engine.require_gpu()

@@ -265,6 +265,89 @@ class _Launch:
     return addr
 
 
+  def run(self, forecast, truth, out, stream) -> None:
+    addr = self.addresses(forecast, truth)
+    aligned = not (addr & 15).any()
+    dev_addr = engine.upload_table(addr, self.plan.device, cache=False)
+    self.step.aligned = bool(aligned)
+    self.step.run(None, list(dev_addr), metrics=out, stream_ptr=stream)
+
+
+def _view_offset(view: torch.Tensor, raw, what: str) -> int:
+  """Byte offset of `view` (what the pass read) inside the chunk's own array
+  `raw`: the same for every chunk of the structure."""
+  if not isinstance(raw, torch.Tensor) or view.dtype != raw.dtype or (
+      view.device != raw.device):
+    raise _NotReplayable(f'{what}: the pass read a copy of the chunk')
+  store = raw.untyped_storage()
+  lo = view.data_ptr()
+  hi = lo + max(view.numel(), 1) * view.element_size()
+  if view.untyped_storage().data_ptr() != store.data_ptr() or not (
+      store.data_ptr() <= lo and hi <= store.data_ptr() + store.nbytes()):
+    raise _NotReplayable(f'{what}: the pass read a copy of the chunk')
+  return lo - raw.data_ptr()
+
+
+class _EnsLaunch:
+  """One recorded ensemble pass (K3 + its region fold: metrics._ens_pass) of a
+  variable of the chunk, replayed through the C ABI with new base pointers --
+  the slab tables are functions of the shapes alone."""
+
+  def __init__(self, rec: dict, fmap: dict, tmap: dict, device):
+    pl = rec['plan']
+    role_e, role_t = fmap.get(id(rec['ens_raw'])), tmap.get(id(rec['truth_raw']))
+    if role_e is None or role_t is None:
+      raise _NotReplayable('an ensemble pass over arrays that are not '
+                           'variables of the chunk')
+    self.names = (role_e[1], role_t[1])
+    self.offsets = (_view_offset(rec['ens'], rec['ens_raw'], role_e[1]),
+                    _view_offset(rec['truth'], rec['truth_raw'], role_t[1]))
+    self.plan, self.skipna = pl, bool(rec['skipna'])
+    self.n_total = int(rec['n_outer'])
+    self.n_metric = _lib.NMETRIC_ENS
+    self.n_values = self.n_metric * pl.n_region * self.n_total
+    lib = self._lib = _lib.load()
+    k = lib.wb2_ens_num_slots(int(self.skipna))
+    tile = lib.wb2_ens_tile_cols(pl.n_col)
+    n_ctile = -(-pl.n_col // tile)
+    seg_eoff, n_ts = pl.seg_entries(tile)
+    self.partials = torch.empty((self.n_total, pl.n_chunk, pl.nwf, n_ts, k),
+                                dtype=torch.float64, device=device)
+    self.keep = (rec['ens_table'], rec['truth_table'], seg_eoff, pl)
+    ptr = _lib.ptr
+    dtype = engine._DTYPES[rec['ens'].dtype]
+    # (dtype, skipna, ens, ens_slab, truth, truth_slab, ...): 2 and 4 change
+    self.partials_args = [
+        dtype, int(self.skipna), None, ptr(rec['ens_table']), None,
+        ptr(rec['truth_table']), int(rec['n_member']),
+        int(rec['member_stride']), self.n_total, pl.n_row, pl.n_col,
+        ptr(pl.w_row), ptr(pl.w_col), ptr(pl.wfield), ptr(pl.chunk_row0),
+        ptr(pl.chunk_nrow), pl.n_chunk, n_ctile, ptr(pl.seg_col0),
+        ptr(seg_eoff), pl.n_seg, n_ts, ptr(self.partials), None]
+    self.combine_args = [
+        int(self.skipna), ptr(self.partials), self.n_total, pl.n_chunk, pl.nwf,
+        pl.n_seg, ptr(seg_eoff), n_ts, ptr(pl.band_chunk0), pl.n_band,
+        ptr(pl.coef_band), ptr(pl.coef_seg), ptr(pl.region_wf),
+        ptr(pl.region_wsum), pl.n_region, None]
+
+  def run(self, forecast, truth, out, stream) -> None:
+    lib = self._lib
+    args = self.partials_args
+    args[2] = forecast[self.names[0]].data.data_ptr() + self.offsets[0]
+    args[4] = truth[self.names[1]].data.data_ptr() + self.offsets[1]
+    hook = engine._LAUNCH_HOOK
+    if hook is not None:
+      hook('begin', 'ens_partials')
+    status = lib.wb2_ens_partials_maps(*args, stream)
+    if status != 0:
+      _lib.check(status, 'wb2_ens_partials_maps')
+    if hook is not None:
+      hook('end', 'ens_partials')
+    status = lib.wb2_ens_combine(*self.combine_args, out.data_ptr(), stream)
+    if status != 0:
+      _lib.check(status, 'wb2_ens_combine')
+
+
 class _NotReplayable(Exception):
   pass
 
@@ -414,11 +497,7 @@ class ChunkProgram:
   def run(self, forecast: xl.Dataset, truth: xl.Dataset, mean) -> None:
     stream = engine.current_stream_ptr(self.device)
     for la, out in zip(self.launches, self.slices):
-      addr = la.addresses(forecast, truth)
-      aligned = not (addr & 15).any()
-      dev_addr = engine.upload_table(addr, self.device, cache=False)
-      la.step.aligned = bool(aligned)
-      la.step.run(None, list(dev_addr), metrics=out, stream_ptr=stream)
+      la.run(forecast, truth, out, stream)
     if getattr(mean, 'keeps_time', False):
       # one destination per (element, time step): 0 + value, exact
       d_sum, d_cnt, round_each = self._kept_tables(mean, forecast)
@@ -464,9 +543,12 @@ def _build(first, forecast, truth, result, mean, loop):
   time_dim, split_dim = mean.dim, mean.split_dim
   fmap = {id(v.data): ('f', k) for k, v in forecast.data_vars.items()}
   tmap = {id(v.data): ('t', k) for k, v in truth.data_vars.items()}
+  if any(l.get('kind') == 'unsupported' for l in first.launches):
+    return _no('a pass the programs do not cover (maps / gathered members)')
   for l in launches_rec:
     l['tables'] = first.tables
-  launches = [_Launch(l, fmap, tmap, device) for l in launches_rec]
+  launches = [(_EnsLaunch if l.get('kind') == 'ens' else _Launch)(
+      l, fmap, tmap, device) for l in launches_rec]
   # ---- probe: which output element does every result element show?
   with Recorder(probe=True) as probe:
     shown = xl.as_dataset(loop())
