@@ -2342,8 +2342,7 @@ def _ens_threshold_layout(forecast, truth, threshold_ds, name, ensemble_dim):
     ens_table = ens_table + (np.arange(fsizes[d], dtype=np.int64)
                              * strides[d]).reshape(shape)
   ens_table = np.ascontiguousarray(ens_table).ravel()
-  identity = (not strided) and np.array_equal(ens_table,
-                                              np.arange(ens_table.size))
+  identity = np.array_equal(ens_table, np.arange(ens_table.size))
   t_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
   h_table = _slab_table(out_dims, out_shape, hrest, hdata.shape[:-2])
   device = engine.require_gpu()
