@@ -860,11 +860,12 @@ def compact(out: dict) -> dict:
     if 'host_fed' in oc:
       line['api_official_chunk']['host_fed'] = _pick(
           oc['host_fed'], 'value', 'h2d_GBps', 'wall_ms_per_chunk', 'error')
-    dt = oc.get('deterministic_temporal') or {}
-    if dt:
-      line['api_official_chunk']['deterministic_temporal'] = (
-          _pick(dt, 'error') if 'error' in dt else
-          {k: _pick(v, 'value', 'host_ms_per_chunk') for k, v in dt.items()})
+    for key in ('deterministic_temporal', 'deterministic_and_temporal'):
+      dt = oc.get(key) or {}
+      if dt:
+        line['api_official_chunk'][key] = (
+            _pick(dt, 'error') if 'error' in dt else
+            {k: _pick(v, 'value', 'host_ms_per_chunk') for k, v in dt.items()})
     if 'deterministic_spatial' in oc:
       ds = oc['deterministic_spatial']
       line['api_official_chunk']['deterministic_spatial'] = _pick(

@@ -360,3 +360,64 @@ def test_ensemble_passes_replay_too(skipna, member_first, monkeypatch):
       vals = np.transpose(vals, [rdims.index(d) for d in dims])
       helpers.assert_close(vals, mean, rtol=1e-6, atol=1e-9,
                            err_msg=f'{mname}/{rname}/{var}')
+
+
+@pytest.mark.parametrize('batch', [1, 3, None])
+def test_several_configs_share_one_pass_over_the_chunks(batch, monkeypatch):
+  """`--eval_configs=deterministic,deterministic_temporal` of the documented
+  0.25-degree command line (docs/source/official-evaluation.md:537-556;
+  evaluation.py:805-828 builds one branch per config, each reading the chunks
+  again): evaluate_chunks({name: Eval}) reads every chunk once -- the K1
+  launches of the chunk serve both configs -- and returns per config exactly
+  what a call of its own returns."""
+  import dataclasses
+  from weatherbench2_amd import engine, evaluation, metrics as gm
+  _, _, gf, gt, cfg = _setup(n_init=5, n_lead=3, n_lat=31, n_lon=72)
+  wv = [gm.WindVectorRMSESqrtBeforeTimeAvg(u_name=u, v_name=v, vector_name=n)
+        for u, v, n in oc.WIND]
+  temporal = dataclasses.replace(
+      cfg, temporal_mean=False,
+      metrics={**cfg.metrics, 'rmse_sqrt_before_time_avg':
+               gm.RMSESqrtBeforeTimeAvg(wind_vector_rmse=wv)})
+  both = {'deterministic': cfg, 'deterministic_temporal': temporal}
+  chunks = oc.chunk_pairs(gf, gt)
+  kwargs = {} if batch is None else {'batch_chunks': batch}
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = {k: evaluation.evaluate_chunks(chunks, c, False, prefetch=0,
+                                        batch_chunks=1)
+          for k, c in both.items()}
+
+  def count_launches(fn):
+    seen = []
+    old = engine.set_launch_hook(lambda when, kernel: seen.append(kernel)
+                                 if when == 'begin' else None)
+    try:
+      out = fn()
+    finally:
+      engine.set_launch_hook(old)
+    return out, seen.count('stream_partials')
+  for how in ('0', '1', 'verify'):
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', how)
+    got, together = count_launches(lambda: evaluation.evaluate_chunks(
+        chunks, both, False, prefetch=0, **kwargs))
+    assert sorted(got) == sorted(both)
+    for k in both:
+      _same(got[k], want[k])
+    if how == '1' and batch == 1:
+      _, alone = count_launches(lambda: evaluation.evaluate_chunks(
+          chunks, cfg, False, prefetch=0, batch_chunks=1))
+      # the second config costs no launch of its own (the first chunk of the
+      # structure is walked three times: record, probe-free verify, build)
+      assert together <= alone + 2, (together, alone)
+
+
+def test_configs_that_replace_the_forecast_differently_are_refused():
+  import dataclasses
+  from weatherbench2_amd import evaluation
+  _, _, gf, gt, cfg = _setup(n_init=2, n_lead=1)
+  other = dataclasses.replace(cfg, evaluate_persistence=True)
+  with pytest.raises(ValueError, match='baseline switches'):
+    evaluation.evaluate_chunks(oc.chunk_pairs(gf, gt), {'a': cfg, 'b': other},
+                               False, prefetch=0)
+  with pytest.raises(ValueError, match='no eval config'):
+    evaluation.evaluate_chunks(oc.chunk_pairs(gf, gt), {}, False, prefetch=0)

@@ -286,3 +286,26 @@ def test_large_map_results_use_one_table_entry_per_run():
   assert np.array_equal(a, b, equal_nan=True)
   assert per_element[0] == 2 * 1 * 19 * 36 and per_run[0] == 2 * 1
   del gen
+
+
+def test_a_map_config_beside_scalar_configs_in_one_call(monkeypatch):
+  """{deterministic, deterministic_spatial}: the scalar config replays its
+  chunk program, the map config its suite, each result equals a call of its
+  own."""
+  from tests import test_chunk_program_gpu as tp
+  from weatherbench2_amd import evaluation
+  _, _, gf, gt, scalar = tp._setup(n_init=4, n_lead=2, n_lat=19, n_lon=36)
+  _, _, _, _, maps = _setup(n_init=1, n_lead=1)
+  both = {'deterministic': scalar, 'deterministic_spatial': maps}
+  chunks = oc.chunk_pairs(gf, gt)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = {k: evaluation.evaluate_chunks(chunks, c, False, prefetch=0,
+                                        batch_chunks=1)
+          for k, c in both.items()}
+  for how in ('1', 'verify'):
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', how)
+    calls = _count_runs(monkeypatch)
+    got = evaluation.evaluate_chunks(chunks, both, False, prefetch=0)
+    for k in both:
+      _same(got[k], want[k])
+    assert len(calls) >= len(chunks) - 1

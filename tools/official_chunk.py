@@ -279,16 +279,18 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
   import torch
   from weatherbench2_amd import engine, evaluation
   marks = {}
-  sink = (evaluation.RunningMean if getattr(cfg, 'temporal_mean', True)
-          else evaluation.RunningConcat)
-  real_result = sink.result
+  sinks = (evaluation.RunningMean, evaluation.RunningConcat)
+  real = [k.result for k in sinks]
 
-  def result(self):
-    marks['enqueued'] = time.perf_counter()  # the host is done with the chunks
-    return real_result(self)
+  def hooked(real_result):
+    def result(self):  # the host is done with the chunks
+      marks.setdefault('enqueued', time.perf_counter())
+      return real_result(self)
+    return result
   ev = _Events(timed_events)
   old = engine.set_launch_hook(ev)
-  sink.result = result
+  for k, r in zip(sinks, real):
+    k.result = hooked(r)
   try:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -298,7 +300,8 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
     torch.cuda.synchronize()
     t1 = time.perf_counter()
   finally:
-    sink.result = real_result
+    for k, r in zip(sinks, real):
+      k.result = r
     engine.set_launch_hook(old)
   n = len(chunks)
   if batch is None:
@@ -446,6 +449,19 @@ def run(dev, n_chunks: int = 512, pool: int = 32,
     out['deterministic_temporal'] = temporal
   except Exception as e:
     out['deterministic_temporal'] = {'error': f'{type(e).__name__}: {e}'}
+  # both configs of the documented command line
+  # (--eval_configs=deterministic,deterministic_temporal) in ONE call: every
+  # chunk is read once, the launches serve both
+  try:
+    pair = {'deterministic': cfg, 'deterministic_temporal': temporal_config(cfg)}
+    together = {}
+    for b in (1, None):
+      gm.clear_caches()
+      measure(chunks[:max(2 * (b or 24), 8)], pair, b, timed_events=False)
+      together['default' if b is None else str(b)] = measure(chunks, pair, b)
+    out['deterministic_and_temporal'] = together
+  except Exception as e:
+    out['deterministic_and_temporal'] = {'error': f'{type(e).__name__}: {e}'}
   try:
     out['deterministic_spatial'] = measure_spatial(chunks, cfg)
   except Exception as e:

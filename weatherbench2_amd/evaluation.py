@@ -1103,83 +1103,134 @@ def _batches(pairs: list, time_dim: str, lead_dim: t.Optional[str]):
   return [(p[0], p[1]) for p in pairs]
 
 
-def _evaluate_piece(forecast, truth_chunk, eval_config, skipna, mean,
+class _PieceProgram:
+  """What replays the chunks of one structure for every config of a call: one
+  chunk program over the configs whose metrics are K1 / K3 passes (they share
+  the launches), one map suite per map-metric config, the generic loop for
+  whatever could not be recorded -- all inside ONE chunk scope, so a pass one
+  part has run answers the others from the cache."""
+
+  def __init__(self, parts):
+    self.parts = parts   # [(runnable or None, [config index])]
+
+  def reset(self):
+    for runnable, _ in self.parts:
+      if runnable is not None:
+        runnable.reset()
+
+  def replays(self) -> bool:
+    return any(runnable is not None for runnable, _ in self.parts)
+
+  def run(self, forecast, truth_chunk, configs, skipna, sinks):
+    from weatherbench2_amd import metrics as gm
+    with gm.chunk_scope():
+      for runnable, idx in self.parts:
+        if runnable is None:
+          for i in idx:
+            sinks[i].add(_metric_and_region_loop(
+                forecast, truth_chunk, configs[i], skipna, compute_chunk=True))
+        elif len(idx) == 1 and not hasattr(runnable, 'groups'):
+          runnable.run(forecast, truth_chunk, sinks[idx[0]])
+        else:
+          runnable.run(forecast, truth_chunk, [sinks[i] for i in idx])
+
+
+def _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks,
                     programs: dict) -> None:
   """One (forecast, truth) piece of a window through the metric x region loop
-  and into the running mean: the generic path for the first piece of every
-  chunk STRUCTURE (recorded), the recorded program for the rest (program.py --
-  same launches, same accumulation order, same bits)."""
-  from weatherbench2_amd import program
+  of every config and into the configs' sinks: the generic path for the first
+  piece of every chunk STRUCTURE (recorded), the recorded program for the rest
+  (program.py, map_suite.py -- same launches, same accumulation order, same
+  bits)."""
+  from weatherbench2_amd import map_suite, metrics as gm, program
   how = program.mode()
   sig = None
-  if how != '0' and mean._on_gpu_or_unset():
+  if how != '0' and all(s._on_gpu_or_unset() for s in sinks):
     sig = program.signature(forecast, truth_chunk)
   prog = programs.get(sig) if sig is not None else False
   if prog:
     if how == 'verify':
-      _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean)
+      _verify_program(prog, forecast, truth_chunk, configs, skipna, sinks)
     else:
-      prog.run(forecast, truth_chunk, mean)
+      prog.run(forecast, truth_chunk, configs, skipna, sinks)
     return
-  loop = lambda: _metric_and_region_loop(forecast, truth_chunk, eval_config,
-                                         skipna, compute_chunk=True)
+
+  def loop(which=None):
+    which = range(len(configs)) if which is None else which
+    with gm.chunk_scope():  # one scope: the configs share the passes
+      return [_metric_and_region_loop(forecast, truth_chunk, configs[i],
+                                      skipna, compute_chunk=True)
+              for i in which]
   if prog is False:      # not replayable (or programs are off)
-    mean.add(loop())
+    for sink, result in zip(sinks, loop()):
+      sink.add(result)
     return
   with program.Recorder() as rec:
-    result = loop()
-  mean.add(result)
+    results = loop()
+  for sink, result in zip(sinks, results):
+    sink.add(result)
   built = None
-  if mean._on_gpu():
-    from weatherbench2_amd import map_suite
-    if map_suite.applies(eval_config):
+  if all(s._on_gpu() for s in sinks):
+    maps = [i for i, c in enumerate(configs) if map_suite.applies(c)]
+    scalar = [i for i in range(len(configs)) if i not in maps]
+    parts = []
+    if scalar:
+      one = program.build(rec, forecast, truth_chunk,
+                          [xl.as_dataset(results[i]) for i in scalar],
+                          [sinks[i] for i in scalar], lambda: loop(scalar))
+      parts.append((one, scalar))
+    for i in maps:
       # map metrics (`deterministic_spatial`): one fused launch per chunk
-      built = map_suite.build(eval_config, forecast, truth_chunk, result, mean,
-                              skipna)
-    else:
-      built = program.build(rec, forecast, truth_chunk, xl.as_dataset(result),
-                            mean, loop)
+      parts.append((map_suite.build(configs[i], forecast, truth_chunk,
+                                    results[i], sinks[i], skipna), [i]))
+    built = _PieceProgram(parts)
+    if not built.replays():
+      built = None
   programs[sig] = built or False
 
 
-def _verify_program(prog, forecast, truth_chunk, eval_config, skipna, mean):
+def _verify_program(prog, forecast, truth_chunk, configs, skipna, sinks):
   """WB2HIP_CHUNK_PROGRAM=verify: the chunk through the program AND through the
   generic path, each from the same accumulator state -- they must leave the
   same bits behind (NaN == NaN)."""
   import torch
-  names = sorted(mean._acc)
-  kept = getattr(mean, 'keeps_time', False)
 
-  def snapshot():
-    if kept:
+  def snapshot(mean):
+    if getattr(mean, 'keeps_time', False):
       return mean.snapshot()
-    for n in names:
-      mean._acc[n].settle()
-    return {n: (mean._acc[n].total.clone(), mean._acc[n].count.clone(),
-                list(mean._acc[n].labels), dict(mean._acc[n].row_of))
-            for n in names}
+    for acc in mean._acc.values():
+      acc.settle()
+    return {n: (acc.total.clone(), acc.count.clone(), list(acc.labels),
+                dict(acc.row_of)) for n, acc in mean._acc.items()}
 
-  def restore(state):
-    if kept:
+  def restore(mean, state):
+    if getattr(mean, 'keeps_time', False):
       return mean.restore(state)
     for n, (total, count, labels, row_of) in state.items():
       acc = mean._acc[n]
       acc.total, acc.count = total.clone(), count.clone()
       acc.labels, acc.row_of, acc.dst = list(labels), dict(row_of), {}
-  before = snapshot()
-  prog.run(forecast, truth_chunk, mean)
-  replayed = snapshot()
-  restore(before)
-  mean.add(_metric_and_region_loop(forecast, truth_chunk, eval_config, skipna,
-                                   compute_chunk=True))
-  if kept:
-    replayed = replayed[0]
-  for n in names:
-    for a, b in zip(replayed[n][:2], (mean._acc[n].total, mean._acc[n].count)):
-      same = a.shape == b.shape and bool(
-          ((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
-      if not same:
-        raise AssertionError(f'chunk program and generic path differ on {n}')
+  before = [snapshot(m) for m in sinks]
+  prog.run(forecast, truth_chunk, configs, skipna, sinks)
+  replayed = [snapshot(m) for m in sinks]
+  for m, state in zip(sinks, before):
+    restore(m, state)
+  from weatherbench2_amd import metrics as gm
+  with gm.chunk_scope():
+    for m, c in zip(sinks, configs):
+      m.add(_metric_and_region_loop(forecast, truth_chunk, c, skipna,
+                                    compute_chunk=True))
+  for m, state in zip(sinks, replayed):
+    if getattr(m, 'keeps_time', False):
+      state = state[0]
+    for n, acc in m._acc.items():
+      if hasattr(acc, 'settle'):
+        acc.settle()
+      for a, b in zip(state[n][:2], (acc.total, acc.count)):
+        same = a.shape == b.shape and bool(
+            ((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
+        if not same:
+          raise AssertionError(f'chunk program and generic path differ on {n}')
   prog.reset()   # (the accumulators were replaced: new addresses)
 
 
@@ -1208,7 +1259,7 @@ def _input_bytes(ds: xl.Dataset) -> int:
 
 def evaluate_chunks(
     chunks: t.Sequence[tuple],
-    eval_config: config.Eval,
+    eval_config: t.Union[config.Eval, t.Dict[str, config.Eval]],
     skipna: bool = False,
     device=None,
     prefetch: int = 2,
@@ -1217,8 +1268,17 @@ def evaluate_chunks(
     climatology=None,
     by_init: bool = True,
     batch_chunks: t.Optional[int] = None,
-) -> xl.Dataset:
+) -> t.Union[xl.Dataset, t.Dict[str, xl.Dataset]]:
   """Evaluates (forecast, truth) chunks and returns the temporal mean.
+
+  `eval_config` may be a dict {name: Eval} like `evaluate_with_beam`'s
+  `eval_configs` (evaluation.py:757-828; the documented 0.25-degree command
+  line runs `--eval_configs=deterministic,deterministic_temporal`): the
+  reference builds one pipeline branch per config, each reading the chunks
+  again; here every chunk is read ONCE -- the configs' loops run inside one
+  chunk scope (a fused pass one config has run answers the next from the
+  cache), their recorded programs share the launches -- and the result is
+  {name: Dataset}.
 
   The baseline switches of `eval_config` are honoured the way the Beam pipeline
   does (evaluation.py:677-733): with `evaluate_climatology` /
@@ -1262,41 +1322,55 @@ def evaluate_chunks(
     raise ValueError(f'{len(chunks)} chunks cannot be sharded over {world} '
                      'ranks (every rank must take part in the all-reduce)')
   lo, hi = shard_bounds(len(chunks), world, rank)
-  substitute = _chunk_substitution(eval_config, truth, climatology, by_init)
+  several = isinstance(eval_config, dict)
+  names = list(eval_config) if several else [None]
+  configs = [eval_config[k] for k in names] if several else [eval_config]
+  if not configs:
+    raise ValueError('no eval config given')
+  switches = {tuple(bool(getattr(c, k, False)) for k in (
+      'evaluate_climatology', 'evaluate_probabilistic_climatology',
+      'evaluate_persistence')) for c in configs}
+  if len(switches) > 1:
+    # (the switches replace the FORECAST of a chunk: configs that disagree on
+    # them do not evaluate the same data)
+    raise ValueError('eval configs with different baseline switches '
+                     '(evaluate_climatology / _probabilistic_climatology / '
+                     '_persistence) cannot share one pass over the chunks')
+  substitute = _chunk_substitution(configs[0], truth, climatology, by_init)
   auto_batch = batch_chunks is None
   batch_chunks = AUTO_BATCH_MAX if auto_batch else max(1, int(batch_chunks))
-  if eval_config.derived_variables or not all(
+  if any(c.derived_variables or not all(
       getattr(m, '_reads_slabs_in_place', False)
-      for m in eval_config.metrics.values()):
+      for m in c.metrics.values()) for c in configs):
     # Chunks are batched only for metrics that read a concatenation in place
     # (the deterministic suite: address tables); every other metric would
     # materialise the window first -- a copy of the data, slower than going
     # chunk by chunk.  Derived variables are computed on (and assigned into)
     # each chunk as the caller handed it in (evaluation.py:402-405).
     batch_chunks, auto_batch = 1, False
-  mean = None   # RunningMean, or RunningConcat for temporal_mean=False
-  window: list = []
+  sinks: list = []  # per config: RunningMean, or RunningConcat for
+  window: list = []  # temporal_mean=False
   # chunk structures seen so far -> their replayable program (program.py), or
   # False where the generic path has to stay
   programs: dict = {}
 
   def flush():
-    nonlocal mean
     if not window:
       return
     first = window[0][0]
     time_dim = 'time' if 'time' in first.dims else 'init_time'
     lead_dim = _lead_dim(first)
     lead_dim = lead_dim if lead_dim in first.dims else None
-    if mean is None:
-      if getattr(eval_config, 'temporal_mean', True) is False:
-        mean = RunningConcat(time_dim, device, split_dim=lead_dim)
-      else:
-        mean = RunningMean(time_dim, skipna, device, split_dim=lead_dim,
-                           split_order='first_seen')
+    if not sinks:
+      for c in configs:
+        if getattr(c, 'temporal_mean', True) is False:
+          sinks.append(RunningConcat(time_dim, device, split_dim=lead_dim))
+        else:
+          sinks.append(RunningMean(time_dim, skipna, device,
+                                   split_dim=lead_dim,
+                                   split_order='first_seen'))
     for forecast, truth_chunk in _batches(window, time_dim, lead_dim):
-      _evaluate_piece(forecast, truth_chunk, eval_config, skipna, mean,
-                      programs)
+      _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks, programs)
     window.clear()
 
   with metrics_lib.pinned_rows_per_chunk(EVALUATE_ROWS_PER_CHUNK):
@@ -1340,8 +1414,10 @@ def evaluate_chunks(
       if len(window) >= batch_chunks:
         flush()
     flush()
-  assert mean is not None
-  return mean.result()
+  assert sinks
+  # (the sinks meet the other ranks one after the other, in config order)
+  results = [sink.result() for sink in sinks]
+  return dict(zip(names, results)) if several else results[0]
 
 
 # ---------------------------------------------------------------------------

@@ -368,21 +368,14 @@ def _nan_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
   return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
 
 
-class ChunkProgram:
-  """The replayable form of one chunk structure (see the module docstring)."""
+class _SinkGroup:
+  """The result variables of ONE eval config of a program and how they reach
+  that config's sink (evaluation.RunningMean / RunningConcat)."""
 
-  def __init__(self, launches, variables, arena, device, time_dim, split_dim):
-    self.launches = launches       # [_Launch]
+  def __init__(self, variables, device, time_dim, split_dim):
     self.variables = variables     # [(name, dims, shape, axis, src, round32)]
-    self.arena = arena             # float64 device tensor: launch outputs
     self.device = device
     self.time_dim, self.split_dim = time_dim, split_dim
-    off = 0
-    self.slices = []
-    for la in launches:
-      self.slices.append(arena[off:off + la.n_values].view(
-          la.n_metric, la.plan.n_region, la.n_total))
-      off += la.n_values
     # every variable's [element][time] source table, one after the other
     src = np.concatenate([v[4].ravel() for v in variables]).astype(np.int32)
     r32 = np.concatenate([v[5] for v in variables]).astype(np.uint8)
@@ -493,16 +486,13 @@ class ChunkProgram:
     self._targets[key] = (stamp, d_sum, d_cnt)
     return d_sum, d_cnt
 
-  # -- replay -------------------------------------------------------------------
-  def run(self, forecast: xl.Dataset, truth: xl.Dataset, mean) -> None:
-    stream = engine.current_stream_ptr(self.device)
-    for la, out in zip(self.launches, self.slices):
-      la.run(forecast, truth, out, stream)
+  # -- one chunk's values into the sink -----------------------------------------
+  def accumulate(self, arena, forecast: xl.Dataset, mean, stream) -> None:
     if getattr(mean, 'keeps_time', False):
       # one destination per (element, time step): 0 + value, exact
       d_sum, d_cnt, round_each = self._kept_tables(mean, forecast)
       status = self._lib.wb2_gather_accumulate(
-          self.arena.data_ptr(), self.src.data_ptr(), round_each.data_ptr(),
+          arena.data_ptr(), self.src.data_ptr(), round_each.data_ptr(),
           self.n_out * self.n_time, 1, 0, d_sum.data_ptr(), d_cnt.data_ptr(),
           stream)
       if status != 0:
@@ -513,26 +503,67 @@ class ChunkProgram:
       labels = np.asarray(forecast.coords[self.split_dim])
     d_sum, d_cnt = self._accumulator_tables(mean, labels)
     status = self._lib.wb2_gather_accumulate(
-        self.arena.data_ptr(), self.src.data_ptr(), self.round32.data_ptr(),
+        arena.data_ptr(), self.src.data_ptr(), self.round32.data_ptr(),
         self.n_out, self.n_time, int(mean.skipna), d_sum.data_ptr(),
         d_cnt.data_ptr(), stream)
     if status != 0:
       _lib.check(status, 'wb2_gather_accumulate')
 
 
-def build(first: Recorder, forecast: xl.Dataset, truth: xl.Dataset, result,
-          mean, loop) -> t.Optional[ChunkProgram]:
+class ChunkProgram:
+  """The replayable form of one chunk structure (see the module docstring):
+  the launches of the loop(s) over it, and one `_SinkGroup` per eval config
+  that was evaluated on the chunk (several configs -- `deterministic` and
+  `deterministic_temporal` of the documented command line -- share the
+  launches: the chunk is read once)."""
+
+  def __init__(self, launches, groups, arena, device, time_dim, split_dim):
+    self.launches = launches       # [_Launch | _EnsLaunch]
+    self.groups = groups           # [_SinkGroup], one per config
+    self.arena = arena             # float64 device tensor: launch outputs
+    self.device = device
+    self.time_dim, self.split_dim = time_dim, split_dim
+    off = 0
+    self.slices = []
+    for la in launches:
+      self.slices.append(arena[off:off + la.n_values].view(
+          la.n_metric, la.plan.n_region, la.n_total))
+      off += la.n_values
+
+  def reset(self):
+    for g in self.groups:
+      g.reset()
+
+  def run(self, forecast: xl.Dataset, truth: xl.Dataset, means) -> None:
+    """`means`: the sink of every config, in the order of the build (a single
+    sink for a single config)."""
+    if not isinstance(means, (list, tuple)):
+      means = [means]
+    stream = engine.current_stream_ptr(self.device)
+    for la, out in zip(self.launches, self.slices):
+      la.run(forecast, truth, out, stream)
+    for group, mean in zip(self.groups, means):
+      group.accumulate(self.arena, forecast, mean, stream)
+
+
+def build(first: Recorder, forecast: xl.Dataset, truth: xl.Dataset, results,
+          means, loop) -> t.Optional[ChunkProgram]:
   """The program of the structure of (forecast, truth), from the recorder that
-  watched the generic pass over it (`result` = what that pass returned, already
-  added to `mean`), or None when the structure cannot be replayed.  `loop()`
-  runs the generic pass again (under the probe recorder)."""
+  watched the generic pass over it; `results` = what that pass returned (one
+  Dataset per eval config, already added to the config's sink in `means`), or
+  None when the structure cannot be replayed.  `loop()` runs the generic pass
+  again (under the probe recorder) and returns the same list.  A single
+  Dataset / sink / loop result stands for a list of one."""
+  if not isinstance(means, (list, tuple)):
+    one = loop
+    results, means, loop = [results], [means], (lambda: [one()])
   try:
-    return _build(first, forecast, truth, result, mean, loop)
+    return _build(first, forecast, truth, results, means, loop)
   except _NotReplayable as e:
     return _no(f'not replayable: {e}')
 
 
-def _build(first, forecast, truth, result, mean, loop):
+def _build(first, forecast, truth, results, means, loop):
   launches_rec = [l for l in first.launches if 'plan' in l]
   if not launches_rec:
     return _no('no launch recorded')
@@ -540,7 +571,7 @@ def _build(first, forecast, truth, result, mean, loop):
   total = sum(int(l['metrics'].numel()) for l in launches_rec)
   if total >= _MAX_ELEMENTS:
     return _no('too many output elements')
-  time_dim, split_dim = mean.dim, mean.split_dim
+  time_dim, split_dim = means[0].dim, means[0].split_dim
   fmap = {id(v.data): ('f', k) for k, v in forecast.data_vars.items()}
   tmap = {id(v.data): ('t', k) for k, v in truth.data_vars.items()}
   if any(l.get('kind') == 'unsupported' for l in first.launches):
@@ -551,11 +582,28 @@ def _build(first, forecast, truth, result, mean, loop):
       l, fmap, tmap, device) for l in launches_rec]
   # ---- probe: which output element does every result element show?
   with Recorder(probe=True) as probe:
-    shown = xl.as_dataset(loop())
+    shown_all = [xl.as_dataset(r) for r in loop()]
   if [l['n'] for l in probe.launches] != [la.n_values for la in launches]:
     return _no('probe saw other launches')
-  variables = []
   flat_real = torch.cat([l['metrics'].reshape(-1) for l in launches_rec])
+  groups = []
+  for shown, result, mean in zip(shown_all, results, means):
+    if (mean.dim, mean.split_dim) != (time_dim, split_dim):
+      return _no('the sinks disagree on the time / lead dims')
+    variables = _group_variables(shown, xl.as_dataset(result), mean, forecast,
+                                 flat_real, total, time_dim)
+    if variables is None:
+      return None
+    groups.append(_SinkGroup(variables, device, time_dim, split_dim))
+  arena = torch.empty((total,), dtype=torch.float64, device=device)
+  return ChunkProgram(launches, groups, arena, device, time_dim, split_dim)
+
+
+def _group_variables(shown, result, mean, forecast, flat_real, total, time_dim):
+  """[(name, dims, shape, time axis, source table, float32 flags)] of one
+  config's result, or None (reason noted) if it is not a rearrangement of the
+  launches' outputs."""
+  variables = []
   for name, da in shown.data_vars.items():
     real = result.data_vars.get(name)
     if real is None or not isinstance(da.data, torch.Tensor) or not isinstance(
@@ -613,5 +661,4 @@ def _build(first, forecast, truth, result, mean, loop):
     return _no('result variables differ')
   if len({v[4].shape[1] for v in variables}) != 1:
     return _no('time lengths differ')
-  arena = torch.empty((total,), dtype=torch.float64, device=device)
-  return ChunkProgram(launches, variables, arena, device, time_dim, split_dim)
+  return variables
