@@ -50,3 +50,25 @@ def test_traffic_of_every_benched_kernel_is_the_algorithmic_bytes():
                                             'spectrum' in name else nbytes), (
         name, got)
     assert got['ratio'] <= limit, (name, got)
+
+
+@pytest.mark.gpu
+def test_the_map_accumulate_kernel_moves_56_bytes_per_point():
+  """wb2_spatial_accumulate_addr over one official chunk (85 slabs): forecast
+  + truth read once (8 B/pt), three float64 running sums read and written
+  (48 B/pt) -- nothing else crosses HBM."""
+  if not (shutil.which('rocprofv3') or os.path.exists('/opt/rocm/bin/rocprofv3')):
+    pytest.skip('rocprofv3 not installed')
+  res = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'tools', 'live_traffic.py'),
+       '--workload', 'map_accumulate'],
+      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+      timeout=600)
+  assert res.returncode == 0, res.stderr[-2000:]
+  got = json.loads(res.stdout.strip().splitlines()[-1])
+  pts = 85 * 721 * 1440
+  assert 'spatial_accumulate_addr_kernel' in got['kernel'], got
+  assert got['algorithmic_bytes'] == pts * 56, got
+  assert 0.97 * pts * 32 <= got['fetch_bytes'] <= 1.03 * pts * 32, got
+  assert 0.97 * pts * 24 <= got['write_bytes'] <= 1.03 * pts * 24, got
+  assert got['ratio'] <= 1.02, got

@@ -56,6 +56,8 @@ def classify(kernel_name: str):
     return SPECTRUM_MODES.get(m.group(1))
   if 'latseg_combine_kernel' in kernel_name:
     return 'spectrum+combine'
+  if 'spatial_accumulate_addr_kernel' in kernel_name:
+    return 'map_accumulate'
   return None
 
 
@@ -65,12 +67,17 @@ def collect(counter: str, probe: str, probe_args: list, timeout: float) -> dict:
   out_dir = tempfile.mkdtemp(prefix=f'wb2_pmc_{counter}_')
   try:
     cmd = [rocprof, '--pmc', counter, '--kernel-trace', '--output-format',
-           'csv', '-d', out_dir, '-o', 'run', '--', sys.executable,
-           os.path.join(ROOT, 'bench.py'), '--traffic-probe', probe,
-           '--no-pmc',
-           '--no-secondary', '--no-pcie', '--no-api', '--no-full-suite',
-           '--no-cpu-baseline', '--warmup', '1', '--steps', '4',
-           '--ramp-ms', '0'] + probe_args
+           'csv', '-d', out_dir, '-o', 'run', '--', sys.executable]
+    if probe == 'map_accumulate':
+      # the fused kernel of map_suite.py alone (tools/map_accumulate_bench.py)
+      cmd += [os.path.join(ROOT, 'tools', 'map_accumulate_bench.py'),
+              '--reps', '6', '--pool', '6']
+    else:
+      cmd += [os.path.join(ROOT, 'bench.py'), '--traffic-probe', probe,
+              '--no-pmc',
+              '--no-secondary', '--no-pcie', '--no-api', '--no-full-suite',
+              '--no-cpu-baseline', '--warmup', '1', '--steps', '4',
+              '--ramp-ms', '0'] + probe_args
     env = dict(os.environ, TMPDIR='/tmp')
     res = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=timeout)
@@ -104,6 +111,9 @@ def algorithmic_bytes(workload: str, units: int, spectrum_units: int = 16,
                       members: int = 50) -> float:
   """SURVEY.md 8(d), strictly, per launch."""
   pts_unit = N_LEV * N_LAT * N_LON
+  if workload == 'map_accumulate':
+    # 85 slabs: forecast + truth read, three float64 sums read and written
+    return 85 * N_LAT * N_LON * 56.0
   if workload == 'deterministic':
     return units * pts_unit * 12.0
   if workload == 'ensemble':
@@ -126,12 +136,13 @@ def main():
   ap.add_argument('--rows-per-chunk', type=int, default=0)
   ap.add_argument('--timeout', type=float, default=240.0)
   ap.add_argument('--workload', default='deterministic',
-                  choices=['deterministic', 'all'])
+                  choices=['deterministic', 'all', 'map_accumulate'])
   ap.add_argument('--variant', default='deterministic',
                   choices=['deterministic', 'official16_landmask', 'skipna'],
                   help='which K1 instantiation to probe (bench.k1_variants)')
   args = ap.parse_args()
-  probe = 'all' if args.workload == 'all' else args.variant
+  probe = ('all' if args.workload == 'all' else 'map_accumulate'
+           if args.workload == 'map_accumulate' else args.variant)
   probe_args = ['--units', str(args.units), '--pool', str(args.pool),
                 '--rows-per-chunk', str(args.rows_per_chunk)]
   fetch = collect('FETCH_SIZE', probe, probe_args, args.timeout)
@@ -154,7 +165,9 @@ def main():
         'algorithmic_bytes': alg, 'ratio': (f_b + w_b) / alg,
         'launches': min(fetch[what][1], write[what][1]),
         'kernel': fetch[what][2][:80], 'counters': note}
-  if args.workload == 'deterministic':
+  if args.workload == 'map_accumulate':
+    print(json.dumps(result['map_accumulate']))
+  elif args.workload == 'deterministic':
     flat = result['deterministic']
     flat['units_per_launch'] = args.units
     print(json.dumps(flat))

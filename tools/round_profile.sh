@@ -40,6 +40,7 @@ if [ "$2" != quick ]; then
   timeout 600 python tools/official_chunk.py --batch 1,16,32,default --host-fed > $OUT/${R}_official_chunk.json 2>/dev/null
   for g in 240x121 64x32; do timeout 300 python tools/official_probabilistic.py --grid $g 2>/dev/null | tail -1; done > $OUT/${R}_official_probabilistic.json
   timeout 300 python tools/map_accumulate_bench.py 2>/dev/null | tail -1 > $OUT/${R}_map_accumulate.json
+  timeout 300 python tools/live_traffic.py --workload map_accumulate 2>/dev/null | tail -1 >> $OUT/${R}_map_accumulate.json
   timeout 600 python tools/k3_variants.py > $OUT/${R}_k3_variants.json 2>/dev/null
   timeout 600 python tools/tier2_variants.py > $OUT/${R}_tier2_variants.json 2>/dev/null
   for th in 4 8 16 32; do WB2HIP_COPY_THREADS=$th timeout 120 python tools/upload_sweep.py 2>/dev/null | tail -1; done > $OUT/${R}_upload_sweep.txt
