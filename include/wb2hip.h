@@ -391,6 +391,24 @@ int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
                           int32_t n_seg, int32_t n_ts, double* partials,
                           double* maps, void* stream);
 
+/* As wb2_ens_partials for slabs given by ADDRESS: ens_addr[o] is the byte
+ * address of member 0's slab of outer index o (member m follows at
+ * m * member_stride elements), truth_addr[o] that of the truth slab (both DEV
+ * int64[n_outer]).  The variables of one `init_time=1,lead_time=1` ensemble
+ * chunk (docs/source/official-evaluation.md:765-860) are separate allocations:
+ * one launch takes all that share a member stride.  Same kernels (and bits) as
+ * wb2_ens_partials for every member count. */
+int wb2_ens_partials_addr(int dtype, int skipna, const int64_t* ens_addr,
+                          const int64_t* truth_addr, int32_t n_member,
+                          int64_t member_stride, int64_t n_outer, int32_t n_row,
+                          int32_t n_col, const double* w_row,
+                          const double* w_col, const double* wfield,
+                          const int32_t* chunk_row0, const int32_t* chunk_nrow,
+                          int32_t n_chunk, int32_t n_ctile,
+                          const int32_t* seg_col0, const int32_t* seg_eoff,
+                          int32_t n_seg, int32_t n_ts, double* partials,
+                          void* stream);
+
 /* As wb2_ens_partials_maps for a GATHERED ensemble: member m of outer index o
  * is the [n_row][n_col] slab at device address member_ptr[o * n_member + m]
  * (DEV int64[n_outer][n_member]) -- no stride, no common base: the forecast of

@@ -130,6 +130,14 @@ def test_new_entry_points_validate_their_arguments(lib):
   assert rc < 0 and b'run=0' in h.wb2_last_error()
   assert h.wb2_time_accumulate_runs(lib.WB2_F32, None, 0, 1, 8, 0, None, 4,
                                     None, None, None) == 0
+  # ensemble slabs by address: no slabs is a no-op, tables are required
+  assert h.wb2_ens_partials_addr(lib.WB2_F32, 0, None, None, 5, 100, 0, 9, 64,
+                                 None, None, None, None, None, 8, 1, None,
+                                 None, 1, 1, None, None) == 0
+  rc = h.wb2_ens_partials_addr(lib.WB2_F32, 0, None, None, 5, 100, 3, 9, 64,
+                               None, None, None, None, None, 8, 1, None, None,
+                               1, 1, None, None)
+  assert rc < 0 and b'null pointer' in h.wb2_last_error()
   # the struct is the header's: 8 int32, 3 pointers, 2 int32, pointer, double,
   # 9 pointers
   assert ctypes.sizeof(lib.PlanTables) == 8 * 4 + 3 * 8 + 2 * 4 + 8 + 8 + 9 * 8

@@ -276,7 +276,7 @@ def test_temporal_mean_false_rejects_a_chunk_that_comes_twice(monkeypatch):
 def _ensemble_chunks(n_init=4, n_lead=3, n_member=5, n_lat=19, n_lon=36,
                      member_first=True, nan=False, seed=0):
   """(oracle forecast, truth) + device-resident product chunks of an ensemble
-  forecast: two variables (one with levels), `number` members."""
+  forecast: three variables (two with levels), `number` members."""
   from oracle.named import DS, NA
   from weatherbench2_amd import evaluation
   rs = np.random.RandomState(seed)
@@ -300,26 +300,31 @@ def _ensemble_chunks(n_init=4, n_lead=3, n_member=5, n_lat=19, n_lon=36,
     return NA(x, dims)
   coords = {'init_time': init, 'lead_time': lead, 'level': level,
             'latitude': lat, 'longitude': lon, 'number': np.arange(n_member)}
-  forecast = DS({'z': field(put(core3)), 't2m': field(put(core2))}, coords)
+  forecast = DS({'z': field(put(core3)), 'q': field(put(core3)),
+                 't2m': field(put(core2))}, coords)
   tcoords = {k: v for k, v in coords.items() if k != 'number'}
-  truth = DS({'z': field(core3), 't2m': field(core2)}, tcoords)
+  truth = DS({'z': field(core3), 'q': field(core3), 't2m': field(core2)},
+             tcoords)
   gf, gt = (evaluation.make_resident(helpers.to_gpu_dataset(x))
             for x in (forecast, truth))
   return forecast, truth, oc.chunk_pairs(gf, gt)
 
 
+@pytest.mark.parametrize('n_member', [5, 7])
 @pytest.mark.parametrize('member_first', [True, False])
 @pytest.mark.parametrize('skipna', [False, True])
-def test_ensemble_passes_replay_too(skipna, member_first, monkeypatch):
+def test_ensemble_passes_replay_too(skipna, member_first, n_member,
+                                    monkeypatch):
   """The `probabilistic` config (scripts/evaluate.py:496-520) at the chunking
   of its command lines (`init_time=1,lead_time=1`,
   docs/source/official-evaluation.md:826-860): the K3 pass of every variable
   + its fold are recorded and replayed with new base pointers -- same bits as
   the generic path, which equals the oracle's time mean."""
   from oracle import evaluation_np as oe, metrics_np as om, regions_np as oreg
-  from weatherbench2_amd import config, evaluation, metrics as gm, program
+  from weatherbench2_amd import config, engine, evaluation, metrics as gm
+  from weatherbench2_amd import program
   forecast, truth, chunks = _ensemble_chunks(member_first=member_first,
-                                             nan=skipna)
+                                             nan=skipna, n_member=n_member)
   dim = 'number'
   names = {'crps': 'CRPS', 'crps_spread': 'CRPSSpread',
            'crps_skill': 'CRPSSkill', 'ensemble_mean_mse': 'EnsembleMeanMSE',
@@ -339,6 +344,21 @@ def test_ensemble_passes_replay_too(skipna, member_first, monkeypatch):
                                    batch_chunks=1)
   _same(got, want)
   assert len(calls) == len(chunks) - 1, program.REASONS
+  if not skipna:
+    # the passes of z and q (same member stride) are ONE launch through their
+    # slabs' addresses -- the kernel of the separate passes, whatever the
+    # member count (5 has a sorting program of its own, 7 is hosted by 8's)
+    seen = []
+    old = engine.set_launch_hook(lambda when, kernel: seen.append(kernel)
+                                 if when == 'begin' else None)
+    try:
+      evaluation.evaluate_chunks(chunks[:4], cfg, skipna, prefetch=0,
+                                 batch_chunks=1)
+    finally:
+      engine.set_launch_hook(old)
+    # first chunk: 3 generic passes + the trial of the fused launch; then
+    # 3 replays of (z + q, t2m)
+    assert seen.count('ens_partials') == 3 + 1 + 3 * 2, seen
   monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', 'verify')
   _same(evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
                                    batch_chunks=1), want)

@@ -180,7 +180,8 @@ def test_exact_member_counts_full_size(dev, m):
 
 
 @pytest.mark.parametrize('m', [3, 7, 21, 44, 77, 100])
-def test_hosted_counts_give_the_padded_networks_values(dev, m, monkeypatch):
+def test_hosted_counts_give_the_padded_networks_values(dev, m, monkeypatch,
+                                                       tmp_path):
   """The hosted program and the padded power-of-two network (WB2HIP_ENS_HOSTED
   is read once per process, so the second form comes from a GATHERED launch
   with the variable unset vs. a child process) do the same operations on the
@@ -230,18 +231,20 @@ def test_hosted_counts_give_the_padded_networks_values(dev, m, monkeypatch):
     assert np.isnan(maps[:, 1, 6 * n_lon + 12]).all()
     assert np.isfinite(maps[:, 0, :100]).all()
   # the padded runtime network in a process of its own
-  np.save('/tmp/wb2_hosted_ens.npy', ens)
-  np.save('/tmp/wb2_hosted_truth.npy', truth)
+  f_ens, f_truth, f_out = (str(tmp_path / f'{k}.npy')
+                           for k in ('ens', 'truth', 'padded'))
+  np.save(f_ens, ens)
+  np.save(f_truth, truth)
   code = f'''
 import numpy as np, torch
 from weatherbench2_amd import engine, plan as plan_lib
-ens = np.load('/tmp/wb2_hosted_ens.npy'); truth = np.load('/tmp/wb2_hosted_truth.npy')
+ens = np.load({f_ens!r}); truth = np.load({f_truth!r})
 dev = torch.device('cuda', 0)
 lat = np.linspace(-90, 90, {n_lat}); lon = np.linspace(0, 360, {n_lon}, endpoint=False)
 pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, None, dev, rows_per_chunk=plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
 maps = torch.empty((6, 2, {slab}), dtype=torch.float64, device=dev)
 engine.ensemble_reduce(pl, torch.as_tensor(ens, device=dev), 2 * {slab}, {m}, None, torch.as_tensor(truth, device=dev), None, 2, False, maps=maps)
-np.save('/tmp/wb2_hosted_padded.npy', maps.cpu().numpy())
+np.save({f_out!r}, maps.cpu().numpy())
 '''
   import os
   env = dict(os.environ, WB2HIP_ENS_HOSTED='0')
@@ -249,7 +252,7 @@ np.save('/tmp/wb2_hosted_padded.npy', maps.cpu().numpy())
   res = subprocess.run([sys.executable, '-c', code], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stderr[-2000:]
-  padded = np.load('/tmp/wb2_hosted_padded.npy')
+  padded = np.load(f_out)
   if m in EXACT:  # (the child's strided launch took the exact kernel too)
     assert np.array_equal(strided, padded, equal_nan=True)
   else:

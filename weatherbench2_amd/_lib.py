@@ -90,6 +90,9 @@ _SIGNATURES = {
     'wb2_ens_partials_maps': (_int, [
         _int, _int, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp,
         _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    'wb2_ens_partials_addr': (_int, [
+        _int, _int, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
+        _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'wb2_ens_partials_gather': (_int, [
         _int, _int, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
         _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

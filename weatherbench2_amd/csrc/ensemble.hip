@@ -361,6 +361,63 @@ int wb2_ens_partials_maps(int dtype, int skipna, const void* ens,
   p.partials = partials;
   p.maps = maps;
   p.member_stride = member_stride;
+  p.ens_scale = p.truth_scale =
+      (long long)n_row * n_col * (dtype == WB2_F32 ? 4 : 8);
+  p.n_outer = n_outer;
+  p.n_member = n_member;
+  p.n_row = n_row;
+  p.n_col = n_col;
+  p.n_chunk = n_chunk;
+  p.n_ctile = n_ctile;
+  p.n_seg = n_seg;
+  p.n_ts = n_ts;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == WB2_F32)
+    return launch_ens_npad<float>(p, skipna != 0, wfield != nullptr, s);
+  return launch_ens_npad<double>(p, skipna != 0, wfield != nullptr, s);
+}
+
+int wb2_ens_partials_addr(int dtype, int skipna, const int64_t* ens_addr,
+                          const int64_t* truth_addr, int32_t n_member,
+                          int64_t member_stride, int64_t n_outer, int32_t n_row,
+                          int32_t n_col, const double* w_row,
+                          const double* w_col, const double* wfield,
+                          const int32_t* chunk_row0, const int32_t* chunk_nrow,
+                          int32_t n_chunk, int32_t n_ctile,
+                          const int32_t* seg_col0, const int32_t* seg_eoff,
+                          int32_t n_seg, int32_t n_ts, double* partials,
+                          void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_REQUIRE(ens_addr && truth_addr && w_row && chunk_row0 && chunk_nrow &&
+                  seg_col0 && seg_eoff && partials,
+              "null pointer argument");
+  WB2_REQUIRE(n_member >= 1 && n_outer >= 0 && n_row > 0 && n_col > 0 &&
+                  n_chunk > 0 && n_seg > 0 && n_ts >= n_seg,
+              "bad sizes");
+  WB2_REQUIRE(n_chunk % 8 == 0, "n_chunk=%d must be a multiple of 8", n_chunk);
+  WB2_REQUIRE(n_outer < (1ll << 31), "n_outer=%lld too large",
+              (long long)n_outer);
+  WB2_REQUIRE(n_ctile == (n_col + kWave - 1) / kWave,
+              "n_ctile=%d does not match ceil(n_col / 64)", n_ctile);
+  if (n_outer == 0) return 0;
+  EnsParams p{};
+  p.ens = nullptr;    // the tables hold byte addresses
+  p.truth = nullptr;
+  p.ens_scale = p.truth_scale = 1;
+  p.ens_slab = reinterpret_cast<const long long*>(ens_addr);
+  p.truth_slab = reinterpret_cast<const long long*>(truth_addr);
+  p.w_row = w_row;
+  p.w_col = w_col;
+  p.wfield = wfield;
+  p.chunk_row0 = chunk_row0;
+  p.chunk_nrow = chunk_nrow;
+  p.seg_col0 = seg_col0;
+  p.seg_eoff = seg_eoff;
+  p.partials = partials;
+  p.member_stride = member_stride;
   p.n_outer = n_outer;
   p.n_member = n_member;
   p.n_row = n_row;
@@ -409,6 +466,8 @@ int wb2_ens_partials_gather(int dtype, int skipna, const int64_t* member_ptr,
   EnsParams p{};
   p.ens = truth;  // unused with member_ptr; any valid address
   p.truth = truth;
+  p.ens_scale = p.truth_scale =
+      (long long)n_row * n_col * (dtype == WB2_F32 ? 4 : 8);
   p.truth_slab = reinterpret_cast<const long long*>(truth_slab);
   p.member_ptr = reinterpret_cast<const long long*>(member_ptr);
   p.w_row = w_row;

@@ -39,6 +39,9 @@ struct EnsParams {
   long long member_stride;
   long long n_outer;
   int n_member, n_row, n_col, n_chunk, n_ctile, n_seg, n_ts;
+  // bytes per unit of ens_slab / truth_slab entries (K3 kernels of this
+  // header: one slab, or 1 for tables of addresses with a NULL base)
+  long long ens_scale, truth_scale;
 };
 
 // Exact float32 instantiations live in translation units of their own
@@ -1016,10 +1019,20 @@ __global__ void __launch_bounds__(256)
   {
     const long long slab_elems = (long long)p.n_row * p.n_col;
     // wave-uniform row base (SGPRs) + this lane's byte offset inside the row
-    const T* xrow0 = static_cast<const T*>(p.ens) + es * slab_elems +
+    // (ens == NULL / truth == NULL: the tables hold byte ADDRESSES of the
+    // slabs -- member 0's for the ensemble -- instead of slab numbers: the
+    // variables of a chunk are separate allocations, wb2_ens_partials_addr;
+    // wave-uniform)
+    // table entry -> slab: entry * scale BYTES from the base.  scale = one
+    // slab for tables of slab numbers; scale = 1 with a NULL base for tables
+    // of byte addresses (the variables of a chunk are separate allocations:
+    // wb2_ens_partials_addr) -- no branch either way
+    const T* xrow0 = reinterpret_cast<const T*>(
+                         static_cast<const char*>(p.ens) + es * p.ens_scale) +
                      (long long)row0 * p.n_col;
     const int lane_bytes = colc * (int)sizeof(T);
-    const T* tb = static_cast<const T*>(p.truth) + ts * slab_elems +
+    const T* tb = reinterpret_cast<const T*>(
+                      static_cast<const char*>(p.truth) + ts * p.truth_scale) +
                   (long long)row0 * p.n_col + colc;
     const double* wfp = WF ? p.wfield + (long long)row0 * p.n_col + colc
                            : nullptr;

@@ -302,6 +302,7 @@ class _EnsLaunch:
     self.names = (role_e[1], role_t[1])
     self.offsets = (_view_offset(rec['ens'], rec['ens_raw'], role_e[1]),
                     _view_offset(rec['truth'], rec['truth_raw'], role_t[1]))
+    self.rec = rec
     self.plan, self.skipna = pl, bool(rec['skipna'])
     self.n_total = int(rec['n_outer'])
     self.n_metric = _lib.NMETRIC_ENS
@@ -346,6 +347,136 @@ class _EnsLaunch:
     status = lib.wb2_ens_combine(*self.combine_args, out.data_ptr(), stream)
     if status != 0:
       _lib.check(status, 'wb2_ens_combine')
+
+
+class _EnsFused:
+  """Several recorded ensemble passes of one chunk (its variables: same plan,
+  member count and stride, dtype, NaN rule) as ONE launch: member 0's slab and
+  the truth slab of every outer index by address (wb2_ens_partials_addr), one
+  fold over all of them.  The kernels are those of the separate passes and the
+  fold is per slab: the same bits.  The output block is
+  [metric][region][all slabs] -- `perm` maps the separate blocks' elements
+  into it."""
+
+  def __init__(self, singles, device):
+    first = singles[0]
+    pl = self.plan = first.plan
+    self.skipna = first.skipna
+    size = first.rec['ens'].element_size()
+    slab = pl.n_row * pl.n_col
+    self.names = [la.names for la in singles]
+    self.bases = [la.offsets for la in singles]
+    self.counts = [la.n_total for la in singles]
+    self.n_total = sum(self.counts)
+    self.n_metric = _lib.NMETRIC_ENS
+    self.n_values = self.n_metric * pl.n_region * self.n_total
+    self.rel_e, self.rel_t = [], []
+    for la in singles:
+      rec, n = la.rec, la.n_total
+      host = lambda tb: (np.arange(n, dtype=np.int64) if tb is None
+                         else tb.cpu().numpy().astype(np.int64))
+      self.rel_e.append(host(rec['ens_table']) * slab * size)
+      self.rel_t.append(host(rec['truth_table']) * slab * size)
+    lib = self._lib = _lib.load()
+    k = lib.wb2_ens_num_slots(int(self.skipna))
+    tile = lib.wb2_ens_tile_cols(pl.n_col)
+    n_ctile = -(-pl.n_col // tile)
+    seg_eoff, n_ts = pl.seg_entries(tile)
+    self.partials = torch.empty((self.n_total, pl.n_chunk, pl.nwf, n_ts, k),
+                                dtype=torch.float64, device=device)
+    self.keep = (seg_eoff, pl)
+    ptr = _lib.ptr
+    # (dtype, skipna, ens addresses, truth addresses, ...)
+    self.partials_args = [
+        engine._DTYPES[first.rec['ens'].dtype], int(self.skipna), None, None,
+        int(first.rec['n_member']), int(first.rec['member_stride']),
+        self.n_total, pl.n_row, pl.n_col, ptr(pl.w_row), ptr(pl.w_col),
+        ptr(pl.wfield), ptr(pl.chunk_row0), ptr(pl.chunk_nrow), pl.n_chunk,
+        n_ctile, ptr(pl.seg_col0), ptr(seg_eoff), pl.n_seg, n_ts,
+        ptr(self.partials)]
+    self.combine_args = [
+        int(self.skipna), ptr(self.partials), self.n_total, pl.n_chunk, pl.nwf,
+        pl.n_seg, ptr(seg_eoff), n_ts, ptr(pl.band_chunk0), pl.n_band,
+        ptr(pl.coef_band), ptr(pl.coef_seg), ptr(pl.region_wf),
+        ptr(pl.region_wsum), pl.n_region, None]
+
+  def perm(self) -> np.ndarray:
+    """Element of the separate passes' output blocks (one after the other) ->
+    element of the fused block."""
+    n_mr = self.n_metric * self.plan.n_region
+    out, off = [], 0
+    for n in self.counts:
+      mr = np.arange(n_mr, dtype=np.int64)[:, None]
+      out.append((mr * self.n_total + off + np.arange(n, dtype=np.int64)
+                  ).ravel())
+      off += n
+    return np.concatenate(out)
+
+  def run(self, forecast, truth, out, stream) -> None:
+    parts_e, parts_t = [], []
+    for (fname, tname), (oe, ot), re_, rt_ in zip(self.names, self.bases,
+                                                 self.rel_e, self.rel_t):
+      parts_e.append(forecast[fname].data.data_ptr() + oe + re_)
+      parts_t.append(truth[tname].data.data_ptr() + ot + rt_)
+    table = engine.upload_table(np.concatenate(parts_e + parts_t),
+                                self.plan.device, cache=False)
+    base = table.data_ptr()
+    args = self.partials_args
+    args[2] = base
+    args[3] = base + 8 * self.n_total
+    lib = self._lib
+    hook = engine._LAUNCH_HOOK
+    if hook is not None:
+      hook('begin', 'ens_partials')
+    status = lib.wb2_ens_partials_addr(*args, stream)
+    if status != 0:
+      _lib.check(status, 'wb2_ens_partials_addr')
+    if hook is not None:
+      hook('end', 'ens_partials')
+    status = lib.wb2_ens_combine(*self.combine_args, out.data_ptr(), stream)
+    if status != 0:
+      _lib.check(status, 'wb2_ens_combine')
+
+
+def _fuse_ensemble_launches(launches, device):
+  """(launches with the compatible ensemble passes fused -- the fused launch
+  stands where the first of its passes stood --, old -> new arena index or
+  None)."""
+  if os.environ.get('WB2HIP_FUSE_ENSEMBLE', '1') == '0':
+    return launches, None
+  key = lambda x: (id(x.plan), x.skipna, int(x.rec['n_member']),
+                   int(x.rec['member_stride']), x.rec['ens'].dtype)
+  by_key: dict = {}
+  for i, la in enumerate(launches):
+    if isinstance(la, _EnsLaunch):
+      by_key.setdefault(key(la), []).append(i)
+  fused_at = {idx[0]: idx for idx in by_key.values() if len(idx) > 1}
+  if not fused_at:
+    return launches, None
+  gone = {i for idx in fused_at.values() for i in idx[1:]}
+  old_off = np.concatenate([[0], np.cumsum([la.n_values for la in launches])])
+  perm = np.empty(int(old_off[-1]), dtype=np.int64)
+  out, new_off = [], 0
+  for i, la in enumerate(launches):
+    if i in gone:
+      continue
+    if i in fused_at:
+      idx = fused_at[i]
+      fused = _EnsFused([launches[j] for j in idx], device)
+      inner = fused.perm()
+      at = 0
+      for j in idx:
+        n = launches[j].n_values
+        perm[old_off[j]:old_off[j] + n] = new_off + inner[at:at + n]
+        at += n
+      out.append(fused)
+      new_off += fused.n_values
+    else:
+      perm[old_off[i]:old_off[i] + la.n_values] = new_off + np.arange(
+          la.n_values, dtype=np.int64)
+      out.append(la)
+      new_off += la.n_values
+  return out, perm
 
 
 class _NotReplayable(Exception):
@@ -586,7 +717,7 @@ def _build(first, forecast, truth, results, means, loop):
   if [l['n'] for l in probe.launches] != [la.n_values for la in launches]:
     return _no('probe saw other launches')
   flat_real = torch.cat([l['metrics'].reshape(-1) for l in launches_rec])
-  groups = []
+  per_sink = []
   for shown, result, mean in zip(shown_all, results, means):
     if (mean.dim, mean.split_dim) != (time_dim, split_dim):
       return _no('the sinks disagree on the time / lead dims')
@@ -594,7 +725,38 @@ def _build(first, forecast, truth, results, means, loop):
                                  flat_real, total, time_dim)
     if variables is None:
       return None
-    groups.append(_SinkGroup(variables, device, time_dim, split_dim))
+    per_sink.append(variables)
+  # the ensemble passes of a chunk's variables become one launch per member
+  # stride (same kernels, per-slab fold: the separate passes' bits -- checked
+  # on this chunk all the same)
+  singles = launches
+  launches, perm = _fuse_ensemble_launches(launches, device)
+  if perm is not None:
+    trial = torch.empty((total,), dtype=torch.float64, device=device)
+    stream = engine.current_stream_ptr(device)
+    off = 0
+    for la in launches:
+      if isinstance(la, _EnsFused):
+        la.run(forecast, truth, trial[off:off + la.n_values], stream)
+      off += la.n_values
+    fused_at = torch.as_tensor(perm, device=device)
+    mine = torch.zeros_like(trial, dtype=torch.bool)
+    off = 0
+    for la in launches:
+      if isinstance(la, _EnsFused):
+        mine[off:off + la.n_values] = True
+      off += la.n_values
+    pick = mine[fused_at]   # old elements that the fused launches produce
+    if not _nan_equal(trial[fused_at][pick], flat_real[pick]):
+      _no('fused ensemble launch differs in bits: separate passes kept')
+      launches, perm = singles, None
+  if perm is not None:
+    per_sink = [[(name, dims, shape, axis,
+                  np.where(src >= 0, perm[np.maximum(src, 0)], -1), r32)
+                 for name, dims, shape, axis, src, r32 in variables]
+                for variables in per_sink]
+  groups = [_SinkGroup(variables, device, time_dim, split_dim)
+            for variables in per_sink]
   arena = torch.empty((total,), dtype=torch.float64, device=device)
   return ChunkProgram(launches, groups, arena, device, time_dim, split_dim)
 
