@@ -217,6 +217,9 @@ def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256) -> dict:
   import torch
   from weatherbench2_amd import engine, evaluation
   cfg = spatial_config(cfg)
+  # (4 lead rows of float64 sums + counts of 85 slabs x 3 maps: 17 GB; inside
+  # bench.py the other legs' cached blocks go first)
+  torch.cuda.empty_cache()
   evaluation.evaluate_chunks(chunks[:4], cfg, False, prefetch=0, batch_chunks=1)
   walls, hosts = {}, {}
   marks = {}
@@ -242,6 +245,7 @@ def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256) -> dict:
       evaluation.RunningMean.result = real_result
       engine.set_launch_hook(old)
     del out
+  torch.cuda.empty_cache()
   host_ms = (hosts[long] - hosts[short]) / (long - short) * 1e3
   ms = [a.elapsed_time(b) for a, b in ev.pairs]
   kernel_ms = sum(ms) / max(len(ms), 1)

@@ -231,6 +231,8 @@ def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
 # destination tables of RunningMean: one entry per run of this many (or more)
 # consecutive elements behind the split dim, one per element below
 _RUN_MIN = 256
+# an accumulator with a split dim starts with at most this many bytes of rows
+_FIRST_ROWS_BYTES = 256 << 20
 
 
 class _Accumulator:
@@ -254,7 +256,11 @@ class _Accumulator:
     else:
       self.pos = dims.index(split)
       self.rest_shape = shape[:self.pos] + shape[self.pos + 1:]
-      alloc = (8,) + self.rest_shape
+      # rows are added by doubling: 8 to start with, fewer when a row is big
+      # (map-valued results: a row of `deterministic_spatial` is 1.3 GB)
+      row_bytes = 8 * int(np.prod(self.rest_shape, dtype=np.int64))
+      alloc = (int(max(1, min(8, _FIRST_ROWS_BYTES // max(row_bytes, 1)))),
+               ) + self.rest_shape
     self.total = torch.zeros(alloc, dtype=torch.float64, device=device)
     self.count = torch.zeros_like(self.total)
 
@@ -500,20 +506,25 @@ class RunningMean:
     labels = self._split_labels(names)
     # (sum, count) in output layout: rows in label order, labels a rank never
     # met (lead-major chunk lists) as zeros
-    sums = {}
-    for n in names:
+    def laid_out(n):
       acc = self._acc[n]
       if acc.split is None:
-        sums[n] = (acc.total, acc.count)
-        continue
+        return acc.total, acc.count
       rows = [acc.row_of.get(v) for v in labels[n].tolist()]
+      if rows == list(range(len(rows))):
+        # the rows as they lie (the usual case): views, no copy -- the maps of
+        # `deterministic_spatial` are gigabytes per variable
+        return acc.total[:len(rows)], acc.count[:len(rows)]
       pad = acc.total.shape[0]
       idx = torch.as_tensor([pad if r is None else r for r in rows],
                             device=acc.total.device)
       zero = torch.zeros((1,) + acc.rest_shape, dtype=torch.float64,
                          device=acc.total.device)
-      sums[n] = tuple(torch.cat([x, zero]).index_select(0, idx)
-                      for x in (acc.total, acc.count))
+      return tuple(torch.cat([x, zero]).index_select(0, idx)
+                   for x in (acc.total, acc.count))
+    # without a process group nothing is exchanged: one variable at a time
+    # (its mean leaves for the host before the next one is laid out)
+    sums = {n: laid_out(n) for n in names} if in_group else {}
     if self.comm is not None and names:
       from weatherbench2_amd import engine
       flat_t = torch.cat([sums[n][0].reshape(-1) for n in names])
@@ -539,8 +550,9 @@ class RunningMean:
     out_vars = {}
     for n in names:
       acc = self._acc[n]
-      total, count = sums[n]
+      total, count = sums[n] if in_group else laid_out(n)
       mean = (total / count).cpu().numpy()  # 0/0 -> NaN like an empty mean
+      del total, count
       if acc.split is not None:
         mean = np.moveaxis(mean, 0, acc.pos)
         if split_labels is not None and not np.array_equal(split_labels,
