@@ -860,6 +860,9 @@ def compact(out: dict) -> dict:
     if 'host_fed' in oc:
       line['api_official_chunk']['host_fed'] = _pick(
           oc['host_fed'], 'value', 'h2d_GBps', 'wall_ms_per_chunk', 'error')
+    if 'host_fed_both_configs' in oc:
+      line['api_official_chunk']['host_fed_both_configs'] = _pick(
+          oc['host_fed_both_configs'], 'value', 'wall_ms_per_chunk', 'error')
     for key in ('deterministic_temporal', 'deterministic_and_temporal'):
       dt = oc.get(key) or {}
       if dt:

@@ -475,6 +475,12 @@ def run(dev, n_chunks: int = 512, pool: int = 32,
       out['host_fed'] = measure_host_fed(chunks, cfg)
     except Exception as e:
       out['host_fed'] = {'error': f'{type(e).__name__}: {e}'}
+    try:  # both configs of the command line from ONE upload of every chunk
+      out['host_fed_both_configs'] = measure_host_fed(
+          chunks, {'deterministic': cfg,
+                   'deterministic_temporal': temporal_config(cfg)})
+    except Exception as e:
+      out['host_fed_both_configs'] = {'error': f'{type(e).__name__}: {e}'}
   out['config'] = {
       'workload': ('official 0.25-degree deterministic chunking: '
                    'init_time=1,lead_time=1 chunks of 13 variables (6 x 13 '

@@ -33,7 +33,7 @@ def build(dev, n_chunks: int, n_lon: int, n_lat: int, pool: int = 8,
           n_lead: int = 4):
   import torch
   import bench
-  from weatherbench2_amd import config, metrics as gm
+  from weatherbench2_amd import metrics as gm
   from weatherbench2_amd import xarray_lite as xl
   lat = np.linspace(-90, 90, n_lat)
   lon = np.linspace(0, 360, n_lon, endpoint=False)
@@ -88,7 +88,7 @@ def main():
   ap.add_argument('--grid', default='240x121')
   args = ap.parse_args()
   import torch
-  from weatherbench2_amd import config, engine, evaluation, program
+  from weatherbench2_amd import config, evaluation, program
   dev = torch.device('cuda:0')
   n_lon, n_lat = (int(x) for x in args.grid.split('x'))
   chunks, metrics, regions, lat, lon = build(dev, args.chunks, n_lon, n_lat)
