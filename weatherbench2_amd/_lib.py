@@ -202,7 +202,9 @@ def ptr(t) -> int:
 
 
 def ptr_array(tensors):
+  """void*[n] of tensors' addresses (None -> NULL; plain ints are taken as
+  addresses: slices of a table the caller keeps alive)."""
   arr = (_vp * len(tensors))()
   for i, t in enumerate(tensors):
-    arr[i] = ptr(t) or None
+    arr[i] = (t if isinstance(t, int) else ptr(t)) or None
   return arr

@@ -1249,7 +1249,7 @@ def _verify_program(prog, forecast, truth_chunk, configs, skipna, sinks):
 # K1 chunking of evaluate_chunks (pinned: the result must not depend on how
 # many chunks share a launch); 32 rows is the measured optimum of launches of
 # 100+ slabs (profiles/r01_rows_per_chunk.md)
-EVALUATE_ROWS_PER_CHUNK = 32
+EVALUATE_ROWS_PER_CHUNK = int(os.environ.get('WB2HIP_EVALUATE_ROWS', '32'))
 
 
 # evaluate_chunks(batch_chunks=None): chunks per window = what holds this many

@@ -174,6 +174,24 @@ def signature(forecast: xl.Dataset, truth: xl.Dataset):
 # ---------------------------------------------------------------------------
 # building
 # ---------------------------------------------------------------------------
+_NO_TABLE = np.zeros(0, dtype=np.int64)
+
+
+def _run_launches(launches, outs, forecast, truth, device, stream) -> None:
+  """One chunk through recorded launches: their address tables in ONE upload
+  (a few hundred integers), then the launches, each on its part."""
+  parts = [la.tables(forecast, truth) for la in launches]
+  sizes = [p.size for p in parts]
+  base = 0
+  if sum(sizes):
+    table = engine.upload_table(np.concatenate(parts), device, cache=False)
+    base = table.data_ptr()
+  off = 0
+  for la, n, out in zip(launches, sizes, outs):
+    la.launch(base + 8 * off, out, stream)
+    off += n
+
+
 class _Launch:
   """One recorded launch, ready to be re-addressed."""
 
@@ -265,12 +283,17 @@ class _Launch:
     return addr
 
 
-  def run(self, forecast, truth, out, stream) -> None:
+  # a chunk's replay: every launch says which addresses it needs (tables), the
+  # program uploads them in ONE table, every launch runs on its part of it
+  def tables(self, forecast, truth) -> np.ndarray:
     addr = self.addresses(forecast, truth)
-    aligned = not (addr & 15).any()
-    dev_addr = engine.upload_table(addr, self.plan.device, cache=False)
-    self.step.aligned = bool(aligned)
-    self.step.run(None, list(dev_addr), metrics=out, stream_ptr=stream)
+    self.step.aligned = not (addr & 15).any()
+    return addr.ravel()
+
+  def launch(self, base: int, out, stream) -> None:
+    step = 8 * self.n_total
+    self.step.run(None, [base + j * step for j in range(self.n_in)],
+                  metrics=out, stream_ptr=stream)
 
 
 def _view_offset(view: torch.Tensor, raw, what: str) -> int:
@@ -331,11 +354,15 @@ class _EnsLaunch:
         ptr(pl.coef_band), ptr(pl.coef_seg), ptr(pl.region_wf),
         ptr(pl.region_wsum), pl.n_region, None]
 
-  def run(self, forecast, truth, out, stream) -> None:
-    lib = self._lib
-    args = self.partials_args
+  def tables(self, forecast, truth) -> np.ndarray:
+    args = self.partials_args   # (base pointers: nothing to upload)
     args[2] = forecast[self.names[0]].data.data_ptr() + self.offsets[0]
     args[4] = truth[self.names[1]].data.data_ptr() + self.offsets[1]
+    return _NO_TABLE
+
+  def launch(self, base: int, out, stream) -> None:
+    lib = self._lib
+    args = self.partials_args
     hook = engine._LAUNCH_HOOK
     if hook is not None:
       hook('begin', 'ens_partials')
@@ -412,15 +439,15 @@ class _EnsFused:
       off += n
     return np.concatenate(out)
 
-  def run(self, forecast, truth, out, stream) -> None:
+  def tables(self, forecast, truth) -> np.ndarray:
     parts_e, parts_t = [], []
     for (fname, tname), (oe, ot), re_, rt_ in zip(self.names, self.bases,
                                                  self.rel_e, self.rel_t):
       parts_e.append(forecast[fname].data.data_ptr() + oe + re_)
       parts_t.append(truth[tname].data.data_ptr() + ot + rt_)
-    table = engine.upload_table(np.concatenate(parts_e + parts_t),
-                                self.plan.device, cache=False)
-    base = table.data_ptr()
+    return np.concatenate(parts_e + parts_t)
+
+  def launch(self, base: int, out, stream) -> None:
     args = self.partials_args
     args[2] = base
     args[3] = base + 8 * self.n_total
@@ -671,8 +698,8 @@ class ChunkProgram:
     if not isinstance(means, (list, tuple)):
       means = [means]
     stream = engine.current_stream_ptr(self.device)
-    for la, out in zip(self.launches, self.slices):
-      la.run(forecast, truth, out, stream)
+    _run_launches(self.launches, self.slices, forecast, truth, self.device,
+                  stream)
     for group, mean in zip(self.groups, means):
       group.accumulate(self.arena, forecast, mean, stream)
 
@@ -737,7 +764,8 @@ def _build(first, forecast, truth, results, means, loop):
     off = 0
     for la in launches:
       if isinstance(la, _EnsFused):
-        la.run(forecast, truth, trial[off:off + la.n_values], stream)
+        _run_launches([la], [trial[off:off + la.n_values]], forecast, truth,
+                      device, stream)
       off += la.n_values
     fused_at = torch.as_tensor(perm, device=device)
     mine = torch.zeros_like(trial, dtype=torch.bool)
