@@ -1370,9 +1370,9 @@ def evaluate_chunks(
     if not window:
       return
     first = window[0][0]
-    time_dim = 'time' if 'time' in first.dims else 'init_time'
+    time_dim = 'time' if first.has_dim('time') else 'init_time'
     lead_dim = _lead_dim(first)
-    lead_dim = lead_dim if lead_dim in first.dims else None
+    lead_dim = lead_dim if first.has_dim(lead_dim) else None
     if not sinks:
       for c in configs:
         if getattr(c, 'temporal_mean', True) is False:
@@ -1680,8 +1680,8 @@ def create_persistence_forecast(forecast, obs):
 
 
 def _lead_dim(forecast: xl.Dataset) -> str:
-  return 'lead_time' if 'lead_time' in forecast.dims or (
-      'lead_time' in forecast.coords) else 'prediction_timedelta'
+  return 'lead_time' if 'lead_time' in forecast.coords or (
+      forecast.has_dim('lead_time')) else 'prediction_timedelta'
 
 
 def _persistence_like_forecast_chunk(forecast_chunk, truth_chunk, truth,

@@ -620,8 +620,11 @@ def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
   return _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest)
 
 
+_LABEL_BYTES: dict = {}  # id(coordinate array) -> (array, content key)
+
+
 def _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest):
-  if 'init_time' in forecast.dims:
+  if forecast.has_dim('init_time'):
     vt = forecast.coords['valid_time']
     if not isinstance(vt, xl.DataArray):
       raise ValueError('valid_time must be a coordinate over (init_time, lead)')
@@ -636,7 +639,15 @@ def _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest):
     if name not in ds.coords:
       return None
     v = _coord_values(ds, name)
-    return (v.dtype.str, v.shape, np.ascontiguousarray(v).tobytes())
+    # coordinate arrays recur (the climatology's always, the chunks' level
+    # array usually): remembered per array OBJECT, kept alive here
+    hit = _LABEL_BYTES.get(id(v))
+    if hit is None or hit[0] is not v:
+      if len(_LABEL_BYTES) >= 64:
+        _LABEL_BYTES.clear()
+      hit = _LABEL_BYTES[id(v)] = (
+          v, (v.dtype.str, v.shape, np.ascontiguousarray(v).tobytes()))
+    return hit[1]
   key = (vt.dtype.str, vt.shape, np.ascontiguousarray(vt).tobytes(), time_dims,
          geo.out_dims, geo.out_shape, crest,
          tuple(cvar.sizes[d] for d in crest),

@@ -133,8 +133,8 @@ def _digest(v: np.ndarray):
 
 def _data_sig(data):
   if isinstance(data, torch.Tensor):
-    return ('t', tuple(data.shape), data.stride(), str(data.dtype),
-            str(data.device), data.data_ptr() % 16)
+    return ('t', data.shape, data.stride(), data.dtype, data.device,
+            data.data_ptr() % 16)
   if isinstance(data, xl.SlabConcat) and data.on_device:
     b = data.bases[0]
     return ('c', tuple(data.shape), len(data.bases), tuple(b.shape),

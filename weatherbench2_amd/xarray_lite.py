@@ -459,6 +459,13 @@ class Dataset:
 
   sizes = dims
 
+  def has_dim(self, name) -> bool:
+    """`name in self.dims` without building the sizes of every variable."""
+    for v in self.data_vars.values():
+      if name in v.dims:
+        return True
+    return False
+
   def __repr__(self):
     return (f'<wb2hip.Dataset vars={list(self.data_vars)} dims={self.dims}>')
 
