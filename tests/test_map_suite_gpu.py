@@ -309,3 +309,57 @@ def test_a_map_config_beside_scalar_configs_in_one_call(monkeypatch):
     for k in both:
       _same(got[k], want[k])
     assert len(calls) >= len(chunks) - 1
+
+
+def test_map_results_without_skipna_keep_no_count_map():
+  """RunningMean over map-valued device results (>= 2^20 elements per lead row)
+  without skipna: every element of a row has the row's number of time steps --
+  no count map is allocated (half of the accumulator state of
+  `deterministic_spatial`), the mean is the sum over the steps / their number,
+  NaNs propagate; with skipna the count map is there as before."""
+  import torch
+  from weatherbench2_amd import evaluation
+  from weatherbench2_amd import xarray_lite as xl
+  dev = torch.device('cuda')
+  g = torch.Generator(device=dev).manual_seed(9)
+  leads = np.array([0, 6], dtype='timedelta64[h]').astype('timedelta64[ns]')
+  dims = ('metric', 'init_time', 'lead_time', 'latitude', 'longitude')
+  n_lat, n_lon = 512, 2048
+  values = torch.randn((1, 3, 2, n_lat, n_lon), generator=g, device=dev)
+  values[0, 1, 0, 7, 9] = float('nan')
+  coords_of = lambda i, sel: {
+      'metric': ['m'], 'init_time': np.array([i]), 'lead_time': leads[sel],
+      'latitude': np.arange(float(n_lat)), 'longitude': np.arange(float(n_lon))}
+  for skipna in (False, True):
+    mean = evaluation.RunningMean('init_time', skipna, dev,
+                                  split_dim='lead_time',
+                                  split_order='first_seen')
+    for i in range(3):
+      for sel in ([1], [0]):   # lead-major inside an init: rows 0 <-> label 1
+        c = coords_of(i, sel)
+        mean.add(xl.Dataset({'z': xl.DataArray(
+            values[:, i:i + 1][:, :, sel].contiguous(), dims, c, 'z')}, c))
+    acc = mean._acc['z']
+    assert (acc._count is None) == (not skipna)
+    got = mean.result()['z']
+    np.testing.assert_array_equal(np.asarray(got.coords['lead_time']),
+                                  leads[[1, 0]])
+    v = values.double().cpu().numpy()[:, :, [1, 0]]
+    with np.errstate(all='ignore'):
+      import warnings
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        want = (np.nanmean if skipna else np.mean)(v, axis=1)
+    # sums continue value by value in time order: the same float64 additions
+    seq = np.zeros_like(want)
+    cnt = np.zeros_like(want)
+    for i in range(3):
+      x = v[:, i]
+      keep = ~np.isnan(x) if skipna else np.ones_like(x, bool)
+      seq += np.where(keep, x, 0.0)
+      cnt += keep
+    with np.errstate(all='ignore'):
+      exact = seq / cnt
+    assert np.array_equal(got.values, exact, equal_nan=True)
+    np.testing.assert_allclose(got.values, want, rtol=1e-12, equal_nan=True)
+    assert np.isnan(got.values[0, 1, 7, 9]) == (not skipna)

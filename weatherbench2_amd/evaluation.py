@@ -233,6 +233,9 @@ def select_truth_at_valid_time(truth, forecast, time_dim: str = 'time',
 _RUN_MIN = 256
 # an accumulator with a split dim starts with at most this many bytes of rows
 _FIRST_ROWS_BYTES = 256 << 20
+# results with this many elements per row or more (maps) keep no count map
+# when NaNs are not skipped (every element has its row's number of steps)
+_LAZY_COUNT_MIN = 1 << 20
 
 
 class _Accumulator:
@@ -240,7 +243,7 @@ class _Accumulator:
   result's shape (minus the averaged dim).  With one: [row, *rest], one row per
   label of the split dim in order of first appearance, the rest dims in order."""
 
-  def __init__(self, dims, shape, split, device):
+  def __init__(self, dims, shape, split, device, lazy_count: bool = False):
     import torch
     self.dims, self.shape, self.split = dims, shape, split
     self.labels: list = []     # label arrays (0-d), row order
@@ -262,7 +265,27 @@ class _Accumulator:
       alloc = (int(max(1, min(8, _FIRST_ROWS_BYTES // max(row_bytes, 1)))),
                ) + self.rest_shape
     self.total = torch.zeros(alloc, dtype=torch.float64, device=device)
-    self.count = torch.zeros_like(self.total)
+    # `lazy_count` (map-valued results without skipna: every element of a row
+    # has the row's number of time steps): no count MAP unless somebody asks
+    # for one -- the steps stay in `pending`, result() divides by them
+    self._count = None if lazy_count else torch.zeros_like(self.total)
+
+  @property
+  def count(self):
+    import torch
+    if self._count is None:
+      self._count = torch.zeros_like(self.total)
+      self.settle()
+    return self._count
+
+  @count.setter
+  def count(self, value):
+    self._count = value
+
+  def steps(self, rows) -> np.ndarray:
+    """Host-side time steps of `rows` (None entries: rows that never came)."""
+    return np.array([0.0 if r is None else float(self.pending.get(r, 0))
+                     for r in rows])
 
   def rows(self, labels: np.ndarray) -> np.ndarray:
     import torch
@@ -281,11 +304,14 @@ class _Accumulator:
     while len(self.labels) > self.total.shape[0]:
       grow = torch.zeros_like(self.total)
       self.total = torch.cat([self.total, grow])
-      self.count = torch.cat([self.count, torch.zeros_like(grow)])
+      if self._count is not None:
+        self._count = torch.cat([self._count, torch.zeros_like(grow)])
     return out
 
   def settle(self):
-    """Brings the host-side step counts into `count`."""
+    """Brings the host-side step counts into `count` (if there is one)."""
+    if self._count is None:
+      return
     for row, steps in self.pending.items():
       if row is None:
         self.count += float(steps)
@@ -404,8 +430,12 @@ class RunningMean:
                                  dtype=torch.float64)
       acc = self._acc.get(name)
       if acc is None:
-        acc = self._acc[name] = _Accumulator(dims, shape if split is None
-                                             else shape, split, self.device)
+        row = int(np.prod(shape, dtype=np.int64)) // (
+            1 if split is None else max(shape[dims.index(split)], 1))
+        lazy = (not self.skipna and self.comm is None and self._on_gpu()
+                and isinstance(raw, torch.Tensor) and row >= _LAZY_COUNT_MIN)
+        acc = self._acc[name] = _Accumulator(dims, shape, split, self.device,
+                                             lazy_count=lazy)
       if acc.pending:
         acc.settle()
       if acc.dims != dims or acc.split != split or (
@@ -430,8 +460,14 @@ class RunningMean:
                           else (acc.destinations(rows), 1))
             hit = acc.dst[key] = (engine.upload_table(table, self.device), run)
           dst, run = hit
-        engine.time_accumulate(values.to(self.device).contiguous(), axis,
-                               self.skipna, acc.total, acc.count, dst, run)
+        if acc._count is None:  # (no count map: the row's steps, on the host)
+          engine.time_accumulate(values.to(self.device).contiguous(), axis,
+                                 False, acc.total, None, dst, run)
+          for r in ([None] if rows is None else rows.tolist()):
+            acc.pending[r] = acc.pending.get(r, 0) + da.shape[axis]
+        else:
+          engine.time_accumulate(values.to(self.device).contiguous(), axis,
+                                 self.skipna, acc.total, acc.count, dst, run)
       else:  # host accumulators (CPU tests of the sharding logic)
         values = values.cpu()
         ok = ~torch.isnan(values) if self.skipna else torch.ones_like(
@@ -508,20 +544,34 @@ class RunningMean:
     # met (lead-major chunk lists) as zeros
     def laid_out(n):
       acc = self._acc[n]
+      # without a count map (and nothing to exchange) the divisor is the
+      # row's number of steps, broadcast
+      lazy = acc._count is None and not in_group
       if acc.split is None:
+        if lazy:
+          return acc.total, torch.as_tensor(acc.steps([None])[0],
+                                            dtype=torch.float64,
+                                            device=acc.total.device)
         return acc.total, acc.count
       rows = [acc.row_of.get(v) for v in labels[n].tolist()]
+      steps = None
+      if lazy:
+        steps = torch.as_tensor(acc.steps(rows), dtype=torch.float64,
+                                device=acc.total.device).reshape(
+                                    (-1,) + (1,) * len(acc.rest_shape))
       if rows == list(range(len(rows))):
         # the rows as they lie (the usual case): views, no copy -- the maps of
         # `deterministic_spatial` are gigabytes per variable
-        return acc.total[:len(rows)], acc.count[:len(rows)]
+        return acc.total[:len(rows)], (
+            steps if lazy else acc.count[:len(rows)])
       pad = acc.total.shape[0]
       idx = torch.as_tensor([pad if r is None else r for r in rows],
                             device=acc.total.device)
       zero = torch.zeros((1,) + acc.rest_shape, dtype=torch.float64,
                          device=acc.total.device)
-      return tuple(torch.cat([x, zero]).index_select(0, idx)
-                   for x in (acc.total, acc.count))
+      picked = [torch.cat([x, zero]).index_select(0, idx)
+                for x in ((acc.total,) if lazy else (acc.total, acc.count))]
+      return (picked[0], steps) if lazy else tuple(picked)
     # without a process group nothing is exchanged: one variable at a time
     # (its mean leaves for the host before the next one is laid out)
     sums = {n: laid_out(n) for n in names} if in_group else {}

@@ -203,7 +203,8 @@ class MapSuite:
       g[0].append(addr[0])
       g[1].append(addr[1])
       g[2].append(np.where(live, acc.total.data_ptr() + 8 * off, 0))
-      g[3].append(np.where(live, acc.count.data_ptr() + 8 * off, 0))
+      g[3].append(np.where(live, acc.count.data_ptr() + 8 * off, 0)
+                  if self.skipna else np.zeros_like(off))
       self._count_steps(acc, rows, sizes[0])
     out = {k: tuple(np.concatenate(x, axis=1) for x in g)
            for k, g in groups.items()}
@@ -303,7 +304,7 @@ class _Plan:
         rows_of[vi] = acc.rows(np.asarray(forecast.coords[acc.split]))
         n_lead = max(n_lead, len(rows_of[vi]))
       total[vi] = acc.total.data_ptr()   # (after rows(): it may have grown)
-      count[vi] = acc.count.data_ptr()
+      count[vi] = acc.count.data_ptr() if suite.skipna else 0
       suite._count_steps(acc, rows_of[vi], key[2])
     rows = np.zeros((n_var, n_lead), dtype=np.int64)
     for vi, r in enumerate(rows_of):
