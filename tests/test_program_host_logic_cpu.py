@@ -139,3 +139,43 @@ def test_fused_ensemble_launches_permute_the_arena_consistently(monkeypatch):
   # nothing to fuse: untouched
   same, none = program._fuse_ensemble_launches([other_a, e2, other_b], 'cpu')
   assert none is None and same == [other_a, e2, other_b]
+
+
+def test_accumulator_without_a_count_map_keeps_the_steps_on_the_host():
+  """`lazy_count`: no count tensor until somebody asks; rows grow without one;
+  the steps per row come back through steps() / materialise into count."""
+  import torch
+  dims = ('metric', 'lead_time', 'latitude', 'longitude')
+  acc = evaluation._Accumulator(dims, (2, 1, 3, 4), 'lead_time', 'cpu',
+                                lazy_count=True)
+  assert acc._count is None
+  rows = acc.rows(np.arange(20))          # more labels than the 8 first rows
+  assert acc._count is None and acc.total.shape[0] >= 20
+  for r in rows[:3].tolist():
+    acc.pending[r] = acc.pending.get(r, 0) + 2
+  acc.pending[1] += 5
+  acc.settle()                             # nothing to settle into
+  assert acc._count is None and acc.pending[1] == 7
+  np.testing.assert_array_equal(acc.steps([1, None, 0, 19]), [7, 0, 2, 0])
+  count = acc.count                        # asked for: built from the steps
+  assert acc._count is count and not acc.pending
+  assert count.shape == acc.total.shape
+  assert torch.equal(count[1], torch.full((2, 3, 4), 7.0, dtype=torch.float64))
+  assert float(count[5].sum()) == 0.0
+  # from here on it behaves like any accumulator
+  acc.pending[5] = 1
+  acc.settle()
+  assert float(acc.count[5, 0, 0, 0]) == 1.0
+  plain = evaluation._Accumulator(dims, (2, 1, 3, 4), 'lead_time', 'cpu')
+  assert plain._count is not None
+
+
+def test_evaluate_chunks_checks_its_configs_before_touching_a_device():
+  from weatherbench2_amd import config, metrics as gm
+  cfg = config.Eval(metrics={'mse': gm.MSE()})
+  import dataclasses
+  other = dataclasses.replace(cfg, evaluate_persistence=True)
+  with pytest.raises(ValueError, match='no eval config'):
+    evaluation.evaluate_chunks([(None, None)], {}, False)
+  with pytest.raises(ValueError, match='baseline switches'):
+    evaluation.evaluate_chunks([(None, None)], {'a': cfg, 'b': other}, False)
