@@ -223,6 +223,44 @@ int wb2_stream_partials_addr(int mode, int dtype, int skipna,
                              const int32_t* seg_eoff, int32_t n_seg,
                              int32_t n_ts, double* partials, void* stream);
 
+/* K1 with the wind-vector pairs of the launch answered from the SAME read as
+ * their per-variable metrics.  The reference forms diff = forecast - truth once
+ * and MSE.compute_chunk derives both the per-variable and the wind-vector
+ * numbers from it (metrics.py:283-301 calling :194-201; scripts/evaluate.py:
+ * 279-311, 420-425); a separate WB2_MODE_WIND launch reads u and v again.
+ *
+ *  mode        WB2_MODE_DET or WB2_MODE_DET_ACC
+ *  in / slab   as wb2_stream_partials_ex; in == NULL: `slab` holds byte
+ *              addresses as in wb2_stream_partials_addr (`aligned16` likewise;
+ *              ignored otherwise)
+ *  n_pair      the LAST 2 * n_pair of the n_outer slabs are the u slabs, then
+ *              the v slabs, of n_pair pairs: pair k = slabs n_outer - 2 n_pair
+ *              + k and n_outer - n_pair + k
+ *  partials    as wb2_stream_partials for all n_outer slabs (the slabs outside
+ *              the pairs go through the per-variable kernel)
+ *  wind_partials DEV double[n_pair][n_chunk][nwf][n_ts][KW], KW =
+ *              wb2_num_slots(WB2_MODE_WIND, skipna): what a WB2_MODE_WIND launch
+ *              over (u, truth u, v, truth v) of the pairs writes, bit for bit
+ *              (fold with wb2_det_combine(WB2_MODE_WIND, ...)).
+ * Every slot -- per-variable and wind -- holds the bits of the separate
+ * launches: same loads, same float32 du^2 + dv^2, same order of additions.
+ * wb2_pairs_supported() says whether the launch geometry has a pair kernel
+ * (rows too narrow for the wide loads have none: launch WB2_MODE_WIND then). */
+int wb2_pairs_supported(int mode, int dtype, int skipna, int has_wfield,
+                        int n_col, int aligned16);
+int wb2_stream_partials_pairs(int mode, int dtype, int skipna,
+                              const void* const* in,
+                              const int64_t* const* slab, int aligned16,
+                              int64_t n_outer, int64_t n_pair, int32_t n_row,
+                              int32_t n_col, const double* w_row,
+                              const double* w_col, const void* wfield,
+                              int wfield_dtype, const int32_t* chunk_row0,
+                              const int32_t* chunk_nrow, int32_t n_chunk,
+                              int32_t n_ctile, const int32_t* seg_col0,
+                              const int32_t* seg_eoff, int32_t n_seg,
+                              int32_t n_ts, double* partials,
+                              double* wind_partials, void* stream);
+
 /*
  * K2: fold the partials into per-region sums and finalise the metrics.
  * Replaces the region loop + concat of evaluation.py:416-430 and the ratio /
@@ -536,6 +574,19 @@ int wb2_det_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
                        int64_t acc_lead, int64_t acc_time, int64_t acc_tail,
                        int acc_skipna, const int64_t* dst, double* sum,
                        double* count, void* stream);
+
+/* wb2_det_suite_step for a launch with wind-vector pairs
+ * (wb2_stream_partials_pairs): K1 over the slabs outside the pairs, the pair
+ * kernel, K2 over all n_outer slabs -> metrics[WB2_NMETRIC][n_region][n_outer],
+ * K2 in mode WIND over the pairs -> wind_metrics[WB2_NMETRIC][n_region][n_pair]
+ * (MSE and RMSE rows meaningful).  No accumulation step: the caller adds the
+ * chunk's values where it wants them (wb2_gather_accumulate). */
+int wb2_det_wind_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
+                            int skipna, const void* const* in,
+                            const int64_t* const* slab, int aligned16,
+                            int64_t n_outer, int64_t n_pair, double* partials,
+                            double* wind_partials, double* metrics,
+                            double* wind_metrics, void* stream);
 
 /* The running temporal mean of a whole chunk result in ONE launch (what
  * TemporalMean / xbeam.Mean does with the Dataset _evaluate_chunk returns,

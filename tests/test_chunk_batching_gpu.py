@@ -59,9 +59,12 @@ def _check_against_oracle(res, want, rtol=1e-9):
 
 @pytest.mark.parametrize('device_resident', [True, False])
 def test_every_variable_of_a_chunk_in_one_launch(device_resident, monkeypatch):
-  """The loop over one chunk: <= 2 K1 launches (deterministic suite + wind
-  vectors) for 6 variables, results bit-identical to one launch per variable
-  under the same chunking, and equal to the oracle's."""
+  """The loop over one chunk: ONE fused pass for 6 variables AND their two
+  wind vectors (wb2_det_wind_suite_step: the u / v pairs are answered from the
+  read of the per-variable metrics, like metrics.py:283-301 derives both from
+  one `diff`; with WB2HIP_WIND_PAIRS=0 a second, MODE_WIND, launch), results
+  bit-identical to one launch per variable and per pair under the same
+  chunking, and equal to the oracle's."""
   from weatherbench2_amd import engine, evaluation, metrics as gm
   forecast, truth, clim, oregions, gf, gt, cfg = _setup(
       device_resident, n_init=2, n_lead=2)
@@ -74,6 +77,13 @@ def test_every_variable_of_a_chunk_in_one_launch(device_resident, monkeypatch):
                                                  compute_chunk=True)
       n_fused = seen.count('stream_partials')
       seen.clear()
+      monkeypatch.setenv('WB2HIP_WIND_PAIRS', '0')
+      gm.clear_caches()
+      unpaired = evaluation._metric_and_region_loop(gf, gt, cfg, False,
+                                                    compute_chunk=True)
+      n_unpaired = seen.count('stream_partials')
+      seen.clear()
+      monkeypatch.delenv('WB2HIP_WIND_PAIRS')
       monkeypatch.setenv('WB2HIP_FUSE_VARIABLES', '0')
       gm.clear_caches()
       single = evaluation._metric_and_region_loop(gf, gt, cfg, False,
@@ -81,12 +91,14 @@ def test_every_variable_of_a_chunk_in_one_launch(device_resident, monkeypatch):
       n_single = seen.count('stream_partials')
     finally:
       engine.set_launch_hook(old)
-  assert n_fused == 2, n_fused
+  assert n_fused == 1, n_fused
+  assert n_unpaired == 2, n_unpaired
   assert n_single == len(oc.VARS_3D) + len(oc.VARS_2D) + len(oc.WIND)
   for name in fused.keys():
-    a, b = fused[name].values, single[name].values
-    assert a.dtype == b.dtype and a.shape == b.shape
-    assert np.array_equal(a, b, equal_nan=True), name
+    for other in (single, unpaired):
+      a, b = fused[name].values, other[name].values
+      assert a.dtype == b.dtype and a.shape == b.shape
+      assert np.array_equal(a, b, equal_nan=True), name
   # against the oracle, chunk values
   from oracle import evaluation_np as oe
   per_chunk = oe.metric_and_region_loop(

@@ -1,0 +1,238 @@
+"""K1p (wb2_stream_partials_pairs / wb2_det_wind_suite_step): the wind-vector
+pairs of a launch answered from the same read as their per-variable metrics.
+
+The reference forms diff = forecast - truth once and derives the per-variable
+MSE and the wind-vector MSE from it
+(/root/reference/weatherbench2/metrics.py:283-301 calling :194-201).  The pair
+kernel must leave the bits of the two separate launches it replaces -- a DET /
+DET_ACC launch over every slab and a WIND launch over the pairs -- and those
+are checked against the NumPy oracle (oracle/metrics_np.py) here as well.
+"""
+import numpy as np
+import pytest
+
+from oracle import metrics_np as om
+from oracle.named import DS, NA
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+  import torch
+  if not torch.cuda.is_available():
+    pytest.fail('-m gpu tests need a HIP device')
+  return torch.device('cuda')
+
+
+def _regions(lat, lon, with_field, seed=5):
+  from weatherbench2_amd import regions as gr
+  from weatherbench2_amd import xarray_lite as xl
+  out = {
+      'global': gr.SliceRegion(),
+      'tropics': gr.SliceRegion(lat_slice=slice(-20, 20)),
+      'extra': gr.SliceRegion(lat_slice=[slice(None, -20), slice(20, None)]),
+      'box': gr.SliceRegion(lat_slice=slice(25, 65),
+                            lon_slice=[slice(300, None), slice(0, 40)]),
+  }
+  if with_field:
+    rs = np.random.RandomState(seed)
+    lsm = np.clip(rs.uniform(-0.5, 1.2, size=(len(lat), len(lon))), 0.0,
+                  1.0).astype(np.float32)
+    mask = xl.DataArray(lsm, ('latitude', 'longitude'),
+                        {'latitude': lat, 'longitude': lon})
+    out['land'] = gr.LandRegion(mask)
+    out['tropics_land'] = gr.CombinedRegion(
+        [gr.SliceRegion(lat_slice=slice(-20, 20)), gr.LandRegion(mask)])
+  return out
+
+
+def _nan_equal(a, b):
+  import torch
+  return a.shape == b.shape and bool(
+      ((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
+
+
+def _separate(engine, _lib, pl, mode, inputs, tables, n_outer, n_pair, skipna):
+  """The two launches the pair kernel replaces."""
+  import torch
+  det, _ = engine.stream_reduce(pl, mode, inputs, tables, n_outer, skipna)
+  first = n_outer - 2 * n_pair
+  u = [tb[first:first + n_pair] for tb in tables[:2]]
+  v = [tb[first + n_pair:] for tb in tables[:2]]
+  wind, _ = engine.stream_reduce(
+      pl, _lib.MODE_WIND, [inputs[0], inputs[1], inputs[0], inputs[1]],
+      [u[0].contiguous(), u[1].contiguous(), v[0].contiguous(),
+       v[1].contiguous()], n_pair, skipna)
+  return det, wind
+
+
+CASES = [
+    # (dtype, acc, skipna, field, layout, n_lat, n_lon, n_single, n_pair, rows)
+    ('float32', True, False, True, 'latlon', 37, 72, 3, 2, 8),
+    ('float32', True, False, False, 'latlon', 37, 72, 0, 3, 8),
+    ('float32', False, False, True, 'latlon', 37, 73, 2, 1, 5),
+    ('float32', True, True, True, 'latlon', 37, 72, 1, 2, 8),
+    ('float32', False, True, False, 'latlon', 19, 36, 4, 4, 3),
+    ('float32', True, False, True, 'lonlat', 37, 72, 2, 2, 8),
+    ('float32', True, False, False, 'lonlat', 37, 72, 0, 1, 7),
+    ('float64', True, False, True, 'latlon', 37, 72, 3, 2, 8),
+    ('float64', True, True, False, 'latlon', 37, 71, 1, 3, 8),
+    ('float64', False, False, True, 'lonlat', 37, 72, 2, 2, 6),
+    # a tile of its own past the row end, many tiles per row
+    ('float32', True, False, True, 'latlon', 13, 700, 1, 2, 4),
+    ('float32', True, True, True, 'latlon', 13, 515, 0, 2, 4),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: '-'.join(map(str, c)))
+def test_pairs_leave_the_bits_of_the_separate_launches(dev, case):
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  dtype, acc, skipna, field, layout, n_lat, n_lon, n_single, n_pair, rows = case
+  tdt = getattr(torch, dtype)
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  pl = plan_lib.build_plan(
+      lat, lon, plan_lib.LATLON if layout == 'latlon' else plan_lib.LONLAT,
+      _regions(lat, lon, field), dev, rows_per_chunk=rows)
+  if not engine.pairs_supported(pl, _lib.MODE_DET_ACC if acc else _lib.MODE_DET,
+                                tdt, skipna):
+    pytest.fail('the geometry of this case has a pair kernel')
+  n_outer = n_single + 2 * n_pair
+  pool = n_outer + 3
+  rs = np.random.RandomState(1000 + CASES.index(case))
+  shape = (pool, pl.n_row, pl.n_col)
+
+  def arr():
+    x = rs.normal(size=shape).astype(dtype)
+    if skipna:
+      x[rs.rand(*shape) < 0.02] = np.nan
+    return torch.as_tensor(x, device=dev)
+  inputs = [arr(), arr()] + ([arr()] if acc else [])
+  tables = [torch.as_tensor(rs.permutation(pool)[:n_outer], dtype=torch.int64,
+                            device=dev) for _ in inputs]
+  mode = _lib.MODE_DET_ACC if acc else _lib.MODE_DET
+  want_det, want_wind = _separate(engine, _lib, pl, mode, inputs, tables,
+                                  n_outer, n_pair, skipna)
+  step = engine.PairSuiteStep(pl, mode, tdt, skipna, n_outer, n_pair)
+  got_det, got_wind = step.run(inputs, tables)
+  assert _nan_equal(got_det, want_det)
+  assert _nan_equal(got_wind[:2], want_wind[:2])   # MSE, RMSE rows
+  # the same through slab ADDRESSES (every slab an allocation of its own)
+  size = pl.n_row * pl.n_col * inputs[0].element_size()
+  addr = [x.data_ptr() + tb * size for x, tb in zip(inputs, tables)]
+  aligned = all(not bool((a % 16).any().item()) for a in addr)
+  step = engine.PairSuiteStep(pl, mode, tdt, skipna, n_outer, n_pair,
+                              aligned=aligned)
+  got_det, got_wind = step.run(None, addr)
+  assert _nan_equal(got_det, want_det)
+  assert _nan_equal(got_wind[:2], want_wind[:2])
+
+
+def test_pairs_match_the_oracle(dev):
+  """u / v of two levels + a surface pair against oracle/metrics_np.py: MSE of
+  every variable and WindVectorMSE of every pair, all regions."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  from oracle import regions_np as oreg
+  n_lat, n_lon = 37, 72
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  regions = _regions(lat, lon, False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev,
+                           rows_per_chunk=8)
+  rs = np.random.RandomState(11)
+  n_pair, n_single = 3, 2
+  n_outer = n_single + 2 * n_pair
+  f = rs.normal(size=(n_outer, n_lat, n_lon)).astype(np.float32)
+  t_ = rs.normal(size=(n_outer, n_lat, n_lon)).astype(np.float32)
+  step = engine.PairSuiteStep(pl, _lib.MODE_DET, torch.float32, False, n_outer,
+                              n_pair)
+  det, wind = step.run([torch.as_tensor(f, device=dev),
+                        torch.as_tensor(t_, device=dev)], [None, None])
+  det, wind = det.cpu().numpy(), wind.cpu().numpy()
+  oregions = {
+      'global': oreg.SliceRegion(),
+      'tropics': oreg.SliceRegion(lat_slice=slice(-20, 20)),
+      'extra': oreg.SliceRegion(lat_slice=[slice(None, -20), slice(20, None)]),
+      'box': oreg.SliceRegion(lat_slice=slice(25, 65),
+                              lon_slice=[slice(300, None), slice(0, 40)]),
+  }
+  dims = ('time', 'latitude', 'longitude')
+  coords = {'time': np.array([np.datetime64('2020-01-01', 'ns')]),
+            'latitude': lat, 'longitude': lon}
+  for ri, rname in enumerate(pl.region_names):
+    for o in range(n_outer):
+      fo = DS({'x': NA(f[o][None], dims)}, coords)
+      to = DS({'x': NA(t_[o][None], dims)}, coords)
+      want = om.MSE().compute_chunk(fo, to, region=oregions[rname])['x'].data
+      helpers.assert_close(det[_lib.METRIC_INDEX['mse'], ri, o], want[0],
+                           rtol=1e-9, err_msg=f'mse {rname} {o}')
+    for k in range(n_pair):
+      iu, iv = n_single + k, n_single + n_pair + k
+      fo = DS({'u': NA(f[iu][None], dims), 'v': NA(f[iv][None], dims)}, coords)
+      to = DS({'u': NA(t_[iu][None], dims), 'v': NA(t_[iv][None], dims)},
+              coords)
+      want = om.WindVectorMSE(u_name='u', v_name='v', vector_name='w'
+                              ).compute_chunk(fo, to, region=oregions[rname])
+      helpers.assert_close(wind[_lib.METRIC_INDEX['mse'], ri, k],
+                           want['w'].data[0], rtol=1e-9,
+                           err_msg=f'wind {rname} {k}')
+
+
+def test_pairs_at_full_size_with_the_official_regions(dev):
+  """721 x 1440 float32, the 13 slice regions + 3 land-mask regions, 32 rows
+  per chunk (evaluate_chunks' geometry), 3 pairs + 2 other slabs, climatology:
+  bits of the separate launches."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  from weatherbench2_amd import regions as gr
+  from weatherbench2_amd import xarray_lite as xl
+  n_lat, n_lon = 721, 1440
+  lat = np.linspace(-90, 90, n_lat)
+  lon = np.linspace(0, 360, n_lon, endpoint=False)
+  regions = helpers.predefined_regions(oracle=False)
+  rs = np.random.RandomState(3)
+  lsm = np.clip(rs.uniform(-0.5, 1.2, size=(n_lat, n_lon)), 0.0, 1.0).astype(
+      np.float32)
+  mask = xl.DataArray(lsm, ('latitude', 'longitude'),
+                      {'latitude': lat, 'longitude': lon})
+  regions['global_land'] = gr.LandRegion(mask)
+  regions['tropics_land'] = gr.CombinedRegion(
+      [gr.SliceRegion(lat_slice=slice(-20, 20)), gr.LandRegion(mask)])
+  regions['extra-tropics_land'] = gr.CombinedRegion(
+      [gr.SliceRegion(lat_slice=[slice(None, -20), slice(20, None)]),
+       gr.LandRegion(mask)])
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev,
+                           rows_per_chunk=32)
+  n_single, n_pair = 2, 3
+  n_outer = n_single + 2 * n_pair
+  gen = torch.Generator(device=dev).manual_seed(7)
+  mk = lambda: torch.randn((n_outer, n_lat, n_lon), dtype=torch.float32,
+                           device=dev, generator=gen)
+  inputs = [mk(), mk(), mk()]
+  tables = [torch.arange(n_outer, dtype=torch.int64, device=dev)
+            for _ in inputs]
+  want_det, want_wind = _separate(engine, _lib, pl, _lib.MODE_DET_ACC, inputs,
+                                  tables, n_outer, n_pair, False)
+  step = engine.PairSuiteStep(pl, _lib.MODE_DET_ACC, torch.float32, False,
+                              n_outer, n_pair)
+  got_det, got_wind = step.run(inputs, tables)
+  assert _nan_equal(got_det, want_det)
+  assert _nan_equal(got_wind[:2], want_wind[:2])
+
+
+def test_rows_too_narrow_have_no_pair_kernel(dev):
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  lat = np.linspace(-90, 90, 5)
+  lon = np.linspace(0, 360, 3, endpoint=False)
+  pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, None, dev,
+                           rows_per_chunk=4)
+  assert not engine.pairs_supported(pl, _lib.MODE_DET, torch.float32, False)
+  step = engine.PairSuiteStep(pl, _lib.MODE_DET, torch.float32, False, 2, 1)
+  x = torch.zeros((2, 5, 3), dtype=torch.float32, device=dev)
+  with pytest.raises(_lib.Wb2HipError, match='no pair kernel'):
+    step.run([x, x], [None, None])

@@ -328,12 +328,22 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
     # suite over all variables, the wind vectors, the SEEPS passes
     total_ms = sum(ms)
     strict = DET_BYTES_PER_CHUNK + SEEPS_BYTES_PER_CHUNK
-    read = strict + WIND_BYTES_PER_CHUNK + SEEPS_REREAD_PER_CHUNK
+    # wind vectors: from the read of the per-variable metrics (the pair
+    # kernel) unless WB2HIP_WIND_PAIRS=0 brings the MODE_WIND launch back
+    paired = os.environ.get('WB2HIP_WIND_PAIRS', '1') != '0'
+    read = strict + (0.0 if paired else WIND_BYTES_PER_CHUNK) + (
+        SEEPS_REREAD_PER_CHUNK)
+    n_pairs = WIND_SLABS_PER_CHUNK * batch
+    det = ('stream_partials_kernel<float,4,DET_ACC,WF> over '
+           f'{(SLABS_PER_CHUNK - 2 * WIND_SLABS_PER_CHUNK) * batch} slabs + '
+           f'stream_pair_kernel<float,4,ACC,WF> over {n_pairs} (u, v) pairs'
+           if paired else
+           'stream_partials_kernel<float,4,DET_ACC,WF> over '
+           f'{SLABS_PER_CHUNK * batch} slabs + <float,4,WIND,WF> over '
+           f'{n_pairs}')
     leg['roofline'] = {
         'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
-        'kernel': 'stream_partials_kernel<float,4,DET_ACC,WF> over '
-                  f'{SLABS_PER_CHUNK * batch} slabs + <float,4,WIND,WF> over '
-                  f'{WIND_SLABS_PER_CHUNK * batch} + 2 x <float,4,SEEPS> over '
+        'kernel': f'{det} + 2 x <float,4,SEEPS> over '
                   f'{batch} per window (K2 inside the brackets)',
         'k1_ms_per_chunk': total_ms / n,
         'algorithmic_bytes_per_chunk': strict,

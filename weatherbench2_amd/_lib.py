@@ -64,6 +64,14 @@ _SIGNATURES = {
         _int, _int, _int, _c.POINTER(_vp), _int, _i64, _i32, _i32,
         _vp, _vp, _vp, _int, _vp, _c.c_double, _vp, _vp, _i32, _i32, _vp, _vp,
         _i32, _i32, _vp, _vp]),
+    'wb2_pairs_supported': (_int, [_int, _int, _int, _int, _int, _int]),
+    'wb2_stream_partials_pairs': (_int, [
+        _int, _int, _int, _c.POINTER(_vp), _c.POINTER(_vp), _int, _i64, _i64,
+        _i32, _i32, _vp, _vp, _vp, _int, _vp, _vp, _i32, _i32, _vp, _vp, _i32,
+        _i32, _vp, _vp, _vp]),
+    'wb2_det_wind_suite_step': (_int, [
+        _c.POINTER(PlanTables), _int, _int, _int, _c.POINTER(_vp),
+        _c.POINTER(_vp), _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'wb2_det_combine': (_int, [
         _int, _int, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp,
         _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -725,6 +725,289 @@ __global__ void __launch_bounds__(512)
 }
 
 // ---------------------------------------------------------------------------
+// K1p: the wind-vector pairs of a launch from the SAME read as their
+// per-variable metrics.
+//
+// The reference forms diff = forecast - truth once; MSE.compute_chunk derives
+// the per-variable numbers AND the wind-vector numbers (du^2 + dv^2, float32)
+// from it (metrics.py:283-301 calling :194-201).  A second K1 launch in mode
+// WIND re-read u and v: 233 MB per 1 067 MB official chunk.  Here the u slab
+// and the v slab of a pair are streamed by the TWO waves of one workgroup, over
+// the same row chunk and column tile: each wave runs the per-variable pass of
+// its slab exactly as stream_partials_kernel does (same loads, same arithmetic,
+// same accumulation order, same fold: the same bits); the u wave hands its
+// float32 d^2 to the v wave through LDS (16 B per lane and row), and the v wave
+// adds its own d^2 in float32 -- metrics.py:195-197 -- and keeps the wind slot
+// the WIND launch kept.  One workgroup barrier per row batch, double-buffered.
+// 13 float64 sums per point live in two waves of 6 and 7: the register budget
+// of the per-variable kernel, with 4 columns per lane and the same halving
+// tree (any narrower tile would change the order of the additions).
+//
+// Slabs: the launch's slab list ends with the u slabs, then the v slabs, of its
+// n_pair pairs (pair k: slabs first + k and first + n_pair + k); wind partials
+// are [n_pair][n_chunk][nwf][n_ts][KW].
+#ifndef WB2_PAIR_U
+#define WB2_PAIR_U WB2_U_ROWS   // rows per batch of the pair kernel
+#endif
+#ifndef WB2_PAIR_WAVES
+#define WB2_PAIR_WAVES 0        // > 0: waves per SIMD the register budget is cut to
+#endif
+#if WB2_PAIR_WAVES > 0
+#define WB2_PAIR_OCCUPANCY \
+  __attribute__((amdgpu_waves_per_eu(WB2_PAIR_WAVES, WB2_PAIR_WAVES)))
+#else
+#define WB2_PAIR_OCCUPANCY
+#endif
+
+struct PairParams {
+  double* wind_partials;
+  long long first;
+  long long n_pair;
+};
+
+template <typename T, int VEC, bool ACC, bool SKIPNA, bool WF,
+          typename FT = double>
+__global__ void __launch_bounds__(128) WB2_PAIR_OCCUPANCY
+    stream_pair_kernel(const StreamParams p, const PairParams pp) {
+  constexpr int MODE = ACC ? WB2_MODE_DET_ACC : WB2_MODE_DET;
+  using M = ModeTraits<MODE, SKIPNA>;
+  using Ops = PointOps<MODE>;
+  using MW = ModeTraits<WB2_MODE_WIND, SKIPNA>;
+  constexpr int NIN = M::NIN, KD = M::K, KW = MW::K, NWF = WF ? 2 : 1;
+  constexpr int U = WB2_PAIR_U;
+  constexpr int TILE = kWave * VEC;
+  constexpr bool PAIRS = WB2_PACK_PAIRS && sizeof(T) == 4 && VEC % 2 == 0;
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  // the u wave's d^2 of a row batch, [buffer][row][lane]
+  __shared__ VT handoff[2][U][kWave];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const unsigned bx = WF ? blockIdx.y : blockIdx.x;
+  const int tile = (int)(bx / (unsigned)p.n_chunk);
+  int chunk = (int)(bx - (unsigned)tile * (unsigned)p.n_chunk);
+  const long long pair = WF ? (long long)blockIdx.z * gridDim.x + blockIdx.x
+                            : (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  if (!WF && WB2_ROTATE_CHUNKS)
+    chunk = (int)(((long long)chunk + pair) % p.n_chunk);
+  const bool live = pair < pp.n_pair;
+  const long long o = pp.first + (live ? pair : 0) + role * pp.n_pair;
+
+  const int row0 = p.chunk_row0[chunk];
+  const int nrow = p.chunk_nrow[chunk];
+  long long slab_idx[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) slab_idx[i] = p.slab[i] ? p.slab[i][o] : o;
+  const int col0 = tile * TILE + lane * VEC;
+  // every lane loads (the loop holds a barrier: it is walked by whole waves);
+  // a lane past the row end reads the row's last VEC columns and its sums are
+  // dropped by the fold (col0 >= n_col is in no seg)
+  const int colb = col0 + VEC > p.n_col ? p.n_col - VEC : col0;
+  if (nrow <= 0 || !live) return;  // both waves of the workgroup alike
+
+  const T* base[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i)
+    base[i] = reinterpret_cast<const T*>(static_cast<const char*>(p.in[i]) +
+                                         slab_idx[i] * p.slab_step_bytes) +
+              (long long)row0 * p.n_col;
+  const FT* wfp = WF ? static_cast<const FT*>(p.wfield) +
+                           (long long)row0 * p.n_col
+                     : nullptr;
+  const double* wrp = p.w_row + row0;
+  auto at = [&](const T* row) {
+    return reinterpret_cast<const WB2_GLOBAL T*>(
+        reinterpret_cast<unsigned long long>(row + colb));
+  };
+  auto at_wf = [&](const FT* row) {
+    return reinterpret_cast<const WB2_GLOBAL FT*>(
+        reinterpret_cast<unsigned long long>(row + colb));
+  };
+
+  // one point's K values into an accumulator set (stream_partials_kernel's
+  // `accumulate`, for the per-variable slots DET = true and the wind slot)
+  auto accumulate = [&](auto& acc, auto is_det, int e, const auto& x,
+                        double wfe, double wr) {
+    constexpr int K = sizeof(x) / sizeof(double);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      acc[0][e][k] = __builtin_fma(wr, x[k], acc[0][e][k]);
+    if constexpr (WF) {
+      const bool inside = wfe > 0.0;
+      const unsigned long long keep = inside ? ~0ull : 0x00000000ffffffffull;
+      const double w2 = wr * wfe;
+      double xs[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (decltype(is_det)::value && k == 1) {
+          xs[1] = __builtin_fabs(xs[0]);
+        } else {
+          xs[k] = __builtin_bit_cast(
+              double, __builtin_bit_cast(unsigned long long, x[k]) & keep);
+        }
+        acc[1][e][k] = __builtin_fma(w2, xs[k], acc[1][e][k]);
+      }
+    }
+  };
+  // The per-variable pass of one row: slots accumulated.  The u wave (WIND =
+  // false) returns its d^2 in `sq`; the v wave (WIND = true) receives the u
+  // wave's there and adds the wind slot of the same point right behind its own
+  // slots (nothing but the loads is live across the barrier).
+  auto consume = [&](auto wind_c, auto& acc, auto& accw,
+                     const T (&v)[NIN][VEC], const double (&wf)[VEC], double wr,
+                     T (&sq)[VEC]) {
+    constexpr bool WIND = decltype(wind_c)::value;
+    auto point = [&](int e, const T (&q)[Ops::NQ]) {
+      double x[KD];
+      Ops::template slots<SKIPNA, T>(q, x);
+      accumulate(acc, std::true_type{}, e, x, wf[e], wr);
+      if constexpr (WIND) {
+        const T qw[1] = {sq[e] + q[1]};  // du^2 + dv^2 in the input dtype
+        double xw[KW];
+        PointOps<WB2_MODE_WIND>::template slots<SKIPNA, T>(qw, xw);
+        accumulate(accw, std::false_type{}, e, xw, wf[e], wr);
+      } else {
+        sq[e] = q[1];
+      }
+    };
+    if constexpr (PAIRS) {
+      typedef T V2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int e = 0; e < VEC; e += 2) {
+        V2 in2[NIN], q2[Ops::NQ];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+          in2[i][0] = v[i][e];
+          in2[i][1] = v[i][e + 1];
+        }
+        Ops::template elementwise<V2>(in2, q2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          T q[Ops::NQ];
+#pragma unroll
+          for (int j = 0; j < Ops::NQ; ++j) q[j] = q2[j][h];
+          point(e + h, q);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T in[NIN], q[Ops::NQ];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) in[i] = v[i][e];
+        Ops::template elementwise<T>(in, q);
+        point(e, q);
+      }
+    }
+  };
+  auto load_row = [&](int r, T (&v)[NIN][VEC], double (&wf)[VEC], double& wr) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+      load_vec<T, VEC>(at(base[i] + (long long)r * p.n_col), v[i]);
+    if constexpr (WF) {
+      load_wf<VEC, FT>(at_wf(wfp + (long long)r * p.n_col), wf);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) wf[e] = 1.0;
+    }
+    wr = wrp[r];
+  };
+
+  double acc[NWF][VEC][KD];
+  double accw[NWF][VEC][KW];
+#pragma unroll
+  for (int w = 0; w < NWF; ++w)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+      for (int k = 0; k < KD; ++k) acc[w][e][k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) accw[w][e][k] = 0.0;
+    }
+
+  // Rows [r, r + n) of the chunk, n <= U, loads in flight together.  The u
+  // wave consumes its batch, stores d^2 and meets the barrier; the v wave meets
+  // the barrier with its loads still in flight, then consumes -- the u wave is
+  // already loading its next batch.  Buffer `it & 1`: the u wave writes it
+  // again two barriers later, after the v wave has read it.
+  auto batch_u = [&](auto n_c, int r, int buf) {
+    constexpr int N = decltype(n_c)::value;
+    T v[N][NIN][VEC];
+    double wf[N][VEC], wr[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) load_row(r + u, v[u], wf[u], wr[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      T sq[VEC];
+      consume(std::false_type{}, acc, accw, v[u], wf[u], wr[u], sq);
+      VT out;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) out[e] = sq[e];
+      handoff[buf][u][lane] = out;
+    }
+    __syncthreads();
+  };
+  auto batch_v = [&](auto n_c, int r, int buf) {
+    constexpr int N = decltype(n_c)::value;
+    T v[N][NIN][VEC];
+    double wf[N][VEC], wr[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) load_row(r + u, v[u], wf[u], wr[u]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const VT theirs = handoff[buf][u][lane];
+      T sq[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sq[e] = theirs[e];
+      consume(std::true_type{}, acc, accw, v[u], wf[u], wr[u], sq);
+    }
+  };
+  int r = 0, it = 0;
+  if (role == 0) {
+#pragma clang loop unroll(disable)
+    for (; r + U <= nrow; r += U, ++it)
+      batch_u(std::integral_constant<int, U>{}, r, it & 1);
+#pragma clang loop unroll(disable)
+    for (; r < nrow; ++r, ++it)
+      batch_u(std::integral_constant<int, 1>{}, r, it & 1);
+  } else {
+#pragma clang loop unroll(disable)
+    for (; r + U <= nrow; r += U, ++it)
+      batch_v(std::integral_constant<int, U>{}, r, it & 1);
+#pragma clang loop unroll(disable)
+    for (; r < nrow; ++r, ++it)
+      batch_v(std::integral_constant<int, 1>{}, r, it & 1);
+  }
+
+  if (p.w_col) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const double wc = p.w_col[colb + e];
+#pragma unroll
+      for (int w = 0; w < NWF; ++w) {
+#pragma unroll
+        for (int k = 0; k < KD; ++k) acc[w][e][k] *= wc;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) accw[w][e][k] *= wc;
+      }
+    }
+  }
+  fold_tile_to_segs<NWF, VEC, KD>(
+      acc, lane, tile, colb, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg,
+      p.n_ts,
+      p.partials + (o * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * KD));
+  if (role == 1)
+    fold_tile_to_segs<NWF, VEC, KW>(
+        accw, lane, tile, colb, col0, p.n_col, p.seg_col0, p.seg_eoff, p.n_seg,
+        p.n_ts,
+        pp.wind_partials +
+            (pair * p.n_chunk + chunk) * (long long)(NWF * p.n_ts * KW));
+}
+
+// ---------------------------------------------------------------------------
 // K2: (chunk, col-tile) partials -> band sums (LDS) -> region sums -> metrics
 // ---------------------------------------------------------------------------
 struct CombineParams {
@@ -1320,6 +1603,143 @@ int stream_partials_impl(int mode, int dtype, int skipna, const void* const* in,
                                        wfield != nullptr, threads, s);
 }
 
+
+// K1p launch: the pairs of a launch (stream_pair_kernel).  `p` is filled as for
+// the per-variable kernel over the same tables (stream_partials_impl).
+template <typename T, int VEC, bool ACC>
+int launch_pairs_flags(const StreamParams& p, const PairParams& pp, bool skipna,
+                       bool wf, hipStream_t stream) {
+  const long long gy = pp.n_pair < 32768 ? pp.n_pair : 32768;
+  const long long gz = (pp.n_pair + gy - 1) / gy;
+  const unsigned per_pair = (unsigned)(p.n_chunk * p.n_ctile);
+  const dim3 grid = wf ? dim3((unsigned)gy, per_pair, (unsigned)gz)
+                       : dim3(per_pair, (unsigned)gy, (unsigned)gz);
+#define WB2_PAIR_LAUNCH(S, W, FT)                                            \
+  hipLaunchKernelGGL((stream_pair_kernel<T, VEC, ACC, S, W, FT>), grid,      \
+                     dim3(2 * kWave), 0, stream, p, pp)
+  if (wf) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (p.wfield_f32) {
+        if (skipna) WB2_PAIR_LAUNCH(true, true, float);
+        else WB2_PAIR_LAUNCH(false, true, float);
+        WB2_HIP_OK(hipGetLastError());
+        return 0;
+      }
+    }
+    if (skipna) WB2_PAIR_LAUNCH(true, true, double);
+    else WB2_PAIR_LAUNCH(false, true, double);
+  } else {
+    if (skipna) WB2_PAIR_LAUNCH(true, false, double);
+    else WB2_PAIR_LAUNCH(false, false, double);
+  }
+#undef WB2_PAIR_LAUNCH
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+bool pairs_supported(int mode, int dtype, bool skipna, bool wf, int n_col,
+                     bool aligned16) {
+  if (mode != WB2_MODE_DET && mode != WB2_MODE_DET_ACC) return false;
+  if (dtype != WB2_F32 && dtype != WB2_F64) return false;
+  // the pair kernel exists at the per-variable kernel's full width only (its
+  // partials share the tile geometry with the per-variable and WIND passes)
+  const int w = dtype == WB2_F32 ? 4 : 2;
+  return vec_width(mode, dtype, skipna, wf, n_col, aligned16) == w &&
+         vec_width(WB2_MODE_WIND, dtype, skipna, wf, n_col, aligned16) == w;
+}
+
+int stream_pairs_impl(int mode, int dtype, int skipna, const void* const* in,
+                      const int64_t* const* slab, int addr_aligned16,
+                      int64_t n_outer, int64_t n_pair, int32_t n_row,
+                      int32_t n_col, const double* w_row, const double* w_col,
+                      const void* wfield, int wfield_dtype,
+                      const int32_t* chunk_row0, const int32_t* chunk_nrow,
+                      int32_t n_chunk, int32_t n_ctile, const int32_t* seg_col0,
+                      const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
+                      double* partials, double* wind_partials, void* stream) {
+  WB2_REQUIRE(n_pair >= 0 && 2 * n_pair <= n_outer,
+              "n_pair=%lld does not fit n_outer=%lld", (long long)n_pair,
+              (long long)n_outer);
+  const int64_t n_single = n_outer - 2 * n_pair;
+  // the slabs outside the pairs: the per-variable kernel, as ever
+  int rc = stream_partials_impl(mode, dtype, skipna, in, slab, addr_aligned16,
+                                n_single, n_row, n_col, w_row, w_col, wfield,
+                                wfield_dtype, nullptr, 0.0, chunk_row0,
+                                chunk_nrow, n_chunk, n_ctile, seg_col0, seg_eoff,
+                                n_seg, n_ts, partials, stream);
+  if (rc != 0 || n_pair == 0) return rc;
+  WB2_REQUIRE(mode == WB2_MODE_DET || mode == WB2_MODE_DET_ACC,
+              "wind-vector pairs ride on WB2_MODE_DET / WB2_MODE_DET_ACC "
+              "(mode=%d)", mode);
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_REQUIRE((in || slab) && w_row && chunk_row0 && chunk_nrow && seg_col0 &&
+                  seg_eoff && partials && wind_partials,
+              "null pointer argument");
+  WB2_REQUIRE(n_row > 0 && n_col > 0 && n_chunk > 0 && n_chunk % 8 == 0 &&
+                  n_seg > 0 && n_outer < (1ll << 31),
+              "bad sizes");
+  const bool by_addr = in == nullptr;
+  const int nin = mode_nin(mode);
+  const long long elem = dtype == WB2_F32 ? 4 : 8;
+  bool aligned = by_addr ? addr_aligned16 != 0 : true;
+  StreamParams p{};
+  for (int i = 0; i < nin; ++i) {
+    if (by_addr) {
+      WB2_REQUIRE(slab[i] != nullptr, "address table %d is null", i);
+      p.slab[i] = reinterpret_cast<const long long*>(slab[i]);
+      continue;
+    }
+    WB2_REQUIRE(in[i] != nullptr, "input %d is null", i);
+    p.in[i] = in[i];
+    p.slab[i] = slab ? reinterpret_cast<const long long*>(slab[i]) : nullptr;
+    aligned = aligned && (reinterpret_cast<uintptr_t>(in[i]) % 16 == 0);
+  }
+  if (wfield) aligned = aligned && reinterpret_cast<uintptr_t>(wfield) % 16 == 0;
+  WB2_REQUIRE(pairs_supported(mode, dtype, skipna != 0, wfield != nullptr, n_col,
+                              aligned),
+              "no pair kernel for this launch (n_col=%d too narrow for the "
+              "wide loads): ask wb2_pairs_supported first", n_col);
+  const int vec = dtype == WB2_F32 ? 4 : 2;
+  p.slab_step_bytes = by_addr ? 1 : (long long)n_row * n_col * elem;
+  p.w_row = w_row;
+  p.w_col = w_col;
+  p.wfield = wfield;
+  p.wfield_f32 = wfield && wfield_dtype == WB2_F32;
+  WB2_REQUIRE(!wfield || wfield_dtype == WB2_F64 ||
+                  (wfield_dtype == WB2_F32 && dtype == WB2_F32),
+              "a float32 weight field goes with float32 inputs");
+  p.chunk_row0 = chunk_row0;
+  p.chunk_nrow = chunk_nrow;
+  p.seg_col0 = seg_col0;
+  p.seg_eoff = seg_eoff;
+  p.n_ts = n_ts;
+  p.partials = partials;
+  p.n_outer = n_outer;
+  p.n_row = n_row;
+  p.n_col = n_col;
+  p.n_chunk = n_chunk;
+  p.n_ctile = (n_col + kWave * vec - 1) / (kWave * vec);
+  WB2_REQUIRE(p.n_ctile == n_ctile,
+              "n_ctile=%d does not match the launch geometry (%d)", n_ctile,
+              p.n_ctile);
+  p.n_seg = n_seg;
+  PairParams pp{};
+  pp.wind_partials = wind_partials;
+  pp.first = n_single;
+  pp.n_pair = n_pair;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool acc = mode == WB2_MODE_DET_ACC;
+  if (dtype == WB2_F32)
+    return acc ? launch_pairs_flags<float, 4, true>(p, pp, skipna != 0,
+                                                    wfield != nullptr, s)
+               : launch_pairs_flags<float, 4, false>(p, pp, skipna != 0,
+                                                     wfield != nullptr, s);
+  return acc ? launch_pairs_flags<double, 2, true>(p, pp, skipna != 0,
+                                                   wfield != nullptr, s)
+             : launch_pairs_flags<double, 2, false>(p, pp, skipna != 0,
+                                                    wfield != nullptr, s);
+}
+
 }  // namespace
 }  // namespace wb2
 
@@ -1408,6 +1828,37 @@ int wb2_stream_partials_addr(int mode, int dtype, int skipna,
                               chunk_nrow,
                               n_chunk, n_ctile, seg_col0, seg_eoff, n_seg, n_ts,
                               partials, stream);
+}
+
+int wb2_pairs_supported(int mode, int dtype, int skipna, int has_wfield,
+                        int n_col, int aligned16) {
+  return wb2::pairs_supported(mode, dtype, skipna != 0, has_wfield != 0, n_col,
+                              aligned16 != 0)
+             ? 1
+             : 0;
+}
+
+int wb2_stream_partials_pairs(int mode, int dtype, int skipna,
+                              const void* const* in,
+                              const int64_t* const* slab, int aligned16,
+                              int64_t n_outer, int64_t n_pair, int32_t n_row,
+                              int32_t n_col, const double* w_row,
+                              const double* w_col, const void* wfield,
+                              int wfield_dtype, const int32_t* chunk_row0,
+                              const int32_t* chunk_nrow, int32_t n_chunk,
+                              int32_t n_ctile, const int32_t* seg_col0,
+                              const int32_t* seg_eoff, int32_t n_seg,
+                              int32_t n_ts, double* partials,
+                              double* wind_partials, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_EMPTY_OK(n_outer);
+  WB2_REQUIRE(in != nullptr || slab != nullptr, "null pointer argument");
+  return stream_pairs_impl(mode, dtype, skipna, in, slab, aligned16, n_outer,
+                           n_pair, n_row, n_col, w_row, w_col, wfield,
+                           wfield_dtype, chunk_row0, chunk_nrow, n_chunk,
+                           n_ctile, seg_col0, seg_eoff, n_seg, n_ts, partials,
+                           wind_partials, stream);
 }
 
 int wb2_det_combine(int mode, int skipna, const double* partials,
@@ -1614,6 +2065,40 @@ int wb2_det_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
   return wb2_time_accumulate_scatter(WB2_F64, metrics, acc_lead, acc_time,
                                      acc_tail, acc_skipna, dst, sum, count,
                                      stream);
+}
+
+int wb2_det_wind_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
+                            int skipna, const void* const* in,
+                            const int64_t* const* slab, int aligned16,
+                            int64_t n_outer, int64_t n_pair, double* partials,
+                            double* wind_partials, double* metrics,
+                            double* wind_metrics, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(plan != nullptr, "null plan");
+  WB2_EMPTY_OK(n_outer);
+  WB2_REQUIRE(in != nullptr || slab != nullptr, "null pointer argument");
+  WB2_REQUIRE(metrics != nullptr && (n_pair == 0 || wind_metrics != nullptr),
+              "metrics is null");
+  const wb2_plan_tables& t = *plan;
+  int rc = stream_pairs_impl(mode, dtype, skipna, in, slab, aligned16, n_outer,
+                             n_pair, t.n_row, t.n_col, t.w_row, t.w_col,
+                             t.wfield, t.wfield_dtype, t.chunk_row0,
+                             t.chunk_nrow, t.n_chunk, t.n_ctile, t.seg_col0,
+                             t.seg_eoff, t.n_seg, t.n_ts, partials,
+                             wind_partials, stream);
+  if (rc != 0) return rc;
+  const int nwf = t.wfield ? 2 : 1;
+  rc = wb2_det_combine(mode, skipna, partials, n_outer, t.n_chunk, nwf, t.n_seg,
+                       t.seg_eoff, t.n_ts, t.band_chunk0, t.n_band, t.coef_band,
+                       t.coef_seg, t.region_wf, t.region_wsum, t.n_region,
+                       nullptr, metrics, stream);
+  if (rc != 0 || n_pair == 0) return rc;
+  return wb2_det_combine(WB2_MODE_WIND, skipna, wind_partials, n_pair,
+                         t.n_chunk, nwf, t.n_seg, t.seg_eoff, t.n_ts,
+                         t.band_chunk0, t.n_band, t.coef_band, t.coef_seg,
+                         t.region_wf, t.region_wsum, t.n_region, nullptr,
+                         wind_metrics, stream);
 }
 
 int wb2_gather_accumulate(const double* arena, const int32_t* src,

@@ -358,6 +358,124 @@ def _stream_launch(plan, mode, dtype, n_outer, skipna, want_sums, aux, scalar,
   return metrics, sums
 
 
+def _suite_field(plan, dtype, mode):
+  """(weight field, its dtype code) of a deterministic launch: float32 where
+  the field's values are float32 numbers and the launch has the instantiation
+  (same bits, half the field bytes per point)."""
+  field, field_code = plan.wfield, _lib.WB2_F64
+  if (dtype == torch.float32 and mode in _FIELD_F32_MODES and
+      getattr(plan, 'wfield32', None) is not None and
+      os.environ.get('WB2HIP_FIELD_F32', '1') != '0'):
+    field, field_code = plan.wfield32, _lib.WB2_F32
+  return field, field_code
+
+
+def pairs_supported(plan: ReductionPlan, mode: int, dtype: torch.dtype,
+                    skipna: bool, aligned: bool = True) -> bool:
+  """Whether a launch of `mode` over `plan` can answer wind-vector pairs from
+  its own read (wb2_pairs_supported; WB2HIP_WIND_PAIRS=0 switches the pair
+  kernel off for A/B runs: the pairs then take a WB2_MODE_WIND launch)."""
+  if os.environ.get('WB2HIP_WIND_PAIRS', '1') == '0' or dtype not in _DTYPES:
+    return False
+  field, _ = _suite_field(plan, dtype, mode)
+  aligned = aligned and (field is None or field.data_ptr() % 16 == 0)
+  return bool(_lib.load().wb2_pairs_supported(
+      mode, _DTYPES[dtype], int(skipna), int(plan.wfield is not None),
+      plan.n_col, int(aligned)))
+
+
+def stream_reduce_pairs(plan: ReductionPlan, mode: int, dtype: torch.dtype,
+                        addr: t.Sequence[torch.Tensor], aligned16: bool,
+                        n_outer: int, n_pair: int, skipna: bool):
+  """K1 + K1p + K2 over slabs given by address, the last 2 * n_pair of them the
+  u slabs then the v slabs of n_pair wind-vector pairs: returns
+  (metrics[NMETRIC, n_region, n_outer], wind[NMETRIC, n_region, n_pair]) --
+  the bits of stream_reduce_addr over the slabs plus a MODE_WIND pass over the
+  pairs, from one read (wb2_det_wind_suite_step)."""
+  for a in addr:
+    if (a.dtype != torch.int64 or a.device != plan.device or
+        a.numel() != n_outer or not a.is_contiguous()):
+      raise ValueError('address tables are contiguous int64[n_outer] on the '
+                       'plan device')
+  step = PairSuiteStep(plan, mode, dtype, skipna, n_outer, n_pair,
+                       aligned=bool(aligned16))
+  return step.run(None, list(addr))
+
+
+class PairSuiteStep:
+  """The deterministic suite over a launch whose last 2 * n_pair slabs are the
+  u slabs, then the v slabs, of n_pair wind-vector pairs: per-variable metrics
+  of all n_outer slabs AND the wind-vector metrics of the pairs from ONE read
+  (wb2_det_wind_suite_step; metrics.py:283-301 calling :194-201 derive both
+  from the same `diff`).  Bit-identical to a DET / DET_ACC launch over the
+  slabs plus a WIND launch over the pairs.
+
+  Prepared once per (plan, mode, dtype, skipna, n_outer, n_pair); `run` takes
+  inputs + slab-number tables, or inputs=None + address tables, and returns
+  (metrics[NMETRIC, n_region, n_outer], wind[NMETRIC, n_region, n_pair])."""
+
+  def __init__(self, plan: ReductionPlan, mode: int, dtype: torch.dtype,
+               skipna: bool, n_outer: int, n_pair: int, aligned: bool = True):
+    import ctypes
+    lib = _lib.load()
+    if dtype not in _DTYPES:
+      raise TypeError(f'unsupported dtype {dtype}')
+    if mode not in (_lib.MODE_DET, _lib.MODE_DET_ACC):
+      raise ValueError('wind-vector pairs ride on MODE_DET / MODE_DET_ACC')
+    if not 0 <= 2 * n_pair <= n_outer:
+      raise ValueError(f'{n_pair=} does not fit {n_outer=}')
+    self.lib, self.plan, self.mode, self.skipna = lib, plan, mode, bool(skipna)
+    self.code, self.n_outer, self.n_pair = _DTYPES[dtype], int(n_outer), int(
+        n_pair)
+    self.aligned = bool(aligned)
+    dev = plan.device
+    field, field_code = _suite_field(plan, dtype, mode)
+    aligned = aligned and (field is None or field.data_ptr() % 16 == 0)
+    tile = lib.wb2_tile_cols_ex(mode, self.code, int(skipna),
+                                int(plan.wfield is not None), plan.n_col,
+                                int(aligned))
+    self.tables, self._keep = plan_tables(plan, tile, field, field_code)
+    n_ts = self._keep[3]
+    k = lib.wb2_num_slots(mode, int(skipna))
+    kw = lib.wb2_num_slots(_lib.MODE_WIND, int(skipna))
+    self.partials = torch.empty((n_outer, plan.n_chunk, plan.nwf, n_ts, k),
+                                dtype=torch.float64, device=dev)
+    self.wind_partials = torch.empty(
+        (max(n_pair, 1), plan.n_chunk, plan.nwf, n_ts, kw),
+        dtype=torch.float64, device=dev)
+    self._tables_ref = ctypes.byref(self.tables)
+    self._fn = lib.wb2_det_wind_suite_step
+    self.n_metric = _lib.NMETRIC
+    self.n_values = _lib.NMETRIC * plan.n_region * (self.n_outer + self.n_pair)
+
+  def run(self, inputs, tables, out: t.Optional[torch.Tensor] = None,
+          stream_ptr: t.Optional[int] = None):
+    """`out` (optional): flat float64[n_values] that receives the per-variable
+    block followed by the wind block."""
+    dev = self.plan.device
+    if out is None:
+      out = torch.empty((self.n_values,), dtype=torch.float64, device=dev)
+    n_det = _lib.NMETRIC * self.plan.n_region * self.n_outer
+    hook = _LAUNCH_HOOK
+    if hook is not None:
+      hook('begin', 'stream_partials')
+    status = self._fn(
+        self._tables_ref, self.mode, self.code, int(self.skipna),
+        None if inputs is None else _lib.ptr_array(inputs),
+        _lib.ptr_array(tables), int(self.aligned), self.n_outer, self.n_pair,
+        self.partials.data_ptr(), self.wind_partials.data_ptr(),
+        out.data_ptr(), out.data_ptr() + 8 * n_det,
+        current_stream_ptr(dev) if stream_ptr is None else stream_ptr)
+    if hook is not None:
+      hook('end', 'stream_partials')
+    if status != 0:
+      _lib.check(status, 'wb2_det_wind_suite_step')
+    flat = out.view(-1)
+    return (flat[:n_det].view(_lib.NMETRIC, self.plan.n_region, self.n_outer),
+            flat[n_det:n_det + _lib.NMETRIC * self.plan.n_region * self.n_pair]
+            .view(_lib.NMETRIC, self.plan.n_region, self.n_pair))
+
+
 class SuiteStep:
   """One chunk of the deterministic suite per call: K1 -> K2 -> the running
   temporal mean through wb2_det_suite_step -- ONE C-ABI call per chunk instead
@@ -637,7 +755,7 @@ def energy_score(plan: ReductionPlan, ens: torch.Tensor, member_stride: int,
   # (a non-contiguous `ens` is a view with intact slabs that the caller
   # addresses through member_stride + ens_slab: metrics._ens_layout)
   if ens.device != dev or truth.device != dev or not truth.is_contiguous() or (
-      not ens.is_contiguous() and ens_slab is None and member_ptrs is None):
+      not ens.is_contiguous() and ens_slab is None):
     raise ValueError('inputs must be contiguous on the plan device')
   for s in (ens_slab, truth_slab):
     if s is not None and (s.dtype != torch.int64 or s.numel() != n_outer):

@@ -882,6 +882,10 @@ def _prefetched(chunks, lo: int, hi: int, depth, stage=None):
     finally:
       for fut in pending:
         fut.cancel()
+      if stage is not None:
+        # the fetch thread's uploader (pinned ring, copy threads) goes with it
+        from weatherbench2_amd import feeder
+        pool.submit(feeder.close_thread_uploaders).result()
 
 
 # host arrays below this size are left to the metrics (coordinates, scalars)
@@ -1207,7 +1211,11 @@ def _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks,
   from weatherbench2_amd import map_suite, metrics as gm, program
   how = program.mode()
   sig = None
-  if how != '0' and all(s._on_gpu_or_unset() for s in sinks):
+  # Derived variables are computed on (and assigned into) every chunk by the
+  # loop itself (evaluation.py:402-405): a replay would look for them in a
+  # chunk that does not have them yet -- such configs keep the generic path.
+  derived = any(c.derived_variables for c in configs)
+  if how != '0' and not derived and all(s._on_gpu_or_unset() for s in sinks):
     sig = program.signature(forecast, truth_chunk)
   prog = programs.get(sig) if sig is not None else False
   if prog:
@@ -1220,9 +1228,17 @@ def _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks,
   def loop(which=None):
     which = range(len(configs)) if which is None else which
     with gm.chunk_scope():  # one scope: the configs share the passes
-      return [_metric_and_region_loop(forecast, truth_chunk, configs[i],
-                                      skipna, compute_chunk=True)
-              for i in which]
+      out = []
+      for i in which:
+        f, t_ = forecast, truth_chunk
+        if derived and len(configs) > 1:
+          # every pipeline branch of the reference reads the chunk itself
+          # (evaluation.py:757-828): one config's derived variables must not
+          # show up in the next config's inputs
+          f, t_ = xl.as_dataset(f).copy(), xl.as_dataset(t_).copy()
+        out.append(_metric_and_region_loop(f, t_, configs[i], skipna,
+                                           compute_chunk=True))
+      return out
   if prog is False:      # not replayable (or programs are off)
     for sink, result in zip(sinks, loop()):
       sink.add(result)

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import threading
 import typing as t
+import weakref
 
 import numpy as np
 import torch
@@ -46,9 +47,35 @@ def copy_threads() -> int:
   return int(min(8, max(2, (os.cpu_count() or 8) // 2)))
 
 
+class _Ring(dict):
+  """One uploader (pinned ring + copy pool, csrc/staging.cpp) + its copy
+  stream.  The native side is destroyed with the object: the thread-local
+  table below dies with its thread (evaluate_chunks starts a fetch thread per
+  call), and an uploader that outlived it would keep its pinned slots (4 x 32
+  MiB), its copy threads, events and stream for the life of the process."""
+
+  def __init__(self, lib, handle, stream):
+    super().__init__(uploader=handle, lib=lib, stream=stream)
+    self._finalizer = weakref.finalize(self, _Ring._destroy, lib, handle.value)
+
+  @staticmethod
+  def _destroy(lib, handle):
+    try:
+      lib.wb2_uploader_destroy(handle)  # waits for the DMAs out of its slots
+    except Exception:  # interpreter shutdown: the process frees it anyway
+      pass
+
+  def close(self):
+    self._finalizer()
+
+
+UPLOADERS_ALIVE = lambda: sum(1 for r in _RINGS if r() is not None
+                              and r()._finalizer.alive)
+_RINGS: list = []   # weak references (diagnostics, tests)
+
+
 class _Staging(threading.local):
-  """Per-thread uploader (pinned ring + copy pool in libwb2hip.so,
-  csrc/staging.cpp) and copy stream per device."""
+  """Per-thread uploader and copy stream per device."""
 
   def __init__(self):
     self.rings: dict = {}
@@ -65,10 +92,22 @@ class _Staging(threading.local):
         _lib.check(lib.wb2_uploader_create(copy_threads(), _SLICE_BYTES,
                                            _RING_SLOTS, ctypes.byref(handle)),
                    'wb2_uploader_create')
-      ring = {'uploader': handle, 'lib': lib,
-              'stream': torch.cuda.Stream(device=device)}
+      ring = _Ring(lib, handle, torch.cuda.Stream(device=device))
       self.rings[key] = ring
+      _RINGS[:] = [r for r in _RINGS if r() is not None] + [weakref.ref(ring)]
     return ring
+
+  def close(self):
+    """Destroys the calling thread's uploaders now (a thread that is about to
+    exit; otherwise the finalizers do it when the thread's table is
+    collected)."""
+    for ring in self.rings.values():
+      ring.close()
+    self.rings.clear()
+
+
+def close_thread_uploaders() -> None:
+  _STAGING.close()
 
 
 _STAGING = _Staging()

@@ -840,13 +840,21 @@ def _resident_aux(aux, device) -> torch.Tensor:
   return ten
 
 
-def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
+def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0,
+               pairs=None, wind_out=None):
   """One fused pass (K1 + K2) per launch signature over the variables in
   `entries` = [(geo, arrays, tables)]: variables that share grid, layout and
   dtype -- every variable of an ERA5-style chunk -- are read by ONE launch
   whose slabs are addressed one by one (wb2_stream_partials_addr); the fold is
   per slab, so every variable's numbers are those of a launch of its own.
   Returns the list of {region_key: metrics[NMETRIC, ...]} dicts, in order.
+
+  `pairs` = [(i_u, i_v)]: entries that are the u and v of a wind-vector metric
+  (same output dims).  Where the launch has a pair kernel their wind-vector
+  numbers come from the same read (wb2_det_wind_suite_step: the reference
+  derives them from the same `diff`, metrics.py:283-301) and are filed in
+  `wind_out[(i_u, i_v)]` as {region_key: metrics[NMETRIC, ...]}; pairs the
+  launch cannot take are simply not filed (the caller runs MODE_WIND for them).
 
   Nothing here waits for the GPU: results stay on the device (tiny fp64
   tensors), `.values` of the returned DataArrays is where the copy (and the
@@ -873,10 +881,29 @@ def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
     lazy = any(isinstance(x, xl.SlabConcat)
                for i in members for x in prepped[i][0])
     rec = program.recorder()
+    # wind-vector pairs inside this launch: their slabs go last (u slabs,
+    # then v slabs), where the pair kernel expects them
+    group_pairs, n_pair, wind = [], 0, None
+    if pairs and mode in (_lib.MODE_DET, _lib.MODE_DET_ACC) and (
+        engine.pairs_supported(pl, mode, prepped[members[0]][2], skipna)):
+      taken: set = set()
+      for a, b in pairs:
+        if a in members and b in members and a != b and not (
+            {a, b} & taken) and (entries[a][0].out_shape ==
+                                 entries[b][0].out_shape):
+          group_pairs.append((a, b))
+          taken |= {a, b}
+      if group_pairs:
+        members = ([i for i in members if i not in taken] +
+                   [a for a, _ in group_pairs] + [b for _, b in group_pairs])
+        n_pair = sum(entries[a][0].n_outer for a, _ in group_pairs)
     if rec is not None and rec.probe:
       # program.py's probe pass: no launch, index-valued results
       metrics = rec.fake_metrics(_lib.GENERIC_KQ.get(mode, _lib.NMETRIC),
                                  pl.n_region, n_total, device)
+      if n_pair:
+        wind = rec.fake_metrics(_lib.NMETRIC, pl.n_region, n_pair, device,
+                                extend=True)
     elif len(members) == 1 and not lazy:
       # one variable in one allocation: slab NUMBERS (wb2_stream_partials_ex)
       i = members[0]
@@ -901,16 +928,39 @@ def _run_group(mode, entries, region, skipna, aux=None, scalar=0.0):
         off += n
       aligned = not (addr % 16).any()
       dev_addr = engine.upload_table(addr, device)
-      metrics, _ = engine.stream_reduce_addr(
-          pl, mode, prepped[members[0]][2], list(dev_addr), aligned, n_total,
-          skipna, aux=aux, scalar=scalar)
+      if n_pair:
+        metrics, wind = engine.stream_reduce_pairs(
+            pl, mode, prepped[members[0]][2], list(dev_addr), aligned, n_total,
+            n_pair, skipna)
+      else:
+        metrics, _ = engine.stream_reduce_addr(
+            pl, mode, prepped[members[0]][2], list(dev_addr), aligned, n_total,
+            skipna, aux=aux, scalar=scalar)
       del keep  # the launch is enqueued: the allocator orders any reuse after it
     if rec is not None and not rec.probe:
       rec.record(plan=pl, mode=mode, dtype=prepped[members[0]][2],
                  n_total=n_total, skipna=bool(skipna), aux=aux, scalar=scalar,
                  members=[(entries[i][0], list(entries[i][1]),
                            list(prepped[i][1]), list(prepped[i][0]))
-                          for i in members], metrics=metrics)
+                          for i in members], metrics=metrics, n_pair=n_pair,
+                 wind_metrics=wind)
+    if n_pair and wind_out is not None:
+      wcasts = {wind.dtype: wind}
+
+      def wview(dtype, off, n, shape, wcasts=wcasts, wind=wind):
+        if dtype not in wcasts:
+          wcasts[dtype] = wind.to(dtype)
+        return wcasts[dtype][:, :, off:off + n].reshape(shape)
+      woff = 0
+      for a, b in group_pairs:
+        geo = entries[a][0]
+        n = geo.n_outer
+        shape = (wind.shape[0], pl.n_region) + geo.out_shape
+        wind_out[(a, b)] = _ByRegion(
+            wview(wind.dtype, woff, n, shape), pl.region_names,
+            lambda dtype, off=woff, n=n, shape=shape, view=wview: view(
+                dtype, off, n, shape))
+        woff += n
     casts = {metrics.dtype: metrics}
 
     def view(dtype, off, n, shape, casts=casts, metrics=metrics):
@@ -1056,8 +1106,25 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
   for n, pl in plans.items():
     by_mode.setdefault(pl[3], []).append(n)
   for mode, names in by_mode.items():
+    # the announced wind-vector pairs whose u and v are both in this launch:
+    # their numbers come from the same read (metrics.py:283-301)
+    wind_plans, wind_out = {}, {}
+    if _fuse_variables() and _ANNOUNCED.wind:
+      for u, v in _ANNOUNCED.wind[-1]:
+        if u in names and v in names and u != v:
+          try:
+            if _RESULTS.get(_wind_key(forecast, truth, u, v, region, skipna)):
+              continue
+            wplan = _wind_plan(forecast, truth, u, v)
+          except _INPUT_ERRORS:
+            continue
+          if all(plans[k][0].layout == wplan[0].layout and
+                 plans[k][0].out_dims == wplan[0].out_dims and
+                 plans[k][0].out_shape == wplan[0].out_shape for k in (u, v)):
+            wind_plans[(names.index(u), names.index(v))] = (u, v, wplan)
     try:
-      results = _run_group(mode, [plans[n][:3] for n in names], region, skipna)
+      results = _run_group(mode, [plans[n][:3] for n in names], region, skipna,
+                           pairs=list(wind_plans), wind_out=wind_out)
     except _INPUT_ERRORS as e:
       if len(names) == 1 and names[0] == name:
         raise
@@ -1070,10 +1137,15 @@ def _det_pass(forecast, truth, name, region, skipna, climatology=None):
       if not names:
         continue
       results = _run_group(mode, [plans[name][:3]], region, skipna)
+      wind_out = {}
     for n, by_region in zip(names, results):
       geo, _, _, _, pins, clim = plans[n]
       _RESULTS.put(_det_key(forecast, truth, n, region, skipna), pins,
                    {'geo': geo, 'by_region': by_region, 'clim': clim})
+    for idx, by_region in wind_out.items():
+      u, v, wplan = wind_plans[idx]
+      _RESULTS.put(_wind_key(forecast, truth, u, v, region, skipna), wplan[3],
+                   (wplan[0], by_region))
   hit = _RESULTS.get(key)
   return hit['geo'], hit['by_region']
 
@@ -1596,6 +1668,18 @@ def _get_n_ensemble(ds: xl.Dataset, ensemble_dim: str,
   return n_ensemble
 
 
+def _torch_dtype_of(data) -> t.Optional[torch.dtype]:
+  """torch dtype of a tensor / NumPy array / lazy container; None if torch has
+  no such dtype."""
+  dtype = getattr(data, 'dtype', None)
+  if isinstance(dtype, torch.dtype):
+    return dtype
+  try:
+    return torch.from_numpy(np.empty(0, dtype=np.dtype(dtype))).dtype
+  except (TypeError, ValueError):
+    return None
+
+
 def _ens_layout(forecast, fvar, tvar, ensemble_dim, allow_gather=False):
   """Device tensors + slab tables of one ensemble variable: member m of outer
   index o is slab  m * stride_member + ens_table[o]  of the forecast array --
@@ -1629,9 +1713,18 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim, allow_gather=False):
   if isinstance(fdata, torch.Tensor) and not fdata.is_contiguous():
     # a VIEW with intact 2-D slabs (an (init_time=1, lead_time=1) chunk sliced
     # out of a resident forecast): addressed through its own strides, no copy
+    # -- but only if the kernel reads the view AS IT IS: a cast to the common
+    # dtype or an upload below returns a compact copy, and the view's strides
+    # would then address memory the copy does not have
     se = int(fdata.shape[-2]) * int(fdata.shape[-1])
     st = fdata.stride()
-    if fdata.dim() >= 2 and st[-1] == 1 and st[-2] == fdata.shape[-1] and all(
+    tdtype = _torch_dtype_of(tdata)
+    common = None if tdtype is None else torch.promote_types(fdata.dtype,
+                                                             tdtype)
+    as_is = (fdata.device.type == 'cuda' and common == fdata.dtype and
+             common in (torch.float32, torch.float64))
+    if as_is and fdata.dim() >= 2 and st[-1] == 1 and (
+        st[-2] == fdata.shape[-1]) and all(
         x >= 0 and x % se == 0 for x in st[:-2]) and se > 0:
       strides = {d: x // se for d, x in zip(frest, st[:-2])}
       strided = True

@@ -94,13 +94,19 @@ class Recorder:
     if table is not None:
       self.tables[id(table)] = (table, recompute)
 
-  def fake_metrics(self, n_metric, n_region, n_outer, device):
+  def fake_metrics(self, n_metric, n_region, n_outer, device,
+                   extend: bool = False):
+    """`extend`: a second output block of the launch noted last (the wind
+    block of a launch with wind-vector pairs)."""
     n = n_metric * n_region * n_outer
     out = (torch.arange(self.offset, self.offset + n, dtype=torch.float64,
                         device=device) + _THIRD).reshape(n_metric, n_region,
                                                          n_outer)
     self.offset += n
-    self.launches.append({'n': n})
+    if extend:
+      self.launches[-1]['n'] += n
+    else:
+      self.launches.append({'n': n})
     return out
 
   def record(self, **launch) -> None:
@@ -263,6 +269,14 @@ class _Launch:
       off += n
     self.n_metric = _lib.GENERIC_KQ.get(self.mode, _lib.NMETRIC)
     self.n_values = self.n_metric * pl.n_region * n_total
+    self.n_pair = int(rec.get('n_pair') or 0)
+    if self.n_pair:
+      # wind-vector pairs answered by the launch itself (metrics._run_group):
+      # its output is the per-variable block followed by the wind block
+      self.step = engine.PairSuiteStep(pl, self.mode, self.dtype, self.skipna,
+                                       n_total, self.n_pair)
+      self.n_values = self.step.n_values
+      return
     # (an auxiliary field -- SEEPS' masked dry fraction -- is a property of
     # the metric's climatology: resident, the same for every chunk)
     self.step = engine.SuiteStep(pl, self.mode, self.dtype, self.skipna,
@@ -292,8 +306,11 @@ class _Launch:
 
   def launch(self, base: int, out, stream) -> None:
     step = 8 * self.n_total
-    self.step.run(None, [base + j * step for j in range(self.n_in)],
-                  metrics=out, stream_ptr=stream)
+    tables = [base + j * step for j in range(self.n_in)]
+    if self.n_pair:
+      self.step.run(None, tables, out=out, stream_ptr=stream)
+    else:
+      self.step.run(None, tables, metrics=out, stream_ptr=stream)
 
 
 def _view_offset(view: torch.Tensor, raw, what: str) -> int:
@@ -683,9 +700,8 @@ class ChunkProgram:
     self.time_dim, self.split_dim = time_dim, split_dim
     off = 0
     self.slices = []
-    for la in launches:
-      self.slices.append(arena[off:off + la.n_values].view(
-          la.n_metric, la.plan.n_region, la.n_total))
+    for la in launches:   # (flat: a launch may write several output blocks)
+      self.slices.append(arena[off:off + la.n_values])
       off += la.n_values
 
   def reset(self):
@@ -726,7 +742,9 @@ def _build(first, forecast, truth, results, means, loop):
   if not launches_rec:
     return _no('no launch recorded')
   device = launches_rec[0]['plan'].device
-  total = sum(int(l['metrics'].numel()) for l in launches_rec)
+  outputs = lambda l: [l['metrics']] + (
+      [l['wind_metrics']] if l.get('wind_metrics') is not None else [])
+  total = sum(int(x.numel()) for l in launches_rec for x in outputs(l))
   if total >= _MAX_ELEMENTS:
     return _no('too many output elements')
   time_dim, split_dim = means[0].dim, means[0].split_dim
@@ -743,7 +761,8 @@ def _build(first, forecast, truth, results, means, loop):
     shown_all = [xl.as_dataset(r) for r in loop()]
   if [l['n'] for l in probe.launches] != [la.n_values for la in launches]:
     return _no('probe saw other launches')
-  flat_real = torch.cat([l['metrics'].reshape(-1) for l in launches_rec])
+  flat_real = torch.cat([x.reshape(-1) for l in launches_rec
+                         for x in outputs(l)])
   per_sink = []
   for shown, result, mean in zip(shown_all, results, means):
     if (mean.dim, mean.split_dim) != (time_dim, split_dim):
