@@ -604,6 +604,84 @@ int wb2_gather_accumulate(const double* arena, const int32_t* src,
                           int skipna, const int64_t* sum_addr,
                           const int64_t* count_addr, void* stream);
 
+/* wb2_gather_accumulate for a sink that KEEPS the time steps
+ * (`temporal_mean=False`, evaluation.py:735: the reference skips TemporalMean
+ * and the output keeps init_time): entry e is added rows[sel[e]] * rsz8[e]
+ * BYTES behind sum_addr[e] / count_addr[e].  `rows` (DEV int64) are the storage
+ * rows of the chunk's (time, lead) label pairs -- all a chunk brings --, `sel`
+ * (DEV int32[n_out]) which of them entry e belongs to and `rsz8` (DEV
+ * int64[n_out]) the bytes of one row of e's storage: structural. */
+int wb2_gather_accumulate_rows(const double* arena, const int32_t* src,
+                               const uint8_t* round32, int64_t n_out,
+                               int64_t n_time, int skipna,
+                               const int64_t* sum_addr,
+                               const int64_t* count_addr, const int64_t* rows,
+                               const int32_t* sel, const int64_t* rsz8,
+                               void* stream);
+
+/*
+ * Chunk programs: every launch of one chunk STRUCTURE recorded once, replayed
+ * per chunk in ONE call -- what _evaluate_chunk + TemporalMean do per chunk
+ * (evaluation.py:583-599, 735-744), 2 920 x 40 times in the official 0.25
+ * degree run, with nothing changing between chunks but the addresses of their
+ * arrays and their valid times.
+ *
+ *  wb2_program_add_launch   one K1 + K2 step (wb2_det_suite_step, or
+ *      wb2_det_wind_suite_step when n_pair > 0) over n_outer slabs given by
+ *      address: input j of slab o is read at ptrs[slot[j * n_outer + o]] +
+ *      rel[j * n_outer + o] (slot / rel: HOST, copied).  `partials` (and
+ *      `wind_partials`) are the launch's DEV scratch, sized as for the suite
+ *      step; its metrics are written at arena + arena_offset (per-variable
+ *      block, then the wind block).  side_stream != 0: the launch runs on the
+ *      program's second stream beside the others (small, latency-bound
+ *      passes) and is joined before the sinks.
+ *  wb2_program_add_gather   entries [first, first + count) of input `input` of
+ *      the launch added LAST are read from a resident array by valid time
+ *      (climatology.sel(dayofyear, hour), metrics.py:398-404) instead:
+ *      address = ptrs[source] + (values[value_offset + cell[k]] + base[k]) *
+ *      step_bytes -- values = the slab number of every (time, lead) cell of
+ *      the chunk (per chunk), cell / base structural (HOST, copied).
+ *  wb2_program_add_sink     one wb2_gather_accumulate over the arena per eval
+ *      config (src / round32: DEV, kept by the caller); sel / rsz8 != NULL:
+ *      wb2_gather_accumulate_rows with at most max_rows rows per chunk.
+ *  wb2_program_finalize     arena = DEV double[...], the launches' outputs side
+ *      by side; n_ptrs / n_values = lengths every replay must bring.
+ *  wb2_program_replay       ptrs / values: HOST.  sink_args: HOST int64[3] per
+ *      sink = {sum table address, count table address (DEV int64 tables as in
+ *      wb2_gather_accumulate), number of rows of this sink in `rows`}; rows:
+ *      HOST int64[n_rows], the kept sinks' rows one sink after the other.
+ *      Everything is enqueued on `stream` (use ONE stream per program); the
+ *      host only waits when it is more than four replays ahead of the copies.
+ * Results are those of the separate calls, bit for bit (same kernels, same
+ * order of additions). */
+int wb2_program_create(void** program);
+int wb2_program_destroy(void* program);
+int wb2_program_add_launch(void* program, const wb2_plan_tables* plan, int mode,
+                           int dtype, int skipna, int32_t n_in, int64_t n_outer,
+                           int64_t n_pair, const int32_t* slot,
+                           const int64_t* rel, double* partials,
+                           double* wind_partials, int64_t arena_offset,
+                           int side_stream);
+int wb2_program_add_gather(void* program, int32_t input, int64_t first,
+                           int64_t count, int32_t source, int64_t step_bytes,
+                           int32_t value_offset, const int32_t* cell,
+                           const int64_t* base);
+int wb2_program_add_sink(void* program, const int32_t* src,
+                         const uint8_t* round32, int64_t n_out, int64_t n_time,
+                         int skipna, const int32_t* sel, const int64_t* rsz8,
+                         int64_t max_rows);
+int wb2_program_finalize(void* program, double* arena, int32_t n_ptrs,
+                         int32_t n_values);
+int wb2_program_replay(void* program, const int64_t* ptrs, int32_t n_ptrs,
+                       const int64_t* values, int32_t n_values,
+                       const int64_t* sink_args, const int64_t* rows,
+                       int32_t n_rows, void* stream);
+/* Host seconds the replays of `program` have spent, by phase: seconds[0]
+ * waiting for a free table slot (the GPU is more than four replays behind:
+ * the run is GPU-bound), [1] filling the address table, [2] its copy, [3] the
+ * launches, [4] the sinks; *replays = number of calls. */
+int wb2_program_stats(void* program, double* seconds, int64_t* replays);
+
 /*
  * The energy score in ONE read of the ensemble (metrics.py:1403-1517;
  * scripts/evaluate.py:541-565 evaluates score, spread and skill per chunk):

@@ -308,6 +308,11 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
       k.result = r
     engine.set_launch_hook(old)
   n = len(chunks)
+  import gc
+  from weatherbench2_amd import program as program_lib
+  gc.collect()
+  replay_stats = list(program_lib.REPLAY_STATS)
+  del program_lib.REPLAY_STATS[:]
   if batch is None:
     first = sum(evaluation._input_bytes(ds) for ds in chunks[0])
     batch = int(min(evaluation.AUTO_BATCH_MAX,
@@ -322,6 +327,9 @@ def measure(chunks, cfg, batch, timed_events: bool = True) -> dict:
       'host_ms_per_chunk': (marks['enqueued'] - t0) / n * 1e3,
       'k1_launches_per_chunk': ev.launches / n,
   }
+  if replay_stats:   # host ms per wb2_program_replay call, by phase
+    leg['replay_host_ms'] = {k: round(v, 4) for k, v in max(
+        replay_stats, key=lambda d: d['replays']).items()}
   if timed_events and ev.pairs:
     ms = [a.elapsed_time(b) for a, b in ev.pairs]
     # every event pair brackets one fused launch (+ its K2): the deterministic

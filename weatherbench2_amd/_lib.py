@@ -81,6 +81,22 @@ _SIGNATURES = {
         _vp, _vp, _vp]),
     'wb2_gather_accumulate': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp,
                                      _vp]),
+    'wb2_gather_accumulate_rows': (_int, [_vp, _vp, _vp, _i64, _i64, _int,
+                                          _vp, _vp, _vp, _vp, _vp, _vp]),
+    'wb2_program_create': (_int, [_c.POINTER(_vp)]),
+    'wb2_program_destroy': (_int, [_vp]),
+    'wb2_program_add_launch': (_int, [
+        _vp, _c.POINTER(PlanTables), _int, _int, _int, _i32, _i64, _i64, _vp,
+        _vp, _vp, _vp, _i64, _int]),
+    'wb2_program_add_gather': (_int, [_vp, _i32, _i64, _i64, _i32, _i64, _i32,
+                                      _vp, _vp]),
+    'wb2_program_add_sink': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp,
+                                    _i64]),
+    'wb2_program_finalize': (_int, [_vp, _vp, _i32, _i32]),
+    'wb2_program_replay': (_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32,
+                                  _vp]),
+    'wb2_program_stats': (_int, [_vp, _c.POINTER(_c.c_double),
+                                 _c.POINTER(_i64)]),
     'wb2_energy_layout': (_int, [_i32, _int, _int, _c.POINTER(_i32),
                                  _c.POINTER(_i32), _c.POINTER(_i32)]),
     'wb2_energy_score': (_int, [

@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libwb2hip.so')
-SOURCES = ('common.cpp', 'comm.cpp', 'staging.cpp', 'stream_reduce.hip', 'ensemble.hip', 'energy_score.hip',
+SOURCES = ('common.cpp', 'comm.cpp', 'staging.cpp', 'program.cpp', 'stream_reduce.hip', 'ensemble.hip', 'energy_score.hip',
            'spectrum.hip', 'spectrum_fused.hip', 'spatial_maps.hip',
            'rank_histogram.hip', 'axis_reduce.hip')
 # compiled once per member count listed in sort3_networks.inc (WB2_SORT3_SIZES)

@@ -1292,17 +1292,26 @@ __global__ void __launch_bounds__(256)
 // separate allocations).  src < 0: the element is a NaN fill (a metric that
 // lacks the variable, evaluation.py:424-437).  Same arithmetic, value by value
 // in time order, as time_accumulate_kernel.
+// `rows` (optional; wb2_gather_accumulate_rows): element e lands rows[sel[e]] *
+// rsz8[e] bytes behind sum_addr[e] / count_addr[e] -- a sink that KEEPS the
+// time steps (temporal_mean=False, evaluation.py:735) files every chunk under
+// the row of its (time, lead) labels; the chunk brings its few row numbers,
+// which entry takes which of them and how long a row is are structural.
 __global__ void __launch_bounds__(256)
     gather_accumulate_kernel(const double* __restrict__ arena,
                              const int* __restrict__ src,
                              const unsigned char* __restrict__ round32,
                              long long n_out, long long n_time, int skipna,
                              const long long* __restrict__ sum_addr,
-                             const long long* __restrict__ count_addr) {
+                             const long long* __restrict__ count_addr,
+                             const long long* __restrict__ rows,
+                             const int* __restrict__ sel,
+                             const long long* __restrict__ rsz8) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_out) return;
-  double* sp = reinterpret_cast<double*>(sum_addr[e]);
-  double* cp = reinterpret_cast<double*>(count_addr[e]);
+  const long long shift = rows ? rows[sel[e]] * rsz8[e] : 0;
+  double* sp = reinterpret_cast<double*>(sum_addr[e] + shift);
+  double* cp = reinterpret_cast<double*>(count_addr[e] + shift);
   double s = *sp, c = *cp;
   const bool r32 = round32[e] != 0;
   const int* q = src + e * n_time;
@@ -2116,7 +2125,35 @@ int wb2_gather_accumulate(const double* arena, const int32_t* src,
                      static_cast<hipStream_t>(stream), arena, src, round32,
                      (long long)n_out, (long long)n_time, skipna,
                      reinterpret_cast<const long long*>(sum_addr),
-                     reinterpret_cast<const long long*>(count_addr));
+                     reinterpret_cast<const long long*>(count_addr),
+                     (const long long*)nullptr, (const int*)nullptr,
+                     (const long long*)nullptr);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int wb2_gather_accumulate_rows(const double* arena, const int32_t* src,
+                               const uint8_t* round32, int64_t n_out,
+                               int64_t n_time, int skipna,
+                               const int64_t* sum_addr,
+                               const int64_t* count_addr, const int64_t* rows,
+                               const int32_t* sel, const int64_t* rsz8,
+                               void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_EMPTY_OK(n_out);
+  WB2_EMPTY_OK(n_time);
+  WB2_REQUIRE(arena && src && round32 && sum_addr && count_addr && rows &&
+                  sel && rsz8,
+              "null pointer argument");
+  hipLaunchKernelGGL(gather_accumulate_kernel,
+                     dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), arena, src, round32,
+                     (long long)n_out, (long long)n_time, skipna,
+                     reinterpret_cast<const long long*>(sum_addr),
+                     reinterpret_cast<const long long*>(count_addr),
+                     reinterpret_cast<const long long*>(rows), sel,
+                     reinterpret_cast<const long long*>(rsz8));
   WB2_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -623,7 +623,8 @@ def _climatology_slabs(climatology: xl.Dataset, cvar: xl.DataArray,
 _LABEL_BYTES: dict = {}  # id(coordinate array) -> (array, content key)
 
 
-def _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest):
+def _valid_times(forecast: xl.Dataset):
+  """(valid times of the chunk, the dims they run over)."""
   if forecast.has_dim('init_time'):
     vt = forecast.coords['valid_time']
     if not isinstance(vt, xl.DataArray):
@@ -633,7 +634,11 @@ def _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest):
   else:
     time_dims = ('time',)
     vt = _coord_values(forecast, 'time')
-  vt = np.asarray(vt)
+  return np.asarray(vt), time_dims
+
+
+def _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest):
+  vt, time_dims = _valid_times(forecast)
 
   def label_bytes(ds, name):
     if name not in ds.coords:
@@ -663,32 +668,85 @@ def _climatology_slabs_by_content(climatology, cvar, forecast, geo, crest):
   return hit
 
 
-def _climatology_slabs_build(climatology, cvar, forecast, geo, crest, vt,
-                             time_dims):
-  doy, hour = _dayofyear_hour(vt)
-
-  stride, strides = 1, {}
-  for d, n in reversed(list(zip(crest, [cvar.sizes[d] for d in crest]))):
-    strides[d] = stride
-    stride *= n
+def _climatology_strides(crest, sizes) -> dict:
   unknown = set(crest) - {'dayofyear', 'hour', 'level'}
   if unknown:
     raise ValueError(f'unsupported climatology dims {unknown}')
-  # time part, shaped like the time dims
-  tpart = _label_positions(_coord_values(climatology, 'dayofyear'), doy,
-                           'dayofyear') * strides['dayofyear']
+  stride, strides = 1, {}
+  for d, n in reversed(list(zip(crest, sizes))):
+    strides[d] = stride
+    stride *= n
+  return strides
+
+
+_LABEL_LUTS: dict = {}  # id(label array) -> (array, lookup table or None)
+
+
+def _small_label_positions(have: np.ndarray, want: np.ndarray, what: str):
+  """_label_positions for an index of small non-negative integers (dayofyear
+  1..366, hour 0..23) through a dense lookup table remembered per label array
+  OBJECT: the per-chunk cost of a climatology gather is two tiny fancy
+  indexings instead of two argsorts."""
+  hit = _LABEL_LUTS.get(id(have))
+  if hit is None or hit[0] is not have:
+    lut = None
+    if have.dtype.kind in 'iu' and have.size and have.min() >= 0 and (
+        have.max() < 4096) and len(np.unique(have)) == have.size:
+      lut = np.full(int(have.max()) + 2, -1, dtype=np.int64)
+      lut[have] = np.arange(have.size, dtype=np.int64)
+    if len(_LABEL_LUTS) >= 64:
+      _LABEL_LUTS.clear()
+    hit = _LABEL_LUTS[id(have)] = (have, lut)
+  lut = hit[1]
+  if lut is None or want.dtype.kind not in 'iu':
+    return _label_positions(have, want, what)
+  pos = lut[np.clip(want, -1, lut.size - 1)]
+  if (pos < 0).any():
+    bad = np.asarray(want).ravel()[(pos < 0).ravel()][0]
+    raise KeyError(f'{what} label {bad!r} not found in climatology')
+  return pos
+
+
+def _climatology_time_values(climatology, crest, sizes, vt,
+                             memo: t.Optional[dict] = None) -> np.ndarray:
+  """The time part of the climatology slab number of every valid time in `vt`
+  (same shape): position of its dayofyear (and hour) label times the stride of
+  that dim (metrics.py:398-404: climatology.sel(dayofyear=..., hour=...)).
+  `memo`: shared by the gathers of one chunk (one calendar conversion)."""
+  strides = _climatology_strides(crest, sizes)
+  when = None if memo is None else memo.get('doy_hour')
+  if when is None or when[0] is not vt:
+    when = (vt,) + tuple(_dayofyear_hour(vt))
+    if memo is not None:
+      memo['doy_hour'] = when
+  _, doy, hour = when
+  tpart = _small_label_positions(_coord_values(climatology, 'dayofyear'), doy,
+                                 'dayofyear') * strides['dayofyear']
   if 'hour' in climatology.coords and 'hour' in crest:
-    tpart = tpart + _label_positions(_coord_values(climatology, 'hour'), hour,
-                                     'hour') * strides['hour']
-  table = np.zeros(geo.out_shape, dtype=np.int64)
+    tpart = tpart + _small_label_positions(
+        _coord_values(climatology, 'hour'), hour, 'hour') * strides['hour']
+  return tpart
+
+
+def _climatology_structure(climatology, cvar, forecast, geo, crest, vt_shape,
+                           time_dims):
+  """(cell, base): output slab k of a variable subtracts climatology slab
+  values.ravel()[cell[k]] + base[k], `values` = _climatology_time_values of
+  the chunk's valid times.  Which (time, lead) cell a slab belongs to and its
+  level part do not depend on the valid times themselves: the same for every
+  chunk of one structure (program.py replays with new `values` only)."""
+  strides = _climatology_strides(crest, [cvar.sizes[d] for d in crest])
   shape = [1] * len(geo.out_shape)
-  for d, n in zip(time_dims, np.shape(vt)):
+  for d, n in zip(time_dims, vt_shape):
     if d not in geo.out_dims:
       raise ValueError(f'time dim {d!r} missing from the forecast variable')
     shape[geo.out_dims.index(d)] = n
   order = [d for d in geo.out_dims if d in time_dims]
-  tpart = np.transpose(tpart, [time_dims.index(d) for d in order])
-  table = table + tpart.reshape(shape)
+  n_cell = int(np.prod(vt_shape, dtype=np.int64))
+  cells = np.arange(n_cell, dtype=np.int64).reshape(vt_shape)
+  cells = np.transpose(cells, [time_dims.index(d) for d in order])
+  cell = np.zeros(geo.out_shape, dtype=np.int64) + cells.reshape(shape)
+  base = np.zeros(geo.out_shape, dtype=np.int64)
   if 'level' in crest:
     if 'level' not in geo.out_dims:
       raise ValueError('climatology has a level dim but the forecast has none')
@@ -696,8 +754,42 @@ def _climatology_slabs_build(climatology, cvar, forecast, geo, crest, vt,
                           _coord_values(forecast, 'level'), 'level')
     shape = [1] * len(geo.out_shape)
     shape[geo.out_dims.index('level')] = len(lv)
-    table = table + (lv * strides['level']).reshape(shape)
-  return np.ascontiguousarray(table).ravel()
+    base = base + (lv * strides['level']).reshape(shape)
+  return (np.ascontiguousarray(cell).ravel(),
+          np.ascontiguousarray(base).ravel())
+
+
+def _climatology_slabs_build(climatology, cvar, forecast, geo, crest, vt,
+                             time_dims):
+  values = _climatology_time_values(
+      climatology, crest, [cvar.sizes[d] for d in crest], vt)
+  cell, base = _climatology_structure(climatology, cvar, forecast, geo, crest,
+                                      np.shape(vt), time_dims)
+  return np.ascontiguousarray(values).ravel()[cell] + base
+
+
+def _climatology_gather(climatology, cvar, forecast, geo, crest):
+  """What a chunk program needs to read this climatology variable for OTHER
+  chunks of the structure: {'cell', 'base'} (structural) and values(other) ->
+  int64[n_cell] (per chunk: label work on the chunk's valid times only)."""
+  vt, time_dims = _valid_times(forecast)
+  sizes = [cvar.sizes[d] for d in crest]
+  cell, base = _climatology_structure(climatology, cvar, forecast, geo, crest,
+                                      np.shape(vt), time_dims)
+
+  def values(other, memo=None, shape=np.shape(vt), dims=time_dims):
+    when = None if memo is None else memo.get('valid_times')
+    if when is None or when[0] is not other:
+      when = (other,) + _valid_times(other)
+      if memo is not None:
+        memo['valid_times'] = when
+    _, vt2, dims2 = when
+    if np.shape(vt2) != shape or dims2 != dims:
+      raise ValueError('the chunk\'s valid times have another layout')
+    return np.ascontiguousarray(_climatology_time_values(
+        climatology, crest, sizes, vt2, memo), dtype=np.int64).ravel()
+  return {'cell': cell, 'base': base, 'values': values,
+          'key': (id(climatology), tuple(crest), tuple(sizes))}
 
 
 def _physical_slabs(x: torch.Tensor, table, n_row: int, n_col: int):
@@ -1044,7 +1136,8 @@ def _det_plan(forecast, truth, name, climatology):
             memo[key] = _climatology_slabs_by_content(climatology, cvar, other,
                                                       geo, crest)
           return memo[key]
-        rec.note_table(ctable, recompute)
+        rec.note_table(ctable, recompute, _climatology_gather(
+            climatology, cvar, forecast, geo, crest))
     except (KeyError, ValueError):
       if not announced:
         raise
@@ -2637,7 +2730,8 @@ class SEEPS(Metric):
           memo[key] = _climatology_slabs_by_content(climatology, wvar, other,
                                                     geo, wrest)
         return memo[key]
-      rec.note_table(wtable, recompute)
+      rec.note_table(wtable, recompute, _climatology_gather(
+          climatology, wvar, forecast, geo, wrest))
     tables.append(wtable)
     aux = self._masked_p1(climatology, geo.layout)
     return geo, [p[0] for p in prepared], tables, aux

@@ -41,6 +41,7 @@ from __future__ import annotations
 import os
 import threading
 import typing as t
+import weakref
 
 import numpy as np
 import torch
@@ -88,11 +89,13 @@ class Recorder:
   def __exit__(self, *exc):
     _ACTIVE.recorder = self._old
 
-  def note_table(self, table, recompute) -> None:
+  def note_table(self, table, recompute, gather=None) -> None:
     """`table` (a slab table the generic path derived from the chunk's LABELS)
-    is what `recompute(forecast)` returns for another chunk."""
+    is what `recompute(forecast)` returns for another chunk.  `gather`
+    (metrics._climatology_gather) splits it into a structural part and the
+    few per-chunk values a native replay needs."""
     if table is not None:
-      self.tables[id(table)] = (table, recompute)
+      self.tables[id(table)] = (table, recompute, gather)
 
   def fake_metrics(self, n_metric, n_region, n_outer, device,
                    extend: bool = False):
@@ -213,14 +216,16 @@ class _Launch:
     self.slot = np.zeros((n_in, n_total), dtype=np.int64)
     self.rel = np.zeros((n_in, n_total), dtype=np.int64)
     self.sources: list = []    # how to get pointer `slot` of a new chunk
-    self.dynamic: list = []    # (input, offset, count, resident array, recompute)
-    self.keep: list = []
+    self.source_keys: list = []  # what pointer `slot` is (shared by launches)
+    self.dynamic: list = []    # (input, offset, count, resident array,
+    self.keep: list = []       #  recompute, gather)
     source_of: dict = {}
 
     def slot_for(key, getter):
       if key not in source_of:
         source_of[key] = len(self.sources)
         self.sources.append(getter)
+        self.source_keys.append(key)
       return source_of[key]
     off = 0
     for geo, arrays, tables, tensors in members:
@@ -265,7 +270,7 @@ class _Launch:
         self.keep.append(base_tensor)
         self.slot[j, off:off + n] = slot_for(
             ('r', id(base_tensor)), lambda f, t_, b=base_tensor: b)
-        self.dynamic.append((j, off, n, x, hit[1]))
+        self.dynamic.append((j, off, n, x, hit[1], hit[2]))
       off += n
     self.n_metric = _lib.GENERIC_KQ.get(self.mode, _lib.NMETRIC)
     self.n_values = self.n_metric * pl.n_region * n_total
@@ -290,7 +295,7 @@ class _Launch:
     if self.dynamic:
       from weatherbench2_amd import metrics as gm
       memo: dict = {}
-      for j, off, n, x, recompute in self.dynamic:
+      for j, off, n, x, recompute, _ in self.dynamic:
         table = recompute(forecast, memo)
         a, _ = gm._slab_addresses(x, table, self.plan.n_row, self.plan.n_col, n)
         addr[j, off:off + n] = a
@@ -529,6 +534,8 @@ class _NotReplayable(Exception):
 
 # why the last structures were not given a program (diagnostics, tests)
 REASONS: list = []
+# host time per replay of the native programs that have been closed
+REPLAY_STATS: list = []
 
 
 def _no(reason: str):
@@ -562,13 +569,14 @@ class _SinkGroup:
     self._lib = _lib.load()
     self._kept = None         # RunningConcat sinks: see _kept_tables
 
-  def _kept_tables(self, sink, forecast):
+  def kept_structure(self, sink):
     """A sink that KEEPS the time steps (evaluation.RunningConcat): every
     (element, time step) entry of the source table has a destination of its
     own, row(time label, lead label) * rest size + rest index.  Structural, on
     the device once: which row of the chunk an entry goes to (`sel`), its rest
-    size and rest offset in bytes.  Per chunk: the rows of the chunk's label
-    combinations (a handful of integers) and four small device ops."""
+    size and rest offset in bytes.  None for a sink that averages."""
+    if not getattr(sink, 'keeps_time', False):
+      return None
     if self._kept is None:
       sel, rsz8, rest8, vid, groups = [], [], [], [], {}
       for i, (name, dims, shape, axis, src, r32) in enumerate(self.variables):
@@ -600,8 +608,16 @@ class _SinkGroup:
                              for v in self.variables]).astype(np.uint8)
       self._kept = {'sel': dev(sel), 'rsz8': dev(rsz8), 'rest8': dev(rest8),
                     'vid': dev(vid), 'groups': groups, 'stamp': None,
-                    'round': torch.as_tensor(each).to(self.device)}
-    k = self._kept
+                    'round': torch.as_tensor(each).to(self.device),
+                    'max_rows': sum(g[1] for g in groups.values())}
+      self._kept['sel32'] = self._kept['sel'].to(torch.int32)
+    return self._kept
+
+  def kept_rows(self, sink, forecast):
+    """Per chunk, for a sink that keeps the time steps: (device table of every
+    entry's row-0 sum address, the same for the counts, the storage rows of
+    the chunk's label combinations -- a handful of integers)."""
+    k = self.kept_structure(sink)
     rows = {g: sink.rows(forecast, g).ravel() for g in k['groups']}
     accs = []
     for name, dims, shape, axis, src, _ in self.variables:
@@ -619,10 +635,18 @@ class _SinkGroup:
       k['sum0'] = sums[k['vid']] + k['rest8']
       k['count0'] = counts[k['vid']] + k['rest8']
       k['stamp'] = stamp
-    chunk_rows = engine.upload_table(np.concatenate(list(rows.values())),
-                                     self.device, cache=False)
+    mine = (next(iter(rows.values())) if len(rows) == 1
+            else np.concatenate(list(rows.values())))
+    return k['sum0'], k['count0'], np.ascontiguousarray(mine, dtype=np.int64)
+
+  def _kept_tables(self, sink, forecast):
+    """The Python replay's form of the above: the destination of every entry
+    worked out with four small device ops."""
+    sum0, count0, rows = self.kept_rows(sink, forecast)
+    k = self._kept
+    chunk_rows = engine.upload_table(rows, self.device, cache=False)
     offset = chunk_rows[k['sel']] * k['rsz8']
-    return k['sum0'] + offset, k['count0'] + offset, k['round']
+    return sum0 + offset, count0 + offset, k['round']
 
   def reset(self):
     """Forget cached accumulator addresses (the accumulators were replaced)."""
@@ -685,6 +709,177 @@ class _SinkGroup:
       _lib.check(status, 'wb2_gather_accumulate')
 
 
+class _Native:
+  """The launches and sinks of a ChunkProgram inside libwb2hip.so
+  (csrc/program.cpp): a chunk is replayed by ONE wb2_program_replay call -- the
+  base pointers of the chunk's arrays, the climatology slab of every valid
+  time, the sinks' accumulator tables go in; the address table, its upload,
+  every launch (small latency-bound passes on a second stream) and the
+  accumulation happen on the C side.  Same kernels, same order: the bits of the
+  Python replay (`WB2HIP_NATIVE_REPLAY=0` keeps that one).
+
+  Raises _NotReplayable for what the C side does not cover (ensemble passes,
+  gathers from lazy containers): the program then replays from Python."""
+
+  def __init__(self, launches, groups, arena, device, means):
+    import ctypes
+    if not all(isinstance(la, _Launch) for la in launches):
+      raise _NotReplayable('ensemble passes replay from Python')
+    lib = self._lib = _lib.load()
+    self.device = device
+    handle = ctypes.c_void_p()
+    _lib.check(lib.wb2_program_create(ctypes.byref(handle)),
+               'wb2_program_create')
+    self._handle = handle
+    self._finalizer = weakref.finalize(self, _Native._close, lib,
+                                       handle.value)
+    # ---- pointer sources, shared by the launches
+    self.getters: list = []     # (index, getter) of the chunk's own arrays
+    index_of: dict = {}
+    fixed: dict = {}
+    keep = self._keep = []
+
+    def source(key, getter):
+      if key not in index_of:
+        index_of[key] = len(index_of)
+        if key[0] == 'r':       # resident: the same pointer for every chunk
+          fixed[index_of[key]] = getter(None, None).data_ptr()
+        else:
+          self.getters.append((index_of[key], getter))
+      return index_of[key]
+    # ---- gathered inputs: one value block per (climatology, dims)
+    self.values: list = []      # values(forecast, memo) per block
+    block_of: dict = {}
+    n_values = 0
+    off = 0
+    for la in launches:
+      remap = np.array([source(k, g) for k, g in zip(la.source_keys,
+                                                     la.sources)],
+                       dtype=np.int32)
+      slot = np.ascontiguousarray(remap[la.slot], dtype=np.int32)
+      rel = np.ascontiguousarray(la.rel, dtype=np.int64)
+      step = la.step
+      side = int(la.mode == _lib.MODE_SEEPS and la.n_total <= 8)
+      wind = getattr(step, 'wind_partials', None)
+      _lib.check(lib.wb2_program_add_launch(
+          handle, step._tables_ref, la.mode, step.code, int(la.skipna),
+          la.n_in, la.n_total, la.n_pair, slot.ctypes.data, rel.ctypes.data,
+          step.partials.data_ptr(), _lib.ptr(wind) or None, off, side),
+                 'wb2_program_add_launch')
+      keep.append(step)
+      for j, first, n, x, _, gather in la.dynamic:
+        if gather is None or not isinstance(x, torch.Tensor) or not (
+            x.is_contiguous()):
+          raise _NotReplayable('a gather the native replay does not cover')
+        block = block_of.get(gather['key'])
+        n_cell = int(gather['cell'].max()) + 1 if gather['cell'].size else 0
+        if block is None:
+          block = block_of[gather['key']] = (n_values, n_cell)
+          self.values.append(gather['values'])
+          n_values += n_cell
+        if block[1] < n_cell:
+          raise _NotReplayable('gathers of one climatology differ in cells')
+        src = source(('r', id(x)), lambda f, t_, x=x: x)
+        cell = np.ascontiguousarray(gather['cell'], dtype=np.int32)
+        base = np.ascontiguousarray(gather['base'], dtype=np.int64)
+        if cell.size != n or base.size != n:
+          raise _NotReplayable('gather tables do not cover the launch slabs')
+        slab_bytes = la.plan.n_row * la.plan.n_col * x.element_size()
+        _lib.check(lib.wb2_program_add_gather(
+            handle, j, first, n, src, slab_bytes, block[0], cell.ctypes.data,
+            base.ctypes.data), 'wb2_program_add_gather')
+        keep.append(x)
+      off += la.n_values
+    self.n_values = n_values
+    # ---- sinks
+    self.groups = groups
+    for g, mean in zip(groups, means):
+      kept = g.kept_structure(mean)
+      if kept is None:
+        _lib.check(lib.wb2_program_add_sink(
+            handle, g.src.data_ptr(), g.round32.data_ptr(), g.n_out, g.n_time,
+            int(bool(mean.skipna)), None, None, 0), 'wb2_program_add_sink')
+      else:
+        _lib.check(lib.wb2_program_add_sink(
+            handle, g.src.data_ptr(), kept['round'].data_ptr(),
+            g.n_out * g.n_time, 1, 0, kept['sel32'].data_ptr(),
+            kept['rsz8'].data_ptr(), kept['max_rows']),
+                   'wb2_program_add_sink')
+    self.n_ptrs = len(index_of)
+    _lib.check(lib.wb2_program_finalize(handle, arena.data_ptr(), self.n_ptrs,
+                                        n_values), 'wb2_program_finalize')
+    self.ptrs = np.zeros(max(self.n_ptrs, 1), dtype=np.int64)
+    for i, p in fixed.items():
+      self.ptrs[i] = p
+    self._ptrs_at = self.ptrs.ctypes.data
+    self.sink_args = np.zeros((max(len(groups), 1), 3), dtype=np.int64)
+    self._sink_at = self.sink_args.ctypes.data
+    self._replay = lib.wb2_program_replay
+    self._no_values = np.zeros(1, dtype=np.int64)
+
+  @staticmethod
+  def _stats(lib, handle) -> dict:
+    import ctypes
+    sec = (ctypes.c_double * 5)()
+    n = ctypes.c_int64()
+    _lib.check(lib.wb2_program_stats(handle, sec, ctypes.byref(n)),
+               'wb2_program_stats')
+    per = max(n.value, 1)
+    names = ('wait_for_slot', 'fill_table', 'copy', 'launches', 'sinks')
+    out = {k: 1e3 * v / per for k, v in zip(names, sec)}
+    out['replays'] = n.value
+    return out
+
+  def stats(self) -> dict:
+    """Host milliseconds per replay by phase (wb2_program_stats)."""
+    return self._stats(self._lib, self._handle)
+
+  @staticmethod
+  def _close(lib, handle):
+    try:   # what the program's replays cost the host (diagnostics, tools)
+      REPLAY_STATS.append(_Native._stats(lib, handle))
+      del REPLAY_STATS[:-16]
+    except Exception:
+      pass
+    lib.wb2_program_destroy(handle)
+
+  def run(self, forecast, truth, means, stream) -> None:
+    ptrs = self.ptrs
+    for i, g in self.getters:
+      ptrs[i] = g(forecast, truth).data_ptr()
+    if self.values:
+      memo: dict = {}
+      values = (self.values[0](forecast, memo) if len(self.values) == 1 else
+                np.concatenate([v(forecast, memo) for v in self.values]))
+    else:
+      values = self._no_values
+    rows, args = None, self.sink_args
+    for k, (group, mean) in enumerate(zip(self.groups, means)):
+      if getattr(mean, 'keeps_time', False):
+        d_sum, d_cnt, mine = group.kept_rows(mean, forecast)
+        rows = mine if rows is None else np.concatenate([rows, mine])
+        args[k, 2] = mine.size
+      else:
+        labels = None
+        if group.split_dim is not None:
+          labels = np.asarray(forecast.coords[group.split_dim])
+        d_sum, d_cnt = group._accumulator_tables(mean, labels)
+        # (the program was built for this sink's NaN rule)
+      args[k, 0], args[k, 1] = d_sum.data_ptr(), d_cnt.data_ptr()
+    hook = engine._LAUNCH_HOOK
+    if hook is not None:   # (brackets every launch of the chunk + the sinks)
+      hook('begin', 'stream_partials')
+    status = self._replay(
+        self._handle, self._ptrs_at, self.n_ptrs, values.ctypes.data,
+        self.n_values, self._sink_at,
+        None if rows is None else rows.ctypes.data,
+        0 if rows is None else rows.size, stream)
+    if hook is not None:
+      hook('end', 'stream_partials')
+    if status != 0:
+      _lib.check(status, 'wb2_program_replay')
+
+
 class ChunkProgram:
   """The replayable form of one chunk structure (see the module docstring):
   the launches of the loop(s) over it, and one `_SinkGroup` per eval config
@@ -692,7 +887,8 @@ class ChunkProgram:
   `deterministic_temporal` of the documented command line -- share the
   launches: the chunk is read once)."""
 
-  def __init__(self, launches, groups, arena, device, time_dim, split_dim):
+  def __init__(self, launches, groups, arena, device, time_dim, split_dim,
+               means=None):
     self.launches = launches       # [_Launch | _EnsLaunch]
     self.groups = groups           # [_SinkGroup], one per config
     self.arena = arena             # float64 device tensor: launch outputs
@@ -703,6 +899,14 @@ class ChunkProgram:
     for la in launches:   # (flat: a launch may write several output blocks)
       self.slices.append(arena[off:off + la.n_values])
       off += la.n_values
+    # the whole replay behind one C-ABI call where the C side covers it
+    self.native = None
+    if means is not None and os.environ.get('WB2HIP_NATIVE_REPLAY',
+                                            '1') != '0':
+      try:
+        self.native = _Native(launches, groups, arena, device, means)
+      except _NotReplayable as e:
+        _no(f'python replay: {e}')
 
   def reset(self):
     for g in self.groups:
@@ -714,6 +918,9 @@ class ChunkProgram:
     if not isinstance(means, (list, tuple)):
       means = [means]
     stream = engine.current_stream_ptr(self.device)
+    if self.native is not None:
+      self.native.run(forecast, truth, means, stream)
+      return
     _run_launches(self.launches, self.slices, forecast, truth, self.device,
                   stream)
     for group, mean in zip(self.groups, means):
@@ -805,7 +1012,8 @@ def _build(first, forecast, truth, results, means, loop):
   groups = [_SinkGroup(variables, device, time_dim, split_dim)
             for variables in per_sink]
   arena = torch.empty((total,), dtype=torch.float64, device=device)
-  return ChunkProgram(launches, groups, arena, device, time_dim, split_dim)
+  return ChunkProgram(launches, groups, arena, device, time_dim, split_dim,
+                      means)
 
 
 def _group_variables(shown, result, mean, forecast, flat_real, total, time_dim):
