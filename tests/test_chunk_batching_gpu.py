@@ -314,8 +314,8 @@ def test_default_window_is_sized_by_the_first_chunk(monkeypatch):
     n_single = seen.count('stream_partials')
   finally:
     engine.set_launch_hook(old)
-  assert n_auto == 2, n_auto  # 18 chunks, one rectangle: det + wind
-  assert n_single == 2 * len(pairs), (n_single, len(pairs))
+  assert n_auto == 1, n_auto  # 18 chunks, one rectangle: ONE fused pass
+  assert n_single == len(pairs), (n_single, len(pairs))
   for name in base.keys():
     for other in (auto, single):
       assert np.array_equal(other[name].values, base[name].values,
