@@ -212,3 +212,48 @@ def test_prefetch_depth_may_change_while_running():
     if item == 2:
       depth[0] = 4
   assert seen == list(range(10)) and sorted(fetched) == list(range(10))
+
+
+@pytest.mark.parametrize('order', ['init', 'lead'])
+def test_concat_chunks_remembered_layout_gives_the_same_concatenation(order):
+  """Windows of one evaluation come with the same rectangle again and again:
+  the second concat takes the remembered layout (one check + one list per
+  variable) and must equal the first way of doing it -- other arrays, same
+  index; a chunk that does not fit is still refused."""
+  forecast, truth = _product(n_init=4, n_lead=3)
+  other_f, _ = _product(n_init=4, n_lead=3)
+  for name, da in other_f.items():   # other values, same labels and shapes
+    other_f.data_vars[name] = xl.DataArray(da.data + 1.0, da.dims,
+                                           other_f.coords, name)
+  evaluation._CONCAT_PLANS.clear()
+  first = evaluation.concat_chunks(
+      [p[0] for p in oc.chunk_pairs(forecast, truth, order)], 'init_time',
+      'lead_time')
+  assert len(evaluation._CONCAT_PLANS) == 1
+  chunks = [p[0] for p in oc.chunk_pairs(other_f, truth, order)]
+  fast = evaluation.concat_chunks(chunks, 'init_time', 'lead_time')
+  evaluation._CONCAT_PLANS.clear()
+  slow = evaluation.concat_chunks(chunks, 'init_time', 'lead_time')
+  for name in slow.keys():
+    a, b = fast[name].data, slow[name].data
+    assert fast[name].dims == slow[name].dims and a.shape == b.shape
+    np.testing.assert_array_equal(a.index, b.index)
+    np.testing.assert_array_equal(a.index, first[name].data.index)
+    np.testing.assert_array_equal(a.offsets, b.offsets)
+    assert len(a.bases) == len(b.bases)
+    assert all(x is y for x, y in zip(a.bases, b.bases))
+    np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+  for k in slow.coords:
+    x, y = fast.coords[k], slow.coords[k]
+    np.testing.assert_array_equal(
+        np.asarray(x.values if isinstance(x, xl.DataArray) else x),
+        np.asarray(y.values if isinstance(y, xl.DataArray) else y))
+  # a strided array in the second window: no concatenation in place
+  bad = list(chunks)
+  name = next(iter(bad[3].keys()))
+  da = bad[3][name]
+  wide = np.zeros(da.shape[:-1] + (2 * da.shape[-1],), dtype=da.dtype)
+  bad[3] = xl.Dataset(dict(bad[3].data_vars), bad[3].coords)
+  bad[3].data_vars[name] = xl.DataArray(wide[..., ::2], da.dims,
+                                        bad[3].coords, name)
+  assert evaluation.concat_chunks(bad, 'init_time', 'lead_time') is None

@@ -15,18 +15,21 @@
 //   sinks     where the chunk's values are accumulated (device tables),
 // and does, on the caller's stream:
 //   1. the slab address of every input of every launch -> one pinned table,
-//      one asynchronous copy (a ring of tables: the host never waits for the
-//      GPU unless it is more than kRing chunks ahead);
+//      one asynchronous copy on a copy stream of the program's (a ring of
+//      tables: the table of chunk k travels while the kernels of chunk k - 1
+//      run; the host waits only when it is kRing chunks ahead of the GPU);
 //   2. every recorded launch -- wb2_det_suite_step / wb2_det_wind_suite_step,
 //      i.e. the kernels of the generic path, bit for bit; launches marked
 //      `side` (the one-slab SEEPS passes: latency-bound) run on a second
 //      stream beside the big one and join before step 3;
 //   3. one wb2_gather_accumulate[_rows] per sink (eval config).
 #include "common.hpp"
+#include "suite_streams.hpp"
 #include "trace.hpp"
 #include "wb2hip.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -79,14 +82,22 @@ struct Program {
   bool finalized = false;
   void* pinned[kRing] = {};
   void* device[kRing] = {};
-  hipEvent_t copied[kRing] = {};
+  hipEvent_t copied[kRing] = {};   // table r is on the device (copy stream)
+  hipEvent_t done[kRing] = {};     // the replay that used table r has finished
   bool busy[kRing] = {};
   int next = 0;
+  // the table of replay k travels while the kernels of replay k - 1 run
+  hipStream_t copy_stream = nullptr;
   // small latency-bound launches run beside the big ones: two high-priority
   // streams (their workgroups take the slots the streaming kernel frees)
   hipStream_t side[kSide] = {};
   hipEvent_t fork = nullptr, join[kSide] = {};
   bool any_side = false;
+  // the pair kernel of a launch with wind-vector pairs beside its
+  // per-variable kernel (WB2HIP_PAIR_STREAM=1; default: behind it)
+  hipStream_t pair_stream = nullptr;
+  hipEvent_t pair_join = nullptr;
+  bool any_pairs = false;
   // host seconds spent in replay, by phase (wb2_program_stats): waiting for a
   // ring slot, filling the table, the copy, the launches, the sinks
   double spent[5] = {};
@@ -101,8 +112,9 @@ inline double now_s() {
 
 int release(Program* p) {
   for (int i = 0; i < kRing; ++i) {
-    if (p->busy[i]) (void)hipEventSynchronize(p->copied[i]);
+    if (p->busy[i]) (void)hipEventSynchronize(p->done[i]);
     if (p->copied[i]) (void)hipEventDestroy(p->copied[i]);
+    if (p->done[i]) (void)hipEventDestroy(p->done[i]);
     if (p->pinned[i]) (void)hipHostFree(p->pinned[i]);
     if (p->device[i]) (void)hipFree(p->device[i]);
   }
@@ -113,7 +125,13 @@ int release(Program* p) {
     }
     if (p->join[i]) (void)hipEventDestroy(p->join[i]);
   }
+  if (p->pair_stream) {
+    (void)hipStreamSynchronize(p->pair_stream);
+    (void)hipStreamDestroy(p->pair_stream);
+  }
+  if (p->pair_join) (void)hipEventDestroy(p->pair_join);
   if (p->fork) (void)hipEventDestroy(p->fork);
+  if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
   delete p;
   return 0;
 }
@@ -176,6 +194,7 @@ int wb2_program_add_launch(void* program, const wb2_plan_tables* plan, int mode,
   la.table_offset = p->table_len;
   p->table_len += (long long)n;
   p->any_side = p->any_side || la.side;
+  p->any_pairs = p->any_pairs || (la.n_pair > 0 && !la.side);
   p->launches.push_back(std::move(la));
   return 0;
 }
@@ -264,7 +283,9 @@ int wb2_program_finalize(void* program, double* arena, int32_t n_ptrs,
     WB2_HIP_OK(hipHostMalloc(&p->pinned[i], bytes, hipHostMallocDefault));
     WB2_HIP_OK(hipMalloc(&p->device[i], bytes));
     WB2_HIP_OK(hipEventCreateWithFlags(&p->copied[i], hipEventDisableTiming));
+    WB2_HIP_OK(hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming));
   }
+  WB2_HIP_OK(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
   if (p->any_side) {
     int least = 0, greatest = 0;
     WB2_HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -274,6 +295,19 @@ int wb2_program_finalize(void* program, double* arena, int32_t n_ptrs,
       WB2_HIP_OK(hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming));
     }
     WB2_HIP_OK(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+  }
+  // measured (profiles/r06_round_log.md): beside each other the two kernels
+  // gain 2 % in 24-chunk windows and lose 5 % chunk by chunk -- off unless
+  // WB2HIP_PAIR_STREAM=1
+  static const bool pair_stream_on = [] {
+    const char* e = getenv("WB2HIP_PAIR_STREAM");
+    return e && e[0] == '1';
+  }();
+  if (p->any_pairs && pair_stream_on) {
+    WB2_HIP_OK(hipStreamCreateWithFlags(&p->pair_stream, hipStreamNonBlocking));
+    WB2_HIP_OK(hipEventCreateWithFlags(&p->pair_join, hipEventDisableTiming));
+    if (!p->fork)
+      WB2_HIP_OK(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
   }
   p->finalized = true;
   return 0;
@@ -298,7 +332,9 @@ int wb2_program_replay(void* program, const int64_t* ptrs, int32_t n_ptrs,
   const int r = p->next;
   p->next = (r + 1) % kRing;
   double t0 = now_s();
-  if (p->busy[r]) WB2_HIP_OK(hipEventSynchronize(p->copied[r]));
+  // (table r -- pinned and device -- is free once the replay that used it has
+  // finished; this is also what keeps the host at most kRing replays ahead)
+  if (p->busy[r]) WB2_HIP_OK(hipEventSynchronize(p->done[r]));
   double t1 = now_s();
   p->spent[0] += t1 - t0;
   t0 = t1;
@@ -328,8 +364,9 @@ int wb2_program_replay(void* program, const int64_t* ptrs, int32_t n_ptrs,
   p->spent[1] += t1 - t0;
   t0 = t1;
   WB2_HIP_OK(hipMemcpyAsync(p->device[r], table, bytes, hipMemcpyHostToDevice,
-                            s));
-  WB2_HIP_OK(hipEventRecord(p->copied[r], s));
+                            p->copy_stream));
+  WB2_HIP_OK(hipEventRecord(p->copied[r], p->copy_stream));
+  WB2_HIP_OK(hipStreamWaitEvent(s, p->copied[r], 0));
   p->busy[r] = true;
   t1 = now_s();
   p->spent[2] += t1 - t0;
@@ -345,10 +382,11 @@ int wb2_program_replay(void* program, const int64_t* ptrs, int32_t n_ptrs,
     if (la.n_pair > 0) {
       const long long n_det =
           (long long)WB2_NMETRIC * la.plan.n_region * la.n_outer;
-      return wb2_det_wind_suite_step(&la.plan, la.mode, la.dtype, la.skipna,
-                                     nullptr, slabs, aligned16, la.n_outer,
-                                     la.n_pair, la.partials, la.wind_partials,
-                                     metrics, metrics + n_det, ls);
+      hipStream_t ps = ls == s ? p->pair_stream : nullptr;
+      return det_wind_suite_step_streams(
+          &la.plan, la.mode, la.dtype, la.skipna, nullptr, slabs, aligned16,
+          la.n_outer, la.n_pair, la.partials, la.wind_partials, metrics,
+          metrics + n_det, ls, ps, ps ? p->pair_join : nullptr);
     }
     return wb2_det_suite_step(&la.plan, la.mode, la.dtype, la.skipna, nullptr,
                               slabs, aligned16, la.n_outer, la.partials,
@@ -356,8 +394,9 @@ int wb2_program_replay(void* program, const int64_t* ptrs, int32_t n_ptrs,
                               ls);
   };
   int n_side = 0;
+  if (p->any_side || p->pair_stream) WB2_HIP_OK(hipEventRecord(p->fork, s));
+  if (p->pair_stream) WB2_HIP_OK(hipStreamWaitEvent(p->pair_stream, p->fork, 0));
   if (p->any_side) {
-    WB2_HIP_OK(hipEventRecord(p->fork, s));
     for (size_t li = 0; li < p->launches.size(); ++li) {
       const Launch& la = p->launches[li];
       if (!la.side) continue;
@@ -404,6 +443,7 @@ int wb2_program_replay(void* program, const int64_t* ptrs, int32_t n_ptrs,
     }
     if (rc != 0) return rc;
   }
+  WB2_HIP_OK(hipEventRecord(p->done[r], s));
   p->spent[4] += now_s() - t0;
   ++p->replays;
   return 0;

@@ -26,6 +26,7 @@
 #include "trace.hpp"
 #include "reduce_common.hpp"
 #include "gauss_math.hpp"
+#include "suite_streams.hpp"
 #include "wb2hip.h"
 
 #include <atomic>
@@ -1665,7 +1666,8 @@ int stream_pairs_impl(int mode, int dtype, int skipna, const void* const* in,
                       const int32_t* chunk_row0, const int32_t* chunk_nrow,
                       int32_t n_chunk, int32_t n_ctile, const int32_t* seg_col0,
                       const int32_t* seg_eoff, int32_t n_seg, int32_t n_ts,
-                      double* partials, double* wind_partials, void* stream) {
+                      double* partials, double* wind_partials, void* stream,
+                      void* pair_stream = nullptr, void* join_event = nullptr) {
   WB2_REQUIRE(n_pair >= 0 && 2 * n_pair <= n_outer,
               "n_pair=%lld does not fit n_outer=%lld", (long long)n_pair,
               (long long)n_outer);
@@ -1736,17 +1738,28 @@ int stream_pairs_impl(int mode, int dtype, int skipna, const void* const* in,
   pp.wind_partials = wind_partials;
   pp.first = n_single;
   pp.n_pair = n_pair;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  // `pair_stream`: the pair kernel beside the per-variable kernel (their
+  // tails overlap); the caller has ordered pair_stream behind whatever made
+  // the inputs, `stream` waits for `join_event` before anything reads the
+  // pairs' partials
+  hipStream_t s = static_cast<hipStream_t>(pair_stream ? pair_stream : stream);
   const bool acc = mode == WB2_MODE_DET_ACC;
   if (dtype == WB2_F32)
-    return acc ? launch_pairs_flags<float, 4, true>(p, pp, skipna != 0,
-                                                    wfield != nullptr, s)
-               : launch_pairs_flags<float, 4, false>(p, pp, skipna != 0,
-                                                     wfield != nullptr, s);
-  return acc ? launch_pairs_flags<double, 2, true>(p, pp, skipna != 0,
+    rc = acc ? launch_pairs_flags<float, 4, true>(p, pp, skipna != 0,
+                                                  wfield != nullptr, s)
+             : launch_pairs_flags<float, 4, false>(p, pp, skipna != 0,
+                                                   wfield != nullptr, s);
+  else
+    rc = acc ? launch_pairs_flags<double, 2, true>(p, pp, skipna != 0,
                                                    wfield != nullptr, s)
              : launch_pairs_flags<double, 2, false>(p, pp, skipna != 0,
                                                     wfield != nullptr, s);
+  if (rc != 0 || !pair_stream) return rc;
+  WB2_REQUIRE(join_event != nullptr, "a pair stream needs a join event");
+  WB2_HIP_OK(hipEventRecord(static_cast<hipEvent_t>(join_event), s));
+  WB2_HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(stream),
+                                static_cast<hipEvent_t>(join_event), 0));
+  return 0;
 }
 
 }  // namespace
@@ -2083,7 +2096,22 @@ int wb2_det_wind_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
                             double* wind_partials, double* metrics,
                             double* wind_metrics, void* stream) {
   WB2_TRACE();
-  using namespace wb2;
+  return wb2::det_wind_suite_step_streams(
+      plan, mode, dtype, skipna, in, slab, aligned16, n_outer, n_pair, partials,
+      wind_partials, metrics, wind_metrics, stream, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace wb2 {
+int det_wind_suite_step_streams(const wb2_plan_tables* plan, int mode,
+                                int dtype, int skipna, const void* const* in,
+                                const int64_t* const* slab, int aligned16,
+                                int64_t n_outer, int64_t n_pair,
+                                double* partials, double* wind_partials,
+                                double* metrics, double* wind_metrics,
+                                void* stream, void* pair_stream,
+                                void* join_event) {
   WB2_REQUIRE(plan != nullptr, "null plan");
   WB2_EMPTY_OK(n_outer);
   WB2_REQUIRE(in != nullptr || slab != nullptr, "null pointer argument");
@@ -2095,7 +2123,7 @@ int wb2_det_wind_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
                              t.wfield, t.wfield_dtype, t.chunk_row0,
                              t.chunk_nrow, t.n_chunk, t.n_ctile, t.seg_col0,
                              t.seg_eoff, t.n_seg, t.n_ts, partials,
-                             wind_partials, stream);
+                             wind_partials, stream, pair_stream, join_event);
   if (rc != 0) return rc;
   const int nwf = t.wfield ? 2 : 1;
   rc = wb2_det_combine(mode, skipna, partials, n_outer, t.n_chunk, nwf, t.n_seg,
@@ -2109,6 +2137,9 @@ int wb2_det_wind_suite_step(const wb2_plan_tables* plan, int mode, int dtype,
                          t.region_wf, t.region_wsum, t.n_region, nullptr,
                          wind_metrics, stream);
 }
+}  // namespace wb2
+
+extern "C" {
 
 int wb2_gather_accumulate(const double* arena, const int32_t* src,
                           const uint8_t* round32, int64_t n_out, int64_t n_time,

@@ -1003,6 +1003,9 @@ def _same_values(a, b) -> bool:
   return a is b or np.array_equal(np.asarray(a), np.asarray(b))
 
 
+_CONCAT_PLANS: dict = {}   # concat_chunks: layout key -> per-variable layout
+
+
 def concat_chunks(datasets: t.Sequence, time_dim: str,
                   lead_dim: t.Optional[str] = None):
   """The chunks of a (time block x lead block) rectangle as ONE Dataset over
@@ -1106,11 +1109,44 @@ def concat_chunks(datasets: t.Sequence, time_dim: str,
   for ds in datasets[1:]:
     if len(ds.data_vars) != len(names):
       return None
+  # The layout of the variables is a function of the rectangle and of the
+  # first chunk's variables: windows of one evaluation come with the same one
+  # again and again.  A remembered layout leaves, per variable, one check of
+  # every chunk's array and a list of them.
+  plan_key = (time_dim, split, tuple(where), tuple(
+      (n, v.dims, tuple(v.shape), v.dtype, type(v.data))
+      for n, v in first.data_vars.items()))
+  plan = _CONCAT_PLANS.get(plan_key)
+  if plan is not None:
+    for name, (rdims, rshape, rdtype, kind, providers, template) in zip(
+        names, plan):
+      if providers is None:   # follows neither split dim: the first chunk's
+        ref = first.data_vars[name]
+        out.data_vars[name] = xl.DataArray(ref.data, rdims, coords, name)
+        continue
+      bases = []
+      is_array = kind is np.ndarray
+      for p in providers:
+        da = datasets[p].data_vars.get(name)
+        if da is None:
+          return None
+        data = da.data
+        if (da.dims != rdims or type(data) is not kind
+            or data.shape != rshape or data.dtype != rdtype
+            or not (data.flags.c_contiguous if is_array
+                    else data.is_contiguous())):
+          return None
+        bases.append(data)
+      out.data_vars[name] = xl.DataArray(template.with_bases(bases), rdims,
+                                         coords, name)
+    return out
+  new_plan = []
   for name in names:
     ref = first.data_vars[name]
     rdims, rshape, rdtype, kind = ref.dims, ref.shape, ref.dtype, type(ref.data)
     if not any(d in rdims for d in split):
       out.data_vars[name] = xl.DataArray(ref.data, rdims, coords, name)
+      new_plan.append((rdims, None, None, None, None, None))
       continue
     if (len(rdims) < 2 or set(rdims[-2:]) != {'latitude', 'longitude'}
         or any(size[d] != rshape[rdims.index(d)] for d in split
@@ -1119,8 +1155,8 @@ def concat_chunks(datasets: t.Sequence, time_dim: str,
     outer = rshape[:-2]
     n = int(np.prod(outer, dtype=np.int64))
     template = np.arange(n, dtype=np.int64).reshape(outer)
-    bases, cells = [], {}
-    for ds, at in zip(datasets, where):
+    bases, cells, providers = [], {}, []
+    for p, (ds, at) in enumerate(zip(datasets, where)):
       da = ds.data_vars.get(name)
       if da is None:
         return None
@@ -1134,9 +1170,18 @@ def concat_chunks(datasets: t.Sequence, time_dim: str,
         continue
       cells[at] = len(bases) * n + template
       bases.append(data)
+      providers.append(p)
     index = assemble(rdims[:-2], outer, cells, np.int64)
-    out.data_vars[name] = xl.DataArray(
-        xl.SlabConcat(bases, index, uniform=True), rdims, coords, name)
+    joined = xl.SlabConcat(bases, index, uniform=True)
+    out.data_vars[name] = xl.DataArray(joined, rdims, coords, name)
+    # (the plain lazy containers only: their arrays are what `kind` says)
+    rememberable = kind is np.ndarray or xl._is_torch(bases[0])
+    new_plan.append((rdims, tuple(rshape), rdtype, kind, providers,
+                     joined.with_bases(())) if rememberable else None)
+  if all(e is not None for e in new_plan):
+    if len(_CONCAT_PLANS) >= 32:
+      _CONCAT_PLANS.clear()
+    _CONCAT_PLANS[plan_key] = new_plan
   return out
 
 

@@ -142,8 +142,9 @@ def _digest(v: np.ndarray):
 
 def _data_sig(data):
   if isinstance(data, torch.Tensor):
-    return ('t', data.shape, data.stride(), data.dtype, data.device,
-            data.data_ptr() % 16)
+    # (not the alignment of the address: the replay picks the kernel for the
+    # addresses it is given, chunk by chunk)
+    return ('t', data.shape, data.stride(), data.dtype, data.device)
   if isinstance(data, xl.SlabConcat) and data.on_device:
     b = data.bases[0]
     return ('c', tuple(data.shape), len(data.bases), tuple(b.shape),
@@ -759,7 +760,10 @@ class _Native:
       slot = np.ascontiguousarray(remap[la.slot], dtype=np.int32)
       rel = np.ascontiguousarray(la.rel, dtype=np.int64)
       step = la.step
-      side = int(la.mode == _lib.MODE_SEEPS and la.n_total <= 8)
+      # SEEPS passes beside the streaming launch: one slab per chunk (two
+      # latency-bound launches chunk by chunk) and VALU-bound at any size --
+      # next to an HBM-bound kernel they cost next to nothing
+      side = int(la.mode == _lib.MODE_SEEPS)
       wind = getattr(step, 'wind_partials', None)
       _lib.check(lib.wb2_program_add_launch(
           handle, step._tables_ref, la.mode, step.code, int(la.skipna),
@@ -816,6 +820,7 @@ class _Native:
     self._sink_at = self.sink_args.ctypes.data
     self._replay = lib.wb2_program_replay
     self._no_values = np.zeros(1, dtype=np.int64)
+    self._values_of: dict = {}
 
   @staticmethod
   def _stats(lib, handle) -> dict:
@@ -848,9 +853,21 @@ class _Native:
     for i, g in self.getters:
       ptrs[i] = g(forecast, truth).data_ptr()
     if self.values:
-      memo: dict = {}
-      values = (self.values[0](forecast, memo) if len(self.values) == 1 else
-                np.concatenate([v(forecast, memo) for v in self.values]))
+      # the climatology slabs of the chunk's valid times: label work on a few
+      # time stamps, remembered per time stamp set (a valid time comes back
+      # with every lead that reaches it)
+      from weatherbench2_amd import metrics as gm
+      vt, dims = gm._valid_times(forecast)
+      key = vt.tobytes()
+      values = self._values_of.get(key)
+      if values is None:
+        memo: dict = {'valid_times': (forecast, vt, dims)}
+        values = (self.values[0](forecast, memo) if len(self.values) == 1
+                  else np.concatenate([v(forecast, memo)
+                                       for v in self.values]))
+        if len(self._values_of) >= 4096:
+          self._values_of.clear()
+        self._values_of[key] = values
     else:
       values = self._no_values
     rows, args = None, self.sink_args

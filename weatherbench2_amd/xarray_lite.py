@@ -201,6 +201,17 @@ class SlabConcat:
     if index.size and (index.max() >= self.n_slab or index.min() < 0):
       raise IndexError(f'slab index out of range [0, {self.n_slab})')
 
+  def with_bases(self, bases) -> 'SlabConcat':
+    """The same concatenation over other arrays -- as many, shaped and typed
+    like this one's (the caller vouches): the index, its range check and the
+    offsets are shared, not recomputed (evaluation.concat_chunks builds the
+    same layout for window after window)."""
+    out = SlabConcat.__new__(SlabConcat)
+    out.slab_shape, out.index = self.slab_shape, self.index
+    out.offsets, out.n_slab = self.offsets, self.n_slab
+    out.bases = list(bases)
+    return out
+
   @property
   def shape(self):
     return tuple(self.index.shape) + self.slab_shape
