@@ -363,3 +363,41 @@ def test_map_results_without_skipna_keep_no_count_map():
     assert np.array_equal(got.values, exact, equal_nan=True)
     np.testing.assert_allclose(got.values, want, rtol=1e-12, equal_nan=True)
     assert np.isnan(got.values[0, 1, 7, 9]) == (not skipna)
+
+
+@pytest.mark.parametrize('skipna', [False, True])
+@pytest.mark.parametrize('k', [1, 3, 8])
+@pytest.mark.parametrize('order', ['init', 'lead'])
+def test_windows_accumulate_k_chunks_of_a_lead_per_launch(order, k, skipna,
+                                                          monkeypatch):
+  """xbeam.Mean combines any number of chunks per key before touching the
+  output (evaluation.py:735-744): inside a window the chunks that carry the
+  same lead label are added by ONE launch (k time steps of that lead: the
+  running sums are loaded and stored once) -- the additions of k separate
+  launches in the same order, so the bits of chunk by chunk, whatever k and
+  whatever the order of the chunk list."""
+  from weatherbench2_amd import evaluation, map_suite
+  n_lead = 3
+  forecast, truth, gf, gt, cfg = _setup(n_init=8, n_lead=n_lead, n_lat=19,
+                                        n_lon=36,
+                                        nan_frac=0.02 if skipna else 0.0)
+  chunks = oc.chunk_pairs(gf, gt, order=order)
+  want = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                    batch_chunks=1)
+  groups = []
+  real = map_suite.MapSuite.run_many
+
+  def run_many(self, pairs, mean):
+    groups.append(len(pairs))
+    return real(self, pairs, mean)
+  monkeypatch.setattr(map_suite.MapSuite, 'run_many', run_many)
+  # init-major: a window of k * n_lead chunks holds k chunks of every lead;
+  # lead-major: k consecutive chunks share their lead
+  window = k * n_lead if order == 'init' else k
+  got = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                   batch_chunks=window)
+  _same(got, want)
+  if k > 1:
+    assert max(groups) == k, groups
+    # every chunk but the generic first one went through a group
+    assert sum(groups) == len(chunks) - 1, groups

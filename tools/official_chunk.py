@@ -214,13 +214,25 @@ def spatial_config(cfg=None):
 SPATIAL_BYTES_PER_POINT = 8.0 + 3 * 16.0
 
 
-def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256) -> dict:
-  """`deterministic_spatial` through evaluate_chunks, chunk by chunk (windows
-  of map-metric chunks are not joined).  The first chunk of a structure takes
-  the generic path and result() brings 8.5 GB of mean maps to the host --
-  one-offs that a production run spreads over ~10^4 chunks: reported are the
-  fused kernel (map_suite.py) under HIP events, the host time per chunk from
-  two list lengths (up to the moment result() is called), and the walls."""
+def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256,
+                    n_lead: int = 4) -> dict:
+  """`deterministic_spatial` through evaluate_chunks: in windows of 8 chunks
+  per lead label (the headline: one accumulate launch adds the k = 8 time
+  steps of a lead, the running sums cross HBM once per 8 chunks) and chunk by
+  chunk (k = 1)."""
+  legs = {'window': _measure_spatial(chunks, cfg, short, long, 8 * n_lead, 8),
+          'chunk_by_chunk': _measure_spatial(chunks, cfg, short, long, 1, 1)}
+  out = dict(legs['window'])
+  out['by_window'] = legs
+  return out
+
+
+def _measure_spatial(chunks, cfg, short, long, batch, k) -> dict:
+  """One window size.  The first chunk of a structure takes the generic path
+  and result() brings 8.5 GB of mean maps to the host -- one-offs that a
+  production run spreads over ~10^4 chunks: reported are the fused kernel
+  (map_suite.py) under HIP events, the host time per chunk from two list
+  lengths (up to the moment result() is called), and the walls."""
   import torch
   from weatherbench2_amd import engine, evaluation
   cfg = spatial_config(cfg)
@@ -244,7 +256,7 @@ def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256) -> dict:
       torch.cuda.synchronize()
       t0 = time.perf_counter()
       out = evaluation.evaluate_chunks(chunks[:n], cfg, False, prefetch=0,
-                                       batch_chunks=1)
+                                       batch_chunks=batch)
       torch.cuda.synchronize()
       walls[n] = time.perf_counter() - t0
       hosts[n] = marks['enqueued'] - t0
@@ -255,29 +267,37 @@ def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256) -> dict:
   torch.cuda.empty_cache()
   host_ms = (hosts[long] - hosts[short]) / (long - short) * 1e3
   ms = [a.elapsed_time(b) for a, b in ev.pairs]
-  kernel_ms = sum(ms) / max(len(ms), 1)
-  bytes_per_chunk = PTS_PER_CHUNK * SPATIAL_BYTES_PER_POINT
+  # (the first chunk of the list goes through the generic path: the launches
+  # cover the other long - 1)
+  kernel_ms = sum(ms) / max(long - 1, 1)
+  # per chunk and grid point: 8 B of forecast + truth; the three float64
+  # running sums read and written once per k chunks
+  per_point = 8.0 + 48.0 / k
+  bytes_per_chunk = PTS_PER_CHUNK * per_point
   steady_ms = max(kernel_ms, host_ms)
   return {
-      'batch_chunks': 1, 'value': PTS_PER_CHUNK / steady_ms * 1e3,
+      'batch_chunks': batch, 'chunks_per_lead_and_launch': k,
+      'value': PTS_PER_CHUNK / steady_ms * 1e3,
       'unit': 'grid-point-evals/s',
       'steady_ms_per_chunk': steady_ms, 'host_ms_per_chunk': host_ms,
-      'wall_s': {str(k): v for k, v in walls.items()},
+      'wall_s': {str(n): v for n, v in walls.items()},
       'fused_launches': len(ms),
       'roofline': {
           'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
           'kernel': 'spatial_accumulate_addr_kernel<float,4,false> over '
-                    f'{SLABS_PER_CHUNK} destinations x 1 step',
+                    f'{SLABS_PER_CHUNK} destinations x {k} steps',
           'kernel_ms_per_chunk': kernel_ms,
+          'algorithmic_bytes_per_point': per_point,
           'algorithmic_bytes_per_chunk': bytes_per_chunk,
           'achieved': bytes_per_chunk / kernel_ms / 1e6,
           'frac': bytes_per_chunk / kernel_ms / 1e6 / HBM_PEAK_GBPS,
       },
       'metrics': list(cfg.metrics),
       'what': 'bias + mse + mae maps of 13 variables (85 slabs) per chunk '
-              'into the float64 running means: 8 B/pt read + 3 x 16 B/pt '
-              'read-modify-write (the fused kernel; the two SpatialSEEPS maps '
-              'of --compute_seeps are computed and accumulated per slab beside '
+              'into the float64 running means: 8 B/pt read per chunk + 3 x 16 '
+              'B/pt read-modify-write of the sums per launch of k chunks of '
+              'one lead (the fused kernel; the two SpatialSEEPS maps of '
+              '--compute_seeps are computed and accumulated per slab beside '
               'it); `value` = points per chunk / max(kernel, '
               'host) time per chunk (the walls include the generic first '
               'chunk and the 8.5 GB result copy)',

@@ -753,6 +753,13 @@ __global__ void __launch_bounds__(512)
 #ifndef WB2_PAIR_WAVES
 #define WB2_PAIR_WAVES 0        // > 0: waves per SIMD the register budget is cut to
 #endif
+#ifndef WB2_PAIR_RELOAD
+// 1: no LDS hand-off and no barrier -- the v wave loads the u slab's forecast
+// and truth itself (the u wave of the same workgroup streams them at about the
+// same time: L2 / L1 hits, no HBM traffic of their own if the caches hold) and
+// forms du^2 with the u wave's arithmetic.  The two waves run free.
+#define WB2_PAIR_RELOAD 0
+#endif
 #if WB2_PAIR_WAVES > 0
 #define WB2_PAIR_OCCUPANCY \
   __attribute__((amdgpu_waves_per_eu(WB2_PAIR_WAVES, WB2_PAIR_WAVES)))
@@ -812,6 +819,21 @@ __global__ void __launch_bounds__(128) WB2_PAIR_OCCUPANCY
     base[i] = reinterpret_cast<const T*>(static_cast<const char*>(p.in[i]) +
                                          slab_idx[i] * p.slab_step_bytes) +
               (long long)row0 * p.n_col;
+#if WB2_PAIR_RELOAD
+  // the u slab's forecast and truth, for the v wave
+  const T* ubase[2];
+  {
+    const long long ou = pp.first + pair;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long su = p.slab[i] ? p.slab[i][ou] : ou;
+      ubase[i] = reinterpret_cast<const T*>(
+                     static_cast<const char*>(p.in[i]) +
+                     su * p.slab_step_bytes) +
+                 (long long)row0 * p.n_col;
+    }
+  }
+#endif
   const FT* wfp = WF ? static_cast<const FT*>(p.wfield) +
                            (long long)row0 * p.n_col
                      : nullptr;
@@ -942,12 +964,16 @@ __global__ void __launch_bounds__(128) WB2_PAIR_OCCUPANCY
     for (int u = 0; u < N; ++u) {
       T sq[VEC];
       consume(std::false_type{}, acc, accw, v[u], wf[u], wr[u], sq);
+#if !WB2_PAIR_RELOAD
       VT out;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) out[e] = sq[e];
       handoff[buf][u][lane] = out;
+#endif
     }
+#if !WB2_PAIR_RELOAD
     __syncthreads();
+#endif
   };
   auto batch_v = [&](auto n_c, int r, int buf) {
     constexpr int N = decltype(n_c)::value;
@@ -955,6 +981,42 @@ __global__ void __launch_bounds__(128) WB2_PAIR_OCCUPANCY
     double wf[N][VEC], wr[N];
 #pragma unroll
     for (int u = 0; u < N; ++u) load_row(r + u, v[u], wf[u], wr[u]);
+#if WB2_PAIR_RELOAD
+    T uu[N][2][VEC];
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        load_vec<T, VEC>(at(ubase[i] + (long long)(r + u) * p.n_col),
+                         uu[u][i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      T sq[VEC];
+      if constexpr (PAIRS) {   // the u wave's own arithmetic (packed)
+        typedef T V2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int e = 0; e < VEC; e += 2) {
+          V2 a, b;
+          a[0] = uu[u][0][e];
+          a[1] = uu[u][0][e + 1];
+          b[0] = uu[u][1][e];
+          b[1] = uu[u][1][e + 1];
+          const V2 d = a - b;
+          const V2 q = d * d;
+          sq[e] = q[0];
+          sq[e + 1] = q[1];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const T d = uu[u][0][e] - uu[u][1][e];
+          sq[e] = d * d;
+        }
+      }
+      consume(std::true_type{}, acc, accw, v[u], wf[u], wr[u], sq);
+    }
+#else
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #pragma unroll
@@ -965,6 +1027,7 @@ __global__ void __launch_bounds__(128) WB2_PAIR_OCCUPANCY
       for (int e = 0; e < VEC; ++e) sq[e] = theirs[e];
       consume(std::true_type{}, acc, accw, v[u], wf[u], wr[u], sq);
     }
+#endif
   };
   int r = 0, it = 0;
   if (role == 0) {

@@ -1326,6 +1326,46 @@ def _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks,
 VERIFY_EVERY = int(os.environ.get('WB2HIP_CHUNK_PROGRAM_VERIFY_EVERY', '256'))
 
 
+def _evaluate_map_window(window, configs, skipna, sinks, programs,
+                         lead_dim) -> None:
+  """A window of chunks through map-metric configs (`deterministic_spatial`,
+  scripts/evaluate.py:431-435, 471-478).  `xbeam.Mean` combines any number of
+  chunks per key before it touches the output (evaluation.py:735-744): the
+  chunks of the window whose map suite exists and that carry the same lead
+  labels are accumulated by ONE launch per suite, in chunk order (the running
+  sums cross HBM once per group instead of once per chunk -- same additions,
+  same order, same bits as chunk by chunk).  A chunk that needs the generic
+  path (the first of its structure) goes alone, after everything queued
+  before it."""
+  from weatherbench2_amd import map_suite, metrics as gm, program
+  pending: dict = {}   # (structure, lead labels) -> [prog, [(forecast, truth)]]
+
+  def drain():
+    for prog, pairs in pending.values():
+      with gm.chunk_scope():
+        for suite, idx in prog.parts:
+          suite.run_many(pairs, sinks[idx[0]])
+    pending.clear()
+  replayable = program.mode() != '0' and all(
+      s._on_gpu_or_unset() for s in sinks)
+  for forecast, truth_chunk in window:
+    sig = program.signature(forecast, truth_chunk) if replayable else None
+    prog = programs.get(sig) if sig is not None else None
+    suites = prog and all(isinstance(r, map_suite.MapSuite) and len(idx) == 1
+                          for r, idx in prog.parts)
+    if not suites or program.mode() == 'verify':
+      drain()
+      _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks, programs)
+      continue
+    labels = forecast.coords.get(lead_dim) if lead_dim else None
+    if isinstance(labels, xl.DataArray):
+      labels = labels.values
+    key = (sig, None if labels is None else
+           (np.asarray(labels).dtype.str, np.asarray(labels).tobytes()))
+    pending.setdefault(key, [prog, []])[1].append((forecast, truth_chunk))
+  drain()
+
+
 def _verify_program(prog, forecast, truth_chunk, configs, skipna, sinks):
   """WB2HIP_CHUNK_PROGRAM=verify: the chunk through the program AND through the
   generic path, each from the same accumulator state -- they must leave the
@@ -1476,7 +1516,12 @@ def evaluate_chunks(
   substitute = _chunk_substitution(configs[0], truth, climatology, by_init)
   auto_batch = batch_chunks is None
   batch_chunks = AUTO_BATCH_MAX if auto_batch else max(1, int(batch_chunks))
-  if any(c.derived_variables or not all(
+  from weatherbench2_amd import map_suite
+  # map-metric configs (`deterministic_spatial`): windows too -- the chunks of
+  # a window that carry the same lead labels go through ONE accumulate launch
+  # (map_suite.MapSuite.run_many)
+  maps_only = all(map_suite.applies(c) for c in configs)
+  if not maps_only and any(c.derived_variables or not all(
       getattr(m, '_reads_slabs_in_place', False)
       for m in c.metrics.values()) for c in configs):
     # Chunks are batched only for metrics that read a concatenation in place
@@ -1506,8 +1551,12 @@ def evaluate_chunks(
           sinks.append(RunningMean(time_dim, skipna, device,
                                    split_dim=lead_dim,
                                    split_order='first_seen'))
-    for forecast, truth_chunk in _batches(window, time_dim, lead_dim):
-      _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks, programs)
+    if maps_only:
+      _evaluate_map_window(window, configs, skipna, sinks, programs, lead_dim)
+    else:
+      for forecast, truth_chunk in _batches(window, time_dim, lead_dim):
+        _evaluate_piece(forecast, truth_chunk, configs, skipna, sinks,
+                        programs)
     window.clear()
 
   with metrics_lib.pinned_rows_per_chunk(EVALUATE_ROWS_PER_CHUNK):

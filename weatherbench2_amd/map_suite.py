@@ -67,6 +67,7 @@ class MapSuite:
     self._plan = None   # _Plan of the structure, after the first run
     self._keep = None
     self._const: dict = {}  # variable -> (offsets [metric][dst], lead, block)
+    self._fast_extras: dict = {}  # (variable, metric index) -> _FastSeeps
 
   def reset(self):
     pass
@@ -104,6 +105,35 @@ class MapSuite:
     for name, m, metric in self.extras:
       self._extra(name, m, metric, forecast, truth, mean)
 
+  def run_many(self, pairs, mean) -> None:
+    """k chunks that carry the SAME lead labels, in chunk order, as ONE
+    launch: the running sums of their destinations are loaded once, the k
+    chunks' time steps added one after the other in chunk order, and stored --
+    the additions of k runs of `run`, in the same order: the same bits, at
+    (8 k + 48) / k instead of 56 bytes of HBM traffic per grid point and
+    chunk (xbeam.Mean combines any number of chunks per key before it touches
+    the output, evaluation.py:735-744)."""
+    plan = self._plan
+    if len(pairs) == 1 or plan is None or not all(
+        plan.matches(f, t_) for f, t_ in pairs):
+      for f, t_ in pairs:
+        self.run(f, t_, mean)
+      return
+    per_chunk = [plan.tables(f, t_, mean, self) for f, t_ in pairs]
+    groups = {}
+    last = per_chunk[-1]   # (a row met by a later chunk may have grown the
+    for key in last:       #  accumulators: the addresses of the last table)
+      fa = np.concatenate([tab[key][0] for tab in per_chunk], axis=0)
+      ta = np.concatenate([tab[key][1] for tab in per_chunk], axis=0)
+      dtype, n_point, _ = key
+      groups[(dtype, n_point, fa.shape[0])] = (fa, ta, last[key][2],
+                                               last[key][3])
+    self._launch(groups)
+    self._fill(mean)
+    for f, t_ in pairs:
+      for name, m, metric in self.extras:
+        self._extra(name, m, metric, f, t_, mean)
+
   def _fill(self, mean):
     """Without skipna a metric that lacks the variable leaves NaN sums (NaN
     maps were added): rows this suite meets first get them here."""
@@ -122,6 +152,14 @@ class MapSuite:
   def _extra(self, name, m, metric, forecast, truth, mean):
     """A single-variable map metric (SpatialSEEPS): its own chunk map, added to
     the slabs of (metric m, variable) -- one destination entry per slab."""
+    fast = self._fast_extras.get((name, m))
+    if fast is None:
+      # the generic way below once per structure, then what it did replayed
+      # from the chunk's pointers and valid times (two C-ABI calls per chunk)
+      self._fast_extras[(name, m)] = _FastSeeps.build(
+          self, name, m, metric, forecast, truth) or False
+    elif fast and fast.matches(forecast, truth):
+      return fast.run(forecast, truth, mean)
     ds = metric.compute_chunk(forecast, truth)
     da = ds[name]
     const, lead, block, n_point = self._const[name]
@@ -241,6 +279,100 @@ class MapSuite:
       if hook is not None:
         hook('end', 'spatial_accumulate')
     self._keep = None  # the launches are enqueued: the allocator orders reuse
+
+
+class _FastSeeps:
+  """One SpatialSEEPS entry of a map suite for the later chunks of a
+  structure: metrics.SpatialSEEPS.compute_chunk + engine.time_accumulate as
+  two C-ABI calls on recorded arguments (wb2_seeps_map into a buffer of its
+  own, wb2_time_accumulate_runs into the running sums) -- the generic path's
+  kernels on the generic path's arguments, so its bits.  Per chunk: the
+  precipitation arrays' pointers, the wet-threshold slab of every valid time
+  (metrics._climatology_gather), the accumulator rows of the lead labels."""
+
+  @classmethod
+  def build(cls, suite, name, m, metric, forecast, truth):
+    try:
+      return cls(suite, name, m, metric, forecast, truth)
+    except (ValueError, KeyError, TypeError):
+      return None
+
+  def __init__(self, suite, name, m, metric, forecast, truth):
+    if type(metric) is not gm.SpatialSEEPS or suite.time_dim is None:
+      raise ValueError('not a SpatialSEEPS entry')
+    f, t_ = gm._inputs(forecast, truth)
+    geo, arrays, tables, aux = metric._prepare(f, t_)
+    fdata, tdata, wdata = arrays
+    if tables[0] is not None or tables[1] is not None:
+      raise ValueError('forecast / truth are read through a slab table')
+    for x in (fdata, tdata, wdata):
+      if not (isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous()):
+        raise ValueError('an input is not a contiguous device tensor')
+    if not (fdata.dtype == tdata.dtype == wdata.dtype) or (
+        fdata.dtype not in engine._DTYPES):
+      raise ValueError('inputs differ in dtype')
+    if fdata is not f[name].data or tdata is not t_[name].data:
+      raise ValueError('the pass read a copy of the chunk')
+    climatology = xl.as_dataset(metric.climatology)
+    wvar = climatology[f'{name}_seeps_threshold']
+    wrest = tuple(d for d in wvar.dims if d not in gm._SPATIAL)
+    self.gather = gm._climatology_gather(climatology, wvar, f, geo, wrest)
+    self.suite, self.name, self.m = suite, name, m
+    self.layouts = (_layout(fdata), _layout(tdata))
+    self.code = engine._DTYPES[fdata.dtype]
+    self.n_outer = geo.n_outer
+    self.n_point = int(fdata.shape[-2]) * int(fdata.shape[-1])
+    self.slab_bytes = self.n_point * fdata.element_size()
+    self.wet = wdata
+    self.aux = gm._resident_aux(aux, suite.device).reshape(-1)
+    self.scalar = float(metric.dry_threshold_mm / 1000.0)
+    self.out = torch.empty((self.n_outer, self.n_point), dtype=torch.float64,
+                           device=suite.device)
+    # the map as the metric hands it over: out_dims + the two spatial dims
+    axis = geo.out_dims.index(suite.time_dim)
+    shape = tuple(geo.out_shape)
+    self.n_lead = int(np.prod(shape[:axis], dtype=np.int64))
+    self.n_time = int(shape[axis])
+    self.n_tail = int(np.prod(shape[axis + 1:], dtype=np.int64)) * self.n_point
+    self._lib = _lib.load()
+
+  def matches(self, forecast, truth) -> bool:
+    return (_layout(forecast[self.name].data) == self.layouts[0] and
+            _layout(truth[self.name].data) == self.layouts[1])
+
+  def run(self, forecast, truth, mean) -> None:
+    import ctypes
+    suite, lib = self.suite, self._lib
+    dev = suite.device
+    stream = engine.current_stream_ptr(dev)
+    g = self.gather
+    table = g['values'](forecast)[g['cell']] + g['base']
+    wet_ptr, wet_tab = self.wet.data_ptr(), None
+    if self.n_outer == 1:   # one slab: its address, no table to upload
+      wet_ptr += int(table[0]) * self.slab_bytes
+    else:
+      wet_tab = engine.upload_table(table, dev)
+    ins = (ctypes.c_void_p * 3)(forecast[self.name].data.data_ptr(),
+                                truth[self.name].data.data_ptr(), wet_ptr)
+    tabs = (ctypes.c_void_p * 3)(None, None, _lib.ptr(wet_tab) or None)
+    status = lib.wb2_seeps_map(self.code, ins, tabs, self.n_outer,
+                               self.n_point, self.aux.data_ptr(), self.scalar,
+                               self.out.data_ptr(), stream)
+    if status != 0:
+      _lib.check(status, 'wb2_seeps_map')
+    const, lead, block, n_point = suite._const[self.name]
+    acc = mean._acc[self.name]
+    rows = 0
+    if acc.split is not None:
+      rows = acc.rows(np.asarray(forecast.coords[acc.split]))[lead]
+    dst = engine.upload_table(rows * block + const[self.m], dev)
+    status = lib.wb2_time_accumulate_runs(
+        _lib.WB2_F64, self.out.data_ptr(), self.n_lead, self.n_time,
+        self.n_tail, int(suite.skipna), dst.data_ptr(), n_point,
+        acc.total.data_ptr(),
+        acc.count.data_ptr() if suite.skipna else None, stream)
+    if status != 0:
+      _lib.check(status, 'wb2_time_accumulate_runs')
 
 
 def _inside(x: torch.Tensor, lo: int, hi: int) -> bool:
