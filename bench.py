@@ -160,7 +160,7 @@ class KernelTimer:
     return float(np.mean([a.elapsed_time(b) for a, b in self.pairs]))
 
 
-def cpu_baseline(seconds: float = 6.0) -> dict:
+def cpu_baseline(seconds: float = 4.0) -> dict:
   """Times the NumPy oracle (the restated reference path: one metric x one
   region at a time, like evaluation.py:408-435) on this box's host cores: one
   process, then one process per PHYSICAL core, then one per logical core
@@ -674,6 +674,39 @@ def main():
 
   solo = rank == 0 and world == 1
 
+  # ---- the WHOLE configs[1] job on one GPU: 730 init times x 4 lead times =
+  # 2 920 units, 183 steps of `units` (the last one partial) through the same
+  # bound calls in one timed region -- that the 20-step headline rate holds for
+  # the 78 ms the job takes
+  if solo and not strong:
+    try:
+      job_units = 2920
+      job_steps = -(-job_units // units)
+      sizes = [min(units, job_units - s_ * units) for s_ in range(job_steps)]
+      for n_u in sorted(set(sizes) - set(suites)):
+        st = engine.SuiteStep(pl, _lib.MODE_DET_ACC, torch.float32, False,
+                              n_u * N_LEV)
+        st.accumulate_into(total, count, (_lib.NMETRIC * nr, n_u, N_LEV))
+        suites[n_u] = st
+      job_tabs = [tables(s_ * units, n_u) for s_, n_u in enumerate(sizes)]
+      job_calls = [suites[n_u].bind([fpool, tpool, cpool], list(tabs))
+                   for tabs, n_u in zip(job_tabs, sizes)]
+      ramp(lambda: step(0, False), args.ramp_ms)
+      dt_job, _, gpu_job = timed_region(lambda i: job_calls[i](), job_steps,
+                                        [total, count])
+      out['config1_full_job'] = {
+          'value': job_units * PTS_PER_UNIT / dt_job,
+          'unit': 'grid-point-evals/s', 'units': job_units,
+          'steps': job_steps, 'ms': dt_job * 1e3, 'gpu_ms': gpu_job,
+          'vs_headline': job_units * PTS_PER_UNIT / dt_job / out['value'],
+          'what': ('BASELINE configs[1] in full: 730 init x 4 lead = 2920 '
+                   f'units of 13 x 721 x 1440 f32, {job_steps} suite steps of '
+                   f'{units} units (the last of {sizes[-1]}), one timed '
+                   'region, one running mean')}
+      del job_calls, job_tabs
+    except Exception as e:
+      out['config1_full_job'] = {'error': f'{type(e).__name__}: {e}'}
+
   def leg(name, fn, *a, **k):
     """A secondary leg never costs the run its headline: errors are recorded
     under the leg's key (and show in the contract line's `errors` list)."""
@@ -698,7 +731,7 @@ def main():
     import official_chunk
     leg('api_official_chunk', official_chunk.run, dev,
         batches=(1, 16, 32, None) if args.detail else (1, None),
-        host_fed=True)
+        host_fed='both' if args.detail else True)
   if solo and not args.no_secondary:
     # ---- BASELINE configs[2] / configs[3], each with its own roofline;
     # bounded step counts keep the whole run in minutes
@@ -822,6 +855,9 @@ def compact(out: dict) -> dict:
     line['cpu_baseline']['sample'] = cb.get('sample_short') or str(
         cb.get('sample', ''))[:200]
   line['unramped'] = _pick(out.get('unramped', {}), 'value', 'ms_per_step')
+  if 'config1_full_job' in out:
+    line['config1_full_job'] = _pick(out['config1_full_job'], 'value', 'units',
+                                     'steps', 'ms', 'vs_headline', 'error')
   if out['n_gpus'] > 1 or out['ranks']['backend']:
     line['ranks'] = out['ranks']
   if 'map_allreduce' in out:
@@ -852,11 +888,17 @@ def compact(out: dict) -> dict:
   if 'api_official_chunk' in out:
     oc = out['api_official_chunk']
     line['api_official_chunk'] = _pick(oc, 'value', 'batch_chunks',
-                                       'wall_ms_per_chunk', 'error')
+                                       'wall_ms_per_chunk', 'chunks', 'error')
+    roof = oc.get('roofline') or {}
+    if roof:
+      line['api_official_chunk']['roofline'] = _pick(
+          roof, 'frac', 'k1_ms_per_chunk', 'traffic_over_algorithmic')
     by = oc.get('by_batch_chunks') or {}
     if '1' in by:
-      line['api_official_chunk']['chunk_by_chunk'] = _pick(
-          by['1'], 'value', 'host_ms_per_chunk')
+      line['api_official_chunk']['chunk_by_chunk'] = dict(
+          _pick(by['1'], 'value', 'host_ms_per_chunk'),
+          k1_ms_per_chunk=(by['1'].get('roofline') or {}).get(
+              'k1_ms_per_chunk'))
     if 'host_fed' in oc:
       line['api_official_chunk']['host_fed'] = _pick(
           oc['host_fed'], 'value', 'h2d_GBps', 'wall_ms_per_chunk', 'error')
@@ -872,10 +914,15 @@ def compact(out: dict) -> dict:
     if 'deterministic_spatial' in oc:
       ds = oc['deterministic_spatial']
       line['api_official_chunk']['deterministic_spatial'] = _pick(
-          ds, 'value', 'steady_ms_per_chunk', 'error')
+          ds, 'value', 'steady_ms_per_chunk', 'chunks_per_lead_and_launch',
+          'error')
       if 'roofline' in ds:
         line['api_official_chunk']['deterministic_spatial']['frac'] = (
             ds['roofline'].get('frac'))
+      k1 = (ds.get('by_window') or {}).get('chunk_by_chunk') or {}
+      if 'value' in k1:
+        line['api_official_chunk']['deterministic_spatial'][
+            'chunk_by_chunk'] = k1['value']
   if 'pcie_inclusive' in out:
     pc = out['pcie_inclusive']
     line['pcie_inclusive'] = {
