@@ -125,7 +125,9 @@ def test_bound_calls_and_address_form(dev):
 
 
 def test_suite_step_matches_oracle(dev):
-  """One step's metrics against the NumPy oracle for every region."""
+  """One step's metrics against the NumPy oracle for every region: MSE, RMSE,
+  MAE, Bias and -- through a climatology with its (hour, dayofyear) gather --
+  ACC (metrics.py:236-301, 319-330, 348-359, 377-414)."""
   import torch
   from oracle import metrics_np as om
   from oracle.named import DS, NA
@@ -143,13 +145,26 @@ def test_suite_step_matches_oracle(dev):
   dims = ('level', 'latitude', 'longitude')
   fd, td = (DS({'z': NA(x, dims)}, coords) for x in (f, t))
   oregions = helpers.predefined_regions(oracle=True)
+  # ACC as the reference computes it: the climatology selected at the valid
+  # time's (dayofyear, hour), anomalies in float32, three spatial averages
+  day = np.datetime64('2020-01-03T00', 'ns')
+  tcoords = dict(coords, time=np.array([day]))
+  tdims = ('time',) + dims
+  ft, tt = (DS({'z': NA(x[None], tdims)}, tcoords) for x in (f, t))
+  clim = DS({'z': NA(np.stack([c + 1, c + 2, c, c - 1])[None],
+                     ('hour', 'dayofyear') + dims)},
+            dict(coords, hour=np.array([0]), dayofyear=np.arange(1, 5)))
+  suite = {'mse': om.MSE(), 'rmse': om.RMSESqrtBeforeTimeAvg(),
+           'mae': om.MAE(), 'bias': om.Bias()}
   for ri, (name, region) in enumerate(oregions.items()):
-    want = om.MSE().compute_chunk(fd, td, region=region)['z'].data
-    np.testing.assert_allclose(got[_lib.METRIC_INDEX['mse'], ri], want,
-                               rtol=1e-9, err_msg=name)
-    want = om.MAE().compute_chunk(fd, td, region=region)['z'].data
-    np.testing.assert_allclose(got[_lib.METRIC_INDEX['mae'], ri], want,
-                               rtol=1e-9, err_msg=name)
+    for mname, metric in suite.items():
+      want = metric.compute_chunk(fd, td, region=region)['z'].data
+      np.testing.assert_allclose(got[_lib.METRIC_INDEX[mname], ri], want,
+                                 rtol=1e-9, atol=1e-12,
+                                 err_msg=f'{mname}/{name}')
+    want = om.ACC(clim).compute_chunk(ft, tt, region=region)['z'].data[0]
+    np.testing.assert_allclose(got[_lib.METRIC_INDEX['acc'], ri], want,
+                               rtol=1e-9, atol=1e-12, err_msg=f'acc/{name}')
 
 
 def test_bad_accumulate_view_is_an_error(dev):
