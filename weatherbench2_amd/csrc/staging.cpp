@@ -177,8 +177,25 @@ struct Uploader {
   std::vector<hipEvent_t> events;
   std::vector<bool> busy;
   int next = 0;
+  // WB2HIP_DMA_STREAMS=n > 1: the DMAs of consecutive slices alternate between
+  // n streams of the uploader's own.  Measured and not kept as the default
+  // (profiles/r06_upload_sweep.txt): 53.6 GB/s on the caller's stream, 48.6
+  // with two, 53.1 with three -- one stream keeps the link busy.
+  std::vector<hipStream_t> dma;
+  hipEvent_t fork = nullptr;
+  std::vector<hipEvent_t> join;
+  size_t slices = 0;
   Uploader(int n_threads, size_t slot) : pool(n_threads), slot_bytes(slot) {}
 };
+
+int dma_streams() {
+  static const int n = [] {
+    const char* e = getenv("WB2HIP_DMA_STREAMS");
+    const int v = e ? atoi(e) : 1;
+    return v < 1 ? 1 : (v > 4 ? 4 : v);
+  }();
+  return n;
+}
 
 }  // namespace
 }  // namespace wb2
@@ -213,6 +230,22 @@ int wb2_uploader_create(int32_t n_threads, int64_t slot_bytes, int32_t n_slots,
     up->events.push_back(ev);
     up->busy.push_back(false);
   }
+  if (dma_streams() > 1) {
+    bool ok = hipEventCreateWithFlags(&up->fork, hipEventDisableTiming) ==
+              hipSuccess;
+    for (int i = 0; ok && i < dma_streams(); ++i) {
+      hipStream_t st = nullptr;
+      hipEvent_t ev = nullptr;
+      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+      if (st) up->dma.push_back(st);
+      if (ev) up->join.push_back(ev);
+    }
+    if (!ok) {
+      wb2_uploader_destroy(up);
+      return fail("the uploader's DMA streams could not be created");
+    }
+  }
   *uploader_out = up;
   return 0;
 }
@@ -227,6 +260,12 @@ int wb2_uploader_destroy(void* uploader) {
     (void)hipEventDestroy(up->events[i]);
     (void)hipHostFree(up->slots[i]);
   }
+  for (hipStream_t st : up->dma) {
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+  }
+  for (hipEvent_t ev : up->join) (void)hipEventDestroy(ev);
+  if (up->fork) (void)hipEventDestroy(up->fork);
   delete up;
   return 0;
 }
@@ -246,6 +285,8 @@ int wb2_host_copy(void* dst, const void* src, int64_t nbytes,
 
 namespace wb2 {
 namespace {
+int uploader_fork(Uploader* up, hipStream_t s);
+int uploader_join(Uploader* up, hipStream_t s);
 int upload_one(Uploader* up, void* dst, const void* src, int64_t nbytes,
                hipStream_t s);
 }  // namespace
@@ -258,8 +299,12 @@ int wb2_uploader_upload(void* uploader, void* dst, const void* src,
   WB2_REQUIRE(uploader != nullptr, "null uploader");
   WB2_EMPTY_OK(nbytes);
   WB2_REQUIRE(dst && src, "null pointer argument");
-  return upload_one(static_cast<Uploader*>(uploader), dst, src, nbytes,
-                    static_cast<hipStream_t>(stream));
+  auto* up = static_cast<Uploader*>(uploader);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = uploader_fork(up, s);
+  if (rc == 0) rc = upload_one(up, dst, src, nbytes, s);
+  const int rj = uploader_join(up, s);
+  return rc != 0 ? rc : rj;
 }
 
 int wb2_uploader_upload_many(void* uploader, int32_t n, void* const* dst,
@@ -270,22 +315,41 @@ int wb2_uploader_upload_many(void* uploader, int32_t n, void* const* dst,
   WB2_REQUIRE(uploader != nullptr, "null uploader");
   WB2_EMPTY_OK(n);
   WB2_REQUIRE(dst && src && nbytes, "null pointer argument");
-  for (int i = 0; i < n; ++i) {
+  auto* up = static_cast<Uploader*>(uploader);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = uploader_fork(up, s);
+  for (int i = 0; rc == 0 && i < n; ++i) {
     WB2_REQUIRE(nbytes[i] >= 0, "nbytes[%d]=%lld is negative", i,
                 (long long)nbytes[i]);
     if (nbytes[i] == 0) continue;
     WB2_REQUIRE(dst[i] && src[i], "buffer %d is null", i);
-    const int rc = upload_one(static_cast<Uploader*>(uploader), dst[i], src[i],
-                              nbytes[i], static_cast<hipStream_t>(stream));
-    if (rc != 0) return rc;
+    rc = upload_one(up, dst[i], src[i], nbytes[i], s);
   }
-  return 0;
+  const int rj = uploader_join(up, s);
+  return rc != 0 ? rc : rj;
 }
 
 }  // extern "C"
 
 namespace wb2 {
 namespace {
+// The uploader's DMA streams start behind what the caller's stream holds (the
+// destination may be a block that stream has just finished with) ...
+int uploader_fork(Uploader* up, hipStream_t s) {
+  if (up->dma.empty()) return 0;
+  WB2_HIP_OK(hipEventRecord(up->fork, s));
+  for (hipStream_t st : up->dma) WB2_HIP_OK(hipStreamWaitEvent(st, up->fork, 0));
+  return 0;
+}
+// ... and the caller's stream goes on behind their copies.
+int uploader_join(Uploader* up, hipStream_t s) {
+  for (size_t i = 0; i < up->dma.size(); ++i) {
+    WB2_HIP_OK(hipEventRecord(up->join[i], up->dma[i]));
+    WB2_HIP_OK(hipStreamWaitEvent(s, up->join[i], 0));
+  }
+  return 0;
+}
+
 int upload_one(Uploader* up, void* dst, const void* src, int64_t nbytes,
                hipStream_t s) {
   const char* from = static_cast<const char*>(src);
@@ -300,8 +364,9 @@ int upload_one(Uploader* up, void* dst, const void* src, int64_t nbytes,
       up->busy[i] = false;
     }
     up->pool.copy(up->slots[i], from, n);
-    WB2_HIP_OK(hipMemcpyAsync(to, up->slots[i], n, hipMemcpyHostToDevice, s));
-    WB2_HIP_OK(hipEventRecord(up->events[i], s));
+    hipStream_t ds = up->dma.empty() ? s : up->dma[up->slices++ % up->dma.size()];
+    WB2_HIP_OK(hipMemcpyAsync(to, up->slots[i], n, hipMemcpyHostToDevice, ds));
+    WB2_HIP_OK(hipEventRecord(up->events[i], ds));
     up->busy[i] = true;
     from += n;
     to += n;
