@@ -35,3 +35,7 @@ def test_fft_core_host_emulation(tmp_path):
   assert set(sizes) == {64, 128, 240, 256, 360, 512, 720, 1024, 1440}
   # float32 transform: error relative to the row's total power
   assert max(sizes.values()) < 1e-6, sizes
+  # the paired last pass (20 x 6 x 6: two butterflies and the recombination in
+  # one lane; every bin produced exactly once)
+  paired = {int(l[1]): float(l[3]) for l in lines if l[0] == 'P'}
+  assert set(paired) == {1440} and max(paired.values()) < 1e-6, paired

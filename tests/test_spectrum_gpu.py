@@ -552,3 +552,56 @@ def test_fused_float64_full_size_and_nan_handling():
     ref = torch.nanmean(spec, 0) if skipna else spec.mean(0)
     torch.testing.assert_close(mean, ref, rtol=1e-12, atol=0, equal_nan=True)
   del lat
+
+
+def test_paired_last_pass_variant_against_the_oracle(tmp_path):
+  """WB2HIP_FFT_PAIRED=1 (measured, not the default: profiles/
+  r06_measured_not_kept.md): the reducing modes of the 1440-point rows on the
+  plan 2 x 20 x 6 x 6 whose last pass runs the butterflies j and T - j of a
+  lane side by side, the recombination in registers (fft_core.hpp:
+  PairedLast).  Another plan rounds differently in float32, so it is held to
+  the oracle's tolerance, not to the materialising kernel's bits."""
+  import os
+  import subprocess
+  import sys
+  n_lon, n_lat, n_time, n_lev = 1440, 9, 4, 2
+  code = (
+      'import numpy as np, torch, sys\n'
+      'sys.path.insert(0, %r)\n'
+      'from weatherbench2_amd import engine\n'
+      'from oracle import spectrum_np\n'
+      'dev = torch.device("cuda")\n'
+      'gen = torch.Generator(device=dev).manual_seed(17)\n'
+      'x = torch.randn((%d, %d, %d, %d), generator=gen, device=dev)\n'
+      'x[1, 0, 2, 5] = float("nan")\n'
+      'lat = np.linspace(-80, 80, %d)\n'
+      'circ = torch.as_tensor(spectrum_np.circumference(lat)).to(dev)\n'
+      'w = torch.as_tensor(np.cos(np.deg2rad(lat))).to(dev)\n'
+      'np.savez(sys.argv[1], x=x.cpu().numpy(),\n'
+      '         mean=engine.zonal_spectrum(x, circ, %d, n_time=%d,\n'
+      '                                    skipna=True).cpu().numpy(),\n'
+      '         lat=engine.zonal_spectrum_lat_mean(x[0], circ, w, %d)\n'
+      '         .cpu().numpy())\n'
+  ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n_time,
+       n_lev, n_lat, n_lon, n_lat, n_lat, n_time, n_lat)
+  out = str(tmp_path / 'paired.npz')
+  env = dict(os.environ, WB2HIP_FFT_PAIRED='1')
+  subprocess.run([sys.executable, '-c', code, out], check=True, env=env,
+                 timeout=300)
+  got = np.load(out)
+  lat = np.linspace(-80, 80, n_lat)
+  x = got['x'].astype(np.float64)
+  spec = spectrum_np.simple_power(x) * spectrum_np.circumference(lat)[:, None]
+  with np.errstate(all='ignore'):
+    import warnings
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      want_mean = np.nanmean(spec, axis=0)
+  ok = ~np.isnan(want_mean).any(axis=-1)
+  assert np.isnan(got['mean'][~ok]).all() == np.isnan(want_mean[~ok]).all()
+  assert _row_rel_err(got['mean'][ok], want_mean[ok]) < 2e-6
+  w = np.cos(np.deg2rad(lat))
+  want_lat = (spec[0] * w[None, :, None]).sum(axis=1) / w.sum()
+  ok = ~np.isnan(want_lat).any(axis=-1)
+  assert ok.sum() >= 1
+  assert _row_rel_err(got['lat'][ok], want_lat[ok]) < 2e-6

@@ -56,6 +56,13 @@ constexpr S lit(float f, double d) {
 
 constexpr int kLanes = 64;  // a wavefront on gfx950
 
+#ifndef WB2_FFT_PAIRED_PAD0
+#define WB2_FFT_PAIRED_PAD0 2    // slab padding of PairedPlan<720>, see Plan
+#endif
+#ifndef WB2_FFT_PAIRED_PAD1
+#define WB2_FFT_PAIRED_PAD1 8
+#endif
+
 // ---- compile-time cos / sin of 2 pi m / r (Taylor series on (-pi, pi]) ------
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr double taylor_sin(double x) {
@@ -249,6 +256,7 @@ template <> struct Radix<8> : Composite<2, 4> {};
 template <> struct Radix<10> : Composite<2, 5> {};
 template <> struct Radix<12> : Composite<4, 3> {};
 template <> struct Radix<16> : Composite<4, 4> {};
+template <> struct Radix<20> : Composite<4, 5> {};
 
 // ---- pass plans: N2 = product of up to three radices --------------------------
 // Chosen so that every pass has at most a few rounds of <= 64 butterflies and
@@ -408,9 +416,8 @@ struct Pass {
 };
 
 // Slab slots a wave needs for a row of N2 complex points (largest layout).
-template <int N2>
+template <int N2, typename PL = Plan<N2>>
 constexpr int slab_slots() {
-  using PL = Plan<N2>;
   constexpr int a = (N2 / PL::R0) * (PL::R0 + PL::PAD0);
   constexpr int b = (N2 / (PL::R0 * PL::R1)) * (PL::R0 * PL::R1 + PL::PAD1);
   return a > b ? (a > N2 ? a : N2) : (b > N2 ? b : N2);
@@ -434,6 +441,117 @@ WB2_HD void recombine_pair(C a, C b, C wq, scalar_t<C> half_inv_n,
   p1 = x1.x * x1.x + x1.y * x1.y;
   p2 = x2.x * x2.x + x2.y * x2.y;
 }
+
+// ---- the last pass with its butterflies PAIRED in the lane ---------------------
+// The real-FFT recombination needs Z[k] and Z[N2 - k].  In the last pass (radix
+// R, NS = T = N2 / R) butterfly j produces the bins j + t T, t = 0..R-1, and the
+// partner of bin j + t T is N2 - j - t T = (T - j) + (R - 1 - t) T: an output of
+// butterfly T - j.  A lane that runs the butterflies j AND T - j therefore holds
+// every pair it needs in registers: no store of the last pass, no load of the
+// recombination -- two thirds of the LDS traffic of a row and one dependent LDS
+// round trip less.  T / 2 + 1 lanes have work (j = 0 .. T / 2): 61 of 64 for
+// 720 = 20 x 6 x 6.  Lane 0 (j = 0) and lane T / 2 pair inside ONE butterfly.
+//
+// Pairs of a lane, s = 0 / 1, u = 0 .. R/2 - 1 (A / B = outputs of j / T - j):
+//   s = 0:  a = A[u], b = B[R-1-u]   bins k = j + u T          and N2 - k
+//   s = 1:  a = B[u], b = A[R-1-u]   bins k = (T - j) + u T    and N2 - k
+// (k <= N2 / 2 in both: `a` is the low bin recombine_pair() wants first).
+template <int N2, int R, int IN_PAD>
+struct PairedLast {
+  static constexpr int T = N2 / R;
+  static constexpr int H = R / 2;
+  static constexpr int NP = T / 2 + 1;       // lanes with work
+  static constexpr int IN_STEP = T + IN_PAD;  // slots between inputs r, r + 1
+  static_assert(R % 2 == 0 && T % 2 == 0 && N2 % R == 0, "paired last pass");
+  static_assert(NP <= kLanes, "one round of pairs");
+
+  static WB2_HD int ja(int lane) { return lane < NP ? lane : NP - 1; }
+  static WB2_HD bool self_paired(int lane) {
+    const int j = ja(lane);
+    return j == 0 || 2 * j == T;
+  }
+  static WB2_HD int jb(int lane) {
+    return self_paired(lane) ? ja(lane) : T - ja(lane);
+  }
+  // bin of pair (s, u): the low one (p1 of recombine_pair); the high one is
+  // N2 - low
+  static WB2_HD int low_bin(int lane, int s, int u) {
+    const int j = ja(lane);
+    return (s == 0 ? j : T - j) + u * T;
+  }
+  // which results of pair (s, u) are this lane's to keep: p1 / p2
+  static WB2_HD bool keeps(int lane, int s, int u, int which) {
+    if (lane >= NP) return false;
+    if (s == 0) return true;
+    const int j = ja(lane);
+    if (2 * j == T) return false;                 // B is A: s = 1 repeats s = 0
+    if (j == 0) return u == H - 1 && which == 0;  // bin N2 / 2, once
+    return true;
+  }
+  template <typename C>
+  static WB2_HD void load_twiddles(const C* __restrict__ twz, int lane,
+                                   C (&tw)[2][R - 1]) {
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      tw[0][r - 1] = twz[ja(lane) * r];
+      tw[1][r - 1] = twz[jb(lane) * r];
+    }
+  }
+  // twq[k] of the low bins of the lane's pairs (twq has N2 / 2 + 1 entries)
+  template <typename C>
+  static WB2_HD void load_recombination(const C* __restrict__ twq, int lane,
+                                        C (&wq)[2][H]) {
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+      wq[0][u] = twq[low_bin(lane, 0, u)];
+      const int k = low_bin(lane, 1, u);
+      wq[1][u] = twq[k <= N2 / 2 ? k : N2 / 2];
+    }
+  }
+  template <typename Load, typename C>
+  static WB2_HD void load(const Load& src, int lane, C (&v)[2][R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      v[0][r] = src(ja(lane) + r * IN_STEP);
+      v[1][r] = src(jb(lane) + r * IN_STEP);
+    }
+  }
+  // after twiddles and butterflies: lane 0's partner outputs are its own,
+  // Z[T + t T] = A[(t + 1) mod R]
+  template <typename C>
+  static WB2_HD void fix_lane0(int lane, C (&v)[2][R]) {
+    const bool first = lane == 0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const C own = v[0][(t + 1) % R];
+      v[1][t].x = first ? own.x : v[1][t].x;
+      v[1][t].y = first ? own.y : v[1][t].y;
+    }
+  }
+  template <typename C>
+  static WB2_HD void recombine(const C (&v)[2][R], const C (&wq)[2][H],
+                               scalar_t<C> half_inv_n,
+                               scalar_t<C> (&p)[2][H][2]) {
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+      recombine_pair(v[0][u], v[1][R - 1 - u], wq[0][u], half_inv_n, p[0][u][0],
+                     p[0][u][1]);
+      recombine_pair(v[1][u], v[0][R - 1 - u], wq[1][u], half_inv_n, p[1][u][0],
+                     p[1][u][1]);
+    }
+  }
+};
+
+// Plans whose last pass is paired (selected by the reducing modes of K4f where
+// measured faster): 720 = 20 x 6 x 6 -> 36 lanes x 20 points from HBM, two
+// rounds of radix 6, 61 lanes x two radix-6 butterflies.
+template <int N2>
+struct PairedPlan;
+template <>
+struct PairedPlan<720> {
+  static constexpr int R0 = 20, R1 = 6, R2 = 6;
+  static constexpr int PAD0 = WB2_FFT_PAIRED_PAD0, PAD1 = WB2_FFT_PAIRED_PAD1;
+};
 
 // The two tables a plan keeps (evaluated in fp64, rounded once):
 //   twz[j] = exp(-2 pi i j / N2)                    j = 0 .. N2-1

@@ -62,6 +62,11 @@ __device__ __forceinline__ void fused_slab_store(C* p, C v) {
 #define WB2_FFT_STORE(v, p) (*(p) = (v))
 
 #include <cstdlib>
+#include <type_traits>
+
+#ifndef WB2_FFT_PAIRED_DEFAULT
+#define WB2_FFT_PAIRED_DEFAULT 0
+#endif
 
 namespace wb2 {
 namespace fused {
@@ -383,6 +388,152 @@ __global__ void __launch_bounds__(64 * WB2_FFT_NWAVE)
   }
 }
 
+// The reducing modes with the last pass PAIRED in the lane (fft_core.hpp:
+// PairedLast, PairedPlan: 1440 = 2 x 20 x 6 x 6).  Passes 0 and 1 as above;
+// the last pass runs the butterflies j and T - j of a lane side by side, the
+// recombination takes its bin pairs from registers: no store of the last pass,
+// no load of the recombination -- the row crosses LDS twice instead of three
+// times and a wave's dependent LDS round trips per row drop from three to two
+// (profiles/r03_k4_stalls.md section 4: the kernel waits on that chain, not on
+// a saturated unit).  Each lane keeps the 12 bins of its two butterflies.
+#ifndef WB2_FFT_PAIRED_WAVES
+#define WB2_FFT_PAIRED_WAVES 0   // > 0: waves per SIMD the registers are cut to
+#endif
+#if WB2_FFT_PAIRED_WAVES > 0
+#define WB2_FFT_PAIRED_OCC \
+  __attribute__((amdgpu_waves_per_eu(WB2_FFT_PAIRED_WAVES, WB2_FFT_PAIRED_WAVES)))
+#else
+#define WB2_FFT_PAIRED_OCC
+#endif
+template <int N2, int MODE, typename S = float>
+__global__ void __launch_bounds__(64 * WB2_FFT_NWAVE) WB2_FFT_PAIRED_OCC
+    fused_spectrum_paired_kernel(const FusedParams p) {
+  static_assert(MODE == TIME_MEAN || MODE == LATSEG, "reducing modes");
+  typedef cx<S> C;
+  using PL = PairedPlan<N2>;
+  constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2;
+  using P0 = Pass<N2, R0, 1, 1, 0, PL::PAD0>;
+  using P1 = Pass<N2, R1, R0, R0, PL::PAD0, PL::PAD1>;
+  using PP = PairedLast<N2, R2, PL::PAD1>;
+  constexpr int N = 2 * N2, NB = N2 + 1, NWAVE = WB2_FFT_NWAVE, H = PP::H;
+  __shared__ __attribute__((aligned(16))) C s_z[NWAVE][slab_slots<N2, PL>()];
+  const C* g_twz = static_cast<const C*>(p.twz);
+  const C* g_twq = static_cast<const C*>(p.twq);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  // twiddles of passes 1 and 2 and of the recombination: functions of the lane
+  C tw1[P1::ROUNDS][P1::NTW], tw2[2][R2 - 1], wq[2][H];
+  P1::load_twiddles(g_twz, lane, tw1);
+  PP::load_twiddles(g_twz, lane, tw2);
+  PP::load_recombination(g_twq, lane, wq);
+  C* z = s_z[wave];
+  const S half_inv_n = (S)0.5 / (S)N;
+  long long rows_out;
+  if constexpr (MODE == TIME_MEAN) rows_out = p.n_rows / p.n_time;
+  else rows_out = p.n_rows / p.n_lat * p.n_seg;
+  const long long stride = (long long)gridDim.x * NWAVE;
+  struct Task {
+    long long row0, nt, row_step;
+    int lat0;
+  };
+  auto task_of = [&](long long o) {
+    Task k{o, 1, 0, 0};
+    if constexpr (MODE == TIME_MEAN) {
+      k.nt = p.n_time;
+      k.row_step = rows_out;
+    } else {
+      const long long field = o / p.n_seg;
+      const int seg = (int)(o - field * p.n_seg);
+      k.lat0 = (int)((long long)seg * p.n_lat / p.n_seg);
+      k.nt = (long long)(seg + 1) * p.n_lat / p.n_seg - k.lat0;
+      k.row0 = field * p.n_lat + k.lat0;
+      k.row_step = 1;
+    }
+    return k;
+  };
+  const long long orow_first = (long long)blockIdx.x * NWAVE + wave;
+  Task next_task = task_of(orow_first < rows_out ? orow_first : 0);
+  for (long long orow_i = orow_first; orow_i < rows_out; orow_i += stride) {
+    double sum[2][H][2];
+    int cnt[2][H];  // TIME + skipna: valid spectra of the pair's two bins
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < H; ++u) {
+        sum[s][u][0] = sum[s][u][1] = 0.0;
+        cnt[s][u] = 0;
+      }
+    const Task task = next_task;
+    if (orow_i + stride < rows_out) next_task = task_of(orow_i + stride);
+    const long long nt = task.nt, row0 = task.row0, row_step = task.row_step;
+    const int lat0 = task.lat0;
+    double c = 0.0;
+    if constexpr (MODE != LATSEG) c = p.circ[(unsigned)(orow_i % p.n_lat)];
+    double* orow = p.out + orow_i * NB;
+    for (long long t = 0; t < nt; ++t) {
+      if constexpr (MODE == LATSEG) c = p.circ[lat0 + t * row_step];
+      const double c2 = 2.0 * c;
+      {  // ---- pass 0: HBM -> butterflies -> contiguous runs in the slab
+        C v[P0::ROUNDS][R0];
+        const C* src = reinterpret_cast<const C*>(
+            static_cast<const S*>(p.x) + (row0 + t * row_step) * N);
+        P0::load([&](int i) { return WB2_FFT_LOAD(src + i); }, lane, v);
+        P0::butterflies(v);
+        P0::store(z, lane, v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      lds_pass<P1, R1>(z, lane, tw1);
+      {  // ---- the paired last pass + recombination, in registers
+        C v[2][R2];
+        PP::load([&](int i) { return lds_read(z + i); }, lane, v);
+        twiddle_block<R2 - 1>(&v[0][1], &tw2[0][0]);
+        twiddle_block<R2 - 1>(&v[1][1], &tw2[1][0]);
+        Radix<R2>::run(v[0]);
+        Radix<R2>::run(v[1]);
+        PP::fix_lane0(lane, v);
+        S pw[2][H][2];
+        PP::recombine(v, wq, half_inv_n, pw);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int u = 0; u < H; ++u) {
+            // derived_variables.py:600: every bin but 0 is doubled (Nyquist too)
+            const bool first = s == 0 && u == 0 && lane == 0;
+            const double v1 = (double)pw[s][u][0] * (first ? c : c2);
+            const double v2 = (double)pw[s][u][1] * c2;
+            if constexpr (MODE == TIME_MEAN) {
+              const bool k1 = !(p.skipna && is_nan(v1));
+              const bool k2 = !(p.skipna && is_nan(v2));
+              sum[s][u][0] += k1 ? v1 : 0.0;
+              sum[s][u][1] += k2 ? v2 : 0.0;
+              cnt[s][u] += (k1 ? 1 : 0) + (k2 ? 0x10000 : 0);
+            } else {
+              sum[s][u][0] += v1;
+              sum[s][u][1] += v2;
+            }
+          }
+      }
+      // (the next row's pass 0 overwrites the slab: after this row's reads)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < H; ++u) {
+        double o1 = sum[s][u][0], o2 = sum[s][u][1];
+        if constexpr (MODE == TIME_MEAN) {
+          o1 /= (double)(cnt[s][u] & 0xffff);
+          o2 /= (double)(cnt[s][u] >> 16);
+        }
+        // (which of its 2 x H x 2 results the lane keeps, and where they go:
+        // worked out here, once per output row, not held in registers)
+        const int low = PP::low_bin(lane, s, u);
+        if (PP::keeps(lane, s, u, 0)) WB2_FFT_STORE(o1, orow + low);
+        if (PP::keeps(lane, s, u, 1)) WB2_FFT_STORE(o2, orow + (N2 - low));
+      }
+  }
+}
+
 // LATSEG second step: out[field][k] = scale * sum_seg partial[field][seg][k],
 // segments added in order (deterministic).  Eight loads are in flight before the
 // first add: with ~75 k threads the kernel is latency-bound otherwise (14.6 us
@@ -452,6 +603,26 @@ int launch(const FusedParams& p, int mode, hipStream_t s) {
   // row-strided waves beyond that (the cap counts 4-wave workgroups)
   if (blocks > WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE)
     blocks = WB2_FFT_MAX_BLOCKS * 4 / WB2_FFT_NWAVE;
+  if constexpr (N2 == 720 && std::is_same<S, float>::value) {
+    // the reducing modes with the last pass paired in the lane
+    // (WB2HIP_FFT_PAIRED=0 | 1: A/B runs; the default is the measured winner)
+    static const bool paired = [] {
+      const char* e = getenv("WB2HIP_FFT_PAIRED");
+      return e ? e[0] == '1' : WB2_FFT_PAIRED_DEFAULT != 0;
+    }();
+    if (paired && mode != MATERIALISE) {
+      if (mode == TIME_MEAN)
+        hipLaunchKernelGGL((fused_spectrum_paired_kernel<N2, TIME_MEAN, S>),
+                           dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0,
+                           s, p);
+      else
+        hipLaunchKernelGGL((fused_spectrum_paired_kernel<N2, LATSEG, S>),
+                           dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0,
+                           s, p);
+      WB2_HIP_OK(hipGetLastError());
+      return 0;
+    }
+  }
   if (mode == TIME_MEAN)
     hipLaunchKernelGGL((fused_spectrum_kernel<N2, TIME_MEAN, S>),
                        dim3((unsigned)blocks), dim3(64 * WB2_FFT_NWAVE), 0, s, p);
