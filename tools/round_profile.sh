@@ -8,7 +8,7 @@
 #   with): the first 60 kernels of each, so that no benched kernel falls off;
 # * the PMC traffic of every benched kernel (tools/live_traffic.py, separate
 #   --pmc passes, --kernel-trace only).
-R=${1:-r05}
+R=${1:-r06}
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -35,14 +35,23 @@ if [ "$2" != quick ]; then
   done
   stats energy_score python $GRAFT_REPO_ROOT/tools/tier2_variants.py --only energy_score --reps 1
   stats k3_hosted python $GRAFT_REPO_ROOT/tools/k3_variants.py --reps 1 --only members44_hosted,members33_hosted,members77_hosted,members45,members51
-  stats official_chunk python $GRAFT_REPO_ROOT/tools/official_chunk.py --batch default
-  stats official_chunk_by_chunk python $GRAFT_REPO_ROOT/tools/official_chunk.py --batch 1
-  timeout 600 python tools/official_chunk.py --batch 1,16,32,default --host-fed > $OUT/${R}_official_chunk.json 2>/dev/null
+  stats official_chunk python $GRAFT_REPO_ROOT/tools/official_chunk.py --batch default --chunks 480 --sections
+  stats official_chunk_by_chunk python $GRAFT_REPO_ROOT/tools/official_chunk.py --batch 1 --chunks 256 --sections
+  stats official_spatial python $GRAFT_REPO_ROOT/tools/spatial_leg.py --window
+  stats official_spatial_by_chunk python $GRAFT_REPO_ROOT/tools/spatial_leg.py --chunk-by-chunk
+  timeout 900 python tools/official_chunk.py --batch 1,16,32,default --host-fed > $OUT/${R}_official_chunk.json 2>/dev/null
+  timeout 300 python tools/pair_bench.py --window 8 --chunks 2 --reps 5 --json $OUT/${R}_pair_bench.jsonl > /dev/null 2>&1
+  timeout 300 python tools/pair_bench.py --reps 5 --json $OUT/${R}_pair_bench.jsonl > /dev/null 2>&1
+  timeout 300 python tools/pair_bench.py --no-field --window 8 --chunks 2 --reps 5 --json $OUT/${R}_pair_bench.jsonl > /dev/null 2>&1
+  timeout 300 python tools/host_fed_leg.py 2>/dev/null | tail -1 > $OUT/${R}_host_fed_leg.json
   for g in 240x121 64x32; do timeout 300 python tools/official_probabilistic.py --grid $g 2>/dev/null | tail -1; done > $OUT/${R}_official_probabilistic.json
   timeout 300 python tools/map_accumulate_bench.py 2>/dev/null | tail -1 > $OUT/${R}_map_accumulate.json
   timeout 300 python tools/live_traffic.py --workload map_accumulate 2>/dev/null | tail -1 >> $OUT/${R}_map_accumulate.json
   timeout 600 python tools/k3_variants.py > $OUT/${R}_k3_variants.json 2>/dev/null
   timeout 600 python tools/tier2_variants.py > $OUT/${R}_tier2_variants.json 2>/dev/null
-  for th in 4 8 16 32; do WB2HIP_COPY_THREADS=$th timeout 120 python tools/upload_sweep.py 2>/dev/null | tail -1; done > $OUT/${R}_upload_sweep.txt
+  ( for th in 4 8 16; do WB2HIP_COPY_THREADS=$th timeout 120 python tools/upload_sweep.py 2>/dev/null | tail -1; done
+    for slots in 4 8; do WB2HIP_STAGE_SLOTS=$slots timeout 120 python tools/upload_sweep.py 2>/dev/null | tail -1; done
+    for ds in 2 3; do WB2HIP_DMA_STREAMS=$ds timeout 120 python tools/upload_sweep.py 2>/dev/null | tail -1; done ) > $OUT/${R}_upload_sweep.txt
 fi
+python tools/kernel_table.py $R > $OUT/${R}_kernel_table.md 2>/dev/null || true
 ls -la $OUT

@@ -20,6 +20,15 @@ if '--profile' in sys.argv:
   pr.disable()
   pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
   sys.exit(0)
+if '--window' in sys.argv or '--chunk-by-chunk' in sys.argv:
+  # one window size alone (for rocprofv3 --stats: one launch shape per file)
+  from weatherbench2_amd import evaluation
+  scfg = oc.spatial_config(cfg)
+  batch = 32 if '--window' in sys.argv else 1
+  evaluation.evaluate_chunks(chunks[:256], scfg, False, prefetch=0,
+                             batch_chunks=batch)
+  torch.cuda.synchronize()
+  sys.exit(0)
 r = oc.measure_spatial(chunks, cfg)
 for k, v in r['by_window'].items():
   print(k, round(v['value'] / 1e9, 1), 'G steady', round(v['steady_ms_per_chunk'], 3),

@@ -228,10 +228,17 @@ __device__ __forceinline__ bool eval_slots(
     // threshold.  Categories: dry x < dry; light dry < x < wet; heavy x >= wet
     // (x == dry is in none: zero contingency row, score 0); NaN stays NaN.
     const T f = in[0], y = in[1], wet = in[2], dry = (T)scalar;
+    // branch-free on purpose: written as nested conditions the category logic
+    // became a switch under exec masks (4 saveexec + 2 branches per point, 36
+    // scalar instructions per point; profiles/r06_round_log.md)
     auto cat = [&](T v) {
-      return v < dry ? 0 : ((v > dry && v < wet) ? 1 : (v >= wet ? 2 : 3));
+      int c = v >= wet ? 2 : 3;
+      c = ((v > dry) & (v < wet)) ? 1 : c;
+      c = v < dry ? 0 : c;
+      return c;
     };
     const int fc = cat(f), tc = cat(y);
+    const unsigned cell = (unsigned)(fc * 4 + tc);  // [forecast_cat][truth_cat]
     const T p1 = (T)aux, one = (T)1;
     // 0.5 * scoring matrix [forecast_cat][truth_cat], in the dtype of p1:
     //   [0][1] 1 / (1 - p1)   [0][2] 4 / (1 - p1)   [1][0] 1 / p1
@@ -239,26 +246,29 @@ __device__ __forceinline__ bool eval_slots(
     // as TWO IEEE divisions per point -- numerator and denominator of the one
     // quotient a cell needs are selected first (the quotients themselves are
     // the reference's, bit for bit), 3 / (2 + p1) serves [2][1] and [2][0] --
-    // instead of the five a select over ready-made entries evaluates.
+    // instead of the five a select over ready-made entries evaluates.  Which
+    // quotients a cell takes: two 16-bit tables indexed by the cell.
     const bool to_dry = tc == 0;  // [1][0], [2][0]: 1 / p1
     const T num = to_dry ? one
                          : (fc == 0 ? (tc == 1 ? one : (T)4) : (T)3);
     const T den = to_dry ? p1 : one - p1;
     const T d1 = num / den;
     const T d2 = (T)3 / ((T)2 + p1);
-    T m = (T)0;
-    if ((fc == 0 && (tc == 1 || tc == 2)) || (fc == 1 && (tc == 0 || tc == 2)))
-      m = d1;
-    if (fc == 2 && tc == 0) m = d1 + d2;
-    if (fc == 2 && tc == 1) m = d2;
-    double v = (double)((T)0.5 * m);
-    if (is_nan(f) || is_nan(y) || is_nan(aux)) v = __builtin_nan("");
+    // d1: cells [0][1] [0][2] [1][0] [1][2] [2][0]; d2: cells [2][0] [2][1]
+    const T a = ((0x0156u >> cell) & 1u) ? d1 : (T)0;
+    const T b = ((0x0300u >> cell) & 1u) ? d2 : (T)0;
+    const T m = a + b;  // (x + 0 is x; [2][0]: d1 + d2 as before)
+    // NaN in -> NaN out (the quotients themselves are finite: p1 is masked to
+    // (min_p1, max_p1) or NaN), selected in the input dtype (one v_cndmask, not
+    // the two of a float64 select)
+    const T half_m = (T)0.5 * m;
+    const bool bad = is_nan(f) | is_nan(y) | is_nan(aux) | is_nan(half_m);
     if constexpr (SKIPNA) {
-      const bool ok = !is_nan(v);
-      x[0] = ok ? v : 0.0;
-      x[1] = ok ? 1.0 : 0.0;
+      const T okf = bad ? (T)0 : (T)1;
+      x[0] = (double)keep_if(half_m, okf);
+      x[1] = (double)okf;
     } else {
-      x[0] = v;
+      x[0] = (double)(bad ? (T)__builtin_nanf("") : half_m);
     }
   } else if constexpr (MODE == WB2_MODE_GAUSS_THR) {
     // metrics.py:975-1000 (Brier), :1043-1066 (ignorance), :1104-1121 (RPS
@@ -651,7 +661,8 @@ __global__ void __launch_bounds__(512)
       T v[U][NIN][VEC];
       double wf[U][VEC];
       double wr[U];
-    };
+      double ax[U][VEC];  // SEEPS: the p1 field of the row (with the batch's
+    };                    // loads, as vectors: it was one 8-byte load per point)
     auto issue = [&](Batch& bt, int r) {
       pin_offsets();
 #pragma unroll
@@ -667,15 +678,19 @@ __global__ void __launch_bounds__(512)
           for (int e = 0; e < VEC; ++e) bt.wf[u][e] = 1.0;
         }
         bt.wr[u] = wrp[r + u];
+        if constexpr (MODE == WB2_MODE_SEEPS)
+          load_wf<VEC, double>(
+              reinterpret_cast<const WB2_GLOBAL double*>(
+                  reinterpret_cast<unsigned long long>(
+                      p.aux + (long long)(row0 + r + u) * p.n_col + colb)),
+              bt.ax[u]);
       }
     };
     auto eat = [&](const Batch& bt, int r) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
         consume(bt.v[u], bt.wf[u], bt.wr[u],
-                MODE == WB2_MODE_SEEPS
-                    ? p.aux + (long long)(row0 + r + u) * p.n_col + colb
-                    : nullptr);
+                MODE == WB2_MODE_SEEPS ? bt.ax[u] : nullptr);
     };
     int r = 0;
 #pragma clang loop unroll(disable)
