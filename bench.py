@@ -1168,8 +1168,11 @@ def pcie_leg(dev, pl, units, nr, total, count) -> dict:
     for i in range(reps):
       xs = []
       for f_, h in zip(feeders, host):
-        if i + 1 < reps:
-          f_.submit(h)          # chunk i + 1 starts to move ...
+        # chunk i + 1 starts to move ...  (also behind the last step: every
+        # timed step then holds exactly one transfer per stream -- rounds 1-5
+        # left the last one out and still divided the bytes of `reps`
+        # transfers by the time of reps - 1: h2d_GBps was 6/5 of the truth)
+        f_.submit(h)
       for f_ in feeders:
         xs.append(f_.acquire())
       xs += resident[:3 - n_streams]

@@ -25,15 +25,15 @@ ROWS = [
     ('spectrum_materialized', 'fused_spectrum_kernel<720, 0, float',
      'K4f MATERIALISE, 16 units', 16 * (UNIT * 4 + 13 * 721 * 721 * 8)),
     ('spectrum', 'fused_spectrum_kernel<720, 2, float',
-     'K4f LATSEG (configs[3]; + latseg_combine)', None),
+     'K4f LATSEG (configs[3]; + latseg_combine), 16 units', 865015424),
     ('spectrum', 'latseg_combine_kernel', 'latseg_combine', None),
     ('spectrum_mean', 'fused_spectrum_kernel<720, 1, float',
-     'K4f TIME_MEAN, 16 units', None),
+     'K4f TIME_MEAN, 16 units', 16 * UNIT * 4 + 13 * 721 * 721 * 8),
     ('spectrum_materialized_f64', 'fused_spectrum_kernel<720, 0, double',
      'K4f MATERIALISE float64, 16 units',
      16 * (UNIT * 8 + 13 * 721 * 721 * 8)),
     ('spectrum_mean_f64', 'fused_spectrum_kernel<720, 1, double',
-     'K4f TIME_MEAN float64', None),
+     'K4f TIME_MEAN float64, 16 units', 16 * UNIT * 8 + 13 * 721 * 721 * 8),
     ('energy_score', 'energy_partials_kernel', 'K3e partials, 50 members',
      UNIT * 51 * 4),
     ('energy_score', 'energy_finalize_kernel', 'K3e finalize', None),
@@ -50,7 +50,8 @@ ROWS = [
      'stream_pair_kernel<float, 4, true, false, true',
      'K1p + field, one chunk (14 pairs)', 28 * PTS * 12),
     ('official_chunk_by_chunk', 'stream_partials_kernel<float, 4, 7',
-     'K1 SEEPS, one slab (beside K1 on a side stream)', PTS * 12),
+     'K1 SEEPS, one slab, on a side stream BESIDE K1 (its duration is not '
+     'its own)', None),
     ('official_spatial', 'spatial_accumulate_addr_kernel',
      'K5a map accumulate, 85 destinations x 8 steps (k = 8)',
      85 * PTS * (8 * 8 + 48)),
