@@ -384,6 +384,8 @@ def test_windows_accumulate_k_chunks_of_a_lead_per_launch(order, k, skipna,
   chunks = oc.chunk_pairs(gf, gt, order=order)
   want = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
                                     batch_chunks=1)
+  # (with WB2HIP_CHUNK_PROGRAM=verify every chunk goes alone, both ways)
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
   groups = []
   real = map_suite.MapSuite.run_many
 
