@@ -341,3 +341,82 @@ def test_gather_entry_point_validates_its_arguments(lib):
                                  None, None, None, 8, 1, None, None, 1, 1, None,
                                  None, None)
   assert rc < 0 and b'null pointer' in h.wb2_last_error()
+
+
+def test_pair_and_program_entry_points_validate_without_a_gpu(lib):
+  """wb2_pairs_supported is pure host logic; a chunk program (csrc/program.cpp)
+  is host state until wb2_program_finalize: its builders check slots, ranges
+  and order before any device call."""
+  h = lib.load()
+  # pair kernels exist at the full vector width of DET / DET_ACC only
+  assert h.wb2_pairs_supported(lib.MODE_DET_ACC, lib.WB2_F32, 0, 1, 1440, 1) == 1
+  assert h.wb2_pairs_supported(lib.MODE_DET, lib.WB2_F64, 1, 0, 721, 0) == 1
+  assert h.wb2_pairs_supported(lib.MODE_DET, lib.WB2_F32, 0, 0, 3, 1) == 0
+  assert h.wb2_pairs_supported(lib.MODE_WIND, lib.WB2_F32, 0, 0, 1440, 1) == 0
+  assert h.wb2_pairs_supported(lib.MODE_SEEPS, lib.WB2_F32, 0, 0, 1440, 1) == 0
+  # n_pair must fit the launch; null tables are rejected before the device
+  assert h.wb2_stream_partials_pairs(
+      lib.MODE_DET, lib.WB2_F32, 0, None, None, 1, 4, 1, 8, 16, None, None,
+      None, lib.WB2_F64, None, None, 8, 1, None, None, 1, 1, None, None,
+      None) < 0
+  assert b'null pointer' in h.wb2_last_error()
+  assert h.wb2_det_wind_suite_step(None, lib.MODE_DET, lib.WB2_F32, 0, None,
+                                   None, 1, 4, 1, None, None, None, None,
+                                   None) < 0
+  assert b'null plan' in h.wb2_last_error()
+
+  prog = ctypes.c_void_p()
+  assert h.wb2_program_create(ctypes.byref(prog)) == 0 and prog.value
+  assert h.wb2_program_create(None) < 0
+  plan = lib.PlanTables(n_row=8, n_col=16, n_chunk=8, n_ctile=1, n_seg=1,
+                        n_ts=1, n_band=1, n_region=1)
+  slot = np.zeros(2 * 3, dtype=np.int32)
+  rel = np.zeros(2 * 3, dtype=np.int64)
+  scratch = ctypes.create_string_buffer(64)
+  part = ctypes.addressof(scratch)
+  # a gather needs a launch; a launch needs its tables and sane sizes
+  assert h.wb2_program_add_gather(prog, 0, 0, 1, 0, 8, 0, slot.ctypes.data,
+                                  rel.ctypes.data) < 0
+  assert b'add a launch first' in h.wb2_last_error()
+  assert h.wb2_program_add_launch(prog, ctypes.byref(plan), lib.MODE_DET,
+                                  lib.WB2_F32, 0, 2, 3, 0, None, None, part,
+                                  None, 0, 0) < 0
+  assert h.wb2_program_add_launch(prog, ctypes.byref(plan), lib.MODE_DET,
+                                  lib.WB2_F32, 0, 2, 3, 2, slot.ctypes.data,
+                                  rel.ctypes.data, part, None, 0, 0) < 0
+  assert b'bad sizes' in h.wb2_last_error()
+  assert h.wb2_program_add_launch(prog, ctypes.byref(plan), lib.MODE_DET,
+                                  lib.WB2_F32, 0, 2, 3, 1, slot.ctypes.data,
+                                  rel.ctypes.data, part, None, 0, 0) < 0
+  assert b'wind_partials' in h.wb2_last_error()
+  slot[4] = -1
+  assert h.wb2_program_add_launch(prog, ctypes.byref(plan), lib.MODE_DET,
+                                  lib.WB2_F32, 0, 2, 3, 0, slot.ctypes.data,
+                                  rel.ctypes.data, part, None, 0, 0) < 0
+  assert b'negative pointer slot' in h.wb2_last_error()
+  slot[4] = 5
+  assert h.wb2_program_add_launch(prog, ctypes.byref(plan), lib.MODE_DET,
+                                  lib.WB2_F32, 0, 2, 3, 0, slot.ctypes.data,
+                                  rel.ctypes.data, part, None, 0, 0) == 0
+  cell = np.array([0, 7], dtype=np.int32)
+  base = np.zeros(2, dtype=np.int64)
+  assert h.wb2_program_add_gather(prog, 1, 1, 2, 0, 8, 0, cell.ctypes.data,
+                                  base.ctypes.data) == 0
+  assert h.wb2_program_add_gather(prog, 2, 0, 1, 0, 8, 0, cell.ctypes.data,
+                                  base.ctypes.data) < 0   # input 2 of 2
+  assert h.wb2_program_add_gather(prog, 0, 2, 2, 0, 8, 0, cell.ctypes.data,
+                                  base.ctypes.data) < 0   # past the launch
+  assert h.wb2_program_add_sink(prog, None, None, 1, 1, 0, None, None, 0) < 0
+  # finalize checks every slot and cell against what a replay will bring
+  assert h.wb2_program_finalize(prog, part, 4, 8) < 0
+  assert b'pointer slot 5' in h.wb2_last_error()
+  assert h.wb2_program_finalize(prog, part, 6, 4) < 0
+  assert b'gather cell' in h.wb2_last_error()
+  # a replay before finalize is refused
+  ptrs = np.zeros(6, dtype=np.int64)
+  args = np.zeros(3, dtype=np.int64)
+  assert h.wb2_program_replay(prog, ptrs.ctypes.data, 6, None, 0,
+                              args.ctypes.data, None, 0, None) < 0
+  assert b'finalize the program first' in h.wb2_last_error()
+  assert h.wb2_program_destroy(prog) == 0
+  assert h.wb2_program_destroy(None) == 0
