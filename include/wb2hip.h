@@ -635,6 +635,13 @@ int wb2_gather_accumulate_rows(const double* arena, const int32_t* src,
  *      block, then the wind block).  side_stream != 0: the launch runs on the
  *      program's second stream beside the others (small, latency-bound
  *      passes) and is joined before the sinks.
+ *  wb2_program_add_ens_launch   one ensemble pass (wb2_ens_partials_addr +
+ *      wb2_ens_combine: the `probabilistic` config, scripts/evaluate.py:496-520)
+ *      over n_outer slabs: slot / rel [2][n_outer] = (member 0's slab, truth
+ *      slab) of every outer index; `plan` carries the ENSEMBLE tile geometry
+ *      (n_ctile, seg_eoff, n_ts for wb2_ens_tile_cols(n_col); wfield float64 or
+ *      NULL); `partials` sized as for wb2_ens_partials; the WB2_NMETRIC_ENS x
+ *      n_region x n_outer values are written at arena + arena_offset.
  *  wb2_program_add_gather   entries [first, first + count) of input `input` of
  *      the launch added LAST are read from a resident array by valid time
  *      (climatology.sel(dayofyear, hour), metrics.py:398-404) instead:
@@ -662,6 +669,11 @@ int wb2_program_add_launch(void* program, const wb2_plan_tables* plan, int mode,
                            const int64_t* rel, double* partials,
                            double* wind_partials, int64_t arena_offset,
                            int side_stream);
+int wb2_program_add_ens_launch(void* program, const wb2_plan_tables* plan,
+                               int dtype, int skipna, int32_t n_member,
+                               int64_t member_stride, int64_t n_outer,
+                               const int32_t* slot, const int64_t* rel,
+                               double* partials, int64_t arena_offset);
 int wb2_program_add_gather(void* program, int32_t input, int64_t first,
                            int64_t count, int32_t source, int64_t step_bytes,
                            int32_t value_offset, const int32_t* cell,

@@ -348,17 +348,26 @@ def test_ensemble_passes_replay_too(skipna, member_first, n_member,
     # the passes of z and q (same member stride) are ONE launch through their
     # slabs' addresses -- the kernel of the separate passes, whatever the
     # member count (5 has a sorting program of its own, 7 is hosted by 8's)
-    seen = []
-    old = engine.set_launch_hook(lambda when, kernel: seen.append(kernel)
-                                 if when == 'begin' else None)
-    try:
-      evaluation.evaluate_chunks(chunks[:4], cfg, skipna, prefetch=0,
-                                 batch_chunks=1)
-    finally:
-      engine.set_launch_hook(old)
-    # first chunk: 3 generic passes + the trial of the fused launch; then
-    # 3 replays of (z + q, t2m)
-    assert seen.count('ens_partials') == 3 + 1 + 3 * 2, seen
+    for native in ('0', '1'):
+      monkeypatch.setenv('WB2HIP_NATIVE_REPLAY', native)
+      seen = []
+      old = engine.set_launch_hook(lambda when, kernel: seen.append(kernel)
+                                   if when == 'begin' else None)
+      try:
+        got4 = evaluation.evaluate_chunks(chunks[:4], cfg, skipna, prefetch=0,
+                                          batch_chunks=1)
+      finally:
+        engine.set_launch_hook(old)
+      # first chunk: 3 generic passes + the trial of the fused launch; then
+      # 3 replays of (z + q, t2m) -- from Python launch by launch, or one
+      # wb2_program_replay call per chunk
+      if native == '0':
+        assert seen.count('ens_partials') == 3 + 1 + 3 * 2, seen
+        first4 = got4
+      else:
+        assert seen.count('ens_partials') == 3 + 1, seen
+        assert seen.count('stream_partials') == 3, seen
+        _same(got4, first4)
   monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', 'verify')
   _same(evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
                                    batch_chunks=1), want)
@@ -380,6 +389,68 @@ def test_ensemble_passes_replay_too(skipna, member_first, n_member,
       vals = np.transpose(vals, [rdims.index(d) for d in dims])
       helpers.assert_close(vals, mean, rtol=1e-6, atol=1e-9,
                            err_msg=f'{mname}/{rname}/{var}')
+
+
+@pytest.mark.parametrize('member_first', [True, False])
+@pytest.mark.parametrize('skipna', [False, True])
+@pytest.mark.parametrize('batch', [2, 4, None])
+def test_ensemble_windows_read_the_chunks_where_they_lie(batch, skipna,
+                                                          member_first,
+                                                          monkeypatch):
+  """The `probabilistic` config over WINDOWS of its (init_time=1, lead_time=1)
+  chunks: K3 takes member 0's slab and the truth slab of every (chunk, level)
+  by address (wb2_ens_partials_addr) -- nothing is concatenated -- and gives,
+  per slab, what it gives chunk by chunk: the same bits for every window size,
+  with and without programs."""
+  from weatherbench2_amd import config, engine, evaluation, metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  _, _, chunks = _ensemble_chunks(n_init=5, n_lead=3, member_first=member_first,
+                                  nan=skipna, n_member=6)
+
+  def own(ds):   # every chunk an allocation of its own, as a reader returns it
+    return xl.Dataset({k: xl.DataArray(v.data.contiguous().clone(), v.dims)
+                       for k, v in ds.data_vars.items()}, dict(ds.coords))
+  chunks = [(own(f), own(t_)) for f, t_ in chunks]
+  dim = 'number'
+  cfg = config.Eval(
+      metrics={'crps': gm.CRPS(ensemble_dim=dim),
+               'crps_spread': gm.CRPSSpread(ensemble_dim=dim),
+               'ensemble_mean_mse': gm.EnsembleMeanMSE(ensemble_dim=dim),
+               'ensemble_variance': gm.EnsembleVariance(ensemble_dim=dim)},
+      regions={'global': gm_regions().SliceRegion(),
+               'north': gm_regions().SliceRegion(lat_slice=slice(20, 90))})
+  kwargs = {} if batch is None else {'batch_chunks': batch}
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                    batch_chunks=1)
+  materialized = []
+  real = xl.SlabConcat.materialize
+  monkeypatch.setattr(xl.SlabConcat, 'materialize',
+                      lambda self, *a, **k: (materialized.append(1),
+                                             real(self, *a, **k))[1])
+  for how in ('0', '1', 'verify'):
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', how)
+    seen = []
+    old = engine.set_launch_hook(lambda when, kernel: seen.append(kernel)
+                                 if when == 'begin' else None)
+    try:
+      got = evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                       **kwargs)
+    finally:
+      engine.set_launch_hook(old)
+    _same(got, want)
+    assert not materialized, 'a window was copied together'
+    if how == '0':
+      # 3 variables per window, one K3 launch each (the 15 chunks are one
+      # window by default; windows of 2 / 4 chunks that are no (init x lead)
+      # rectangle are evaluated in smaller pieces)
+      n = seen.count('ens_partials')
+      assert (n == 3) if batch is None else (n < 3 * len(chunks)), seen
+
+
+def gm_regions():
+  from weatherbench2_amd import regions
+  return regions
 
 
 @pytest.mark.parametrize('batch', [1, 3, None])

@@ -91,8 +91,7 @@ def test_fused_ensemble_launches_permute_the_arena_consistently(monkeypatch):
     la = program._EnsLaunch.__new__(program._EnsLaunch)
     la.plan, la.skipna, la.n_total = plan, False, n
     la.n_metric, la.n_values = n_metric, n_metric * n_region * n
-    la.rec = {'n_member': 5, 'member_stride': stride,
-              'ens': torch.zeros(1, dtype=torch.float32)}
+    la.n_member, la.member_stride, la.dtype = 5, stride, torch.float32
     return la
   other_a, other_b = _FakeLaunch(5, n_region, 4), _FakeLaunch(5, n_region, 2)
   e1, e2, e3 = ens(2, 100), ens(3, 7), ens(1, 100)

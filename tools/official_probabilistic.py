@@ -86,6 +86,9 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--chunks', type=int, default=256)
   ap.add_argument('--grid', default='240x121')
+  ap.add_argument('--windows', default='8,default',
+                  type=lambda v: [None if x == 'default' else int(x)
+                                  for x in v.split(',') if x])
   args = ap.parse_args()
   import torch
   from weatherbench2_amd import config, evaluation, program
@@ -97,18 +100,31 @@ def main():
          'slabs_per_chunk': len(VARS_3D) * len(LEVELS) + len(VARS_2D),
          'regions': None if regions is None else len(regions)}
   pts = out['slabs_per_chunk'] * n_lon * n_lat
-  for how in ('0', '1'):
-    os.environ['WB2HIP_CHUNK_PROGRAM'] = how
-    evaluation.evaluate_chunks(chunks[:8], cfg, False, prefetch=0,
-                               batch_chunks=1)
+  # bytes K3 has to read per chunk: 50 members + the truth of every slab
+  chunk_bytes = pts * 4 * (N_MEMBER + 1)
+  out['chunk_MB'] = chunk_bytes / 1e6
+
+  def leg(batch):
+    evaluation.evaluate_chunks(chunks[:max(8, 2 * (batch or 32))], cfg, False,
+                               prefetch=0, batch_chunks=batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, batch_chunks=1)
+    evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                               batch_chunks=batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out['programs_' + how] = {
-        'ms_per_chunk': dt / len(chunks) * 1e3,
-        'value': len(chunks) * pts / dt, 'unit': 'grid-point-evals/s'}
+    return {'ms_per_chunk': dt / len(chunks) * 1e3,
+            'value': len(chunks) * pts / dt, 'unit': 'grid-point-evals/s',
+            'GBps': len(chunks) * chunk_bytes / dt / 1e9,
+            'hbm_frac': len(chunks) * chunk_bytes / dt / 8e12}
+  for how in ('0', '1'):
+    os.environ['WB2HIP_CHUNK_PROGRAM'] = how
+    out['programs_' + how] = leg(1)
+  # windows (evaluate_chunks' default: as many chunks as hold 16 GiB, at most
+  # 32): K3 reads the chunks of a window where they lie, one launch per
+  # member stride
+  for batch in args.windows:
+    out[f'window_{batch or "default"}'] = leg(batch)
   out['reasons'] = program.REASONS[-3:]
   print(json.dumps(out))
 

@@ -88,6 +88,9 @@ _SIGNATURES = {
     'wb2_program_add_launch': (_int, [
         _vp, _c.POINTER(PlanTables), _int, _int, _int, _i32, _i64, _i64, _vp,
         _vp, _vp, _vp, _i64, _int]),
+    'wb2_program_add_ens_launch': (_int, [
+        _vp, _c.POINTER(PlanTables), _int, _int, _i32, _i64, _i64, _vp, _vp,
+        _vp, _i64]),
     'wb2_program_add_gather': (_int, [_vp, _i32, _i64, _i64, _i32, _i64, _i32,
                                       _vp, _vp]),
     'wb2_program_add_sink': (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp,

@@ -19,6 +19,7 @@
 //      tables: the table of chunk k travels while the kernels of chunk k - 1
 //      run; the host waits only when it is kRing chunks ahead of the GPU);
 //   2. every recorded launch -- wb2_det_suite_step / wb2_det_wind_suite_step,
+//      or wb2_ens_partials_addr + wb2_ens_combine for an ensemble pass --
 //      i.e. the kernels of the generic path, bit for bit; launches marked
 //      `side` (the one-slab SEEPS passes: latency-bound) run on a second
 //      stream beside the big one and join before step 3;
@@ -53,6 +54,10 @@ struct Gather {
 struct Launch {
   wb2_plan_tables plan;
   int mode, dtype, skipna, n_in, side;
+  // an ensemble pass (K3 + its fold): inputs = (member 0's slab, truth slab)
+  bool ensemble = false;
+  int n_member = 0;
+  long long member_stride = 0;
   long long n_outer, n_pair;
   std::vector<int> slot;        // [n_in][n_outer]
   std::vector<long long> rel;   // [n_in][n_outer]
@@ -195,6 +200,47 @@ int wb2_program_add_launch(void* program, const wb2_plan_tables* plan, int mode,
   p->table_len += (long long)n;
   p->any_side = p->any_side || la.side;
   p->any_pairs = p->any_pairs || (la.n_pair > 0 && !la.side);
+  p->launches.push_back(std::move(la));
+  return 0;
+}
+
+int wb2_program_add_ens_launch(void* program, const wb2_plan_tables* plan,
+                               int dtype, int skipna, int32_t n_member,
+                               int64_t member_stride, int64_t n_outer,
+                               const int32_t* slot, const int64_t* rel,
+                               double* partials, int64_t arena_offset) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(program && plan && slot && rel && partials,
+              "null pointer argument");
+  auto* p = static_cast<Program*>(program);
+  WB2_REQUIRE(!p->finalized, "the program is finalized");
+  WB2_REQUIRE(n_member >= 1 && member_stride >= 0 && n_outer > 0 &&
+                  arena_offset >= 0,
+              "bad sizes: n_member=%d member_stride=%lld n_outer=%lld",
+              n_member, (long long)member_stride, (long long)n_outer);
+  WB2_REQUIRE(plan->wfield == nullptr || plan->wfield_dtype == WB2_F64,
+              "the ensemble kernels read a float64 weight field");
+  Launch la{};
+  la.plan = *plan;
+  la.mode = WB2_MODE_ENS;
+  la.dtype = dtype;
+  la.skipna = skipna;
+  la.n_in = 2;
+  la.ensemble = true;
+  la.n_member = n_member;
+  la.member_stride = member_stride;
+  la.n_outer = n_outer;
+  const size_t n = 2 * (size_t)n_outer;
+  la.slot.assign(slot, slot + n);
+  la.rel.assign(reinterpret_cast<const long long*>(rel),
+                reinterpret_cast<const long long*>(rel) + n);
+  for (size_t i = 0; i < n; ++i)
+    WB2_REQUIRE(la.slot[i] >= 0, "negative pointer slot");
+  la.partials = partials;
+  la.arena_offset = arena_offset;
+  la.table_offset = p->table_len;
+  p->table_len += (long long)n;
   p->launches.push_back(std::move(la));
   return 0;
 }
@@ -379,6 +425,21 @@ int wb2_program_replay(void* program, const int64_t* ptrs, int32_t n_ptrs,
     for (int j = 0; j < la.n_in; ++j)
       slabs[j] = dev + la.table_offset + (long long)j * la.n_outer;
     double* metrics = p->arena + la.arena_offset;
+    if (la.ensemble) {
+      const wb2_plan_tables& t = la.plan;
+      int rc = wb2_ens_partials_addr(
+          la.dtype, la.skipna, slabs[0], slabs[1], la.n_member,
+          la.member_stride, la.n_outer, t.n_row, t.n_col, t.w_row, t.w_col,
+          static_cast<const double*>(t.wfield), t.chunk_row0, t.chunk_nrow,
+          t.n_chunk, t.n_ctile, t.seg_col0, t.seg_eoff, t.n_seg, t.n_ts,
+          la.partials, ls);
+      if (rc != 0) return rc;
+      return wb2_ens_combine(la.skipna, la.partials, la.n_outer, t.n_chunk,
+                             t.wfield ? 2 : 1, t.n_seg, t.seg_eoff, t.n_ts,
+                             t.band_chunk0, t.n_band, t.coef_band, t.coef_seg,
+                             t.region_wf, t.region_wsum, t.n_region, nullptr,
+                             metrics, ls);
+    }
     if (la.n_pair > 0) {
       const long long n_det =
           (long long)WB2_NMETRIC * la.plan.n_region * la.n_outer;

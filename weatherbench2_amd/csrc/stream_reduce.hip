@@ -1108,13 +1108,13 @@ __device__ __forceinline__ double nan_if_zero(double d) {
   return d != 0.0 ? d : __builtin_nan("");
 }
 
-__global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void det_combine_body(const CombineParams& p,
+                                                 const long long o,
+                                                 double* lds) {
   const int K = p.K;
   const int cell = p.nwf * p.n_seg * K;
   double* bandsum = lds;                     // [n_band][nwf][n_seg][K]
   double* rsum = lds + p.n_band * cell;      // [n_region][K]
-  const long long o = blockIdx.x;
   const int tid = threadIdx.x;
   // the region coefficients are read in dependent loops below: from LDS (a
   // global load per iteration cost ~10 us per slab, one workgroup per slab)
@@ -1316,6 +1316,25 @@ __global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p
     m[WB2_METRIC_BIAS * stride] = bias;
     m[WB2_METRIC_ACC * stride] = acc;
   }
+}
+
+__global__ void __launch_bounds__(1024) det_combine_kernel(const CombineParams p) {
+  extern __shared__ double lds[];
+  det_combine_body(p, blockIdx.x, lds);
+}
+
+// Two folds in ONE launch: blocks [0, a.n_outer) fold `a`, the rest fold `b` --
+// the per-variable slabs of a chunk and its wind-vector pairs
+// (wb2_det_wind_suite_step).  Every block runs the code of the single launch
+// on the parameters of its fold: the same bits, one launch (and one queue
+// barrier) less per chunk.
+__global__ void __launch_bounds__(1024)
+    det_combine2_kernel(const CombineParams a, const CombineParams b) {
+  extern __shared__ double lds[];
+  if ((long long)blockIdx.x < a.n_outer)
+    det_combine_body(a, blockIdx.x, lds);
+  else
+    det_combine_body(b, (long long)blockIdx.x - a.n_outer, lds);
 }
 
 // The running temporal mean (xbeam.Mean's (sum, count) combiner,
@@ -1985,23 +2004,16 @@ namespace wb2 {
 // The body of wb2_det_combine with the slot count given (the energy-score pass
 // folds 2 x block member sums per virtual slab: a generic mode whose slot
 // count is not a function of the mode alone).
-int combine_slots(int mode, int skipna, int k_slots, const double* partials,
-                  int64_t n_outer, int32_t n_chunk, int32_t nwf, int32_t n_seg,
-                  const int32_t* seg_eoff, int32_t n_ts,
-                  const int32_t* band_chunk0, int32_t n_band,
-                  const double* coef_band, const double* coef_seg,
-                  const int32_t* region_wf, const double* region_wsum,
-                  int32_t n_region, double* sums, double* metrics,
-                  void* stream) {
-  WB2_EMPTY_OK(n_outer);
-  WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
-                  region_wf && region_wsum,
-              "null pointer argument");
-  WB2_REQUIRE(n_outer >= 0 && n_chunk > 0 && n_ts >= n_seg &&
-                  (nwf == 1 || nwf == 2) && n_seg > 0 && n_band > 0 &&
-                  n_region > 0,
-              "bad sizes");
-  if (n_outer == 0) return 0;
+namespace {
+CombineParams combine_params(int mode, int skipna, int k_slots,
+                             const double* partials, int64_t n_outer,
+                             int32_t n_chunk, int32_t nwf, int32_t n_seg,
+                             const int32_t* seg_eoff, int32_t n_ts,
+                             const int32_t* band_chunk0, int32_t n_band,
+                             const double* coef_band, const double* coef_seg,
+                             const int32_t* region_wf,
+                             const double* region_wsum, int32_t n_region,
+                             double* sums, double* metrics, size_t* lds) {
   CombineParams p{};
   p.partials = partials;
   p.seg_eoff = seg_eoff;
@@ -2027,10 +2039,85 @@ int combine_slots(int mode, int skipna, int k_slots, const double* partials,
   while (p.group < kWave &&
          (long long)n_band * nwf * n_seg * 8 * (2 * p.group) <= 1024)
     p.group *= 2;
-  const size_t lds = ((size_t)n_band * nwf * n_seg * p.K +
-                      (size_t)n_region * p.K * (1 + (size_t)n_band) +
-                      (size_t)n_region * ((size_t)n_seg + n_band)) *
-                     sizeof(double);
+  *lds = ((size_t)n_band * nwf * n_seg * p.K +
+          (size_t)n_region * p.K * (1 + (size_t)n_band) +
+          (size_t)n_region * ((size_t)n_seg + n_band)) *
+         sizeof(double);
+  return p;
+}
+}  // namespace
+
+// The folds of a launch with wind-vector pairs -- wb2_det_combine over the
+// per-variable partials and wb2_det_combine(WB2_MODE_WIND) over the pairs' -- as
+// ONE launch (det_combine2_kernel) when both fit the default dynamic LDS;
+// the two launches otherwise.
+int combine_det_and_wind(const wb2_plan_tables& t, int mode, int skipna,
+                         const double* partials, int64_t n_outer,
+                         const double* wind_partials, int64_t n_pair,
+                         double* metrics, double* wind_metrics, void* stream) {
+  const int nwf = t.wfield ? 2 : 1;
+  size_t lds_a = 0, lds_b = 0;
+  const CombineParams a = combine_params(
+      mode, skipna, wb2_num_slots(mode, skipna), partials, n_outer, t.n_chunk,
+      nwf, t.n_seg, t.seg_eoff, t.n_ts, t.band_chunk0, t.n_band, t.coef_band,
+      t.coef_seg, t.region_wf, t.region_wsum, t.n_region, nullptr, metrics,
+      &lds_a);
+  const CombineParams b = combine_params(
+      WB2_MODE_WIND, skipna, wb2_num_slots(WB2_MODE_WIND, skipna),
+      wind_partials, n_pair, t.n_chunk, nwf, t.n_seg, t.seg_eoff, t.n_ts,
+      t.band_chunk0, t.n_band, t.coef_band, t.coef_seg, t.region_wf,
+      t.region_wsum, t.n_region, nullptr, wind_metrics, &lds_b);
+  const size_t lds = lds_a > lds_b ? lds_a : lds_b;
+  static const bool fused = [] {  // WB2HIP_FUSED_FOLDS=0: A/B runs
+    const char* e = getenv("WB2HIP_FUSED_FOLDS");
+    return !(e && e[0] == '0');
+  }();
+  if (!fused || lds > 64 * 1024 || n_outer <= 0 || n_pair <= 0 ||
+      n_outer + n_pair >= (1ll << 31) || !partials || !wind_partials ||
+      !metrics || !wind_metrics || !t.seg_eoff || !t.band_chunk0 ||
+      !t.coef_band || !t.coef_seg || !t.region_wf || !t.region_wsum ||
+      t.n_chunk <= 0 || t.n_seg <= 0 || t.n_ts < t.n_seg || t.n_band <= 0 ||
+      t.n_region <= 0) {  // (the two calls below report what is wrong)
+    int rc = wb2_det_combine(mode, skipna, partials, n_outer, t.n_chunk, nwf,
+                             t.n_seg, t.seg_eoff, t.n_ts, t.band_chunk0,
+                             t.n_band, t.coef_band, t.coef_seg, t.region_wf,
+                             t.region_wsum, t.n_region, nullptr, metrics,
+                             stream);
+    if (rc != 0 || n_pair == 0) return rc;
+    return wb2_det_combine(WB2_MODE_WIND, skipna, wind_partials, n_pair,
+                           t.n_chunk, nwf, t.n_seg, t.seg_eoff, t.n_ts,
+                           t.band_chunk0, t.n_band, t.coef_band, t.coef_seg,
+                           t.region_wf, t.region_wsum, t.n_region, nullptr,
+                           wind_metrics, stream);
+  }
+  hipLaunchKernelGGL(det_combine2_kernel, dim3((unsigned)(n_outer + n_pair)),
+                     dim3(1024), lds, static_cast<hipStream_t>(stream), a, b);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int combine_slots(int mode, int skipna, int k_slots, const double* partials,
+                  int64_t n_outer, int32_t n_chunk, int32_t nwf, int32_t n_seg,
+                  const int32_t* seg_eoff, int32_t n_ts,
+                  const int32_t* band_chunk0, int32_t n_band,
+                  const double* coef_band, const double* coef_seg,
+                  const int32_t* region_wf, const double* region_wsum,
+                  int32_t n_region, double* sums, double* metrics,
+                  void* stream) {
+  WB2_EMPTY_OK(n_outer);
+  WB2_REQUIRE(partials && seg_eoff && band_chunk0 && coef_band && coef_seg &&
+                  region_wf && region_wsum,
+              "null pointer argument");
+  WB2_REQUIRE(n_outer >= 0 && n_chunk > 0 && n_ts >= n_seg &&
+                  (nwf == 1 || nwf == 2) && n_seg > 0 && n_band > 0 &&
+                  n_region > 0,
+              "bad sizes");
+  if (n_outer == 0) return 0;
+  size_t lds = 0;
+  const CombineParams p = combine_params(
+      mode, skipna, k_slots, partials, n_outer, n_chunk, nwf, n_seg, seg_eoff,
+      n_ts, band_chunk0, n_band, coef_band, coef_seg, region_wf, region_wsum,
+      n_region, sums, metrics, &lds);
   // gfx950: a workgroup may take all 160 KiB of a CU's LDS; beyond the default
   // 64 KiB of dynamic LDS the kernel has to be told once
   WB2_REQUIRE(lds <= 160 * 1024,
@@ -2203,17 +2290,8 @@ int det_wind_suite_step_streams(const wb2_plan_tables* plan, int mode,
                              t.seg_eoff, t.n_seg, t.n_ts, partials,
                              wind_partials, stream, pair_stream, join_event);
   if (rc != 0) return rc;
-  const int nwf = t.wfield ? 2 : 1;
-  rc = wb2_det_combine(mode, skipna, partials, n_outer, t.n_chunk, nwf, t.n_seg,
-                       t.seg_eoff, t.n_ts, t.band_chunk0, t.n_band, t.coef_band,
-                       t.coef_seg, t.region_wf, t.region_wsum, t.n_region,
-                       nullptr, metrics, stream);
-  if (rc != 0 || n_pair == 0) return rc;
-  return wb2_det_combine(WB2_MODE_WIND, skipna, wind_partials, n_pair,
-                         t.n_chunk, nwf, t.n_seg, t.seg_eoff, t.n_ts,
-                         t.band_chunk0, t.n_band, t.coef_band, t.coef_seg,
-                         t.region_wf, t.region_wsum, t.n_region, nullptr,
-                         wind_metrics, stream);
+  return combine_det_and_wind(t, mode, skipna, partials, n_outer, wind_partials,
+                              n_pair, metrics, wind_metrics, stream);
 }
 }  // namespace wb2
 

@@ -645,13 +645,19 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
                     truth_slab: t.Optional[torch.Tensor], n_outer: int,
                     skipna: bool, want_sums: bool = False,
                     maps: t.Optional[torch.Tensor] = None,
-                    member_ptrs: t.Optional[torch.Tensor] = None):
+                    member_ptrs: t.Optional[torch.Tensor] = None,
+                    addresses: t.Optional[torch.Tensor] = None):
   """Runs K3 + the region fold.  `ens` holds the members member-major with
   `member_stride` elements between members; `truth` is [n_slab, n_row, n_col].
   With `member_ptrs` (int64[n_outer, n_member] device ADDRESSES of the member
   slabs, `gather_pointers`) the ensemble is read in place from wherever its
   slabs live: `ens` is then only the tensor those addresses point into (kept
   alive, dtype), `member_stride` and `ens_slab` are ignored.
+  With `addresses` (int64[2, n_outer] on the device: the byte address of member
+  0's slab and of the truth slab of every outer index; member m follows
+  `member_stride` elements behind member 0 -- wb2_ens_partials_addr) `ens` and
+  `truth` are tensors of the right dtype that stay alive, nothing more: the
+  chunks of a window are read where they lie (xarray_lite.SlabConcat).
 
   Returns (metrics[NMETRIC_ENS, n_region, n_outer], sums or None).
   """
@@ -662,7 +668,13 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
     raise TypeError(f'unsupported / mismatched dtypes {ens.dtype} {truth.dtype}')
   # (a non-contiguous `ens` is a view with intact slabs that the caller
   # addresses through member_stride + ens_slab: metrics._ens_layout)
-  if ens.device != dev or truth.device != dev or not truth.is_contiguous() or (
+  if addresses is not None:
+    if (addresses.dtype != torch.int64 or addresses.device != dev or
+        not addresses.is_contiguous() or addresses.numel() != 2 * n_outer or
+        maps is not None or member_ptrs is not None):
+      raise ValueError('addresses is a contiguous int64[2, n_outer] on the '
+                       'plan device (no maps, no member_ptrs)')
+  elif ens.device != dev or truth.device != dev or not truth.is_contiguous() or (
       not ens.is_contiguous() and ens_slab is None and member_ptrs is None):
     raise ValueError('inputs must be contiguous on the plan device')
   for s in (ens_slab, truth_slab):
@@ -686,7 +698,16 @@ def ensemble_reduce(plan: ReductionPlan, ens: torch.Tensor,
   if maps is not None and (maps.dtype != torch.float64 or maps.numel() !=
                            6 * n_outer * plan.n_row * plan.n_col):
     raise ValueError('maps must be float64[6, n_outer, n_row * n_col]')
-  if member_ptrs is not None:
+  if addresses is not None:
+    base = addresses.data_ptr()
+    _lib.check(lib.wb2_ens_partials_addr(
+        _DTYPES[dtype], int(skipna), base, base + 8 * n_outer, n_member,
+        member_stride, n_outer, plan.n_row, plan.n_col, _lib.ptr(plan.w_row),
+        _lib.ptr(plan.w_col), _lib.ptr(plan.wfield), _lib.ptr(plan.chunk_row0),
+        _lib.ptr(plan.chunk_nrow), plan.n_chunk, n_ctile,
+        _lib.ptr(plan.seg_col0), _lib.ptr(seg_eoff), plan.n_seg, n_ts,
+        _lib.ptr(partials), stream), 'wb2_ens_partials_addr')
+  elif member_ptrs is not None:
     _lib.check(lib.wb2_ens_partials_gather(
         _DTYPES[dtype], int(skipna), _lib.ptr(member_ptrs), _lib.ptr(truth),
         _lib.ptr(truth_slab), n_member, n_outer, plan.n_row, plan.n_col,

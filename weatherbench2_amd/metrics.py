@@ -1881,6 +1881,101 @@ def _ens_layout(forecast, fvar, tvar, ensemble_dim, allow_gather=False):
           to_dev(truth_table), strides[ensemble_dim], n_member, device, None)
 
 
+def _ens_concat_layout(forecast, fvar, tvar, ensemble_dim):
+  """The layout of one ensemble variable of a WINDOW of chunks
+  (evaluation.concat_chunks: `fvar.data` is an xarray_lite.SlabConcat over the
+  chunks' own arrays) for K3 by address: member 0's slab and the truth slab of
+  every outer index, one member stride for all of them.  None where the window
+  cannot be read where it lies (a cast, host data, members that do not follow
+  each other at one stride): the caller materialises it as before."""
+  if ensemble_dim not in fvar.dims:
+    raise ValueError(f'{ensemble_dim=} not found in {fvar.dims=}')
+  fdata, frest, layout = _spatial_last(fvar, None)
+  if not isinstance(fdata, xl.SlabConcat) or not fdata.on_device:
+    return None
+  tdata, trest, _ = _spatial_last(tvar, layout)
+  if ensemble_dim in trest:
+    raise ValueError(f'truth must not have the ensemble dim {ensemble_dim!r}')
+  dtype = fdata.dtype
+  on_device = (tdata.on_device if isinstance(tdata, xl.SlabConcat) else
+               isinstance(tdata, torch.Tensor) and tdata.device.type == 'cuda')
+  if dtype not in (torch.float32, torch.float64) or not on_device or (
+      _torch_dtype_of(tdata) != dtype):
+    return None
+  fsizes = dict(zip(frest, fdata.shape[:-2]))
+  n_member = fsizes[ensemble_dim]
+  out_dims = [d for d in frest if d != ensemble_dim]
+  sizes = {d: fsizes[d] for d in out_dims}
+  n_own = len(out_dims)
+  for d, n in zip(trest, tdata.shape[:-2]):
+    if d not in out_dims:
+      out_dims.append(d)
+      sizes[d] = n
+  out_dims = tuple(out_dims)
+  out_shape = tuple(sizes[d] for d in out_dims)
+  geo = _Geometry(layout, out_dims, out_shape,
+                  _coord_values(forecast, 'latitude'),
+                  _coord_values(forecast, 'longitude'))
+  _check_grid(geo, fdata)
+  _check_grid(geo, tdata)
+  # slab numbers (in the virtual concatenation of the chunks) [outer..., member]
+  index = np.moveaxis(fdata.index, frest.index(ensemble_dim), -1)
+  first = index[..., 0]
+  stride = 0
+  if n_member > 1:
+    steps = index[..., 1:] - index[..., :-1]
+    stride = int(steps.flat[0]) if steps.size else 0
+    home = lambda ix: np.searchsorted(fdata.offsets, ix, side='right') - 1
+    if stride < 0 or (steps != stride).any() or (
+        home(first) != home(index[..., -1])).any():
+      return None
+  wide = lambda a: np.ascontiguousarray(np.broadcast_to(
+      a.reshape(a.shape + (1,) * (len(out_dims) - n_own)), out_shape)).ravel()
+  first = wide(first)
+  n_outer = geo.n_outer
+  item = fdata.bases[0].element_size()
+  step = fdata.slab_shape[0] * fdata.slab_shape[1] * item
+  base_of = np.searchsorted(fdata.offsets, first, side='right') - 1
+  starts = np.array([b.data_ptr() for b in fdata.bases], dtype=np.int64)
+  ens_addr = starts[base_of] + (first - fdata.offsets[base_of]) * step
+  truth_table = _slab_table(out_dims, out_shape, trest, tdata.shape[:-2])
+  truth_addr, keep = _slab_addresses(tdata, truth_table, fdata.slab_shape[0],
+                                     fdata.slab_shape[1], n_outer)
+  return dict(geo=geo, dtype=dtype, n_member=n_member,
+              member_stride=stride * fdata.slab_shape[0] * fdata.slab_shape[1],
+              ens_addr=ens_addr, truth_addr=truth_addr,
+              keep=(fdata.bases, keep), ens_first=first,
+              truth_table=truth_table, truth_data=tdata)
+
+
+def _ens_pass_concat(fvar, tvar, lay, region, skipna):
+  """_ens_pass over a window read in place: (geo, device, plan, metrics)."""
+  geo = lay['geo']
+  device = engine.require_gpu()
+  regions, _ = _region_set_for(region)
+  pl = plan_lib.cached_plan(
+      geo.latitude, geo.longitude, geo.layout, regions, device,
+      plan_lib.ENSEMBLE_ROWS_PER_CHUNK)
+  rec = program.recorder()
+  if rec is not None and rec.probe:
+    return geo, pl, rec.fake_metrics(_lib.NMETRIC_ENS, pl.n_region, geo.n_outer,
+                                     device)
+  table = engine.upload_table(
+      np.concatenate([lay['ens_addr'], lay['truth_addr']]), device)
+  like = lay['keep'][0][0]     # (a tensor of the dtype: the kernel is told
+  metrics, _ = engine.ensemble_reduce(   # addresses, not tensors)
+      pl, like, lay['member_stride'], lay['n_member'], None, like, None,
+      geo.n_outer, skipna, addresses=table)
+  if rec is not None:
+    rec.record(kind='ens', plan=pl, ens=None, ens_raw=fvar.data,
+               truth=None, truth_raw=tvar.data, concat=lay,
+               member_stride=lay['member_stride'], n_member=lay['n_member'],
+               ens_table=None, truth_table=lay['truth_table'],
+               n_outer=geo.n_outer, skipna=bool(skipna), metrics=metrics,
+               dtype=lay['dtype'])
+  return geo, pl, metrics
+
+
 def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
               want_maps: bool = False):
   """All ensemble metrics of one variable for the active regions (and, with
@@ -1892,6 +1987,19 @@ def _ens_pass(forecast, truth, name, ensemble_dim, region, skipna,
   hit = _RESULTS.get(key)
   if hit is not None:
     return hit
+  lay = None
+  if isinstance(fvar.data, xl.SlabConcat) and not want_maps:
+    # a window of chunks (evaluate_chunks): read where the chunks lie
+    lay = _ens_concat_layout(forecast, fvar, tvar, ensemble_dim)
+  if lay is not None:
+    geo, pl, metrics = _ens_pass_concat(fvar, tvar, lay, region, skipna)
+    dev = metrics.reshape((_lib.NMETRIC_ENS, pl.n_region) + geo.out_shape)
+    geo.region_wsum = dict(zip(pl.region_names,
+                               (float(w) for w in pl.region_wsum_host)))
+    value = (geo, {nm: dev[:, i] for i, nm in enumerate(pl.region_names)},
+             lay['n_member'])
+    _RESULTS.put(key, tuple(pins), value)
+    return value
   (geo, ften, tten, ens_table, truth_table, member_slabs, n_member, device,
    member_ptrs) = _ens_layout(forecast, fvar, tvar, ensemble_dim,
                               allow_gather=True)
@@ -2006,6 +2114,12 @@ class EnsembleMetric(Metric):
     rank histograms) keep the generic per-region fan-out."""
     return (type(self).compute_chunk is EnsembleMetric.compute_chunk
             and type(self).compute is EnsembleMetric.compute)
+
+  @property
+  def _reads_slabs_in_place(self) -> bool:
+    """K3 reads a window of chunks through slab addresses (_ens_pass):
+    evaluate_chunks may batch chunks for the scalar ensemble metrics."""
+    return self._uses_fused_scalars()
 
   def compute_chunk_regions(self, forecast, truth, regions, skipna=False):
     if not self._uses_fused_scalars():

@@ -334,99 +334,19 @@ def _view_offset(view: torch.Tensor, raw, what: str) -> int:
   return lo - raw.data_ptr()
 
 
-class _EnsLaunch:
-  """One recorded ensemble pass (K3 + its region fold: metrics._ens_pass) of a
-  variable of the chunk, replayed through the C ABI with new base pointers --
-  the slab tables are functions of the shapes alone."""
+class _EnsPass:
+  """An ensemble pass (K3 + its region fold) over slabs given by ADDRESS
+  (wb2_ens_partials_addr): member 0's slab and the truth slab of every outer
+  index are `slot` / `rel` [2][n_total] -- pointer source and byte offset, as
+  for `_Launch`.  Subclasses fill them."""
 
-  def __init__(self, rec: dict, fmap: dict, tmap: dict, device):
-    pl = rec['plan']
-    role_e, role_t = fmap.get(id(rec['ens_raw'])), tmap.get(id(rec['truth_raw']))
-    if role_e is None or role_t is None:
-      raise _NotReplayable('an ensemble pass over arrays that are not '
-                           'variables of the chunk')
-    self.names = (role_e[1], role_t[1])
-    self.offsets = (_view_offset(rec['ens'], rec['ens_raw'], role_e[1]),
-                    _view_offset(rec['truth'], rec['truth_raw'], role_t[1]))
-    self.rec = rec
-    self.plan, self.skipna = pl, bool(rec['skipna'])
-    self.n_total = int(rec['n_outer'])
+  def _setup(self, pl, skipna, dtype, n_member, member_stride, n_total,
+             device):
+    self.plan, self.skipna, self.dtype = pl, bool(skipna), dtype
+    self.n_member, self.member_stride = int(n_member), int(member_stride)
+    self.n_total = int(n_total)
     self.n_metric = _lib.NMETRIC_ENS
     self.n_values = self.n_metric * pl.n_region * self.n_total
-    lib = self._lib = _lib.load()
-    k = lib.wb2_ens_num_slots(int(self.skipna))
-    tile = lib.wb2_ens_tile_cols(pl.n_col)
-    n_ctile = -(-pl.n_col // tile)
-    seg_eoff, n_ts = pl.seg_entries(tile)
-    self.partials = torch.empty((self.n_total, pl.n_chunk, pl.nwf, n_ts, k),
-                                dtype=torch.float64, device=device)
-    self.keep = (rec['ens_table'], rec['truth_table'], seg_eoff, pl)
-    ptr = _lib.ptr
-    dtype = engine._DTYPES[rec['ens'].dtype]
-    # (dtype, skipna, ens, ens_slab, truth, truth_slab, ...): 2 and 4 change
-    self.partials_args = [
-        dtype, int(self.skipna), None, ptr(rec['ens_table']), None,
-        ptr(rec['truth_table']), int(rec['n_member']),
-        int(rec['member_stride']), self.n_total, pl.n_row, pl.n_col,
-        ptr(pl.w_row), ptr(pl.w_col), ptr(pl.wfield), ptr(pl.chunk_row0),
-        ptr(pl.chunk_nrow), pl.n_chunk, n_ctile, ptr(pl.seg_col0),
-        ptr(seg_eoff), pl.n_seg, n_ts, ptr(self.partials), None]
-    self.combine_args = [
-        int(self.skipna), ptr(self.partials), self.n_total, pl.n_chunk, pl.nwf,
-        pl.n_seg, ptr(seg_eoff), n_ts, ptr(pl.band_chunk0), pl.n_band,
-        ptr(pl.coef_band), ptr(pl.coef_seg), ptr(pl.region_wf),
-        ptr(pl.region_wsum), pl.n_region, None]
-
-  def tables(self, forecast, truth) -> np.ndarray:
-    args = self.partials_args   # (base pointers: nothing to upload)
-    args[2] = forecast[self.names[0]].data.data_ptr() + self.offsets[0]
-    args[4] = truth[self.names[1]].data.data_ptr() + self.offsets[1]
-    return _NO_TABLE
-
-  def launch(self, base: int, out, stream) -> None:
-    lib = self._lib
-    args = self.partials_args
-    hook = engine._LAUNCH_HOOK
-    if hook is not None:
-      hook('begin', 'ens_partials')
-    status = lib.wb2_ens_partials_maps(*args, stream)
-    if status != 0:
-      _lib.check(status, 'wb2_ens_partials_maps')
-    if hook is not None:
-      hook('end', 'ens_partials')
-    status = lib.wb2_ens_combine(*self.combine_args, out.data_ptr(), stream)
-    if status != 0:
-      _lib.check(status, 'wb2_ens_combine')
-
-
-class _EnsFused:
-  """Several recorded ensemble passes of one chunk (its variables: same plan,
-  member count and stride, dtype, NaN rule) as ONE launch: member 0's slab and
-  the truth slab of every outer index by address (wb2_ens_partials_addr), one
-  fold over all of them.  The kernels are those of the separate passes and the
-  fold is per slab: the same bits.  The output block is
-  [metric][region][all slabs] -- `perm` maps the separate blocks' elements
-  into it."""
-
-  def __init__(self, singles, device):
-    first = singles[0]
-    pl = self.plan = first.plan
-    self.skipna = first.skipna
-    size = first.rec['ens'].element_size()
-    slab = pl.n_row * pl.n_col
-    self.names = [la.names for la in singles]
-    self.bases = [la.offsets for la in singles]
-    self.counts = [la.n_total for la in singles]
-    self.n_total = sum(self.counts)
-    self.n_metric = _lib.NMETRIC_ENS
-    self.n_values = self.n_metric * pl.n_region * self.n_total
-    self.rel_e, self.rel_t = [], []
-    for la in singles:
-      rec, n = la.rec, la.n_total
-      host = lambda tb: (np.arange(n, dtype=np.int64) if tb is None
-                         else tb.cpu().numpy().astype(np.int64))
-      self.rel_e.append(host(rec['ens_table']) * slab * size)
-      self.rel_t.append(host(rec['truth_table']) * slab * size)
     lib = self._lib = _lib.load()
     k = lib.wb2_ens_num_slots(int(self.skipna))
     tile = lib.wb2_ens_tile_cols(pl.n_col)
@@ -438,11 +358,10 @@ class _EnsFused:
     ptr = _lib.ptr
     # (dtype, skipna, ens addresses, truth addresses, ...)
     self.partials_args = [
-        engine._DTYPES[first.rec['ens'].dtype], int(self.skipna), None, None,
-        int(first.rec['n_member']), int(first.rec['member_stride']),
-        self.n_total, pl.n_row, pl.n_col, ptr(pl.w_row), ptr(pl.w_col),
-        ptr(pl.wfield), ptr(pl.chunk_row0), ptr(pl.chunk_nrow), pl.n_chunk,
-        n_ctile, ptr(pl.seg_col0), ptr(seg_eoff), pl.n_seg, n_ts,
+        engine._DTYPES[dtype], int(self.skipna), None, None, self.n_member,
+        self.member_stride, self.n_total, pl.n_row, pl.n_col, ptr(pl.w_row),
+        ptr(pl.w_col), ptr(pl.wfield), ptr(pl.chunk_row0), ptr(pl.chunk_nrow),
+        pl.n_chunk, n_ctile, ptr(pl.seg_col0), ptr(seg_eoff), pl.n_seg, n_ts,
         ptr(self.partials)]
     self.combine_args = [
         int(self.skipna), ptr(self.partials), self.n_total, pl.n_chunk, pl.nwf,
@@ -450,25 +369,14 @@ class _EnsFused:
         ptr(pl.coef_band), ptr(pl.coef_seg), ptr(pl.region_wf),
         ptr(pl.region_wsum), pl.n_region, None]
 
-  def perm(self) -> np.ndarray:
-    """Element of the separate passes' output blocks (one after the other) ->
-    element of the fused block."""
-    n_mr = self.n_metric * self.plan.n_region
-    out, off = [], 0
-    for n in self.counts:
-      mr = np.arange(n_mr, dtype=np.int64)[:, None]
-      out.append((mr * self.n_total + off + np.arange(n, dtype=np.int64)
-                  ).ravel())
-      off += n
-    return np.concatenate(out)
+  def fuse_key(self):
+    return (id(self.plan), self.skipna, self.n_member, self.member_stride,
+            self.dtype)
 
   def tables(self, forecast, truth) -> np.ndarray:
-    parts_e, parts_t = [], []
-    for (fname, tname), (oe, ot), re_, rt_ in zip(self.names, self.bases,
-                                                 self.rel_e, self.rel_t):
-      parts_e.append(forecast[fname].data.data_ptr() + oe + re_)
-      parts_t.append(truth[tname].data.data_ptr() + ot + rt_)
-    return np.concatenate(parts_e + parts_t)
+    ptrs = np.fromiter((g(forecast, truth).data_ptr() for g in self.sources),
+                       dtype=np.int64, count=len(self.sources))
+    return (ptrs[self.slot] + self.rel).ravel()
 
   def launch(self, base: int, out, stream) -> None:
     args = self.partials_args
@@ -488,14 +396,123 @@ class _EnsFused:
       _lib.check(status, 'wb2_ens_combine')
 
 
+class _EnsLaunch(_EnsPass):
+  """One recorded ensemble pass (metrics._ens_pass) of a variable of the chunk
+  -- or of a window of chunks read in place (metrics._ens_pass_concat: the
+  variable is an xarray_lite.SlabConcat, one pointer source per chunk) --,
+  replayed with new base pointers: the offsets are functions of the shapes
+  alone."""
+
+  def __init__(self, rec: dict, fmap: dict, tmap: dict, device):
+    pl = rec['plan']
+    role_e, role_t = fmap.get(id(rec['ens_raw'])), tmap.get(id(rec['truth_raw']))
+    if role_e is None or role_t is None:
+      raise _NotReplayable('an ensemble pass over arrays that are not '
+                           'variables of the chunk')
+    n = int(rec['n_outer'])
+    self.sources, self.source_keys = [], []
+    self.slot = np.zeros((2, n), dtype=np.int64)
+    self.rel = np.zeros((2, n), dtype=np.int64)
+    source_of: dict = {}
+
+    def slot_for(key, getter):
+      if key not in source_of:
+        source_of[key] = len(self.sources)
+        self.sources.append(getter)
+        self.source_keys.append(key)
+      return source_of[key]
+
+    def whole(which, name):
+      return slot_for((which, name), lambda f, t_, w=which, nm=name: (
+          f if w == 'f' else t_)[nm].data)
+
+    def per_chunk(j, which, name, x, index, step):
+      home = np.searchsorted(x.offsets, index, side='right') - 1
+      self.rel[j] = (index - x.offsets[home]) * step
+      for k in np.unique(home):
+        self.slot[j][home == k] = slot_for(
+            (which, name, int(k)), lambda f, t_, w=which, nm=name, k=int(k): (
+                f if w == 'f' else t_)[nm].data.bases[k])
+    lay = rec.get('concat')
+    if lay is None:
+      dtype = rec['ens'].dtype
+      step = pl.n_row * pl.n_col * rec['ens'].element_size()
+      host = lambda tb: (np.arange(n, dtype=np.int64) if tb is None
+                         else tb.cpu().numpy().astype(np.int64))
+      self.rel[0] = (_view_offset(rec['ens'], rec['ens_raw'], role_e[1]) +
+                     host(rec['ens_table']) * step)
+      self.rel[1] = (_view_offset(rec['truth'], rec['truth_raw'], role_t[1]) +
+                     host(rec['truth_table']) * step)
+      self.slot[0] = whole(*role_e)
+      self.slot[1] = whole(*role_t)
+    else:
+      dtype = lay['dtype']
+      x, tdata, tb = rec['ens_raw'], lay['truth_data'], lay['truth_table']
+      step = pl.n_row * pl.n_col * x.bases[0].element_size()
+      per_chunk(0, role_e[0], role_e[1], x, lay['ens_first'], step)
+      if tdata is not rec['truth_raw']:
+        raise _NotReplayable(f'{role_t[1]}: the pass read a copy of the chunk')
+      if isinstance(tdata, xl.SlabConcat):
+        index = tdata.index.ravel()
+        per_chunk(1, role_t[0], role_t[1], tdata,
+                  index if tb is None else index[tb], step)
+      else:
+        from weatherbench2_amd import metrics as gm
+        addr, _ = gm._slab_addresses(tdata, tb, pl.n_row, pl.n_col, n)
+        self.rel[1] = addr - tdata.data_ptr()
+        self.slot[1] = whole(*role_t)
+    self._setup(pl, rec['skipna'], dtype, rec['n_member'],
+                rec['member_stride'], n, device)
+
+
+class _EnsFused(_EnsPass):
+  """Several recorded ensemble passes of one chunk (its variables: same plan,
+  member count and stride, dtype, NaN rule) as ONE launch over the slabs of all
+  of them, one fold.  The kernels are those of the separate passes and the
+  fold is per slab: the same bits.  The output block is
+  [metric][region][all slabs] -- `perm` maps the separate blocks' elements
+  into it."""
+
+  def __init__(self, singles, device):
+    first = singles[0]
+    self.counts = [la.n_total for la in singles]
+    self.sources, self.source_keys = [], []
+    source_of: dict = {}
+    slots = []
+    for la in singles:
+      remap = np.empty(len(la.sources), dtype=np.int64)
+      for i, (key, getter) in enumerate(zip(la.source_keys, la.sources)):
+        if key not in source_of:
+          source_of[key] = len(self.sources)
+          self.sources.append(getter)
+          self.source_keys.append(key)
+        remap[i] = source_of[key]
+      slots.append(remap[la.slot])
+    self.slot = np.concatenate(slots, axis=1)
+    self.rel = np.concatenate([la.rel for la in singles], axis=1)
+    self._setup(first.plan, first.skipna, first.dtype, first.n_member,
+                first.member_stride, sum(self.counts), device)
+
+  def perm(self) -> np.ndarray:
+    """Element of the separate passes' output blocks (one after the other) ->
+    element of the fused block."""
+    n_mr = self.n_metric * self.plan.n_region
+    out, off = [], 0
+    for n in self.counts:
+      mr = np.arange(n_mr, dtype=np.int64)[:, None]
+      out.append((mr * self.n_total + off + np.arange(n, dtype=np.int64)
+                  ).ravel())
+      off += n
+    return np.concatenate(out)
+
+
 def _fuse_ensemble_launches(launches, device):
   """(launches with the compatible ensemble passes fused -- the fused launch
   stands where the first of its passes stood --, old -> new arena index or
   None)."""
   if os.environ.get('WB2HIP_FUSE_ENSEMBLE', '1') == '0':
     return launches, None
-  key = lambda x: (id(x.plan), x.skipna, int(x.rec['n_member']),
-                   int(x.rec['member_stride']), x.rec['ens'].dtype)
+  key = lambda x: x.fuse_key()
   by_key: dict = {}
   for i, la in enumerate(launches):
     if isinstance(la, _EnsLaunch):
@@ -719,13 +736,11 @@ class _Native:
   accumulation happen on the C side.  Same kernels, same order: the bits of the
   Python replay (`WB2HIP_NATIVE_REPLAY=0` keeps that one).
 
-  Raises _NotReplayable for what the C side does not cover (ensemble passes,
-  gathers from lazy containers): the program then replays from Python."""
+  Raises _NotReplayable for what the C side does not cover (gathers from lazy
+  containers): the program then replays from Python."""
 
   def __init__(self, launches, groups, arena, device, means):
     import ctypes
-    if not all(isinstance(la, _Launch) for la in launches):
-      raise _NotReplayable('ensemble passes replay from Python')
     lib = self._lib = _lib.load()
     self.device = device
     handle = ctypes.c_void_p()
@@ -754,6 +769,24 @@ class _Native:
     n_values = 0
     off = 0
     for la in launches:
+      if isinstance(la, _EnsPass):
+        # K3 + its fold: (member 0's slab, truth slab) of every outer index
+        remap = np.array([source(k, g) for k, g in zip(la.source_keys,
+                                                       la.sources)],
+                         dtype=np.int32)
+        slot = np.ascontiguousarray(remap[la.slot], dtype=np.int32)
+        rel = np.ascontiguousarray(la.rel, dtype=np.int64)
+        pl = la.plan
+        tables, held = engine.plan_tables(
+            pl, lib.wb2_ens_tile_cols(pl.n_col), field=pl.wfield)
+        _lib.check(lib.wb2_program_add_ens_launch(
+            handle, ctypes.byref(tables), engine._DTYPES[la.dtype],
+            int(la.skipna), la.n_member, la.member_stride, la.n_total,
+            slot.ctypes.data, rel.ctypes.data, la.partials.data_ptr(), off),
+                   'wb2_program_add_ens_launch')
+        keep.append((la, tables, held))
+        off += la.n_values
+        continue
       remap = np.array([source(k, g) for k, g in zip(la.source_keys,
                                                      la.sources)],
                        dtype=np.int32)
