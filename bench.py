@@ -47,6 +47,10 @@ and on one GPU (N = 1), each with its own `roofline`:
                   through evaluation.evaluate_chunks (its default window -- 24
                   chunks -- and batch_chunks=1 / 16 / 32):
                   tools/official_chunk.py;
+  api_probabilistic  the `probabilistic` config at the chunking of its command
+                  lines (IFS ENS 240 x 121, 50 members, init_time=1,lead_time=1,
+                  13 regions) through evaluation.evaluate_chunks, in its default
+                  windows and chunk by chunk: tools/official_probabilistic.py;
   pcie_inclusive  inputs arriving from pinned host memory through the
                   pipelined feeder (never `value`);
   cpu_baseline    the NumPy oracle on this box's host cores;
@@ -732,6 +736,11 @@ def main():
     leg('api_official_chunk', official_chunk.run, dev,
         batches=(1, 16, 32, None) if args.detail else (1, None),
         host_fed='both' if args.detail else True)
+    # ---- the `probabilistic` config at the chunking of ITS command lines
+    # (IFS ENS, 240 x 121, 50 members, init_time=1,lead_time=1): chunk by
+    # chunk and in evaluate_chunks' default windows
+    import official_probabilistic
+    leg('api_probabilistic', official_probabilistic.run, dev)
   if solo and not args.no_secondary:
     # ---- BASELINE configs[2] / configs[3], each with its own roofline;
     # bounded step counts keep the whole run in minutes
@@ -923,6 +932,12 @@ def compact(out: dict) -> dict:
       if 'value' in k1:
         line['api_official_chunk']['deterministic_spatial'][
             'chunk_by_chunk'] = k1['value']
+  if 'api_probabilistic' in out:
+    ap = out['api_probabilistic']
+    line['api_probabilistic'] = _pick(ap, 'value', 'ms_per_chunk', 'hbm_frac',
+                                      'grid', 'error')
+    if 'programs_1' in ap:
+      line['api_probabilistic']['chunk_by_chunk'] = ap['programs_1']['value']
   if 'pcie_inclusive' in out:
     pc = out['pcie_inclusive']
     line['pcie_inclusive'] = {
@@ -952,8 +967,8 @@ def emit(out: dict, args) -> None:
   line = compact(out)
   text = json.dumps(line)
   if len(text) >= LINE_LIMIT:  # shed the optional summaries, never the contract
-    for key in ('pcie_inclusive', 'api', 'unramped', 'api_official_chunk',
-                'spectrum', 'ensemble', 'full_suite', 'map_allreduce'):
+    for key in ('pcie_inclusive', 'api', 'unramped', 'api_probabilistic',
+                'api_official_chunk', 'spectrum', 'ensemble', 'full_suite', 'map_allreduce'):
       line.pop(key, None)
       text = json.dumps(line)
       if len(text) < LINE_LIMIT:

@@ -82,21 +82,16 @@ def build(dev, n_chunks: int, n_lon: int, n_lat: int, pool: int = 8,
   return chunks, metrics, bench.predefined_regions(), lat, lon
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--chunks', type=int, default=256)
-  ap.add_argument('--grid', default='240x121')
-  ap.add_argument('--windows', default='8,default',
-                  type=lambda v: [None if x == 'default' else int(x)
-                                  for x in v.split(',') if x])
-  args = ap.parse_args()
+def run(dev, chunks: int = 1024, grid: str = '240x121', windows=(None,),
+        generic: bool = False) -> dict:
+  """`bench.py`'s `api_probabilistic` leg: the replayed run chunk by chunk and
+  in windows (`generic`: also the generic path, 3 ms of Python per chunk)."""
   import torch
   from weatherbench2_amd import config, evaluation, program
-  dev = torch.device('cuda:0')
-  n_lon, n_lat = (int(x) for x in args.grid.split('x'))
-  chunks, metrics, regions, lat, lon = build(dev, args.chunks, n_lon, n_lat)
+  n_lon, n_lat = (int(x) for x in grid.split('x'))
+  chunk_list, metrics, regions, lat, lon = build(dev, chunks, n_lon, n_lat)
   cfg = config.Eval(metrics=metrics, regions=regions)
-  out = {'grid': args.grid, 'members': N_MEMBER, 'chunks': args.chunks,
+  out = {'grid': grid, 'members': N_MEMBER, 'chunks': chunks,
          'slabs_per_chunk': len(VARS_3D) * len(LEVELS) + len(VARS_2D),
          'regions': None if regions is None else len(regions)}
   pts = out['slabs_per_chunk'] * n_lon * n_lat
@@ -104,29 +99,55 @@ def main():
   chunk_bytes = pts * 4 * (N_MEMBER + 1)
   out['chunk_MB'] = chunk_bytes / 1e6
 
-  def leg(batch):
-    evaluation.evaluate_chunks(chunks[:max(8, 2 * (batch or 32))], cfg, False,
+  def leg(batch, some=None):
+    mine = chunk_list if some is None else chunk_list[:some]
+    evaluation.evaluate_chunks(mine[:max(8, 2 * (batch or 32))], cfg, False,
                                prefetch=0, batch_chunks=batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+    evaluation.evaluate_chunks(mine, cfg, False, prefetch=0,
                                batch_chunks=batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {'ms_per_chunk': dt / len(chunks) * 1e3,
-            'value': len(chunks) * pts / dt, 'unit': 'grid-point-evals/s',
-            'GBps': len(chunks) * chunk_bytes / dt / 1e9,
-            'hbm_frac': len(chunks) * chunk_bytes / dt / 8e12}
-  for how in ('0', '1'):
-    os.environ['WB2HIP_CHUNK_PROGRAM'] = how
-    out['programs_' + how] = leg(1)
-  # windows (evaluate_chunks' default: as many chunks as hold 16 GiB, at most
-  # 32): K3 reads the chunks of a window where they lie, one launch per
-  # member stride
-  for batch in args.windows:
-    out[f'window_{batch or "default"}'] = leg(batch)
+    return {'ms_per_chunk': dt / len(mine) * 1e3,
+            'value': len(mine) * pts / dt, 'unit': 'grid-point-evals/s',
+            'GBps': len(mine) * chunk_bytes / dt / 1e9,
+            'hbm_frac': len(mine) * chunk_bytes / dt / 8e12}
+  before = os.environ.get('WB2HIP_CHUNK_PROGRAM')
+  try:
+    if generic:
+      os.environ['WB2HIP_CHUNK_PROGRAM'] = '0'
+      out['programs_0'] = leg(1, some=min(chunks, 256))
+    os.environ['WB2HIP_CHUNK_PROGRAM'] = '1'
+    out['programs_1'] = leg(1)
+    # windows (evaluate_chunks' default: as many chunks as hold 16 GiB, at
+    # most 32): K3 reads the chunks of a window where they lie, one launch per
+    # member stride
+    for batch in windows:
+      out[f'window_{batch or "default"}'] = leg(batch)
+  finally:
+    if before is None:
+      os.environ.pop('WB2HIP_CHUNK_PROGRAM', None)
+    else:
+      os.environ['WB2HIP_CHUNK_PROGRAM'] = before
+  best = out.get('window_default') or out['programs_1']
+  out.update(value=best['value'], unit=best['unit'],
+             ms_per_chunk=best['ms_per_chunk'], hbm_frac=best['hbm_frac'])
   out['reasons'] = program.REASONS[-3:]
-  print(json.dumps(out))
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--chunks', type=int, default=1024)
+  ap.add_argument('--grid', default='240x121')
+  ap.add_argument('--windows', default='8,default',
+                  type=lambda v: [None if x == 'default' else int(x)
+                                  for x in v.split(',') if x])
+  args = ap.parse_args()
+  import torch
+  print(json.dumps(run(torch.device('cuda:0'), args.chunks, args.grid,
+                       args.windows, generic=True)))
 
 
 if __name__ == '__main__':

@@ -17,12 +17,15 @@ def main():
   dev = torch.device('cuda:0')
   chunks, metrics, regions, _, _ = op.build(dev, 512, 240, 121)
   cfg = config.Eval(metrics=metrics, regions=regions)
-  evaluation.evaluate_chunks(chunks[:8], cfg, False, prefetch=0,
-                             batch_chunks=1)
+  batch = None if len(sys.argv) > 1 and sys.argv[1] == 'default' else int(
+      sys.argv[1]) if len(sys.argv) > 1 else 1
+  evaluation.evaluate_chunks(chunks[:64], cfg, False, prefetch=0,
+                             batch_chunks=batch)
   torch.cuda.synchronize()
   pr = cProfile.Profile()
   pr.enable()
-  evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0, batch_chunks=1)
+  evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                             batch_chunks=batch)
   torch.cuda.synchronize()
   pr.disable()
   st = pstats.Stats(pr)

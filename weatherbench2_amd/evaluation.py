@@ -770,19 +770,41 @@ class RunningConcat:
       acc.count.index_fill_(0, index, 1.0)
 
   def result(self) -> xl.Dataset:
+    import torch
     import torch.distributed as dist
+    several = dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size() > 1)
+
+    def final_dtype(name):
+      try:
+        final = torch.from_numpy(
+            np.empty(0, dtype=np.dtype(self._dtypes[name]))).dtype
+        return final if final.is_floating_point else None
+      except TypeError:
+        return None
     pieces = {}
     for name, acc in self._acc.items():
       keys = list(self._rows[acc.key_dims])
       rows = sorted(acc.filled)
+      if rows:
+        # rows 0 .. n - 1 are a slice; the values leave the device in the
+        # dtype of the result (the same rounding as numpy's astype, half the
+        # bytes for float32 results).  One process: they stay on the device
+        # until they are in place (below).
+        values = (acc.total[:len(rows)] if rows[-1] == len(rows) - 1
+                  else acc.total[rows])
+        if several or not values.is_cuda:
+          final = final_dtype(name)
+          if final is not None and final != values.dtype:
+            values = values.to(final)
+          values = values.cpu().numpy()
+      else:
+        values = np.zeros((0,) + acc.rest_shape)
       pieces[name] = (acc.dims, acc.key_dims, acc.rest_shape,
-                      [keys[r] for r in rows],
-                      acc.total[rows].cpu().numpy() if rows else
-                      np.zeros((0,) + acc.rest_shape), self._dtypes[name])
+                      [keys[r] for r in rows], values, self._dtypes[name])
     seen = {d: list(v.values()) for d, v in self._seen.items()}
     everyone = [(pieces, seen)]
-    if dist.is_available() and dist.is_initialized() and (
-        dist.get_world_size() > 1):
+    if several:
       everyone = [None] * dist.get_world_size()
       dist.all_gather_object(everyone, (pieces, seen))
     labels: dict = {}
@@ -797,24 +819,67 @@ class RunningConcat:
       coords[d] = np.array(list(known.values()), dtype=np.asarray(first).dtype)
     out = xl.Dataset(coords=coords)
     names = []
+    places: dict = {}
     for rank_pieces, _ in everyone:
       names += [n for n in rank_pieces if n not in names]
     for name in names:
       ref = next(p[name] for p, _ in everyone if name in p)
       dims, key_dims, rest_shape, _, _, dtype = ref
-      pos = [{v: i for i, v in enumerate(labels[d])} for d in key_dims]
-      full = np.full(tuple(len(labels[d]) for d in key_dims) + rest_shape,
-                     np.nan, dtype=np.float64)
-      for rank_pieces, _ in everyone:
+      grid = tuple(len(labels[d]) for d in key_dims)
+      rest_dims = [d for d in dims if d not in key_dims]
+      order = list(key_dims) + rest_dims
+      perm = [order.index(d) for d in dims]
+      full = None
+      for rank, (rank_pieces, _) in enumerate(everyone):
         if name not in rank_pieces:
           continue
         _, _, _, keys, values, _ = rank_pieces[name]
-        for key, value in zip(keys, values):
-          full[tuple(p[k] for p, k in zip(pos, key))] = value
-      rest_dims = [d for d in dims if d not in key_dims]
-      order = list(key_dims) + rest_dims
-      full = np.transpose(full, [order.index(d) for d in dims])
-      out.data_vars[name] = xl.DataArray(full.astype(dtype), dims, coords, name)
+        if not keys:
+          continue
+        # where every row goes: one index array per key dim, shared by the
+        # variables of a rank that were filed under the same label combinations
+        memo = (rank, key_dims, len(keys), keys[0], keys[-1])
+        where = places.get(memo)
+        if where is None or where[0] != keys:
+          pos = [{v: i for i, v in enumerate(labels[d])} for d in key_dims]
+          index = tuple(
+              np.fromiter((p[key[j]] for key in keys), dtype=np.int64,
+                          count=len(keys)) for j, p in enumerate(pos))
+          flat = np.ravel_multi_index(index, grid) if grid else None
+          whole = flat is not None and flat.size == int(np.prod(grid)) and (
+              np.array_equal(flat, np.arange(flat.size)))
+          where = places[memo] = (keys, index, whole, {})
+        if isinstance(values, torch.Tensor):
+          # (one process, device rows) placed, transposed and rounded on the
+          # device: one compact copy to the host per variable
+          if where[2]:   # every combination, in order: the rows ARE the result
+            placed = values.reshape(grid + rest_shape)
+          else:
+            placed = torch.full(grid + rest_shape, float('nan'),
+                                dtype=values.dtype, device=values.device)
+            at = where[3].get(values.device)
+            if at is None:
+              at = where[3][values.device] = tuple(
+                  torch.as_tensor(ix, device=values.device) for ix in where[1])
+            placed[at] = values
+          placed = placed.permute(perm)
+          final = final_dtype(name)
+          if final is not None and final != placed.dtype:
+            placed = placed.to(final)
+          full = placed.contiguous().cpu().numpy()
+          perm = None
+          continue
+        if full is None:
+          full = np.full(grid + rest_shape, np.nan, dtype=np.result_type(
+              np.float32, np.asarray(values).dtype))
+        full[where[1]] = values
+      if full is None:
+        full = np.full(grid + rest_shape, np.nan, dtype=np.float64)
+      if perm is not None:
+        full = np.transpose(full, perm)
+      out.data_vars[name] = xl.DataArray(
+          np.ascontiguousarray(full.astype(dtype, copy=False)), dims, coords,
+          name)
     return out
 
 
