@@ -21,6 +21,7 @@ def main():
   ap.add_argument('--members', type=int, default=50)
   ap.add_argument('--gb', type=float, default=2.7)
   ap.add_argument('--grids', default='1440x721,240x121,64x32')
+  ap.add_argument('--iters', type=int, default=20)
   args = ap.parse_args()
   import torch
   import bench
@@ -42,11 +43,11 @@ def main():
     truth = torch.randn((n_slab, n_lat, n_lon), device=dev)
     run = lambda: engine.ensemble_reduce(pl, ens, n_slab * slab, m, None, truth,
                                          None, n_slab, False)
-    for _ in range(3):
+    for _ in range(max(3, args.iters // 4)):
       run()
     torch.cuda.synchronize()
     e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-    n = 20
+    n = args.iters
     e0.record()
     for _ in range(n):
       run()
