@@ -398,6 +398,23 @@ def test_pair_and_program_entry_points_validate_without_a_gpu(lib):
   assert h.wb2_program_add_launch(prog, ctypes.byref(plan), lib.MODE_DET,
                                   lib.WB2_F32, 0, 2, 3, 0, slot.ctypes.data,
                                   rel.ctypes.data, part, None, 0, 0) == 0
+  # an ensemble pass: member count, stride, tables and a float64 field
+  eslot = np.zeros(2 * 3, dtype=np.int32)
+  assert h.wb2_program_add_ens_launch(prog, ctypes.byref(plan), lib.WB2_F32, 0,
+                                      0, 128, 3, eslot.ctypes.data,
+                                      rel.ctypes.data, part, 0) < 0
+  assert b'bad sizes' in h.wb2_last_error()
+  assert h.wb2_program_add_ens_launch(prog, ctypes.byref(plan), lib.WB2_F32, 0,
+                                      5, 128, 3, None, rel.ctypes.data, part,
+                                      0) < 0
+  assert b'null pointer' in h.wb2_last_error()
+  field32 = lib.PlanTables(n_row=8, n_col=16, n_chunk=8, n_ctile=1, n_seg=1,
+                           n_ts=1, n_band=1, n_region=1, wfield=part,
+                           wfield_dtype=lib.WB2_F32)
+  assert h.wb2_program_add_ens_launch(prog, ctypes.byref(field32), lib.WB2_F32,
+                                      0, 5, 128, 3, eslot.ctypes.data,
+                                      rel.ctypes.data, part, 0) < 0
+  assert b'float64 weight field' in h.wb2_last_error()
   cell = np.array([0, 7], dtype=np.int32)
   base = np.zeros(2, dtype=np.int64)
   assert h.wb2_program_add_gather(prog, 1, 1, 2, 0, 8, 0, cell.ctypes.data,

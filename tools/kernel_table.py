@@ -52,6 +52,14 @@ ROWS = [
     ('official_chunk_by_chunk', 'stream_partials_kernel<float, 4, 7',
      'K1 SEEPS, one slab, on a side stream BESIDE K1 (its duration is not '
      'its own)', None),
+    # every K3 launch of `official_probabilistic.py --chunks 1024 --windows
+    # default --only-windows`: (64 warm-up + 1024 timed + 2 x 32 trial) chunks
+    # of 23 slabs x 51 arrays of 240 x 121 float32, each read once -- the bytes
+    # of the whole run over its launches (2 per 32-chunk window: 576 and 160
+    # slabs; the first window of a call goes variable by variable)
+    ('official_probabilistic', 'ens_partials_kernel<float, 64, 50',
+     'K3 by address, 32-chunk windows of the 240 x 121 ENS chunks (all '
+     'launches of the run)', ('total', 1152 * 23 * 240 * 121 * 51 * 4)),
     ('official_spatial', 'spatial_accumulate_addr_kernel',
      'K5a map accumulate, 85 destinations x 8 steps (k = 8)',
      85 * PTS * (8 * 8 + 48)),
@@ -80,6 +88,8 @@ def main():
     if not hits:
       continue
     name, calls, avg = max(hits, key=lambda s: s[1] * s[2])
+    if isinstance(nbytes, tuple):   # bytes of the whole run
+      nbytes = nbytes[1] / calls
     if nbytes:
       tbps = nbytes / (avg * 1e-9) / 1e12
       tail = f'{nbytes / 1e6:.1f} | {tbps:.2f} | **{tbps * 1e12 / PEAK:.3f}**'

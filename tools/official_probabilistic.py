@@ -83,7 +83,7 @@ def build(dev, n_chunks: int, n_lon: int, n_lat: int, pool: int = 8,
 
 
 def run(dev, chunks: int = 1024, grid: str = '240x121', windows=(None,),
-        generic: bool = False) -> dict:
+        generic: bool = False, chunk_by_chunk: bool = True) -> dict:
   """`bench.py`'s `api_probabilistic` leg: the replayed run chunk by chunk and
   in windows (`generic`: also the generic path, 3 ms of Python per chunk)."""
   import torch
@@ -119,7 +119,8 @@ def run(dev, chunks: int = 1024, grid: str = '240x121', windows=(None,),
       os.environ['WB2HIP_CHUNK_PROGRAM'] = '0'
       out['programs_0'] = leg(1, some=min(chunks, 256))
     os.environ['WB2HIP_CHUNK_PROGRAM'] = '1'
-    out['programs_1'] = leg(1)
+    if chunk_by_chunk:
+      out['programs_1'] = leg(1)
     # windows (evaluate_chunks' default: as many chunks as hold 16 GiB, at
     # most 32): K3 reads the chunks of a window where they lie, one launch per
     # member stride
@@ -130,7 +131,8 @@ def run(dev, chunks: int = 1024, grid: str = '240x121', windows=(None,),
       os.environ.pop('WB2HIP_CHUNK_PROGRAM', None)
     else:
       os.environ['WB2HIP_CHUNK_PROGRAM'] = before
-  best = out.get('window_default') or out['programs_1']
+  best = out.get('window_default') or out.get('programs_1') or next(
+      v for k, v in out.items() if k.startswith('window_'))
   out.update(value=best['value'], unit=best['unit'],
              ms_per_chunk=best['ms_per_chunk'], hbm_frac=best['hbm_frac'])
   out['reasons'] = program.REASONS[-3:]
@@ -144,10 +146,14 @@ def main():
   ap.add_argument('--windows', default='8,default',
                   type=lambda v: [None if x == 'default' else int(x)
                                   for x in v.split(',') if x])
+  ap.add_argument('--only-windows', action='store_true',
+                  help='no generic and no chunk-by-chunk leg (kernel profiles '
+                       'of the window launches)')
   args = ap.parse_args()
   import torch
   print(json.dumps(run(torch.device('cuda:0'), args.chunks, args.grid,
-                       args.windows, generic=True)))
+                       args.windows, generic=not args.only_windows,
+                       chunk_by_chunk=not args.only_windows)))
 
 
 if __name__ == '__main__':

@@ -37,6 +37,7 @@ if [ "$2" != quick ]; then
   stats k3_hosted python $GRAFT_REPO_ROOT/tools/k3_variants.py --reps 1 --only members44_hosted,members33_hosted,members77_hosted,members45,members51
   stats official_chunk python $GRAFT_REPO_ROOT/tools/official_chunk.py --batch default --chunks 480 --sections
   stats official_chunk_by_chunk python $GRAFT_REPO_ROOT/tools/official_chunk.py --batch 1 --chunks 256 --sections
+  stats official_probabilistic python $GRAFT_REPO_ROOT/tools/official_probabilistic.py --chunks 1024 --windows default --only-windows
   stats official_spatial python $GRAFT_REPO_ROOT/tools/spatial_leg.py --window
   stats official_spatial_by_chunk python $GRAFT_REPO_ROOT/tools/spatial_leg.py --chunk-by-chunk
   timeout 900 python tools/official_chunk.py --batch 1,16,32,default --host-fed > $OUT/${R}_official_chunk.json 2>/dev/null
@@ -45,6 +46,7 @@ if [ "$2" != quick ]; then
   timeout 300 python tools/pair_bench.py --no-field --window 8 --chunks 2 --reps 5 --json $OUT/${R}_pair_bench.jsonl > /dev/null 2>&1
   timeout 300 python tools/host_fed_leg.py 2>/dev/null | tail -1 > $OUT/${R}_host_fed_leg.json
   for g in 240x121 64x32; do timeout 300 python tools/official_probabilistic.py --grid $g 2>/dev/null | tail -1; done > $OUT/${R}_official_probabilistic.json
+  timeout 300 python tools/k3_grid.py --iters 200 2>/dev/null | tail -1 > $OUT/${R}_k3_grid.json
   timeout 300 python tools/map_accumulate_bench.py 2>/dev/null | tail -1 > $OUT/${R}_map_accumulate.json
   timeout 300 python tools/live_traffic.py --workload map_accumulate 2>/dev/null | tail -1 >> $OUT/${R}_map_accumulate.json
   timeout 600 python tools/k3_variants.py > $OUT/${R}_k3_variants.json 2>/dev/null
