@@ -1538,7 +1538,9 @@ def evaluate_chunks(
   configuration does): results accumulate per lead label (`RunningMean`).
 
   `batch_chunks` = k (deterministic suites: MSE / RMSE / MAE / Bias / ACC /
-  wind vectors; ignored otherwise; None = as many chunks as hold
+  wind vectors / SEEPS, the scalar ensemble metrics -- CRPS, spread, skill,
+  ensemble-mean MSE, variance: K3 reads the chunks of a window by address --
+  and the map suite; ignored otherwise; None = as many chunks as hold
   AUTO_BATCH_BYTES of input, at most AUTO_BATCH_MAX -- 24 of the official
   0.25-degree chunks) evaluates k consecutive chunks in ONE pass of
   the metric x region loop: they are concatenated without copying (`concat_chunks`: a
@@ -1590,7 +1592,8 @@ def evaluate_chunks(
       getattr(m, '_reads_slabs_in_place', False)
       for m in c.metrics.values()) for c in configs):
     # Chunks are batched only for metrics that read a concatenation in place
-    # (the deterministic suite: address tables); every other metric would
+    # (the deterministic suite and the scalar ensemble metrics: address
+    # tables); every other metric would
     # materialise the window first -- a copy of the data, slower than going
     # chunk by chunk.  Derived variables are computed on (and assigned into)
     # each chunk as the caller handed it in (evaluation.py:402-405).
