@@ -68,6 +68,7 @@ class MapSuite:
     self._keep = None
     self._const: dict = {}  # variable -> (offsets [metric][dst], lead, block)
     self._fast_extras: dict = {}  # (variable, metric index) -> _FastSeeps
+    self._times_memo: dict = {}
 
   def reset(self):
     pass
@@ -346,7 +347,11 @@ class _FastSeeps:
     dev = suite.device
     stream = engine.current_stream_ptr(dev)
     g = self.gather
-    table = g['values'](forecast)[g['cell']] + g['base']
+    memo = suite._times_memo   # (the chunk's valid times: once per chunk for
+    if memo.get('of') is not forecast:   # all SpatialSEEPS entries)
+      memo.clear()
+      memo['of'] = forecast
+    table = g['values'](forecast, memo)[g['cell']] + g['base']
     wet_ptr, wet_tab = self.wet.data_ptr(), None
     if self.n_outer == 1:   # one slab: its address, no table to upload
       wet_ptr += int(table[0]) * self.slab_bytes

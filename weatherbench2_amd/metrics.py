@@ -777,6 +777,9 @@ def _climatology_gather(climatology, cvar, forecast, geo, crest):
   cell, base = _climatology_structure(climatology, cvar, forecast, geo, crest,
                                       np.shape(vt), time_dims)
 
+  seen: dict = {}   # valid times -> values (a valid time comes back with
+                    # every lead that reaches it; read-only for the callers)
+
   def values(other, memo=None, shape=np.shape(vt), dims=time_dims):
     when = None if memo is None else memo.get('valid_times')
     if when is None or when[0] is not other:
@@ -786,8 +789,15 @@ def _climatology_gather(climatology, cvar, forecast, geo, crest):
     _, vt2, dims2 = when
     if np.shape(vt2) != shape or dims2 != dims:
       raise ValueError('the chunk\'s valid times have another layout')
-    return np.ascontiguousarray(_climatology_time_values(
-        climatology, crest, sizes, vt2, memo), dtype=np.int64).ravel()
+    key = np.ascontiguousarray(vt2).tobytes()
+    hit = seen.get(key)
+    if hit is None:
+      if len(seen) >= 4096:
+        seen.clear()
+      hit = seen[key] = np.ascontiguousarray(_climatology_time_values(
+          climatology, crest, sizes, vt2, memo), dtype=np.int64).ravel()
+      hit.setflags(write=False)
+    return hit
   return {'cell': cell, 'base': base, 'values': values,
           'key': (id(climatology), tuple(crest), tuple(sizes))}
 
