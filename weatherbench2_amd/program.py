@@ -26,9 +26,13 @@ first chunk of a structure while a recorder watches, and replays the rest:
            float32 number);
   verify   the mapping reproduces the first chunk's real result bit for bit
            (NaN == NaN), else the structure keeps the generic path;
-  replay   per chunk: pointers -> address tables (NumPy), one
-           wb2_det_suite_step per recorded launch, ONE wb2_gather_accumulate
-           that feeds every variable's (sum, count) accumulators.
+  replay   per chunk ONE wb2_program_replay call (`_Native`, csrc/program.cpp:
+           the chunk's base pointers and valid times in; address table, its
+           upload, every recorded launch -- wb2_det_suite_step /
+           wb2_det_wind_suite_step, or wb2_ens_partials_addr + wb2_ens_combine
+           for an ensemble pass -- and ONE wb2_gather_accumulate per config
+           that feeds every variable's (sum, count) accumulators on the C
+           side); WB2HIP_NATIVE_REPLAY=0: the same steps from Python.
 
 The replayed launches are the recorded ones (same plan, same chunking, same
 kernels) and the accumulation adds the same values in the same order, so a run
