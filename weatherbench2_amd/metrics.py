@@ -1901,14 +1901,15 @@ def _ens_concat_layout(forecast, fvar, tvar, ensemble_dim):
   if ensemble_dim not in fvar.dims:
     raise ValueError(f'{ensemble_dim=} not found in {fvar.dims=}')
   fdata, frest, layout = _spatial_last(fvar, None)
-  if not isinstance(fdata, xl.SlabConcat) or not fdata.on_device:
+  in_hbm = lambda x: isinstance(x, torch.Tensor) and x.device.type == 'cuda'
+  if not isinstance(fdata, xl.SlabConcat) or not in_hbm(fdata.bases[0]):
     return None
   tdata, trest, _ = _spatial_last(tvar, layout)
   if ensemble_dim in trest:
     raise ValueError(f'truth must not have the ensemble dim {ensemble_dim!r}')
   dtype = fdata.dtype
-  on_device = (tdata.on_device if isinstance(tdata, xl.SlabConcat) else
-               isinstance(tdata, torch.Tensor) and tdata.device.type == 'cuda')
+  on_device = in_hbm(tdata.bases[0] if isinstance(tdata, xl.SlabConcat)
+                     else tdata)
   if dtype not in (torch.float32, torch.float64) or not on_device or (
       _torch_dtype_of(tdata) != dtype):
     return None

@@ -256,7 +256,8 @@ class _Launch:
               self.slot[j, off:off + n][base == k] = s
           else:
             from weatherbench2_amd import metrics as gm
-            addr, _ = gm._slab_addresses(x, tb, pl.n_row, pl.n_col, n)
+            addr, held = gm._slab_addresses(x, tb, pl.n_row, pl.n_col, n)
+            _same_storage(held, x, name)
             self.rel[j, off:off + n] = addr - x.data_ptr()
             self.slot[j, off:off + n] = slot_for(
                 (which, name), lambda f, t_, w=which, nm=name: (
@@ -321,6 +322,16 @@ class _Launch:
       self.step.run(None, tables, out=out, stream_ptr=stream)
     else:
       self.step.run(None, tables, metrics=out, stream_ptr=stream)
+
+
+def _same_storage(held, raw, what: str) -> None:
+  """`held` = what metrics._slab_addresses addressed for the chunk's array
+  `raw`: the array itself or a view of it -- a compact copy (slabs that are not
+  intact in a strided view) has addresses that mean nothing for the next
+  chunk."""
+  if isinstance(held, torch.Tensor) and isinstance(raw, torch.Tensor) and (
+      held.untyped_storage().data_ptr() != raw.untyped_storage().data_ptr()):
+    raise _NotReplayable(f'{what}: the pass read a copy of the chunk')
 
 
 def _view_offset(view: torch.Tensor, raw, what: str) -> int:
@@ -462,7 +473,8 @@ class _EnsLaunch(_EnsPass):
                   index if tb is None else index[tb], step)
       else:
         from weatherbench2_amd import metrics as gm
-        addr, _ = gm._slab_addresses(tdata, tb, pl.n_row, pl.n_col, n)
+        addr, held = gm._slab_addresses(tdata, tb, pl.n_row, pl.n_col, n)
+        _same_storage(held, tdata, role_t[1])
         self.rel[1] = addr - tdata.data_ptr()
         self.slot[1] = whole(*role_t)
     self._setup(pl, rec['skipna'], dtype, rec['n_member'],
