@@ -391,6 +391,42 @@ def test_ensemble_passes_replay_too(skipna, member_first, n_member,
                            err_msg=f'{mname}/{rname}/{var}')
 
 
+@pytest.mark.parametrize('n_member,double', [(1, False), (3, True)])
+def test_ensemble_windows_of_one_member_and_of_float64(n_member, double,
+                                                       monkeypatch):
+  """The edges of the in-place window read: a single member (member stride 0;
+  CRPSSpread's zeros / NaN-over-an-empty-region rule) and float64 chunks."""
+  import torch
+  from weatherbench2_amd import config, evaluation, metrics as gm
+  from weatherbench2_amd import xarray_lite as xl
+  _, _, chunks = _ensemble_chunks(n_init=4, n_lead=2, n_member=n_member)
+
+  def own(ds):
+    return xl.Dataset({k: xl.DataArray(
+        (v.data.double() if double else v.data).contiguous().clone(), v.dims)
+                       for k, v in ds.data_vars.items()}, dict(ds.coords))
+  chunks = [(own(f), own(t_)) for f, t_ in chunks]
+  dim = 'number'
+  cfg = config.Eval(
+      metrics={'crps': gm.CRPS(ensemble_dim=dim),
+               'crps_spread': gm.CRPSSpread(ensemble_dim=dim),
+               'crps_skill': gm.CRPSSkill(ensemble_dim=dim),
+               'debiased': gm.DebiasedEnsembleMeanMSE(ensemble_dim=dim),
+               'ensemble_variance': gm.EnsembleVariance(ensemble_dim=dim)},
+      regions={'global': gm_regions().SliceRegion(),
+               'nowhere': gm_regions().SliceRegion(lat_slice=slice(91, 95))})
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '0')
+  want = evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                                    batch_chunks=1)
+  for how in ('0', '1'):
+    monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', how)
+    for batch in (2, None):
+      kwargs = {} if batch is None else {'batch_chunks': batch}
+      _same(evaluation.evaluate_chunks(chunks, cfg, False, prefetch=0,
+                                       **kwargs), want)
+  del torch
+
+
 @pytest.mark.parametrize('member_first', [True, False])
 @pytest.mark.parametrize('skipna', [False, True])
 @pytest.mark.parametrize('batch', [2, 4, None])
