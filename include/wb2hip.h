@@ -390,6 +390,15 @@ int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
                   int64_t n_outer, int64_t n_point, const double* aux,
                   double scalar, double* out, void* stream);
 
+/* wb2_seeps_map for slabs given by ADDRESS: addr[i][o] (DEV int64[n_outer], i =
+ * forecast, truth, wet threshold) is the byte address of input i's slab of
+ * outer index o -- the (init_time=1, lead_time=1) chunks of a window are
+ * allocations of their own; one launch scores the k chunks that carry one lead
+ * label (map_suite.py) and wb2_time_accumulate_runs adds them in chunk order. */
+int wb2_seeps_map_addr(int dtype, const int64_t* const* addr, int64_t n_outer,
+                       int64_t n_point, const double* aux, double scalar,
+                       double* out, void* stream);
+
 /*
  * RankHistogram (metrics.py:1894-2042): truth's rank among the n_member
  * members of each sample, binned by (n_member + 1) / n_bins, as float64.

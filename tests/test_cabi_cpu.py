@@ -130,6 +130,13 @@ def test_new_entry_points_validate_their_arguments(lib):
   assert rc < 0 and b'run=0' in h.wb2_last_error()
   assert h.wb2_time_accumulate_runs(lib.WB2_F32, None, 0, 1, 8, 0, None, 4,
                                     None, None, None) == 0
+  # SEEPS maps of slabs given by address: same checks as wb2_seeps_map
+  assert h.wb2_seeps_map_addr(lib.WB2_F32, None, 0, 100, None, 0.0, None,
+                              None) == 0
+  rc = h.wb2_seeps_map_addr(lib.WB2_F32, None, 4, 100, None, 0.0, None, None)
+  assert rc < 0 and b'null pointer' in h.wb2_last_error()
+  rc = h.wb2_seeps_map_addr(9, None, 4, 100, None, 0.0, None, None)
+  assert rc < 0 and b'unknown dtype' in h.wb2_last_error()
   # ensemble slabs by address: no slabs is a no-op, tables are required
   assert h.wb2_ens_partials_addr(lib.WB2_F32, 0, None, None, 5, 100, 0, 9, 64,
                                  None, None, None, None, None, 8, 1, None,

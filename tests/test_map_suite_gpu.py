@@ -179,6 +179,20 @@ def test_with_the_spatial_seeps_pair_of_compute_seeps(order, skipna,
   monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', 'verify')
   _same(evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
                                    batch_chunks=1), want)
+  # in windows the SEEPS maps of the k chunks of a lead label are ONE
+  # wb2_seeps_map_addr launch + one accumulate of k steps: the same bits
+  from weatherbench2_amd import map_suite
+  monkeypatch.setenv('WB2HIP_CHUNK_PROGRAM', '1')
+  many = []
+  real_many = map_suite._FastSeeps.run_many
+  monkeypatch.setattr(
+      map_suite._FastSeeps, 'run_many',
+      lambda self, pairs, mean: (many.append(len(pairs)),
+                                 real_many(self, pairs, mean))[1])
+  for kwargs in ({'batch_chunks': 6}, {}):
+    _same(evaluation.evaluate_chunks(chunks, cfg, skipna, prefetch=0,
+                                     **kwargs), want)
+  assert many and max(many) > 1, many
   labels = list(got.coords['metric'])
   # every other variable is NaN under the SEEPS labels
   assert np.isnan(got['geopotential'].values[labels.index('seeps_a')]).all()

@@ -131,6 +131,8 @@ _SIGNATURES = {
         _vp]),
     'wb2_seeps_map': (_int, [_int, _c.POINTER(_vp), _c.POINTER(_vp), _i64, _i64,
                              _vp, _c.c_double, _vp, _vp]),
+    'wb2_seeps_map_addr': (_int, [_int, _c.POINTER(_vp), _i64, _i64, _vp,
+                                  _c.c_double, _vp, _vp]),
     'wb2_axis_moments_splits': (_int, [_i64, _i64, _i64, _i64]),
     'wb2_axis_moments': (_int, [_int, _vp, _i64, _i64, _i64, _vp, _i64, _int,
                                 _int, _vp, _vp, _vp, _vp, _vp]),

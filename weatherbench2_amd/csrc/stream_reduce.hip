@@ -1550,6 +1550,7 @@ struct SeepsMapParams {
   double scalar;               // dry threshold
   double* out;                 // [n_outer][n_point]
   long long n_outer, n_point;
+  bool by_addr;                // slab[i][o] = byte address of the slab
 };
 
 // A thread owns one grid point of kSeepsMapSlabs consecutive outer slabs: p1
@@ -1573,8 +1574,10 @@ __global__ void __launch_bounds__(256) seeps_map_kernel(const SeepsMapParams p) 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const long long sl = p.slab[i] ? p.slab[i][o] : o;
-      in[s][i] = __builtin_nontemporal_load(static_cast<const T*>(p.in[i]) +
-                                            sl * p.n_point + pt);
+      // (o is the same for the whole workgroup: a scalar select)
+      const T* src = p.by_addr ? reinterpret_cast<const T*>(sl)
+                               : static_cast<const T*>(p.in[i]) + sl * p.n_point;
+      in[s][i] = __builtin_nontemporal_load(src + pt);
     }
   }
 #pragma unroll
@@ -2345,20 +2348,19 @@ int wb2_gather_accumulate_rows(const double* arena, const int32_t* src,
   return 0;
 }
 
-int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
-                  int64_t n_outer, int64_t n_point, const double* aux,
-                  double scalar, double* out, void* stream) {
-  WB2_TRACE();
-  using namespace wb2;
-  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
-  WB2_EMPTY_OK(n_outer);
-  WB2_EMPTY_OK(n_point);
-  WB2_REQUIRE(in && in[0] && in[1] && in[2] && aux && out,
-              "null pointer argument");
+}  // extern "C"
+
+namespace wb2 {
+namespace {
+int seeps_map_impl(int dtype, const void* const* in,
+                   const int64_t* const* slab, bool by_addr, int64_t n_outer,
+                   int64_t n_point, const double* aux, double scalar,
+                   double* out, void* stream) {
   if (n_outer == 0 || n_point == 0) return 0;
   SeepsMapParams p{};
+  p.by_addr = by_addr;
   for (int i = 0; i < 3; ++i) {
-    p.in[i] = in[i];
+    p.in[i] = in ? in[i] : nullptr;
     p.slab[i] = slab ? reinterpret_cast<const long long*>(slab[i]) : nullptr;
   }
   p.aux = aux;
@@ -2378,6 +2380,38 @@ int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
     hipLaunchKernelGGL(seeps_map_kernel<double>, grid, dim3(256), 0, s, p);
   WB2_HIP_OK(hipGetLastError());
   return 0;
+}
+}  // namespace
+}  // namespace wb2
+
+extern "C" {
+
+int wb2_seeps_map(int dtype, const void* const* in, const int64_t* const* slab,
+                  int64_t n_outer, int64_t n_point, const double* aux,
+                  double scalar, double* out, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_EMPTY_OK(n_point);
+  WB2_REQUIRE(in && in[0] && in[1] && in[2] && aux && out,
+              "null pointer argument");
+  return seeps_map_impl(dtype, in, slab, false, n_outer, n_point, aux, scalar,
+                        out, stream);
+}
+
+int wb2_seeps_map_addr(int dtype, const int64_t* const* addr, int64_t n_outer,
+                       int64_t n_point, const double* aux, double scalar,
+                       double* out, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(dtype == WB2_F32 || dtype == WB2_F64, "unknown dtype %d", dtype);
+  WB2_EMPTY_OK(n_outer);
+  WB2_EMPTY_OK(n_point);
+  WB2_REQUIRE(addr && addr[0] && addr[1] && addr[2] && aux && out,
+              "null pointer argument");
+  return seeps_map_impl(dtype, nullptr, addr, true, n_outer, n_point, aux,
+                        scalar, out, stream);
 }
 
 }  // extern "C"

@@ -131,9 +131,13 @@ class MapSuite:
                                                last[key][3])
     self._launch(groups)
     self._fill(mean)
-    for f, t_ in pairs:
-      for name, m, metric in self.extras:
-        self._extra(name, m, metric, f, t_, mean)
+    for name, m, metric in self.extras:
+      fast = self._fast_extras.get((name, m))
+      if fast and all(fast.matches(f, t_) for f, t_ in pairs):
+        fast.run_many(pairs, mean)   # one map launch + one accumulate
+      else:
+        for f, t_ in pairs:
+          self._extra(name, m, metric, f, t_, mean)
 
   def _fill(self, mean):
     """Without skipna a metric that lacks the variable leaves NaN sums (NaN
@@ -329,6 +333,7 @@ class _FastSeeps:
     self.scalar = float(metric.dry_threshold_mm / 1000.0)
     self.out = torch.empty((self.n_outer, self.n_point), dtype=torch.float64,
                            device=suite.device)
+    self._outs: dict = {}   # chunks per launch -> map buffer (run_many)
     # the map as the metric hands it over: out_dims + the two spatial dims
     axis = geo.out_dims.index(suite.time_dim)
     shape = tuple(geo.out_shape)
@@ -373,6 +378,61 @@ class _FastSeeps:
     dst = engine.upload_table(rows * block + const[self.m], dev)
     status = lib.wb2_time_accumulate_runs(
         _lib.WB2_F64, self.out.data_ptr(), self.n_lead, self.n_time,
+        self.n_tail, int(suite.skipna), dst.data_ptr(), n_point,
+        acc.total.data_ptr(),
+        acc.count.data_ptr() if suite.skipna else None, stream)
+    if status != 0:
+      _lib.check(status, 'wb2_time_accumulate_runs')
+
+
+  def run_many(self, pairs, mean) -> None:
+    """The k chunks of a window that carry the same lead labels: ONE
+    wb2_seeps_map_addr launch over the slabs of all of them (by address) and
+    ONE wb2_time_accumulate_runs that adds the k chunks' time steps in chunk
+    order -- the additions of k calls of `run`, in the same order."""
+    import ctypes
+    suite, lib = self.suite, self._lib
+    dev = suite.device
+    stream = engine.current_stream_ptr(dev)
+    k, n = len(pairs), self.n_outer
+    g = self.gather
+    memo = suite._times_memo
+    addr = np.empty((3, k, n), dtype=np.int64)
+    own = np.arange(n, dtype=np.int64) * self.slab_bytes
+    for c, (forecast, truth) in enumerate(pairs):
+      if memo.get('of') is not forecast:
+        memo.clear()
+        memo['of'] = forecast
+      table = g['values'](forecast, memo)[g['cell']] + g['base']
+      addr[0, c] = forecast[self.name].data.data_ptr() + own
+      addr[1, c] = truth[self.name].data.data_ptr() + own
+      addr[2, c] = self.wet.data_ptr() + table * self.slab_bytes
+    # a chunk's slabs run (lead part, time, tail); the launch writes them as
+    # (lead part, chunk, time, tail): k chunks = k x n_time steps of one run
+    tail = self.n_tail // self.n_point
+    addr = addr.reshape(3, k, self.n_lead, self.n_time, tail).transpose(
+        0, 2, 1, 3, 4)
+    tab = engine.upload_table(np.ascontiguousarray(addr).ravel(), dev)
+    out = self._outs.get(k)
+    if out is None:
+      out = self._outs[k] = torch.empty((k * n, self.n_point),
+                                        dtype=torch.float64, device=dev)
+    base = tab.data_ptr()
+    tabs = (ctypes.c_void_p * 3)(base, base + 8 * k * n, base + 16 * k * n)
+    status = lib.wb2_seeps_map_addr(self.code, tabs, k * n, self.n_point,
+                                    self.aux.data_ptr(), self.scalar,
+                                    out.data_ptr(), stream)
+    if status != 0:
+      _lib.check(status, 'wb2_seeps_map_addr')
+    forecast = pairs[-1][0]
+    const, lead, block, n_point = suite._const[self.name]
+    acc = mean._acc[self.name]
+    rows = 0
+    if acc.split is not None:
+      rows = acc.rows(np.asarray(forecast.coords[acc.split]))[lead]
+    dst = engine.upload_table(rows * block + const[self.m], dev)
+    status = lib.wb2_time_accumulate_runs(
+        _lib.WB2_F64, out.data_ptr(), self.n_lead, k * self.n_time,
         self.n_tail, int(suite.skipna), dst.data_ptr(), n_point,
         acc.total.data_ptr(),
         acc.count.data_ptr() if suite.skipna else None, stream)
