@@ -902,6 +902,16 @@ int wb2_uploader_upload_many(void* uploader, int32_t n, void* const* dst,
                              const void* const* src, const int64_t* nbytes,
                              void* stream);
 
+/* The way back: results that leave for the host (the float64 time-mean maps
+ * of the Spatial* metrics are gigabytes per variable; the reference writes
+ * them out after xbeam.Mean, weatherbench2/evaluation.py:735-752).  dst (HOST,
+ * pageable) <- src (DEV), nbytes, through the same ring: the DMAs of the next
+ * n_slots - 1 slices run on `stream` (behind whatever produced src there) while
+ * the pool copies the slice that has arrived out of its slot.  Returns when
+ * dst is complete. */
+int wb2_uploader_download(void* uploader, void* dst, const void* src,
+                          int64_t nbytes, void* stream);
+
 /* RCCL communicator for callers that do not use torch.distributed: rank 0 makes
  * a 128-byte id (wb2_comm_unique_id), distributes it by any means (file, MPI,
  * socket), every rank calls wb2_comm_init_rank with the device it computes on

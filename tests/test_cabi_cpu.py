@@ -114,6 +114,8 @@ def test_new_entry_points_validate_their_arguments(lib):
                                  None) < 0
   assert h.wb2_uploader_upload(None, None, None, 16, None) < 0
   assert b'null uploader' in h.wb2_last_error()
+  assert h.wb2_uploader_download(None, None, None, 16, None) < 0
+  assert b'null uploader' in h.wb2_last_error()
   # the map entries: empty chunks are no-ops, the rest is checked up front
   assert h.wb2_spatial_accumulate_addr(lib.WB2_F32, 0, 1, None, None, 0, 5,
                                        100, None, None, None) == 0

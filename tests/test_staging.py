@@ -75,6 +75,47 @@ def test_upload_round_trip():
 
 
 @pytest.mark.gpu
+def test_download_round_trip(monkeypatch):
+  """Results leave through the same ring (wb2_uploader_download): every byte of
+  the tensor, behind its producer on the current stream, between uploads."""
+  import torch
+  from weatherbench2_amd import feeder
+  dev = torch.device('cuda')
+  g = torch.Generator(device=dev).manual_seed(3)
+  sl = feeder._SLICE_BYTES
+  # the small ones take torch's own copy; then one slice, a ring and a bit,
+  # three rounds of the ring with a ragged tail
+  monkeypatch.setattr(feeder, '_DOWNLOAD_MIN_BYTES', 1 << 16)
+  for nbytes in (8, 1 << 16, sl, feeder._RING_SLOTS * sl + 4096,
+                 3 * feeder._RING_SLOTS * sl // 2 + 12344):
+    x = torch.randn(nbytes // 8, dtype=torch.float64, device=dev, generator=g)
+    y = x * 2.0 + 1.0          # produced on the current stream, not yet done
+    got = feeder.download(y)
+    assert got.dtype == np.float64 and got.shape == (nbytes // 8,)
+    assert np.array_equal(got, y.cpu().numpy())
+    del x, y
+  # a strided view leaves as its contiguous copy; float32; 3-D
+  x = torch.randn((5, 300, 4100), dtype=torch.float32, device=dev, generator=g)
+  view = x[:, ::2, 1:4097]
+  got = feeder.download(view)
+  assert got.dtype == np.float32 and got.shape == (5, 150, 4096)
+  assert np.array_equal(got, view.cpu().numpy())
+  # between two uploads: the slots of the upload are waited for, the ring goes
+  # on where the download left it
+  rs = np.random.default_rng(5)
+  a = rs.standard_normal(3 * sl // 4 + 17)
+  up = feeder.upload(a, dev)
+  got = feeder.download(x)
+  up2 = feeder.upload(a, dev)
+  torch.cuda.synchronize()
+  assert np.array_equal(got, x.cpu().numpy())
+  assert np.array_equal(up.cpu().numpy(), a)
+  assert np.array_equal(up2.cpu().numpy(), a)
+  # host tensors pass through
+  assert np.array_equal(feeder.download(torch.arange(5.0)), np.arange(5.0))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('batch', [1, 3, None])
 def test_host_fed_chunks_equal_device_resident_chunks(batch):
   """The same chunk list once device-resident, once with every forecast

@@ -169,6 +169,7 @@ _SIGNATURES = {
     'wb2_uploader_destroy': (_int, [_vp]),
     'wb2_host_copy': (_int, [_vp, _vp, _i64, _i32]),
     'wb2_uploader_upload': (_int, [_vp, _vp, _vp, _i64, _vp]),
+    'wb2_uploader_download': (_int, [_vp, _vp, _vp, _i64, _vp]),
     'wb2_uploader_upload_many': (_int, [_vp, _i32, _c.POINTER(_vp),
                                         _c.POINTER(_vp), _c.POINTER(_i64),
                                         _vp]),

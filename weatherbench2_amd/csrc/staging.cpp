@@ -329,6 +329,66 @@ int wb2_uploader_upload_many(void* uploader, int32_t n, void* const* dst,
   return rc != 0 ? rc : rj;
 }
 
+int wb2_uploader_download(void* uploader, void* dst, const void* src,
+                          int64_t nbytes, void* stream) {
+  WB2_TRACE();
+  using namespace wb2;
+  WB2_REQUIRE(uploader != nullptr, "null uploader");
+  WB2_EMPTY_OK(nbytes);
+  WB2_REQUIRE(dst && src, "null pointer argument");
+  auto* up = static_cast<Uploader*>(uploader);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n_slots = (int)up->slots.size();
+  // slots still being read by the DMA of an earlier upload
+  for (int i = 0; i < n_slots; ++i) {
+    if (up->busy[i]) {
+      WB2_HIP_OK(hipEventSynchronize(up->events[i]));
+      up->busy[i] = false;
+    }
+  }
+  const char* from = static_cast<const char*>(src);
+  char* to = static_cast<char*>(dst);
+  size_t left = (size_t)nbytes;
+  // slices in flight, oldest first: slot (head + k) % n_slots holds slice k
+  int head = up->next, in_flight = 0;
+  char* out = to;
+  std::vector<size_t> len((size_t)n_slots, 0);
+  auto drain_one = [&]() -> int {
+    WB2_HIP_OK(hipEventSynchronize(up->events[head]));
+    up->pool.copy(out, up->slots[head], len[(size_t)head]);
+    out += len[(size_t)head];
+    head = (head + 1) % n_slots;
+    --in_flight;
+    return 0;
+  };
+  int rc = 0;
+  while (rc == 0 && (left || in_flight)) {
+    if (left && in_flight < n_slots) {
+      const size_t n = left < up->slot_bytes ? left : up->slot_bytes;
+      const int i = (head + in_flight) % n_slots;
+      const hipError_t e1 =
+          hipMemcpyAsync(up->slots[i], from, n, hipMemcpyDeviceToHost, s);
+      const hipError_t e2 =
+          e1 == hipSuccess ? hipEventRecord(up->events[i], s) : e1;
+      if (e2 != hipSuccess) {
+        // what is in flight writes into the ring: wait before the slots are
+        // used again
+        (void)hipStreamSynchronize(s);
+        return fail("HIP error: %s", hipGetErrorString(e2));
+      }
+      len[(size_t)i] = n;
+      ++in_flight;
+      from += n;
+      left -= n;
+    } else {
+      rc = drain_one();
+    }
+  }
+  if (rc != 0) (void)hipStreamSynchronize(s);
+  up->next = head;
+  return rc;
+}
+
 }  // extern "C"
 
 namespace wb2 {

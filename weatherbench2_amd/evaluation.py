@@ -598,10 +598,12 @@ class RunningMean:
     coords = dict(self._coords)
     split_labels = None
     out_vars = {}
+    from weatherbench2_amd import feeder
     for n in names:
       acc = self._acc[n]
       total, count = sums[n] if in_group else laid_out(n)
-      mean = (total / count).cpu().numpy()  # 0/0 -> NaN like an empty mean
+      # 0/0 -> NaN like an empty mean; maps leave through the pinned ring
+      mean = feeder.download(total / count)
       del total, count
       if acc.split is not None:
         mean = np.moveaxis(mean, 0, acc.pos)
