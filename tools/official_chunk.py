@@ -229,8 +229,9 @@ def measure_spatial(chunks, cfg=None, short: int = 64, long: int = 256,
 
 def _measure_spatial(chunks, cfg, short, long, batch, k) -> dict:
   """One window size.  The first chunk of a structure takes the generic path
-  and result() brings 8.5 GB of mean maps to the host -- one-offs that a
-  production run spreads over ~10^4 chunks: reported are the fused kernel
+  and result() brings 8.5 GB of mean maps to the host (through the pinned
+  ring: `result`) -- one-offs that a production run spreads over ~10^4
+  chunks: reported are the fused kernel
   (map_suite.py) under HIP events, the host time per chunk from two list
   lengths (up to the moment result() is called), and the walls."""
   import torch
@@ -268,6 +269,11 @@ def _measure_spatial(chunks, cfg, short, long, batch, k) -> dict:
       torch.cuda.synchronize()
       walls[n] = time.perf_counter() - t0
       hosts[n] = marks['enqueued'] - t0
+      # result(): the queue drains, then the mean maps leave for the host
+      # through the pinned ring (feeder.download)
+      marks['result_s'] = time.perf_counter() - marks['enqueued']
+      marks['result_bytes'] = sum(
+          v.data.nbytes for v in out.data_vars.values())
     finally:
       evaluation.RunningMean.result = real_result
       evaluation._evaluate_map_window = real_window
@@ -297,6 +303,9 @@ def _measure_spatial(chunks, cfg, short, long, batch, k) -> dict:
       'unit': 'grid-point-evals/s',
       'steady_ms_per_chunk': steady_ms, 'host_ms_per_chunk': host_ms,
       'wall_s': {str(n): v for n, v in walls.items()},
+      'result': {'bytes': marks['result_bytes'], 's': marks['result_s'],
+                 'GBps_incl_queue_drain':
+                     marks['result_bytes'] / marks['result_s'] / 1e9},
       'fused_launches': len(ms),
       'roofline': {
           'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,

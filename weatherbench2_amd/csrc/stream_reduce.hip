@@ -349,6 +349,9 @@ __device__ __forceinline__ bool eval_slots(
 #ifndef WB2_NT_LOADS
 #define WB2_NT_LOADS 1
 #endif
+#ifndef WB2_K1_RING_DEFAULT
+#define WB2_K1_RING_DEFAULT 0   // rows per wave in flight of the ring form
+#endif
 #ifndef WB2_GAUSS_GROUP
 // Gaussian modes: points of a lane's load evaluated as one straight-line block
 // (2: two dependent fp64 chains interleaved at 114 VGPRs; 4 costs a wave per SIMD)
@@ -398,6 +401,54 @@ __device__ __forceinline__ void load_wf(const WB2_GLOBAL FT* p,
   for (int e = 0; e < VEC; ++e) v[e] = (double)x[e];
 }
 
+// LDS-DMA (gfx950 `global_load_lds_dwordx4`): 16 bytes per lane straight from
+// global memory into LDS at M0 + 16 * lane, no VGPR in between.  `row` is the
+// wave-uniform row pointer (an SGPR pair), `voff` the lane's byte offset in the
+// row, `lds_dst` the wave-uniform LDS byte address of the 1 KiB destination.
+// hipcc does not count these loads (inline asm): the ring kernel waits for
+// them itself (ring_wait).
+template <bool NT>
+__device__ __forceinline__ void glds16(unsigned long long row, unsigned voff,
+                                       unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (NT) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(row), "s"(lds_dst)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(row), "s"(lds_dst)
+        : "memory");
+  }
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n in [0, 23]
+__device__ __forceinline__ void ring_wait(int n) {
+  switch (n) {
+#define WB2_RING_WAIT(N) \
+  case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    WB2_RING_WAIT(0) WB2_RING_WAIT(1) WB2_RING_WAIT(2) WB2_RING_WAIT(3)
+    WB2_RING_WAIT(4) WB2_RING_WAIT(5) WB2_RING_WAIT(6) WB2_RING_WAIT(7)
+    WB2_RING_WAIT(8) WB2_RING_WAIT(9) WB2_RING_WAIT(10) WB2_RING_WAIT(11)
+    WB2_RING_WAIT(12) WB2_RING_WAIT(13) WB2_RING_WAIT(14) WB2_RING_WAIT(15)
+    WB2_RING_WAIT(16) WB2_RING_WAIT(17) WB2_RING_WAIT(18) WB2_RING_WAIT(19)
+    WB2_RING_WAIT(20) WB2_RING_WAIT(21) WB2_RING_WAIT(22) WB2_RING_WAIT(23)
+#undef WB2_RING_WAIT
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
 // Geometry.  Workgroups are dealt to the 8 XCDs round-robin by their linear
 // index, and the chunks of a slab differ in size (bands cut them at region
 // boundaries, the last one is short, the padding to a multiple of 8 is empty).
@@ -423,8 +474,19 @@ __device__ __forceinline__ void load_wf(const WB2_GLOBAL FT* p,
 // lane are in flight before the first one is consumed.  The prologue is written
 // branch-free on purpose: every scalar (table / slab-index) load is issued
 // before the first wait, instead of one dependent round trip per table.
+//
+// RING > 0 (float32, 4 columns per lane, point-op modes, no skipna): the rows
+// of the chunk come through a ring of RING row stages per wave in LDS, filled
+// by LDS-DMA -- row r + RING is requested when row r has been read out of its
+// stage, so RING rows of NIN (+ 1: the float32 weight field) x 1 KiB per wave
+// are in flight ALL the time and none of them holds a VGPR.  The batch form
+// has its U rows in flight only while it waits for them (then it computes with
+// nothing outstanding), and what it may keep in flight is bounded by registers:
+// the land-mask instantiation (157 VGPRs, 3 waves per SIMD) has 72 KB per CU
+// outstanding at best.  Same loads per lane, same arithmetic in the same order:
+// the same bits.
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF,
-          bool SG = false, typename FT = double>
+          bool SG = false, typename FT = double, int RING = 0>
 __global__ void __launch_bounds__(512)
     stream_partials_kernel(const StreamParams p) {
   using M = ModeTraits<MODE, SKIPNA>;
@@ -693,6 +755,70 @@ __global__ void __launch_bounds__(512)
                 MODE == WB2_MODE_SEEPS ? bt.ax[u] : nullptr);
     };
     int r = 0;
+    if constexpr (RING > 0) {
+      static_assert(sizeof(T) == 4 && VEC == 4 && POINT_OPS && !SKIPNA && !SG,
+                    "ring kernel: float32 x 4 columns, point-op modes");
+      static_assert(!WF || sizeof(FT) == 4, "ring kernel: float32 field");
+      constexpr int NSLOT = NIN + (WF ? 1 : 0);
+      static_assert((RING - 1) * NSLOT <= 23, "ring_wait covers 0..23");
+      extern __shared__ __attribute__((aligned(16))) char ring_lds[];
+      typedef __attribute__((address_space(3))) char* LdsPtr;
+      typedef T V4 __attribute__((ext_vector_type(4)));
+      const LdsPtr mine = (LdsPtr)ring_lds + wave * (RING * NSLOT * 1024);
+      const unsigned mine_addr = (unsigned)(unsigned long long)mine;
+      const unsigned voff = (unsigned)colb * 4u;
+      auto request = [&](int row) {   // wave-uniform row < nrow
+        const unsigned dst = mine_addr + (unsigned)(row % RING) * (NSLOT * 1024);
+#pragma unroll
+        for (int i = 0; i < NIN; ++i)
+          glds16<WB2_NT_LOADS != 0>(
+              reinterpret_cast<unsigned long long>(
+                  base[i] + (long long)row * p.n_col),
+              voff, dst + i * 1024);
+        if constexpr (WF)
+          glds16<false>(reinterpret_cast<unsigned long long>(
+                            wfp + (long long)row * p.n_col),
+                        voff, dst + NIN * 1024);
+      };
+      int requested = nrow < RING ? nrow : RING;
+      for (int q = 0; q < requested; ++q) request(q);
+#pragma clang loop unroll(disable)
+      for (; r < nrow; ++r) {
+        // rows r + 1 .. requested - 1 may still be on their way
+        ring_wait((requested - r - 1) * NSLOT);
+        const LdsPtr st = mine + (r % RING) * (NSLOT * 1024) + lane * 16;
+        T v[NIN][VEC];
+        double wf[VEC];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+          const V4 x = *reinterpret_cast<
+              const __attribute__((address_space(3))) V4*>(st + i * 1024);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[i][e] = x[e];
+        }
+        if constexpr (WF) {
+          const V4 x = *reinterpret_cast<
+              const __attribute__((address_space(3))) V4*>(st + NIN * 1024);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) wf[e] = (double)x[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) wf[e] = 1.0;
+        }
+        // the row weight by a scalar load of our own (behind the asm memory
+        // clobbers hipcc turns wrp[r] into a VECTOR load and waits vmcnt(0)
+        // for it: the ring would drain every row)
+        double wr;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0"
+                     : "=s"(wr)
+                     : "s"(wrp + r)
+                     : "memory");
+        // the stage (and wr) in registers before its next row is requested
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wr) : : "memory");
+        if (requested < nrow) request(requested++);
+        consume(v, wf, wr, nullptr);
+      }
+    }
 #pragma clang loop unroll(disable)
     for (; r + U <= nrow; r += U) {
       Batch bt;
@@ -1441,8 +1567,48 @@ bool field_f32_supported(int dtype, int mode) {
                               mode == WB2_MODE_WIND);
 }
 
+// The ring form of K1 (stream_partials_kernel<..., RING>): WB2HIP_K1_RING = rows
+// per wave in flight (0 = the batch form), WB2HIP_K1_RING_WAVES = waves per
+// workgroup (0 = as the batch form).
+// (read at every launch: tests and A/B runs switch inside one process)
+int ring_depth() {
+  const char* e = getenv("WB2HIP_K1_RING");
+  const int v = e ? atoi(e) : WB2_K1_RING_DEFAULT;
+  return v < 2 ? 0 : (v > 5 ? 5 : v);
+}
+int ring_waves() {
+  const char* e = getenv("WB2HIP_K1_RING_WAVES");
+  const int v = e ? atoi(e) : 0;
+  return v < 1 ? 0 : (v > 8 ? 8 : v);
+}
+
+template <typename T, int VEC, int MODE, bool SKIPNA, bool WF, typename FT,
+          int RING>
+int launch_ring(const StreamParams& p, dim3 grid, int threads,
+                hipStream_t stream) {
+  constexpr int NSLOT = ModeTraits<MODE, SKIPNA>::NIN + (WF ? 1 : 0);
+  const size_t lds = (size_t)(threads / kWave) * RING * NSLOT * 1024;
+  auto kern = stream_partials_kernel<T, VEC, MODE, SKIPNA, WF, false, FT, RING>;
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(kern),
+      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  WB2_HIP_OK(attr);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, p);
+  WB2_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int VEC, int MODE, bool SKIPNA, bool WF>
 int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
+  constexpr bool HAS_RING = std::is_same<T, float>::value && VEC == 4 &&
+                            !SKIPNA &&
+                            (MODE == WB2_MODE_DET || MODE == WB2_MODE_DET_ACC);
+  const bool ring = HAS_RING && ring_depth() > 0 && !p.unaligned &&
+                    (!WF || p.wfield_f32);
+  if (ring && ring_waves() > 0) {
+    const int tiles = p.n_ctile;
+    threads = (ring_waves() < tiles ? ring_waves() : tiles) * kWave;
+  }
   const int nwave = threads / kWave;
   const int n_tblk = (p.n_ctile + nwave - 1) / nwave;
   const long long gy = p.n_outer < 32768 ? p.n_outer : 32768;
@@ -1468,6 +1634,25 @@ int launch_stream(const StreamParams& p, int threads, hipStream_t stream) {
           dim3(threads), 0, stream, p);
       WB2_HIP_OK(hipGetLastError());
       return 0;
+    }
+  }
+  if constexpr (HAS_RING) {
+    if (ring) {
+      using FT = typename std::conditional<WF, float, double>::type;
+      switch (ring_depth()) {
+        case 2:
+          return launch_ring<T, VEC, MODE, SKIPNA, WF, FT, 2>(p, grid, threads,
+                                                              stream);
+        case 3:
+          return launch_ring<T, VEC, MODE, SKIPNA, WF, FT, 3>(p, grid, threads,
+                                                              stream);
+        case 4:
+          return launch_ring<T, VEC, MODE, SKIPNA, WF, FT, 4>(p, grid, threads,
+                                                              stream);
+        default:
+          return launch_ring<T, VEC, MODE, SKIPNA, WF, FT, 5>(p, grid, threads,
+                                                              stream);
+      }
     }
   }
   if constexpr (field_f32_supported<T, MODE>() && WF) {

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from weatherbench2_amd import engine
+from weatherbench2_amd import feeder
 from weatherbench2_amd import xarray_lite as xl
 
 EARTH_RADIUS_M = 1000 * (6357 + 6378) / 2  # schema.py:59
@@ -126,7 +127,7 @@ class ZonalEnergySpectrum(DerivedVariable):
                                        ('zonal_wavenumber', 'latitude'))
     coords['wavelength'] = xl.DataArray(wavelength,
                                         ('zonal_wavenumber', 'latitude'))
-    result = xl.DataArray(out.cpu().numpy(), out_dims, coords,
+    result = xl.DataArray(feeder.download(out), out_dims, coords,
                           self.variable_name)
     if out_dims != ref_dims:
       result = result.transpose(*ref_dims)
@@ -176,7 +177,7 @@ def zonal_energy_spectrum_area_mean(dataset, variable_name: str) -> xl.DataArray
             and not (isinstance(v, xl.DataArray)
                      and ({'longitude', 'latitude'} & set(v.dims)))}
   coords['zonal_wavenumber'] = np.arange(n_bins)
-  return xl.DataArray(out.cpu().numpy(), rest + ('zonal_wavenumber',), coords,
+  return xl.DataArray(feeder.download(out), rest + ('zonal_wavenumber',), coords,
                       variable_name)
 
 

@@ -320,7 +320,8 @@ class DataArray:
       # default stream; a reader on a private stream waits for that first
       from weatherbench2_amd import engine
       engine.order_read(self.data)
-      return self.data.detach().cpu().numpy()
+      from weatherbench2_amd import feeder
+      return feeder.download(self.data.detach())
     if isinstance(self.data, _LAZY):
       return self.data.materialize_host()
     return self.data
