@@ -619,6 +619,10 @@ __global__ void __launch_bounds__(512)
         // out of the sum: clearing the high dword (sign, exponent, top of the
         // mantissa) of the float64 slot does that in ONE 32-bit AND instead
         // of the two v_cndmask of a 64-bit select.
+#ifdef WB2_DIAG_WF_NOFMA   // timing diagnostic only: the field is loaded, not used
+        acc[1][e][0] += wfe;
+        return;
+#endif
         const bool inside = wfe > 0.0;
         const unsigned long long keep = inside ? ~0ull : 0x00000000ffffffffull;
         const double w2 = wr * wfe;
@@ -734,7 +738,11 @@ __global__ void __launch_bounds__(512)
           load_vec<T, VEC>(at(base[i] + (long long)(r + u) * p.n_col),
                            bt.v[u][i]);
         if constexpr (WF) {
+#ifdef WB2_DIAG_WF_SAMEROW   // timing diagnostic only: every row reads field row 0
+          load_wf<VEC, FT>(at_wf(wfp + (long long)(u) * p.n_col), bt.wf[u]);
+#else
           load_wf<VEC, FT>(at_wf(wfp + (long long)(r + u) * p.n_col), bt.wf[u]);
+#endif
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) bt.wf[u][e] = 1.0;
