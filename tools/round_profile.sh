@@ -45,6 +45,7 @@ if [ "$2" != quick ]; then
   timeout 300 python tools/pair_bench.py --reps 5 --json $OUT/${R}_pair_bench.jsonl > /dev/null 2>&1
   timeout 300 python tools/pair_bench.py --no-field --window 8 --chunks 2 --reps 5 --json $OUT/${R}_pair_bench.jsonl > /dev/null 2>&1
   timeout 300 python tools/host_fed_leg.py 2>/dev/null | tail -1 > $OUT/${R}_host_fed_leg.json
+  timeout 300 python tools/download_bench.py 2>/dev/null | tail -1 > $OUT/${R}_download.json
   for g in 240x121 64x32; do timeout 300 python tools/official_probabilistic.py --grid $g 2>/dev/null | tail -1; done > $OUT/${R}_official_probabilistic.json
   timeout 300 python tools/k3_grid.py --iters 200 2>/dev/null | tail -1 > $OUT/${R}_k3_grid.json
   timeout 300 python tools/map_accumulate_bench.py 2>/dev/null | tail -1 > $OUT/${R}_map_accumulate.json

@@ -1479,9 +1479,13 @@ def _verify_program(prog, forecast, truth_chunk, configs, skipna, sinks):
 
 
 # K1 chunking of evaluate_chunks (pinned: the result must not depend on how
-# many chunks share a launch); 32 rows is the measured optimum of launches of
-# 100+ slabs (profiles/r01_rows_per_chunk.md)
-EVALUATE_ROWS_PER_CHUNK = int(os.environ.get('WB2HIP_EVALUATE_ROWS', '32'))
+# many chunks share a launch).  32 rows is the measured optimum of launches of
+# ~200 slabs (profiles/r01_rows_per_chunk.md); the windows of the production
+# path launch 1 000+ slabs, where the per-workgroup prologue and fold weigh
+# more than the tail: 24 / 32 / 40 / 48 / 64 rows give 412 / 425 / 423 / 434 /
+# 434 G evals/s in the default window and 291 / 296 / 282 / 296 / 275 G chunk
+# by chunk (official chunks, one box, profiles/r06_round_log.md)
+EVALUATE_ROWS_PER_CHUNK = int(os.environ.get('WB2HIP_EVALUATE_ROWS', '48'))
 
 
 # evaluate_chunks(batch_chunks=None): chunks per window = what holds this many
