@@ -180,6 +180,9 @@ class _TableUploads(threading.local):
 
 _TABLES = _TableUploads()
 _TABLE_SLOT_BYTES = 1 << 18
+# A slot is reused when the copy out of it has run: with 8 slots the host was
+# held at 8 tables ahead of the device -- a window of the map suite uploads 20
+_TABLE_SLOTS = int(os.environ.get('WB2HIP_TABLE_SLOTS', 32))
 
 
 def upload_table(table: np.ndarray, device, cache: bool = True) -> torch.Tensor:
@@ -213,7 +216,7 @@ def upload_table(table: np.ndarray, device, cache: bool = True) -> torch.Tensor:
     if ring is None:
       ring = st.ring[str(device)] = [
           [torch.empty(_TABLE_SLOT_BYTES // 8, dtype=torch.int64).pin_memory()
-           for _ in range(8)], [None] * 8, 0]
+           for _ in range(_TABLE_SLOTS)], [None] * _TABLE_SLOTS, 0]
     slots, events, nxt = ring
     ring[2] = (nxt + 1) % len(slots)
     if events[nxt] is not None:
