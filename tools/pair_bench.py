@@ -56,7 +56,7 @@ def run(args):
     from tests import helpers
     regions = helpers.predefined_regions(oracle=False)
   pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON, regions, dev,
-                           rows_per_chunk=32)
+                           rows_per_chunk=int(os.environ.get("WB2HIP_EVALUATE_ROWS", 48)))
   n_outer, n_pair = 85 * args.window, 14 * args.window
   pools = []
   for c in range(args.chunks):
