@@ -236,3 +236,40 @@ def test_rows_too_narrow_have_no_pair_kernel(dev):
   x = torch.zeros((2, 5, 3), dtype=torch.float32, device=dev)
   with pytest.raises(_lib.Wb2HipError, match='no pair kernel'):
     step.run([x, x], [None, None])
+
+
+@pytest.mark.parametrize('with_field', [False, True])
+@pytest.mark.parametrize('mode_name', ['MODE_DET', 'MODE_DET_ACC'])
+def test_ring_form_of_the_per_variable_kernel_gives_the_same_bits(
+    dev, monkeypatch, with_field, mode_name):
+  """WB2HIP_K1_RING (an option, not the default -- measured in
+  profiles/r06_measured_not_kept.md): the rows of a chunk through a per-wave
+  LDS ring filled by LDS-DMA.  Same loads per lane, same arithmetic, same
+  order: the bits of the batch form, for every ring depth and workgroup width,
+  row counts below / at / above the depth, a ragged last column tile."""
+  import torch
+  from weatherbench2_amd import _lib, engine, plan as plan_lib
+  mode = getattr(_lib, mode_name)
+  nin = 3 if mode == _lib.MODE_DET_ACC else 2
+  for n_lat, n_lon, rows in ((721, 1440, 48), (37, 1000, 5), (9, 260, 2)):
+    lat = np.linspace(-90, 90, n_lat)
+    lon = np.linspace(0, 360, n_lon, endpoint=False)
+    pl = plan_lib.build_plan(lat, lon, plan_lib.LATLON,
+                             _regions(lat, lon, with_field), dev,
+                             rows_per_chunk=rows)
+    n_outer = 5
+    gen = torch.Generator(device=dev).manual_seed(11)
+    inputs = [torch.randn((n_outer, n_lat, n_lon), dtype=torch.float32,
+                          device=dev, generator=gen) for _ in range(nin)]
+    inputs[0][1, 3, 7] = float('nan')   # a NaN travels like in the batch form
+    monkeypatch.delenv('WB2HIP_K1_RING', raising=False)
+    monkeypatch.delenv('WB2HIP_K1_RING_WAVES', raising=False)
+    want, _ = engine.stream_reduce(pl, mode, inputs, [None] * nin, n_outer,
+                                   False)
+    want = want.clone()
+    for depth, waves in ((2, 0), (3, 0), (4, 0), (5, 0), (3, 1), (4, 3)):
+      monkeypatch.setenv('WB2HIP_K1_RING', str(depth))
+      monkeypatch.setenv('WB2HIP_K1_RING_WAVES', str(waves))
+      got, _ = engine.stream_reduce(pl, mode, inputs, [None] * nin, n_outer,
+                                    False)
+      assert _nan_equal(got, want), (n_lat, n_lon, depth, waves)
