@@ -32,7 +32,9 @@ def test_fft_core_host_emulation(tmp_path):
   out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
   lines = [l.split() for l in out.strip().splitlines()]
   sizes = {int(l[1]): float(l[3]) for l in lines if l[0] == 'N'}
-  assert set(sizes) == {64, 128, 240, 256, 360, 512, 720, 1024, 1440}
+  assert set(sizes) == {64, 128, 240, 256, 360, 512, 720, 1024, 1440, 96, 288,
+                        320, 384, 480, 640, 768, 1280, 1800, 2048, 2560, 2880,
+                        3600}
   # float32 transform: error relative to the row's total power
   assert max(sizes.values()) < 1e-6, sizes
   # the paired last pass (20 x 6 x 6: two butterflies and the recombination in

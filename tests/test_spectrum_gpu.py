@@ -214,7 +214,9 @@ def test_full_size_unit_parseval_and_determinism():
   assert np.max(np.abs(got - want)) / want.sum() < 2e-6
 
 
-@pytest.mark.parametrize('n_lon', [64, 128, 240, 256, 360, 512, 720, 1024, 1440])
+@pytest.mark.parametrize('n_lon', [64, 128, 240, 256, 360, 512, 720, 1024, 1440,
+                                   96, 288, 320, 384, 480, 640, 768, 1280, 1800,
+                                   2048, 2560, 2880, 3600])
 def test_fused_fft_matches_rocfft_path(n_lon):
   """The single-kernel LDS FFT and the rocFFT pipeline agree to fp32 noise."""
   import os

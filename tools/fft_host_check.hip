@@ -181,6 +181,9 @@ int main() {
   }
   WB2_CHECK(32) WB2_CHECK(64) WB2_CHECK(120) WB2_CHECK(128) WB2_CHECK(180)
   WB2_CHECK(256) WB2_CHECK(360) WB2_CHECK(512) WB2_CHECK(720)
+  WB2_CHECK(48) WB2_CHECK(144) WB2_CHECK(160) WB2_CHECK(192)
+  WB2_CHECK(240) WB2_CHECK(320) WB2_CHECK(384) WB2_CHECK(640)
+  WB2_CHECK(900) WB2_CHECK(1024) WB2_CHECK(1280) WB2_CHECK(1440) WB2_CHECK(1800)
   std::printf("worst %.3e\n", worst);
   return worst < 2e-6 ? 0 : 1;
 }

@@ -252,6 +252,8 @@ struct Composite {
   }
 };
 template <> struct Radix<6> : Composite<2, 3> {};
+template <> struct Radix<9> : Composite<3, 3> {};
+template <> struct Radix<15> : Composite<3, 5> {};
 template <> struct Radix<8> : Composite<2, 4> {};
 template <> struct Radix<10> : Composite<2, 5> {};
 template <> struct Radix<12> : Composite<4, 3> {};
@@ -286,6 +288,26 @@ WB2_FFT_PLAN(256, 4, 8, 8, 0, 0)
 WB2_FFT_PLAN(360, 6, 6, 10, 0, 0)
 WB2_FFT_PLAN(512, 8, 8, 8, 0, 0)
 WB2_FFT_PLAN(720, 12, 12, 5, 2, 12)
+// Grids beyond the WeatherBench 2 datasets' own (N = 64, 128, 240, 256, 360,
+// 512, 720, 1024, 1440 above): every other even row length whose half is a
+// multiple of 4 (the adjacent-bin epilogue) and a product of up to three
+// radices out of 2 ... 20, in common use -- 3.75, 1.25, 1.125, 0.9375, 0.75,
+// 0.5625, 0.46875, 0.28125, 0.2, 0.17578125, 0.140625, 0.125 and 0.1 degree
+// grids.  Unpadded slabs (not tuned); any other
+// length keeps the hipFFT path (spectrum.hip).
+WB2_FFT_PLAN(48, 6, 8, 1, 0, 0)        // N = 96
+WB2_FFT_PLAN(144, 12, 12, 1, 0, 0)     // 288
+WB2_FFT_PLAN(160, 10, 16, 1, 0, 0)     // 320
+WB2_FFT_PLAN(192, 12, 16, 1, 0, 0)     // 384
+WB2_FFT_PLAN(240, 12, 20, 1, 0, 0)     // 480
+WB2_FFT_PLAN(320, 16, 20, 1, 0, 0)     // 640
+WB2_FFT_PLAN(384, 6, 8, 8, 0, 0)       // 768
+WB2_FFT_PLAN(640, 8, 8, 10, 0, 0)      // 1280
+WB2_FFT_PLAN(900, 10, 10, 9, 0, 0)     // 1800
+WB2_FFT_PLAN(1024, 8, 8, 16, 0, 0)     // 2048
+WB2_FFT_PLAN(1280, 8, 10, 16, 0, 0)    // 2560
+WB2_FFT_PLAN(1440, 12, 12, 10, 0, 0)   // 2880
+WB2_FFT_PLAN(1800, 10, 12, 15, 0, 0)   // 3600
 #undef WB2_FFT_PLAN
 
 // ---- one Stockham pass of radix R; NS = product of the radices already done ---

@@ -658,8 +658,10 @@ int latseg_segments(long long n_field, int n_lat) {
 }  // namespace fused
 
 // Entry points used by spectrum.hip ------------------------------------------
-#define WB2_FUSED_SIZES(X) \
-  X(32) X(64) X(120) X(128) X(180) X(256) X(360) X(512) X(720)
+#define WB2_FUSED_SIZES(X)                                                    \
+  X(32) X(64) X(120) X(128) X(180) X(256) X(360) X(512) X(720) X(48)           \
+  X(144) X(160) X(192) X(240) X(320) X(384) X(640) X(900) X(1024)       \
+  X(1280) X(1440) X(1800)
 
 bool fused_spectrum_supported(int dtype, int n_lon) {
   if ((dtype != WB2_F32 && dtype != WB2_F64) || n_lon % 2) return false;
