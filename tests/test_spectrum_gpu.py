@@ -214,9 +214,32 @@ def test_full_size_unit_parseval_and_determinism():
   assert np.max(np.abs(got - want)) / want.sum() < 2e-6
 
 
-@pytest.mark.parametrize('n_lon', [64, 128, 240, 256, 360, 512, 720, 1024, 1440,
-                                   96, 288, 320, 384, 480, 640, 768, 1280, 1800,
+@pytest.mark.parametrize('dtype,tol', [(np.float32, 1e-6), (np.float64, 1e-13)])
+@pytest.mark.parametrize('n_lon', [96, 288, 320, 384, 480, 640, 768, 1280, 1800,
                                    2048, 2560, 2880, 3600])
+def test_row_lengths_beyond_the_datasets_grids(n_lon, dtype, tol):
+  """The plans added for other grids (fft_core.hpp): materialised, time-mean
+  and latitude-mean modes against the fp64 NumPy spectrum of the same rows."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda')
+  rs = np.random.RandomState(n_lon)
+  n_time, n_lat = 3, 7
+  x = rs.standard_normal((n_time, 2, n_lat, n_lon)).astype(dtype)
+  lat = np.linspace(-75, 75, n_lat)
+  circ_np = spectrum_np.circumference(lat)
+  circ = torch.as_tensor(circ_np).to(dev)
+  want = spectrum_np.simple_power(x.astype(np.float64)) * circ_np[None, None, :,
+                                                                 None]
+  xd = torch.as_tensor(x).to(dev)
+  got = engine.zonal_spectrum(xd, circ, n_lat).cpu().numpy()
+  assert _row_rel_err(got, want) < tol
+  mean = engine.zonal_spectrum(xd, circ, n_lat, n_time, False).cpu().numpy()
+  assert _row_rel_err(mean, want.mean(0)) < tol
+
+
+@pytest.mark.parametrize('n_lon', [64, 128, 240, 256, 360, 512, 720, 1024, 1440,
+                                   96, 1800, 3600])
 def test_fused_fft_matches_rocfft_path(n_lon):
   """The single-kernel LDS FFT and the rocFFT pipeline agree to fp32 noise."""
   import os
