@@ -236,6 +236,15 @@ def test_row_lengths_beyond_the_datasets_grids(n_lon, dtype, tol):
   assert _row_rel_err(got, want) < tol
   mean = engine.zonal_spectrum(xd, circ, n_lat, n_time, False).cpu().numpy()
   assert _row_rel_err(mean, want.mean(0)) < tol
+  # the latitude mean fused into the kernel (configs[3]'s mode) == the
+  # materialised spectrum reduced afterwards
+  w = torch.as_tensor(np.cos(np.deg2rad(lat))).to(dev)
+  fields = xd.reshape(-1, n_lat, n_lon)
+  lat_mean = engine.zonal_spectrum_lat_mean(fields, circ, w, n_lat)
+  two_pass = (engine.zonal_spectrum(fields, circ, n_lat) *
+              w[None, :, None]).sum(1) / w.sum()
+  torch.testing.assert_close(lat_mean, two_pass, rtol=1e-12,
+                             atol=1e-12 * float(two_pass.abs().max()))
 
 
 @pytest.mark.parametrize('n_lon', [64, 128, 240, 256, 360, 512, 720, 1024, 1440,

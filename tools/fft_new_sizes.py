@@ -26,7 +26,7 @@ for n_lon in %r:
   del x, y
 print(json.dumps(out))
 '''
-sizes = [96, 288, 320, 384, 480, 640, 768, 1280, 1800, 2048, 2560, 2880, 3600, 1440]
+sizes = [int(a) for a in sys.argv[1:]] or [96, 288, 320, 384, 480, 640, 768, 1280, 1800, 2048, 2560, 2880, 3600, 1440]
 res = {}
 for backend in ('fused', 'rocfft'):
   env = dict(os.environ)
