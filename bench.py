@@ -1388,14 +1388,14 @@ def land_sea_mask(rs, lat, lon):
       np.float32)
 
 
-def official_regions():
+def official_regions(n_lat: int = 0, n_lon: int = 0):
   """The 16 regions of the reference's `deterministic` config with a land-sea
   mask present (scripts/evaluate.py:345-395): the 13 slice regions +
   global_land, extra-tropics_land, tropics_land."""
   from weatherbench2_amd import regions as R
   from weatherbench2_amd import xarray_lite as xl
-  lat = np.linspace(-90, 90, N_LAT)
-  lon = np.linspace(0, 360, N_LON, endpoint=False)
+  lat = np.linspace(-90, 90, n_lat or N_LAT)
+  lon = np.linspace(0, 360, n_lon or N_LON, endpoint=False)
   lsm = xl.DataArray(land_sea_mask(np.random.RandomState(7), lat, lon),
                      ('latitude', 'longitude'),
                      {'latitude': lat, 'longitude': lon})

@@ -34,6 +34,10 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 N_LEV, N_LAT, N_LON = 13, 721, 1440
+# WB2HIP_OFFICIAL_GRID=240x121: the same legs on the 1.5-degree grid (what most
+# WeatherBench 2 scorecards are computed on)
+if os.environ.get('WB2HIP_OFFICIAL_GRID'):
+  N_LON, N_LAT = (int(v) for v in os.environ['WB2HIP_OFFICIAL_GRID'].split('x'))
 VARS_3D = ('geopotential', 'temperature', 'u_component_of_wind',
            'v_component_of_wind', 'specific_humidity', 'wind_speed')
 VARS_2D = ('2m_temperature', '10m_u_component_of_wind',
@@ -173,7 +177,7 @@ def build(dev, n_chunks: int, pool: int, n_lead: int = 4, seeps: bool = True):
     for key, precip, dry in SEEPS:
       metrics[key] = gm.SEEPS(climatology=clim, precip_name=precip,
                               dry_threshold_mm=dry)
-  cfg = config.Eval(metrics=metrics, regions=bench.official_regions())
+  cfg = config.Eval(metrics=metrics, regions=bench.official_regions(N_LAT, N_LON))
   return chunks, cfg
 
 
