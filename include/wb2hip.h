@@ -787,8 +787,13 @@ int wb2_spatial_accumulate(int dtype, int skipna, const void* forecast,
  *   S[row, k] = |F[k] / n_lon|^2 * (k == 0 ? 1 : 2) * circumference[row % n_lat]
  * in fp64 (numpy widens float32 power * int64 to float64 at the same point).
  *
- *  plan        host handle for (dtype, n_lon, n_rows); creation may take seconds
- *              (rocFFT compiles its kernels at run time) -- create once, reuse.
+ *  plan        host handle for (dtype, n_lon, n_rows) -- create once, reuse.
+ *              For the 22 row lengths with a one-kernel LDS transform
+ *              (spectrum_fused.hip) creation makes twiddle tables only; the
+ *              hipFFT plan behind the other lengths takes seconds (rocFFT
+ *              compiles its kernels at run time) and is made at creation --
+ *              or, for a one-kernel length, by the first call that cannot take
+ *              that kernel (x not 16-byte aligned, n_time >= 65536).
  *  x           DEV [n_rows][n_lon], longitude contiguous; rows ordered
  *              (time, ..., latitude) with latitude the fastest row index
  *  circumference DEV double[n_lat] = cos(lat * pi / 180) * 2 pi R   (:578-581)

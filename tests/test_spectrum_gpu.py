@@ -639,3 +639,30 @@ def test_paired_last_pass_variant_against_the_oracle(tmp_path):
   ok = ~np.isnan(want_lat).any(axis=-1)
   assert ok.sum() >= 1
   assert _row_rel_err(got['lat'][ok], want_lat[ok]) < 2e-6
+
+
+def test_unaligned_rows_take_the_late_hipfft_plan():
+  """A plan of a length the one-kernel transform handles creates no hipFFT plan
+  (rocFFT compiles kernels at plan creation: seconds); a call whose rows do not
+  start on a 16-byte boundary cannot take that kernel and makes the hipFFT plan
+  then -- with buffers of its own, not the caller's workspace."""
+  import torch
+  from weatherbench2_amd import engine
+  dev = torch.device('cuda')
+  n_lat, n_lon = 5, 240
+  gen = torch.Generator(device=dev).manual_seed(77)
+  flat = torch.randn(3 * n_lat * n_lon + 1, generator=gen, device=dev)
+  x = flat[1:].view(3, n_lat, n_lon)
+  assert x.data_ptr() % 16 != 0 and x.is_contiguous()
+  lat = np.linspace(-60, 60, n_lat)
+  circ = torch.as_tensor(spectrum_np.circumference(lat)).to(dev)
+  want = spectrum_np.simple_power(x.cpu().numpy().astype(np.float64)) * (
+      spectrum_np.circumference(lat)[None, :, None])
+  for _ in range(2):   # the second call finds the late plan
+    got = engine.zonal_spectrum(x, circ, n_lat).cpu().numpy()
+    assert _row_rel_err(got, want) < 2e-6
+  mean = engine.zonal_spectrum(x, circ, n_lat, 3, True).cpu().numpy()
+  assert _row_rel_err(mean, want.mean(0)) < 2e-6
+  # the aligned copy of the same rows goes through the one kernel, same plan
+  fused = engine.zonal_spectrum(x.clone(), circ, n_lat).cpu().numpy()
+  assert _row_rel_err(fused, got) < 2e-6

@@ -26,6 +26,8 @@
 
 #include <hipfft/hipfft.h>
 
+#include <mutex>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -57,6 +59,14 @@ struct SpectrumPlan {
   bool packed = false;       // even n_lon: C2C on n_lon/2 points + own recombination
   bool fused = false;        // spectrum_fused.hip handles (dtype, n_lon)
   void* tables = nullptr;    // fused path: twiddle tables, owned by the plan
+  // A plan of a length the one-kernel transform handles makes its hipFFT plan
+  // only when a call cannot take that kernel (x not 16-byte aligned, n_time >=
+  // 65536): rocFFT compiles its kernels at plan creation -- seconds per (length,
+  // batch) that almost no call needs.  Such a late plan owns its buffers
+  // (`late_spec`, hipFFT's own work area) instead of using the caller's workspace.
+  bool late = false;
+  void* late_spec = nullptr;
+  std::mutex mu;
 };
 
 // native 2-vectors (re, im): accepted by the nontemporal builtins
@@ -179,6 +189,37 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The hipFFT plan of `p` (batched 1-D transform of its rows).  own_work_area:
+// hipFFT allocates its work area itself (late plans); otherwise it is part of
+// the caller's workspace and its size goes to p->fft_work_bytes.
+int make_fft_plan(SpectrumPlan* p, bool own_work_area) {
+  const int n_bins = p->n_lon / 2 + 1;
+  int n[1] = {p->packed ? p->n_lon / 2 : p->n_lon};
+  hipfftResult rc = hipfftCreate(&p->fft);
+  if (rc == HIPFFT_SUCCESS)
+    rc = hipfftSetAutoAllocation(p->fft, own_work_area ? 1 : 0);
+  size_t work = 0;
+  if (rc == HIPFFT_SUCCESS) {
+    if (p->packed) {
+      rc = hipfftMakePlanMany(p->fft, 1, n, nullptr, 1, n[0], nullptr, 1, n[0],
+                              p->dtype == WB2_F32 ? HIPFFT_C2C : HIPFFT_Z2Z,
+                              (int)p->n_rows, &work);
+    } else {
+      rc = hipfftMakePlanMany(p->fft, 1, n, nullptr, 1, p->n_lon, nullptr, 1,
+                              n_bins,
+                              p->dtype == WB2_F32 ? HIPFFT_R2C : HIPFFT_D2Z,
+                              (int)p->n_rows, &work);
+    }
+  }
+  if (rc != HIPFFT_SUCCESS) {
+    if (p->fft) hipfftDestroy(p->fft);
+    p->fft = 0;
+    return fail("hipFFT plan creation failed (hipfftResult %d)", (int)rc);
+  }
+  p->fft_work_bytes = own_work_area ? 0 : work;
+  return 0;
+}
+
 }  // namespace
 }  // namespace wb2
 
@@ -200,32 +241,18 @@ int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
   const int row_len = p->packed ? n_lon / 2 : n_bins;
   p->complex_bytes =
       (size_t)n_rows * row_len * (dtype == WB2_F32 ? 8 : 16);
-  int n[1] = {p->packed ? n_lon / 2 : n_lon};
-  hipfftResult rc = hipfftCreate(&p->fft);
-  if (rc == HIPFFT_SUCCESS) rc = hipfftSetAutoAllocation(p->fft, 0);
-  size_t work = 0;
-  if (rc == HIPFFT_SUCCESS) {
-    if (p->packed) {
-      rc = hipfftMakePlanMany(p->fft, 1, n, nullptr, 1, n[0], nullptr, 1, n[0],
-                              dtype == WB2_F32 ? HIPFFT_C2C : HIPFFT_Z2Z,
-                              (int)n_rows, &work);
-    } else {
-      rc = hipfftMakePlanMany(p->fft, 1, n, nullptr, 1, n_lon, nullptr, 1,
-                              n_bins,
-                              dtype == WB2_F32 ? HIPFFT_R2C : HIPFFT_D2Z,
-                              (int)n_rows, &work);
-    }
-  }
-  if (rc != HIPFFT_SUCCESS) {
-    if (p->fft) hipfftDestroy(p->fft);
-    delete p;
-    return fail("hipFFT plan creation failed (hipfftResult %d)", (int)rc);
-  }
-  p->fft_work_bytes = work;
   // WB2HIP_SPECTRUM_BACKEND=rocfft forces the two-kernel path (tests, A/B runs)
   const char* backend = std::getenv("WB2HIP_SPECTRUM_BACKEND");
   p->fused = fused_spectrum_supported(dtype, n_lon) &&
              !(backend && std::strcmp(backend, "rocfft") == 0);
+  p->late = p->fused;
+  if (!p->late) {
+    const int rc = make_fft_plan(p, /*own_work_area=*/false);
+    if (rc != 0) {
+      delete p;
+      return rc;
+    }
+  }
   if (p->fused) {
     // the twiddle tables are generated once, here (device of the calling
     // thread), instead of by an extra kernel in front of every transform
@@ -237,7 +264,7 @@ int wb2_spectrum_plan_create(int dtype, int32_t n_lon, int64_t n_rows,
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       if (p->tables) (void)hipFree(p->tables);
-      hipfftDestroy(p->fft);
+      if (p->fft) hipfftDestroy(p->fft);
       delete p;
       return fail("twiddle table setup failed: %s", hipGetErrorString(e));
     }
@@ -250,8 +277,9 @@ int wb2_spectrum_plan_destroy(void* plan) {
   WB2_TRACE();
   auto* p = static_cast<wb2::SpectrumPlan*>(plan);
   if (!p) return 0;
-  hipfftDestroy(p->fft);
+  if (p->fft) hipfftDestroy(p->fft);
   if (p->tables) (void)hipFree(p->tables);
+  if (p->late_spec) (void)hipFree(p->late_spec);
   delete p;
   return 0;
 }
@@ -262,8 +290,10 @@ int64_t wb2_spectrum_plan_workspace(void* plan) {
   size_t tw = (size_t)(p->n_lon / 2 + 1) * (p->dtype == WB2_F32 ? 8 : 16);
   if (p->fused && wb2::fused_spectrum_table_bytes(p->dtype, p->n_lon) > tw)
     tw = wb2::fused_spectrum_table_bytes(p->dtype, p->n_lon);
-  return (int64_t)(wb2::align_up(p->complex_bytes) +
-                   wb2::align_up(p->fft_work_bytes) + wb2::align_up(tw));
+  // (a late hipFFT plan brings its own transform buffer and work area)
+  const size_t spec = p->late ? 0 : p->complex_bytes;
+  return (int64_t)(wb2::align_up(spec) + wb2::align_up(p->fft_work_bytes) +
+                   wb2::align_up(tw));
 }
 
 int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
@@ -283,15 +313,26 @@ int wb2_zonal_spectrum(void* plan, const void* x, const double* circumference,
   WB2_REQUIRE(rows_out % n_lat == 0, "rows per time step not a multiple of n_lat");
   hipStream_t s = static_cast<hipStream_t>(stream);
   char* ws = static_cast<char*>(workspace);
-  void* spec = ws;
-  void* fft_work = ws + align_up(p->complex_bytes);
-  void* tw = ws + align_up(p->complex_bytes) + align_up(p->fft_work_bytes);
   // (the fused time mean keeps its per-bin sample counts in 16 bits)
   if (p->fused && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_time < 65536)
     return fused_spectrum_run(x, p->dtype, p->n_rows, p->n_lon, circumference,
                               n_lat, n_time, skipna, out, p->tables, s);
+  void* spec = ws;
+  if (p->late) {   // the first call that needs hipFFT after all makes its plan
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (!p->fft) {
+      const int made = make_fft_plan(p, /*own_work_area=*/true);
+      if (made != 0) return made;
+    }
+    if (!p->late_spec)
+      WB2_HIP_OK(hipMalloc(&p->late_spec, p->complex_bytes));
+    spec = p->late_spec;
+  }
+  const size_t spec_in_ws = p->late ? 0 : p->complex_bytes;
+  void* fft_work = ws + align_up(spec_in_ws);
+  void* tw = ws + align_up(spec_in_ws) + align_up(p->fft_work_bytes);
   hipfftResult rc = hipfftSetStream(p->fft, s);
-  if (rc == HIPFFT_SUCCESS && p->fft_work_bytes)
+  if (rc == HIPFFT_SUCCESS && p->fft_work_bytes && !p->late)
     rc = hipfftSetWorkArea(p->fft, fft_work);
   if (rc == HIPFFT_SUCCESS) {
     if (p->packed) {
