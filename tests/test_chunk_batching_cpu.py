@@ -257,3 +257,31 @@ def test_concat_chunks_remembered_layout_gives_the_same_concatenation(order):
   bad[3].data_vars[name] = xl.DataArray(wide[..., ::2], da.dims,
                                         bad[3].coords, name)
   assert evaluation.concat_chunks(bad, 'init_time', 'lead_time') is None
+  # ... nor with another dtype, another shape, other dims or a variable missing
+  # in one chunk (every refusal of the remembered layout's whole-list checks)
+  def replaced(make):
+    out = list(chunks)
+    ref = out[5][name]
+    out[5] = xl.Dataset(dict(out[5].data_vars), out[5].coords)
+    new = make(ref)
+    if new is None:
+      del out[5].data_vars[name]
+    else:
+      out[5].data_vars[name] = new
+    return out
+  as_array = lambda da: np.asarray(da.values)
+  assert evaluation.concat_chunks(chunks, 'init_time', 'lead_time') is not None
+  for make in (
+      lambda da: xl.DataArray(as_array(da).astype(np.float16)
+                              if isinstance(da.data, np.ndarray) else
+                              da.data.to(torch.float16), da.dims,
+                              chunks[5].coords, name),
+      lambda da: xl.DataArray(da.data[..., :-1].copy()
+                              if isinstance(da.data, np.ndarray) else
+                              da.data[..., :-1].contiguous(), da.dims,
+                              chunks[5].coords, name),
+      lambda da: xl.DataArray(da.data, da.dims[:-2] + da.dims[:-3:-1],
+                              chunks[5].coords, name),
+      lambda da: None):
+    assert evaluation.concat_chunks(replaced(make), 'init_time',
+                                    'lead_time') is None
